@@ -1,0 +1,38 @@
+# Builds the product library (HIP, gfx950 only) and the CPU oracle (test infra).
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
+SRC := beamform_amd/csrc
+OBJ := build/obj
+LIB := beamform_amd/lib/libbfcore.so
+
+HIP_SRCS := $(SRC)/das_fused.hip $(SRC)/pipeline.hip
+CPP_SRCS := $(SRC)/capi.cpp $(SRC)/config.cpp
+OBJS := $(patsubst $(SRC)/%.hip,$(OBJ)/%.o,$(HIP_SRCS)) $(patsubst $(SRC)/%.cpp,$(OBJ)/%.o,$(CPP_SRCS))
+HDRS := $(wildcard $(SRC)/*.hpp) include/bfcore.h
+
+all: $(LIB) oracle
+
+$(OBJ)/%.o: $(SRC)/%.hip $(HDRS)
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OBJ)/%.o: $(SRC)/%.cpp $(HDRS)
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p beamform_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle -s
+
+emul:
+	g++ -O2 -std=c++17 -fPIC -shared -o tests/host_emul/libemul.so tests/host_emul/emul.cpp
+
+clean:
+	rm -rf build $(LIB) tests/host_emul/libemul.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle emul clean

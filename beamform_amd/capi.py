@@ -1,0 +1,199 @@
+"""ctypes binding of libbfcore.so (include/bfcore.h).
+
+Thin plumbing only: device memory comes from the caller (torch tensors / raw
+pointers); all compute happens in the HIP kernels behind the C ABI.  Loading
+fails loudly when the library is missing -- there is no Python or CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .params import ALGO_ID
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbfcore.so")
+
+BF_MAX_MICS = 32
+BF_MAX_INTERF = 15
+BF_PLANAR, BF_INTERLEAVED = 0, 1
+BF_DAS_FUSED_F32, BF_DAS_BINS_F64 = 0, 1
+
+#: every symbol include/bfcore.h declares
+EXPORTS = (
+    "bf_version", "bf_strerror", "bf_last_error", "bf_device_count", "bf_config_init", "bf_config_load_yaml",
+    "bf_config_parse_yaml", "bf_create", "bf_destroy", "bf_set_theta", "bf_set_interference", "bf_process_hop",
+    "bf_process_batch", "bf_process_batch_device", "bf_get_weights", "bf_state_size", "bf_get_state", "bf_set_state",
+    "bf_reset", "bf_time_batch_device",
+)
+
+
+class BfConfig(C.Structure):
+    _fields_ = [
+        ("algo", C.c_int), ("n_mics", C.c_int), ("hop", C.c_int), ("sample_rate", C.c_double),
+        ("mic_x", C.c_double * BF_MAX_MICS), ("mic_y", C.c_double * BF_MAX_MICS), ("theta", C.c_double),
+        ("n_interf", C.c_int), ("interf_angle", C.c_double * BF_MAX_INTERF), ("verbose", C.c_int),
+        ("past_windows", C.c_int), ("freq_mag_threshold", C.c_double), ("freq_max", C.c_double),
+        ("freq_min", C.c_double), ("out_amp", C.c_double), ("interf_angle_threshold", C.c_double),
+        ("mu", C.c_double), ("lambda_", C.c_double),
+        ("min_phase", C.c_double), ("mag_mult", C.c_double), ("mag_threshold", C.c_double),
+        ("min_mag", C.c_double), ("smooth_size", C.c_int),
+        ("mcra_alphaS", C.c_double), ("mcra_alphaD", C.c_double), ("mcra_alphaD2", C.c_double),
+        ("mcra_delta", C.c_double), ("mcra_L", C.c_int),
+        ("mpf_alphaS", C.c_double), ("mpf_eta", C.c_double), ("mpf_rev_gamma", C.c_double),
+        ("mpf_rev_delta", C.c_double), ("noise_floor", C.c_double),
+        ("out_only_noise", C.c_int), ("out_only_mcra", C.c_int),
+        ("device", C.c_int), ("n_streams", C.c_int), ("layout", C.c_int), ("das_impl", C.c_int),
+    ]
+
+
+class BfError(RuntimeError):
+    def __init__(self, code, what, detail=""):
+        super().__init__(f"{what}: [{code}] {detail}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """dlopen libbfcore.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `make` (or __graft_entry__.build()); "
+                          "beamform_amd has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    L.bf_version.restype = C.c_char_p
+    L.bf_strerror.restype = C.c_char_p
+    L.bf_strerror.argtypes = [C.c_int]
+    L.bf_last_error.restype = C.c_char_p
+    L.bf_last_error.argtypes = [C.c_void_p]
+    L.bf_config_init.argtypes = [C.POINTER(BfConfig), C.c_int]
+    L.bf_config_load_yaml.argtypes = [C.POINTER(BfConfig), C.c_char_p]
+    L.bf_config_parse_yaml.argtypes = [C.POINTER(BfConfig), C.c_char_p]
+    L.bf_create.argtypes = [C.POINTER(BfConfig), C.POINTER(C.c_void_p)]
+    L.bf_destroy.argtypes = [C.c_void_p]
+    L.bf_destroy.restype = None
+    L.bf_set_theta.argtypes = [C.c_void_p, C.c_double]
+    L.bf_set_interference.argtypes = [C.c_void_p, C.c_uint, C.c_double]
+    L.bf_process_hop.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32]
+    L.bf_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.bf_process_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bf_get_weights.argtypes = [C.c_void_p, C.c_void_p]
+    L.bf_state_size.restype = C.c_size_t
+    L.bf_state_size.argtypes = [C.c_void_p]
+    L.bf_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.bf_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.bf_reset.argtypes = [C.c_void_p]
+    L.bf_time_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.POINTER(C.c_float)]
+    _lib = L
+    return L
+
+
+def config_from_params(p: dict, device: int = 0, n_streams: int = 1, layout: int = BF_PLANAR,
+                       das_impl: int = BF_DAS_FUSED_F32) -> BfConfig:
+    """bf_config from a beamform_amd.params dict (launch defaults first, then overrides)."""
+    L = load()
+    c = BfConfig()
+    rc = L.bf_config_init(C.byref(c), ALGO_ID[p["algo"]])
+    if rc:
+        raise BfError(rc, "bf_config_init", L.bf_strerror(rc).decode())
+    c.n_mics = p["n_mics"]
+    c.hop = p["hop"]
+    c.sample_rate = p["sample_rate"]
+    for i, (x, y) in enumerate(p["mics"]):
+        c.mic_x[i], c.mic_y[i] = x, y
+    c.theta = p["theta"]
+    c.n_interf = len(p["interf"])
+    for i, a in enumerate(p["interf"]):
+        c.interf_angle[i] = a
+    for k in ("past_windows", "freq_mag_threshold", "freq_max", "freq_min", "out_amp", "mu", "lambda_", "min_phase",
+              "mag_mult", "mag_threshold", "min_mag", "smooth_size", "mcra_alphaS", "mcra_alphaD", "mcra_alphaD2",
+              "mcra_delta", "mcra_L", "mpf_alphaS", "mpf_eta", "mpf_rev_gamma", "mpf_rev_delta", "noise_floor",
+              "out_only_noise", "out_only_mcra"):
+        setattr(c, k, p[k])
+    c.device, c.n_streams, c.layout, c.das_impl = device, n_streams, layout, das_impl
+    return c
+
+
+class Beamformer:
+    """One beamformer node behind the C ABI (das|mvdr|lcmv|gss|phase|phasempf)."""
+
+    def __init__(self, params: dict, device: int = 0, n_streams: int = 1, layout: int = BF_PLANAR,
+                 das_impl: int = BF_DAS_FUSED_F32):
+        self._L = load()
+        self.cfg = config_from_params(params, device, n_streams, layout, das_impl)
+        self.M, self.H, self.N = params["n_mics"], params["hop"], 2 * params["hop"]
+        self.S = len(params["interf"]) + 1 if params["algo"] in ("lcmv", "gss") else 1
+        self.n_streams = n_streams
+        self._h = C.c_void_p()
+        rc = self._L.bf_create(C.byref(self.cfg), C.byref(self._h))
+        if rc:
+            raise BfError(rc, "bf_create", self._L.bf_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.bf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc, what):
+        if rc:
+            raise BfError(rc, what, (self._L.bf_last_error(self._h) or b"").decode() or self._L.bf_strerror(rc).decode())
+
+    def set_theta(self, deg: float):
+        self._chk(self._L.bf_set_theta(self._h, float(deg)), "bf_set_theta")
+
+    def set_interference(self, idx: int, deg: float):
+        self._chk(self._L.bf_set_interference(self._h, int(idx), float(deg)), "bf_set_interference")
+
+    def reset(self):
+        self._chk(self._L.bf_reset(self._h), "bf_reset")
+
+    def weights(self) -> np.ndarray:
+        w = np.empty((self.N, self.M, self.S), np.complex128)
+        self._chk(self._L.bf_get_weights(self._h, w.ctypes.data), "bf_get_weights")
+        return w
+
+    def process_hop(self, x: np.ndarray) -> np.ndarray:
+        """x [M, H] float32 (host) -> [H] float32: one jack_callback."""
+        x = np.ascontiguousarray(x, np.float32)
+        assert x.shape == (self.M, self.H)
+        ptrs = (C.c_void_p * self.M)(*[x[m].ctypes.data for m in range(self.M)])
+        out = np.empty(self.H, np.float32)
+        self._chk(self._L.bf_process_hop(self._h, ptrs, out.ctypes.data, self.H), "bf_process_hop")
+        return out
+
+    def process(self, x: np.ndarray) -> np.ndarray:
+        """Host batch. planar: x [S, M, F*H] (or [M, F*H] when S == 1); interleaved: [S, F*H, M]."""
+        x = np.ascontiguousarray(x, np.float32)
+        n = x.size // (self.n_streams * self.M * self.H)
+        y = np.empty((self.n_streams, n * self.H), np.float32)
+        self._chk(self._L.bf_process_batch(self._h, x.ctypes.data, n, y.ctypes.data), "bf_process_batch")
+        return y[0] if self.n_streams == 1 else y
+
+    def process_device(self, x_ptr: int, n_frames: int, y_ptr: int, spectrum_ptr: int = 0, stream: int = 0):
+        self._chk(self._L.bf_process_batch_device(self._h, x_ptr, n_frames, y_ptr, spectrum_ptr or None, stream or None),
+                  "bf_process_batch_device")
+
+    def time_device(self, x_ptr: int, n_frames: int, y_ptr: int, iters: int, stream: int = 0) -> float:
+        ms = C.c_float()
+        self._chk(self._L.bf_time_batch_device(self._h, x_ptr, n_frames, y_ptr, stream or None, iters, C.byref(ms)),
+                  "bf_time_batch_device")
+        return float(ms.value)
+
+    def get_state(self) -> bytes:
+        n = self._L.bf_state_size(self._h)
+        buf = C.create_string_buffer(n)
+        self._chk(self._L.bf_get_state(self._h, buf, n), "bf_get_state")
+        return buf.raw
+
+    def set_state(self, blob: bytes):
+        self._chk(self._L.bf_set_state(self._h, blob, len(blob)), "bf_set_state")

@@ -1,0 +1,500 @@
+// capi.cpp -- the C ABI of libbfcore.so (include/bfcore.h) and the host-side
+// state a reference node keeps in file-scope globals (util.h:24-50, das.cpp:15-25).
+//
+// Host work done here is start-up / control-plane only (geometry, steering
+// weights in double precision, table upload, launch sizing); every per-frame
+// operation runs in the gfx950 kernels.  There is no CPU compute fallback.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/bfcore.h"
+#include "geometry.hpp"
+#include "kernels.hpp"
+#include "pipeline.hpp"
+
+using namespace bf;
+
+static thread_local std::string g_last_error;
+
+struct bf_handle {
+    bf_config cfg;
+    int M = 0, H = 0, N = 0, S = 1, n_streams = 1;
+    int device = 0, n_cus = 256;
+    std::string err;
+
+    // control plane (guarded by mu): what update_weights() owns in the reference
+    std::mutex mu;
+    ArrayGeometry geo;
+    std::vector<double> freqs;
+    SteeringSet steer;
+    double angle = 0.0;
+    std::vector<double> interf;
+    bool tables_dirty = true;
+
+    // fused-DAS device state
+    f32x2 *d_gains[2] = {nullptr, nullptr};
+    int gains_cur = 0;
+    f32x2 *d_twiddle = nullptr;
+    float *d_window = nullptr;
+    float *d_hist = nullptr;  // the hop before the next frame (the reference's ring buffer content)
+    float *d_tail[2] = {nullptr, nullptr};
+    int tail_cur = 0;
+    f32x2 *d_sdump = nullptr;
+    size_t sdump_cap = 0;
+
+    // bin pipeline (mvdr/lcmv/gss/phase/phasempf and DAS_BINS_F64)
+    BinPipeline *pipe = nullptr;
+
+    // staging for the host-buffer entry points
+    float *d_x = nullptr, *d_y = nullptr;
+    size_t d_x_cap = 0, d_y_cap = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int fail(bf_handle *h, int code, const char *what, hipError_t e = hipSuccess) {
+    std::string msg = what ? what : "";
+    if (e != hipSuccess) {
+        msg += ": ";
+        msg += hipGetErrorString(e);
+    }
+    if (h) h->err = msg;
+    g_last_error = msg;
+    return code;
+}
+
+#define BF_HIP(h, call)                                                  \
+    do {                                                                 \
+        hipError_t e_ = (call);                                          \
+        if (e_ != hipSuccess) return fail((h), BF_EIO, #call, e_);       \
+    } while (0)
+
+bool uses_fused_das(const bf_handle *h) { return h->cfg.algo == BF_DAS && h->cfg.das_impl == BF_DAS_FUSED_F32; }
+
+// update_weights(): recompute every steering column from the current angles.
+void rebuild_steering(bf_handle *h, bool first) {
+    h->steer.update_column(h->geo, h->freqs, 0, h->angle, first);
+    for (int k = 0; k < h->S - 1; ++k) h->steer.update_column(h->geo, h->freqs, k + 1, h->interf[k], first);
+    h->tables_dirty = true;
+}
+
+// Upload whatever set_theta changed; stream-ordered, double-buffered so a batch
+// already in flight keeps reading the table it was launched with.
+int sync_tables(bf_handle *h, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->tables_dirty) return BF_OK;
+    if (uses_fused_das(h)) {
+        std::vector<f32x2> g = das_pair_gains(h->steer, (h->M + 1) / 2);
+        const int nxt = h->gains_cur ^ 1;
+        BF_HIP(h, hipMemcpyAsync(h->d_gains[nxt], g.data(), g.size() * sizeof(f32x2), hipMemcpyHostToDevice, s));
+        h->gains_cur = nxt;
+    }
+    if (h->pipe) {
+        int rc = h->pipe->upload_steering(h->steer, s);
+        if (rc != BF_OK) return fail(h, rc, h->pipe->error().c_str());
+    }
+    h->tables_dirty = false;
+    return BF_OK;
+}
+
+int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_dev, void *spectrum_dev, hipStream_t s,
+                  int layout, long mic_stride) {
+    const long F = (long)n_frames;
+    const int S = h->n_streams;
+    const long slots = (long)h->n_cus * 16;  // half-wavefronts resident at one 512-thread block per CU
+    long cps = slots / S;
+    if (cps < 1) cps = 1;
+    if (cps > F) cps = F;
+    const long fpc = (F + cps - 1) / cps;
+    cps = (F + fpc - 1) / fpc;
+
+    if (spectrum_dev) {
+        const size_t need = (size_t)S * F * 1024;
+        if (need > h->sdump_cap) {
+            if (h->d_sdump) hipFree(h->d_sdump);
+            h->d_sdump = nullptr;
+            h->sdump_cap = 0;
+            BF_HIP(h, hipMalloc((void **)&h->d_sdump, need * sizeof(f32x2)));
+            h->sdump_cap = need;
+        }
+    }
+
+    DasFusedArgs a;
+    a.x = x_dev;
+    a.hist = h->d_hist;
+    a.y = y_dev;
+    a.tail_in = h->d_tail[h->tail_cur];
+    a.tail_out = h->d_tail[h->tail_cur ^ 1];
+    a.gains = h->d_gains[h->gains_cur];
+    a.twiddle = h->d_twiddle;
+    a.window = h->d_window;
+    a.sdump = spectrum_dev ? h->d_sdump : nullptr;
+    a.n_frames = F;
+    a.mic_stride = mic_stride;
+    a.stream_stride_x = (long)h->M * F * h->H;
+    a.n_streams = S;
+    a.n_mics = h->M;
+    a.frames_per_chunk = (int)fpc;
+    a.chunks_per_stream = (int)cps;
+    a.layout = layout;
+    BF_HIP(h, launch_das_fused(a, s));
+    h->tail_cur ^= 1;
+
+    // ring-buffer carry: keep the last hop of every mic for the next call (util.h:305-308)
+    if (layout == BF_PLANAR) {
+        BF_HIP(h, hipMemcpy2DAsync(h->d_hist, (size_t)h->H * sizeof(float), x_dev + (F - 1) * h->H,
+                                   (size_t)mic_stride * sizeof(float), (size_t)h->H * sizeof(float), (size_t)S * h->M,
+                                   hipMemcpyDeviceToDevice, s));
+    } else {
+        BF_HIP(h, hipMemcpy2DAsync(h->d_hist, (size_t)h->H * h->M * sizeof(float), x_dev + (F - 1) * (long)h->H * h->M,
+                                   (size_t)F * h->H * h->M * sizeof(float), (size_t)h->H * h->M * sizeof(float), (size_t)S,
+                                   hipMemcpyDeviceToDevice, s));
+    }
+    if (spectrum_dev) BF_HIP(h, launch_das_hermitian_dump(h->d_sdump, (f64x2 *)spectrum_dev, (long)S * F, s));
+    return BF_OK;
+}
+
+int run_batch_device(bf_handle *h, const float *x_dev, size_t n_frames, float *y_dev, void *spectrum_dev, hipStream_t s,
+                     int layout, long mic_stride) {
+    if (n_frames == 0) return BF_OK;
+    int rc = sync_tables(h, s);
+    if (rc != BF_OK) return rc;
+    if (uses_fused_das(h)) return run_das_fused(h, x_dev, n_frames, y_dev, spectrum_dev, s, layout, mic_stride);
+    rc = h->pipe->run(x_dev, (long)n_frames, y_dev, (f64x2 *)spectrum_dev, s, layout, mic_stride);
+    if (rc != BF_OK) return fail(h, rc, h->pipe->error().c_str());
+    return BF_OK;
+}
+
+int ensure_staging(bf_handle *h, size_t x_elems, size_t y_elems) {
+    if (x_elems > h->d_x_cap) {
+        if (h->d_x) hipFree(h->d_x);
+        h->d_x = nullptr;
+        h->d_x_cap = 0;
+        BF_HIP(h, hipMalloc((void **)&h->d_x, x_elems * sizeof(float)));
+        h->d_x_cap = x_elems;
+    }
+    if (y_elems > h->d_y_cap) {
+        if (h->d_y) hipFree(h->d_y);
+        h->d_y = nullptr;
+        h->d_y_cap = 0;
+        BF_HIP(h, hipMalloc((void **)&h->d_y, y_elems * sizeof(float)));
+        h->d_y_cap = y_elems;
+    }
+    return BF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *bf_version(void) { return "bfcore-mi355x 0.1 (gfx950)"; }
+
+const char *bf_strerror(int code) {
+    switch (code) {
+        case BF_OK: return "ok";
+        case BF_EINVAL: return "invalid argument or configuration";
+        case BF_ENOMEM: return "out of memory";
+        case BF_ENODEV: return "no usable HIP device (this library has no CPU fallback)";
+        case BF_ENOSYS: return "algorithm or variant not available in this build";
+        case BF_EIO: return "HIP runtime error";
+        case BF_ENOENT: return "file not found";
+        default: return "unknown error";
+    }
+}
+
+const char *bf_last_error(const bf_handle *h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+int bf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bf_create(const bf_config *cfg, bf_handle **out) {
+    if (!cfg || !out) return BF_EINVAL;
+    *out = nullptr;
+    if (cfg->algo < BF_DAS || cfg->algo > BF_PHASEMPF) return fail(nullptr, BF_EINVAL, "algo out of range");
+    if (cfg->n_mics < 1 || cfg->n_mics > BF_MAX_MICS) return fail(nullptr, BF_EINVAL, "n_mics out of range");
+    if (cfg->hop != 512) return fail(nullptr, BF_ENOSYS, "only hop 512 (fft_win 1024) is built");
+    if (cfg->n_streams < 1) return fail(nullptr, BF_EINVAL, "n_streams < 1");
+    if (cfg->n_interf < 0 || cfg->n_interf > BF_MAX_INTERF) return fail(nullptr, BF_EINVAL, "n_interf out of range");
+    if (cfg->layout != BF_PLANAR && cfg->layout != BF_INTERLEAVED) return fail(nullptr, BF_EINVAL, "layout");
+    int ndev = bf_device_count();
+    if (ndev <= 0) return fail(nullptr, BF_ENODEV, "no HIP device visible; libbfcore has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, BF_ENODEV, "device ordinal out of range");
+
+    bf_handle *h = new bf_handle();
+    h->cfg = *cfg;
+    h->M = cfg->n_mics;
+    h->H = cfg->hop;
+    h->N = 2 * cfg->hop;
+    const bool multi = (cfg->algo == BF_LCMV || cfg->algo == BF_GSS);
+    h->S = multi ? cfg->n_interf + 1 : 1;
+    h->n_streams = cfg->n_streams;
+    h->device = cfg->device;
+    h->angle = cfg->theta;
+    for (int k = 0; k < h->S - 1; ++k) h->interf.push_back(cfg->interf_angle[k]);
+
+#define BF_CREATE_HIP(call)                                   \
+    do {                                                      \
+        hipError_t e_ = (call);                               \
+        if (e_ != hipSuccess) {                               \
+            int rc_ = fail(nullptr, BF_EIO, #call, e_);       \
+            bf_destroy(h);                                    \
+            return rc_;                                       \
+        }                                                     \
+    } while (0)
+
+    BF_CREATE_HIP(hipSetDevice(h->device));
+    hipDeviceProp_t prop;
+    BF_CREATE_HIP(hipGetDeviceProperties(&prop, h->device));
+    h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+    // handle_params + calculate_frequency_vector + update_weights(true)
+    h->geo.set(cfg->mic_x, cfg->mic_y, h->M);
+    h->freqs = frequency_vector(h->N, cfg->sample_rate);
+    h->steer.allocate(h->N, h->M, h->S);
+    rebuild_steering(h, true);
+
+    BF_CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    BF_CREATE_HIP(hipEventCreate(&h->ev0));
+    BF_CREATE_HIP(hipEventCreate(&h->ev1));
+
+    const size_t S = h->n_streams;
+    if (uses_fused_das(h)) {
+        const size_t gsz = (size_t)((h->M + 1) / 2) * 1024;
+        BF_CREATE_HIP(hipMalloc((void **)&h->d_gains[0], gsz * sizeof(f32x2)));
+        BF_CREATE_HIP(hipMalloc((void **)&h->d_gains[1], gsz * sizeof(f32x2)));
+        std::vector<f32x2> tw = twiddle_table_32x32<f32x2>();
+        BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle, tw.size() * sizeof(f32x2)));
+        BF_CREATE_HIP(hipMemcpy(h->d_twiddle, tw.data(), tw.size() * sizeof(f32x2), hipMemcpyHostToDevice));
+        std::vector<double> hd = sqrt_hann(h->N);
+        std::vector<float> hf(h->N);
+        for (int i = 0; i < h->N; ++i) hf[i] = (float)hd[i];
+        BF_CREATE_HIP(hipMalloc((void **)&h->d_window, hf.size() * sizeof(float)));
+        BF_CREATE_HIP(hipMemcpy(h->d_window, hf.data(), hf.size() * sizeof(float), hipMemcpyHostToDevice));
+        BF_CREATE_HIP(hipMalloc((void **)&h->d_hist, S * h->M * h->H * sizeof(float)));
+        BF_CREATE_HIP(hipMalloc((void **)&h->d_tail[0], S * h->H * sizeof(float)));
+        BF_CREATE_HIP(hipMalloc((void **)&h->d_tail[1], S * h->H * sizeof(float)));
+    } else {
+        h->pipe = BinPipeline::create(h->cfg, h->n_cus);
+        if (!h->pipe) {
+            int rc = fail(nullptr, BF_ENOSYS, "bin pipeline for this algorithm is not built");
+            bf_destroy(h);
+            return rc;
+        }
+        int rc = h->pipe->init();
+        if (rc != BF_OK) {
+            fail(nullptr, rc, h->pipe->error().c_str());
+            bf_destroy(h);
+            return rc;
+        }
+    }
+#undef BF_CREATE_HIP
+    int rc = bf_reset(h);
+    if (rc != BF_OK) {
+        bf_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return BF_OK;
+}
+
+void bf_destroy(bf_handle *h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (int i = 0; i < 2; ++i) {
+        if (h->d_gains[i]) hipFree(h->d_gains[i]);
+        if (h->d_tail[i]) hipFree(h->d_tail[i]);
+    }
+    if (h->d_twiddle) hipFree(h->d_twiddle);
+    if (h->d_window) hipFree(h->d_window);
+    if (h->d_hist) hipFree(h->d_hist);
+    if (h->d_sdump) hipFree(h->d_sdump);
+    if (h->d_x) hipFree(h->d_x);
+    if (h->d_y) hipFree(h->d_y);
+    delete h->pipe;
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int bf_reset(bf_handle *h) {
+    if (!h) return BF_EINVAL;
+    BF_HIP(h, hipSetDevice(h->device));
+    const size_t S = h->n_streams;
+    if (uses_fused_das(h)) {
+        // prepare_overlap_and_add: ring pre-filled with one hop of zeros, out_buff calloc'ed (util.h:272-286)
+        BF_HIP(h, hipMemset(h->d_hist, 0, S * h->M * h->H * sizeof(float)));
+        BF_HIP(h, hipMemset(h->d_tail[0], 0, S * h->H * sizeof(float)));
+        BF_HIP(h, hipMemset(h->d_tail[1], 0, S * h->H * sizeof(float)));
+        h->tail_cur = 0;
+    } else if (h->pipe) {
+        int rc = h->pipe->reset();
+        if (rc != BF_OK) return fail(h, rc, h->pipe->error().c_str());
+    }
+    return BF_OK;
+}
+
+int bf_set_theta(bf_handle *h, double degrees) {
+    if (!h) return BF_EINVAL;
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->angle = degrees;
+    rebuild_steering(h, false);
+    if (h->pipe) h->pipe->on_theta_changed();  // gss resets its demixing matrices (gss.cpp:90-93)
+    return BF_OK;
+}
+
+int bf_set_interference(bf_handle *h, unsigned id, double degrees) {
+    if (!h) return BF_EINVAL;
+    if (h->cfg.algo != BF_LCMV && h->cfg.algo != BF_GSS) return fail(h, BF_EINVAL, "node has no interferers");
+    std::lock_guard<std::mutex> lk(h->mu);
+    // lcmv.cpp:259-281, update of an existing interferer.  Structural changes
+    // (append / remove-when-too-close, lcmv.cpp:266-305) would re-allocate every
+    // per-bin matrix; not supported at run time in this build.
+    if (id < 1 || id > h->interf.size()) return fail(h, BF_ENOSYS, "adding/removing interferers at run time is not built");
+    for (size_t i = 0; i < h->interf.size(); ++i)
+        if (i != id - 1 && std::abs(h->interf[i] - degrees) < h->cfg.interf_angle_threshold)
+            return fail(h, BF_ENOSYS, "interferer removal (too close to another) is not built");
+    h->interf[id - 1] = degrees;
+    rebuild_steering(h, false);
+    if (h->pipe) h->pipe->on_theta_changed();
+    return BF_OK;
+}
+
+int bf_get_weights(bf_handle *h, double *w_host) {
+    if (!h || !w_host) return BF_EINVAL;
+    std::lock_guard<std::mutex> lk(h->mu);
+    memcpy(w_host, h->steer.w.data(), h->steer.w.size() * sizeof(cplxd));
+    return BF_OK;
+}
+
+int bf_process_batch_device(bf_handle *h, const float *x_dev, size_t n_frames, float *y_dev, void *spectrum_dev,
+                            void *hip_stream) {
+    if (!h || !x_dev || !y_dev) return BF_EINVAL;
+    BF_HIP(h, hipSetDevice(h->device));
+    return run_batch_device(h, x_dev, n_frames, y_dev, spectrum_dev, (hipStream_t)hip_stream, h->cfg.layout,
+                            (long)n_frames * h->H);
+}
+
+int bf_process_batch(bf_handle *h, const float *x_host, size_t n_frames, float *y_host) {
+    if (!h || !x_host || !y_host) return BF_EINVAL;
+    if (n_frames == 0) return BF_OK;
+    BF_HIP(h, hipSetDevice(h->device));
+    const size_t xe = (size_t)h->n_streams * h->M * n_frames * h->H;
+    const size_t ye = (size_t)h->n_streams * n_frames * h->H;
+    int rc = ensure_staging(h, xe, ye);
+    if (rc != BF_OK) return rc;
+    BF_HIP(h, hipMemcpyAsync(h->d_x, x_host, xe * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    rc = run_batch_device(h, h->d_x, n_frames, h->d_y, nullptr, h->stream, h->cfg.layout, (long)n_frames * h->H);
+    if (rc != BF_OK) return rc;
+    BF_HIP(h, hipMemcpyAsync(y_host, h->d_y, ye * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    BF_HIP(h, hipStreamSynchronize(h->stream));
+    return BF_OK;
+}
+
+int bf_process_hop(bf_handle *h, const float *const *in, float *out, uint32_t nframes) {
+    if (!h || !in || !out) return BF_EINVAL;
+    if ((int)nframes != h->H) return fail(h, BF_EINVAL, "nframes must equal the configured hop");
+    if (h->n_streams != 1) return fail(h, BF_EINVAL, "bf_process_hop drives stream 0 of a single-stream handle");
+    BF_HIP(h, hipSetDevice(h->device));
+    int rc = ensure_staging(h, (size_t)h->M * h->H, (size_t)h->H);
+    if (rc != BF_OK) return rc;
+    std::vector<float> packed((size_t)h->M * h->H);
+    if (h->cfg.layout == BF_PLANAR) {
+        for (int m = 0; m < h->M; ++m) memcpy(packed.data() + (size_t)m * h->H, in[m], sizeof(float) * h->H);
+    } else {
+        for (int m = 0; m < h->M; ++m)
+            for (int n = 0; n < h->H; ++n) packed[(size_t)n * h->M + m] = in[m][n];
+    }
+    BF_HIP(h, hipMemcpyAsync(h->d_x, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    rc = run_batch_device(h, h->d_x, 1, h->d_y, nullptr, h->stream, h->cfg.layout, (long)h->H);
+    if (rc != BF_OK) return rc;
+    BF_HIP(h, hipMemcpyAsync(out, h->d_y, sizeof(float) * h->H, hipMemcpyDeviceToHost, h->stream));
+    BF_HIP(h, hipStreamSynchronize(h->stream));
+    return BF_OK;
+}
+
+int bf_time_batch_device(bf_handle *h, const float *x_dev, size_t n_frames, float *y_dev, void *hip_stream, int iters,
+                         float *ms_per_call) {
+    if (!h || !x_dev || !y_dev || iters < 1 || !ms_per_call) return BF_EINVAL;
+    BF_HIP(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    BF_HIP(h, hipEventRecord(h->ev0, s));
+    for (int i = 0; i < iters; ++i) {
+        int rc = run_batch_device(h, x_dev, n_frames, y_dev, nullptr, s, h->cfg.layout, (long)n_frames * h->H);
+        if (rc != BF_OK) return rc;
+    }
+    BF_HIP(h, hipEventRecord(h->ev1, s));
+    BF_HIP(h, hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    BF_HIP(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *ms_per_call = ms / (float)iters;
+    return BF_OK;
+}
+
+// ---- checkpoint -------------------------------------------------------------
+struct bf_state_header {
+    uint32_t magic, algo, n_mics, n_streams, hop, das_impl;
+    uint64_t payload;
+};
+static const uint32_t kStateMagic = 0x42465354;  // "BFST"
+
+size_t bf_state_size(const bf_handle *h) {
+    if (!h) return 0;
+    size_t payload;
+    if (uses_fused_das(h))
+        payload = ((size_t)h->n_streams * h->M * h->H + (size_t)h->n_streams * h->H) * sizeof(float);
+    else
+        payload = h->pipe ? h->pipe->state_bytes() : 0;
+    return sizeof(bf_state_header) + payload;
+}
+
+int bf_get_state(bf_handle *h, void *blob, size_t size) {
+    if (!h || !blob || size < bf_state_size(h)) return BF_EINVAL;
+    BF_HIP(h, hipSetDevice(h->device));
+    BF_HIP(h, hipDeviceSynchronize());
+    bf_state_header hd = {kStateMagic, (uint32_t)h->cfg.algo, (uint32_t)h->M, (uint32_t)h->n_streams, (uint32_t)h->H,
+                          (uint32_t)h->cfg.das_impl, (uint64_t)(bf_state_size(h) - sizeof(bf_state_header))};
+    memcpy(blob, &hd, sizeof(hd));
+    char *p = (char *)blob + sizeof(hd);
+    if (uses_fused_das(h)) {
+        const size_t hb = (size_t)h->n_streams * h->M * h->H * sizeof(float), tb = (size_t)h->n_streams * h->H * sizeof(float);
+        BF_HIP(h, hipMemcpy(p, h->d_hist, hb, hipMemcpyDeviceToHost));
+        BF_HIP(h, hipMemcpy(p + hb, h->d_tail[h->tail_cur], tb, hipMemcpyDeviceToHost));
+        return BF_OK;
+    }
+    int rc = h->pipe->get_state(p);
+    return rc == BF_OK ? BF_OK : fail(h, rc, h->pipe->error().c_str());
+}
+
+int bf_set_state(bf_handle *h, const void *blob, size_t size) {
+    if (!h || !blob || size < bf_state_size(h)) return BF_EINVAL;
+    bf_state_header hd;
+    memcpy(&hd, blob, sizeof(hd));
+    if (hd.magic != kStateMagic || hd.algo != (uint32_t)h->cfg.algo || hd.n_mics != (uint32_t)h->M ||
+        hd.n_streams != (uint32_t)h->n_streams || hd.hop != (uint32_t)h->H || hd.das_impl != (uint32_t)h->cfg.das_impl)
+        return fail(h, BF_EINVAL, "state blob does not match this handle");
+    BF_HIP(h, hipSetDevice(h->device));
+    BF_HIP(h, hipDeviceSynchronize());
+    const char *p = (const char *)blob + sizeof(hd);
+    if (uses_fused_das(h)) {
+        const size_t hb = (size_t)h->n_streams * h->M * h->H * sizeof(float), tb = (size_t)h->n_streams * h->H * sizeof(float);
+        BF_HIP(h, hipMemcpy(h->d_hist, p, hb, hipMemcpyHostToDevice));
+        BF_HIP(h, hipMemcpy(h->d_tail[h->tail_cur], p + hb, tb, hipMemcpyHostToDevice));
+        return BF_OK;
+    }
+    int rc = h->pipe->set_state(p);
+    return rc == BF_OK ? BF_OK : fail(h, rc, h->pipe->error().c_str());
+}
+
+}  // extern "C"

@@ -1,0 +1,160 @@
+// geometry.hpp -- host-side (double precision) array geometry, frequency vector,
+// steering weights and the derived device tables.
+//
+// Mirrors, for this path only, what the reference computes at start-up and on
+// every /theta message:
+//   handle_params            util.h:52-134   (dist/angle from RAW yaml xy: quirk Q2)
+//   calculate_delays         util.h:136-161
+//   calculate_frequency_vector util.h:190-199 (quirk Q1: f[N/2-1]=sr/2, f[N/2] undefined -> 0)
+//   hann / create_hann_winn  util.h:201-211
+//   update_weights           das.cpp:27-45, lcmv.cpp:44-86
+// Header-only so the CPU-side unit tests can compile it with g++.
+#pragma once
+
+#include <cmath>
+#include <complex>
+#include <vector>
+
+#include "fft32.hpp"
+
+namespace bf {
+
+typedef std::complex<double> cplxd;
+
+constexpr double kPi = 3.141592653589793238462643383279502884;
+constexpr double kSoundSpeed = 343.0;  // util.h:25
+
+struct ArrayGeometry {
+    int n_mics = 0;
+    std::vector<double> dist;     // sqrt(x^2+y^2) of the raw coordinates
+    std::vector<double> ang_deg;  // atan2(y,x) in degrees of the raw coordinates
+
+    void set(const double *x, const double *y, int n) {
+        n_mics = n;
+        dist.resize(n);
+        ang_deg.resize(n);
+        for (int i = 0; i < n; ++i) {
+            dist[i] = std::sqrt(x[i] * x[i] + y[i] * y[i]);
+            ang_deg[i] = std::atan2(y[i], x[i]) * (180.0 / kPi);
+        }
+    }
+
+    // Far-field delay of every mic relative to mic 0 for a source at `angle` degrees.
+    void delays(double angle, double *tau) const {
+        for (int i = 0; i < n_mics; ++i) {
+            if (i == 0) {
+                tau[i] = 0.0;
+                continue;
+            }
+            double d = ang_deg[i] - angle;
+            if (d > 180)
+                d -= 360;
+            else if (d < -180)
+                d += 360;
+            tau[i] = dist[i] * std::cos(d * (kPi / 180.0)) / (-kSoundSpeed);
+        }
+    }
+};
+
+// FFT-bin -> Hz including the reference's two off-by-one quirks (Q1).
+inline std::vector<double> frequency_vector(int n_fft, double sample_rate) {
+    std::vector<double> f(n_fft, 0.0);
+    for (int k = 1; k < n_fft / 2; ++k) {
+        f[k] = ((double)k / (double)n_fft) * sample_rate;
+        f[n_fft - k] = -((double)k / (double)n_fft) * sample_rate;
+    }
+    f[n_fft / 2 - 1] = sample_rate / 2;
+    return f;
+}
+
+// Periodic sqrt-Hann analysis/synthesis window.
+inline std::vector<double> sqrt_hann(int n_fft) {
+    std::vector<double> h(n_fft);
+    for (int i = 0; i < n_fft; ++i) h[i] = std::sqrt(0.5 - 0.5 * std::cos(2 * kPi * i / n_fft));
+    return h;
+}
+
+// Steering / constraint matrices, [bin][mic][col] with col 0 = look direction and
+// col k>=1 = interferer k.  `first` = the reference's update_weights(ini=true):
+// row 0 (reference mic) is only ever written then (quirk Q3), so after a
+// structural re-allocation it stays 0 until the next cold start.
+struct SteeringSet {
+    int n_fft = 0, n_mics = 0, n_cols = 1;
+    std::vector<cplxd> w;  // [n_fft][n_mics][n_cols]
+
+    cplxd &at(int j, int m, int c) { return w[((size_t)j * n_mics + m) * n_cols + c]; }
+    const cplxd &at(int j, int m, int c) const { return w[((size_t)j * n_mics + m) * n_cols + c]; }
+
+    void allocate(int nfft, int mics, int cols) {
+        n_fft = nfft;
+        n_mics = mics;
+        n_cols = cols;
+        w.assign((size_t)nfft * mics * cols, cplxd(0, 0));
+    }
+
+    void update_column(const ArrayGeometry &g, const std::vector<double> &freqs, int col, double angle, bool first) {
+        std::vector<double> tau(n_mics);
+        g.delays(angle, tau.data());
+        const cplxd minus_i(0, -1);
+        for (int m = 0; m < n_mics; ++m) {
+            if (m == 0) {
+                if (first)
+                    for (int j = 0; j < n_fft; ++j) at(j, 0, col) = 1.0;
+            } else {
+                for (int j = 0; j < n_fft; ++j) at(j, m, col) = std::exp(minus_i * (double)2 * kPi * freqs[j] * tau[m]);
+            }
+        }
+    }
+};
+
+struct f32x2 {
+    float x, y;
+};
+struct f64x2 {
+    double x, y;
+};
+
+// exp(-2 pi i k l / 1024) for k,l in [0,32): the inter-pass twiddles of the 32x32
+// decomposition, laid out [k][l] so that lanes (l) read consecutive addresses.
+template <typename V>
+inline std::vector<V> twiddle_table_32x32() {
+    std::vector<V> t(1024);
+    for (int k = 0; k < 32; ++k)
+        for (int l = 0; l < 32; ++l) {
+            double a = -2.0 * kPi * (double)(k * l) / 1024.0;
+            t[k * 32 + l].x = (decltype(t[0].x))std::cos(a);
+            t[k * 32 + l].y = (decltype(t[0].x))std::sin(a);
+        }
+    return t;
+}
+
+// Per-pair complex gains of the fused DAS kernel.
+//
+// The reference computes y = Re IFFT( sum_m conj(w[m,k]) X_m[k] / M ) (das.cpp:60-66,
+// util.h:249).  Two real mics (a,b) are transformed as one complex signal
+// Z = FFT(a + i b); with c_m = conj(w_m)/M and its Hermitian part
+// ce_m[k] = (c_m[k] + conj(c_m[N-k]))/2 the same real output is
+//   y = Re IFFT( sum_pairs D_p[k] Z_p[k] ),   D_p = ce_a - i ce_b
+// (derivation in DESIGN.md).  1/N of util.h:249 is folded in.  Odd mic counts
+// get a zero b-channel.  Layout: [pair][pos i][lane l] = D_p[l + 32*brev5(i)],
+// the register/lane order in which fft1024 leaves the spectrum.
+inline std::vector<f32x2> das_pair_gains(const SteeringSet &s, int n_pairs_alloc) {
+    const int N = s.n_fft, M = s.n_mics;
+    std::vector<f32x2> D((size_t)n_pairs_alloc * N, f32x2{0.f, 0.f});
+    auto ce = [&](int m, int k) -> cplxd {
+        if (m >= M) return cplxd(0, 0);
+        cplxd c1 = std::conj(s.at(k, m, 0)) / (double)M;
+        cplxd c2 = std::conj(s.at((N - k) % N, m, 0)) / (double)M;
+        return 0.5 * (c1 + std::conj(c2));
+    };
+    for (int p = 0; p < (M + 1) / 2; ++p)
+        for (int i = 0; i < 32; ++i)
+            for (int l = 0; l < 32; ++l) {
+                int k = l + 32 * brev5(i);
+                cplxd d = (ce(2 * p, k) - cplxd(0, 1) * ce(2 * p + 1, k)) / (double)N;
+                D[((size_t)p * 32 + i) * 32 + l] = f32x2{(float)d.real(), (float)d.imag()};
+            }
+    return D;
+}
+
+}  // namespace bf

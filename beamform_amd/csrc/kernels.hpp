@@ -1,0 +1,35 @@
+// kernels.hpp -- host-visible launchers of the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "geometry.hpp"
+
+namespace bf {
+
+// ---- fused fp32 DAS (das_fused.hip) ------------------------------------------
+struct DasFusedArgs {
+    const float *x;        // input samples, layout per `layout`
+    const float *hist;     // [stream][mic][hop] (planar) or [stream][hop][mic]: the hop before frame 0
+    float *y;              // [stream][n_frames*hop]
+    const float *tail_in;  // [stream][hop] second half of the frame before frame 0 (out_buff[0], util.h:302)
+    float *tail_out;       // [stream][hop] second half of the last frame of this batch
+    const f32x2 *gains;    // das_pair_gains() table
+    const f32x2 *twiddle;  // twiddle_table_32x32<f32x2>()
+    const float *window;   // sqrt-Hann, fp32, natural order [1024]
+    f32x2 *sdump;          // nullable: [stream][frame][1024] accumulated pair spectrum S (1/N folded in)
+    long n_frames;         // frames per stream
+    long mic_stride;       // planar: samples between mics of one stream
+    long stream_stride_x;  // samples between streams in x
+    int n_streams;
+    int n_mics;
+    int frames_per_chunk;
+    int chunks_per_stream;
+    int layout;            // bf_layout
+};
+hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t stream);
+
+// S dump -> Hermitian part of the reference's y_fft as double2 [frames][1024]
+hipError_t launch_das_hermitian_dump(const f32x2 *sdump, f64x2 *out, long n_frames_total, hipStream_t stream);
+
+}  // namespace bf

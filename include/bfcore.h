@@ -1,0 +1,176 @@
+/*
+ * bfcore.h -- C ABI of the MI355X beamforming core (libbfcore.so).
+ *
+ * Drop-in boundary for the per-callback hot path of balkce/beamform:
+ *   STFT (sqrt-Hann, 50 % hop) -> per-bin complex weighting -> ISTFT + overlap-add
+ * as driven by every node's jack_callback (das, mvdr, lcmv, gss, phase, phasempf).
+ * Plain C types only; device buffers are raw HIP device pointers.
+ *
+ * Each entry point names the reference interface it replaces (file:line relative
+ * to the reference root).  All functions return 0 on success or a negative
+ * BF_E* code; nothing here exits the process, prints, or keeps global state
+ * (the reference keeps everything in file-scope globals, util.h:24-50).
+ *
+ * There is NO CPU fallback: bf_create fails with BF_ENODEV when no HIP device is
+ * usable.
+ */
+#ifndef BFCORE_H
+#define BFCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BF_MAX_MICS 32
+#define BF_MAX_INTERF 15 /* beamform_config.yaml:43-57 lists angle_interf1..15 */
+
+/* Which node's apply_weights() runs between the STFT and the ISTFT. */
+enum bf_algo {
+    BF_DAS = 0,      /* das.cpp:47-70 */
+    BF_MVDR = 1,     /* mvdr.cpp:62-115 */
+    BF_LCMV = 2,     /* lcmv.cpp:88-140 */
+    BF_GSS = 3,      /* gss.cpp:96-156 */
+    BF_PHASE = 4,    /* phase.cpp:70-134 */
+    BF_PHASEMPF = 5  /* phasempf.cpp:193-302 + :331-334 */
+};
+
+enum bf_error {
+    BF_OK = 0,
+    BF_EINVAL = -22,   /* bad argument / inconsistent config */
+    BF_ENOMEM = -12,   /* host or device allocation failed */
+    BF_ENODEV = -19,   /* no usable HIP device (no CPU fallback exists) */
+    BF_ENOSYS = -38,   /* algorithm/variant not built into this library */
+    BF_EIO = -5,       /* HIP runtime error; see bf_last_error() */
+    BF_ENOENT = -2     /* config file not found */
+};
+
+/* How bf_process_batch* lays out multichannel input. */
+enum bf_layout {
+    BF_PLANAR = 0,      /* [stream][mic][sample]  -- what JACK hands the callback (rosjack.cpp:538-547) */
+    BF_INTERLEAVED = 1  /* [stream][sample][mic]  -- interleaved frame buffer */
+};
+
+/* DAS implementation selector (other algorithms always use the f64 bin pipeline). */
+enum bf_das_impl {
+    BF_DAS_FUSED_F32 = 0, /* one fused kernel, fp32 arithmetic (headline path) */
+    BF_DAS_BINS_F64 = 1   /* STFT -> per-bin kernel -> ISTFT in fp64; dumps the full N-bin spectrum */
+};
+
+/*
+ * Everything a node reads from the ROS parameter server
+ * (handle_params util.h:52-134 + each node's *_handle_params) plus the two
+ * JACK-server facts rosjack_create() records (rosjack.cpp:131-134).
+ * bf_config_init() fills the launch-file values.
+ */
+typedef struct bf_config {
+    int algo;                      /* enum bf_algo */
+    int n_mics;                    /* number_of_microphones (util.h:122) */
+    int hop;                       /* rosjack_window_size; fft_win = 2*hop (util.h:261). 512 only in this build */
+    double sample_rate;            /* rosjack_sample_rate */
+    double mic_x[BF_MAX_MICS];     /* RAW mic<i>.x / .y from beamform_config.yaml (util.h:82-92) */
+    double mic_y[BF_MAX_MICS];
+    double theta;                  /* initial_angle, degrees (util.h:68-73) */
+    int n_interf;                  /* number of angle_interf<k> with |angle| <= 180 (util.h:101-113) */
+    double interf_angle[BF_MAX_INTERF];
+    int verbose;
+    /* mvdr / lcmv / gss */
+    int past_windows;              /* mvdr.cpp:151-157 */
+    double freq_mag_threshold;     /* mvdr.cpp:159-164 */
+    double freq_max, freq_min;     /* mvdr.cpp:166-178 */
+    double out_amp;                /* mvdr.cpp:180-185 (also phasempf.cpp:448-453) */
+    double interf_angle_threshold; /* lcmv.cpp:212-217 */
+    double mu, lambda_;            /* gss.cpp:219-231 */
+    /* phase */
+    double min_phase;              /* phase.cpp:169-175, phasempf.cpp:359-365 */
+    double mag_mult, mag_threshold;/* phase.cpp:177-189 */
+    /* phasempf */
+    double min_mag;                /* phasempf.cpp:367-372 */
+    int smooth_size;               /* phasempf.cpp:374-383 */
+    double mcra_alphaS, mcra_alphaD, mcra_alphaD2, mcra_delta; /* phasempf.cpp:385-411 */
+    int mcra_L;                    /* phasempf.cpp:413-418 */
+    double mpf_alphaS, mpf_eta, mpf_rev_gamma, mpf_rev_delta;  /* phasempf.cpp:420-446 */
+    double noise_floor;            /* phasempf.cpp:455-460 */
+    int out_only_noise, out_only_mcra; /* phasempf.cpp:462-474 */
+    /* build-specific (no reference counterpart) */
+    int device;                    /* HIP device ordinal */
+    int n_streams;                 /* independent audio streams per batch (each = one reference node's state) */
+    int layout;                    /* enum bf_layout for bf_process_batch* input */
+    int das_impl;                  /* enum bf_das_impl */
+} bf_config;
+
+typedef struct bf_handle bf_handle;
+
+/* Library identification / diagnostics. */
+const char *bf_version(void);
+const char *bf_strerror(int code);
+/* Last HIP/runtime error text recorded on this handle (or globally when h==NULL). */
+const char *bf_last_error(const bf_handle *h);
+/* Number of HIP devices visible; <= 0 means the product cannot run. */
+int bf_device_count(void);
+
+/* Launch-file defaults for `algo` and the uncommented geometry of
+ * beamform_config.yaml:15-17 (aira3).  Replaces the getParam fallbacks. */
+int bf_config_init(bf_config *cfg, int algo);
+/* Parse a beamform_config.yaml-style file (util.h:61-113 keys: verbose,
+ * initial_angle, mic<i>: {id,x,y[,z]}, angle_interf<k>) plus the flat
+ * per-node keys the launch files set (past_windows, freq_max, ...). */
+int bf_config_load_yaml(bf_config *cfg, const char *path);
+/* Same parser on an in-memory string. */
+int bf_config_parse_yaml(bf_config *cfg, const char *text);
+
+/* main(): prepare_overlap_and_add + buffer/plan allocation + update_weights(true)
+ * (das.cpp:119-140 and the same block in every node). */
+int bf_create(const bf_config *cfg, bf_handle **out);
+void bf_destroy(bf_handle *h);
+
+/* theta_roscallback: angle = msg->data; update_weights() (das.cpp:94-99).
+ * Thread-safe against a concurrent bf_process_*: takes effect at the next
+ * hop/batch (the reference updates in place with no lock). */
+int bf_set_theta(bf_handle *h, double degrees);
+/* interf_theta_roscallback (lcmv.cpp:258-309, gss.cpp): id is 1-based. */
+int bf_set_interference(bf_handle *h, unsigned id, double degrees);
+
+/* jack_callback body: do_overlap(in, out, nframes, apply_weights)
+ * (das.cpp:72-92, util.h:289-314).  in = n_mics pointers to nframes float32
+ * (host memory, as input_from_rosjack returns), out = nframes float32 (host).
+ * nframes must equal cfg.hop.  Stream 0 only. */
+int bf_process_hop(bf_handle *h, const float *const *in, float *out, uint32_t nframes);
+
+/* n_frames consecutive callbacks per stream in one call, host buffers.
+ * x: layout per cfg.layout with n_frames*hop samples per mic;
+ * y: [n_streams][n_frames*hop].  State carries over to the next call exactly
+ * as consecutive callbacks would. */
+int bf_process_batch(bf_handle *h, const float *x_host, size_t n_frames, float *y_host);
+
+/* Same, buffers already resident in HBM; enqueued on `hip_stream`
+ * (a hipStream_t, NULL = default stream) without host synchronisation.
+ * spectrum_dev (nullable): receives y_fft per frame as double2
+ * [n_streams][n_frames][2*hop] (see DESIGN.md for the DAS fused variant). */
+int bf_process_batch_device(bf_handle *h, const float *x_dev, size_t n_frames, float *y_dev,
+                            void *spectrum_dev, void *hip_stream);
+
+/* Steering / constraint matrices as the reference's update_weights builds them:
+ * [2*hop][n_mics][n_interf+1] complex double (re,im). */
+int bf_get_weights(bf_handle *h, double *w_host);
+
+/* Checkpoint of all per-stream state (ring hop, OLA tail, covariance history,
+ * GSS demixing matrices, MCRA/MPF vectors, smoothing tail).  The reference has
+ * no counterpart (state lives in process globals). */
+size_t bf_state_size(const bf_handle *h);
+int bf_get_state(bf_handle *h, void *blob_host, size_t size);
+int bf_set_state(bf_handle *h, const void *blob_host, size_t size);
+/* Back to the reference's cold start (zeroed rings/tails/history). */
+int bf_reset(bf_handle *h);
+
+/* Kernel-only timing hook for bench.py: runs bf_process_batch_device `iters`
+ * times between two hipEvents on `hip_stream`; returns mean ms per call. */
+int bf_time_batch_device(bf_handle *h, const float *x_dev, size_t n_frames, float *y_dev, void *hip_stream,
+                         int iters, float *ms_per_call);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BFCORE_H */
