@@ -1,7 +1,7 @@
 # Builds the product library (HIP, gfx950 only) and the CPU oracle (test infra).
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
-HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -fno-slp-vectorize -Wall -Wno-unused-function
 SRC := beamform_amd/csrc
 OBJ := build/obj
 LIB := beamform_amd/lib/libbfcore.so

@@ -90,7 +90,7 @@ def load():
     L.bf_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.bf_reset.argtypes = [C.c_void_p]
     L.bf_time_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int,
-                                       C.POINTER(C.c_float)]
+                                       C.POINTER(C.c_float), C.POINTER(C.c_float)]
     _lib = L
     return L
 
@@ -183,11 +183,12 @@ class Beamformer:
         self._chk(self._L.bf_process_batch_device(self._h, x_ptr, n_frames, y_ptr, spectrum_ptr or None, stream or None),
                   "bf_process_batch_device")
 
-    def time_device(self, x_ptr: int, n_frames: int, y_ptr: int, iters: int, stream: int = 0) -> float:
-        ms = C.c_float()
-        self._chk(self._L.bf_time_batch_device(self._h, x_ptr, n_frames, y_ptr, stream or None, iters, C.byref(ms)),
-                  "bf_time_batch_device")
-        return float(ms.value)
+    def time_device(self, x_ptr: int, n_frames: int, y_ptr: int, iters: int, stream: int = 0):
+        """(mean ms per call, mean ms per launch of the dominant kernel), HIP events on `stream`."""
+        ms, msk = C.c_float(), C.c_float()
+        self._chk(self._L.bf_time_batch_device(self._h, x_ptr, n_frames, y_ptr, stream or None, iters, C.byref(ms),
+                                               C.byref(msk)), "bf_time_batch_device")
+        return float(ms.value), float(msk.value)
 
     def get_state(self) -> bytes:
         n = self._L.bf_state_size(self._h)

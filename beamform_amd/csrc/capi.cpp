@@ -55,6 +55,9 @@ struct bf_handle {
     size_t d_x_cap = 0, d_y_cap = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // per-launch timing of the dominant kernel (bf_time_batch_device)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> *kernel_events = nullptr;
 };
 
 namespace {
@@ -118,7 +121,7 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     if (spectrum_dev) {
         const size_t need = (size_t)S * F * 1024;
         if (need > h->sdump_cap) {
-            if (h->d_sdump) hipFree(h->d_sdump);
+            if (h->d_sdump) (void)hipFree(h->d_sdump);
             h->d_sdump = nullptr;
             h->sdump_cap = 0;
             BF_HIP(h, hipMalloc((void **)&h->d_sdump, need * sizeof(f32x2)));
@@ -144,7 +147,15 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     a.frames_per_chunk = (int)fpc;
     a.chunks_per_stream = (int)cps;
     a.layout = layout;
+    hipEvent_t k0 = nullptr, k1 = nullptr;
+    if (h->kernel_events) {
+        BF_HIP(h, hipEventCreate(&k0));
+        BF_HIP(h, hipEventCreate(&k1));
+        h->kernel_events->push_back(std::make_pair(k0, k1));
+        BF_HIP(h, hipEventRecord(k0, s));
+    }
     BF_HIP(h, launch_das_fused(a, s));
+    if (k1) BF_HIP(h, hipEventRecord(k1, s));
     h->tail_cur ^= 1;
 
     // ring-buffer carry: keep the last hop of every mic for the next call (util.h:305-308)
@@ -174,14 +185,14 @@ int run_batch_device(bf_handle *h, const float *x_dev, size_t n_frames, float *y
 
 int ensure_staging(bf_handle *h, size_t x_elems, size_t y_elems) {
     if (x_elems > h->d_x_cap) {
-        if (h->d_x) hipFree(h->d_x);
+        if (h->d_x) (void)hipFree(h->d_x);
         h->d_x = nullptr;
         h->d_x_cap = 0;
         BF_HIP(h, hipMalloc((void **)&h->d_x, x_elems * sizeof(float)));
         h->d_x_cap = x_elems;
     }
     if (y_elems > h->d_y_cap) {
-        if (h->d_y) hipFree(h->d_y);
+        if (h->d_y) (void)hipFree(h->d_y);
         h->d_y = nullptr;
         h->d_y_cap = 0;
         BF_HIP(h, hipMalloc((void **)&h->d_y, y_elems * sizeof(float)));
@@ -309,22 +320,22 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
 
 void bf_destroy(bf_handle *h) {
     if (!h) return;
-    hipSetDevice(h->device);
-    if (h->stream) hipStreamSynchronize(h->stream);
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int i = 0; i < 2; ++i) {
-        if (h->d_gains[i]) hipFree(h->d_gains[i]);
-        if (h->d_tail[i]) hipFree(h->d_tail[i]);
+        if (h->d_gains[i]) (void)hipFree(h->d_gains[i]);
+        if (h->d_tail[i]) (void)hipFree(h->d_tail[i]);
     }
-    if (h->d_twiddle) hipFree(h->d_twiddle);
-    if (h->d_window) hipFree(h->d_window);
-    if (h->d_hist) hipFree(h->d_hist);
-    if (h->d_sdump) hipFree(h->d_sdump);
-    if (h->d_x) hipFree(h->d_x);
-    if (h->d_y) hipFree(h->d_y);
+    if (h->d_twiddle) (void)hipFree(h->d_twiddle);
+    if (h->d_window) (void)hipFree(h->d_window);
+    if (h->d_hist) (void)hipFree(h->d_hist);
+    if (h->d_sdump) (void)hipFree(h->d_sdump);
+    if (h->d_x) (void)hipFree(h->d_x);
+    if (h->d_y) (void)hipFree(h->d_y);
     delete h->pipe;
-    if (h->ev0) hipEventDestroy(h->ev0);
-    if (h->ev1) hipEventDestroy(h->ev1);
-    if (h->stream) hipStreamDestroy(h->stream);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
@@ -425,20 +436,31 @@ int bf_process_hop(bf_handle *h, const float *const *in, float *out, uint32_t nf
 }
 
 int bf_time_batch_device(bf_handle *h, const float *x_dev, size_t n_frames, float *y_dev, void *hip_stream, int iters,
-                         float *ms_per_call) {
+                         float *ms_per_call, float *ms_kernel) {
     if (!h || !x_dev || !y_dev || iters < 1 || !ms_per_call) return BF_EINVAL;
     BF_HIP(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)hip_stream;
-    BF_HIP(h, hipEventRecord(h->ev0, s));
-    for (int i = 0; i < iters; ++i) {
-        int rc = run_batch_device(h, x_dev, n_frames, y_dev, nullptr, s, h->cfg.layout, (long)n_frames * h->H);
-        if (rc != BF_OK) return rc;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
+    h->kernel_events = ms_kernel ? &kev : nullptr;
+    int rc = BF_OK;
+    hipError_t e = hipEventRecord(h->ev0, s);
+    for (int i = 0; i < iters && rc == BF_OK && e == hipSuccess; ++i)
+        rc = run_batch_device(h, x_dev, n_frames, y_dev, nullptr, s, h->cfg.layout, (long)n_frames * h->H);
+    h->kernel_events = nullptr;
+    if (e == hipSuccess) e = hipEventRecord(h->ev1, s);
+    if (e == hipSuccess) e = hipEventSynchronize(h->ev1);
+    float ms = 0.f, msk = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, h->ev0, h->ev1);
+    for (auto &pr : kev) {
+        float t = 0.f;
+        if (e == hipSuccess && rc == BF_OK && hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) msk += t;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
     }
-    BF_HIP(h, hipEventRecord(h->ev1, s));
-    BF_HIP(h, hipEventSynchronize(h->ev1));
-    float ms = 0.f;
-    BF_HIP(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    if (rc != BF_OK) return rc;
+    if (e != hipSuccess) return fail(h, BF_EIO, "bf_time_batch_device", e);
     *ms_per_call = ms / (float)iters;
+    if (ms_kernel) *ms_kernel = kev.empty() ? 0.f : msk / (float)kev.size();
     return BF_OK;
 }
 

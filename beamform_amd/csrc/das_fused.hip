@@ -21,6 +21,8 @@
 // 8.5 KiB transpose per FFT plus the 8 KiB twiddle table reads.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "fft1024.hpp"
 #include "kernels.hpp"
 
@@ -35,7 +37,8 @@ constexpr int kHop = 512;
 constexpr int kNfft = 1024;
 constexpr int kWinStride = 36;  // floats per lane row: 144 B keeps ds_read_b128 groups conflict-free
 
-template <int LAYOUT>
+// ABL: timing-only ablation bits (outputs are wrong when != 0): 1 = no gain loads, 2 = no input loads, 4 = no LDS transpose
+template <int LAYOUT, int ABL = 0>
 __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
     // one LDS object: [twiddles 1024][16 transpose buffers][window 32 lanes x 36]
     __shared__ __attribute__((aligned(16))) cx<float> lds[1024 + kHalves * 32 * kRS + (32 * kWinStride) / 2];
@@ -84,7 +87,13 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             const bool b_ok = (2 * p + 1) < M;
             const int mb = b_ok ? 2 * p + 1 : ma;
             const float bscale = b_ok ? 1.f : 0.f;
-            if (LAYOUT == 0) {
+            if (ABL & 2) {
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    re[j] = (float)(j + lane) * 1e-3f + (float)tc;
+                    im[j] = (float)(j - lane) * 1e-3f;
+                }
+            } else if (LAYOUT == 0) {
                 const float *a1 = (tc >= 1 ? xs + (long)ma * a.mic_stride + (tc - 1) * kHop : hs + ma * kHop) + lane;
                 const float *b1 = (tc >= 1 ? xs + (long)mb * a.mic_stride + (tc - 1) * kHop : hs + mb * kHop) + lane;
                 const float *a2 = xs + (long)ma * a.mic_stride + tc * kHop + lane;
@@ -116,23 +125,28 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                 re[4 * g + 3] *= hv.w; im[4 * g + 3] *= hv.w * bscale;
             }
 
-            fft1024_fwd_a<float>(re, im, lane, s_tw, buf);
-            __builtin_amdgcn_wave_barrier();
-            fft1024_fwd_b<float>(re, im, lane, buf);
-            __builtin_amdgcn_wave_barrier();
+            if (ABL & 4) {
+                fft32_dif<float, -1>(re, im);
+                fft32_dif<float, -1>(re, im);
+            } else {
+                fft1024_fwd_a<float>(re, im, lane, s_tw, buf);
+                __builtin_amdgcn_wave_barrier();
+                fft1024_fwd_b<float>(re, im, lane, buf);
+                __builtin_amdgcn_wave_barrier();
+            }
 
             const f32x2 *gp = a.gains + (long)p * 1024 + lane;
             if (p == 0) {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
-                    const f32x2 g = gp[32 * i];
+                    const f32x2 g = (ABL & 1) ? f32x2{0.5f + i, 0.25f} : gp[32 * i];
                     Sr[i] = g.x * re[i] - g.y * im[i];
                     Si[i] = g.x * im[i] + g.y * re[i];
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
-                    const f32x2 g = gp[32 * i];
+                    const f32x2 g = (ABL & 1) ? f32x2{0.5f + i, 0.25f} : gp[32 * i];
                     Sr[i] += g.x * re[i] - g.y * im[i];
                     Si[i] += g.x * im[i] + g.y * re[i];
                 }
@@ -145,10 +159,15 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             for (int i = 0; i < 32; ++i) sd[32 * brev5(i)] = f32x2{Sr[i], Si[i]};
         }
 
-        fft1024_inv_a<float>(Sr, Si, lane, s_tw, buf);
-        __builtin_amdgcn_wave_barrier();
-        fft1024_inv_b<float>(Sr, Si, lane, buf);
-        __builtin_amdgcn_wave_barrier();
+        if (ABL & 4) {
+            fft32_dit<float, +1>(Sr, Si);
+            fft32_dif<float, +1>(Sr, Si);
+        } else {
+            fft1024_inv_a<float>(Sr, Si, lane, s_tw, buf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024_inv_b<float>(Sr, Si, lane, buf);
+            __builtin_amdgcn_wave_barrier();
+        }
 
         // position i holds sample n = 32*brev5(i) + lane; even i -> first half, odd i -> n + 512
         float h[32];
@@ -194,6 +213,18 @@ __global__ void das_hermitian_dump_kernel(const f32x2 *s, f64x2 *out, long total
 hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t stream) {
     const long chunks = (long)a.chunks_per_stream * a.n_streams;
     const unsigned blocks = (unsigned)((chunks + kHalves - 1) / kHalves);
+    static const int abl = getenv("BF_ABLATE") ? atoi(getenv("BF_ABLATE")) : 0;
+    if (abl && a.layout == 0) {
+        switch (abl) {
+            case 1: hipLaunchKernelGGL((das_fused_kernel<0, 1>), dim3(blocks), dim3(kBlock), 0, stream, a); break;
+            case 2: hipLaunchKernelGGL((das_fused_kernel<0, 2>), dim3(blocks), dim3(kBlock), 0, stream, a); break;
+            case 3: hipLaunchKernelGGL((das_fused_kernel<0, 3>), dim3(blocks), dim3(kBlock), 0, stream, a); break;
+            case 4: hipLaunchKernelGGL((das_fused_kernel<0, 4>), dim3(blocks), dim3(kBlock), 0, stream, a); break;
+            case 7: hipLaunchKernelGGL((das_fused_kernel<0, 7>), dim3(blocks), dim3(kBlock), 0, stream, a); break;
+            default: break;
+        }
+        return hipGetLastError();
+    }
     if (a.layout == 0)
         hipLaunchKernelGGL(das_fused_kernel<0>, dim3(blocks), dim3(kBlock), 0, stream, a);
     else

@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- STFT frames/s of the beamforming hot path on MI355X.
+
+A "step" is one pass of the hot path (window -> FFTs -> per-bin weight-and-sum
+-> IFFT -> overlap-add) over one batch of synthetic multichannel audio that is
+already resident in HBM.  Workload at N=1: BASELINE.json configs[1]
+(das, 8 mics, 1024-pt FFT / hop 512, 65536-frame batch).  With --gpus N the
+launcher starts one rank per GPU (torch.distributed over RCCL); every rank
+processes its own 65536-frame shard (weak scaling: independent frame ranges, no
+data-path collective), and the per-rank output slabs are collected on rank 0
+with one RCCL gather after the last step ("final gather", inside the timed
+region).
+
+Prints ONE JSON line on rank 0.  See DESIGN.md "Measurement" for definitions.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HOP = 512
+NFFT = 1024
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def algorithmic_bytes_per_frame(n_mics: int) -> int:
+    """M*H*4 B of new input + H*4 B of output per frame."""
+    return n_mics * HOP * 4 + HOP * 4
+
+
+def cpu_baseline(algo: str, n_mics: int, frames: int):
+    """The oracle (CPU restatement of the reference FFTW/Eigen path), one thread, bounded sample."""
+    import numpy as np
+    import oracle
+    from beamform_amd.params import make_params
+    from beamform_amd.synth import make_scene
+    p = make_params(algo, n_mics=n_mics)
+    reps = max(1, frames // 512)
+    x = np.tile(make_scene(n_mics, 512, seed=11), (1, reps))
+    F = x.shape[1] // HOP
+    node = oracle.OracleNode(p)
+    node.process(np.ascontiguousarray(x[:, : 64 * HOP]))  # warm caches / page in
+    t0 = time.perf_counter()
+    node.process(x)
+    dt = time.perf_counter() - t0
+    return {
+        "value": F / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+        "sample": f"{algo} {n_mics}-mic hop512 fft1024, {F} frames of the seeded synthetic scene, "
+                  f"{dt:.1f} s on 1 of {os.cpu_count()} host cores (oracle/bf_oracle.cpp; FFTW/Eigen/JACK/ROS absent "
+                  "from the image, so the reference binary itself cannot be timed)",
+    }
+
+
+def load_traffic(tag: str):
+    """HBM bytes per launch from a committed rocprofv3 --pmc summary (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", f"traffic_{tag}.json")
+    if os.path.exists(path):
+        try:
+            with open(path) as f:
+                return json.load(f).get("hbm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--algo", default="das", choices=["das", "mvdr", "lcmv", "gss", "phase", "phasempf"])
+    ap.add_argument("--mics", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=65536, help="frames per GPU per step")
+    ap.add_argument("--streams", type=int, default=1)
+    ap.add_argument("--layout", default="planar", choices=["planar", "interleaved"])
+    ap.add_argument("--gather", default="final", choices=["final", "step", "none"])
+    ap.add_argument("--cpu-frames", type=int, default=16384, help="frames in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from beamform_amd.capi import BF_INTERLEAVED, BF_PLANAR, Beamformer
+    from beamform_amd.params import make_params
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    M, F, S = args.mics, args.frames, args.streams
+    interf = (-60.0, 90.0, 150.0) if args.algo in ("lcmv", "gss") else ()
+    p = make_params(args.algo, n_mics=M, interf=interf)
+    layout = BF_PLANAR if args.layout == "planar" else BF_INTERLEAVED
+    bf = Beamformer(p, device=local_rank, n_streams=S, layout=layout)
+
+    # synthetic input, resident in HBM before the timed region: uniform noise in [-0.5, 0.5)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    shape = (S, M, F * HOP) if layout == BF_PLANAR else (S, F * HOP, M)
+    x = torch.rand(shape, device=dev, generator=g, dtype=torch.float32) - 0.5
+    y = torch.empty((S, F * HOP), device=dev, dtype=torch.float32)
+    gathered = None
+    if world > 1 and args.gather != "none" and rank == 0:
+        gathered = [torch.empty_like(y) for _ in range(world)]
+    stream = torch.cuda.current_stream(dev)
+    sptr = stream.cuda_stream
+
+    def step():
+        bf.process_device(x.data_ptr(), F, y.data_ptr(), 0, sptr)
+        if world > 1 and args.gather == "step":
+            dist.gather(y, gathered, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1 and args.gather == "final":
+        dist.gather(y, gathered, dst=0)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant-kernel duration: HIP events on the launch stream, one pair per launch
+    k_iters = max(5, min(args.steps, 50))
+    ms_call, ms_kernel = bf.time_device(x.data_ptr(), F, y.data_ptr(), k_iters, sptr)
+    torch.cuda.synchronize(dev)
+
+    if rank == 0:
+        frames_total = world * S * F * args.steps
+        value = frames_total / dt
+        bpf = algorithmic_bytes_per_frame(M)
+        units_per_launch = S * F
+        achieved = bpf * units_per_launch / (ms_kernel * 1e-3) / 1e9 if ms_kernel > 0 else 0.0
+        tag = f"{args.algo}{M}"
+        out = {
+            "metric": "stft_frames_per_sec", "value": value, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.algo == "das" else "f64", "data": "synthetic",
+            "config": {"workload": f"{args.algo} {M}-mic 1024-pt (hop 512), {F}-frame batch per GPU, {S} stream(s), "
+                                   f"{args.layout} input resident in HBM", "frames_per_gpu": F, "mics": M, "fft": NFFT,
+                       "hop": HOP, "streams": S, "layout": args.layout, "gather": args.gather if world > 1 else "n/a",
+                       "parallelism": f"frame-sharded x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(tag),
+                         "kernel": "das_fused_kernel" if args.algo == "das" else "bin pipeline",
+                         "kernel_ms": ms_kernel, "call_ms": ms_call, "algorithmic_bytes_per_frame": bpf,
+                         "frames_per_launch": units_per_launch, "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
+        }
+        if not args.no_cpu and args.cpu_frames > 0:
+            out["cpu_baseline"] = cpu_baseline(args.algo, M, args.cpu_frames)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -165,10 +165,12 @@ int bf_set_state(bf_handle *h, const void *blob_host, size_t size);
 /* Back to the reference's cold start (zeroed rings/tails/history). */
 int bf_reset(bf_handle *h);
 
-/* Kernel-only timing hook for bench.py: runs bf_process_batch_device `iters`
- * times between two hipEvents on `hip_stream`; returns mean ms per call. */
+/* Timing hook for bench.py: runs bf_process_batch_device `iters` times between
+ * two hipEvents recorded on `hip_stream` (mean ms per call -> *ms_per_call) and,
+ * when ms_kernel != NULL, brackets every launch of the dominant kernel with its
+ * own event pair on the same stream (mean ms per launch -> *ms_kernel). */
 int bf_time_batch_device(bf_handle *h, const float *x_dev, size_t n_frames, float *y_dev, void *hip_stream,
-                         int iters, float *ms_per_call);
+                         int iters, float *ms_per_call, float *ms_kernel);
 
 #ifdef __cplusplus
 }
