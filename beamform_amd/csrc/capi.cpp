@@ -41,9 +41,9 @@ struct bf_handle {
     int gains_cur = 0;
     f32x2 *d_twiddle = nullptr;
     float *d_window = nullptr;
-    float *d_hist = nullptr;  // the hop before the next frame (the reference's ring buffer content)
+    float *d_hist[2] = {nullptr, nullptr};  // the hop before the next frame (the reference's ring buffer content)
     float *d_tail[2] = {nullptr, nullptr};
-    int tail_cur = 0;
+    int tail_cur = 0;  // index of the valid hist/tail pair; the kernel writes the other one
     f32x2 *d_sdump = nullptr;
     size_t sdump_cap = 0;
 
@@ -131,7 +131,8 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
 
     DasFusedArgs a;
     a.x = x_dev;
-    a.hist = h->d_hist;
+    a.hist_in = h->d_hist[h->tail_cur];
+    a.hist_out = h->d_hist[h->tail_cur ^ 1];
     a.y = y_dev;
     a.tail_in = h->d_tail[h->tail_cur];
     a.tail_out = h->d_tail[h->tail_cur ^ 1];
@@ -158,16 +159,6 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     if (k1) BF_HIP(h, hipEventRecord(k1, s));
     h->tail_cur ^= 1;
 
-    // ring-buffer carry: keep the last hop of every mic for the next call (util.h:305-308)
-    if (layout == BF_PLANAR) {
-        BF_HIP(h, hipMemcpy2DAsync(h->d_hist, (size_t)h->H * sizeof(float), x_dev + (F - 1) * h->H,
-                                   (size_t)mic_stride * sizeof(float), (size_t)h->H * sizeof(float), (size_t)S * h->M,
-                                   hipMemcpyDeviceToDevice, s));
-    } else {
-        BF_HIP(h, hipMemcpy2DAsync(h->d_hist, (size_t)h->H * h->M * sizeof(float), x_dev + (F - 1) * (long)h->H * h->M,
-                                   (size_t)F * h->H * h->M * sizeof(float), (size_t)h->H * h->M * sizeof(float), (size_t)S,
-                                   hipMemcpyDeviceToDevice, s));
-    }
     if (spectrum_dev) BF_HIP(h, launch_das_hermitian_dump(h->d_sdump, (f64x2 *)spectrum_dev, (long)S * F, s));
     return BF_OK;
 }
@@ -291,7 +282,8 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
         for (int i = 0; i < h->N; ++i) hf[i] = (float)hd[i];
         BF_CREATE_HIP(hipMalloc((void **)&h->d_window, hf.size() * sizeof(float)));
         BF_CREATE_HIP(hipMemcpy(h->d_window, hf.data(), hf.size() * sizeof(float), hipMemcpyHostToDevice));
-        BF_CREATE_HIP(hipMalloc((void **)&h->d_hist, S * h->M * h->H * sizeof(float)));
+        BF_CREATE_HIP(hipMalloc((void **)&h->d_hist[0], S * h->M * h->H * sizeof(float)));
+        BF_CREATE_HIP(hipMalloc((void **)&h->d_hist[1], S * h->M * h->H * sizeof(float)));
         BF_CREATE_HIP(hipMalloc((void **)&h->d_tail[0], S * h->H * sizeof(float)));
         BF_CREATE_HIP(hipMalloc((void **)&h->d_tail[1], S * h->H * sizeof(float)));
     } else {
@@ -325,10 +317,10 @@ void bf_destroy(bf_handle *h) {
     for (int i = 0; i < 2; ++i) {
         if (h->d_gains[i]) (void)hipFree(h->d_gains[i]);
         if (h->d_tail[i]) (void)hipFree(h->d_tail[i]);
+        if (h->d_hist[i]) (void)hipFree(h->d_hist[i]);
     }
     if (h->d_twiddle) (void)hipFree(h->d_twiddle);
     if (h->d_window) (void)hipFree(h->d_window);
-    if (h->d_hist) (void)hipFree(h->d_hist);
     if (h->d_sdump) (void)hipFree(h->d_sdump);
     if (h->d_x) (void)hipFree(h->d_x);
     if (h->d_y) (void)hipFree(h->d_y);
@@ -345,7 +337,8 @@ int bf_reset(bf_handle *h) {
     const size_t S = h->n_streams;
     if (uses_fused_das(h)) {
         // prepare_overlap_and_add: ring pre-filled with one hop of zeros, out_buff calloc'ed (util.h:272-286)
-        BF_HIP(h, hipMemset(h->d_hist, 0, S * h->M * h->H * sizeof(float)));
+        BF_HIP(h, hipMemset(h->d_hist[0], 0, S * h->M * h->H * sizeof(float)));
+        BF_HIP(h, hipMemset(h->d_hist[1], 0, S * h->M * h->H * sizeof(float)));
         BF_HIP(h, hipMemset(h->d_tail[0], 0, S * h->H * sizeof(float)));
         BF_HIP(h, hipMemset(h->d_tail[1], 0, S * h->H * sizeof(float)));
         h->tail_cur = 0;
@@ -491,7 +484,7 @@ int bf_get_state(bf_handle *h, void *blob, size_t size) {
     char *p = (char *)blob + sizeof(hd);
     if (uses_fused_das(h)) {
         const size_t hb = (size_t)h->n_streams * h->M * h->H * sizeof(float), tb = (size_t)h->n_streams * h->H * sizeof(float);
-        BF_HIP(h, hipMemcpy(p, h->d_hist, hb, hipMemcpyDeviceToHost));
+        BF_HIP(h, hipMemcpy(p, h->d_hist[h->tail_cur], hb, hipMemcpyDeviceToHost));
         BF_HIP(h, hipMemcpy(p + hb, h->d_tail[h->tail_cur], tb, hipMemcpyDeviceToHost));
         return BF_OK;
     }
@@ -511,7 +504,7 @@ int bf_set_state(bf_handle *h, const void *blob, size_t size) {
     const char *p = (const char *)blob + sizeof(hd);
     if (uses_fused_das(h)) {
         const size_t hb = (size_t)h->n_streams * h->M * h->H * sizeof(float), tb = (size_t)h->n_streams * h->H * sizeof(float);
-        BF_HIP(h, hipMemcpy(h->d_hist, p, hb, hipMemcpyHostToDevice));
+        BF_HIP(h, hipMemcpy(h->d_hist[h->tail_cur], p, hb, hipMemcpyHostToDevice));
         BF_HIP(h, hipMemcpy(h->d_tail[h->tail_cur], p + hb, tb, hipMemcpyHostToDevice));
         return BF_OK;
     }

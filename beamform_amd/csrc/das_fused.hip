@@ -8,17 +8,22 @@
 //   fftw_execute(y_inverse)        das.cpp:66       -> one complex IFFT-1024, real part kept
 //   overlap_and_add_prepare_output util.h:244-253   1/N (folded into D) and synthesis window
 //   out = prev[H+n] + cur[n]       util.h:301-302   overlap-add, tail kept in registers
+//   ring advance / buffer swap     util.h:305-313   last hop + tail written back as carried state
 //
 // Mapping: a 32-lane half-wavefront owns a run of consecutive frames of one
 // stream; each lane holds 32 complex points in VGPRs (fft1024.hpp).  The two
 // halves of a wavefront work on different frame runs, so no cross-lane traffic
-// exists outside the per-FFT LDS transpose, and there is no workgroup barrier in
+// exists outside the per-FFT LDS transpose and there is no workgroup barrier in
 // the main loop.  The first frame of every run is recomputed (not stored) to
 // obtain the overlap tail; run 0 of a stream takes it from the carried state.
 //
-// Bound: HBM stream of M*H*4 B in + H*4 B out per frame at >= 40 % of 8 TB/s
-// needs ~50 % of the fp32 VALU peak for the 5 FFTs per frame; LDS carries one
-// 8.5 KiB transpose per FFT plus the 8 KiB twiddle table reads.
+// LDS (one 512-thread block per CU, 16 half-wavefronts):
+//   8 KiB inter-pass twiddles + 16 x 4.5 KiB plane-split transpose buffers
+//   + 4.5 KiB window ([lane][j]) + 8 KiB x ceil(M/2) pair gains  (118 KiB at M = 8)
+// so the only global traffic in the loop is the input stream and the output hop.
+//
+// Bound: HBM stream of M*H*4 B in + H*4 B out per frame; at >= 40 % of 8 TB/s the
+// 5 FFT-1024 per frame need about half of the fp32 VALU peak.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -32,30 +37,40 @@ namespace {
 
 constexpr int kBlock = 512;
 constexpr int kHalves = kBlock / 32;
-constexpr int kRS = tr_stride<float>::value;
+constexpr int kPS = plane_stride<float>::value;  // 36
 constexpr int kHop = 512;
 constexpr int kNfft = 1024;
-constexpr int kWinStride = 36;  // floats per lane row: 144 B keeps ds_read_b128 groups conflict-free
+constexpr int kLdsTw = 2048;                 // floats
+constexpr int kLdsPlane = 32 * kPS;          // floats per half-wavefront
+constexpr int kLdsWin = 32 * kPS;            // floats
+constexpr int kLdsFixed = kLdsTw + kHalves * kLdsPlane + kLdsWin;
 
-// ABL: timing-only ablation bits (outputs are wrong when != 0): 1 = no gain loads, 2 = no input loads, 4 = no LDS transpose
-template <int LAYOUT, int ABL = 0>
+// NPL = number of pair-gain tables held in LDS (0: read gains from global memory)
+template <int LAYOUT, int NPL, bool PREFETCH = false>
 __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
-    // one LDS object: [twiddles 1024][16 transpose buffers][window 32 lanes x 36]
-    __shared__ __attribute__((aligned(16))) cx<float> lds[1024 + kHalves * 32 * kRS + (32 * kWinStride) / 2];
-    cx<float> *s_tw = lds;
-    float *s_win = reinterpret_cast<float *>(lds + 1024 + kHalves * 32 * kRS);
+    __shared__ __attribute__((aligned(16))) float lds[kLdsFixed + NPL * 2048];
+    const cx<float> *s_tw = reinterpret_cast<const cx<float> *>(lds);
+    float *s_win = lds + kLdsTw + kHalves * kLdsPlane;
+    const cx<float> *s_gain = reinterpret_cast<const cx<float> *>(lds + kLdsFixed);
+
     const int tid = threadIdx.x;
     const int lane = tid & 31;
     const int hw = tid >> 5;
-    cx<float> *buf = lds + 1024 + hw * (32 * kRS);
+    float *pbuf = lds + kLdsTw + hw * kLdsPlane;
+    const int M = a.n_mics;
+    const int n_pairs = (M + 1) >> 1;
 
-    for (int i = tid; i < 1024; i += kBlock) {
-        const f32x2 w = a.twiddle[i];
-        s_tw[i] = cx<float>{w.x, w.y};
+    {
+        const float *twf = reinterpret_cast<const float *>(a.twiddle);
+        for (int i = tid; i < kLdsTw; i += kBlock) lds[i] = twf[i];
+        for (int i = tid; i < kNfft; i += kBlock) s_win[(i & 31) * kPS + (i >> 5)] = a.window[i];  // [lane][j]
+        if (NPL > 0) {
+            const float *gf = reinterpret_cast<const float *>(a.gains);
+            for (int i = tid; i < n_pairs * 2048; i += kBlock) lds[kLdsFixed + i] = gf[i];
+        }
     }
-    for (int i = tid; i < 1024; i += kBlock) s_win[(i & 31) * kWinStride + (i >> 5)] = a.window[i];  // [lane][j]
     __syncthreads();
-    const float4 *wrow = reinterpret_cast<const float4 *>(s_win + lane * kWinStride);
+    const float4 *wrow = reinterpret_cast<const float4 *>(s_win + lane * kPS);
 
     const long chunk = (long)blockIdx.x * kHalves + hw;
     int stream = (int)(chunk / a.chunks_per_stream);
@@ -63,11 +78,9 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
     const bool chunk_ok = stream < a.n_streams;
     if (!chunk_ok) stream = a.n_streams - 1;  // keep addresses valid; stores are predicated
     const long t0 = c_in_s * a.frames_per_chunk;
-    const int M = a.n_mics;
-    const int n_pairs = (M + 1) >> 1;
 
     const float *xs = a.x + (long)stream * a.stream_stride_x;
-    const float *hs = a.hist + (long)stream * M * kHop;
+    const float *hs = a.hist_in + (long)stream * M * kHop;
     float *ys = a.y + (long)stream * a.n_frames * kHop;
 
     float tail[16];
@@ -75,78 +88,89 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
     for (int q = 0; q < 16; ++q) tail[q] = 0.f;
 
     float re[32], im[32], Sr[32], Si[32];
+    float xa[32], xb[32];  // raw samples of the NEXT pair, in flight while the current pair is transformed
+
+    // frame index handled at loop step `it` (step 0 = warm-up frame), clamped into the batch
+    auto frame_of = [&](int it) -> long {
+        long t = t0 - 1 + it;
+        if (t < 0) t = 0;
+        if (t > a.n_frames - 1) t = a.n_frames - 1;
+        return t;
+    };
+    auto issue_loads = [&](long tc, int p) {
+        const int ma = 2 * p;
+        const int mb = (2 * p + 1 < M) ? 2 * p + 1 : ma;
+        if (LAYOUT == 0) {
+            const float *a1 = (tc >= 1 ? xs + (long)ma * a.mic_stride + (tc - 1) * kHop : hs + ma * kHop) + lane;
+            const float *b1 = (tc >= 1 ? xs + (long)mb * a.mic_stride + (tc - 1) * kHop : hs + mb * kHop) + lane;
+            const float *a2 = xs + (long)ma * a.mic_stride + tc * kHop + lane;
+            const float *b2 = xs + (long)mb * a.mic_stride + tc * kHop + lane;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                xa[j] = a1[32 * j];
+                xb[j] = b1[32 * j];
+                xa[j + 16] = a2[32 * j];
+                xb[j + 16] = b2[32 * j];
+            }
+        } else {
+            const float *s1 = (tc >= 1 ? xs + (tc - 1) * (long)kHop * M : hs) + (long)lane * M;
+            const float *s2 = xs + tc * (long)kHop * M + (long)lane * M;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                xa[j] = s1[(long)32 * j * M + ma];
+                xb[j] = s1[(long)32 * j * M + mb];
+                xa[j + 16] = s2[(long)32 * j * M + ma];
+                xb[j + 16] = s2[(long)32 * j * M + mb];
+            }
+        }
+    };
+
+    if (PREFETCH) issue_loads(frame_of(0), 0);
 
     for (int it = 0; it <= a.frames_per_chunk; ++it) {
         const long t = t0 - 1 + it;  // it == 0: warm-up frame (overlap tail only)
         const bool store = chunk_ok && it > 0 && t < a.n_frames;
-        long tc = t < 0 ? 0 : t;
-        if (tc > a.n_frames - 1) tc = a.n_frames - 1;
 
         for (int p = 0; p < n_pairs; ++p) {
-            const int ma = 2 * p;
-            const bool b_ok = (2 * p + 1) < M;
-            const int mb = b_ok ? 2 * p + 1 : ma;
-            const float bscale = b_ok ? 1.f : 0.f;
-            if (ABL & 2) {
-#pragma unroll
-                for (int j = 0; j < 32; ++j) {
-                    re[j] = (float)(j + lane) * 1e-3f + (float)tc;
-                    im[j] = (float)(j - lane) * 1e-3f;
-                }
-            } else if (LAYOUT == 0) {
-                const float *a1 = (tc >= 1 ? xs + (long)ma * a.mic_stride + (tc - 1) * kHop : hs + ma * kHop) + lane;
-                const float *b1 = (tc >= 1 ? xs + (long)mb * a.mic_stride + (tc - 1) * kHop : hs + mb * kHop) + lane;
-                const float *a2 = xs + (long)ma * a.mic_stride + tc * kHop + lane;
-                const float *b2 = xs + (long)mb * a.mic_stride + tc * kHop + lane;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    re[j] = a1[32 * j];
-                    im[j] = b1[32 * j];
-                    re[j + 16] = a2[32 * j];
-                    im[j + 16] = b2[32 * j];
-                }
-            } else {
-                const float *s1 = (tc >= 1 ? xs + (tc - 1) * (long)kHop * M : hs) + (long)lane * M;
-                const float *s2 = xs + tc * (long)kHop * M + (long)lane * M;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    re[j] = s1[(long)32 * j * M + ma];
-                    im[j] = s1[(long)32 * j * M + mb];
-                    re[j + 16] = s2[(long)32 * j * M + ma];
-                    im[j + 16] = s2[(long)32 * j * M + mb];
-                }
-            }
+            const float bscale = (2 * p + 1 < M) ? 1.f : 0.f;
+            if (!PREFETCH) issue_loads(frame_of(it), p);
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const float4 hv = wrow[g];
-                re[4 * g + 0] *= hv.x; im[4 * g + 0] *= hv.x * bscale;
-                re[4 * g + 1] *= hv.y; im[4 * g + 1] *= hv.y * bscale;
-                re[4 * g + 2] *= hv.z; im[4 * g + 2] *= hv.z * bscale;
-                re[4 * g + 3] *= hv.w; im[4 * g + 3] *= hv.w * bscale;
+                re[4 * g + 0] = xa[4 * g + 0] * hv.x; im[4 * g + 0] = xb[4 * g + 0] * (hv.x * bscale);
+                re[4 * g + 1] = xa[4 * g + 1] * hv.y; im[4 * g + 1] = xb[4 * g + 1] * (hv.y * bscale);
+                re[4 * g + 2] = xa[4 * g + 2] * hv.z; im[4 * g + 2] = xb[4 * g + 2] * (hv.z * bscale);
+                re[4 * g + 3] = xa[4 * g + 3] * hv.w; im[4 * g + 3] = xb[4 * g + 3] * (hv.w * bscale);
+            }
+            // prefetch the next pair (same frame) or pair 0 of the next frame
+            if (PREFETCH) {
+                if (p + 1 < n_pairs)
+                    issue_loads(frame_of(it), p + 1);
+                else if (it < a.frames_per_chunk)
+                    issue_loads(frame_of(it + 1), 0);
             }
 
-            if (ABL & 4) {
-                fft32_dif<float, -1>(re, im);
-                fft32_dif<float, -1>(re, im);
-            } else {
-                fft1024_fwd_a<float>(re, im, lane, s_tw, buf);
-                __builtin_amdgcn_wave_barrier();
-                fft1024_fwd_b<float>(re, im, lane, buf);
-                __builtin_amdgcn_wave_barrier();
-            }
+            fft1024p_fwd_A<float>(re, im, lane, s_tw, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_B<float>(re, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_C<float, false>(im, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_D<float, -1>(re, im, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
 
-            const f32x2 *gp = a.gains + (long)p * 1024 + lane;
+            const cx<float> *gp = (NPL > 0 ? s_gain : reinterpret_cast<const cx<float> *>(a.gains)) + (long)p * 1024 + lane;
             if (p == 0) {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
-                    const f32x2 g = (ABL & 1) ? f32x2{0.5f + i, 0.25f} : gp[32 * i];
+                    const cx<float> g = gp[32 * i];
                     Sr[i] = g.x * re[i] - g.y * im[i];
                     Si[i] = g.x * im[i] + g.y * re[i];
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
-                    const f32x2 g = (ABL & 1) ? f32x2{0.5f + i, 0.25f} : gp[32 * i];
+                    const cx<float> g = gp[32 * i];
                     Sr[i] += g.x * re[i] - g.y * im[i];
                     Si[i] += g.x * im[i] + g.y * re[i];
                 }
@@ -159,15 +183,14 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             for (int i = 0; i < 32; ++i) sd[32 * brev5(i)] = f32x2{Sr[i], Si[i]};
         }
 
-        if (ABL & 4) {
-            fft32_dit<float, +1>(Sr, Si);
-            fft32_dif<float, +1>(Sr, Si);
-        } else {
-            fft1024_inv_a<float>(Sr, Si, lane, s_tw, buf);
-            __builtin_amdgcn_wave_barrier();
-            fft1024_inv_b<float>(Sr, Si, lane, buf);
-            __builtin_amdgcn_wave_barrier();
-        }
+        fft1024p_inv_A<float>(Sr, Si, lane, s_tw, pbuf);
+        __builtin_amdgcn_wave_barrier();
+        fft1024p_B<float>(Sr, lane, pbuf);
+        __builtin_amdgcn_wave_barrier();
+        fft1024p_C<float, true>(Si, lane, pbuf);
+        __builtin_amdgcn_wave_barrier();
+        fft1024p_D<float, +1>(Sr, Si, lane, pbuf);
+        __builtin_amdgcn_wave_barrier();
 
         // position i holds sample n = 32*brev5(i) + lane; even i -> first half, odd i -> n + 512
         float h[32];
@@ -190,9 +213,18 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             for (int q = 0; q < 16; ++q) tail[q] = ti[32 * brev5(2 * q)];
         }
         if (store && t == a.n_frames - 1) {
+            // carried state for the next call: OLA tail (out_buff[0]) and the last input hop (ring buffer)
             float *to = a.tail_out + (long)stream * kHop + lane;
 #pragma unroll
             for (int q = 0; q < 16; ++q) to[32 * brev5(2 * q)] = tail[q];
+            float *ho = a.hist_out + (long)stream * M * kHop;
+            if (LAYOUT == 0) {
+                for (int m = 0; m < M; ++m)
+                    for (int j = 0; j < 16; ++j)
+                        ho[m * kHop + 32 * j + lane] = xs[(long)m * a.mic_stride + t * kHop + 32 * j + lane];
+            } else {
+                for (int j = 0; j < 16 * M; ++j) ho[32 * j + lane] = xs[t * (long)kHop * M + 32 * j + lane];
+            }
         }
     }
 }
@@ -208,27 +240,36 @@ __global__ void das_hermitian_dump_kernel(const f32x2 *s, f64x2 *out, long total
     out[idx] = f64x2{0.5 * kNfft * ((double)u.x + (double)v.x), 0.5 * kNfft * ((double)u.y - (double)v.y)};
 }
 
+template <int LAYOUT>
+void launch_layout(const DasFusedArgs &a, unsigned blocks, hipStream_t stream) {
+    const int np = (a.n_mics + 1) / 2;
+    // BF_DAS_PREFETCH=1 selects the register-prefetch build (slower today: it spills at 256 VGPRs)
+    static const bool pf = getenv("BF_DAS_PREFETCH") && atoi(getenv("BF_DAS_PREFETCH")) != 0;
+    if (pf && np <= 4) {
+        hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 4, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
+        return;
+    }
+    if (np <= 1)
+        hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 1>), dim3(blocks), dim3(kBlock), 0, stream, a);
+    else if (np <= 2)
+        hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 2>), dim3(blocks), dim3(kBlock), 0, stream, a);
+    else if (np <= 4)
+        hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 4>), dim3(blocks), dim3(kBlock), 0, stream, a);
+    else if (np <= 8)
+        hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 8>), dim3(blocks), dim3(kBlock), 0, stream, a);
+    else  // > 16 mics: the gain tables no longer fit beside the transpose buffers
+        hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 0>), dim3(blocks), dim3(kBlock), 0, stream, a);
+}
+
 }  // namespace
 
 hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t stream) {
     const long chunks = (long)a.chunks_per_stream * a.n_streams;
     const unsigned blocks = (unsigned)((chunks + kHalves - 1) / kHalves);
-    static const int abl = getenv("BF_ABLATE") ? atoi(getenv("BF_ABLATE")) : 0;
-    if (abl && a.layout == 0) {
-        switch (abl) {
-            case 1: hipLaunchKernelGGL((das_fused_kernel<0, 1>), dim3(blocks), dim3(kBlock), 0, stream, a); break;
-            case 2: hipLaunchKernelGGL((das_fused_kernel<0, 2>), dim3(blocks), dim3(kBlock), 0, stream, a); break;
-            case 3: hipLaunchKernelGGL((das_fused_kernel<0, 3>), dim3(blocks), dim3(kBlock), 0, stream, a); break;
-            case 4: hipLaunchKernelGGL((das_fused_kernel<0, 4>), dim3(blocks), dim3(kBlock), 0, stream, a); break;
-            case 7: hipLaunchKernelGGL((das_fused_kernel<0, 7>), dim3(blocks), dim3(kBlock), 0, stream, a); break;
-            default: break;
-        }
-        return hipGetLastError();
-    }
     if (a.layout == 0)
-        hipLaunchKernelGGL(das_fused_kernel<0>, dim3(blocks), dim3(kBlock), 0, stream, a);
+        launch_layout<0>(a, blocks, stream);
     else
-        hipLaunchKernelGGL(das_fused_kernel<1>, dim3(blocks), dim3(kBlock), 0, stream, a);
+        launch_layout<1>(a, blocks, stream);
     return hipGetLastError();
 }
 

@@ -108,4 +108,76 @@ BF_HD void fft1024_inv_b(T (&re)[32], T (&im)[32], int lane, const cx<T> *buf) {
     fft32_dif<T, +1>(re, im);
 }
 
+// ---- plane-split variant ------------------------------------------------------
+// Same transform, but the transpose moves the real plane and then the imaginary
+// plane through ONE scalar buffer of 32 x plane_stride elements: half the LDS
+// footprint per half-wavefront (which is what lets the gain/twiddle/window tables
+// live in LDS as well).  Four phases; on the GPU a wavefront runs them back to
+// back (LDS ops of one wave execute in order), the CPU emulation runs each phase
+// for all 32 lanes before the next.
+template <typename T>
+struct plane_stride;
+template <>
+struct plane_stride<float> {
+    static constexpr int value = 36;  // 144 B rows: 16-lane ds_read_b128 groups hit distinct banks
+};
+template <>
+struct plane_stride<double> {
+    static constexpr int value = 34;  // 272 B rows
+};
+
+// phase A (forward): 32-pt DIF, inter-pass twiddle, real plane out
+template <typename T>
+BF_HD void fft1024p_fwd_A(T (&re)[32], T (&im)[32], int lane, const cx<T> *tw, T *pbuf) {
+    constexpr int PS = plane_stride<T>::value;
+    fft32_dif<T, -1>(re, im);
+#pragma unroll
+    for (int i = 1; i < 32; ++i) {
+        const int k1 = brev5(i);
+        const cx<T> w = tw[k1 * 32 + lane];
+        const T xr = re[i], xi = im[i];
+        re[i] = xr * w.x - xi * w.y;
+        im[i] = xr * w.y + xi * w.x;
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) pbuf[brev5(i) * PS + lane] = re[i];
+}
+// phase A (backward): 32-pt DIT (bit-reversed in, natural out), conj twiddle, real plane out
+template <typename T>
+BF_HD void fft1024p_inv_A(T (&re)[32], T (&im)[32], int lane, const cx<T> *tw, T *pbuf) {
+    constexpr int PS = plane_stride<T>::value;
+    fft32_dit<T, +1>(re, im);
+#pragma unroll
+    for (int n2 = 1; n2 < 32; ++n2) {
+        const cx<T> w = tw[n2 * 32 + lane];
+        const T xr = re[n2], xi = im[n2];
+        re[n2] = xr * w.x + xi * w.y;
+        im[n2] = xi * w.x - xr * w.y;
+    }
+#pragma unroll
+    for (int n2 = 0; n2 < 32; ++n2) pbuf[n2 * PS + lane] = re[n2];
+}
+// phase B: real plane in (row `lane`)
+template <typename T>
+BF_HD void fft1024p_B(T (&re)[32], int lane, const T *pbuf) {
+    constexpr int PS = plane_stride<T>::value;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) re[c] = pbuf[lane * PS + c];
+}
+// phase C: imaginary plane out; `natural` selects the register->row map of the phase-A that ran
+template <typename T, bool NATURAL>
+BF_HD void fft1024p_C(const T (&im)[32], int lane, T *pbuf) {
+    constexpr int PS = plane_stride<T>::value;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) pbuf[(NATURAL ? i : brev5(i)) * PS + lane] = im[i];
+}
+// phase D: imaginary plane in, second 32-pt DIF (DIR = -1 forward, +1 backward)
+template <typename T, int DIR>
+BF_HD void fft1024p_D(T (&re)[32], T (&im)[32], int lane, const T *pbuf) {
+    constexpr int PS = plane_stride<T>::value;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) im[c] = pbuf[lane * PS + c];
+    fft32_dif<T, DIR>(re, im);
+}
+
 }  // namespace bf

@@ -10,7 +10,8 @@ namespace bf {
 // ---- fused fp32 DAS (das_fused.hip) ------------------------------------------
 struct DasFusedArgs {
     const float *x;        // input samples, layout per `layout`
-    const float *hist;     // [stream][mic][hop] (planar) or [stream][hop][mic]: the hop before frame 0
+    const float *hist_in;  // [stream][mic][hop] (planar) or [stream][hop][mic]: the hop before frame 0
+    float *hist_out;       // same layout: the last hop of this batch (ring-buffer carry, util.h:305-308)
     float *y;              // [stream][n_frames*hop]
     const float *tail_in;  // [stream][hop] second half of the frame before frame 0 (out_buff[0], util.h:302)
     float *tail_out;       // [stream][hop] second half of the last frame of this batch
