@@ -1,0 +1,507 @@
+// pipeline_kernels.hip -- gfx950 kernels of the fp64 bin pipeline (see pipeline.hip).
+#include "pipeline_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include "fft1024.hpp"
+
+namespace bf {
+
+namespace {
+
+constexpr int kHop = 512;
+constexpr int kN = 1024;
+constexpr int kPSd = plane_stride<double>::value;  // 34
+
+// ---- tiny complex helpers (double) ---------------------------------------------------
+struct cd {
+    double x, y;
+};
+__device__ __forceinline__ cd mk(double x, double y) { return cd{x, y}; }
+__device__ __forceinline__ cd operator+(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cd operator-(cd a, cd b) { return cd{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cd operator*(cd a, cd b) { return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ cd operator*(cd a, double s) { return cd{a.x * s, a.y * s}; }
+__device__ __forceinline__ cd conj(cd a) { return cd{a.x, -a.y}; }
+__device__ __forceinline__ double norm2(cd a) { return a.x * a.x + a.y * a.y; }
+__device__ __forceinline__ double cabs(cd a) { return hypot(a.x, a.y); }
+__device__ __forceinline__ cd cdiv(cd a, cd b) {
+    // Smith's algorithm, as libstdc++/libgcc __divdc3 do for finite operands
+    if (fabs(b.x) >= fabs(b.y)) {
+        const double r = b.y / b.x, d = b.x + b.y * r;
+        return cd{(a.x + a.y * r) / d, (a.y - a.x * r) / d};
+    }
+    const double r = b.x / b.y, d = b.x * r + b.y;
+    return cd{(a.x * r + a.y) / d, (a.y * r - a.x) / d};
+}
+__device__ __forceinline__ cd ld(const f64x2 *p) {
+    const f64x2 v = *p;
+    return cd{v.x, v.y};
+}
+
+// problem index -> FFT bin whose packed spectrum is read, and whether X must be conjugated
+__device__ __forceinline__ int q_src_bin(int q) { return q == 513 ? 511 : q; }
+__device__ __forceinline__ int q_bin(int q) { return q; }
+
+// X_m for problem q out of the packed pair spectra of one frame (Zf = [NP][1024]).
+template <int MP>
+__device__ __forceinline__ void load_X(const f64x2 *Zf, int q, int M, cd (&X)[MP]) {
+    const int k = q_src_bin(q);
+    const int kn = (kN - k) & (kN - 1);
+#pragma unroll
+    for (int p = 0; p < MP / 2; ++p) {
+        if (2 * p < M) {
+            const cd z = ld(Zf + p * kN + k);
+            const cd zc = conj(ld(Zf + p * kN + kn));
+            cd xa = (z + zc) * 0.5;                 // (Z[k] + conj Z[N-k]) / 2
+            const cd d = z - zc;                    // (Z[k] - conj Z[N-k]) / (2i) = -i/2 * d
+            cd xb = cd{0.5 * d.y, -0.5 * d.x};
+            if (q == 513) {
+                xa = conj(xa);
+                xb = conj(xb);
+            }
+            X[2 * p] = xa;
+            X[2 * p + 1] = xb;
+        } else {
+            X[2 * p] = cd{0, 0};
+            X[2 * p + 1] = cd{0, 0};
+        }
+    }
+}
+
+// ======================================================================================
+//                                        STFT
+// ======================================================================================
+constexpr int kStftBlock = 256;
+constexpr int kStftHalves = kStftBlock / 32;
+
+template <int LAYOUT>
+__global__ __launch_bounds__(kStftBlock) void stft_kernel(StftArgs a) {
+    __shared__ __attribute__((aligned(16))) double lds[2048 + kStftHalves * 32 * kPSd + 32 * kPSd];
+    const cx<double> *s_tw = reinterpret_cast<const cx<double> *>(lds);
+    double *s_win = lds + 2048 + kStftHalves * 32 * kPSd;
+    const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
+    double *pbuf = lds + 2048 + hw * 32 * kPSd;
+    {
+        const double *twf = reinterpret_cast<const double *>(a.tw);
+        for (int i = tid; i < 2048; i += kStftBlock) lds[i] = twf[i];
+        for (int i = tid; i < kN; i += kStftBlock) s_win[(i & 31) * kPSd + (i >> 5)] = a.win[i];
+    }
+    __syncthreads();
+    const int M = a.n_mics, NP = (M + 1) >> 1;
+    const long total = (long)a.n_streams * a.n_frames * NP;
+    const long stride = (long)gridDim.x * kStftHalves;
+    const long rounds = (total + stride - 1) / stride;
+    double re[32], im[32];
+    for (long r = 0; r < rounds; ++r) {
+        long item = r * stride + (long)blockIdx.x * kStftHalves + hw;
+        const bool ok = item < total;
+        if (!ok) item = total - 1;
+        const int p = (int)(item % NP);
+        const long st = item / NP;
+        const long t = st % a.n_frames;
+        const int s = (int)(st / a.n_frames);
+        const float *xs = a.x + (long)s * a.stream_stride_x;
+        const float *hs = a.hist + (long)s * M * kHop;
+        const int ma = 2 * p;
+        const bool b_ok = 2 * p + 1 < M;
+        const int mb = b_ok ? 2 * p + 1 : ma;
+        if (LAYOUT == 0) {
+            const float *a1 = (t >= 1 ? xs + (long)ma * a.mic_stride + (t - 1) * kHop : hs + ma * kHop) + lane;
+            const float *b1 = (t >= 1 ? xs + (long)mb * a.mic_stride + (t - 1) * kHop : hs + mb * kHop) + lane;
+            const float *a2 = xs + (long)ma * a.mic_stride + t * kHop + lane;
+            const float *b2 = xs + (long)mb * a.mic_stride + t * kHop + lane;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                re[j] = (double)a1[32 * j];
+                im[j] = (double)b1[32 * j];
+                re[j + 16] = (double)a2[32 * j];
+                im[j + 16] = (double)b2[32 * j];
+            }
+        } else {
+            const float *s1 = (t >= 1 ? xs + (t - 1) * (long)kHop * M : hs) + (long)lane * M;
+            const float *s2 = xs + t * (long)kHop * M + (long)lane * M;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                re[j] = (double)s1[(long)32 * j * M + ma];
+                im[j] = (double)s1[(long)32 * j * M + mb];
+                re[j + 16] = (double)s2[(long)32 * j * M + ma];
+                im[j + 16] = (double)s2[(long)32 * j * M + mb];
+            }
+        }
+        const double bs = b_ok ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const double h = s_win[lane * kPSd + j];
+            re[j] *= h;          // buf[j]*hann_win[i]  (util.h:235)
+            im[j] *= h * bs;
+        }
+        fft1024p_fwd_A<double>(re, im, lane, s_tw, pbuf);
+        __builtin_amdgcn_wave_barrier();
+        fft1024p_B<double>(re, lane, pbuf);
+        __builtin_amdgcn_wave_barrier();
+        fft1024p_C<double, false>(im, lane, pbuf);
+        __builtin_amdgcn_wave_barrier();
+        fft1024p_D<double, -1>(re, im, lane, pbuf);
+        __builtin_amdgcn_wave_barrier();
+        if (ok) {
+            f64x2 *zo = a.Z + (((long)s * a.frames_ws + a.frame_off + t) * NP + p) * kN + lane;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) zo[32 * brev5(i)] = f64x2{re[i], im[i]};
+        }
+    }
+}
+
+// ======================================================================================
+//                                        ISTFT
+// ======================================================================================
+constexpr int kIstftBlock = 256;
+constexpr int kIstftHalves = kIstftBlock / 32;
+
+// Hermitian part of y_fft at bin k (0..1023) from the per-bin kernels' output row.
+__device__ __forceinline__ cd herm_at(const f64x2 *row, int k) {
+    if (k == 0 || k == 512) return cd{row[k].x, 0.0};
+    if (k == 511) {
+        const cd u = ld(row + 511), v = conj(ld(row + 513));
+        return (u + v) * 0.5;
+    }
+    if (k == 513) {
+        const cd u = ld(row + 513), v = conj(ld(row + 511));
+        return (u + v) * 0.5;
+    }
+    if (k < 512) return ld(row + k);
+    return conj(ld(row + (kN - k)));
+}
+
+__global__ __launch_bounds__(kIstftBlock) void istft_kernel(IstftArgs a, int pairs_per_chunk, int chunks_per_stream) {
+    __shared__ __attribute__((aligned(16))) double lds[2048 + kIstftHalves * 32 * kPSd + 32 * kPSd];
+    const cx<double> *s_tw = reinterpret_cast<const cx<double> *>(lds);
+    double *s_win = lds + 2048 + kIstftHalves * 32 * kPSd;
+    const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
+    double *pbuf = lds + 2048 + hw * 32 * kPSd;
+    {
+        const double *twf = reinterpret_cast<const double *>(a.tw);
+        for (int i = tid; i < 2048; i += kIstftBlock) lds[i] = twf[i];
+        for (int i = tid; i < kN; i += kIstftBlock) s_win[(i & 31) * kPSd + (i >> 5)] = a.win[i];
+    }
+    __syncthreads();
+    const long chunk = (long)blockIdx.x * kIstftHalves + hw;
+    int s = (int)(chunk / chunks_per_stream);
+    const long c_in_s = chunk - (long)s * chunks_per_stream;
+    const bool chunk_ok = s < a.n_streams;
+    if (!chunk_ok) s = a.n_streams - 1;
+    const long t0 = c_in_s * 2L * pairs_per_chunk;  // first frame of this run (even)
+    const f64x2 *Ys = a.Yh + (long)s * a.n_frames * kYhStride;
+    float *ys = a.y + (long)s * a.n_frames * kHop;
+
+    float tail[16];  // second half of the previous frame, as float (out_buff[0], util.h:302)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tail[q] = 0.f;
+    double re[32], im[32];
+
+    for (int it = 0; it <= pairs_per_chunk; ++it) {
+        const long ta = t0 - 2 + 2L * it;  // frames (ta, ta+1); it == 0 is the warm-up pair
+        const bool va = ta >= 0 && ta < a.n_frames;
+        const bool vb = ta + 1 >= 0 && ta + 1 < a.n_frames;
+        const f64x2 *ra = Ys + (va ? ta : 0) * kYhStride;
+        const f64x2 *rb = Ys + (vb ? ta + 1 : 0) * kYhStride;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int k = lane + 32 * brev5(i);
+            cd u = herm_at(ra, k), v = herm_at(rb, k);
+            if (!va) u = cd{0, 0};
+            if (!vb) v = cd{0, 0};
+            re[i] = u.x - v.y;  // Ya + i*Yb
+            im[i] = u.y + v.x;
+        }
+        fft1024p_inv_A<double>(re, im, lane, s_tw, pbuf);
+        __builtin_amdgcn_wave_barrier();
+        fft1024p_B<double>(re, lane, pbuf);
+        __builtin_amdgcn_wave_barrier();
+        fft1024p_C<double, true>(im, lane, pbuf);
+        __builtin_amdgcn_wave_barrier();
+        fft1024p_D<double, +1>(re, im, lane, pbuf);
+        __builtin_amdgcn_wave_barrier();
+
+        // position i: sample n = 32*brev5(i) + lane.  re -> frame ta, im -> frame ta+1.
+        // overlap_and_add_prepare_output (util.h:247-252) with the reference's float stores.
+        float oa[32], ob[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const double h = s_win[lane * kPSd + brev5(i)];
+            float fa = (float)(re[i] / 1024.0);
+            fa = (float)((double)fa * h);
+            float fb = (float)(im[i] / 1024.0);
+            fb = (float)((double)fb * h);
+            if (a.use_post_amp) {  // mvdr.cpp:112-114
+                fa = (float)((double)fa * a.post_amp);
+                fb = (float)((double)fb * a.post_amp);
+            }
+            oa[i] = fa;
+            ob[i] = fb;
+        }
+        const bool st_a = chunk_ok && it > 0 && va;
+        const bool st_b = chunk_ok && it > 0 && vb;
+        if (it == 0 && t0 == 0) {  // stream start: tail comes from the carried state, not from frame -1
+            const float *ti = a.tail_in + (long)s * kHop + lane;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tail[q] = ti[32 * brev5(2 * q)];
+        } else if (it == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tail[q] = ob[2 * q + 1];
+        }
+        if (it > 0) {
+            if (st_a) {
+                float *yo = ys + ta * kHop + lane;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) yo[32 * brev5(2 * q)] = tail[q] + oa[2 * q];
+            }
+            if (st_b) {
+                float *yo = ys + (ta + 1) * kHop + lane;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) yo[32 * brev5(2 * q)] = oa[2 * q + 1] + ob[2 * q];
+            }
+            if (st_a && ta == a.n_frames - 1) {  // odd frame count: the batch ends on frame a
+                float *to = a.tail_out + (long)s * kHop + lane;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) to[32 * brev5(2 * q)] = oa[2 * q + 1];
+            }
+            if (st_b && ta + 1 == a.n_frames - 1) {
+                float *to = a.tail_out + (long)s * kHop + lane;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) to[32 * brev5(2 * q)] = ob[2 * q + 1];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tail[q] = ob[2 * q + 1];
+        }
+    }
+}
+
+// full 1024-bin y_fft dump from the per-problem rows
+__global__ void expand_spectrum_kernel(const f64x2 *Yh, f64x2 *out, long frames_total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= frames_total * kN) return;
+    const long f = idx / kN;
+    const int j = (int)(idx - f * kN);
+    const f64x2 *row = Yh + f * kYhStride;
+    f64x2 v;
+    if (j <= 513) {
+        v = row[j];
+    } else {
+        v = row[kN - j];
+        v.y = -v.y;
+    }
+    out[idx] = v;
+}
+
+// ======================================================================================
+//                         pointwise per-bin kernels: das, phase
+// ======================================================================================
+struct BinCtx {
+    const f64x2 *Zf;   // packed spectra of this frame [NP][1024]
+    const f64x2 *steer;
+    int M, q;
+};
+
+// das.cpp:60-63
+template <int MP>
+__device__ __forceinline__ cd das_bin(const BinCtx &c) {
+    cd X[MP];
+    load_X<MP>(c.Zf, c.q, c.M, X);
+    const int j = q_bin(c.q);
+    cd acc{0, 0};
+#pragma unroll
+    for (int m = 0; m < MP; ++m)
+        if (m < c.M) acc = acc + conj(ld(c.steer + (long)m * kN + j)) * X[m];
+    return cd{acc.x / (double)c.M, acc.y / (double)c.M};
+}
+
+// mean over mic pairs of the wrapped |p_m - p_m'| with the reference's summation order
+// (get_overall_phase_diff, phase.cpp:53-68)
+template <int MP>
+__device__ __forceinline__ double pair_phase_mean(const double (&ph)[MP], int M) {
+    double d[MP];
+#pragma unroll
+    for (int i = 0; i < MP; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < MP; ++k) {
+            if (k > i && k < M) {
+                double r = fabs(ph[i] - ph[k]);
+                if (r > M_PI) r = 2 * M_PI - r;
+                acc += r;
+            }
+        }
+        d[i] = acc;
+    }
+    double tot = 0.0;
+#pragma unroll
+    for (int i = MP - 1; i >= 0; --i)
+        if (i < M - 1) tot = d[i] + tot;
+    const int num = M * (M - 1) / 2;
+    return tot / (double)num;  // 0/0 = NaN when M == 1, as the reference
+}
+
+// phase.cpp:87-127
+template <int MP>
+__device__ __forceinline__ cd phase_bin(const BinCtx &c, const bf_config &cfg) {
+    cd X[MP];
+    load_X<MP>(c.Zf, c.q, c.M, X);
+    const int j = q_bin(c.q);
+    if (j == 0) return X[0];
+    double mag = 0.0;
+#pragma unroll
+    for (int m = 0; m < MP; ++m)
+        if (m < c.M) mag += cabs(X[m]);
+    mag /= (double)c.M;
+    const double pha = atan2(X[0].y, X[0].x);
+    bool keep = false;
+    if (mag / 1024.0 > cfg.mag_threshold) {
+        double ph[MP];
+#pragma unroll
+        for (int m = 0; m < MP; ++m) {
+            if (m < c.M) {
+                const cd u = conj(ld(c.steer + (long)m * kN + j)) * X[m];
+                ph[m] = atan2(u.y, u.x);
+            } else {
+                ph[m] = 0.0;
+            }
+        }
+        const double mean = pair_phase_mean<MP>(ph, c.M);
+        keep = mean < cfg.min_phase * M_PI / 180;
+    }
+    if (!keep) mag *= cfg.mag_mult;
+    return cd{mag * cos(pha), mag * sin(pha)};
+}
+
+template <int MP, int ALGO>
+__global__ __launch_bounds__(256) void pointwise_bins_kernel(BinsArgs a) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)a.n_streams * a.n_frames * kNQ;
+    if (idx >= total) return;
+    const int q = (int)(idx % kNQ);
+    const long st = idx / kNQ;
+    const long t = st % a.n_frames;
+    const int s = (int)(st / a.n_frames);
+    const int NP = (a.n_mics + 1) >> 1;
+    BinCtx c;
+    c.Zf = a.Z + (((long)s * a.frames_ws + a.frame_off + t) * NP) * kN;
+    c.steer = a.steer;
+    c.M = a.n_mics;
+    c.q = q;
+    cd y;
+    if (ALGO == BF_DAS)
+        y = das_bin<MP>(c);
+    else
+        y = phase_bin<MP>(c, a.cfg);
+    a.Yh[((long)s * a.n_frames + t) * kYhStride + q] = f64x2{y.x, y.y};
+}
+
+__global__ void smooth_kernel(const float *yraw, float *y, const double *state, long n, int n_streams, int sz) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n_streams) return;
+    const int s = (int)(idx / n);
+    const long i = idx - (long)s * n;
+    const float *yr = yraw + (long)s * n;
+    const double *st = state + (long)s * 64;  // st[63] = most recent raw sample before this batch
+    double acc = 0.0;
+    for (int k = sz - 1; k >= 0; --k) {  // oldest first, as get_mean() sums past_samples[0..]
+        const long src = i - k;
+        const double v = src >= 0 ? (double)yr[src] : st[64 + src];
+        acc += v;
+    }
+    y[idx] = (float)(acc / (double)sz);
+}
+__global__ void smooth_state_kernel(const float *yraw, double *state, long n, int n_streams) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 64 * n_streams) return;
+    const int s = idx / 64, k = idx % 64;
+    const long src = n - 64 + k;
+    // n >= 512 always (one hop), so the new state is entirely inside this batch
+    state[(long)s * 64 + k] = (double)yraw[(long)s * n + src];
+}
+
+}  // namespace
+
+// ---- launchers ---------------------------------------------------------------------------
+hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
+    const long total = (long)a.n_streams * a.n_frames * ((a.n_mics + 1) / 2);
+    long blocks = (total + kStftHalves - 1) / kStftHalves;
+    const long cap = (long)n_cus * 4;
+    if (blocks > cap) blocks = cap;
+    if (a.layout == 0)
+        hipLaunchKernelGGL(stft_kernel<0>, dim3((unsigned)blocks), dim3(kStftBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL(stft_kernel<1>, dim3((unsigned)blocks), dim3(kStftBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s) {
+    const long pairs = (a.n_frames + 1) / 2;
+    long slots = (long)n_cus * kIstftHalves * 2 / a.n_streams;
+    if (slots < 1) slots = 1;
+    long cps = slots < pairs ? slots : pairs;
+    const long ppc = (pairs + cps - 1) / cps;
+    cps = (pairs + ppc - 1) / ppc;
+    const long chunks = cps * a.n_streams;
+    hipLaunchKernelGGL(istft_kernel, dim3((unsigned)((chunks + kIstftHalves - 1) / kIstftHalves)), dim3(kIstftBlock), 0, s, a,
+                       (int)ppc, (int)cps);
+    return hipGetLastError();
+}
+
+hipError_t launch_smooth(const float *yraw, float *y, double *state, long n_frames, int n_streams, int smooth_size,
+                         hipStream_t s) {
+    const long n = n_frames * kHop;
+    const long total = n * n_streams;
+    hipLaunchKernelGGL(smooth_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, yraw, y, state, n, n_streams,
+                       smooth_size);
+    hipLaunchKernelGGL(smooth_state_kernel, dim3((unsigned)((64 * n_streams + 255) / 256)), dim3(256), 0, s, yraw, state, n,
+                       n_streams);
+    return hipGetLastError();
+}
+
+hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s);
+hipError_t launch_phasempf(const BinsArgs &a, int n_cus, hipStream_t s);
+hipError_t launch_gss(const BinsArgs &a, int n_cus, hipStream_t s);
+
+template <int ALGO>
+static void launch_pointwise(const BinsArgs &a, hipStream_t s) {
+    const long total = (long)a.n_streams * a.n_frames * kNQ;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (a.n_mics <= 4)
+        hipLaunchKernelGGL((pointwise_bins_kernel<4, ALGO>), dim3(blocks), dim3(256), 0, s, a);
+    else if (a.n_mics <= 8)
+        hipLaunchKernelGGL((pointwise_bins_kernel<8, ALGO>), dim3(blocks), dim3(256), 0, s, a);
+    else if (a.n_mics <= 16)
+        hipLaunchKernelGGL((pointwise_bins_kernel<16, ALGO>), dim3(blocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((pointwise_bins_kernel<32, ALGO>), dim3(blocks), dim3(256), 0, s, a);
+}
+
+hipError_t launch_bins(const BinsArgs &a, int n_cus, hipStream_t s) {
+    hipError_t e = hipSuccess;
+    switch (a.cfg.algo) {
+        case BF_DAS: launch_pointwise<BF_DAS>(a, s); e = hipGetLastError(); break;
+        case BF_PHASE: launch_pointwise<BF_PHASE>(a, s); e = hipGetLastError(); break;
+        case BF_MVDR:
+        case BF_LCMV: e = launch_mvdr_lcmv(a, n_cus, s); break;
+        case BF_PHASEMPF: e = launch_phasempf(a, n_cus, s); break;
+        case BF_GSS: e = launch_gss(a, n_cus, s); break;
+        default: e = hipErrorInvalidValue; break;
+    }
+    if (e != hipSuccess) return e;
+    if (a.spectrum) {
+        const long frames = (long)a.n_streams * a.n_frames;
+        hipLaunchKernelGGL(expand_spectrum_kernel, dim3((unsigned)((frames * kN + 255) / 256)), dim3(256), 0, s, a.Yh,
+                           a.spectrum, frames);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+// placeholders until the recursive / matrix kernels land
+hipError_t launch_mvdr_lcmv(const BinsArgs &, int, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_phasempf(const BinsArgs &, int, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_gss(const BinsArgs &, int, hipStream_t) { return hipErrorNotSupported; }
+
+}  // namespace bf

@@ -1,0 +1,63 @@
+// pipeline_kernels.hpp -- argument blocks and launchers of the fp64 bin-pipeline kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/bfcore.h"
+#include "geometry.hpp"
+
+namespace bf {
+
+// Problems per frame handed to the per-bin kernels: q = 0..512 is FFT bin q, q = 513 is bin
+// 513.  Bins 514..1023 are the exact conjugates of bins 510..1 (real input, conjugate-
+// symmetric steering) and are never computed; 511/513 are NOT conjugates of each other
+// because of the reference's frequency-vector quirk Q1 (util.h:198), hence the extra slot.
+constexpr int kNQ = 514;
+constexpr int kYhStride = 516;  // f64x2 per frame in the per-bin output buffer (16-byte friendly)
+constexpr int kMpfVecs = 7;     // S_prev, S_tmp, S_min, lambda_noise, Z, rev0, rev1 (phasempf.cpp:67-76)
+
+struct StftArgs {
+    const float *x;
+    const float *hist;  // hop before frame 0, layout as x
+    f64x2 *Z;           // [stream][frames_ws][NP][1024]
+    const f64x2 *tw;
+    const double *win;
+    long n_frames, frames_ws, frame_off, mic_stride, stream_stride_x;
+    int n_streams, n_mics, layout;
+};
+hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s);
+
+struct BinsArgs {
+    const f64x2 *Z;      // [stream][frames_ws][NP][1024]
+    f64x2 *Yh;           // [stream][n_frames][kYhStride]: y_fft of problems q = 0..513
+    f64x2 *spectrum;     // nullable: [stream][n_frames][1024] full y_fft dump
+    const f64x2 *steer;  // [col][mic][1024]
+    const double *freqs; // [1024]
+    long n_frames, frames_ws, frame_off;
+    int n_streams, n_mics, kp1;
+    bf_config cfg;
+    f64x2 *gssW;         // [stream][1024][kp1][n_mics]
+    double *mpf;         // [stream][kMpfVecs*1024 + 8]
+    int gss_reset;
+};
+hipError_t launch_bins(const BinsArgs &a, int n_cus, hipStream_t s);
+
+struct IstftArgs {
+    const f64x2 *Yh;
+    float *y;              // [stream][n_frames*512]
+    const float *tail_in;  // [stream][512]
+    float *tail_out;
+    const f64x2 *tw;
+    const double *win;
+    long n_frames;
+    int n_streams;
+    double post_amp;
+    int use_post_amp;
+};
+hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s);
+
+// phasempf.cpp:331-334: moving average over the output samples, state = last 63 raw samples
+hipError_t launch_smooth(const float *yraw, float *y, double *state, long n_frames, int n_streams, int smooth_size,
+                         hipStream_t s);
+
+}  // namespace bf
