@@ -205,40 +205,55 @@ __global__ __launch_bounds__(kIstftBlock) void istft_kernel(IstftArgs a, int pai
         const bool vb = ta + 1 >= 0 && ta + 1 < a.n_frames;
         const f64x2 *ra = Ys + (va ? ta : 0) * kYhStride;
         const f64x2 *rb = Ys + (vb ? ta + 1 : 0) * kYhStride;
+        float oa[32], ob[32];
+        // Two frames share one complex IFFT (Ya + i*Yb -> re = frame a, im = frame b).  A frame the
+        // reference turns into NaN/Inf (mvdr/lcmv: inverse of an all-zero covariance) would
+        // poison its partner through the shared transform, so such pairs are transformed one at a time.
+        bool bad = false;
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
             const int k = lane + 32 * brev5(i);
-            cd u = herm_at(ra, k), v = herm_at(rb, k);
-            if (!va) u = cd{0, 0};
-            if (!vb) v = cd{0, 0};
-            re[i] = u.x - v.y;  // Ya + i*Yb
-            im[i] = u.y + v.x;
+            const cd u = herm_at(ra, k), v = herm_at(rb, k);
+            bad = bad || (va && !(isfinite(u.x) && isfinite(u.y))) || (vb && !(isfinite(v.x) && isfinite(v.y)));
         }
-        fft1024p_inv_A<double>(re, im, lane, s_tw, pbuf);
-        __builtin_amdgcn_wave_barrier();
-        fft1024p_B<double>(re, lane, pbuf);
-        __builtin_amdgcn_wave_barrier();
-        fft1024p_C<double, true>(im, lane, pbuf);
-        __builtin_amdgcn_wave_barrier();
-        fft1024p_D<double, +1>(re, im, lane, pbuf);
-        __builtin_amdgcn_wave_barrier();
-
-        // position i: sample n = 32*brev5(i) + lane.  re -> frame ta, im -> frame ta+1.
-        // overlap_and_add_prepare_output (util.h:247-252) with the reference's float stores.
-        float oa[32], ob[32];
+        const bool split = __any(bad ? 1 : 0) != 0;
+        for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
+            const bool useA = va && (!split || pass == 0);
+            const bool useB = vb && (!split || pass == 1);
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const double h = s_win[lane * kPSd + brev5(i)];
-            float fa = (float)(re[i] / 1024.0);
-            fa = (float)((double)fa * h);
-            float fb = (float)(im[i] / 1024.0);
-            fb = (float)((double)fb * h);
-            if (a.use_post_amp) {  // mvdr.cpp:112-114
-                fa = (float)((double)fa * a.post_amp);
-                fb = (float)((double)fb * a.post_amp);
+            for (int i = 0; i < 32; ++i) {
+                const int k = lane + 32 * brev5(i);
+                cd u = herm_at(ra, k), v = herm_at(rb, k);
+                if (!useA) u = cd{0, 0};
+                if (!useB) v = cd{0, 0};
+                re[i] = u.x - v.y;  // Ya + i*Yb
+                im[i] = u.y + v.x;
             }
-            oa[i] = fa;
-            ob[i] = fb;
+            fft1024p_inv_A<double>(re, im, lane, s_tw, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_B<double>(re, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_C<double, true>(im, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_D<double, +1>(re, im, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+
+            // position i: sample n = 32*brev5(i) + lane.  re -> frame ta, im -> frame ta+1.
+            // overlap_and_add_prepare_output (util.h:247-252) with the reference's float stores.
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const double h = s_win[lane * kPSd + brev5(i)];
+                float fa = (float)(re[i] / 1024.0);
+                fa = (float)((double)fa * h);
+                float fb = (float)(im[i] / 1024.0);
+                fb = (float)((double)fb * h);
+                if (a.use_post_amp) {  // mvdr.cpp:112-114
+                    fa = (float)((double)fa * a.post_amp);
+                    fb = (float)((double)fb * a.post_amp);
+                }
+                if (useA || (!va && pass == 0)) oa[i] = fa;
+                if (useB || (!vb && pass == 0)) ob[i] = fb;
+            }
         }
         const bool st_a = chunk_ok && it > 0 && va;
         const bool st_b = chunk_ok && it > 0 && vb;
@@ -421,6 +436,252 @@ __global__ void smooth_state_kernel(const float *yraw, double *state, long n, in
     state[(long)s * 64 + k] = (double)yraw[(long)s * n + src];
 }
 
+
+// ======================================================================================
+//                     mvdr / lcmv: covariance, Cholesky solve, constraints
+// ======================================================================================
+// One group of MP lanes per (stream, bin) problem, lane i <-> microphone i; the group walks a
+// tile of consecutive frames so the sample covariance of the previous P frames
+//   R = past_ffts[j] * past_ffts[j]^H                     (mvdr.cpp:87, lcmv.cpp:112)
+// is slid by one rank-1 update and one downdate per frame (recomputed from scratch at the tile
+// start).  The reference inverts R o whiteR with PartialPivLU and forms
+//   mvdr:  w = R^-1 a / (a^H R^-1 a),   y = w^H x                     (mvdr.cpp:88-94)
+//   lcmv:  W = R^-1 C (C^H R^-1 C)^-1,  y = W(:,0)^H x                (lcmv.cpp:113-119)
+// R o whiteR is Hermitian positive definite whenever every mic has history energy, so with
+// R = L L^H, U = L^-1 [C | x]:   G = U_C^H U_C,  g = U_C^H u_x,  y = (G^-1 g)_0
+// (mvdr is the KP1 = 1 case: y = u_a^H u_x / u_a^H u_a).  Lane i owns row i of the
+// factorisation; columns are exchanged through LDS (one wavefront executes its LDS operations
+// in order, so only compiler barriers separate the phases).  A zero covariance (frame 0 of a
+// cold start) yields 0 * inf = NaN, the same NaN frame the reference emits.
+template <int KM>
+struct GramIdx {  // entries of the Hermitian upper triangle of G followed by g
+    static constexpr int NG = KM * (KM + 1) / 2;
+    static constexpr int NE = NG + KM;
+};
+
+template <int MP, int KM>
+__global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, int tiles_per_stream) {
+    constexpr int GPB = 256 / MP;          // problem groups per block
+    constexpr int NB = KM + 1;             // right-hand sides: constraints + current frame
+    constexpr int NE = GramIdx<KM>::NE;
+    __shared__ cd s_col[GPB][MP];
+    __shared__ cd s_x[GPB][MP];
+    __shared__ cd s_xo[GPB][MP];
+    __shared__ cd s_u[GPB][NB][MP];
+    __shared__ cd s_e[GPB][NE + 1];
+
+    const int grp = threadIdx.x / MP;
+    const int i = threadIdx.x % MP;
+    const int q = blockIdx.x * GPB + grp;
+    if (q >= kNQ) return;
+    const int s = blockIdx.y / tiles_per_stream;
+    const long tA = (long)(blockIdx.y % tiles_per_stream) * tile;
+    long tB = tA + tile;
+    if (tB > a.n_frames) tB = a.n_frames;
+    const int M = a.n_mics, NP = (M + 1) >> 1, KP1 = a.kp1, P = a.cfg.past_windows;
+    const int j = q_bin(q);
+    const bool lcmv = a.cfg.algo == BF_LCMV;
+    f64x2 *yout = a.Yh + ((long)s * a.n_frames) * kYhStride + q;
+    const f64x2 *Zs = a.Z + ((long)s * a.frames_ws + a.frame_off) * NP * kN;  // frame 0 of this batch
+
+    // one microphone's spectrum at this problem's bin, frame t (may be negative: history)
+    const int ksrc = q_src_bin(q), kneg = (kN - ksrc) & (kN - 1);
+    auto load_xi = [&](long t) -> cd {
+        if (i >= M) return cd{0, 0};
+        const f64x2 *Zf = Zs + t * NP * kN + (i >> 1) * kN;
+        const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
+        cd x;
+        if ((i & 1) == 0) {
+            x = (z + zc) * 0.5;
+        } else {
+            const cd d = z - zc;
+            x = cd{0.5 * d.y, -0.5 * d.x};
+        }
+        return q == 513 ? conj(x) : x;
+    };
+
+    const double f = fabs(a.freqs[j]);
+    const bool inband = f >= a.cfg.freq_min && f <= a.cfg.freq_max;
+    if (!inband || (!lcmv && j == 0)) {
+        // mvdr.cpp:76 y_fft[0] = in_fft(0,0); out of band: y_fft[j] = 0 (mvdr.cpp:103)
+        for (long t = tA; t < tB; ++t) {
+            cd y{0, 0};
+            if (!lcmv && j == 0) {
+                const cd x = load_xi(t);
+                s_x[grp][i] = x;
+                __builtin_amdgcn_wave_barrier();
+                y = s_x[grp][0];
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (i == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+        }
+        return;
+    }
+
+    cd cst[KM];  // this mic's entries of the constraint columns (weights[j](i, r))
+#pragma unroll
+    for (int r = 0; r < KM; ++r)
+        cst[r] = (r < KP1 && i < M) ? ld(a.steer + ((long)r * M + i) * kN + j) : cd{0, 0};
+
+    // R row i (lower triangle c <= i is what the factorisation reads)
+    cd R[MP];
+#pragma unroll
+    for (int c = 0; c < MP; ++c) R[c] = cd{0, 0};
+    for (int p = 1; p <= P; ++p) {
+        const cd x = load_xi(tA - p);
+        s_x[grp][i] = x;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < MP; ++c) R[c] = R[c] + x * conj(s_x[grp][c]);
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    for (long t = tA; t < tB; ++t) {
+        const cd x = load_xi(t);
+        const cd xo = load_xi(t - P);
+        s_x[grp][i] = x;
+        s_xo[grp][i] = xo;
+        __builtin_amdgcn_wave_barrier();
+        double mag = 0.0;
+        for (int m = 0; m < M; ++m) mag += cabs(s_x[grp][m]);
+        mag /= (double)((unsigned)M * 1024u);
+        cd y;
+        if (mag > a.cfg.freq_mag_threshold) {
+            cd A[MP], b[NB];
+#pragma unroll
+            for (int c = 0; c < MP; ++c) A[c] = R[c];
+            if (i < M) {
+                // cwiseProduct(whiteR): diagonal * 1.001 (mvdr.cpp:239-243)
+#pragma unroll
+                for (int c = 0; c < MP; ++c)
+                    if (c == i) A[c] = A[c] * 1.001;
+            } else {
+#pragma unroll
+                for (int c = 0; c < MP; ++c) A[c] = cd{c == i ? 1.0 : 0.0, 0.0};
+            }
+#pragma unroll
+            for (int r = 0; r < KM; ++r) b[r] = cst[r];
+            b[KM] = x;
+#pragma unroll
+            for (int jj = 0; jj < MP; ++jj) {
+                s_col[grp][i] = A[jj];  // raw column jj, row i
+                if (i == jj) {
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) s_u[grp][r][0] = b[r];
+                }
+                __builtin_amdgcn_wave_barrier();
+                const double d = sqrt(s_col[grp][jj].x);
+                const double inv = 1.0 / d;
+                const cd Lij = A[jj] * inv;
+                if (i > jj) {
+#pragma unroll
+                    for (int c = jj + 1; c < MP; ++c)
+                        if (c <= i) A[c] = A[c] - Lij * conj(s_col[grp][c] * inv);
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) b[r] = b[r] - Lij * (s_u[grp][r][0] * inv);
+                } else if (i == jj) {
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) b[r] = b[r] * inv;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            // b[r] is now row i of U = L^-1 [C | x]
+#pragma unroll
+            for (int r = 0; r < NB; ++r) s_u[grp][r][i] = (i < M) ? b[r] : cd{0, 0};
+            __builtin_amdgcn_wave_barrier();
+            // Gram entries: e < NG: G(r,r2) with r <= r2; e >= NG: g(r)
+            for (int e = i; e < NE; e += MP) {
+                int r = 0, r2 = 0;
+                if (e < GramIdx<KM>::NG) {
+                    int rem = e;
+                    while (rem >= KM - r) { rem -= KM - r; ++r; }
+                    r2 = r + rem;
+                } else {
+                    r = e - GramIdx<KM>::NG;
+                    r2 = KM;
+                }
+                cd acc{0, 0};
+                for (int m = 0; m < M; ++m) acc = acc + conj(s_u[grp][r][m]) * s_u[grp][r2][m];
+                s_e[grp][e] = acc;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // every lane solves the (KP1 x KP1) system G y = g redundantly; padding rows are identity
+            cd Gm[KM][KM], gv[KM];
+            {
+                int e = 0;
+#pragma unroll
+                for (int r = 0; r < KM; ++r)
+#pragma unroll
+                    for (int r2 = r; r2 < KM; ++r2) {
+                        const cd v = s_e[grp][e++];
+                        Gm[r][r2] = v;
+                        Gm[r2][r] = conj(v);
+                    }
+#pragma unroll
+                for (int r = 0; r < KM; ++r) gv[r] = s_e[grp][GramIdx<KM>::NG + r];
+#pragma unroll
+                for (int r = 0; r < KM; ++r)
+                    if (r >= KP1) {
+#pragma unroll
+                        for (int r2 = 0; r2 < KM; ++r2) {
+                            Gm[r][r2] = cd{r == r2 ? 1.0 : 0.0, 0.0};
+                            Gm[r2][r] = cd{r == r2 ? 1.0 : 0.0, 0.0};
+                        }
+                        gv[r] = cd{0, 0};
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < KM; ++k) {  // Gaussian elimination (G is Hermitian positive definite)
+                const cd pinv = cdiv(cd{1, 0}, Gm[k][k]);
+#pragma unroll
+                for (int r = k + 1; r < KM; ++r) {
+                    const cd fct = Gm[r][k] * pinv;
+#pragma unroll
+                    for (int c = k + 1; c < KM; ++c) Gm[r][c] = Gm[r][c] - fct * Gm[k][c];
+                    gv[r] = gv[r] - fct * gv[k];
+                }
+            }
+#pragma unroll
+            for (int k = KM - 1; k >= 0; --k) {
+                cd acc = gv[k];
+#pragma unroll
+                for (int c = k + 1; c < KM; ++c) acc = acc - Gm[k][c] * gv[c];
+                gv[k] = cdiv(acc, Gm[k][k]);
+            }
+            y = gv[0];
+        } else {
+            y = s_x[grp][0] * 0.01;  // in_fft(0,j)*0.01 (mvdr.cpp:96)
+        }
+        if (i == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+        // slide the covariance window: + x_t x_t^H - x_{t-P} x_{t-P}^H (mvdr.cpp:100-101)
+#pragma unroll
+        for (int c = 0; c < MP; ++c) R[c] = R[c] + x * conj(s_x[grp][c]) - xo * conj(s_xo[grp][c]);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace
+
+hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
+    int tile = 64;
+    if (a.n_frames < tile) tile = (int)a.n_frames;
+    const int tps = (int)((a.n_frames + tile - 1) / tile);
+    const int M = a.n_mics, km = a.kp1 <= 1 ? 1 : 4;
+#define BF_LAUNCH_ML(MP_, KM_)                                                                                   \
+    hipLaunchKernelGGL((mvdr_lcmv_kernel<MP_, KM_>), dim3((kNQ + (256 / MP_) - 1) / (256 / MP_), tps * a.n_streams), \
+                       dim3(256), 0, s, a, tile, tps)
+    if (M <= 4) {
+        if (km == 1) BF_LAUNCH_ML(4, 1); else BF_LAUNCH_ML(4, 4);
+    } else if (M <= 8) {
+        if (km == 1) BF_LAUNCH_ML(8, 1); else BF_LAUNCH_ML(8, 4);
+    } else {
+        if (km == 1) BF_LAUNCH_ML(16, 1); else BF_LAUNCH_ML(16, 4);
+    }
+#undef BF_LAUNCH_ML
+    return hipGetLastError();
+}
+
+namespace {
 }  // namespace
 
 // ---- launchers ---------------------------------------------------------------------------
@@ -460,7 +721,6 @@ hipError_t launch_smooth(const float *yraw, float *y, double *state, long n_fram
     return hipGetLastError();
 }
 
-hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s);
 hipError_t launch_phasempf(const BinsArgs &a, int n_cus, hipStream_t s);
 hipError_t launch_gss(const BinsArgs &a, int n_cus, hipStream_t s);
 
@@ -500,7 +760,6 @@ hipError_t launch_bins(const BinsArgs &a, int n_cus, hipStream_t s) {
 }
 
 // placeholders until the recursive / matrix kernels land
-hipError_t launch_mvdr_lcmv(const BinsArgs &, int, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_phasempf(const BinsArgs &, int, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_gss(const BinsArgs &, int, hipStream_t) { return hipErrorNotSupported; }
 
