@@ -195,7 +195,9 @@ int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipS
     const long FT = Phist_ + F;  // frames in the Z workspace per stream
     int rc = ensure((void **)&d_Z_, &Z_cap_, (size_t)S_ * FT * NP_ * 1024 * sizeof(f64x2));
     if (rc != BF_OK) return rc;
-    rc = ensure((void **)&d_Yh_, &Yh_cap_, (size_t)S_ * F * kYhStride * sizeof(f64x2));
+    // phasempf keeps |out_int|^2 (one double per problem) behind the spectrum rows
+    rc = ensure((void **)&d_Yh_, &Yh_cap_,
+                (size_t)S_ * F * kYhStride * (sizeof(f64x2) + (cfg_.algo == BF_PHASEMPF ? sizeof(double) : 0)));
     if (rc != BF_OK) return rc;
     if (cfg_.algo == BF_PHASEMPF) {
         rc = ensure((void **)&d_yraw_, &yraw_cap_, (size_t)S_ * F * 512 * sizeof(float));

@@ -682,7 +682,288 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
 }
 
 namespace {
+
+// ======================================================================================
+//                   phasempf: phase mask (parallel) + MCRA / MPF recursion (sequential)
+// ======================================================================================
+// Pass 1, one thread per (stream, frame, problem): the binary phase mask of phasempf.cpp:210-248.
+// out_soi goes to Yh (complex), |out_int|^2 to aux.
+template <int MP>
+__global__ __launch_bounds__(256) void mpf_mask_kernel(BinsArgs a, double *aux) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)a.n_streams * a.n_frames * kNQ;
+    if (idx >= total) return;
+    const int q = (int)(idx % kNQ);
+    const long st = idx / kNQ;
+    const long t = st % a.n_frames;
+    const int s = (int)(st / a.n_frames);
+    const int M = a.n_mics, NP = (M + 1) >> 1;
+    const f64x2 *Zf = a.Z + (((long)s * a.frames_ws + a.frame_off + t) * NP) * kN;
+    cd X[MP];
+    load_X<MP>(Zf, q, M, X);
+    const int j = q_bin(q);
+    const long o = ((long)s * a.n_frames + t) * kYhStride + q;
+    if (j == 0) {  // out_soi[0] = out_int[0] = in_fft(0,0); the squares at index 0 are never written: defined 0
+        a.Yh[o] = f64x2{X[0].x, X[0].y};
+        aux[o] = 0.0;
+        return;
+    }
+    double ph[MP];
+    double mag = 0.0;
+#pragma unroll
+    for (int m = 0; m < MP; ++m) {
+        if (m < M) {
+            const cd u = conj(ld(a.steer + (long)m * kN + j)) * X[m];
+            ph[m] = atan2(u.y, u.x);
+            mag += cabs(X[m]);
+        } else {
+            ph[m] = 0.0;
+        }
+    }
+    const double mean = pair_phase_mean<MP>(ph, M);
+    mag /= (double)M;
+    const double pha = atan2(X[0].y, X[0].x);
+    const bool is_soi = mean < a.cfg.min_phase * M_PI / 180;
+    const double lo = mag * a.cfg.min_mag;
+    const double msoi = is_soi ? mag : lo, mint = is_soi ? lo : mag;
+    const double c = cos(pha), sn = sin(pha);
+    const cd soi{msoi * c, msoi * sn}, in{mint * c, mint * sn};
+    a.Yh[o] = f64x2{soi.x, soi.y};
+    aux[o] = norm2(in);
+}
+
+struct MpfState {
+    double Sprev, Stmp, Smin, lam, Z, rev0, rev1;
+};
+
+// one frame of mcra() + the MPF block + spectral subtraction for one bin (phasempf.cpp:140-191,254-295)
+__device__ __forceinline__ cd mpf_step(MpfState &st, const bf_config &c, int j, cd soi, double int2, bool search_reset,
+                                       bool firstL, int cL) {
+    const double soi2 = (j == 0) ? 0.0 : norm2(soi);
+    double Sf;
+    if (j == 0) {
+        Sf = cabs(soi);
+    } else {
+        Sf = 0.0;
+        if (j - 1 >= 1) Sf += 0.25 * soi2;  // quirk Q15e: every tap multiplies soi2[j]
+        Sf += 0.5 * soi2;
+        if (j + 1 < kN) Sf += 0.25 * soi2;
+    }
+    const double S = (c.mcra_alphaS * st.Sprev) + ((1 - c.mcra_alphaS) * Sf);
+    if (search_reset) {
+        st.Smin = st.Stmp > S ? S : st.Stmp;
+        st.Stmp = S;
+    } else {
+        st.Smin = st.Smin > S ? S : st.Smin;
+        st.Stmp = st.Stmp > S ? S : st.Stmp;
+    }
+    if (firstL || S < st.Smin * c.mcra_delta || st.lam > soi2) {
+        const double ic = 1.0 / (double)cL;
+        if (firstL && ic > c.mcra_alphaD)
+            st.lam = ic * st.lam + (1.0 - ic) * soi2;
+        else
+            st.lam = c.mcra_alphaD2 * st.lam + (1.0 - c.mcra_alphaD) * soi2;  // quirk Q15g
+    }
+    st.Sprev = S;
+    st.Z = c.mpf_alphaS * st.Z + (1 - c.mpf_alphaS) * int2;
+    const double leak = c.mpf_eta * st.Z;
+    const double kq = 1 - c.mpf_rev_gamma / c.mpf_rev_delta;  // quirk Q15i
+    st.rev0 = c.mpf_rev_gamma * st.rev0 + kq * soi2;
+    st.rev1 = c.mpf_rev_gamma * st.rev1 + kq * int2;
+    const double Lam = sqrt(st.lam + leak + st.rev0 + st.rev1);
+    if (j == 0) return cd{0, 0};  // quirk Q15d: y_fft[0] is never written; defined 0
+    const double as = cabs(soi);
+    double mg;
+    if (c.out_only_noise) {
+        mg = Lam * c.out_amp;
+    } else {
+        mg = (as - (c.out_only_mcra ? sqrt(st.lam) : Lam)) * c.out_amp;
+        if (mg < 0) mg = c.noise_floor;
+    }
+    // mag * (cos, sin)(arg(soi)) == mag * soi/|soi|; arg(0) = 0
+    if (as == 0.0) return cd{mg, 0.0};
+    return cd{mg * (soi.x / as), mg * (soi.y / as)};
+}
+
+// Pass 2, one thread per (stream, problem), sequential over frames.
+__global__ __launch_bounds__(64) void mpf_recursion_kernel(BinsArgs a, const double *aux) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.n_streams * kNQ) return;
+    const int s = idx / kNQ, q = idx % kNQ;
+    const int j = q_bin(q);
+    double *sv = a.mpf + (long)s * (kMpfVecs * kN + 8);
+    MpfState st{sv[0 * kN + j], sv[1 * kN + j], sv[2 * kN + j], sv[3 * kN + j], sv[4 * kN + j], sv[5 * kN + j], sv[6 * kN + j]};
+    int cL = (int)sv[kMpfVecs * kN + 0];
+    bool firstL = sv[kMpfVecs * kN + 1] == 0.0;  // stored as "first_L is over" flag so a zeroed state = cold start
+    f64x2 *row = a.Yh + ((long)s * a.n_frames) * kYhStride + q;
+    const double *arow = aux + ((long)s * a.n_frames) * kYhStride + q;
+    for (long t = 0; t < a.n_frames; ++t) {
+        const cd soi = ld(row + t * kYhStride);
+        const double int2 = arow[t * kYhStride];
+        const bool reset = cL > a.cfg.mcra_L;  // phasempf.cpp:161
+        if (reset) {
+            cL = 1;
+            firstL = false;
+        } else {
+            cL++;
+        }
+        const cd y = mpf_step(st, a.cfg, j, soi, int2, reset, firstL, cL);
+        row[t * kYhStride] = f64x2{y.x, y.y};
+    }
+    sv[0 * kN + j] = st.Sprev; sv[1 * kN + j] = st.Stmp; sv[2 * kN + j] = st.Smin; sv[3 * kN + j] = st.lam;
+    sv[4 * kN + j] = st.Z; sv[5 * kN + j] = st.rev0; sv[6 * kN + j] = st.rev1;
+    if (q == 0) {
+        sv[kMpfVecs * kN + 0] = (double)cL;
+        sv[kMpfVecs * kN + 1] = firstL ? 0.0 : 1.0;
+    }
+}
+
+// ======================================================================================
+//                              gss: geometric source separation
+// ======================================================================================
+// One group of MP lanes per (stream, problem), lane m owns column m of the demixing matrix
+// W_j (S x M) and walks the frames in order (the update is recursive, gss.cpp:136).
+template <int MP, int KM>
+__global__ __launch_bounds__(256) void gss_kernel(BinsArgs a) {
+    constexpr int GPB = 256 / MP;
+    __shared__ cd s_x[GPB][MP];
+    __shared__ cd s_p[GPB][KM][MP];
+    const int grp = threadIdx.x / MP, m = threadIdx.x % MP;
+    const int gq = blockIdx.x * GPB + grp;
+    if (gq >= a.n_streams * kNQ) return;
+    const int s = gq / kNQ, q = gq % kNQ;
+    const int j = q_bin(q);
+    const int M = a.n_mics, NP = (M + 1) >> 1, S = a.kp1;
+    f64x2 *yout = a.Yh + ((long)s * a.n_frames) * kYhStride + q;
+    const f64x2 *Zs = a.Z + ((long)s * a.frames_ws + a.frame_off) * NP * kN;
+    const double f = fabs(a.freqs[j]);
+    const bool inband = f >= a.cfg.freq_min && f <= a.cfg.freq_max;
+    if (!inband) {
+        if (m == 0)
+            for (long t = 0; t < a.n_frames; ++t) yout[t * kYhStride] = f64x2{0, 0};
+        return;
+    }
+    const int ksrc = q_src_bin(q), kneg = (kN - ksrc) & (kN - 1);
+    cd C[KM], W[KM];
+    f64x2 *Wg = a.gssW + (((long)s * kN + j) * S) * M;
+#pragma unroll
+    for (int r = 0; r < KM; ++r) {
+        C[r] = (r < S && m < M) ? ld(a.steer + ((long)r * M + m) * kN + j) : cd{0, 0};
+        if (a.gss_reset)
+            W[r] = conj(C[r]);  // sep_matrix[j] = weights[j].adjoint() (gss.cpp:92)
+        else
+            W[r] = (r < S && m < M) ? ld(Wg + (long)r * M + m) : cd{0, 0};
+    }
+    const double mu = a.cfg.mu, keep = 1 - a.cfg.lambda_ * a.cfg.mu;
+    const double c2 = (double)(size_t)(2 * (1 / (size_t)S));  // integer arithmetic, quirk Q13
+    for (long t = 0; t < a.n_frames; ++t) {
+        cd x{0, 0};
+        if (m < M) {
+            const f64x2 *Zf = Zs + t * NP * kN + (m >> 1) * kN;
+            const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
+            if ((m & 1) == 0) {
+                x = (z + zc) * 0.5;
+            } else {
+                const cd d = z - zc;
+                x = cd{0.5 * d.y, -0.5 * d.x};
+            }
+            if (q == 513) x = conj(x);
+        }
+        s_x[grp][m] = x;
+#pragma unroll
+        for (int r = 0; r < KM; ++r) s_p[grp][r][m] = W[r] * x;
+        __builtin_amdgcn_wave_barrier();
+        double mag = 0.0, alpha = 0.0;
+        for (int k = 0; k < M; ++k) {
+            const cd v = s_x[grp][k];
+            mag += cabs(v);
+            alpha += norm2(v);
+        }
+        mag /= (double)((unsigned)M * 1024u);
+        cd y;
+        if (mag > a.cfg.freq_mag_threshold) {
+            cd yf[KM];
+#pragma unroll
+            for (int r = 0; r < KM; ++r) {
+                cd acc{0, 0};
+                for (int k = 0; k < M; ++k) acc = acc + s_p[grp][r][k];
+                yf[r] = acc;
+            }
+            y = yf[0];
+            alpha *= alpha;
+            const double c1 = (double)(4 * (size_t)S) * (1 / alpha);
+            cd Ey[KM];
+#pragma unroll
+            for (int r = 0; r < KM; ++r) {
+                cd acc{0, 0};
+#pragma unroll
+                for (int r2 = 0; r2 < KM; ++r2)
+                    if (r2 != r && r < S && r2 < S) acc = acc + (yf[r] * conj(yf[r2])) * yf[r2];
+                Ey[r] = acc;
+            }
+            cd d2[KM];
+#pragma unroll
+            for (int r = 0; r < KM; ++r) d2[r] = cd{0, 0};
+            if (c2 != 0.0) {  // only S == 1: dj2 = 2 (W C - I) C^H
+                __builtin_amdgcn_wave_barrier();
+                s_p[grp][0][m] = W[0] * C[0];
+                __builtin_amdgcn_wave_barrier();
+                cd wc{0, 0};
+                for (int k = 0; k < M; ++k) wc = wc + s_p[grp][0][k];
+                wc.x -= 1.0;
+                d2[0] = (wc * conj(C[0])) * c2;
+            }
+#pragma unroll
+            for (int r = 0; r < KM; ++r)
+                if (r < S) W[r] = (W[r] * keep) - ((Ey[r] * conj(x)) * c1 + d2[r]) * mu;
+        } else {
+            y = s_x[grp][0] * 0.01;
+        }
+        if (m == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int r = 0; r < KM; ++r)
+        if (r < S && m < M) Wg[(long)r * M + m] = f64x2{W[r].x, W[r].y};
+}
+
 }  // namespace
+
+hipError_t launch_phasempf(const BinsArgs &a, int n_cus, hipStream_t s) {
+    // aux (|out_int|^2 per problem) lives behind the Yh rows: Yh was allocated with 2x room by the pipeline
+    double *aux = reinterpret_cast<double *>(a.Yh + (long)a.n_streams * a.n_frames * kYhStride);
+    const long total = (long)a.n_streams * a.n_frames * kNQ;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (a.n_mics <= 4)
+        hipLaunchKernelGGL((mpf_mask_kernel<4>), dim3(blocks), dim3(256), 0, s, a, aux);
+    else if (a.n_mics <= 8)
+        hipLaunchKernelGGL((mpf_mask_kernel<8>), dim3(blocks), dim3(256), 0, s, a, aux);
+    else if (a.n_mics <= 16)
+        hipLaunchKernelGGL((mpf_mask_kernel<16>), dim3(blocks), dim3(256), 0, s, a, aux);
+    else
+        hipLaunchKernelGGL((mpf_mask_kernel<32>), dim3(blocks), dim3(256), 0, s, a, aux);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int nthr = a.n_streams * kNQ;
+    hipLaunchKernelGGL(mpf_recursion_kernel, dim3((nthr + 63) / 64), dim3(64), 0, s, a, (const double *)aux);
+    return hipGetLastError();
+}
+
+hipError_t launch_gss(const BinsArgs &a, int n_cus, hipStream_t s) {
+    const int M = a.n_mics, km = a.kp1 <= 1 ? 1 : 4;
+    const int groups = a.n_streams * kNQ;
+#define BF_LAUNCH_GSS(MP_, KM_) \
+    hipLaunchKernelGGL((gss_kernel<MP_, KM_>), dim3((groups + (256 / MP_) - 1) / (256 / MP_)), dim3(256), 0, s, a)
+    if (M <= 4) {
+        if (km == 1) BF_LAUNCH_GSS(4, 1); else BF_LAUNCH_GSS(4, 4);
+    } else if (M <= 8) {
+        if (km == 1) BF_LAUNCH_GSS(8, 1); else BF_LAUNCH_GSS(8, 4);
+    } else {
+        if (km == 1) BF_LAUNCH_GSS(16, 1); else BF_LAUNCH_GSS(16, 4);
+    }
+#undef BF_LAUNCH_GSS
+    return hipGetLastError();
+}
 
 // ---- launchers ---------------------------------------------------------------------------
 hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
@@ -759,8 +1040,5 @@ hipError_t launch_bins(const BinsArgs &a, int n_cus, hipStream_t s) {
     return e;
 }
 
-// placeholders until the recursive / matrix kernels land
-hipError_t launch_phasempf(const BinsArgs &, int, hipStream_t) { return hipErrorNotSupported; }
-hipError_t launch_gss(const BinsArgs &, int, hipStream_t) { return hipErrorNotSupported; }
 
 }  // namespace bf

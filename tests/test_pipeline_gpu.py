@@ -135,3 +135,82 @@ def test_mvdr_lcmv_full_size_windows(algo, M, interf, F):
     torch.cuda.synchronize()
     y = yd.cpu().numpy()
     assert windows_vs_oracle(p, x, y) < TOL_TIME
+
+
+@pytest.mark.parametrize("M,F,over", [(8, 120, {}), (4, 70, {}), (8, 60, dict(out_only_mcra=1)), (8, 60, dict(out_only_noise=1)),
+                                      (3, 40, dict(smooth_size=7, mcra_L=10))])
+def test_phasempf_matches_oracle(M, F, over):
+    """Mask + MCRA + MPF recursion + output smoothing; mcra_L=10 exercises the minima-search reset inside the run."""
+    import oracle
+    p = make_params("phasempf", n_mics=M, theta=20.0, **over)
+    x = make_scene(M, F, seed=600 + M)
+    y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
+    y, Y = run_gpu(p, x)
+    check(y, Y, y_ref, Y_ref)
+
+
+@pytest.mark.parametrize("M,interf,F", [(8, (-60.0, 90.0), 50), (4, (), 40), (16, (-60.0, 90.0, 150.0), 20)])
+def test_gss_matches_oracle(M, interf, F):
+    import oracle
+    p = make_params("gss", n_mics=M, interf=interf, theta=20.0)
+    x = make_scene(M, F, seed=700 + M)
+    y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
+    y, Y = run_gpu(p, x)
+    check(y, Y, y_ref, Y_ref)
+
+
+@pytest.mark.parametrize("algo,interf", [("phasempf", ()), ("gss", (-60.0, 90.0)), ("phase", ()), ("lcmv", (-60.0,))])
+def test_recursive_state_carries_across_batches_and_theta(algo, interf):
+    """Batches of uneven length == one stream; /theta in the middle == the oracle's set_theta
+    (gss re-initialises its demixing matrices, gss.cpp:90-93)."""
+    import oracle
+    from beamform_amd.capi import Beamformer
+    _torch()
+    M, F = 8, 36
+    p = make_params(algo, n_mics=M, interf=interf, theta=20.0)
+    x = make_scene(M, F, seed=81)
+    node = oracle.OracleNode(p)
+    bf = Beamformer(p)
+    cuts = [0, 5, 6, 17, 36]
+    ys, refs = [], []
+    for n, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        if n == 2:
+            node.set_theta(-40.0)
+            bf.set_theta(-40.0)
+        seg = np.ascontiguousarray(x[:, a * 512:b * 512])
+        refs.append(node.process(seg)[0])
+        ys.append(bf.process(seg))
+    y, y_ref = np.concatenate(ys), np.concatenate(refs)
+    ok = np.isfinite(y_ref)
+    assert (np.isfinite(y) == ok).all()
+    assert rel_l2(y[ok], y_ref[ok]) < TOL_TIME
+
+
+@pytest.mark.parametrize("algo", ["mvdr", "phasempf", "gss"])
+def test_pipeline_checkpoint_roundtrip(algo):
+    from beamform_amd.capi import Beamformer
+    _torch()
+    M, F = 4, 16
+    p = make_params(algo, n_mics=M, theta=10.0, interf=(-60.0,) if algo == "gss" else ())
+    x = make_scene(M, 2 * F, seed=2)
+    a = Beamformer(p)
+    a.process(np.ascontiguousarray(x[:, : F * 512]))
+    blob = a.get_state()
+    ya2 = a.process(np.ascontiguousarray(x[:, F * 512:]))
+    b = Beamformer(p)
+    b.process(np.ascontiguousarray(x[:, : 3 * 512]))  # scramble b's state first
+    b.set_state(blob)
+    yb2 = b.process(np.ascontiguousarray(x[:, F * 512:]))
+    assert np.array_equal(ya2, yb2, equal_nan=True)
+
+
+def test_multi_stream_phasempf_config4_shape():
+    """BASELINE config 4 shape at reduced size: S independent streams x F_s frames, recursion per stream."""
+    import oracle
+    M, S, F = 8, 6, 40
+    p = make_params("phasempf", n_mics=M, theta=20.0)
+    xs = np.stack([make_scene(M, F, seed=40 + s) for s in range(S)])
+    y, Y = run_gpu(p, xs, n_streams=S)
+    for s in range(S):
+        y_ref, Y_ref = oracle.OracleNode(p).process(xs[s], want_spectrum=True)
+        check(y[s], Y[s], y_ref, Y_ref)
