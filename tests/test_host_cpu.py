@@ -1,0 +1,174 @@
+"""CPU suite (no GPU): host-side logic of the product -- the kernels' algebra run through the CPU
+emulation harness, the C ABI surface, the YAML reader, and the loud failure without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from beamform_amd.params import make_params
+from beamform_amd.synth import make_scene
+from conftest import ROOT, rel_l2
+
+P = C.c_void_p
+
+
+def _ptr(a):
+    return a.ctypes.data_as(P)
+
+
+def test_emulated_fft32_and_fft1024(emul_lib):
+    rng = np.random.default_rng(0)
+    for dit in (0, 1):
+        for d in (-1, 1):
+            x = rng.standard_normal(32) + 1j * rng.standard_normal(32)
+            o = np.empty(32, np.complex128)
+            emul_lib.emul_fft32(_ptr(x), _ptr(o), d, dit)
+            ref = np.fft.fft(x) if d < 0 else np.fft.ifft(x) * 32
+            assert rel_l2(o, ref) < 1e-14
+    for use_float, tol in ((0, 1e-14), (1, 5e-7)):
+        for d in (-1, 1):
+            x = rng.standard_normal(1024) + 1j * rng.standard_normal(1024)
+            o = np.empty(1024, np.complex128)
+            emul_lib.emul_fft1024(_ptr(x), _ptr(o), d, use_float)
+            ref = np.fft.fft(x) if d < 0 else np.fft.ifft(x) * 1024
+            assert rel_l2(o, ref) < tol
+
+
+@pytest.mark.parametrize("M,theta", [(8, 20.0), (4, 0.0), (3, -75.0), (16, 135.0), (1, 0.0)])
+def test_emulated_fused_das_matches_oracle(emul_lib, M, theta):
+    """Pair packing + Hermitian-part gains + unpaired inverse, in fp32 exactly as the kernel does it."""
+    import oracle
+    F = 10
+    p = make_params("das", n_mics=M, theta=theta)
+    x = make_scene(M, F, seed=31 + M)
+    y_ref, _ = oracle.OracleNode(p).process(x)
+    y = np.empty(F * 512, np.float32)
+    mx = np.array([m[0] for m in p["mics"]])
+    my = np.array([m[1] for m in p["mics"]])
+    emul_lib.emul_das_fused(M, 512, C.c_double(48000.0), _ptr(mx), _ptr(my), C.c_double(theta), _ptr(x), C.c_long(F), _ptr(y))
+    assert rel_l2(y, y_ref) < 1e-6
+
+
+def test_host_geometry_matches_oracle(emul_lib):
+    import oracle
+    p = make_params("das", n_mics=8, theta=57.0)
+    node = oracle.OracleNode(p)
+    f = np.empty(1024)
+    emul_lib.emul_freqs(1024, C.c_double(48000.0), _ptr(f))
+    assert np.array_equal(f, node.freqs())
+    h = np.empty(1024)
+    emul_lib.emul_hann(1024, _ptr(h))
+    assert np.array_equal(h, node.hann())
+    mx = np.array([m[0] for m in p["mics"]])
+    my = np.array([m[1] for m in p["mics"]])
+    tau = np.empty(8)
+    emul_lib.emul_delays(8, _ptr(mx), _ptr(my), C.c_double(57.0), _ptr(tau))
+    assert np.array_equal(tau, node.delays())
+
+
+def test_library_exports_every_declared_symbol():
+    from beamform_amd import capi
+    lib = capi.load()
+    header = open(os.path.join(ROOT, "include", "bfcore.h")).read()
+    declared = set(re.findall(r"\b(bf_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"bfcore" in lib.bf_version()
+
+
+def test_config_defaults_are_the_launch_file_values():
+    from beamform_amd import capi
+    lib = capi.load()
+    c = capi.BfConfig()
+    assert lib.bf_config_init(C.byref(c), 1) == 0       # mvdr.launch:6-10
+    assert (c.past_windows, c.freq_mag_threshold, c.freq_max, c.freq_min, c.out_amp) == (10, 0.001, 16000.0, 100.0, 1.0)
+    assert (c.n_mics, c.hop, c.sample_rate) == (3, 512, 48000.0)   # aira3, beamform_config.yaml:15-17
+    assert (c.mic_x[2], c.mic_y[2]) == (-0.156, -0.090)
+    assert lib.bf_config_init(C.byref(c), 5) == 0       # phasempf.launch
+    assert (c.min_phase, c.min_mag, c.smooth_size, c.mcra_L, c.out_amp) == (30.0, 0.05, 3, 50, 2.5)
+    assert lib.bf_config_init(C.byref(c), 3) == 0       # gss.launch
+    assert (c.out_amp, c.mu, c.lambda_) == (0.1, 0.001, 0.0)
+    assert lib.bf_config_init(C.byref(c), 4) == 0       # phase: fallbacks of phase.cpp:180,187 (Q14)
+    assert (c.min_phase, c.mag_mult, c.mag_threshold) == (10.0, 0.1, 0.05)
+    assert lib.bf_config_init(C.byref(c), 9) != 0
+
+
+YAML = b"""verbose: true
+initial_angle: 12.5
+
+#aira3
+#mic0: {id: 0, x:  9.000, y:  9.000}
+mic0:  {id:  0, x:  0.158, y:  0.115, z:  0.000}
+mic1:  {id:  1, x:  0.158, y: -0.115, z:  0.000}
+mic2:  {id:  2, x: -0.045, y:  0.000, z:  0.000}
+mic3:  {id:  3, x: -0.050, y: -0.188, z:  0.000}
+mic5:  {id:  5, x: 1, y: 1}
+
+angle_interf1:  -60.0
+angle_interf2:  90
+angle_interf3:  181.0
+angle_interf4:  10.0
+past_windows: 12
+freq_max: 8000
+MCRA_L: 20
+lambda: 0.5
+write_file_path: ''
+"""
+
+
+def test_yaml_reader_follows_handle_params():
+    """util.h:82-113: mics consumed until the first missing index, interferers until the first |angle| > 180."""
+    from beamform_amd import capi
+    lib = capi.load()
+    c = capi.BfConfig()
+    lib.bf_config_init(C.byref(c), 2)
+    assert lib.bf_config_parse_yaml(C.byref(c), YAML) == 0
+    assert c.theta == 12.5 and c.verbose == 1
+    assert c.n_mics == 4 and (c.mic_x[3], c.mic_y[3]) == (-0.050, -0.188)      # mic4 missing -> mic5 ignored
+    assert c.n_interf == 2 and (c.interf_angle[0], c.interf_angle[1]) == (-60.0, 90.0)
+    assert (c.past_windows, c.freq_max, c.mcra_L, c.lambda_) == (12, 8000.0, 20, 0.5)
+    path = os.path.join(ROOT, "tests", "golden", "_tmp_cfg.yaml")
+    with open(path, "wb") as f:
+        f.write(YAML)
+    try:
+        c2 = capi.BfConfig()
+        lib.bf_config_init(C.byref(c2), 0)
+        assert lib.bf_config_load_yaml(C.byref(c2), path.encode()) == 0 and c2.n_mics == 4
+        assert lib.bf_config_load_yaml(C.byref(c2), b"/nonexistent.yaml") == -2
+    finally:
+        os.remove(path)
+
+
+def test_create_fails_loudly_without_gpu_or_with_bad_config():
+    import torch
+    from beamform_amd import capi
+    lib = capi.load()
+    c = capi.config_from_params(make_params("das", n_mics=8))
+    h = C.c_void_p()
+    if not torch.cuda.is_available():
+        assert lib.bf_device_count() <= 0
+        assert lib.bf_create(C.byref(c), C.byref(h)) == -19           # BF_ENODEV: no CPU fallback
+        assert b"no CPU fallback" in lib.bf_last_error(None)
+        with pytest.raises(capi.BfError):
+            capi.Beamformer(make_params("das", n_mics=8))
+    c.hop = 256
+    assert lib.bf_create(C.byref(c), C.byref(h)) in (-38, -19)        # unsupported hop (or no device)
+    c.hop, c.n_mics = 512, 0
+    assert lib.bf_create(C.byref(c), C.byref(h)) == -22
+    assert lib.bf_create(None, C.byref(h)) == -22
+    assert lib.bf_strerror(-19).startswith(b"no usable HIP device")
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: no product source may reference it."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "beamform_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, fn), errors="ignore").read()
+                if re.search(r"^\s*(import|from)\s+oracle|liboracle|bf_oracle|np_oracle", txt, re.M):
+                    bad.append(fn)
+    assert not bad, bad
