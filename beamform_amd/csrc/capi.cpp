@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -41,6 +42,7 @@ struct bf_handle {
     int gains_cur = 0;
     f32x2 *d_twiddle = nullptr;
     float *d_window = nullptr;
+    float *d_zeros = nullptr;
     float *d_hist[2] = {nullptr, nullptr};  // the hop before the next frame (the reference's ring buffer content)
     float *d_tail[2] = {nullptr, nullptr};
     int tail_cur = 0;  // index of the valid hist/tail pair; the kernel writes the other one
@@ -111,7 +113,8 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
                   int layout, long mic_stride) {
     const long F = (long)n_frames;
     const int S = h->n_streams;
-    const long slots = (long)h->n_cus * 16;  // half-wavefronts resident at one 512-thread block per CU
+    static const int slots_per_cu = getenv("BF_DAS_SLOTS") ? atoi(getenv("BF_DAS_SLOTS")) : 16;
+    const long slots = (long)h->n_cus * slots_per_cu;  // half-wavefronts resident per CU
     long cps = slots / S;
     if (cps < 1) cps = 1;
     if (cps > F) cps = F;
@@ -139,6 +142,7 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     a.gains = h->d_gains[h->gains_cur];
     a.twiddle = h->d_twiddle;
     a.window = h->d_window;
+    a.zeros = h->d_zeros;
     a.sdump = spectrum_dev ? h->d_sdump : nullptr;
     a.n_frames = F;
     a.mic_stride = mic_stride;
@@ -282,6 +286,8 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
         for (int i = 0; i < h->N; ++i) hf[i] = (float)hd[i];
         BF_CREATE_HIP(hipMalloc((void **)&h->d_window, hf.size() * sizeof(float)));
         BF_CREATE_HIP(hipMemcpy(h->d_window, hf.data(), hf.size() * sizeof(float), hipMemcpyHostToDevice));
+        BF_CREATE_HIP(hipMalloc((void **)&h->d_zeros, 1024 * sizeof(float)));
+        BF_CREATE_HIP(hipMemset(h->d_zeros, 0, 1024 * sizeof(float)));
         BF_CREATE_HIP(hipMalloc((void **)&h->d_hist[0], S * h->M * h->H * sizeof(float)));
         BF_CREATE_HIP(hipMalloc((void **)&h->d_hist[1], S * h->M * h->H * sizeof(float)));
         BF_CREATE_HIP(hipMalloc((void **)&h->d_tail[0], S * h->H * sizeof(float)));
@@ -321,6 +327,7 @@ void bf_destroy(bf_handle *h) {
     }
     if (h->d_twiddle) (void)hipFree(h->d_twiddle);
     if (h->d_window) (void)hipFree(h->d_window);
+    if (h->d_zeros) (void)hipFree(h->d_zeros);
     if (h->d_sdump) (void)hipFree(h->d_sdump);
     if (h->d_x) (void)hipFree(h->d_x);
     if (h->d_y) (void)hipFree(h->d_y);

@@ -48,7 +48,8 @@ constexpr int kLdsFixed = kLdsTw + kHalves * kLdsPlane + kLdsWin;
 // NPL = number of pair-gain tables held in LDS (0: read gains from global memory)
 template <int LAYOUT, int NPL, bool PREFETCH = false>
 __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[kLdsFixed + NPL * 2048];
+    // PREFETCH keeps the overlap tail in LDS (16 floats per lane) to make room for the in-flight samples
+    __shared__ __attribute__((aligned(16))) float lds[kLdsFixed + NPL * 2048 + (PREFETCH ? kHalves * 16 * 32 : 0)];
     const cx<float> *s_tw = reinterpret_cast<const cx<float> *>(lds);
     float *s_win = lds + kLdsTw + kHalves * kLdsPlane;
     const cx<float> *s_gain = reinterpret_cast<const cx<float> *>(lds + kLdsFixed);
@@ -83,9 +84,14 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
     const float *hs = a.hist_in + (long)stream * M * kHop;
     float *ys = a.y + (long)stream * a.n_frames * kHop;
 
+    float *s_tail = lds + kLdsFixed + NPL * 2048 + (PREFETCH ? (hw * 16) * 32 + lane : 0);  // [q][lane]
     float tail[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) tail[q] = 0.f;
+    if (PREFETCH) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s_tail[32 * q] = 0.f;
+    }
 
     float re[32], im[32], Sr[32], Si[32];
     float xa[32], xb[32];  // raw samples of the NEXT pair, in flight while the current pair is transformed
@@ -163,6 +169,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             if (p == 0) {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
+                    if ((i & 7) == 0) BF_SCHED_FENCE();
                     const cx<float> g = gp[32 * i];
                     Sr[i] = g.x * re[i] - g.y * im[i];
                     Si[i] = g.x * im[i] + g.y * re[i];
@@ -170,6 +177,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             } else {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
+                    if ((i & 7) == 0) BF_SCHED_FENCE();
                     const cx<float> g = gp[32 * i];
                     Sr[i] += g.x * re[i] - g.y * im[i];
                     Si[i] += g.x * im[i] + g.y * re[i];
@@ -199,6 +207,10 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             const float4 hv = wrow[g];
             h[4 * g + 0] = hv.x; h[4 * g + 1] = hv.y; h[4 * g + 2] = hv.z; h[4 * g + 3] = hv.w;
         }
+        if (PREFETCH) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tail[q] = s_tail[32 * q];
+        }
         if (store) {
             float *yo = ys + t * kHop + lane;
 #pragma unroll
@@ -211,6 +223,10 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             const float *ti = a.tail_in + (long)stream * kHop + lane;
 #pragma unroll
             for (int q = 0; q < 16; ++q) tail[q] = ti[32 * brev5(2 * q)];
+        }
+        if (PREFETCH) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s_tail[32 * q] = tail[q];
         }
         if (store && t == a.n_frames - 1) {
             // carried state for the next call: OLA tail (out_buff[0]) and the last input hop (ring buffer)

@@ -133,12 +133,14 @@ BF_HD void fft1024p_fwd_A(T (&re)[32], T (&im)[32], int lane, const cx<T> *tw, T
     fft32_dif<T, -1>(re, im);
 #pragma unroll
     for (int i = 1; i < 32; ++i) {
+        if ((i & 7) == 0) BF_SCHED_FENCE();
         const int k1 = brev5(i);
         const cx<T> w = tw[k1 * 32 + lane];
         const T xr = re[i], xi = im[i];
         re[i] = xr * w.x - xi * w.y;
         im[i] = xr * w.y + xi * w.x;
     }
+    BF_SCHED_FENCE();
 #pragma unroll
     for (int i = 0; i < 32; ++i) pbuf[brev5(i) * PS + lane] = re[i];
 }
@@ -149,6 +151,7 @@ BF_HD void fft1024p_inv_A(T (&re)[32], T (&im)[32], int lane, const cx<T> *tw, T
     fft32_dit<T, +1>(re, im);
 #pragma unroll
     for (int n2 = 1; n2 < 32; ++n2) {
+        if ((n2 & 7) == 0) BF_SCHED_FENCE();
         const cx<T> w = tw[n2 * 32 + lane];
         const T xr = re[n2], xi = im[n2];
         re[n2] = xr * w.x + xi * w.y;

@@ -16,6 +16,14 @@
 #define BF_HD inline __attribute__((always_inline))
 #endif
 
+// Compiler scheduling fence (no instruction): keeps the scheduler from hoisting a whole table's worth of
+// LDS/global loads above the arithmetic that frees their registers.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define BF_SCHED_FENCE() ((void)0)
+#endif
+
 namespace bf {
 
 constexpr int brev5(int i) {

@@ -18,6 +18,7 @@ struct DasFusedArgs {
     const f32x2 *gains;    // das_pair_gains() table
     const f32x2 *twiddle;  // twiddle_table_32x32<f32x2>()
     const float *window;   // sqrt-Hann, fp32, natural order [1024]
+    const float *zeros;    // >= 1024 zero floats: partner channel of the last mic when n_mics is odd
     f32x2 *sdump;          // nullable: [stream][frame][1024] accumulated pair spectrum S (1/N folded in)
     long n_frames;         // frames per stream
     long mic_stride;       // planar: samples between mics of one stream
