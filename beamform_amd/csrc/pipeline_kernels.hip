@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "fft1024.hpp"
 
 namespace bf {
@@ -453,6 +455,119 @@ __global__ void smooth_state_kernel(const float *yraw, double *state, long n, in
 // factorisation; columns are exchanged through LDS (one wavefront executes its LDS operations
 // in order, so only compiler barriers separate the phases).  A zero covariance (frame 0 of a
 // cold start) yields 0 * inf = NaN, the same NaN frame the reference emits.
+// ---- mvdr fast path: one thread per (stream, bin), whole problem in registers -----------------
+// For M <= 8 the lower triangle of R (36 complex) and of its working copy fit the 512-entry
+// register file of a wavefront that has a SIMD to itself (fp64 FMA issues every 4 cycles, so one
+// wavefront per SIMD already keeps the fp64 pipe busy).  Lanes are consecutive bins: spectra
+// loads are coalesced, no LDS, no idle lanes.  Same maths as mvdr_lcmv_kernel with KP1 = 1:
+//   R o whiteR = L L^H,  u = L^-1 a,  v = L^-1 x,  y = u^H v / u^H u.
+template <int MP>
+__global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, int tiles_per_stream) {
+    constexpr int NT = MP * (MP + 1) / 2;
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    const int s = blockIdx.y / tiles_per_stream;
+    const long tA = (long)(blockIdx.y % tiles_per_stream) * tile;
+    long tB = tA + tile;
+    if (tB > a.n_frames) tB = a.n_frames;
+    const int M = a.n_mics, NP = (M + 1) >> 1, P = a.cfg.past_windows;
+    const bool live = q < kNQ;
+    const int qq = live ? q : kNQ - 1;
+    const int j = q_bin(qq);
+    const double f = fabs(a.freqs[j]);
+    const bool inband = live && f >= a.cfg.freq_min && f <= a.cfg.freq_max;
+    f64x2 *yout = a.Yh + ((long)s * a.n_frames) * kYhStride + qq;
+    const f64x2 *Zs = a.Z + ((long)s * a.frames_ws + a.frame_off) * NP * kN;
+    if (__builtin_amdgcn_ballot_w64(inband) == 0) {  // whole wavefront out of band (mvdr.cpp:103) or bin 0 (:76)
+        if (live)
+            for (long t = tA; t < tB; ++t) {
+                cd y{0, 0};
+                if (j == 0) {
+                    cd X[MP];
+                    load_X<MP>(Zs + t * NP * kN, qq, M, X);
+                    y = X[0];
+                }
+                yout[t * kYhStride] = f64x2{y.x, y.y};
+            }
+        return;
+    }
+    cd st[MP];
+#pragma unroll
+    for (int m = 0; m < MP; ++m) st[m] = (m < M) ? ld(a.steer + (long)m * kN + j) : cd{0, 0};
+
+    cd R[NT];  // lower triangle, row-major: R[i*(i+1)/2 + c], c <= i
+#pragma unroll
+    for (int e = 0; e < NT; ++e) R[e] = cd{0, 0};
+    for (int p = 1; p <= P; ++p) {
+        cd X[MP];
+        load_X<MP>(Zs + (tA - p) * NP * kN, qq, M, X);
+#pragma unroll
+        for (int i = 0; i < MP; ++i)
+#pragma unroll
+            for (int c = 0; c <= i; ++c) R[i * (i + 1) / 2 + c] = R[i * (i + 1) / 2 + c] + X[i] * conj(X[c]);
+    }
+    for (long t = tA; t < tB; ++t) {
+        cd X[MP];
+        load_X<MP>(Zs + t * NP * kN, qq, M, X);
+        double mag = 0.0;
+#pragma unroll
+        for (int m = 0; m < MP; ++m)
+            if (m < M) mag += sqrt(norm2(X[m]));  // |X| well inside double range: no hypot scaling needed
+        mag /= (double)((unsigned)M * 1024u);
+        cd A[NT], ua[MP], ux[MP];
+#pragma unroll
+        for (int i = 0; i < MP; ++i) {
+#pragma unroll
+            for (int c = 0; c <= i; ++c) {
+                cd v = R[i * (i + 1) / 2 + c];
+                if (c == i) v = (i < M) ? v * 1.001 : cd{1.0, 0.0};  // whiteR diagonal (mvdr.cpp:239-243); padding = identity
+                A[i * (i + 1) / 2 + c] = v;
+            }
+            ua[i] = st[i];
+            ux[i] = X[i];
+        }
+#pragma unroll
+        for (int jj = 0; jj < MP; ++jj) {
+            const double inv = rsqrt(A[jj * (jj + 1) / 2 + jj].x);  // 1/L_jj; L_jj itself is never needed
+            ua[jj] = ua[jj] * inv;
+            ux[jj] = ux[jj] * inv;
+#pragma unroll
+            for (int i = jj + 1; i < MP; ++i) {
+                const cd Lij = A[i * (i + 1) / 2 + jj] * inv;
+                A[i * (i + 1) / 2 + jj] = Lij;
+                ua[i] = ua[i] - Lij * ua[jj];
+                ux[i] = ux[i] - Lij * ux[jj];
+            }
+#pragma unroll
+            for (int c = jj + 1; c < MP; ++c) {
+                const cd Lc = conj(A[c * (c + 1) / 2 + jj]);
+#pragma unroll
+                for (int i = c; i < MP; ++i)
+                    A[i * (i + 1) / 2 + c] = A[i * (i + 1) / 2 + c] - A[i * (i + 1) / 2 + jj] * Lc;
+            }
+        }
+        cd num{0, 0};
+        double den = 0.0;
+#pragma unroll
+        for (int i = 0; i < MP; ++i) {
+            num = num + conj(ua[i]) * ux[i];
+            den += norm2(ua[i]);
+        }
+        cd y = cd{num.x / den, num.y / den};
+        if (!(mag > a.cfg.freq_mag_threshold)) y = X[0] * 0.01;  // mvdr.cpp:96
+        if (!inband) y = cd{0, 0};
+        if (j == 0) y = X[0];
+        if (live) yout[t * kYhStride] = f64x2{y.x, y.y};
+        // slide the covariance window (mvdr.cpp:100-101)
+        cd Xo[MP];
+        load_X<MP>(Zs + (t - P) * NP * kN, qq, M, Xo);
+#pragma unroll
+        for (int i = 0; i < MP; ++i)
+#pragma unroll
+            for (int c = 0; c <= i; ++c)
+                R[i * (i + 1) / 2 + c] = R[i * (i + 1) / 2 + c] + X[i] * conj(X[c]) - Xo[i] * conj(Xo[c]);
+    }
+}
+
 template <int KM>
 struct GramIdx {  // entries of the Hermitian upper triangle of G followed by g
     static constexpr int NG = KM * (KM + 1) / 2;
@@ -667,6 +782,18 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
     if (a.n_frames < tile) tile = (int)a.n_frames;
     const int tps = (int)((a.n_frames + tile - 1) / tile);
     const int M = a.n_mics, km = a.kp1 <= 1 ? 1 : 4;
+    static const bool no_fast = getenv("BF_MVDR_GROUP") && atoi(getenv("BF_MVDR_GROUP")) != 0;
+    if (a.cfg.algo == BF_MVDR && M <= 8 && !no_fast) {
+        int ft = 32;
+        if (a.n_frames < ft) ft = (int)a.n_frames;
+        const int ftps = (int)((a.n_frames + ft - 1) / ft);
+        const dim3 grid((kNQ + 63) / 64, ftps * a.n_streams);
+        if (M <= 4)
+            hipLaunchKernelGGL((mvdr_fast_kernel<4>), grid, dim3(64), 0, s, a, ft, ftps);
+        else
+            hipLaunchKernelGGL((mvdr_fast_kernel<8>), grid, dim3(64), 0, s, a, ft, ftps);
+        return hipGetLastError();
+    }
 #define BF_LAUNCH_ML(MP_, KM_)                                                                                   \
     hipLaunchKernelGGL((mvdr_lcmv_kernel<MP_, KM_>), dim3((kNQ + (256 / MP_) - 1) / (256 / MP_), tps * a.n_streams), \
                        dim3(256), 0, s, a, tile, tps)
