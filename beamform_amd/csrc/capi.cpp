@@ -113,13 +113,13 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
                   int layout, long mic_stride) {
     const long F = (long)n_frames;
     const int S = h->n_streams;
-    static const int slots_per_cu = getenv("BF_DAS_SLOTS") ? atoi(getenv("BF_DAS_SLOTS")) : 16;
-    const long slots = (long)h->n_cus * slots_per_cu;  // half-wavefronts resident per CU
-    long cps = slots / S;
-    if (cps < 1) cps = 1;
-    if (cps > F) cps = F;
-    const long fpc = (F + cps - 1) / cps;
-    cps = (F + fpc - 1) / fpc;
+    // one block (16 half-wavefronts) per run of consecutive frames; runs are multiples of 16 frames and
+    // there are about as many runs as CUs
+    long runs = h->n_cus / S;
+    if (runs < 1) runs = 1;
+    long fpc = (F + runs - 1) / runs;
+    fpc = ((fpc + 15) / 16) * 16;
+    const long cps = (F + fpc - 1) / fpc;
 
     if (spectrum_dev) {
         const size_t need = (size_t)S * F * 1024;
@@ -152,6 +152,7 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     a.frames_per_chunk = (int)fpc;
     a.chunks_per_stream = (int)cps;
     a.layout = layout;
+    BF_HIP(h, prepare_das_fused(a, s));
     hipEvent_t k0 = nullptr, k1 = nullptr;
     if (h->kernel_events) {
         BF_HIP(h, hipEventCreate(&k0));

@@ -46,13 +46,22 @@ constexpr int kLdsWin = 32 * kPS;            // floats
 constexpr int kLdsFixed = kLdsTw + kHalves * kLdsPlane + kLdsWin;
 
 // NPL = number of pair-gain tables held in LDS (0: read gains from global memory)
-template <int LAYOUT, int NPL, bool PREFETCH = false>
+//
+// Work split: one 512-thread block (16 half-wavefronts) owns a run of consecutive frames of one
+// stream and walks it 16 frames at a time -- half-wavefront hw transforms frame t0 + 16*it + hw.
+// Neighbouring half-wavefronts therefore read the shared hop of the 50 % overlap within the same
+// few microseconds (L1/L2 hit): HBM sees every input sample once (the per-run variant this
+// replaces fetched every hop twice: profiles/r01_c_traffic_das8_v2kernel.json).  The overlap-add
+// partner (second half of frame t-1) comes from the neighbour through a 17-slot LDS ring; only the
+// first hop of a run needs the previous run's last frame, and that one hop is completed by two
+// float atomic adds into a pre-zeroed hop (sum of two terms: order-independent, bit-exact).
+template <int LAYOUT, int NPL>
 __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
-    // PREFETCH keeps the overlap tail in LDS (16 floats per lane) to make room for the in-flight samples
-    __shared__ __attribute__((aligned(16))) float lds[kLdsFixed + NPL * 2048 + (PREFETCH ? kHalves * 16 * 32 : 0)];
+    __shared__ __attribute__((aligned(16))) float lds[kLdsFixed + NPL * 2048 + 17 * kHop];
     const cx<float> *s_tw = reinterpret_cast<const cx<float> *>(lds);
     float *s_win = lds + kLdsTw + kHalves * kLdsPlane;
     const cx<float> *s_gain = reinterpret_cast<const cx<float> *>(lds + kLdsFixed);
+    float *s_tails = lds + kLdsFixed + NPL * 2048;  // slot 0 = carry from the previous iteration, slot hw+1 = this one
 
     const int tid = threadIdx.x;
     const int lane = tid & 31;
@@ -70,90 +79,64 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             for (int i = tid; i < n_pairs * 2048; i += kBlock) lds[kLdsFixed + i] = gf[i];
         }
     }
+    const int stream = blockIdx.x / a.chunks_per_stream;
+    const long c_in_s = blockIdx.x - (long)stream * a.chunks_per_stream;
+    const long T0 = c_in_s * a.frames_per_chunk;
+    long T1 = T0 + a.frames_per_chunk;
+    if (T1 > a.n_frames) T1 = a.n_frames;
+    if (T0 == 0) {  // stream start: the overlap partner of frame 0 is the carried state (out_buff[0], util.h:302)
+        for (int i = tid; i < kHop; i += kBlock) s_tails[i] = a.tail_in[(long)stream * kHop + i];
+    }
     __syncthreads();
     const float4 *wrow = reinterpret_cast<const float4 *>(s_win + lane * kPS);
-
-    const long chunk = (long)blockIdx.x * kHalves + hw;
-    int stream = (int)(chunk / a.chunks_per_stream);
-    const long c_in_s = chunk - (long)stream * a.chunks_per_stream;
-    const bool chunk_ok = stream < a.n_streams;
-    if (!chunk_ok) stream = a.n_streams - 1;  // keep addresses valid; stores are predicated
-    const long t0 = c_in_s * a.frames_per_chunk;
 
     const float *xs = a.x + (long)stream * a.stream_stride_x;
     const float *hs = a.hist_in + (long)stream * M * kHop;
     float *ys = a.y + (long)stream * a.n_frames * kHop;
 
-    float *s_tail = lds + kLdsFixed + NPL * 2048 + (PREFETCH ? (hw * 16) * 32 + lane : 0);  // [q][lane]
-    float tail[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) tail[q] = 0.f;
-    if (PREFETCH) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) s_tail[32 * q] = 0.f;
-    }
-
     float re[32], im[32], Sr[32], Si[32];
-    float xa[32], xb[32];  // raw samples of the NEXT pair, in flight while the current pair is transformed
+    const int n_iter = (int)((T1 - T0 + kHalves - 1) / kHalves);
 
-    // frame index handled at loop step `it` (step 0 = warm-up frame), clamped into the batch
-    auto frame_of = [&](int it) -> long {
-        long t = t0 - 1 + it;
-        if (t < 0) t = 0;
-        if (t > a.n_frames - 1) t = a.n_frames - 1;
-        return t;
-    };
-    auto issue_loads = [&](long tc, int p) {
-        const int ma = 2 * p;
-        const int mb = (2 * p + 1 < M) ? 2 * p + 1 : ma;
-        if (LAYOUT == 0) {
-            const float *a1 = (tc >= 1 ? xs + (long)ma * a.mic_stride + (tc - 1) * kHop : hs + ma * kHop) + lane;
-            const float *b1 = (tc >= 1 ? xs + (long)mb * a.mic_stride + (tc - 1) * kHop : hs + mb * kHop) + lane;
-            const float *a2 = xs + (long)ma * a.mic_stride + tc * kHop + lane;
-            const float *b2 = xs + (long)mb * a.mic_stride + tc * kHop + lane;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                xa[j] = a1[32 * j];
-                xb[j] = b1[32 * j];
-                xa[j + 16] = a2[32 * j];
-                xb[j + 16] = b2[32 * j];
-            }
-        } else {
-            const float *s1 = (tc >= 1 ? xs + (tc - 1) * (long)kHop * M : hs) + (long)lane * M;
-            const float *s2 = xs + tc * (long)kHop * M + (long)lane * M;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                xa[j] = s1[(long)32 * j * M + ma];
-                xb[j] = s1[(long)32 * j * M + mb];
-                xa[j + 16] = s2[(long)32 * j * M + ma];
-                xb[j + 16] = s2[(long)32 * j * M + mb];
-            }
-        }
-    };
-
-    if (PREFETCH) issue_loads(frame_of(0), 0);
-
-    for (int it = 0; it <= a.frames_per_chunk; ++it) {
-        const long t = t0 - 1 + it;  // it == 0: warm-up frame (overlap tail only)
-        const bool store = chunk_ok && it > 0 && t < a.n_frames;
+    for (int it = 0; it < n_iter; ++it) {
+        const long t = T0 + (long)it * kHalves + hw;
+        const bool valid = t < T1;
+        const long tc = valid ? t : T1 - 1;
 
         for (int p = 0; p < n_pairs; ++p) {
-            const float bscale = (2 * p + 1 < M) ? 1.f : 0.f;
-            if (!PREFETCH) issue_loads(frame_of(it), p);
+            const int ma = 2 * p;
+            const bool b_ok = (2 * p + 1) < M;
+            const int mb = b_ok ? 2 * p + 1 : ma;
+            const float bscale = b_ok ? 1.f : 0.f;
+            if (LAYOUT == 0) {
+                const float *a1 = (tc >= 1 ? xs + (long)ma * a.mic_stride + (tc - 1) * kHop : hs + ma * kHop) + lane;
+                const float *b1 = (tc >= 1 ? xs + (long)mb * a.mic_stride + (tc - 1) * kHop : hs + mb * kHop) + lane;
+                const float *a2 = xs + (long)ma * a.mic_stride + tc * kHop + lane;
+                const float *b2 = xs + (long)mb * a.mic_stride + tc * kHop + lane;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    re[j] = a1[32 * j];
+                    im[j] = b1[32 * j];
+                    re[j + 16] = a2[32 * j];
+                    im[j + 16] = b2[32 * j];
+                }
+            } else {
+                const float *s1 = (tc >= 1 ? xs + (tc - 1) * (long)kHop * M : hs) + (long)lane * M;
+                const float *s2 = xs + tc * (long)kHop * M + (long)lane * M;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    re[j] = s1[(long)32 * j * M + ma];
+                    im[j] = s1[(long)32 * j * M + mb];
+                    re[j + 16] = s2[(long)32 * j * M + ma];
+                    im[j + 16] = s2[(long)32 * j * M + mb];
+                }
+            }
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const float4 hv = wrow[g];
-                re[4 * g + 0] = xa[4 * g + 0] * hv.x; im[4 * g + 0] = xb[4 * g + 0] * (hv.x * bscale);
-                re[4 * g + 1] = xa[4 * g + 1] * hv.y; im[4 * g + 1] = xb[4 * g + 1] * (hv.y * bscale);
-                re[4 * g + 2] = xa[4 * g + 2] * hv.z; im[4 * g + 2] = xb[4 * g + 2] * (hv.z * bscale);
-                re[4 * g + 3] = xa[4 * g + 3] * hv.w; im[4 * g + 3] = xb[4 * g + 3] * (hv.w * bscale);
-            }
-            // prefetch the next pair (same frame) or pair 0 of the next frame
-            if (PREFETCH) {
-                if (p + 1 < n_pairs)
-                    issue_loads(frame_of(it), p + 1);
-                else if (it < a.frames_per_chunk)
-                    issue_loads(frame_of(it + 1), 0);
+                re[4 * g + 0] *= hv.x; im[4 * g + 0] *= hv.x * bscale;
+                re[4 * g + 1] *= hv.y; im[4 * g + 1] *= hv.y * bscale;
+                re[4 * g + 2] *= hv.z; im[4 * g + 2] *= hv.z * bscale;
+                re[4 * g + 3] *= hv.w; im[4 * g + 3] *= hv.w * bscale;
             }
 
             fft1024p_fwd_A<float>(re, im, lane, s_tw, pbuf);
@@ -185,7 +168,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             }
         }
 
-        if (a.sdump != nullptr && store) {
+        if (a.sdump != nullptr && valid) {
             f32x2 *sd = a.sdump + ((long)stream * a.n_frames + t) * kNfft + lane;
 #pragma unroll
             for (int i = 0; i < 32; ++i) sd[32 * brev5(i)] = f32x2{Sr[i], Si[i]};
@@ -207,41 +190,51 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             const float4 hv = wrow[g];
             h[4 * g + 0] = hv.x; h[4 * g + 1] = hv.y; h[4 * g + 2] = hv.z; h[4 * g + 3] = hv.w;
         }
-        if (PREFETCH) {
+        // second half of this frame -> ring slot hw+1 (the partner of frame t+1's first half)
+        float *my_slot = s_tails + (hw + 1) * kHop + lane;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) tail[q] = s_tail[32 * q];
-        }
-        if (store) {
+        for (int q = 0; q < 16; ++q) my_slot[32 * brev5(2 * q)] = Sr[2 * q + 1] * h[brev5(2 * q + 1)];
+        __syncthreads();
+        if (valid) {
             float *yo = ys + t * kHop + lane;
+            const float *prev = s_tails + hw * kHop + lane;  // frame t-1: neighbour, or slot 0 for hw == 0
+            if (t == T0 && T0 > 0) {
+                // first hop of the run: the previous run adds its half separately (both into a zeroed hop)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) yo[32 * brev5(2 * q)] = tail[q] + Sr[2 * q] * h[brev5(2 * q)];
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) tail[q] = Sr[2 * q + 1] * h[brev5(2 * q + 1)];
-
-        if (it == 0 && t0 == 0) {  // stream start: overlap tail comes from the carried state
-            const float *ti = a.tail_in + (long)stream * kHop + lane;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) tail[q] = ti[32 * brev5(2 * q)];
-        }
-        if (PREFETCH) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) s_tail[32 * q] = tail[q];
-        }
-        if (store && t == a.n_frames - 1) {
-            // carried state for the next call: OLA tail (out_buff[0]) and the last input hop (ring buffer)
-            float *to = a.tail_out + (long)stream * kHop + lane;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) to[32 * brev5(2 * q)] = tail[q];
-            float *ho = a.hist_out + (long)stream * M * kHop;
-            if (LAYOUT == 0) {
-                for (int m = 0; m < M; ++m)
-                    for (int j = 0; j < 16; ++j)
-                        ho[m * kHop + 32 * j + lane] = xs[(long)m * a.mic_stride + t * kHop + 32 * j + lane];
+                for (int q = 0; q < 16; ++q) atomicAdd(yo + 32 * brev5(2 * q), Sr[2 * q] * h[brev5(2 * q)]);
             } else {
-                for (int j = 0; j < 16 * M; ++j) ho[32 * j + lane] = xs[t * (long)kHop * M + 32 * j + lane];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) yo[32 * brev5(2 * q)] = prev[32 * brev5(2 * q)] + Sr[2 * q] * h[brev5(2 * q)];
+            }
+            if (t == T1 - 1) {
+                if (T1 < a.n_frames) {  // last frame of the run: its second half belongs to the next run's first hop
+                    float *yn = ys + T1 * kHop + lane;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) atomicAdd(yn + 32 * brev5(2 * q), Sr[2 * q + 1] * h[brev5(2 * q + 1)]);
+                } else {
+                    // end of the batch: carried state for the next call (OLA tail and the last input hop)
+                    float *to = a.tail_out + (long)stream * kHop + lane;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) to[32 * brev5(2 * q)] = Sr[2 * q + 1] * h[brev5(2 * q + 1)];
+                    float *ho = a.hist_out + (long)stream * M * kHop;
+                    if (LAYOUT == 0) {
+                        for (int m = 0; m < M; ++m)
+                            for (int j = 0; j < 16; ++j)
+                                ho[m * kHop + 32 * j + lane] = xs[(long)m * a.mic_stride + t * kHop + 32 * j + lane];
+                    } else {
+                        for (int j = 0; j < 16 * M; ++j) ho[32 * j + lane] = xs[t * (long)kHop * M + 32 * j + lane];
+                    }
+                }
             }
         }
+        __syncthreads();
+        if (hw == kHalves - 1) {  // carry: frame t0+16*it+15 is the partner of the next iteration's first frame
+            const float *src = s_tails + kHalves * kHop + lane;
+            float *dst = s_tails + lane;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) dst[32 * q] = src[32 * q];
+        }
+        // the next iteration's first __syncthreads orders this copy before slot 0 is read
     }
 }
 
@@ -259,29 +252,34 @@ __global__ void das_hermitian_dump_kernel(const f32x2 *s, f64x2 *out, long total
 template <int LAYOUT>
 void launch_layout(const DasFusedArgs &a, unsigned blocks, hipStream_t stream) {
     const int np = (a.n_mics + 1) / 2;
-    // BF_DAS_PREFETCH=1 selects the register-prefetch build (slower today: it spills at 256 VGPRs)
-    static const bool pf = getenv("BF_DAS_PREFETCH") && atoi(getenv("BF_DAS_PREFETCH")) != 0;
-    if (pf && np <= 4) {
-        hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 4, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
-        return;
-    }
     if (np <= 1)
         hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 1>), dim3(blocks), dim3(kBlock), 0, stream, a);
     else if (np <= 2)
         hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 2>), dim3(blocks), dim3(kBlock), 0, stream, a);
     else if (np <= 4)
         hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 4>), dim3(blocks), dim3(kBlock), 0, stream, a);
-    else if (np <= 8)
-        hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 8>), dim3(blocks), dim3(kBlock), 0, stream, a);
-    else  // > 16 mics: the gain tables no longer fit beside the transpose buffers
+    else  // > 8 mics: the gain tables no longer fit beside the transpose buffers and the tail ring
         hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 0>), dim3(blocks), dim3(kBlock), 0, stream, a);
 }
 
 }  // namespace
 
+// Runs are multiples of 16 frames; the first hop of every run but the first of a stream is completed by
+// atomic adds and must be zero beforehand (prepare_das_fused).
+hipError_t prepare_das_fused(const DasFusedArgs &a, hipStream_t stream) {
+    if (a.chunks_per_stream > 1) {
+        for (int s = 0; s < a.n_streams; ++s) {
+            hipError_t e = hipMemset2DAsync(a.y + ((long)s * a.n_frames + a.frames_per_chunk) * kHop,
+                                            (size_t)a.frames_per_chunk * kHop * sizeof(float), 0, kHop * sizeof(float),
+                                            (size_t)a.chunks_per_stream - 1, stream);
+            if (e != hipSuccess) return e;
+        }
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t stream) {
-    const long chunks = (long)a.chunks_per_stream * a.n_streams;
-    const unsigned blocks = (unsigned)((chunks + kHalves - 1) / kHalves);
+    const unsigned blocks = (unsigned)((long)a.chunks_per_stream * a.n_streams);
     if (a.layout == 0)
         launch_layout<0>(a, blocks, stream);
     else

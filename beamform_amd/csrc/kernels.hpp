@@ -29,6 +29,7 @@ struct DasFusedArgs {
     int chunks_per_stream;
     int layout;            // bf_layout
 };
+hipError_t prepare_das_fused(const DasFusedArgs &a, hipStream_t stream);  // zero the atomically-completed hops
 hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t stream);
 
 // S dump -> Hermitian part of the reference's y_fft as double2 [frames][1024]
