@@ -19,7 +19,7 @@
 // Compiler scheduling fence (no instruction): keeps the scheduler from hoisting a whole table's worth of
 // LDS/global loads above the arithmetic that frees their registers.
 #if defined(__HIP_DEVICE_COMPILE__)
-#define BF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define BF_SCHED_FENCE() ((void)0)  // disabled: see DESIGN.md (fences cost more in exposed LDS latency than they saved)
 #else
 #define BF_SCHED_FENCE() ((void)0)
 #endif
@@ -70,71 +70,61 @@ constexpr double sin32(int k) {
     return t[k];
 }
 
-// (xr + i xi) * exp(DIR * 2*pi*i * k / 32), k in [0,16) known after unrolling.
+BF_HD float bf_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+BF_HD double bf_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// Decimation-in-time butterfly with the twiddle fused into the additions (Linzer-Feig form):
+//   (a, b) -> (a + w b, a - w b),  w = exp(DIR * 2*pi*i * k / 32),  k in [0,16) known after unrolling.
+// With rho = Im(w)/Re(w) (or its reciprocal when |Re w| < |Im w|) the general case is 6 FMAs instead
+// of a 4-op complex multiply plus 4 additions; trivial twiddles stay pure additions.
 // DIR = -1: forward (FFTW_FORWARD sign), +1: backward.
 template <typename T, int DIR>
-BF_HD void mul_w32(int k, T xr, T xi, T &yr, T &yi) {
+BF_HD void bfly_dit(int k, T &ar, T &ai, T &br, T &bi) {
+    const T xr = br, xi = bi, pr = ar, pi = ai;
     if (k == 0) {
-        yr = xr;
-        yi = xi;
-    } else if (k == 8) {  // exp(DIR*i*pi/2) = DIR*i
+        ar = pr + xr;
+        ai = pi + xi;
+        br = pr - xr;
+        bi = pi - xi;
+    } else if (k == 8) {  // w = DIR * i
         if (DIR < 0) {
-            yr = xi;
-            yi = -xr;
+            ar = pr + xi;
+            ai = pi - xr;
+            br = pr - xi;
+            bi = pi + xr;
         } else {
-            yr = -xi;
-            yi = xr;
+            ar = pr - xi;
+            ai = pi + xr;
+            br = pr + xi;
+            bi = pi - xr;
         }
-    } else if (k == 4) {  // (1 + DIR*i)/sqrt2
-        const T r = (T)0.70710678118654752440084436210485;
-        if (DIR < 0) {
-            yr = (xr + xi) * r;
-            yi = (xi - xr) * r;
-        } else {
-            yr = (xr - xi) * r;
-            yi = (xr + xi) * r;
-        }
-    } else if (k == 12) {  // (-1 + DIR*i)/sqrt2
-        const T r = (T)0.70710678118654752440084436210485;
-        if (DIR < 0) {
-            yr = (xi - xr) * r;
-            yi = -(xr + xi) * r;
-        } else {
-            yr = -(xr + xi) * r;
-            yi = (xr - xi) * r;
-        }
-    } else {
+    } else if (k <= 4 || k >= 12) {  // |Re w| >= |Im w|
         const T c = (T)cos32(k);
-        const T s = (T)(DIR * sin32(k));
-        yr = xr * c - xi * s;
-        yi = xr * s + xi * c;
+        const T rho = (T)(DIR * sin32(k) / cos32(k));
+        const T u = bf_fma(-rho, xi, xr);
+        const T v = bf_fma(rho, xr, xi);
+        ar = bf_fma(c, u, pr);
+        ai = bf_fma(c, v, pi);
+        br = bf_fma(-c, u, pr);
+        bi = bf_fma(-c, v, pi);
+    } else {  // |Re w| < |Im w|: factor Im w instead
+        const T sn = (T)(DIR * sin32(k));
+        const T rho = (T)(cos32(k) / (DIR * sin32(k)));
+        const T u = bf_fma(rho, xr, -xi);
+        const T v = bf_fma(rho, xi, xr);
+        ar = bf_fma(sn, u, pr);
+        ai = bf_fma(sn, v, pi);
+        br = bf_fma(-sn, u, pr);
+        bi = bf_fma(-sn, v, pi);
     }
 }
 
-// Decimation in frequency: natural-order input, output X[brev5(i)] at position i.
-template <typename T, int DIR>
-BF_HD void fft32_dif(T (&re)[32], T (&im)[32]) {
-#pragma unroll
-    for (int s = 0; s < 5; ++s) {
-        const int half = 16 >> s;
-        const int tstep = 1 << s;
-#pragma unroll
-        for (int blk = 0; blk < 32; blk += 2 * half) {
-#pragma unroll
-            for (int j = 0; j < half; ++j) {
-                const int a = blk + j, b = a + half;
-                const T ar = re[a], ai = im[a], br = re[b], bi = im[b];
-                re[a] = ar + br;
-                im[a] = ai + bi;
-                mul_w32<T, DIR>(j * tstep, ar - br, ai - bi, re[b], im[b]);
-            }
-        }
-    }
-}
-
-// Decimation in time: input x[brev5(i)] at position i, natural-order output.
-template <typename T, int DIR>
-BF_HD void fft32_dit(T (&re)[32], T (&im)[32]) {
+// In-place radix-2 DIT on logical positions; PERM maps a logical position to the physical
+// register.  Logical input L[i] = x[brev5(i)], logical output L[k] = X[k].
+//   PERM = identity: physical in = bit-reversed, out = natural          (fft32_dit)
+//   PERM = brev5   : physical in = natural,      out = X[brev5(i)] at i (fft32_dif's contract)
+template <typename T, int DIR, bool PERM_BREV>
+BF_HD void fft32_core(T (&re)[32], T (&im)[32]) {
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
         const int half = 1 << s;
@@ -143,17 +133,25 @@ BF_HD void fft32_dit(T (&re)[32], T (&im)[32]) {
         for (int blk = 0; blk < 32; blk += 2 * half) {
 #pragma unroll
             for (int j = 0; j < half; ++j) {
-                const int a = blk + j, b = a + half;
-                T tr, ti;
-                mul_w32<T, DIR>(j * tstep, re[b], im[b], tr, ti);
-                const T ar = re[a], ai = im[a];
-                re[a] = ar + tr;
-                im[a] = ai + ti;
-                re[b] = ar - tr;
-                im[b] = ai - ti;
+                const int la = blk + j, lb = la + half;
+                const int a = PERM_BREV ? brev5(la) : la;
+                const int b = PERM_BREV ? brev5(lb) : lb;
+                bfly_dit<T, DIR>(j * tstep, re[a], im[a], re[b], im[b]);
             }
         }
     }
+}
+
+// natural-order input, output X[brev5(i)] at position i
+template <typename T, int DIR>
+BF_HD void fft32_dif(T (&re)[32], T (&im)[32]) {
+    fft32_core<T, DIR, true>(re, im);
+}
+
+// input x[brev5(i)] at position i, natural-order output
+template <typename T, int DIR>
+BF_HD void fft32_dit(T (&re)[32], T (&im)[32]) {
+    fft32_core<T, DIR, false>(re, im);
 }
 
 }  // namespace bf

@@ -13,6 +13,7 @@ ap.add_argument("--frames", type=int, default=65536)
 ap.add_argument("--streams", type=int, default=1)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--layout", default="planar")
+ap.add_argument("--warmup", type=int, default=10)
 a = ap.parse_args()
 interf = (-60.0, 90.0, 150.0) if a.algo in ("lcmv", "gss") else ()
 p = make_params(a.algo, n_mics=a.mics, interf=interf)
@@ -21,5 +22,8 @@ bf = Beamformer(p, n_streams=a.streams, layout=lay)
 shape = (a.streams, a.mics, a.frames * 512) if lay == BF_PLANAR else (a.streams, a.frames * 512, a.mics)
 x = torch.rand(shape, device="cuda") - 0.5
 y = torch.empty((a.streams, a.frames * 512), device="cuda")
+for _ in range(a.warmup):
+    bf.process_device(x.data_ptr(), a.frames, y.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
 ms, msk = bf.time_device(x.data_ptr(), a.frames, y.data_ptr(), a.iters, torch.cuda.current_stream().cuda_stream)
 print(f"{a.algo} M={a.mics} F={a.frames} S={a.streams}: call {ms:.4f} ms, kernel {msk:.4f} ms, {a.frames*a.streams/ms/1e3:.3f} Mframes/s")
