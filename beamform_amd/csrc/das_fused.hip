@@ -120,14 +120,27 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                     im[j + 16] = b2[32 * j];
                 }
             } else {
+                // interleaved [sample][mic]: the two mics of a pair are adjacent -> one 8-byte load per sample
                 const float *s1 = (tc >= 1 ? xs + (tc - 1) * (long)kHop * M : hs) + (long)lane * M;
                 const float *s2 = xs + tc * (long)kHop * M + (long)lane * M;
+                if (b_ok && (M & 1) == 0) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    re[j] = s1[(long)32 * j * M + ma];
-                    im[j] = s1[(long)32 * j * M + mb];
-                    re[j + 16] = s2[(long)32 * j * M + ma];
-                    im[j + 16] = s2[(long)32 * j * M + mb];
+                    for (int j = 0; j < 16; ++j) {
+                        const float2 u = *reinterpret_cast<const float2 *>(s1 + (long)32 * j * M + ma);
+                        const float2 w = *reinterpret_cast<const float2 *>(s2 + (long)32 * j * M + ma);
+                        re[j] = u.x;
+                        im[j] = u.y;
+                        re[j + 16] = w.x;
+                        im[j + 16] = w.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        re[j] = s1[(long)32 * j * M + ma];
+                        im[j] = s1[(long)32 * j * M + mb];
+                        re[j + 16] = s2[(long)32 * j * M + ma];
+                        im[j + 16] = s2[(long)32 * j * M + mb];
+                    }
                 }
             }
 #pragma unroll
