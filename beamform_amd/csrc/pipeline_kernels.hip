@@ -36,6 +36,17 @@ __device__ __forceinline__ cd cdiv(cd a, cd b) {
     const double r = b.x / b.y, d = b.x * r + b.y;
     return cd{(a.x * r + a.y) / d, (a.y * r - a.x) / d};
 }
+// acc - a * conj(b) and acc + a * conj(b), four FMAs each
+__device__ __forceinline__ cd cfms_conj(cd acc, cd a, cd b) {
+    return cd{fma(-a.y, b.y, fma(-a.x, b.x, acc.x)), fma(a.x, b.y, fma(-a.y, b.x, acc.y))};
+}
+__device__ __forceinline__ cd cfma_conj(cd acc, cd a, cd b) {
+    return cd{fma(a.y, b.y, fma(a.x, b.x, acc.x)), fma(-a.x, b.y, fma(a.y, b.x, acc.y))};
+}
+// acc - a * b
+__device__ __forceinline__ cd cfms(cd acc, cd a, cd b) {
+    return cd{fma(a.y, b.y, fma(-a.x, b.x, acc.x)), fma(-a.y, b.x, fma(-a.x, b.y, acc.y))};
+}
 __device__ __forceinline__ cd ld(const f64x2 *p) {
     const f64x2 v = *p;
     return cd{v.x, v.y};
@@ -503,7 +514,7 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
 #pragma unroll
         for (int i = 0; i < MP; ++i)
 #pragma unroll
-            for (int c = 0; c <= i; ++c) R[i * (i + 1) / 2 + c] = R[i * (i + 1) / 2 + c] + X[i] * conj(X[c]);
+            for (int c = 0; c <= i; ++c) R[i * (i + 1) / 2 + c] = cfma_conj(R[i * (i + 1) / 2 + c], X[i], X[c]);
     }
     for (long t = tA; t < tB; ++t) {
         cd X[MP];
@@ -534,22 +545,22 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
             for (int i = jj + 1; i < MP; ++i) {
                 const cd Lij = A[i * (i + 1) / 2 + jj] * inv;
                 A[i * (i + 1) / 2 + jj] = Lij;
-                ua[i] = ua[i] - Lij * ua[jj];
-                ux[i] = ux[i] - Lij * ux[jj];
+                ua[i] = cfms(ua[i], Lij, ua[jj]);
+                ux[i] = cfms(ux[i], Lij, ux[jj]);
             }
 #pragma unroll
             for (int c = jj + 1; c < MP; ++c) {
-                const cd Lc = conj(A[c * (c + 1) / 2 + jj]);
+                const cd Lc = A[c * (c + 1) / 2 + jj];
 #pragma unroll
                 for (int i = c; i < MP; ++i)
-                    A[i * (i + 1) / 2 + c] = A[i * (i + 1) / 2 + c] - A[i * (i + 1) / 2 + jj] * Lc;
+                    A[i * (i + 1) / 2 + c] = cfms_conj(A[i * (i + 1) / 2 + c], A[i * (i + 1) / 2 + jj], Lc);
             }
         }
         cd num{0, 0};
         double den = 0.0;
 #pragma unroll
         for (int i = 0; i < MP; ++i) {
-            num = num + conj(ua[i]) * ux[i];
+            num = cfma_conj(num, ux[i], ua[i]);
             den += norm2(ua[i]);
         }
         cd y = cd{num.x / den, num.y / den};
@@ -564,7 +575,7 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
         for (int i = 0; i < MP; ++i)
 #pragma unroll
             for (int c = 0; c <= i; ++c)
-                R[i * (i + 1) / 2 + c] = R[i * (i + 1) / 2 + c] + X[i] * conj(X[c]) - Xo[i] * conj(Xo[c]);
+                R[i * (i + 1) / 2 + c] = cfms_conj(cfma_conj(R[i * (i + 1) / 2 + c], X[i], X[c]), Xo[i], Xo[c]);
     }
 }
 
@@ -647,7 +658,7 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
         s_x[grp][i] = x;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int c = 0; c < MP; ++c) R[c] = R[c] + x * conj(s_x[grp][c]);
+        for (int c = 0; c < MP; ++c) R[c] = cfma_conj(R[c], x, s_x[grp][c]);
         __builtin_amdgcn_wave_barrier();
     }
 
@@ -658,7 +669,7 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
         s_xo[grp][i] = xo;
         __builtin_amdgcn_wave_barrier();
         double mag = 0.0;
-        for (int m = 0; m < M; ++m) mag += cabs(s_x[grp][m]);
+        for (int m = 0; m < M; ++m) mag += sqrt(norm2(s_x[grp][m]));
         mag /= (double)((unsigned)M * 1024u);
         cd y;
         if (mag > a.cfg.freq_mag_threshold) {
@@ -685,15 +696,14 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
                     for (int r = 0; r < NB; ++r) s_u[grp][r][0] = b[r];
                 }
                 __builtin_amdgcn_wave_barrier();
-                const double d = sqrt(s_col[grp][jj].x);
-                const double inv = 1.0 / d;
+                const double inv = rsqrt(s_col[grp][jj].x);  // 1 / L_jj
                 const cd Lij = A[jj] * inv;
                 if (i > jj) {
 #pragma unroll
                     for (int c = jj + 1; c < MP; ++c)
-                        if (c <= i) A[c] = A[c] - Lij * conj(s_col[grp][c] * inv);
+                        if (c <= i) A[c] = cfms_conj(A[c], Lij, s_col[grp][c] * inv);
 #pragma unroll
-                    for (int r = 0; r < NB; ++r) b[r] = b[r] - Lij * (s_u[grp][r][0] * inv);
+                    for (int r = 0; r < NB; ++r) b[r] = cfms(b[r], Lij, s_u[grp][r][0] * inv);
                 } else if (i == jj) {
 #pragma unroll
                     for (int r = 0; r < NB; ++r) b[r] = b[r] * inv;
@@ -716,7 +726,7 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
                     r2 = KM;
                 }
                 cd acc{0, 0};
-                for (int m = 0; m < M; ++m) acc = acc + conj(s_u[grp][r][m]) * s_u[grp][r2][m];
+                for (int m = 0; m < M; ++m) acc = cfma_conj(acc, s_u[grp][r2][m], s_u[grp][r][m]);
                 s_e[grp][e] = acc;
             }
             __builtin_amdgcn_wave_barrier();
@@ -770,7 +780,7 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
         if (i == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
         // slide the covariance window: + x_t x_t^H - x_{t-P} x_{t-P}^H (mvdr.cpp:100-101)
 #pragma unroll
-        for (int c = 0; c < MP; ++c) R[c] = R[c] + x * conj(s_x[grp][c]) - xo * conj(s_xo[grp][c]);
+        for (int c = 0; c < MP; ++c) R[c] = cfms_conj(cfma_conj(R[c], x, s_x[grp][c]), xo, s_xo[grp][c]);
         __builtin_amdgcn_wave_barrier();
     }
 }
