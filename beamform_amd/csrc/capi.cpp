@@ -41,6 +41,9 @@ struct bf_handle {
     f32x2 *d_gains[2] = {nullptr, nullptr};
     int gains_cur = 0;
     f32x2 *d_twiddle = nullptr;
+    f32x2 *d_twiddle_w64 = nullptr;
+    f32x2 *d_gains_w64[2] = {nullptr, nullptr};
+    bool use_w64 = false;
     float *d_window = nullptr;
     float *d_zeros = nullptr;
     float *d_hist[2] = {nullptr, nullptr};  // the hop before the next frame (the reference's ring buffer content)
@@ -99,6 +102,9 @@ int sync_tables(bf_handle *h, hipStream_t s) {
         std::vector<f32x2> g = das_pair_gains(h->steer, (h->M + 1) / 2);
         const int nxt = h->gains_cur ^ 1;
         BF_HIP(h, hipMemcpyAsync(h->d_gains[nxt], g.data(), g.size() * sizeof(f32x2), hipMemcpyHostToDevice, s));
+        std::vector<f32x2> g64 = das_pair_gains_w64(g, (h->M + 1) / 2);
+        BF_HIP(h, hipMemcpyAsync(h->d_gains_w64[nxt], g64.data(), g64.size() * sizeof(f32x2), hipMemcpyHostToDevice, s));
+        BF_HIP(h, hipStreamSynchronize(s));  // pageable staging vectors go out of scope
         h->gains_cur = nxt;
     }
     if (h->pipe) {
@@ -139,8 +145,8 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     a.y = y_dev;
     a.tail_in = h->d_tail[h->tail_cur];
     a.tail_out = h->d_tail[h->tail_cur ^ 1];
-    a.gains = h->d_gains[h->gains_cur];
-    a.twiddle = h->d_twiddle;
+    a.gains = h->use_w64 ? h->d_gains_w64[h->gains_cur] : h->d_gains[h->gains_cur];
+    a.twiddle = h->use_w64 ? h->d_twiddle_w64 : h->d_twiddle;
     a.window = h->d_window;
     a.zeros = h->d_zeros;
     a.sdump = spectrum_dev ? h->d_sdump : nullptr;
@@ -160,7 +166,7 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
         h->kernel_events->push_back(std::make_pair(k0, k1));
         BF_HIP(h, hipEventRecord(k0, s));
     }
-    BF_HIP(h, launch_das_fused(a, s));
+    BF_HIP(h, h->use_w64 ? launch_das_fused_w64(a, s) : launch_das_fused(a, s));
     if (k1) BF_HIP(h, hipEventRecord(k1, s));
     h->tail_cur ^= 1;
 
@@ -279,6 +285,14 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
         const size_t gsz = (size_t)((h->M + 1) / 2) * 1024;
         BF_CREATE_HIP(hipMalloc((void **)&h->d_gains[0], gsz * sizeof(f32x2)));
         BF_CREATE_HIP(hipMalloc((void **)&h->d_gains[1], gsz * sizeof(f32x2)));
+        BF_CREATE_HIP(hipMalloc((void **)&h->d_gains_w64[0], gsz * sizeof(f32x2)));
+        BF_CREATE_HIP(hipMalloc((void **)&h->d_gains_w64[1], gsz * sizeof(f32x2)));
+        {
+            std::vector<f32x2> tw64 = twiddle_table_w64();
+            BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle_w64, tw64.size() * sizeof(f32x2)));
+            BF_CREATE_HIP(hipMemcpy(h->d_twiddle_w64, tw64.data(), tw64.size() * sizeof(f32x2), hipMemcpyHostToDevice));
+        }
+        h->use_w64 = getenv("BF_DAS_W64") && atoi(getenv("BF_DAS_W64")) != 0;
         std::vector<f32x2> tw = twiddle_table_32x32<f32x2>();
         BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle, tw.size() * sizeof(f32x2)));
         BF_CREATE_HIP(hipMemcpy(h->d_twiddle, tw.data(), tw.size() * sizeof(f32x2), hipMemcpyHostToDevice));
@@ -323,10 +337,12 @@ void bf_destroy(bf_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int i = 0; i < 2; ++i) {
         if (h->d_gains[i]) (void)hipFree(h->d_gains[i]);
+        if (h->d_gains_w64[i]) (void)hipFree(h->d_gains_w64[i]);
         if (h->d_tail[i]) (void)hipFree(h->d_tail[i]);
         if (h->d_hist[i]) (void)hipFree(h->d_hist[i]);
     }
     if (h->d_twiddle) (void)hipFree(h->d_twiddle);
+    if (h->d_twiddle_w64) (void)hipFree(h->d_twiddle_w64);
     if (h->d_window) (void)hipFree(h->d_window);
     if (h->d_zeros) (void)hipFree(h->d_zeros);
     if (h->d_sdump) (void)hipFree(h->d_sdump);

@@ -15,6 +15,7 @@
 #include <complex>
 #include <vector>
 
+#include "fft1024_w64.hpp"
 #include "fft32.hpp"
 
 namespace bf {
@@ -155,6 +156,39 @@ inline std::vector<f32x2> das_pair_gains(const SteeringSet &s, int n_pairs_alloc
                 D[((size_t)p * 32 + i) * 32 + l] = f32x2{(float)d.real(), (float)d.imag()};
             }
     return D;
+}
+
+
+// Same gains in the register/lane order of the 64-lane factorisation (fft1024_w64.hpp):
+// [pair][register r][lane] = D_p[w64_bin(lane, r)].
+inline std::vector<f32x2> das_pair_gains_w64(const std::vector<f32x2> &D32, int n_pairs) {
+    std::vector<f32x2> D((size_t)n_pairs * 1024);
+    for (int p = 0; p < n_pairs; ++p) {
+        // invert the 32x32 layout: position i, lane l -> bin l + 32*brev5(i)
+        std::vector<f32x2> nat(1024);
+        for (int i = 0; i < 32; ++i)
+            for (int l = 0; l < 32; ++l) nat[l + 32 * brev5(i)] = D32[((size_t)p * 32 + i) * 32 + l];
+        for (int r = 0; r < 16; ++r)
+            for (int l = 0; l < 64; ++l) D[((size_t)p * 16 + r) * 64 + l] = nat[w64_bin(l, r)];
+    }
+    return D;
+}
+
+// twiddles of the 64-lane factorisation: [0, 1024) = W1024^(k1*lane) laid out [k1][lane];
+// [1024, 1088) = W64^(b*k2) laid out [b][k2]
+inline std::vector<f32x2> twiddle_table_w64() {
+    std::vector<f32x2> t(1024 + 64);
+    for (int k = 0; k < 16; ++k)
+        for (int l = 0; l < 64; ++l) {
+            double a = -2.0 * kPi * (double)(k * l) / 1024.0;
+            t[k * 64 + l] = f32x2{(float)std::cos(a), (float)std::sin(a)};
+        }
+    for (int b = 0; b < 4; ++b)
+        for (int k = 0; k < 16; ++k) {
+            double a = -2.0 * kPi * (double)(b * k) / 64.0;
+            t[1024 + b * 16 + k] = f32x2{(float)std::cos(a), (float)std::sin(a)};
+        }
+    return t;
 }
 
 }  // namespace bf

@@ -29,6 +29,8 @@ struct DasFusedArgs {
     int chunks_per_stream;
     int layout;            // bf_layout
 };
+// 64-lane variant (das_fused_w64.hip): `gains` / `twiddle` must be the *_w64 tables
+hipError_t launch_das_fused_w64(const DasFusedArgs &a, hipStream_t stream);
 hipError_t prepare_das_fused(const DasFusedArgs &a, hipStream_t stream);  // zero the atomically-completed hops
 hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t stream);
 

@@ -19,7 +19,7 @@ def emul_lib():
     import ctypes
     so = os.path.join(ROOT, "tests", "host_emul", "libemul.so")
     src = os.path.join(ROOT, "tests", "host_emul", "emul.cpp")
-    hdrs = [os.path.join(ROOT, "beamform_amd", "csrc", f) for f in ("fft32.hpp", "fft1024.hpp", "geometry.hpp")]
+    hdrs = [os.path.join(ROOT, "beamform_amd", "csrc", f) for f in ("fft32.hpp", "fft1024.hpp", "fft1024_w64.hpp", "geometry.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
     return ctypes.CDLL(so)

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../beamform_amd/csrc/fft1024.hpp"
+#include "../../beamform_amd/csrc/fft1024_w64.hpp"
 #include "../../beamform_amd/csrc/geometry.hpp"
 
 using namespace bf;
@@ -55,6 +56,103 @@ static void fft1024_emul(const double *in, double *out, int dir) {
             }
         }
     }
+}
+
+
+// ---- 64-lane x 16-point factorisation (fft1024_w64.hpp) -----------------------------------------
+namespace {
+constexpr int kRS64 = 68;
+inline int brev2(int i) { return ((i & 1) << 1) | ((i >> 1) & 1); }
+
+// T1 forward: reg-position i (k1 = brev4(i)), lane 4a+b  ->  reg a, lane 4*k1+b
+template <typename T>
+void w64_T1_fwd(T (*re)[16], T (*im)[16]) {
+    static T br[16 * kRS64], bi[16 * kRS64];
+    for (int l = 0; l < 64; ++l)
+        for (int i = 0; i < 16; ++i) { br[brev4(i) * kRS64 + l] = re[l][i]; bi[brev4(i) * kRS64 + l] = im[l][i]; }
+    for (int l = 0; l < 64; ++l)
+        for (int a = 0; a < 16; ++a) { re[l][a] = br[(l >> 2) * kRS64 + 4 * a + (l & 3)]; im[l][a] = bi[(l >> 2) * kRS64 + 4 * a + (l & 3)]; }
+}
+template <typename T>
+void w64_T1_inv(T (*re)[16], T (*im)[16]) {
+    static T br[16 * kRS64], bi[16 * kRS64];
+    for (int l = 0; l < 64; ++l)
+        for (int a = 0; a < 16; ++a) { br[(l >> 2) * kRS64 + 4 * a + (l & 3)] = re[l][a]; bi[(l >> 2) * kRS64 + 4 * a + (l & 3)] = im[l][a]; }
+    for (int l = 0; l < 64; ++l)
+        for (int i = 0; i < 16; ++i) { re[l][i] = br[brev4(i) * kRS64 + l]; im[l][i] = bi[brev4(i) * kRS64 + l]; }
+}
+// T2 forward: position g' + 4*brev2(q) at lane (.., b)  ->  register 4*g + b at lane (.., q); g' = brev2(g)
+template <typename T>
+void w64_T2_fwd(T (*re)[16], T (*im)[16]) {
+    static T nr[64][16], ni[64][16];
+    for (int l = 0; l < 64; ++l)
+        for (int g = 0; g < 4; ++g)
+            for (int q = 0; q < 4; ++q) {
+                const int b = l & 3, src_pos = brev2(g) + 4 * brev2(q), dl = (l & ~3) | q;
+                nr[dl][4 * g + b] = re[l][src_pos];
+                ni[dl][4 * g + b] = im[l][src_pos];
+            }
+    memcpy(re, nr, sizeof(nr));
+    memcpy(im, ni, sizeof(ni));
+}
+template <typename T>
+void w64_T2_inv(T (*re)[16], T (*im)[16]) {
+    static T nr[64][16], ni[64][16];
+    for (int l = 0; l < 64; ++l)
+        for (int g = 0; g < 4; ++g)
+            for (int b = 0; b < 4; ++b) {
+                const int q = l & 3, dst_pos = brev2(g) + 4 * brev2(q), dl = (l & ~3) | b;
+                nr[dl][dst_pos] = re[l][4 * g + b];
+                ni[dl][dst_pos] = im[l][4 * g + b];
+            }
+    memcpy(re, nr, sizeof(nr));
+    memcpy(im, ni, sizeof(ni));
+}
+
+template <typename T>
+void fft1024_w64_emul(const double *in, double *out, int dir) {
+    std::vector<cx<T>> tw1(16 * 64), tw2(4 * 16);
+    for (int k = 0; k < 16; ++k)
+        for (int l = 0; l < 64; ++l) {
+            double a = -2.0 * kPi * (k * l) / 1024.0;
+            tw1[k * 64 + l] = cx<T>{(T)std::cos(a), (T)std::sin(a)};
+        }
+    for (int b = 0; b < 4; ++b)
+        for (int k = 0; k < 16; ++k) {
+            double a = -2.0 * kPi * (b * k) / 64.0;
+            tw2[b * 16 + k] = cx<T>{(T)std::cos(a), (T)std::sin(a)};
+        }
+    static T re[64][16], im[64][16];
+    if (dir < 0) {
+        for (int l = 0; l < 64; ++l) {
+            for (int j = 0; j < 16; ++j) { re[l][j] = (T)in[2 * (64 * j + l)]; im[l][j] = (T)in[2 * (64 * j + l) + 1]; }
+            w64_fwd_p1<T>(re[l], im[l], l, tw1.data());
+        }
+        w64_T1_fwd<T>(re, im);
+        for (int l = 0; l < 64; ++l) w64_fwd_p2<T>(re[l], im[l], l, tw2.data());
+        w64_T2_fwd<T>(re, im);
+        for (int l = 0; l < 64; ++l) {
+            w64_fwd_p3<T>(re[l], im[l]);
+            for (int r = 0; r < 16; ++r) { out[2 * w64_bin(l, r)] = re[l][r]; out[2 * w64_bin(l, r) + 1] = im[l][r]; }
+        }
+    } else {
+        for (int l = 0; l < 64; ++l) {
+            for (int r = 0; r < 16; ++r) { re[l][r] = (T)in[2 * w64_bin(l, r)]; im[l][r] = (T)in[2 * w64_bin(l, r) + 1]; }
+            w64_inv_p3<T>(re[l], im[l]);
+        }
+        w64_T2_inv<T>(re, im);
+        for (int l = 0; l < 64; ++l) w64_inv_p2<T>(re[l], im[l], l, tw2.data());
+        w64_T1_inv<T>(re, im);
+        for (int l = 0; l < 64; ++l) {
+            w64_inv_p1<T>(re[l], im[l], l, tw1.data());
+            for (int j = 0; j < 16; ++j) { out[2 * (64 * j + l)] = re[l][j]; out[2 * (64 * j + l) + 1] = im[l][j]; }
+        }
+    }
+}
+}  // namespace
+
+extern "C" void emul_fft1024_w64(const double *in, double *out, int dir, int use_float) {
+    if (use_float) fft1024_w64_emul<float>(in, out, dir); else fft1024_w64_emul<double>(in, out, dir);
 }
 
 extern "C" {

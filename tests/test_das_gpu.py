@@ -165,3 +165,25 @@ def test_das_large_batch_properties():
     # from the 2nd hop on, history matches the big run exactly
     d = (o[1024:] - outs[0][(t0 + 1) * 512:(t0 + n) * 512]).abs().max().item()
     assert d < 1e-6, d
+
+
+def test_das_w64_variant_matches_oracle(monkeypatch):
+    """The experimental 64-lane x 16-point FFT factorisation (BF_DAS_W64=1, das_fused_w64.hip) must agree with
+    the oracle like the default kernel does (measured slower in round 1, kept as the round-2 base)."""
+    import oracle
+    from beamform_amd.capi import Beamformer
+    torch = _torch()
+    monkeypatch.setenv("BF_DAS_W64", "1")
+    for M, F in [(8, 37), (3, 18)]:
+        p = make_params("das", n_mics=M, theta=-25.0)
+        x = make_scene(M, F, seed=7 + M)
+        y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
+        bf = Beamformer(p)
+        xd = torch.from_numpy(x).cuda()
+        yd = torch.empty(F * 512, dtype=torch.float32, device="cuda")
+        Yd = torch.empty((F, 1024, 2), dtype=torch.float64, device="cuda")
+        bf.process_device(xd.data_ptr(), F, yd.data_ptr(), Yd.data_ptr())
+        torch.cuda.synchronize()
+        assert rel_l2(yd.cpu().numpy(), y_ref) < TOL_TIME
+        Yh = Yd.cpu().numpy().view(np.complex128)[..., 0]
+        assert max(rel_l2(Yh[t], _herm(Y_ref)[t]) for t in range(F)) < TOL_SPECTRUM

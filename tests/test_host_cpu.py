@@ -36,6 +36,18 @@ def test_emulated_fft32_and_fft1024(emul_lib):
             assert rel_l2(o, ref) < tol
 
 
+def test_emulated_fft1024_w64(emul_lib):
+    """64-lane x 16-point three-pass factorisation (fft1024_w64.hpp): index maps and twiddles."""
+    rng = np.random.default_rng(1)
+    for use_float, tol in ((0, 1e-14), (1, 5e-7)):
+        for d in (-1, 1):
+            x = rng.standard_normal(1024) + 1j * rng.standard_normal(1024)
+            o = np.empty(1024, np.complex128)
+            emul_lib.emul_fft1024_w64(_ptr(x), _ptr(o), d, use_float)
+            ref = np.fft.fft(x) if d < 0 else np.fft.ifft(x) * 1024
+            assert rel_l2(o, ref) < tol
+
+
 @pytest.mark.parametrize("M,theta", [(8, 20.0), (4, 0.0), (3, -75.0), (16, 135.0), (1, 0.0)])
 def test_emulated_fused_das_matches_oracle(emul_lib, M, theta):
     """Pair packing + Hermitian-part gains + unpaired inverse, in fp32 exactly as the kernel does it."""
