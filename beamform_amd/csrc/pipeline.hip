@@ -215,6 +215,17 @@ int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipS
     sa.x = x; sa.hist = d_hist_; sa.Z = d_Z_; sa.tw = d_tw_; sa.win = d_win_;
     sa.n_frames = F; sa.frames_ws = FT; sa.frame_off = Phist_; sa.mic_stride = mic_stride;
     sa.stream_stride_x = (long)M_ * F * 512; sa.n_streams = S_; sa.n_mics = M_; sa.layout = layout;
+    sa.skip_lo = 1024; sa.skip_hi = 0;  // store everything ...
+    if (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS) {
+        // ... except, for the band-limited nodes, the bins between the highest in-band bin k and its mirror N-k
+        // (quirk Q1 makes bins 511..513 irregular: only skip when the band ends below them)
+        int kmax = 0;
+        for (int k = 0; k <= 513; ++k) {
+            const double f = std::fabs(freqs_[k]);
+            if (f >= cfg_.freq_min && f <= cfg_.freq_max) kmax = k;
+        }
+        if (kmax < 510) { sa.skip_lo = kmax; sa.skip_hi = 1024 - kmax; }
+    }
     PIPE_HIP(launch_stft(sa, n_cus_, stream));
 
     // ring-buffer carry (util.h:305-308)

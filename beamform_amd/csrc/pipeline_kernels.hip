@@ -160,7 +160,11 @@ __global__ __launch_bounds__(kStftBlock) void stft_kernel(StftArgs a) {
         if (ok) {
             f64x2 *zo = a.Z + (((long)s * a.frames_ws + a.frame_off + t) * NP + p) * kN + lane;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) zo[32 * brev5(i)] = f64x2{re[i], im[i]};
+            for (int i = 0; i < 32; ++i) {
+                const int row = 32 * brev5(i);  // bins row .. row+31 of this store
+                if (row > a.skip_lo && row + 31 < a.skip_hi) continue;  // band-limited nodes never read these bins
+                zo[row] = f64x2{re[i], im[i]};
+            }
         }
     }
 }

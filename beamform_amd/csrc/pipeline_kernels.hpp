@@ -24,6 +24,7 @@ struct StftArgs {
     const double *win;
     long n_frames, frames_ws, frame_off, mic_stride, stream_stride_x;
     int n_streams, n_mics, layout;
+    int skip_lo, skip_hi;  // packed-spectrum bins in (skip_lo, skip_hi) are never read by the per-bin kernel: not stored
 };
 hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s);
 

@@ -100,11 +100,31 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    # test hook for single-GPU boxes: BF_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and uses gloo for the
+    # (host-staged) gather, so the launcher / barrier / gather code path can be exercised without 2 GPUs
+    one_dev = os.environ.get("BF_BENCH_ONE_DEVICE", "0") == "1"
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def gather_to_rank0(t, out_list):
+        if one_dev:
+            host = t.cpu()
+            dist.gather(host, [torch.empty_like(host) for _ in range(world)] if rank == 0 else None, dst=0)
+        else:
+            dist.gather(t, out_list, dst=0)
+
+    def all_max(vals):
+        t = torch.tensor(vals, device="cpu" if one_dev else dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t]
 
     M, F, S = args.mics, args.frames, args.streams
     interf = (-60.0, 90.0, 150.0) if args.algo in ("lcmv", "gss") else ()
@@ -118,7 +138,7 @@ def main():
     x = torch.rand(shape, device=dev, generator=g, dtype=torch.float32) - 0.5
     y = torch.empty((S, F * HOP), device=dev, dtype=torch.float32)
     gathered = None
-    if world > 1 and args.gather != "none" and rank == 0:
+    if world > 1 and args.gather != "none" and rank == 0 and not one_dev:
         gathered = [torch.empty_like(y) for _ in range(world)]
     stream = torch.cuda.current_stream(dev)
     sptr = stream.cuda_stream
@@ -126,7 +146,7 @@ def main():
     def step():
         bf.process_device(x.data_ptr(), F, y.data_ptr(), 0, sptr)
         if world > 1 and args.gather == "step":
-            dist.gather(y, gathered, dst=0)
+            gather_to_rank0(y, gathered)
 
     for _ in range(args.warmup):
         step()
@@ -144,20 +164,18 @@ def main():
     dt = time.perf_counter() - t0
     gather_dt = 0.0
     if world > 1 and args.gather == "final":  # output delivery, outside the hot path: timed on its own
-        dist.gather(y, gathered, dst=0)        # first call also builds the RCCL channels
+        gather_to_rank0(y, gathered)           # first call also builds the RCCL channels
         torch.cuda.synchronize(dev)
         dist.barrier()
         torch.cuda.synchronize(dev)
         g0 = time.perf_counter()
-        dist.gather(y, gathered, dst=0)
+        gather_to_rank0(y, gathered)
         torch.cuda.synchronize(dev)
         dist.barrier()
         torch.cuda.synchronize(dev)
         gather_dt = time.perf_counter() - g0
     if world > 1:
-        t = torch.tensor([dt, gather_dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, gather_dt = float(t[0].item()), float(t[1].item())
+        dt, gather_dt = all_max([dt, gather_dt])
 
     # dominant-kernel duration: HIP events on the launch stream, one pair per launch
     k_iters = max(5, min(args.steps, 50))
@@ -200,7 +218,9 @@ def main():
                        "value_including_final_gather": (frames_total / (dt + gather_dt)) if gather_dt > 0 else None,
                        "parallelism": f"frame-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(tag),
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # PMC traffic exists for the headline workload only (profiles/traffic_das8.json)
+                         "traffic": load_traffic(tag) if (F == 65536 and S == 1 and args.layout == "planar") else None,
                          "kernel": "das_fused_kernel" if args.algo == "das" else "bin pipeline",
                          "kernel_ms": ms_kernel, "call_ms": ms_call, "algorithmic_bytes_per_frame": bpf,
                          "frames_per_launch": units_per_launch, "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
