@@ -26,7 +26,7 @@ EXPORTS = (
     "bf_version", "bf_strerror", "bf_last_error", "bf_device_count", "bf_config_init", "bf_config_load_yaml",
     "bf_config_parse_yaml", "bf_create", "bf_destroy", "bf_set_theta", "bf_set_interference", "bf_process_hop",
     "bf_process_batch", "bf_process_batch_device", "bf_get_weights", "bf_state_size", "bf_get_state", "bf_set_state",
-    "bf_reset", "bf_time_batch_device",
+    "bf_reset", "bf_time_batch_device", "bf_n_interferers",
 )
 
 
@@ -80,6 +80,7 @@ def load():
     L.bf_destroy.restype = None
     L.bf_set_theta.argtypes = [C.c_void_p, C.c_double]
     L.bf_set_interference.argtypes = [C.c_void_p, C.c_uint, C.c_double]
+    L.bf_n_interferers.argtypes = [C.c_void_p]
     L.bf_process_hop.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32]
     L.bf_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.bf_process_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -151,8 +152,12 @@ class Beamformer:
     def set_theta(self, deg: float):
         self._chk(self._L.bf_set_theta(self._h, float(deg)), "bf_set_theta")
 
-    def set_interference(self, idx: int, deg: float):
+    def set_interference(self, idx: int, deg: float) -> int:
+        """interf_theta_roscallback; returns the interferer count afterwards."""
         self._chk(self._L.bf_set_interference(self._h, int(idx), float(deg)), "bf_set_interference")
+        k = self._L.bf_n_interferers(self._h)
+        self.S = k + 1
+        return k
 
     def reset(self):
         self._chk(self._L.bf_reset(self._h), "bf_reset")

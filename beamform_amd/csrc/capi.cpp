@@ -386,17 +386,44 @@ int bf_set_interference(bf_handle *h, unsigned id, double degrees) {
     if (!h) return BF_EINVAL;
     if (h->cfg.algo != BF_LCMV && h->cfg.algo != BF_GSS) return fail(h, BF_EINVAL, "node has no interferers");
     std::lock_guard<std::mutex> lk(h->mu);
-    // lcmv.cpp:259-281, update of an existing interferer.  Structural changes
-    // (append / remove-when-too-close, lcmv.cpp:266-305) would re-allocate every
-    // per-bin matrix; not supported at run time in this build.
-    if (id < 1 || id > h->interf.size()) return fail(h, BF_ENOSYS, "adding/removing interferers at run time is not built");
-    for (size_t i = 0; i < h->interf.size(); ++i)
-        if (i != id - 1 && std::abs(h->interf[i] - degrees) < h->cfg.interf_angle_threshold)
-            return fail(h, BF_ENOSYS, "interferer removal (too close to another) is not built");
-    h->interf[id - 1] = degrees;
+    std::vector<double> &ia = h->interf;
+    const double thr = h->cfg.interf_angle_threshold;
+    bool structural = false;
+    if (id >= 1 && id <= ia.size()) {  // lcmv.cpp:259-281
+        ia[id - 1] = degrees;
+        for (size_t i = 0; i < ia.size(); ++i) {
+            if (i != (id - 1) && std::abs(ia[i] - degrees) < thr) {
+                ia.erase(ia.begin() + id - 1);
+                structural = true;
+                break;
+            }
+        }
+    } else if (id > ia.size()) {  // lcmv.cpp:282-305
+        size_t i;
+        for (i = 0; i < ia.size(); ++i)
+            if (std::abs(ia[i] - degrees) < thr) break;
+        if (i != ia.size()) return BF_OK;  // too close to an existing interferer: ignored, as the reference does
+        if (ia.size() + 1 > 3) return fail(h, BF_ENOSYS, "per-bin kernels are built for up to 3 interferers");
+        ia.push_back(degrees);
+        structural = true;
+    } else {
+        return fail(h, BF_EINVAL, "interference id must be >= 1");
+    }
+    if (structural) {
+        // free_interf_buffers + allocate_interf_buffers: weights come back zeroed, row 0 is not rewritten (Q3)
+        h->S = (int)ia.size() + 1;
+        h->steer.allocate(h->N, h->M, h->S);
+        if (h->pipe) h->pipe->set_columns(h->S);
+    }
     rebuild_steering(h, false);
-    if (h->pipe) h->pipe->on_theta_changed();
+    if (h->pipe) h->pipe->on_theta_changed();  // gss: sep_matrix = weights^H (gss.cpp:90-93)
     return BF_OK;
+}
+
+int bf_n_interferers(bf_handle *h) {
+    if (!h) return BF_EINVAL;
+    std::lock_guard<std::mutex> lk(h->mu);
+    return (int)h->interf.size();
 }
 
 int bf_get_weights(bf_handle *h, double *w_host) {

@@ -41,6 +41,7 @@ namespace {
     } while (0)
 
 class BinPipelineImpl : public BinPipeline {
+    static constexpr int kMaxCols = 4;  // look direction + up to 3 interferers (per-bin kernels: KM = 4)
    public:
     BinPipelineImpl(const bf_config &c, int n_cus) : cfg_(c), n_cus_(n_cus) {
         M_ = c.n_mics;
@@ -78,7 +79,7 @@ class BinPipelineImpl : public BinPipeline {
         freqs_ = frequency_vector(1024, cfg_.sample_rate);
         PIPE_HIP(hipMalloc((void **)&d_freq_, 1024 * sizeof(double)));
         PIPE_HIP(hipMemcpy(d_freq_, freqs_.data(), 1024 * sizeof(double), hipMemcpyHostToDevice));
-        for (int i = 0; i < 2; ++i) PIPE_HIP(hipMalloc((void **)&d_steer_[i], (size_t)1024 * M_ * KP1_ * sizeof(f64x2)));
+        for (int i = 0; i < 2; ++i) PIPE_HIP(hipMalloc((void **)&d_steer_[i], (size_t)1024 * M_ * kMaxCols * sizeof(f64x2)));
         PIPE_HIP(hipMalloc((void **)&d_hist_, (size_t)S_ * M_ * 512 * sizeof(float)));
         PIPE_HIP(hipMalloc((void **)&d_tail_[0], (size_t)S_ * 512 * sizeof(float)));
         PIPE_HIP(hipMalloc((void **)&d_tail_[1], (size_t)S_ * 512 * sizeof(float)));
@@ -105,8 +106,8 @@ class BinPipelineImpl : public BinPipeline {
 
     int upload_steering(const SteeringSet &s, hipStream_t stream) override {
         // device layout [col][mic][bin] so that lanes (bins) read consecutive addresses
-        std::vector<f64x2> t((size_t)1024 * M_ * KP1_);
-        for (int c = 0; c < KP1_; ++c)
+        std::vector<f64x2> t((size_t)1024 * M_ * s.n_cols);
+        for (int c = 0; c < s.n_cols; ++c)
             for (int m = 0; m < M_; ++m)
                 for (int j = 0; j < 1024; ++j) {
                     const cplxd w = s.at(j, m, c);
@@ -120,6 +121,10 @@ class BinPipelineImpl : public BinPipeline {
     }
 
     void on_theta_changed() override { gss_reset_pending_ = true; }
+    void set_columns(int kp1) override {
+        KP1_ = kp1;
+        gss_reset_pending_ = true;
+    }
 
     int run(const float *x, long F, float *y, f64x2 *spectrum, hipStream_t stream, int layout, long mic_stride) override;
 
@@ -131,7 +136,7 @@ class BinPipelineImpl : public BinPipeline {
 
    private:
     size_t zhist_bytes() const { return Phist_ ? (size_t)S_ * Phist_ * NP_ * 1024 * sizeof(f64x2) : 0; }
-    size_t gss_bytes() const { return cfg_.algo == BF_GSS ? (size_t)S_ * 1024 * KP1_ * M_ * sizeof(f64x2) : 0; }
+    size_t gss_bytes() const { return cfg_.algo == BF_GSS ? (size_t)S_ * 1024 * kMaxCols * M_ * sizeof(f64x2) : 0; }
     size_t mpf_bytes() const { return cfg_.algo == BF_PHASEMPF ? (size_t)S_ * (kMpfVecs * 1024 + 8) * sizeof(double) : 0; }
     size_t smooth_bytes() const { return cfg_.algo == BF_PHASEMPF ? (size_t)S_ * 64 * sizeof(double) : 0; }
 

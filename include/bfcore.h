@@ -130,8 +130,14 @@ void bf_destroy(bf_handle *h);
  * Thread-safe against a concurrent bf_process_*: takes effect at the next
  * hop/batch (the reference updates in place with no lock). */
 int bf_set_theta(bf_handle *h, double degrees);
-/* interf_theta_roscallback (lcmv.cpp:258-309, gss.cpp): id is 1-based. */
+/* interf_theta_roscallback (lcmv.cpp:258-309, gss.cpp:288-339): id is 1-based.  id <= current count updates that
+ * interferer (and removes it when it lands within interf_angle_threshold of another one); id > count appends a
+ * new interferer unless it is that close to an existing one.  As in the reference, a structural change rebuilds
+ * the weight matrices zeroed and re-runs update_weights() without ini, so the reference-mic row is 0 afterwards
+ * (quirk Q3).  Up to 3 interferers in this build (BF_ENOSYS beyond).  Takes effect at the next hop/batch. */
 int bf_set_interference(bf_handle *h, unsigned id, double degrees);
+/* Current number of interferers (interference_angles.size()). */
+int bf_n_interferers(bf_handle *h);
 
 /* jack_callback body: do_overlap(in, out, nframes, apply_weights)
  * (das.cpp:72-92, util.h:289-314).  in = n_mics pointers to nframes float32

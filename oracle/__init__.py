@@ -57,6 +57,7 @@ def lib():
         L.orc_create.argtypes = [C.POINTER(OrcParams)]
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_set_theta.argtypes = [C.c_void_p, C.c_double]
+        L.orc_set_interference.argtypes = [C.c_void_p, C.c_uint, C.c_double, C.c_double]
         L.orc_process_hop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_process.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
         for f in ("orc_get_freqs", "orc_get_delays", "orc_get_hann", "orc_get_weights"):
@@ -105,6 +106,12 @@ class OracleNode:
 
     def set_theta(self, deg: float):
         lib().orc_set_theta(self._h, float(deg))
+
+    def set_interference(self, idx: int, deg: float, threshold: float = 1.0) -> int:
+        """interf_theta_roscallback; threshold = interf_angle_threshold (launch files: 1.0).  Returns the interferer count."""
+        k = lib().orc_set_interference(self._h, int(idx), float(deg), float(threshold))
+        self.S = k + 1
+        return k
 
     def process_hop(self, x: np.ndarray, want_spectrum: bool = False):
         """x: [M, H] float32 -> (out [H] float32, Y [N] complex128 or None)."""

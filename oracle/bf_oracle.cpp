@@ -604,6 +604,41 @@ void orc_set_theta(orc_node *n, double deg) {
     update_weights(n, false);
 }
 
+/* free_interf_buffers + allocate_interf_buffers (lcmv.cpp:221-256, gss.cpp:242-286): everything sized by the
+ * interferer count is rebuilt zeroed */
+static void realloc_interf(orc_node *n) {
+    n->S = (int)n->interference_angles.size() + 1;
+    n->interf_delays.assign(n->S - 1, std::vector<double>(n->M));
+    n->weights.assign(n->N, Mat(n->M, n->S));
+    n->weights_h.assign(n->N, Mat(n->S, n->M));
+    if (n->p.algo == ORC_GSS) n->sep_matrix.assign(n->N, Mat(n->S, n->M));
+}
+
+int orc_set_interference(orc_node *n, unsigned id, double angle, double thr) {
+    std::vector<double> &ia = n->interference_angles;
+    if (id >= 1 && id <= ia.size()) {
+        ia[id - 1] = angle;
+        for (size_t i = 0; i < ia.size(); i++) {
+            if (i != (id - 1) && std::abs(ia[i] - angle) < thr) {
+                ia.erase(ia.begin() + id - 1);
+                realloc_interf(n);
+                break;
+            }
+        }
+        update_weights(n, false);
+    } else if (id > ia.size()) {
+        size_t i;
+        for (i = 0; i < ia.size(); i++)
+            if (std::abs(ia[i] - angle) < thr) break;
+        if (i == ia.size()) {
+            ia.push_back(angle);
+            realloc_interf(n);
+            update_weights(n, false);
+        }
+    }
+    return (int)ia.size();
+}
+
 /* jack_callback -> do_overlap (util.h:289-314) */
 int orc_process_hop(orc_node *n, const float *in, float *out, double *Y) {
     const int H = n->H;

@@ -60,6 +60,12 @@ void orc_destroy(orc_node *n);
 /* theta_roscallback: angle = msg; update_weights() (das.cpp:94-99) */
 void orc_set_theta(orc_node *n, double deg);
 
+/* interf_theta_roscallback (lcmv.cpp:258-309, gss.cpp:288-339): id is 1-based; updates an existing interferer,
+ * removes it when it lands within interf_angle_threshold of another one, or appends a new one.  Structural
+ * changes re-allocate the (zeroed) weight matrices and call update_weights() WITHOUT ini, so the reference-mic
+ * row stays 0 afterwards (quirk Q3).  Returns the new number of interferers. */
+int orc_set_interference(orc_node *n, unsigned id, double angle, double interf_angle_threshold);
+
 /* One jack_callback worth of work: do_overlap(in, out, nframes, apply_weights)
  * (+ phasempf output smoothing).  in = [n_mics][hop] planar float32, out = [hop].
  * If Y != NULL it receives y_fft of this frame (fft_win complex doubles, re/im

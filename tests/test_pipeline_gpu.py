@@ -214,3 +214,35 @@ def test_multi_stream_phasempf_config4_shape():
     for s in range(S):
         y_ref, Y_ref = oracle.OracleNode(p).process(xs[s], want_spectrum=True)
         check(y[s], Y[s], y_ref, Y_ref)
+
+
+@pytest.mark.parametrize("algo", ["lcmv", "gss"])
+def test_interferer_update_add_remove(algo):
+    """/theta_interference (lcmv.cpp:258-309): move an interferer, append one, remove one by moving it next to another --
+    including the reference's quirk that a structural change leaves the reference-mic weight row at 0."""
+    import oracle
+    from beamform_amd.capi import Beamformer
+    _torch()
+    M, F = 8, 40
+    p = make_params(algo, n_mics=M, interf=(-60.0, 90.0), theta=20.0)
+    x = make_scene(M, F, seed=91)
+    node = oracle.OracleNode(p)
+    bf = Beamformer(p)
+    script = {8: (1, -45.0), 16: (3, 150.0), 24: (2, 149.5), 32: (5, 10.0)}   # move, append, remove (0.5 < threshold 1.0), append
+    ys, refs = [], []
+    for t in range(F):
+        if t in script:
+            k_ref = node.set_interference(*script[t])
+            k = bf.set_interference(*script[t])
+            assert k == k_ref
+            assert np.abs(bf.weights() - node.weights()).max() < 1e-14
+        seg = np.ascontiguousarray(x[:, t * 512:(t + 1) * 512])
+        refs.append(node.process(seg)[0])
+        ys.append(bf.process(seg))
+    assert bf.weights().shape[2] == 4 and np.all(bf.weights()[:, 0, :] == 0)      # Q3 after the structural changes
+    y, y_ref = np.concatenate(ys), np.concatenate(refs)
+    ok = np.isfinite(y_ref)
+    assert (np.isfinite(y) == ok).all()
+    assert rel_l2(y[ok], y_ref[ok]) < TOL_TIME
+    with pytest.raises(Exception):
+        bf.set_interference(9, -120.0)          # a 4th interferer is beyond this build (BF_ENOSYS)
