@@ -31,6 +31,9 @@ $(LIB): $(OBJS)
 oracle:
 	$(MAKE) -C oracle -s
 
+ubench:
+	for f in valu_rate fetch_calib w64_test; do $(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fno-slp-vectorize -Wno-unused-result tools/ubench/$$f.hip -o tools/ubench/$$f.bin; done
+
 emul:
 	g++ -O2 -std=c++17 -fPIC -shared -o tests/host_emul/libemul.so tests/host_emul/emul.cpp
 
@@ -38,4 +41,4 @@ clean:
 	rm -rf build $(LIB) tests/host_emul/libemul.so examples/file_node
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle emul clean
+.PHONY: all oracle emul ubench clean
