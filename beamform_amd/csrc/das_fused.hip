@@ -97,52 +97,64 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
     float re[32], im[32], Sr[32], Si[32];
     const int n_iter = (int)((T1 - T0 + kHalves - 1) / kHalves);
 
+    // frame handled by this half-wavefront at iteration `it` (clamped into the run: invalid slots redo its last frame)
+    auto frame_of = [&](int it) -> long {
+        const long t = T0 + (long)it * kHalves + hw;
+        return t < T1 ? t : T1 - 1;
+    };
+    // raw samples of mic pair p of frame tc into re (mic 2p) / im (mic 2p+1), natural order j <-> sample 32*j + lane
+    auto issue_loads = [&](long tc, int p) {
+        const int ma = 2 * p;
+        const int mb = (2 * p + 1 < M) ? 2 * p + 1 : ma;
+        if (LAYOUT == 0) {
+            const float *a1 = (tc >= 1 ? xs + (long)ma * a.mic_stride + (tc - 1) * kHop : hs + ma * kHop) + lane;
+            const float *b1 = (tc >= 1 ? xs + (long)mb * a.mic_stride + (tc - 1) * kHop : hs + mb * kHop) + lane;
+            const float *a2 = xs + (long)ma * a.mic_stride + tc * kHop + lane;
+            const float *b2 = xs + (long)mb * a.mic_stride + tc * kHop + lane;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                re[j] = a1[32 * j];
+                im[j] = b1[32 * j];
+                re[j + 16] = a2[32 * j];
+                im[j + 16] = b2[32 * j];
+            }
+        } else {
+            // interleaved [sample][mic]: the two mics of a pair are adjacent -> one 8-byte load per sample
+            const float *s1 = (tc >= 1 ? xs + (tc - 1) * (long)kHop * M : hs) + (long)lane * M;
+            const float *s2 = xs + tc * (long)kHop * M + (long)lane * M;
+            if (mb != ma && (M & 1) == 0) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float2 u = *reinterpret_cast<const float2 *>(s1 + (long)32 * j * M + ma);
+                    const float2 w = *reinterpret_cast<const float2 *>(s2 + (long)32 * j * M + ma);
+                    re[j] = u.x;
+                    im[j] = u.y;
+                    re[j + 16] = w.x;
+                    im[j + 16] = w.y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    re[j] = s1[(long)32 * j * M + ma];
+                    im[j] = s1[(long)32 * j * M + mb];
+                    re[j + 16] = s2[(long)32 * j * M + ma];
+                    im[j + 16] = s2[(long)32 * j * M + mb];
+                }
+            }
+        }
+    };
+
+    issue_loads(frame_of(0), 0);  // pair 0 of the first frame; later pair-0 loads fly during the previous inverse FFT
+
     for (int it = 0; it < n_iter; ++it) {
         const long t = T0 + (long)it * kHalves + hw;
         const bool valid = t < T1;
         const long tc = valid ? t : T1 - 1;
 
         for (int p = 0; p < n_pairs; ++p) {
-            const int ma = 2 * p;
             const bool b_ok = (2 * p + 1) < M;
-            const int mb = b_ok ? 2 * p + 1 : ma;
             const float bscale = b_ok ? 1.f : 0.f;
-            if (LAYOUT == 0) {
-                const float *a1 = (tc >= 1 ? xs + (long)ma * a.mic_stride + (tc - 1) * kHop : hs + ma * kHop) + lane;
-                const float *b1 = (tc >= 1 ? xs + (long)mb * a.mic_stride + (tc - 1) * kHop : hs + mb * kHop) + lane;
-                const float *a2 = xs + (long)ma * a.mic_stride + tc * kHop + lane;
-                const float *b2 = xs + (long)mb * a.mic_stride + tc * kHop + lane;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    re[j] = a1[32 * j];
-                    im[j] = b1[32 * j];
-                    re[j + 16] = a2[32 * j];
-                    im[j + 16] = b2[32 * j];
-                }
-            } else {
-                // interleaved [sample][mic]: the two mics of a pair are adjacent -> one 8-byte load per sample
-                const float *s1 = (tc >= 1 ? xs + (tc - 1) * (long)kHop * M : hs) + (long)lane * M;
-                const float *s2 = xs + tc * (long)kHop * M + (long)lane * M;
-                if (b_ok && (M & 1) == 0) {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const float2 u = *reinterpret_cast<const float2 *>(s1 + (long)32 * j * M + ma);
-                        const float2 w = *reinterpret_cast<const float2 *>(s2 + (long)32 * j * M + ma);
-                        re[j] = u.x;
-                        im[j] = u.y;
-                        re[j + 16] = w.x;
-                        im[j + 16] = w.y;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        re[j] = s1[(long)32 * j * M + ma];
-                        im[j] = s1[(long)32 * j * M + mb];
-                        re[j + 16] = s2[(long)32 * j * M + ma];
-                        im[j + 16] = s2[(long)32 * j * M + mb];
-                    }
-                }
-            }
+            if (p > 0) issue_loads(tc, p);
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const float4 hv = wrow[g];
@@ -165,7 +177,6 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             if (p == 0) {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
-                    if ((i & 7) == 0) BF_SCHED_FENCE();
                     const cx<float> g = gp[32 * i];
                     Sr[i] = g.x * re[i] - g.y * im[i];
                     Si[i] = g.x * im[i] + g.y * re[i];
@@ -173,7 +184,6 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             } else {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
-                    if ((i & 7) == 0) BF_SCHED_FENCE();
                     const cx<float> g = gp[32 * i];
                     Sr[i] += g.x * re[i] - g.y * im[i];
                     Si[i] += g.x * im[i] + g.y * re[i];
@@ -186,6 +196,9 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
 #pragma unroll
             for (int i = 0; i < 32; ++i) sd[32 * brev5(i)] = f32x2{Sr[i], Si[i]};
         }
+
+        // the next frame's first pair streams in while the inverse transform runs on (Sr, Si)
+        if (it + 1 < n_iter) issue_loads(frame_of(it + 1), 0);
 
         fft1024p_inv_A<float>(Sr, Si, lane, s_tw, pbuf);
         __builtin_amdgcn_wave_barrier();
