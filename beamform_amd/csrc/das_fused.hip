@@ -144,7 +144,9 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
         }
     };
 
-    issue_loads(frame_of(0), 0);  // pair 0 of the first frame; later pair-0 loads fly during the previous inverse FFT
+    // planar: pair 0 of a frame is requested before the previous frame's inverse FFT (one round of latency hidden);
+    // interleaved: address arithmetic per sample is register-hungry, loads stay inside the round
+    if (LAYOUT == 0) issue_loads(frame_of(0), 0);
 
     for (int it = 0; it < n_iter; ++it) {
         const long t = T0 + (long)it * kHalves + hw;
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
         for (int p = 0; p < n_pairs; ++p) {
             const bool b_ok = (2 * p + 1) < M;
             const float bscale = b_ok ? 1.f : 0.f;
-            if (p > 0) issue_loads(tc, p);
+            if (p > 0 || LAYOUT != 0) issue_loads(tc, p);
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const float4 hv = wrow[g];
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
         }
 
         // the next frame's first pair streams in while the inverse transform runs on (Sr, Si)
-        if (it + 1 < n_iter) issue_loads(frame_of(it + 1), 0);
+        if (LAYOUT == 0 && it + 1 < n_iter) issue_loads(frame_of(it + 1), 0);
 
         fft1024p_inv_A<float>(Sr, Si, lane, s_tw, pbuf);
         __builtin_amdgcn_wave_barrier();
