@@ -102,11 +102,12 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
         const long t = T0 + (long)it * kHalves + hw;
         return t < T1 ? t : T1 - 1;
     };
-    // raw samples of mic pair p of frame tc into re (mic 2p) / im (mic 2p+1), natural order j <-> sample 32*j + lane
+    // planar layout: raw samples of mic pair p of frame tc into re (mic 2p) / im (mic 2p+1), natural order
+    // j <-> sample 32*j + lane
     auto issue_loads = [&](long tc, int p) {
         const int ma = 2 * p;
         const int mb = (2 * p + 1 < M) ? 2 * p + 1 : ma;
-        if (LAYOUT == 0) {
+        {
             const float *a1 = (tc >= 1 ? xs + (long)ma * a.mic_stride + (tc - 1) * kHop : hs + ma * kHop) + lane;
             const float *b1 = (tc >= 1 ? xs + (long)mb * a.mic_stride + (tc - 1) * kHop : hs + mb * kHop) + lane;
             const float *a2 = xs + (long)ma * a.mic_stride + tc * kHop + lane;
@@ -117,29 +118,6 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                 im[j] = b1[32 * j];
                 re[j + 16] = a2[32 * j];
                 im[j + 16] = b2[32 * j];
-            }
-        } else {
-            // interleaved [sample][mic]: the two mics of a pair are adjacent -> one 8-byte load per sample
-            const float *s1 = (tc >= 1 ? xs + (tc - 1) * (long)kHop * M : hs) + (long)lane * M;
-            const float *s2 = xs + tc * (long)kHop * M + (long)lane * M;
-            if (mb != ma && (M & 1) == 0) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const float2 u = *reinterpret_cast<const float2 *>(s1 + (long)32 * j * M + ma);
-                    const float2 w = *reinterpret_cast<const float2 *>(s2 + (long)32 * j * M + ma);
-                    re[j] = u.x;
-                    im[j] = u.y;
-                    re[j + 16] = w.x;
-                    im[j + 16] = w.y;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    re[j] = s1[(long)32 * j * M + ma];
-                    im[j] = s1[(long)32 * j * M + mb];
-                    re[j + 16] = s2[(long)32 * j * M + ma];
-                    im[j + 16] = s2[(long)32 * j * M + mb];
-                }
             }
         }
     };
@@ -156,7 +134,34 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
         for (int p = 0; p < n_pairs; ++p) {
             const bool b_ok = (2 * p + 1) < M;
             const float bscale = b_ok ? 1.f : 0.f;
-            if (p > 0 || LAYOUT != 0) issue_loads(tc, p);
+            if (LAYOUT != 0) {
+                // interleaved [sample][mic]: the two mics of a pair are adjacent -> one 8-byte load per sample
+                const int ma = 2 * p;
+                const int mb = b_ok ? 2 * p + 1 : ma;
+                const float *s1 = (tc >= 1 ? xs + (tc - 1) * (long)kHop * M : hs) + (long)lane * M;
+                const float *s2 = xs + tc * (long)kHop * M + (long)lane * M;
+                if (b_ok && (M & 1) == 0) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const float2 u = *reinterpret_cast<const float2 *>(s1 + (long)32 * j * M + ma);
+                        const float2 w = *reinterpret_cast<const float2 *>(s2 + (long)32 * j * M + ma);
+                        re[j] = u.x;
+                        im[j] = u.y;
+                        re[j + 16] = w.x;
+                        im[j + 16] = w.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        re[j] = s1[(long)32 * j * M + ma];
+                        im[j] = s1[(long)32 * j * M + mb];
+                        re[j + 16] = s2[(long)32 * j * M + ma];
+                        im[j + 16] = s2[(long)32 * j * M + mb];
+                    }
+                }
+            } else if (p > 0) {
+                issue_loads(tc, p);
+            }
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const float4 hv = wrow[g];
