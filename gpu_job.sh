@@ -1,12 +1,8 @@
 cd /root/repo
 export TMPDIR=/tmp
-export BF_DAS_W64=1
-P="rocprofv3 --kernel-trace --output-format csv"
-i=0
-for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_LDS" \
-           "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SMEM" \
-           "GRBM_GUI_ACTIVE SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_MISC"; do
-  i=$((i+1))
-  $P --pmc $set -d gpurun_out/w$i -- python tools/run_das.py --iters 3 > gpurun_out/w$i.log 2>&1
-done
-python tools/pmc_summary.py gpurun_out/w1 gpurun_out/w2 gpurun_out/w3 | cut -c62-
+python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; python -c "
+import json; d=json.load(open('gpurun_out/bench_final.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['kernel_ms'], d['extra'], d['cpu_baseline']['value'])"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_e -- python bench.py --no-cpu --no-extra > gpurun_out/prof_e.log 2>&1
+for f in $(find gpurun_out/prof_e -name "*kernel_stats*"); do cut -c1-160 $f | head -3; done
