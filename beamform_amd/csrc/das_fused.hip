@@ -57,11 +57,15 @@ constexpr int kLdsFixed = kLdsTw + kHalves * kLdsPlane + kLdsWin;
 // float atomic adds into a pre-zeroed hop (sum of two terms: order-independent, bit-exact).
 template <int LAYOUT, int NPL>
 __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[kLdsFixed + NPL * 2048 + 17 * kHop];
+    __shared__ __attribute__((aligned(16))) float lds[kLdsFixed + NPL * 2048 + 17 * kHop + 32];
     const cx<float> *s_tw = reinterpret_cast<const cx<float> *>(lds);
     float *s_win = lds + kLdsTw + kHalves * kLdsPlane;
     const cx<float> *s_gain = reinterpret_cast<const cx<float> *>(lds + kLdsFixed);
-    float *s_tails = lds + kLdsFixed + NPL * 2048;  // slot 0 = carry from the previous iteration, slot hw+1 = this one
+    // 17-slot ring of frame tails: frame t (run-relative r = t - T0) parks its second half in slot (r + 1) % 17 and
+    // frame t+1 picks it up there.  With 16 frames in flight the reader of a slot is always its next writer, so the
+    // only hazard is read-after-write: one flag per slot (= the frame whose tail it holds) replaces block barriers.
+    float *s_tails = lds + kLdsFixed + NPL * 2048;
+    volatile int *s_flag = reinterpret_cast<volatile int *>(lds + kLdsFixed + NPL * 2048 + 17 * kHop);
 
     const int tid = threadIdx.x;
     const int lane = tid & 31;
@@ -87,6 +91,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
     if (T0 == 0) {  // stream start: the overlap partner of frame 0 is the carried state (out_buff[0], util.h:302)
         for (int i = tid; i < kHop; i += kBlock) s_tails[i] = a.tail_in[(long)stream * kHop + i];
     }
+    if (tid < 17) s_flag[tid] = (tid == 0) ? (int)(T0 - 1) : -2;  // slot 0 holds "frame T0-1" (state, or unused when T0 > 0)
     __syncthreads();
     const float4 *wrow = reinterpret_cast<const float4 *>(s_win + lane * kPS);
 
@@ -223,19 +228,28 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             const float4 hv = wrow[g];
             h[4 * g + 0] = hv.x; h[4 * g + 1] = hv.y; h[4 * g + 2] = hv.z; h[4 * g + 3] = hv.w;
         }
-        // second half of this frame -> ring slot hw+1 (the partner of frame t+1's first half)
-        float *my_slot = s_tails + (hw + 1) * kHop + lane;
+        // second half of this frame -> its ring slot, then publish (LDS operations of a wavefront complete in order)
+        const int r = (int)(tc - T0);
+        const int my = (r + 1) % 17, pv = r % 17;
+        if (valid) {
+            float *my_slot = s_tails + my * kHop + lane;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) my_slot[32 * brev5(2 * q)] = Sr[2 * q + 1] * h[brev5(2 * q + 1)];
-        __syncthreads();
+            for (int q = 0; q < 16; ++q) my_slot[32 * brev5(2 * q)] = Sr[2 * q + 1] * h[brev5(2 * q + 1)];
+            // data then flag: LDS operations of one wavefront execute in issue order, so a compiler barrier suffices
+            asm volatile("" ::: "memory");
+            if (lane == 0) s_flag[my] = (int)t;
+        }
         if (valid) {
             float *yo = ys + t * kHop + lane;
-            const float *prev = s_tails + hw * kHop + lane;  // frame t-1: neighbour, or slot 0 for hw == 0
             if (t == T0 && T0 > 0) {
                 // first hop of the run: the previous run adds its half separately (both into a zeroed hop)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) atomicAdd(yo + 32 * brev5(2 * q), Sr[2 * q] * h[brev5(2 * q)]);
             } else {
+                // wait for frame t-1's tail (neighbouring half-wavefront, or the last one of the previous iteration)
+                while (s_flag[pv] != (int)(t - 1)) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+                const float *prev = s_tails + pv * kHop + lane;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) yo[32 * brev5(2 * q)] = prev[32 * brev5(2 * q)] + Sr[2 * q] * h[brev5(2 * q)];
             }
@@ -260,14 +274,6 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                 }
             }
         }
-        __syncthreads();
-        if (hw == kHalves - 1) {  // carry: frame t0+16*it+15 is the partner of the next iteration's first frame
-            const float *src = s_tails + kHalves * kHop + lane;
-            float *dst = s_tails + lane;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) dst[32 * q] = src[32 * q];
-        }
-        // the next iteration's first __syncthreads orders this copy before slot 0 is read
     }
 }
 
