@@ -26,7 +26,14 @@ __device__ __forceinline__ cd operator*(cd a, cd b) { return cd{a.x * b.x - a.y 
 __device__ __forceinline__ cd operator*(cd a, double s) { return cd{a.x * s, a.y * s}; }
 __device__ __forceinline__ cd conj(cd a) { return cd{a.x, -a.y}; }
 __device__ __forceinline__ double norm2(cd a) { return a.x * a.x + a.y * a.y; }
-__device__ __forceinline__ double cabs(cd a) { return hypot(a.x, a.y); }
+// |a|: spectra of [-1,1] audio are far from the double range limits, so no hypot-style rescaling is needed
+__device__ __forceinline__ double cabs(cd a) { return sqrt(a.x * a.x + a.y * a.y); }
+// mag * (cos, sin)(arg z) without trigonometry: mag * z/|z|; arg(0) = 0 as std::arg does
+__device__ __forceinline__ cd with_phase_of(double mag, cd z) {
+    const double r = cabs(z);
+    if (r == 0.0) return cd{mag, 0.0};
+    return cd{mag * (z.x / r), mag * (z.y / r)};
+}
 __device__ __forceinline__ cd cdiv(cd a, cd b) {
     // Smith's algorithm, as libstdc++/libgcc __divdc3 do for finite operands
     if (fabs(b.x) >= fabs(b.y)) {
@@ -386,7 +393,6 @@ __device__ __forceinline__ cd phase_bin(const BinCtx &c, const bf_config &cfg) {
     for (int m = 0; m < MP; ++m)
         if (m < c.M) mag += cabs(X[m]);
     mag /= (double)c.M;
-    const double pha = atan2(X[0].y, X[0].x);
     bool keep = false;
     if (mag / 1024.0 > cfg.mag_threshold) {
         double ph[MP];
@@ -403,7 +409,7 @@ __device__ __forceinline__ cd phase_bin(const BinCtx &c, const bf_config &cfg) {
         keep = mean < cfg.min_phase * M_PI / 180;
     }
     if (!keep) mag *= cfg.mag_mult;
-    return cd{mag * cos(pha), mag * sin(pha)};
+    return with_phase_of(mag, X[0]);  // mag * (cos, sin)(arg X_0)  (phase.cpp:115-122)
 }
 
 template <int MP, int ALGO>
@@ -863,12 +869,10 @@ __global__ __launch_bounds__(256) void mpf_mask_kernel(BinsArgs a, double *aux) 
     }
     const double mean = pair_phase_mean<MP>(ph, M);
     mag /= (double)M;
-    const double pha = atan2(X[0].y, X[0].x);
     const bool is_soi = mean < a.cfg.min_phase * M_PI / 180;
     const double lo = mag * a.cfg.min_mag;
     const double msoi = is_soi ? mag : lo, mint = is_soi ? lo : mag;
-    const double c = cos(pha), sn = sin(pha);
-    const cd soi{msoi * c, msoi * sn}, in{mint * c, mint * sn};
+    const cd soi = with_phase_of(msoi, X[0]), in = with_phase_of(mint, X[0]);
     a.Yh[o] = f64x2{soi.x, soi.y};
     aux[o] = norm2(in);
 }
