@@ -123,7 +123,7 @@ def config_from_params(p: dict, device: int = 0, n_streams: int = 1, layout: int
 
 
 class Beamformer:
-    """One beamformer node behind the C ABI (das|mvdr|lcmv|gss|phase|phasempf)."""
+    """One beamformer node behind the C ABI (das|mvdr|lcmv|gss|phase|phasempf|mcra)."""
 
     def __init__(self, params: dict, device: int = 0, n_streams: int = 1, layout: int = BF_PLANAR,
                  das_impl: int = BF_DAS_FUSED_F32):

@@ -65,7 +65,7 @@ bool parse_flow_map(const std::string &v, std::map<std::string, double> *m) {
 extern "C" {
 
 int bf_config_init(bf_config *c, int algo) {
-    if (!c || algo < BF_DAS || algo > BF_PHASEMPF) return BF_EINVAL;
+    if (!c || algo < BF_DAS || algo > BF_MCRA) return BF_EINVAL;
     memset(c, 0, sizeof(*c));
     c->algo = algo;
     c->hop = 512;              // JACK period behind "1024-pt FFT" (util.h:261)
@@ -100,6 +100,7 @@ int bf_config_init(bf_config *c, int algo) {
     c->noise_floor = 0.001;
     c->out_only_noise = 0; c->out_only_mcra = 0;
     if (algo == BF_PHASEMPF) { c->min_phase = 30.0; c->out_amp = 2.5; }
+    if (algo == BF_MCRA) { c->mcra_L = 300; c->out_amp = 3.5; }  // launch/mcra.launch:6-12
     c->device = 0;
     c->n_streams = 1;
     c->layout = BF_PLANAR;
@@ -146,6 +147,14 @@ int bf_config_parse_yaml(bf_config *c, const char *text) {
         BF_KEY_D(interf_angle_threshold) BF_KEY_D(mu)
         if (key == "lambda") { c->lambda_ = d; continue; }
         BF_KEY_D(min_phase) BF_KEY_D(mag_mult) BF_KEY_D(mag_threshold) BF_KEY_D(min_mag) BF_KEY_I(smooth_size)
+        // the mcra node reads the same quantities without the MCRA_ prefix (mcra.cpp:180-217)
+        if (c->algo == BF_MCRA) {
+            if (key == "alphaS") { c->mcra_alphaS = d; continue; }
+            if (key == "alphaD") { c->mcra_alphaD = d; continue; }
+            if (key == "alphaD2") { c->mcra_alphaD2 = d; continue; }
+            if (key == "delta") { c->mcra_delta = d; continue; }
+            if (key == "L") { c->mcra_L = (int)d; continue; }
+        }
         if (key == "MCRA_alphaS") { c->mcra_alphaS = d; continue; }
         if (key == "MCRA_alphaD") { c->mcra_alphaD = d; continue; }
         if (key == "MCRA_alphaD2") { c->mcra_alphaD2 = d; continue; }

@@ -45,7 +45,8 @@ class BinPipelineImpl : public BinPipeline {
    public:
     BinPipelineImpl(const bf_config &c, int n_cus) : cfg_(c), n_cus_(n_cus) {
         M_ = c.n_mics;
-        NP_ = (M_ + 1) / 2;
+        MF_ = (c.algo == BF_MCRA) ? 1 : M_;  // the mcra node only transforms channel 0 (mcra.cpp:72-73)
+        NP_ = (MF_ + 1) / 2;
         S_ = c.n_streams;
         const bool multi = (c.algo == BF_LCMV || c.algo == BF_GSS);
         KP1_ = multi ? c.n_interf + 1 : 1;
@@ -85,10 +86,8 @@ class BinPipelineImpl : public BinPipeline {
         PIPE_HIP(hipMalloc((void **)&d_tail_[1], (size_t)S_ * 512 * sizeof(float)));
         if (Phist_ > 0) PIPE_HIP(hipMalloc((void **)&d_zhist_, zhist_bytes()));
         if (cfg_.algo == BF_GSS) PIPE_HIP(hipMalloc((void **)&d_gssW_, gss_bytes()));
-        if (cfg_.algo == BF_PHASEMPF) {
-            PIPE_HIP(hipMalloc((void **)&d_mpf_, mpf_bytes()));
-            PIPE_HIP(hipMalloc((void **)&d_smooth_, smooth_bytes()));
-        }
+        if (cfg_.algo == BF_PHASEMPF || cfg_.algo == BF_MCRA) PIPE_HIP(hipMalloc((void **)&d_mpf_, mpf_bytes()));
+        if (cfg_.algo == BF_PHASEMPF) PIPE_HIP(hipMalloc((void **)&d_smooth_, smooth_bytes()));
         return BF_OK;
     }
 
@@ -137,7 +136,9 @@ class BinPipelineImpl : public BinPipeline {
    private:
     size_t zhist_bytes() const { return Phist_ ? (size_t)S_ * Phist_ * NP_ * 1024 * sizeof(f64x2) : 0; }
     size_t gss_bytes() const { return cfg_.algo == BF_GSS ? (size_t)S_ * 1024 * kMaxCols * M_ * sizeof(f64x2) : 0; }
-    size_t mpf_bytes() const { return cfg_.algo == BF_PHASEMPF ? (size_t)S_ * (kMpfVecs * 1024 + 8) * sizeof(double) : 0; }
+    size_t mpf_bytes() const {
+        return (cfg_.algo == BF_PHASEMPF || cfg_.algo == BF_MCRA) ? (size_t)S_ * (kMpfVecs * 1024 + 8) * sizeof(double) : 0;
+    }
     size_t smooth_bytes() const { return cfg_.algo == BF_PHASEMPF ? (size_t)S_ * 64 * sizeof(double) : 0; }
 
     int copy_state(char *p, bool to_host) {
@@ -175,7 +176,7 @@ class BinPipelineImpl : public BinPipeline {
     }
 
     bf_config cfg_;
-    int n_cus_, M_, NP_, S_, KP1_, Phist_;
+    int n_cus_, M_, MF_, NP_, S_, KP1_, Phist_;
     std::vector<double> freqs_;
     f64x2 *d_tw_ = nullptr;
     double *d_win_ = nullptr, *d_freq_ = nullptr;
@@ -219,7 +220,7 @@ int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipS
     StftArgs sa;
     sa.x = x; sa.hist = d_hist_; sa.Z = d_Z_; sa.tw = d_tw_; sa.win = d_win_;
     sa.n_frames = F; sa.frames_ws = FT; sa.frame_off = Phist_; sa.mic_stride = mic_stride;
-    sa.stream_stride_x = (long)M_ * F * 512; sa.n_streams = S_; sa.n_mics = M_; sa.layout = layout;
+    sa.stream_stride_x = (long)M_ * F * 512; sa.n_streams = S_; sa.n_mics = M_; sa.n_fft_mics = MF_; sa.layout = layout;
     sa.skip_lo = 1024; sa.skip_hi = 0;  // store everything ...
     if (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS) {
         // ... except, for the band-limited nodes, the bins between the highest in-band bin k and its mirror N-k
@@ -245,7 +246,7 @@ int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipS
 
     BinsArgs ba;
     ba.Z = d_Z_; ba.Yh = d_Yh_; ba.spectrum = spectrum; ba.steer = d_steer_[steer_cur_]; ba.freqs = d_freq_;
-    ba.n_frames = F; ba.frames_ws = FT; ba.frame_off = Phist_; ba.n_streams = S_; ba.n_mics = M_; ba.kp1 = KP1_;
+    ba.n_frames = F; ba.frames_ws = FT; ba.frame_off = Phist_; ba.n_streams = S_; ba.n_mics = MF_; ba.kp1 = KP1_;
     ba.cfg = cfg_; ba.gssW = d_gssW_; ba.mpf = d_mpf_; ba.gss_reset = gss_reset_pending_ ? 1 : 0;
     PIPE_HIP(launch_bins(ba, n_cus_, stream));
     gss_reset_pending_ = false;

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kStftBlock) void stft_kernel(StftArgs a) {
         for (int i = tid; i < kN; i += kStftBlock) s_win[(i & 31) * kPSd + (i >> 5)] = a.win[i];
     }
     __syncthreads();
-    const int M = a.n_mics, NP = (M + 1) >> 1;
+    const int M = a.n_mics, MF = a.n_fft_mics, NP = (MF + 1) >> 1;
     const long total = (long)a.n_streams * a.n_frames * NP;
     const long stride = (long)gridDim.x * kStftHalves;
     const long rounds = (total + stride - 1) / stride;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kStftBlock) void stft_kernel(StftArgs a) {
         const float *xs = a.x + (long)s * a.stream_stride_x;
         const float *hs = a.hist + (long)s * M * kHop;
         const int ma = 2 * p;
-        const bool b_ok = 2 * p + 1 < M;
+        const bool b_ok = 2 * p + 1 < MF;
         const int mb = b_ok ? 2 * p + 1 : ma;
         if (LAYOUT == 0) {
             const float *a1 = (t >= 1 ? xs + (long)ma * a.mic_stride + (t - 1) * kHop : hs + ma * kHop) + lane;
@@ -964,6 +964,76 @@ __global__ __launch_bounds__(64) void mpf_recursion_kernel(BinsArgs a, const dou
 }
 
 // ======================================================================================
+//                  mcra node: single-channel MCRA noise subtraction (mcra.cpp:64-155)
+// ======================================================================================
+// One thread per (stream, problem), sequential over frames (S, S_min, S_tmp and lambda recurse over time).
+// Only channel 0 is transformed (mcra.cpp:72-73), its pair partner is zero, so the packed spectrum IS X and
+// the neighbouring bins of the 3-tap frequency smoothing are plain loads.
+__global__ __launch_bounds__(64) void mcra_node_kernel(BinsArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.n_streams * kNQ) return;
+    const int s = idx / kNQ, q = idx % kNQ;
+    const int j = q_bin(q);
+    double *sv = a.mpf + (long)s * (kMpfVecs * kN + 8);
+    double Sprev = sv[0 * kN + j], Stmp = sv[1 * kN + j], Smin = sv[2 * kN + j], lam = sv[3 * kN + j];
+    int cL = (int)sv[kMpfVecs * kN + 0];
+    bool firstL = sv[kMpfVecs * kN + 1] == 0.0;  // stored inverted: a zeroed state is a cold start
+    const f64x2 *Zs = a.Z + ((long)s * a.frames_ws + a.frame_off) * kN;
+    f64x2 *row = a.Yh + ((long)s * a.n_frames) * kYhStride + q;
+    const double aS = a.cfg.mcra_alphaS, aD = a.cfg.mcra_alphaD, aD2 = a.cfg.mcra_alphaD2, delta = a.cfg.mcra_delta;
+    for (long t = 0; t < a.n_frames; ++t) {
+        const f64x2 *Zf = Zs + t * kN;
+        const cd x = ld(Zf + j);
+        const double x2 = norm2(x);  // in_fft_square (mcra.cpp:77)
+        double Sf;
+        if (j == 0) {
+            Sf = cabs(x);  // magnitude, not power (mcra.cpp:83)
+        } else {           // 0.25 / 0.5 / 0.25 over bins j-1, j, j+1 inside [1, N) (mcra.cpp:84-92); j+1 <= 514 < N here
+            Sf = 0.0;
+            if (j - 1 >= 1) Sf += 0.25 * norm2(ld(Zf + j - 1));
+            Sf += 0.5 * x2;
+            Sf += 0.25 * norm2(ld(Zf + j + 1));
+        }
+        const double S = (aS * Sprev) + ((1 - aS) * Sf);
+        if (cL > a.cfg.mcra_L) {  // mcra.cpp:100-113
+            Smin = Stmp > S ? S : Stmp;
+            Stmp = S;
+            cL = 1;
+            firstL = false;
+        } else {
+            Smin = Smin > S ? S : Smin;
+            Stmp = Stmp > S ? S : Stmp;
+            cL++;
+        }
+        if (firstL || S < Smin * delta || lam > x2) {  // mcra.cpp:116-124
+            const double invL = 1.0 / (double)cL;
+            if (firstL && invL > aD)
+                lam = invL * lam + (1.0 - invL) * x2;
+            else
+                lam = aD2 * lam + (1.0 - aD) * x2;
+        }
+        cd y{0, 0};  // bin 0 is never written by the node (quirk Q16, mcra.cpp:127)
+        if (j != 0) {
+            double mag;
+            if (a.cfg.out_only_noise) {
+                mag = sqrt(lam) * a.cfg.out_amp;
+            } else {
+                mag = (cabs(x) - sqrt(lam)) * a.cfg.out_amp;
+                if (mag < 0) mag = 0.0;
+            }
+            y = with_phase_of(mag, x);
+        }
+        row[t * kYhStride] = f64x2{y.x, y.y};
+        Sprev = S;
+    }
+    sv[0 * kN + j] = Sprev; sv[1 * kN + j] = Stmp; sv[2 * kN + j] = Smin; sv[3 * kN + j] = lam;
+    if (q == 0) {
+        sv[kMpfVecs * kN + 0] = (double)cL;
+        sv[kMpfVecs * kN + 1] = firstL ? 0.0 : 1.0;
+    }
+}
+
+// ======================================================================================
 //                              gss: geometric source separation
 // ======================================================================================
 // One group of MP lanes per (stream, problem), lane m owns column m of the demixing matrix
@@ -1112,7 +1182,7 @@ hipError_t launch_gss(const BinsArgs &a, int n_cus, hipStream_t s) {
 
 // ---- launchers ---------------------------------------------------------------------------
 hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
-    const long total = (long)a.n_streams * a.n_frames * ((a.n_mics + 1) / 2);
+    const long total = (long)a.n_streams * a.n_frames * ((a.n_fft_mics + 1) / 2);
     long blocks = (total + kStftHalves - 1) / kStftHalves;
     const long cap = (long)n_cus * 4;
     if (blocks > cap) blocks = cap;
@@ -1173,6 +1243,10 @@ hipError_t launch_bins(const BinsArgs &a, int n_cus, hipStream_t s) {
         case BF_LCMV: e = launch_mvdr_lcmv(a, n_cus, s); break;
         case BF_PHASEMPF: e = launch_phasempf(a, n_cus, s); break;
         case BF_GSS: e = launch_gss(a, n_cus, s); break;
+        case BF_MCRA:
+            hipLaunchKernelGGL(mcra_node_kernel, dim3((a.n_streams * kNQ + 63) / 64), dim3(64), 0, s, a);
+            e = hipGetLastError();
+            break;
         default: e = hipErrorInvalidValue; break;
     }
     if (e != hipSuccess) return e;

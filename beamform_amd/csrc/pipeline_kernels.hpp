@@ -24,6 +24,7 @@ struct StftArgs {
     const double *win;
     long n_frames, frames_ws, frame_off, mic_stride, stream_stride_x;
     int n_streams, n_mics, layout;
+    int n_fft_mics;        // channels actually transformed (= n_mics; 1 for the single-channel mcra node)
     int skip_lo, skip_hi;  // packed-spectrum bins in (skip_lo, skip_hi) are never read by the per-bin kernel: not stored
 };
 hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s);
@@ -38,7 +39,7 @@ struct BinsArgs {
     int n_streams, n_mics, kp1;
     bf_config cfg;
     f64x2 *gssW;         // [stream][1024][kp1][n_mics]
-    double *mpf;         // [stream][kMpfVecs*1024 + 8]
+    double *mpf;         // [stream][kMpfVecs*1024 + 8] (the mcra node uses vectors 0..3 and the two scalars)
     int gss_reset;
 };
 hipError_t launch_bins(const BinsArgs &a, int n_cus, hipStream_t s);

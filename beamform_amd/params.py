@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import copy
 
-ALGOS = ("das", "mvdr", "lcmv", "gss", "phase", "phasempf")
+ALGOS = ("das", "mvdr", "lcmv", "gss", "phase", "phasempf", "mcra")
 ALGO_ID = {name: i for i, name in enumerate(ALGOS)}
 
 #: beamform/beamform_config.yaml:20-35 ("aira16"), z dropped as util.h:82-92 does.
@@ -39,6 +39,9 @@ LAUNCH_DEFAULTS = {
                      mcra_alphaD2=0.98, mcra_delta=0.001, mcra_L=50, mpf_alphaS=0.7, mpf_eta=0.3,
                      mpf_rev_gamma=0.9, mpf_rev_delta=1.0, out_amp=2.5, noise_floor=0.001,
                      out_only_noise=0, out_only_mcra=0),
+    # launch/mcra.launch:6-12 (single-channel node)
+    "mcra": dict(mcra_alphaS=0.95, mcra_alphaD=0.95, mcra_alphaD2=0.98, mcra_delta=0.001, mcra_L=300, out_amp=3.5,
+                 out_only_noise=0),
 }
 
 _BASE = dict(

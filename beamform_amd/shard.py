@@ -5,7 +5,7 @@ The path shards naturally: frames are independent except for
   * mvdr/lcmv's covariance of the previous P frames,
 so rank r recomputes `halo` warm-up frames in front of its range locally and drops their output;
 no data-path collective is needed.  The only collective is the final gather of the output hops
-(RCCL over xGMI on GPUs; gloo in the CPU tests).  gss and phasempf recurse over frames and shard
+(RCCL over xGMI on GPUs; gloo in the CPU tests).  gss, phasempf and the mcra node recurse over frames and shard
 by stream only (halo = None).
 """
 from __future__ import annotations
@@ -20,7 +20,7 @@ def halo_frames(params: dict):
         return 1                                  # overlap-add neighbour only
     if algo in ("mvdr", "lcmv"):
         return int(params["past_windows"]) + 1    # covariance history of frame lo-1, plus that frame
-    return None                                   # gss / phasempf: recursion over frames
+    return None                                   # gss / phasempf / mcra: recursion over frames
 
 
 @dataclass

@@ -34,7 +34,9 @@ enum bf_algo {
     BF_LCMV = 2,     /* lcmv.cpp:88-140 */
     BF_GSS = 3,      /* gss.cpp:96-156 */
     BF_PHASE = 4,    /* phase.cpp:70-134 */
-    BF_PHASEMPF = 5  /* phasempf.cpp:193-302 + :331-334 */
+    BF_PHASEMPF = 5, /* phasempf.cpp:193-302 + :331-334 */
+    BF_MCRA = 6      /* mcra.cpp:64-155: single-channel MCRA noise subtraction (channel 0 only; uses mcra_*, out_amp,
+                        out_only_noise) */
 };
 
 enum bf_error {

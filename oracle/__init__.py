@@ -18,7 +18,7 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 MAX_MICS = 32
 MAX_INTERF = 16
-ALGO_ID = {"das": 0, "mvdr": 1, "lcmv": 2, "gss": 3, "phase": 4, "phasempf": 5}
+ALGO_ID = {"das": 0, "mvdr": 1, "lcmv": 2, "gss": 3, "phase": 4, "phasempf": 5, "mcra": 6}
 
 
 class OrcParams(C.Structure):
@@ -88,7 +88,7 @@ def to_struct(p: dict) -> OrcParams:
 
 
 class OracleNode:
-    """One reference node (das|mvdr|lcmv|gss|phase|phasempf) in double precision on the CPU."""
+    """One reference node (das|mvdr|lcmv|gss|phase|phasempf|mcra) in double precision on the CPU."""
 
     def __init__(self, params: dict):
         self.p = params

@@ -25,6 +25,8 @@
  *   Q1   freqs[fft_win/2] is never written (util.h:190-199)        -> 0.0
  *   Q15d phasempf y_fft[0] is never written (phasempf.cpp:274)     -> 0.0
  *        phasempf out_soi_square[0]/out_int_square[0] never written -> 0.0
+ *   Q16  mcra node: "y_fft[j] = in_fft(0,0)" runs with j == fft_win (mcra.cpp:127, one element past
+ *        the buffer); y_fft[0] is never written                      -> 0.0
  */
 #include "bf_oracle.h"
 
@@ -471,6 +473,66 @@ static void mcra(orc_node *n) {
     for (int j = 0; j < N; j++) n->S_prev[j] = n->S_[j];
 }
 
+
+/* mcra.cpp:64-155 -- the single-channel MCRA spectral-subtraction node (only channel 0 is used, mcra.cpp:72-73) */
+static void apply_mcra_node(orc_node *n) {
+    static const double win[3] = {0.25, 0.5, 0.25}; /* mcra.cpp:29-31 */
+    static const int pos[3] = {-1, 0, 1};
+    const int N = n->N;
+    prepare_input(n, 0, n->x_time.data());
+    dft_pow2(n->x_time.data(), n->x_fft.data(), N, -1);
+    for (int j = 0; j < N; j++) { /* mcra.cpp:75-78 */
+        n->in_fft(0, j) = n->x_fft[j];
+        n->soi2[j] = std::norm(n->x_fft[j]);
+    }
+    n->S_f[0] = std::abs(n->in_fft(0, 0)); /* magnitude, not power: mcra.cpp:83 */
+    for (int j = 1; j < N; j++) {          /* mcra.cpp:84-92: 3-tap smoothing over the neighbouring bins, bin 0 excluded */
+        n->S_f[j] = 0.0;
+        for (int i = 0; i < 3; i++) {
+            int this_j = j + pos[i];
+            if (this_j >= 1 && this_j < N) n->S_f[j] += win[i] * n->soi2[this_j];
+        }
+    }
+    for (int j = 0; j < N; j++) n->S_[j] = (n->p.mcra_alphaS * n->S_prev[j]) + ((1 - n->p.mcra_alphaS) * n->S_f[j]);
+    if (n->current_L > n->p.mcra_L) { /* mcra.cpp:100-113 */
+        for (int j = 0; j < N; j++) {
+            n->S_min[j] = dmin(n->S_tmp[j], n->S_[j]);
+            n->S_tmp[j] = n->S_[j];
+        }
+        n->current_L = 1;
+        n->first_L = false;
+    } else {
+        for (int j = 0; j < N; j++) {
+            n->S_min[j] = dmin(n->S_min[j], n->S_[j]);
+            n->S_tmp[j] = dmin(n->S_tmp[j], n->S_[j]);
+        }
+        n->current_L++;
+    }
+    for (int j = 0; j < N; j++) { /* mcra.cpp:116-124 */
+        if (n->first_L || n->S_[j] < n->S_min[j] * n->p.mcra_delta || n->lambda_noise[j] > n->soi2[j]) {
+            if (n->first_L && ((1.0f / (double)n->current_L) > n->p.mcra_alphaD)) {
+                n->lambda_noise[j] = (1.0f / (double)n->current_L) * n->lambda_noise[j] +
+                                     (1.0f - (1.0f / (double)n->current_L)) * n->soi2[j];
+            } else {
+                n->lambda_noise[j] = n->p.mcra_alphaD2 * n->lambda_noise[j] + (1.0f - n->p.mcra_alphaD) * n->soi2[j];
+            }
+        }
+    }
+    /* mcra.cpp:127: the store of in_fft(0,0) lands one past the end of y_fft; y_fft[0] keeps its value 0 (Q16) */
+    for (int j = 1; j < N; j++) { /* mcra.cpp:128-143 */
+        double this_pha = std::arg(n->in_fft(0, j));
+        double this_mag;
+        if (n->p.out_only_noise) {
+            this_mag = (sqrt(n->lambda_noise[j])) * n->p.out_amp;
+        } else {
+            this_mag = (std::abs(n->in_fft(0, j)) - sqrt(n->lambda_noise[j])) * n->p.out_amp;
+            if (this_mag < 0) this_mag = 0.0;
+        }
+        n->y_fft[j] = cd(this_mag * cos(this_pha), this_mag * sin(this_pha));
+    }
+    for (int j = 0; j < N; j++) n->S_prev[j] = n->S_[j]; /* mcra.cpp:146-148 */
+}
+
 /* phasempf.cpp:193-302 */
 static void apply_phasempf(orc_node *n) {
     forward_all(n);
@@ -535,6 +597,7 @@ static void apply_weights(orc_node *n, float *out, double *Ydump) {
         case ORC_LCMV: apply_mvdr_lcmv(n, true); break;
         case ORC_GSS: apply_gss(n); break;
         case ORC_PHASE: apply_phase(n); break;
+        case ORC_MCRA: apply_mcra_node(n); break;
         default: apply_phasempf(n); break;
     }
     if (Ydump) memcpy(Ydump, n->y_fft.data(), sizeof(cd) * n->N);
@@ -584,6 +647,10 @@ orc_node *orc_create(const orc_params *p) {
     }
     if (p->algo == ORC_GSS) n->sep_matrix.assign(n->N, Mat(n->S, n->M));
     n->phases_aligned.resize(n->M);
+    if (p->algo == ORC_MCRA) { /* mcra.cpp:257-271 */
+        std::vector<double> z(n->N, 0.0);
+        n->soi2 = z; n->S_ = z; n->S_prev = z; n->S_f = z; n->S_tmp = z; n->S_min = z; n->lambda_noise = z;
+    }
     if (p->algo == ORC_PHASEMPF) {
         n->past_samples.assign(p->smooth_size, 0.0); /* calloc, phasempf.cpp:510 */
         n->out_soi.assign(n->N, cd(0, 0)); n->out_int.assign(n->N, cd(0, 0));

@@ -23,7 +23,8 @@ extern "C" {
 #define ORC_MAX_MICS 32
 #define ORC_MAX_INTERF 16
 
-enum { ORC_DAS = 0, ORC_MVDR = 1, ORC_LCMV = 2, ORC_GSS = 3, ORC_PHASE = 4, ORC_PHASEMPF = 5 };
+enum { ORC_DAS = 0, ORC_MVDR = 1, ORC_LCMV = 2, ORC_GSS = 3, ORC_PHASE = 4, ORC_PHASEMPF = 5,
+       ORC_MCRA = 6 /* single-channel mcra node, mcra.cpp */ };
 
 typedef struct orc_params {
     int algo;
@@ -41,7 +42,7 @@ typedef struct orc_params {
     double mu, lambda_;
     /* phase (phase.cpp:24-27) */
     double min_phase, mag_mult, mag_threshold;
-    /* phasempf (phasempf.cpp:30-59) */
+    /* phasempf (phasempf.cpp:30-59); the mcra node (mcra.cpp:40-48) uses the mcra_* fields, out_amp and out_only_noise */
     double min_mag;
     int smooth_size;
     double mcra_alphaS, mcra_alphaD, mcra_alphaD2, mcra_delta;

@@ -249,6 +249,43 @@ def phasempf_bins(p, X, w):
     return Y
 
 
+def mcra_node_bins(p, X):
+    """mcra.cpp:64-155 (channel 0 only).  Returns Y [F, N]."""
+    F, M, N = X.shape
+    aS, aD, aD2, delta, L = p["mcra_alphaS"], p["mcra_alphaD"], p["mcra_alphaD2"], p["mcra_delta"], p["mcra_L"]
+    Sprev = np.zeros(N); Stmp = np.zeros(N); Smin = np.zeros(N); lam = np.zeros(N)
+    cL, firstL = 0, True
+    Y = np.zeros((F, N), np.complex128)
+    for t in range(F):
+        x = X[t, 0]
+        x2 = x.real ** 2 + x.imag ** 2
+        lo = np.concatenate([[0.0], x2[:-1]]); lo[1] = 0.0   # bin 0 is excluded from the smoothing window
+        hi = np.concatenate([x2[1:], [0.0]])                 # bin N does not exist
+        Sf = (0.25 * lo + 0.5 * x2) + 0.25 * hi
+        Sf[0] = np.abs(x[0])
+        S = aS * Sprev + (1 - aS) * Sf
+        if cL > L:
+            Smin = np.minimum(Stmp, S); Stmp = S.copy(); cL = 1; firstL = False
+        else:
+            Smin = np.minimum(Smin, S); Stmp = np.minimum(Stmp, S); cL += 1
+        cond = np.ones(N, bool) if firstL else ((S < Smin * delta) | (lam > x2))
+        if firstL and (1.0 / cL) > aD:
+            new = (1.0 / cL) * lam + (1.0 - 1.0 / cL) * x2
+        else:
+            new = aD2 * lam + (1.0 - aD) * x2
+        lam = np.where(cond, new, lam)
+        Sprev = S
+        ph = np.angle(x)
+        if p["out_only_noise"]:
+            g = np.sqrt(lam) * p["out_amp"]
+        else:
+            g = np.maximum((np.abs(x) - np.sqrt(lam)) * p["out_amp"], 0.0)
+        Yt = g * np.cos(ph) + 1j * (g * np.sin(ph))
+        Yt[0] = 0.0  # never written by the node
+        Y[t] = Yt
+    return Y
+
+
 def constraint_matrices(p: dict, theta: float) -> np.ndarray:
     """lcmv.cpp:44-86: C_j = [steer, interferer_1..K] -> [N, M, S]."""
     cols = [steering(p, theta)] + [steering(p, a) for a in p["interf"]]
@@ -274,6 +311,8 @@ def process(p: dict, x: np.ndarray):
         Y = phase_bins(p, X, w)
     elif algo == "phasempf":
         Y = phasempf_bins(p, X, w)
+    elif algo == "mcra":
+        Y = mcra_node_bins(p, X)
     else:
         raise ValueError(algo)
     y = istft_ola(p, Y, post)

@@ -31,19 +31,23 @@ CASES = [
     ("lcmv16", "lcmv", 16, (-60.0, 90.0, 150.0), 14, 20.0),  # config 5 shape
     ("gss8", "gss", 8, (-60.0, 90.0), 12, 20.0),
     ("phase8", "phase", 8, (), 10, 20.0),
+    ("mcra2", "mcra", 2, (), 24, 0.0, dict(mcra_L=8)),  # SURVEY 8(f) row 2; short L puts the minima reset inside the run
 ]
 
 
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
-    for name, algo, M, interf, F, theta in CASES:
-        p = make_params(algo, n_mics=M, interf=interf, theta=theta)
+    only = set(sys.argv[1:])  # optional: names to (re)generate; default all
+    for name, algo, M, interf, F, theta, *over in CASES:
+        if only and name not in only:
+            continue
+        p = make_params(algo, n_mics=M, interf=interf, theta=theta, **(over[0] if over else {}))
         x = make_scene(M, F, seed=sum(map(ord, name)))
         y, Y = oracle.OracleNode(p).process(x, want_spectrum=True)
         y2, Y2 = np_oracle.process(p, x)
         fin = np.isfinite(Y).all(axis=1)
         assert (fin == np.isfinite(Y2).all(axis=1)).all(), name
-        worst = max(np.linalg.norm(Y[t] - Y2[t]) / np.linalg.norm(Y2[t]) for t in range(F) if fin[t])
+        worst = max(np.linalg.norm(Y[t] - Y2[t]) / (np.linalg.norm(Y2[t]) or 1.0) for t in range(F) if fin[t])
         assert worst < 1e-10, (name, worst)
         ok = np.isfinite(y)
         assert np.array_equal(y[ok], y2[ok]), name

@@ -32,7 +32,8 @@ def test_oracle_reproduces_golden(path):
 
 
 @pytest.mark.parametrize("algo,M,interf", [("das", 4, ()), ("mvdr", 8, ()), ("lcmv", 8, (-60.0, 90.0)),
-                                           ("gss", 8, (-60.0,)), ("gss", 3, ()), ("phase", 8, ()), ("phasempf", 8, ())])
+                                           ("gss", 8, (-60.0,)), ("gss", 3, ()), ("phase", 8, ()), ("phasempf", 8, ()),
+                                           ("mcra", 4, ())])
 def test_oracle_agrees_with_numpy_restatement(algo, M, interf):
     p = make_params(algo, n_mics=M, interf=interf, theta=-30.0)
     x = make_scene(M, 20, seed=17)
@@ -43,6 +44,18 @@ def test_oracle_agrees_with_numpy_restatement(algo, M, interf):
     assert max(rel_l2(Y[t], Y2[t]) for t in range(20) if fin[t]) < 1e-10
     ok = np.isfinite(y)
     assert np.array_equal(y[ok], y2[ok])
+
+
+def test_mcra_node_minima_reset_agrees_with_numpy_restatement():
+    """mcra.cpp:100-113 with a short L so the S_min/S_tmp reset and the end of first_L fall inside the run."""
+    p = make_params("mcra", n_mics=2, mcra_L=6)
+    x = make_scene(2, 40, seed=23)
+    y, Y = oracle.OracleNode(p).process(x, want_spectrum=True)
+    y2, Y2 = np_oracle.process(p, x)
+    assert max(rel_l2(Y[t], Y2[t]) for t in range(40)) < 1e-10
+    assert np.array_equal(y, y2)
+    assert np.all(Y[:, 0] == 0)           # Q16: bin 0 never written
+    assert np.abs(Y[5:, 1:]).max() > 0    # and the rest is live
 
 
 def test_fft_matches_numpy():

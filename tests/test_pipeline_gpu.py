@@ -18,11 +18,11 @@ def _torch():
     return torch
 
 
-def run_gpu(p, x, n_streams=1, **kw):
+def run_gpu(p, x, n_streams=1, F=None, **kw):
     """-> (y [F*512] float32, Y [F,1024] complex128) through bf_process_batch_device."""
     from beamform_amd.capi import Beamformer
     torch = _torch()
-    F = x.shape[-1] // 512
+    F = F or x.shape[-1] // 512
     bf = Beamformer(p, n_streams=n_streams, **kw)
     xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
     yd = torch.empty((n_streams, F * 512), dtype=torch.float32, device="cuda")
@@ -149,6 +149,25 @@ def test_phasempf_matches_oracle(M, F, over):
     check(y, Y, y_ref, Y_ref)
 
 
+@pytest.mark.parametrize("M,F,over,layout", [(4, 90, {}, "planar"), (1, 50, dict(mcra_L=7), "planar"),
+                                             (8, 40, dict(out_only_noise=1, mcra_L=12), "planar"),
+                                             (3, 30, dict(mcra_L=5), "interleaved")])
+def test_mcra_node_matches_oracle(M, F, over, layout):
+    """SURVEY 8(f) row 2: the single-channel mcra node (mcra.cpp:64-155) -- only channel 0 of the M inputs is used;
+    small mcra_L exercises the minima-search reset; interleaved input checks the channel-0 stride."""
+    import oracle
+    from beamform_amd.capi import BF_INTERLEAVED
+    p = make_params("mcra", n_mics=M, **over)
+    x = make_scene(M, F, seed=900 + M)
+    y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
+    if layout == "planar":
+        y, Y = run_gpu(p, x)
+    else:
+        y, Y = run_gpu(p, np.ascontiguousarray(x.T), F=F, layout=BF_INTERLEAVED)
+    check(y, Y, y_ref, Y_ref)
+    assert np.all(Y[:, 0] == 0)  # quirk Q16: bin 0 is never written by the node
+
+
 @pytest.mark.parametrize("M,interf,F", [(8, (-60.0, 90.0), 50), (4, (), 40), (16, (-60.0, 90.0, 150.0), 20)])
 def test_gss_matches_oracle(M, interf, F):
     import oracle
@@ -159,7 +178,8 @@ def test_gss_matches_oracle(M, interf, F):
     check(y, Y, y_ref, Y_ref)
 
 
-@pytest.mark.parametrize("algo,interf", [("phasempf", ()), ("gss", (-60.0, 90.0)), ("phase", ()), ("lcmv", (-60.0,))])
+@pytest.mark.parametrize("algo,interf", [("phasempf", ()), ("gss", (-60.0, 90.0)), ("phase", ()), ("lcmv", (-60.0,)),
+                                         ("mcra", ())])
 def test_recursive_state_carries_across_batches_and_theta(algo, interf):
     """Batches of uneven length == one stream; /theta in the middle == the oracle's set_theta
     (gss re-initialises its demixing matrices, gss.cpp:90-93)."""
@@ -186,7 +206,7 @@ def test_recursive_state_carries_across_batches_and_theta(algo, interf):
     assert rel_l2(y[ok], y_ref[ok]) < TOL_TIME
 
 
-@pytest.mark.parametrize("algo", ["mvdr", "phasempf", "gss"])
+@pytest.mark.parametrize("algo", ["mvdr", "phasempf", "gss", "mcra"])
 def test_pipeline_checkpoint_roundtrip(algo):
     from beamform_amd.capi import Beamformer
     _torch()
