@@ -14,7 +14,7 @@ import numpy as np
 from .params import ALGO_ID
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbfcore.so")
+LIB_PATH = os.environ.get("BFCORE_LIB") or os.path.join(_HERE, "lib", "libbfcore.so")  # BFCORE_LIB: A/B builds of the same ABI
 
 BF_MAX_MICS = 32
 BF_MAX_INTERF = 15
@@ -26,7 +26,7 @@ EXPORTS = (
     "bf_version", "bf_strerror", "bf_last_error", "bf_device_count", "bf_config_init", "bf_config_load_yaml",
     "bf_config_parse_yaml", "bf_create", "bf_destroy", "bf_set_theta", "bf_set_interference", "bf_process_hop",
     "bf_process_batch", "bf_process_batch_device", "bf_get_weights", "bf_state_size", "bf_get_state", "bf_set_state",
-    "bf_reset", "bf_time_batch_device", "bf_n_interferers",
+    "bf_reset", "bf_time_batch_device", "bf_n_interferers", "bf_set_theta_dir", "bf_set_thetas", "bf_stream_rms",
 )
 
 
@@ -45,7 +45,7 @@ class BfConfig(C.Structure):
         ("mpf_alphaS", C.c_double), ("mpf_eta", C.c_double), ("mpf_rev_gamma", C.c_double),
         ("mpf_rev_delta", C.c_double), ("noise_floor", C.c_double),
         ("out_only_noise", C.c_int), ("out_only_mcra", C.c_int),
-        ("device", C.c_int), ("n_streams", C.c_int), ("layout", C.c_int), ("das_impl", C.c_int),
+        ("device", C.c_int), ("n_streams", C.c_int), ("layout", C.c_int), ("das_impl", C.c_int), ("n_dirs", C.c_int),
     ]
 
 
@@ -79,6 +79,9 @@ def load():
     L.bf_destroy.argtypes = [C.c_void_p]
     L.bf_destroy.restype = None
     L.bf_set_theta.argtypes = [C.c_void_p, C.c_double]
+    L.bf_set_theta_dir.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.bf_set_thetas.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+    L.bf_stream_rms.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_double), C.c_void_p]
     L.bf_set_interference.argtypes = [C.c_void_p, C.c_uint, C.c_double]
     L.bf_n_interferers.argtypes = [C.c_void_p]
     L.bf_process_hop.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32]
@@ -97,7 +100,7 @@ def load():
 
 
 def config_from_params(p: dict, device: int = 0, n_streams: int = 1, layout: int = BF_PLANAR,
-                       das_impl: int = BF_DAS_FUSED_F32) -> BfConfig:
+                       das_impl: int = BF_DAS_FUSED_F32, n_dirs: int = 1) -> BfConfig:
     """bf_config from a beamform_amd.params dict (launch defaults first, then overrides)."""
     L = load()
     c = BfConfig()
@@ -118,7 +121,7 @@ def config_from_params(p: dict, device: int = 0, n_streams: int = 1, layout: int
               "mcra_delta", "mcra_L", "mpf_alphaS", "mpf_eta", "mpf_rev_gamma", "mpf_rev_delta", "noise_floor",
               "out_only_noise", "out_only_mcra"):
         setattr(c, k, p[k])
-    c.device, c.n_streams, c.layout, c.das_impl = device, n_streams, layout, das_impl
+    c.device, c.n_streams, c.layout, c.das_impl, c.n_dirs = device, n_streams, layout, das_impl, n_dirs
     return c
 
 
@@ -126,9 +129,11 @@ class Beamformer:
     """One beamformer node behind the C ABI (das|mvdr|lcmv|gss|phase|phasempf|mcra)."""
 
     def __init__(self, params: dict, device: int = 0, n_streams: int = 1, layout: int = BF_PLANAR,
-                 das_impl: int = BF_DAS_FUSED_F32):
+                 das_impl: int = BF_DAS_FUSED_F32, n_dirs: int = 1):
         self._L = load()
-        self.cfg = config_from_params(params, device, n_streams, layout, das_impl)
+        self.cfg = config_from_params(params, device, n_streams, layout, das_impl, n_dirs)
+        self.n_dirs = max(1, n_dirs)
+        self.n_out = n_streams * self.n_dirs  # output streams: [stream][dir]
         self.M, self.H, self.N = params["n_mics"], params["hop"], 2 * params["hop"]
         self.S = len(params["interf"]) + 1 if params["algo"] in ("lcmv", "gss") else 1
         self.n_streams = n_streams
@@ -152,6 +157,20 @@ class Beamformer:
     def set_theta(self, deg: float):
         self._chk(self._L.bf_set_theta(self._h, float(deg)), "bf_set_theta")
 
+    def set_theta_dir(self, d: int, deg: float):
+        self._chk(self._L.bf_set_theta_dir(self._h, int(d), float(deg)), "bf_set_theta_dir")
+
+    def set_thetas(self, degs):
+        """One /theta per look direction (n_dirs of them), one table rebuild."""
+        a = (C.c_double * len(degs))(*[float(v) for v in degs])
+        self._chk(self._L.bf_set_thetas(self._h, a, len(degs)), "bf_set_thetas")
+
+    def stream_rms(self, y_ptr: int, n_frames: int, stream: int = 0) -> np.ndarray:
+        """RMS of every output stream of a device-resident batch -> [n_streams, n_dirs] float64."""
+        out = (C.c_double * self.n_out)()
+        self._chk(self._L.bf_stream_rms(self._h, y_ptr, n_frames, out, stream or None), "bf_stream_rms")
+        return np.array(out[:], np.float64).reshape(self.n_streams, self.n_dirs)
+
     def set_interference(self, idx: int, deg: float) -> int:
         """interf_theta_roscallback; returns the interferer count afterwards."""
         self._chk(self._L.bf_set_interference(self._h, int(idx), float(deg)), "bf_set_interference")
@@ -172,17 +191,17 @@ class Beamformer:
         x = np.ascontiguousarray(x, np.float32)
         assert x.shape == (self.M, self.H)
         ptrs = (C.c_void_p * self.M)(*[x[m].ctypes.data for m in range(self.M)])
-        out = np.empty(self.H, np.float32)
+        out = np.empty((self.n_dirs, self.H), np.float32)
         self._chk(self._L.bf_process_hop(self._h, ptrs, out.ctypes.data, self.H), "bf_process_hop")
-        return out
+        return out[0] if self.n_dirs == 1 else out
 
     def process(self, x: np.ndarray) -> np.ndarray:
         """Host batch. planar: x [S, M, F*H] (or [M, F*H] when S == 1); interleaved: [S, F*H, M]."""
         x = np.ascontiguousarray(x, np.float32)
         n = x.size // (self.n_streams * self.M * self.H)
-        y = np.empty((self.n_streams, n * self.H), np.float32)
+        y = np.empty((self.n_out, n * self.H), np.float32)
         self._chk(self._L.bf_process_batch(self._h, x.ctypes.data, n, y.ctypes.data), "bf_process_batch")
-        return y[0] if self.n_streams == 1 else y
+        return y[0] if self.n_out == 1 else y
 
     def process_device(self, x_ptr: int, n_frames: int, y_ptr: int, spectrum_ptr: int = 0, stream: int = 0):
         self._chk(self._L.bf_process_batch_device(self._h, x_ptr, n_frames, y_ptr, spectrum_ptr or None, stream or None),

@@ -6,6 +6,7 @@
 // operation runs in the gfx950 kernels.  There is no CPU compute fallback.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -24,7 +25,8 @@ static thread_local std::string g_last_error;
 
 struct bf_handle {
     bf_config cfg;
-    int M = 0, H = 0, N = 0, S = 1, n_streams = 1;
+    int M = 0, H = 0, N = 0, S = 1, n_streams = 1;  // n_streams: input streams
+    int n_dirs = 1, n_out = 1;                      // look directions per input stream; output streams = n_streams * n_dirs
     int device = 0, n_cus = 256;
     std::string err;
 
@@ -32,8 +34,8 @@ struct bf_handle {
     std::mutex mu;
     ArrayGeometry geo;
     std::vector<double> freqs;
-    SteeringSet steer;
-    double angle = 0.0;
+    std::vector<SteeringSet> steer;  // one per look direction
+    std::vector<double> angle;       // /theta of every look direction
     std::vector<double> interf;
     bool tables_dirty = true;
 
@@ -51,6 +53,7 @@ struct bf_handle {
     int tail_cur = 0;  // index of the valid hist/tail pair; the kernel writes the other one
     f32x2 *d_sdump = nullptr;
     size_t sdump_cap = 0;
+    double *d_sumsq = nullptr;  // bf_stream_rms scratch
 
     // bin pipeline (mvdr/lcmv/gss/phase/phasempf and DAS_BINS_F64)
     BinPipeline *pipe = nullptr;
@@ -87,9 +90,12 @@ int fail(bf_handle *h, int code, const char *what, hipError_t e = hipSuccess) {
 bool uses_fused_das(const bf_handle *h) { return h->cfg.algo == BF_DAS && h->cfg.das_impl == BF_DAS_FUSED_F32; }
 
 // update_weights(): recompute every steering column from the current angles.
-void rebuild_steering(bf_handle *h, bool first) {
-    h->steer.update_column(h->geo, h->freqs, 0, h->angle, first);
-    for (int k = 0; k < h->S - 1; ++k) h->steer.update_column(h->geo, h->freqs, k + 1, h->interf[k], first);
+void rebuild_steering(bf_handle *h, bool first, int only_dir = -1) {
+    for (int d = 0; d < h->n_dirs; ++d) {
+        if (only_dir >= 0 && d != only_dir) continue;
+        h->steer[d].update_column(h->geo, h->freqs, 0, h->angle[d], first);
+        for (int k = 0; k < h->S - 1; ++k) h->steer[d].update_column(h->geo, h->freqs, k + 1, h->interf[k], first);
+    }
     h->tables_dirty = true;
 }
 
@@ -99,11 +105,20 @@ int sync_tables(bf_handle *h, hipStream_t s) {
     std::lock_guard<std::mutex> lk(h->mu);
     if (!h->tables_dirty) return BF_OK;
     if (uses_fused_das(h)) {
-        std::vector<f32x2> g = das_pair_gains(h->steer, (h->M + 1) / 2);
+        const int np = (h->M + 1) / 2;
+        std::vector<f32x2> g, g64;  // [dir][pair][1024]
+        for (int d = 0; d < h->n_dirs; ++d) {
+            const std::vector<f32x2> gd = das_pair_gains(h->steer[d], np);
+            g.insert(g.end(), gd.begin(), gd.end());
+            if (h->use_w64) {
+                const std::vector<f32x2> gw = das_pair_gains_w64(gd, np);
+                g64.insert(g64.end(), gw.begin(), gw.end());
+            }
+        }
         const int nxt = h->gains_cur ^ 1;
         BF_HIP(h, hipMemcpyAsync(h->d_gains[nxt], g.data(), g.size() * sizeof(f32x2), hipMemcpyHostToDevice, s));
-        std::vector<f32x2> g64 = das_pair_gains_w64(g, (h->M + 1) / 2);
-        BF_HIP(h, hipMemcpyAsync(h->d_gains_w64[nxt], g64.data(), g64.size() * sizeof(f32x2), hipMemcpyHostToDevice, s));
+        if (h->use_w64)
+            BF_HIP(h, hipMemcpyAsync(h->d_gains_w64[nxt], g64.data(), g64.size() * sizeof(f32x2), hipMemcpyHostToDevice, s));
         BF_HIP(h, hipStreamSynchronize(s));  // pageable staging vectors go out of scope
         h->gains_cur = nxt;
     }
@@ -118,7 +133,7 @@ int sync_tables(bf_handle *h, hipStream_t s) {
 int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_dev, void *spectrum_dev, hipStream_t s,
                   int layout, long mic_stride) {
     const long F = (long)n_frames;
-    const int S = h->n_streams;
+    const int S = h->n_out;
     // one block (16 half-wavefronts) per run of consecutive frames; runs are multiples of 16 frames and
     // there are about as many runs as CUs
     long runs = h->n_cus / S;
@@ -154,6 +169,7 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     a.mic_stride = mic_stride;
     a.stream_stride_x = (long)h->M * F * h->H;
     a.n_streams = S;
+    a.n_dirs = h->n_dirs;
     a.n_mics = h->M;
     a.frames_per_chunk = (int)fpc;
     a.chunks_per_stream = (int)cps;
@@ -237,6 +253,9 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
     if (cfg->n_mics < 1 || cfg->n_mics > BF_MAX_MICS) return fail(nullptr, BF_EINVAL, "n_mics out of range");
     if (cfg->hop != 512) return fail(nullptr, BF_ENOSYS, "only hop 512 (fft_win 1024) is built");
     if (cfg->n_streams < 1) return fail(nullptr, BF_EINVAL, "n_streams < 1");
+    if (cfg->n_dirs < 0 || cfg->n_dirs > BF_MAX_DIRS) return fail(nullptr, BF_EINVAL, "n_dirs out of range");
+    if (cfg->n_dirs > 1 && !(cfg->algo == BF_DAS || cfg->algo == BF_PHASE || cfg->algo == BF_MVDR || cfg->algo == BF_LCMV))
+        return fail(nullptr, BF_ENOSYS, "look-direction batches are built for das, phase, mvdr and lcmv");
     if (cfg->n_interf < 0 || cfg->n_interf > BF_MAX_INTERF) return fail(nullptr, BF_EINVAL, "n_interf out of range");
     if (cfg->layout != BF_PLANAR && cfg->layout != BF_INTERLEAVED) return fail(nullptr, BF_EINVAL, "layout");
     int ndev = bf_device_count();
@@ -251,8 +270,11 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
     const bool multi = (cfg->algo == BF_LCMV || cfg->algo == BF_GSS);
     h->S = multi ? cfg->n_interf + 1 : 1;
     h->n_streams = cfg->n_streams;
+    h->n_dirs = cfg->n_dirs > 1 ? cfg->n_dirs : 1;
+    h->cfg.n_dirs = h->n_dirs;
+    h->n_out = h->n_streams * h->n_dirs;
     h->device = cfg->device;
-    h->angle = cfg->theta;
+    h->angle.assign(h->n_dirs, cfg->theta);
     for (int k = 0; k < h->S - 1; ++k) h->interf.push_back(cfg->interf_angle[k]);
 
 #define BF_CREATE_HIP(call)                                   \
@@ -273,16 +295,17 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
     // handle_params + calculate_frequency_vector + update_weights(true)
     h->geo.set(cfg->mic_x, cfg->mic_y, h->M);
     h->freqs = frequency_vector(h->N, cfg->sample_rate);
-    h->steer.allocate(h->N, h->M, h->S);
+    h->steer.resize(h->n_dirs);
+    for (auto &st : h->steer) st.allocate(h->N, h->M, h->S);
     rebuild_steering(h, true);
 
     BF_CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     BF_CREATE_HIP(hipEventCreate(&h->ev0));
     BF_CREATE_HIP(hipEventCreate(&h->ev1));
 
-    const size_t S = h->n_streams;
+    const size_t S = h->n_streams, So = h->n_out;
     if (uses_fused_das(h)) {
-        const size_t gsz = (size_t)((h->M + 1) / 2) * 1024;
+        const size_t gsz = (size_t)((h->M + 1) / 2) * 1024 * h->n_dirs;
         BF_CREATE_HIP(hipMalloc((void **)&h->d_gains[0], gsz * sizeof(f32x2)));
         BF_CREATE_HIP(hipMalloc((void **)&h->d_gains[1], gsz * sizeof(f32x2)));
         BF_CREATE_HIP(hipMalloc((void **)&h->d_gains_w64[0], gsz * sizeof(f32x2)));
@@ -292,7 +315,7 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
             BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle_w64, tw64.size() * sizeof(f32x2)));
             BF_CREATE_HIP(hipMemcpy(h->d_twiddle_w64, tw64.data(), tw64.size() * sizeof(f32x2), hipMemcpyHostToDevice));
         }
-        h->use_w64 = getenv("BF_DAS_W64") && atoi(getenv("BF_DAS_W64")) != 0;
+        h->use_w64 = getenv("BF_DAS_W64") && atoi(getenv("BF_DAS_W64")) != 0 && h->n_dirs == 1;
         std::vector<f32x2> tw = twiddle_table_32x32<f32x2>();
         BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle, tw.size() * sizeof(f32x2)));
         BF_CREATE_HIP(hipMemcpy(h->d_twiddle, tw.data(), tw.size() * sizeof(f32x2), hipMemcpyHostToDevice));
@@ -305,8 +328,8 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
         BF_CREATE_HIP(hipMemset(h->d_zeros, 0, 1024 * sizeof(float)));
         BF_CREATE_HIP(hipMalloc((void **)&h->d_hist[0], S * h->M * h->H * sizeof(float)));
         BF_CREATE_HIP(hipMalloc((void **)&h->d_hist[1], S * h->M * h->H * sizeof(float)));
-        BF_CREATE_HIP(hipMalloc((void **)&h->d_tail[0], S * h->H * sizeof(float)));
-        BF_CREATE_HIP(hipMalloc((void **)&h->d_tail[1], S * h->H * sizeof(float)));
+        BF_CREATE_HIP(hipMalloc((void **)&h->d_tail[0], So * h->H * sizeof(float)));
+        BF_CREATE_HIP(hipMalloc((void **)&h->d_tail[1], So * h->H * sizeof(float)));
     } else {
         h->pipe = BinPipeline::create(h->cfg, h->n_cus);
         if (!h->pipe) {
@@ -346,6 +369,7 @@ void bf_destroy(bf_handle *h) {
     if (h->d_window) (void)hipFree(h->d_window);
     if (h->d_zeros) (void)hipFree(h->d_zeros);
     if (h->d_sdump) (void)hipFree(h->d_sdump);
+    if (h->d_sumsq) (void)hipFree(h->d_sumsq);
     if (h->d_x) (void)hipFree(h->d_x);
     if (h->d_y) (void)hipFree(h->d_y);
     delete h->pipe;
@@ -363,8 +387,8 @@ int bf_reset(bf_handle *h) {
         // prepare_overlap_and_add: ring pre-filled with one hop of zeros, out_buff calloc'ed (util.h:272-286)
         BF_HIP(h, hipMemset(h->d_hist[0], 0, S * h->M * h->H * sizeof(float)));
         BF_HIP(h, hipMemset(h->d_hist[1], 0, S * h->M * h->H * sizeof(float)));
-        BF_HIP(h, hipMemset(h->d_tail[0], 0, S * h->H * sizeof(float)));
-        BF_HIP(h, hipMemset(h->d_tail[1], 0, S * h->H * sizeof(float)));
+        BF_HIP(h, hipMemset(h->d_tail[0], 0, (size_t)h->n_out * h->H * sizeof(float)));
+        BF_HIP(h, hipMemset(h->d_tail[1], 0, (size_t)h->n_out * h->H * sizeof(float)));
         h->tail_cur = 0;
     } else if (h->pipe) {
         int rc = h->pipe->reset();
@@ -373,12 +397,40 @@ int bf_reset(bf_handle *h) {
     return BF_OK;
 }
 
-int bf_set_theta(bf_handle *h, double degrees) {
+int bf_set_theta_dir(bf_handle *h, int dir, double degrees) {
     if (!h) return BF_EINVAL;
+    if (dir < 0 || dir >= h->n_dirs) return fail(h, BF_EINVAL, "look direction index out of range");
     std::lock_guard<std::mutex> lk(h->mu);
-    h->angle = degrees;
-    rebuild_steering(h, false);
+    h->angle[dir] = degrees;
+    rebuild_steering(h, false, dir);
     if (h->pipe) h->pipe->on_theta_changed();  // gss resets its demixing matrices (gss.cpp:90-93)
+    return BF_OK;
+}
+
+int bf_set_theta(bf_handle *h, double degrees) { return bf_set_theta_dir(h, 0, degrees); }
+
+int bf_set_thetas(bf_handle *h, const double *degrees, int n) {
+    if (!h || !degrees) return BF_EINVAL;
+    if (n < 1 || n > h->n_dirs) return fail(h, BF_EINVAL, "more angles than look directions");
+    std::lock_guard<std::mutex> lk(h->mu);
+    for (int d = 0; d < n; ++d) {
+        h->angle[d] = degrees[d];
+        rebuild_steering(h, false, d);
+    }
+    if (h->pipe) h->pipe->on_theta_changed();
+    return BF_OK;
+}
+
+int bf_stream_rms(bf_handle *h, const float *y_dev, size_t n_frames, double *rms_host, void *hip_stream) {
+    if (!h || !y_dev || !rms_host || n_frames == 0) return BF_EINVAL;
+    BF_HIP(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (!h->d_sumsq) BF_HIP(h, hipMalloc((void **)&h->d_sumsq, sizeof(double) * h->n_out));
+    const long n = (long)n_frames * h->H;
+    BF_HIP(h, launch_stream_rms(y_dev, n, h->n_out, h->d_sumsq, s));
+    BF_HIP(h, hipMemcpyAsync(rms_host, h->d_sumsq, sizeof(double) * h->n_out, hipMemcpyDeviceToHost, s));
+    BF_HIP(h, hipStreamSynchronize(s));
+    for (int i = 0; i < h->n_out; ++i) rms_host[i] = std::sqrt(rms_host[i] / (double)n);  // energy2theta.py:23-27
     return BF_OK;
 }
 
@@ -412,7 +464,7 @@ int bf_set_interference(bf_handle *h, unsigned id, double degrees) {
     if (structural) {
         // free_interf_buffers + allocate_interf_buffers: weights come back zeroed, row 0 is not rewritten (Q3)
         h->S = (int)ia.size() + 1;
-        h->steer.allocate(h->N, h->M, h->S);
+        for (auto &st : h->steer) st.allocate(h->N, h->M, h->S);
         if (h->pipe) h->pipe->set_columns(h->S);
     }
     rebuild_steering(h, false);
@@ -429,7 +481,7 @@ int bf_n_interferers(bf_handle *h) {
 int bf_get_weights(bf_handle *h, double *w_host) {
     if (!h || !w_host) return BF_EINVAL;
     std::lock_guard<std::mutex> lk(h->mu);
-    memcpy(w_host, h->steer.w.data(), h->steer.w.size() * sizeof(cplxd));
+    memcpy(w_host, h->steer[0].w.data(), h->steer[0].w.size() * sizeof(cplxd));  // look direction 0
     return BF_OK;
 }
 
@@ -446,7 +498,7 @@ int bf_process_batch(bf_handle *h, const float *x_host, size_t n_frames, float *
     if (n_frames == 0) return BF_OK;
     BF_HIP(h, hipSetDevice(h->device));
     const size_t xe = (size_t)h->n_streams * h->M * n_frames * h->H;
-    const size_t ye = (size_t)h->n_streams * n_frames * h->H;
+    const size_t ye = (size_t)h->n_out * n_frames * h->H;
     int rc = ensure_staging(h, xe, ye);
     if (rc != BF_OK) return rc;
     BF_HIP(h, hipMemcpyAsync(h->d_x, x_host, xe * sizeof(float), hipMemcpyHostToDevice, h->stream));
@@ -462,7 +514,7 @@ int bf_process_hop(bf_handle *h, const float *const *in, float *out, uint32_t nf
     if ((int)nframes != h->H) return fail(h, BF_EINVAL, "nframes must equal the configured hop");
     if (h->n_streams != 1) return fail(h, BF_EINVAL, "bf_process_hop drives stream 0 of a single-stream handle");
     BF_HIP(h, hipSetDevice(h->device));
-    int rc = ensure_staging(h, (size_t)h->M * h->H, (size_t)h->H);
+    int rc = ensure_staging(h, (size_t)h->M * h->H, (size_t)h->n_out * h->H);
     if (rc != BF_OK) return rc;
     std::vector<float> packed((size_t)h->M * h->H);
     if (h->cfg.layout == BF_PLANAR) {
@@ -474,7 +526,7 @@ int bf_process_hop(bf_handle *h, const float *const *in, float *out, uint32_t nf
     BF_HIP(h, hipMemcpyAsync(h->d_x, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     rc = run_batch_device(h, h->d_x, 1, h->d_y, nullptr, h->stream, h->cfg.layout, (long)h->H);
     if (rc != BF_OK) return rc;
-    BF_HIP(h, hipMemcpyAsync(out, h->d_y, sizeof(float) * h->H, hipMemcpyDeviceToHost, h->stream));
+    BF_HIP(h, hipMemcpyAsync(out, h->d_y, sizeof(float) * h->n_out * h->H, hipMemcpyDeviceToHost, h->stream));  // [dir][hop]
     BF_HIP(h, hipStreamSynchronize(h->stream));
     return BF_OK;
 }
@@ -519,7 +571,7 @@ size_t bf_state_size(const bf_handle *h) {
     if (!h) return 0;
     size_t payload;
     if (uses_fused_das(h))
-        payload = ((size_t)h->n_streams * h->M * h->H + (size_t)h->n_streams * h->H) * sizeof(float);
+        payload = ((size_t)h->n_streams * h->M * h->H + (size_t)h->n_out * h->H) * sizeof(float);
     else
         payload = h->pipe ? h->pipe->state_bytes() : 0;
     return sizeof(bf_state_header) + payload;
@@ -529,12 +581,12 @@ int bf_get_state(bf_handle *h, void *blob, size_t size) {
     if (!h || !blob || size < bf_state_size(h)) return BF_EINVAL;
     BF_HIP(h, hipSetDevice(h->device));
     BF_HIP(h, hipDeviceSynchronize());
-    bf_state_header hd = {kStateMagic, (uint32_t)h->cfg.algo, (uint32_t)h->M, (uint32_t)h->n_streams, (uint32_t)h->H,
-                          (uint32_t)h->cfg.das_impl, (uint64_t)(bf_state_size(h) - sizeof(bf_state_header))};
+    bf_state_header hd = {kStateMagic, (uint32_t)h->cfg.algo, (uint32_t)h->M, (uint32_t)h->n_streams | ((uint32_t)h->n_dirs << 20),
+                          (uint32_t)h->H, (uint32_t)h->cfg.das_impl, (uint64_t)(bf_state_size(h) - sizeof(bf_state_header))};
     memcpy(blob, &hd, sizeof(hd));
     char *p = (char *)blob + sizeof(hd);
     if (uses_fused_das(h)) {
-        const size_t hb = (size_t)h->n_streams * h->M * h->H * sizeof(float), tb = (size_t)h->n_streams * h->H * sizeof(float);
+        const size_t hb = (size_t)h->n_streams * h->M * h->H * sizeof(float), tb = (size_t)h->n_out * h->H * sizeof(float);
         BF_HIP(h, hipMemcpy(p, h->d_hist[h->tail_cur], hb, hipMemcpyDeviceToHost));
         BF_HIP(h, hipMemcpy(p + hb, h->d_tail[h->tail_cur], tb, hipMemcpyDeviceToHost));
         return BF_OK;
@@ -548,13 +600,13 @@ int bf_set_state(bf_handle *h, const void *blob, size_t size) {
     bf_state_header hd;
     memcpy(&hd, blob, sizeof(hd));
     if (hd.magic != kStateMagic || hd.algo != (uint32_t)h->cfg.algo || hd.n_mics != (uint32_t)h->M ||
-        hd.n_streams != (uint32_t)h->n_streams || hd.hop != (uint32_t)h->H || hd.das_impl != (uint32_t)h->cfg.das_impl)
+        hd.n_streams != ((uint32_t)h->n_streams | ((uint32_t)h->n_dirs << 20)) || hd.hop != (uint32_t)h->H || hd.das_impl != (uint32_t)h->cfg.das_impl)
         return fail(h, BF_EINVAL, "state blob does not match this handle");
     BF_HIP(h, hipSetDevice(h->device));
     BF_HIP(h, hipDeviceSynchronize());
     const char *p = (const char *)blob + sizeof(hd);
     if (uses_fused_das(h)) {
-        const size_t hb = (size_t)h->n_streams * h->M * h->H * sizeof(float), tb = (size_t)h->n_streams * h->H * sizeof(float);
+        const size_t hb = (size_t)h->n_streams * h->M * h->H * sizeof(float), tb = (size_t)h->n_out * h->H * sizeof(float);
         BF_HIP(h, hipMemcpy(h->d_hist[h->tail_cur], p, hb, hipMemcpyHostToDevice));
         BF_HIP(h, hipMemcpy(h->d_tail[h->tail_cur], p + hb, tb, hipMemcpyHostToDevice));
         return BF_OK;

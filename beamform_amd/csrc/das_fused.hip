@@ -74,17 +74,19 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
     const int M = a.n_mics;
     const int n_pairs = (M + 1) >> 1;
 
+    const int stream = blockIdx.x / a.chunks_per_stream;  // output stream = input stream * n_dirs + look direction
+    const long c_in_s = blockIdx.x - (long)stream * a.chunks_per_stream;
+    const int in_stream = stream / a.n_dirs;
+    const f32x2 *gains = a.gains + (long)(stream - in_stream * a.n_dirs) * n_pairs * 1024;
     {
         const float *twf = reinterpret_cast<const float *>(a.twiddle);
         for (int i = tid; i < kLdsTw; i += kBlock) lds[i] = twf[i];
         for (int i = tid; i < kNfft; i += kBlock) s_win[(i & 31) * kPS + (i >> 5)] = a.window[i];  // [lane][j]
         if (NPL > 0) {
-            const float *gf = reinterpret_cast<const float *>(a.gains);
+            const float *gf = reinterpret_cast<const float *>(gains);
             for (int i = tid; i < n_pairs * 2048; i += kBlock) lds[kLdsFixed + i] = gf[i];
         }
     }
-    const int stream = blockIdx.x / a.chunks_per_stream;
-    const long c_in_s = blockIdx.x - (long)stream * a.chunks_per_stream;
     const long T0 = c_in_s * a.frames_per_chunk;
     long T1 = T0 + a.frames_per_chunk;
     if (T1 > a.n_frames) T1 = a.n_frames;
@@ -95,8 +97,8 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
     __syncthreads();
     const float4 *wrow = reinterpret_cast<const float4 *>(s_win + lane * kPS);
 
-    const float *xs = a.x + (long)stream * a.stream_stride_x;
-    const float *hs = a.hist_in + (long)stream * M * kHop;
+    const float *xs = a.x + (long)in_stream * a.stream_stride_x;
+    const float *hs = a.hist_in + (long)in_stream * M * kHop;
     float *ys = a.y + (long)stream * a.n_frames * kHop;
 
     float re[32], im[32], Sr[32], Si[32];
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             fft1024p_D<float, -1>(re, im, lane, pbuf);
             __builtin_amdgcn_wave_barrier();
 
-            const cx<float> *gp = (NPL > 0 ? s_gain : reinterpret_cast<const cx<float> *>(a.gains)) + (long)p * 1024 + lane;
+            const cx<float> *gp = (NPL > 0 ? s_gain : reinterpret_cast<const cx<float> *>(gains)) + (long)p * 1024 + lane;
             if (p == 0) {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                     float *to = a.tail_out + (long)stream * kHop + lane;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) to[32 * brev5(2 * q)] = Sr[2 * q + 1] * h[brev5(2 * q + 1)];
-                    float *ho = a.hist_out + (long)stream * M * kHop;
+                    float *ho = a.hist_out + (long)in_stream * M * kHop;  // every direction writes the same values
                     if (LAYOUT == 0) {
                         for (int m = 0; m < M; ++m)
                             for (int j = 0; j < 16; ++j)
@@ -301,6 +303,22 @@ void launch_layout(const DasFusedArgs &a, unsigned blocks, hipStream_t stream) {
         hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 0>), dim3(blocks), dim3(kBlock), 0, stream, a);
 }
 
+// Sum of squares of every output stream (double accumulation): bf_stream_rms.
+__global__ __launch_bounds__(256) void stream_sumsq_kernel(const float *y, long n, double *sumsq) {
+    const float *ys = y + (long)blockIdx.y * n;
+    double acc = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const double v = (double)ys[i];
+        acc += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sumsq + blockIdx.y, part[0] + part[1] + part[2] + part[3]);
+}
+
 }  // namespace
 
 // Runs are multiples of 16 frames; the first hop of every run but the first of a stream is completed by
@@ -323,6 +341,16 @@ hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t stream) {
         launch_layout<0>(a, blocks, stream);
     else
         launch_layout<1>(a, blocks, stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_stream_rms(const float *y, long n_samples, int n_streams, double *sumsq, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(sumsq, 0, sizeof(double) * n_streams, stream);
+    if (e != hipSuccess) return e;
+    long bx = (n_samples + 256L * 64 - 1) / (256L * 64);
+    if (bx < 1) bx = 1;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(stream_sumsq_kernel, dim3((unsigned)bx, (unsigned)n_streams), dim3(256), 0, stream, y, n_samples, sumsq);
     return hipGetLastError();
 }
 

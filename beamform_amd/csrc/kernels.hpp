@@ -15,7 +15,7 @@ struct DasFusedArgs {
     float *y;              // [stream][n_frames*hop]
     const float *tail_in;  // [stream][hop] second half of the frame before frame 0 (out_buff[0], util.h:302)
     float *tail_out;       // [stream][hop] second half of the last frame of this batch
-    const f32x2 *gains;    // das_pair_gains() table
+    const f32x2 *gains;    // das_pair_gains() tables, one per look direction: [dir][pair][1024]
     const f32x2 *twiddle;  // twiddle_table_32x32<f32x2>()
     const float *window;   // sqrt-Hann, fp32, natural order [1024]
     const float *zeros;    // >= 1024 zero floats: partner channel of the last mic when n_mics is odd
@@ -23,7 +23,8 @@ struct DasFusedArgs {
     long n_frames;         // frames per stream
     long mic_stride;       // planar: samples between mics of one stream
     long stream_stride_x;  // samples between streams in x
-    int n_streams;
+    int n_streams;         // OUTPUT streams = input streams * n_dirs (stream = input * n_dirs + dir)
+    int n_dirs;            // look directions per input stream (>= 1); x / hist are indexed by the input stream
     int n_mics;
     int frames_per_chunk;
     int chunks_per_stream;
@@ -35,6 +36,9 @@ hipError_t prepare_das_fused(const DasFusedArgs &a, hipStream_t stream);  // zer
 hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t stream);
 
 // S dump -> Hermitian part of the reference's y_fft as double2 [frames][1024]
+// per-stream root-mean-square of y [n_streams][n_samples] -> rms[n_streams] (double); `sumsq` = n_streams doubles of scratch
+hipError_t launch_stream_rms(const float *y, long n_samples, int n_streams, double *sumsq, hipStream_t stream);
+
 hipError_t launch_das_hermitian_dump(const f32x2 *sdump, f64x2 *out, long n_frames_total, hipStream_t stream);
 
 }  // namespace bf

@@ -47,7 +47,9 @@ class BinPipelineImpl : public BinPipeline {
         M_ = c.n_mics;
         MF_ = (c.algo == BF_MCRA) ? 1 : M_;  // the mcra node only transforms channel 0 (mcra.cpp:72-73)
         NP_ = (MF_ + 1) / 2;
-        S_ = c.n_streams;
+        S_ = c.n_streams;                                   // input streams
+        D_ = c.n_dirs > 1 ? c.n_dirs : 1;                   // look directions per input stream
+        So_ = S_ * D_;                                      // output streams
         const bool multi = (c.algo == BF_LCMV || c.algo == BF_GSS);
         KP1_ = multi ? c.n_interf + 1 : 1;
         Phist_ = (c.algo == BF_MVDR || c.algo == BF_LCMV) ? c.past_windows : 0;
@@ -80,10 +82,11 @@ class BinPipelineImpl : public BinPipeline {
         freqs_ = frequency_vector(1024, cfg_.sample_rate);
         PIPE_HIP(hipMalloc((void **)&d_freq_, 1024 * sizeof(double)));
         PIPE_HIP(hipMemcpy(d_freq_, freqs_.data(), 1024 * sizeof(double), hipMemcpyHostToDevice));
-        for (int i = 0; i < 2; ++i) PIPE_HIP(hipMalloc((void **)&d_steer_[i], (size_t)1024 * M_ * kMaxCols * sizeof(f64x2)));
+        for (int i = 0; i < 2; ++i)
+            PIPE_HIP(hipMalloc((void **)&d_steer_[i], (size_t)D_ * 1024 * M_ * kMaxCols * sizeof(f64x2)));
         PIPE_HIP(hipMalloc((void **)&d_hist_, (size_t)S_ * M_ * 512 * sizeof(float)));
-        PIPE_HIP(hipMalloc((void **)&d_tail_[0], (size_t)S_ * 512 * sizeof(float)));
-        PIPE_HIP(hipMalloc((void **)&d_tail_[1], (size_t)S_ * 512 * sizeof(float)));
+        PIPE_HIP(hipMalloc((void **)&d_tail_[0], (size_t)So_ * 512 * sizeof(float)));
+        PIPE_HIP(hipMalloc((void **)&d_tail_[1], (size_t)So_ * 512 * sizeof(float)));
         if (Phist_ > 0) PIPE_HIP(hipMalloc((void **)&d_zhist_, zhist_bytes()));
         if (cfg_.algo == BF_GSS) PIPE_HIP(hipMalloc((void **)&d_gssW_, gss_bytes()));
         if (cfg_.algo == BF_PHASEMPF || cfg_.algo == BF_MCRA) PIPE_HIP(hipMalloc((void **)&d_mpf_, mpf_bytes()));
@@ -93,8 +96,8 @@ class BinPipelineImpl : public BinPipeline {
 
     int reset() override {
         PIPE_HIP(hipMemset(d_hist_, 0, (size_t)S_ * M_ * 512 * sizeof(float)));
-        PIPE_HIP(hipMemset(d_tail_[0], 0, (size_t)S_ * 512 * sizeof(float)));
-        PIPE_HIP(hipMemset(d_tail_[1], 0, (size_t)S_ * 512 * sizeof(float)));
+        PIPE_HIP(hipMemset(d_tail_[0], 0, (size_t)So_ * 512 * sizeof(float)));
+        PIPE_HIP(hipMemset(d_tail_[1], 0, (size_t)So_ * 512 * sizeof(float)));
         tail_cur_ = 0;
         if (d_zhist_) PIPE_HIP(hipMemset(d_zhist_, 0, zhist_bytes()));  // past_ffts setZero (mvdr.cpp:228-232)
         if (d_mpf_) PIPE_HIP(hipMemset(d_mpf_, 0, mpf_bytes()));          // phasempf.cpp:535-545, current_L=0/first_L
@@ -103,19 +106,22 @@ class BinPipelineImpl : public BinPipeline {
         return BF_OK;
     }
 
-    int upload_steering(const SteeringSet &s, hipStream_t stream) override {
-        // device layout [col][mic][bin] so that lanes (bins) read consecutive addresses
-        std::vector<f64x2> t((size_t)1024 * M_ * s.n_cols);
-        for (int c = 0; c < s.n_cols; ++c)
-            for (int m = 0; m < M_; ++m)
-                for (int j = 0; j < 1024; ++j) {
-                    const cplxd w = s.at(j, m, c);
-                    t[((size_t)c * M_ + m) * 1024 + j] = f64x2{w.real(), w.imag()};
-                }
+    int upload_steering(const std::vector<SteeringSet> &dirs, hipStream_t stream) override {
+        // device layout [dir][col][mic][bin] so that lanes (bins) read consecutive addresses
+        const int nc = dirs[0].n_cols;
+        std::vector<f64x2> t((size_t)D_ * 1024 * M_ * nc);
+        for (int d = 0; d < D_; ++d)
+            for (int c = 0; c < nc; ++c)
+                for (int m = 0; m < M_; ++m)
+                    for (int j = 0; j < 1024; ++j) {
+                        const cplxd w = dirs[d].at(j, m, c);
+                        t[(((size_t)d * nc + c) * M_ + m) * 1024 + j] = f64x2{w.real(), w.imag()};
+                    }
         const int nxt = steer_cur_ ^ 1;
         PIPE_HIP(hipMemcpyAsync(d_steer_[nxt], t.data(), t.size() * sizeof(f64x2), hipMemcpyHostToDevice, stream));
         PIPE_HIP(hipStreamSynchronize(stream));  // `t` is pageable and about to go out of scope
         steer_cur_ = nxt;
+        steer_dir_stride_ = (long)nc * M_ * 1024;
         return BF_OK;
     }
 
@@ -128,7 +134,7 @@ class BinPipelineImpl : public BinPipeline {
     int run(const float *x, long F, float *y, f64x2 *spectrum, hipStream_t stream, int layout, long mic_stride) override;
 
     size_t state_bytes() const override {
-        return (size_t)S_ * M_ * 512 * 4 + (size_t)S_ * 512 * 4 + zhist_bytes() + gss_bytes() + mpf_bytes() + smooth_bytes();
+        return (size_t)S_ * M_ * 512 * 4 + (size_t)So_ * 512 * 4 + zhist_bytes() + gss_bytes() + mpf_bytes() + smooth_bytes();
     }
     int get_state(void *host) override { return copy_state((char *)host, true); }
     int set_state(const void *host) override { return copy_state((char *)host, false); }
@@ -144,7 +150,7 @@ class BinPipelineImpl : public BinPipeline {
     int copy_state(char *p, bool to_host) {
         PIPE_HIP(hipDeviceSynchronize());
         struct Seg { void *d; size_t n; } segs[] = {
-            {d_hist_, (size_t)S_ * M_ * 512 * 4}, {d_tail_[tail_cur_], (size_t)S_ * 512 * 4}, {d_zhist_, zhist_bytes()},
+            {d_hist_, (size_t)S_ * M_ * 512 * 4}, {d_tail_[tail_cur_], (size_t)So_ * 512 * 4}, {d_zhist_, zhist_bytes()},
             {d_gssW_, gss_bytes()}, {d_mpf_, mpf_bytes()}, {d_smooth_, smooth_bytes()}};
         for (auto &s : segs) {
             if (!s.n) continue;
@@ -176,7 +182,8 @@ class BinPipelineImpl : public BinPipeline {
     }
 
     bf_config cfg_;
-    int n_cus_, M_, MF_, NP_, S_, KP1_, Phist_;
+    int n_cus_, M_, MF_, NP_, S_, D_, So_, KP1_, Phist_;
+    long steer_dir_stride_ = 0;
     std::vector<double> freqs_;
     f64x2 *d_tw_ = nullptr;
     double *d_win_ = nullptr, *d_freq_ = nullptr;
@@ -203,7 +210,7 @@ int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipS
     if (rc != BF_OK) return rc;
     // phasempf keeps |out_int|^2 (one double per problem) behind the spectrum rows
     rc = ensure((void **)&d_Yh_, &Yh_cap_,
-                (size_t)S_ * F * kYhStride * (sizeof(f64x2) + (cfg_.algo == BF_PHASEMPF ? sizeof(double) : 0)));
+                (size_t)So_ * F * kYhStride * (sizeof(f64x2) + (cfg_.algo == BF_PHASEMPF ? sizeof(double) : 0)));
     if (rc != BF_OK) return rc;
     if (cfg_.algo == BF_PHASEMPF) {
         rc = ensure((void **)&d_yraw_, &yraw_cap_, (size_t)S_ * F * 512 * sizeof(float));
@@ -246,7 +253,8 @@ int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipS
 
     BinsArgs ba;
     ba.Z = d_Z_; ba.Yh = d_Yh_; ba.spectrum = spectrum; ba.steer = d_steer_[steer_cur_]; ba.freqs = d_freq_;
-    ba.n_frames = F; ba.frames_ws = FT; ba.frame_off = Phist_; ba.n_streams = S_; ba.n_mics = MF_; ba.kp1 = KP1_;
+    ba.n_frames = F; ba.frames_ws = FT; ba.frame_off = Phist_; ba.n_streams = So_; ba.n_mics = MF_; ba.kp1 = KP1_;
+    ba.n_dirs = D_; ba.steer_dir_stride = steer_dir_stride_;
     ba.cfg = cfg_; ba.gssW = d_gssW_; ba.mpf = d_mpf_; ba.gss_reset = gss_reset_pending_ ? 1 : 0;
     PIPE_HIP(launch_bins(ba, n_cus_, stream));
     gss_reset_pending_ = false;
@@ -258,7 +266,7 @@ int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipS
 
     IstftArgs ia;
     ia.Yh = d_Yh_; ia.y = (cfg_.algo == BF_PHASEMPF) ? d_yraw_ : y; ia.tail_in = d_tail_[tail_cur_];
-    ia.tail_out = d_tail_[tail_cur_ ^ 1]; ia.tw = d_tw_; ia.win = d_win_; ia.n_frames = F; ia.n_streams = S_;
+    ia.tail_out = d_tail_[tail_cur_ ^ 1]; ia.tw = d_tw_; ia.win = d_win_; ia.n_frames = F; ia.n_streams = So_;
     ia.post_amp = (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS) ? cfg_.out_amp : 1.0;
     ia.use_post_amp = (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS) ? 1 : 0;
     PIPE_HIP(launch_istft(ia, n_cus_, stream));

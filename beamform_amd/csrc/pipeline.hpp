@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/bfcore.h"
 #include "geometry.hpp"
@@ -20,7 +21,7 @@ class BinPipeline {
     virtual ~BinPipeline() {}
     virtual int init() = 0;
     virtual int reset() = 0;
-    virtual int upload_steering(const SteeringSet &s, hipStream_t stream) = 0;
+    virtual int upload_steering(const std::vector<SteeringSet> &dirs, hipStream_t stream) = 0;  // one set per look direction
     virtual void on_theta_changed() = 0;
     virtual void set_columns(int kp1) = 0;  // interferer added/removed (lcmv.cpp:266-305)
     virtual int run(const float *x_dev, long n_frames, float *y_dev, f64x2 *spectrum_dev, hipStream_t stream, int layout,

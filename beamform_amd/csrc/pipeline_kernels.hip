@@ -423,8 +423,8 @@ __global__ __launch_bounds__(256) void pointwise_bins_kernel(BinsArgs a) {
     const int s = (int)(st / a.n_frames);
     const int NP = (a.n_mics + 1) >> 1;
     BinCtx c;
-    c.Zf = a.Z + (((long)s * a.frames_ws + a.frame_off + t) * NP) * kN;
-    c.steer = a.steer;
+    c.Zf = a.Z + (((long)(s / a.n_dirs) * a.frames_ws + a.frame_off + t) * NP) * kN;
+    c.steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
     c.M = a.n_mics;
     c.q = q;
     cd y;
@@ -497,7 +497,8 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
     const double f = fabs(a.freqs[j]);
     const bool inband = live && f >= a.cfg.freq_min && f <= a.cfg.freq_max;
     f64x2 *yout = a.Yh + ((long)s * a.n_frames) * kYhStride + qq;
-    const f64x2 *Zs = a.Z + ((long)s * a.frames_ws + a.frame_off) * NP * kN;
+    const f64x2 *Zs = a.Z + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
+    const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
     if (__builtin_amdgcn_ballot_w64(inband) == 0) {  // whole wavefront out of band (mvdr.cpp:103) or bin 0 (:76)
         if (live)
             for (long t = tA; t < tB; ++t) {
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
     }
     cd st[MP];
 #pragma unroll
-    for (int m = 0; m < MP; ++m) st[m] = (m < M) ? ld(a.steer + (long)m * kN + j) : cd{0, 0};
+    for (int m = 0; m < MP; ++m) st[m] = (m < M) ? ld(steer + (long)m * kN + j) : cd{0, 0};
 
     cd R[NT];  // lower triangle, row-major: R[i*(i+1)/2 + c], c <= i
 #pragma unroll
@@ -618,7 +619,8 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
     const int j = q_bin(q);
     const bool lcmv = a.cfg.algo == BF_LCMV;
     f64x2 *yout = a.Yh + ((long)s * a.n_frames) * kYhStride + q;
-    const f64x2 *Zs = a.Z + ((long)s * a.frames_ws + a.frame_off) * NP * kN;  // frame 0 of this batch
+    const f64x2 *Zs = a.Z + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;  // frame 0 of this batch
+    const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
 
     // one microphone's spectrum at this problem's bin, frame t (may be negative: history)
     const int ksrc = q_src_bin(q), kneg = (kN - ksrc) & (kN - 1);
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
     cd cst[KM];  // this mic's entries of the constraint columns (weights[j](i, r))
 #pragma unroll
     for (int r = 0; r < KM; ++r)
-        cst[r] = (r < KP1 && i < M) ? ld(a.steer + ((long)r * M + i) * kN + j) : cd{0, 0};
+        cst[r] = (r < KP1 && i < M) ? ld(steer + ((long)r * M + i) * kN + j) : cd{0, 0};
 
     // R row i (lower triangle c <= i is what the factorisation reads)
     cd R[MP];

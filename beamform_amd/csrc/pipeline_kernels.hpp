@@ -33,10 +33,12 @@ struct BinsArgs {
     const f64x2 *Z;      // [stream][frames_ws][NP][1024]
     f64x2 *Yh;           // [stream][n_frames][kYhStride]: y_fft of problems q = 0..513
     f64x2 *spectrum;     // nullable: [stream][n_frames][1024] full y_fft dump
-    const f64x2 *steer;  // [col][mic][1024]
+    const f64x2 *steer;  // [dir][col][mic][1024]
     const double *freqs; // [1024]
     long n_frames, frames_ws, frame_off;
-    int n_streams, n_mics, kp1;
+    int n_streams, n_mics, kp1;  // n_streams = OUTPUT streams (input streams * n_dirs)
+    int n_dirs;                  // look directions per input stream: Z is indexed by stream / n_dirs, steer by stream % n_dirs
+    long steer_dir_stride;       // f64x2 elements between the steering tables of two look directions
     bf_config cfg;
     f64x2 *gssW;         // [stream][1024][kp1][n_mics]
     double *mpf;         // [stream][kMpfVecs*1024 + 8] (the mcra node uses vectors 0..3 and the two scalars)

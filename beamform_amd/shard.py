@@ -63,3 +63,26 @@ def gather_hops(y_local, n_frames: int, world: int, rank: int, hop: int = 512, d
     if rank != dst:
         return None
     return torch.cat([o[: n * hop] for o, n in zip(out, sizes)])
+
+
+def plan_dirs(n_dirs: int, world: int, rank: int):
+    """Look-direction sharding: every rank sees the whole input and evaluates a contiguous,
+    near-equal slice [lo, hi) of the direction list; no halo, no exchange until the final gather."""
+    base, rem = divmod(n_dirs, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_dirs(y_local, n_dirs: int, world: int, rank: int, dst: int = 0):
+    """Collect per-rank direction slabs [dirs_r, samples] on `dst` in direction order; one collective."""
+    import torch
+    import torch.distributed as dist
+    sizes = [plan_dirs(n_dirs, world, r)[1] - plan_dirs(n_dirs, world, r)[0] for r in range(world)]
+    n = y_local.shape[-1]
+    buf = torch.zeros((max(sizes), n), dtype=y_local.dtype, device=y_local.device)
+    buf[: y_local.shape[0]] = y_local
+    out = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, out, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([o[:k] for o, k in zip(out, sizes)])

@@ -101,7 +101,12 @@ typedef struct bf_config {
     int n_streams;                 /* independent audio streams per batch (each = one reference node's state) */
     int layout;                    /* enum bf_layout for bf_process_batch* input */
     int das_impl;                  /* enum bf_das_impl */
+    int n_dirs;                    /* look directions evaluated per input stream from the SAME samples (0/1 = one, the
+                                      reference node).  Output stream index = stream * n_dirs + dir.  das, phase, mvdr,
+                                      lcmv only (their state does not depend on the direction); SURVEY 8(e) "look
+                                      directions" / 8(f) row 4 */
 } bf_config;
+#define BF_MAX_DIRS 64
 
 typedef struct bf_handle bf_handle;
 
@@ -132,6 +137,16 @@ void bf_destroy(bf_handle *h);
  * Thread-safe against a concurrent bf_process_*: takes effect at the next
  * hop/batch (the reference updates in place with no lock). */
 int bf_set_theta(bf_handle *h, double degrees);
+/* Look-direction batch: direction `dir` (0 <= dir < n_dirs) of every input stream gets its own /theta;
+ * bf_set_theta() is bf_set_theta_dir(h, 0, deg).  bf_set_thetas sets directions 0..n-1 with one table rebuild.
+ * Every direction starts at bf_config.theta. */
+int bf_set_theta_dir(bf_handle *h, int dir, double degrees);
+int bf_set_thetas(bf_handle *h, const double *degrees, int n);
+/* Root-mean-square of each output stream of a batch that is resident on the device (y as written by
+ * bf_process_batch_device): rms_host[n_streams * n_dirs].  This is the quantity the reference's theta controllers
+ * steer on (scripts/energy2theta.py:23-27 get_energy_from_list), so "publish theta, wait, measure" becomes
+ * "evaluate n_dirs candidates in one batch and pick". */
+int bf_stream_rms(bf_handle *h, const float *y_dev, size_t n_frames, double *rms_host, void *hip_stream);
 /* interf_theta_roscallback (lcmv.cpp:258-309, gss.cpp:288-339): id is 1-based.  id <= current count updates that
  * interferer (and removes it when it lands within interf_angle_threshold of another one); id > count appends a
  * new interferer unless it is that close to an existing one.  As in the reference, a structural change rebuilds
@@ -144,7 +159,7 @@ int bf_n_interferers(bf_handle *h);
 /* jack_callback body: do_overlap(in, out, nframes, apply_weights)
  * (das.cpp:72-92, util.h:289-314).  in = n_mics pointers to nframes float32
  * (host memory, as input_from_rosjack returns), out = nframes float32 (host).
- * nframes must equal cfg.hop.  Stream 0 only. */
+ * nframes must equal cfg.hop.  Single-stream handles only; with n_dirs > 1 `out` receives [n_dirs][nframes]. */
 int bf_process_hop(bf_handle *h, const float *const *in, float *out, uint32_t nframes);
 
 /* n_frames consecutive callbacks per stream in one call, host buffers.

@@ -73,3 +73,53 @@ def test_two_rank_sharding_reproduces_single_stream(algo, M, F):
     assert np.array_equal(full[: lo1 * 512], y_ref[: lo1 * 512], equal_nan=True)
     # rank 1's first owned hop already has exact history (halo), so the rest is bit-identical too
     assert np.array_equal(full[lo1 * 512:], y_ref[lo1 * 512:], equal_nan=True)
+
+
+def test_plan_dirs_partitions_exactly():
+    for D, W in [(5, 2), (16, 8), (3, 4)]:
+        cover = []
+        for r in range(W):
+            lo, hi = shard.plan_dirs(D, W, r)
+            cover += list(range(lo, hi))
+        assert cover == list(range(D))
+
+
+def _dir_worker(rank, world, port, thetas, M, F, ret):
+    import torch
+    import torch.distributed as dist
+    import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = make_scene(M, F, seed=321)
+    lo, hi = shard.plan_dirs(len(thetas), world, rank)
+    ys = [oracle.OracleNode(make_params("das", n_mics=M, theta=t)).process(x)[0] for t in thetas[lo:hi]]
+    y_own = torch.from_numpy(np.stack(ys)) if ys else torch.zeros((0, F * 512))
+    full = shard.gather_dirs(y_own, len(thetas), world, rank)
+    if rank == 0:
+        ret.put(full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_direction_sharding():
+    """the theta list shards across ranks, every rank reads the whole input, one gather."""
+    import torch.multiprocessing as mp
+    import oracle
+    thetas, M, F = [-90.0, -20.0, 20.0, 75.0, 160.0], 4, 9
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_dir_worker, args=(r, 2, port, thetas, M, F, ret)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    full = ret.get(timeout=120)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    x = make_scene(M, F, seed=321)
+    for d, t in enumerate(thetas):
+        assert np.array_equal(full[d], oracle.OracleNode(make_params("das", n_mics=M, theta=t)).process(x)[0])

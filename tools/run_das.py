@@ -14,16 +14,20 @@ ap.add_argument("--streams", type=int, default=1)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--layout", default="planar")
 ap.add_argument("--warmup", type=int, default=10)
+ap.add_argument("--dirs", type=int, default=1, help="look directions per input stream (same input, n_dirs outputs)")
 a = ap.parse_args()
 interf = (-60.0, 90.0, 150.0) if a.algo in ("lcmv", "gss") else ()
 p = make_params(a.algo, n_mics=a.mics, interf=interf)
 lay = BF_PLANAR if a.layout == "planar" else BF_INTERLEAVED
-bf = Beamformer(p, n_streams=a.streams, layout=lay)
+bf = Beamformer(p, n_streams=a.streams, layout=lay, n_dirs=a.dirs)
+if a.dirs > 1:
+    bf.set_thetas([-90.0 + 180.0 * d / (a.dirs - 1) for d in range(a.dirs)])
 shape = (a.streams, a.mics, a.frames * 512) if lay == BF_PLANAR else (a.streams, a.frames * 512, a.mics)
 x = torch.rand(shape, device="cuda") - 0.5
-y = torch.empty((a.streams, a.frames * 512), device="cuda")
+y = torch.empty((a.streams * a.dirs, a.frames * 512), device="cuda")
 for _ in range(a.warmup):
     bf.process_device(x.data_ptr(), a.frames, y.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
 ms, msk = bf.time_device(x.data_ptr(), a.frames, y.data_ptr(), a.iters, torch.cuda.current_stream().cuda_stream)
-print(f"{a.algo} M={a.mics} F={a.frames} S={a.streams}: call {ms:.4f} ms, kernel {msk:.4f} ms, {a.frames*a.streams/ms/1e3:.3f} Mframes/s")
+print(f"{a.algo} M={a.mics} F={a.frames} S={a.streams} D={a.dirs}: call {ms:.4f} ms, kernel {msk:.4f} ms, "
+      f"{a.frames*a.streams/ms/1e3:.3f} Mframes/s in, {a.frames*a.streams*a.dirs/ms/1e3:.3f} M beam-frames/s out")
