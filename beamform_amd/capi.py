@@ -46,7 +46,13 @@ class BfConfig(C.Structure):
         ("mpf_rev_delta", C.c_double), ("noise_floor", C.c_double),
         ("out_only_noise", C.c_int), ("out_only_mcra", C.c_int),
         ("device", C.c_int), ("n_streams", C.c_int), ("layout", C.c_int), ("das_impl", C.c_int), ("n_dirs", C.c_int),
+        ("gsc_use_vad", C.c_int), ("gsc_vad_threshold", C.c_double), ("gsc_mu0", C.c_double), ("gsc_mu_max", C.c_double),
+        ("gsc_filter_size", C.c_int),
     ]
+
+
+#: defaults of parameters added after the first golden fixtures were written (launch/gsc.launch:6-11)
+_LATER_KEYS = dict(gsc_use_vad=0, gsc_vad_threshold=0.1, gsc_mu0=0.0001, gsc_mu_max=0.1, gsc_filter_size=128)
 
 
 class BfError(RuntimeError):
@@ -119,14 +125,15 @@ def config_from_params(p: dict, device: int = 0, n_streams: int = 1, layout: int
     for k in ("past_windows", "freq_mag_threshold", "freq_max", "freq_min", "out_amp", "mu", "lambda_", "min_phase",
               "mag_mult", "mag_threshold", "min_mag", "smooth_size", "mcra_alphaS", "mcra_alphaD", "mcra_alphaD2",
               "mcra_delta", "mcra_L", "mpf_alphaS", "mpf_eta", "mpf_rev_gamma", "mpf_rev_delta", "noise_floor",
-              "out_only_noise", "out_only_mcra"):
-        setattr(c, k, p[k])
+              "out_only_noise", "out_only_mcra", "gsc_use_vad", "gsc_vad_threshold", "gsc_mu0", "gsc_mu_max",
+              "gsc_filter_size"):
+        setattr(c, k, p[k] if k in p else _LATER_KEYS[k])  # fixtures written before a key existed
     c.device, c.n_streams, c.layout, c.das_impl, c.n_dirs = device, n_streams, layout, das_impl, n_dirs
     return c
 
 
 class Beamformer:
-    """One beamformer node behind the C ABI (das|mvdr|lcmv|gss|phase|phasempf|mcra)."""
+    """One beamformer node behind the C ABI (das|mvdr|lcmv|gss|phase|phasempf|mcra|gsc)."""
 
     def __init__(self, params: dict, device: int = 0, n_streams: int = 1, layout: int = BF_PLANAR,
                  das_impl: int = BF_DAS_FUSED_F32, n_dirs: int = 1):

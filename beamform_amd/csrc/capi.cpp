@@ -249,7 +249,7 @@ int bf_device_count(void) {
 int bf_create(const bf_config *cfg, bf_handle **out) {
     if (!cfg || !out) return BF_EINVAL;
     *out = nullptr;
-    if (cfg->algo < BF_DAS || cfg->algo > BF_MCRA) return fail(nullptr, BF_EINVAL, "algo out of range");
+    if (cfg->algo < BF_DAS || cfg->algo > BF_GSC) return fail(nullptr, BF_EINVAL, "algo out of range");
     if (cfg->n_mics < 1 || cfg->n_mics > BF_MAX_MICS) return fail(nullptr, BF_EINVAL, "n_mics out of range");
     if (cfg->hop != 512) return fail(nullptr, BF_ENOSYS, "only hop 512 (fft_win 1024) is built");
     if (cfg->n_streams < 1) return fail(nullptr, BF_EINVAL, "n_streams < 1");

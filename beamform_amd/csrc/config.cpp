@@ -65,7 +65,7 @@ bool parse_flow_map(const std::string &v, std::map<std::string, double> *m) {
 extern "C" {
 
 int bf_config_init(bf_config *c, int algo) {
-    if (!c || algo < BF_DAS || algo > BF_MCRA) return BF_EINVAL;
+    if (!c || algo < BF_DAS || algo > BF_GSC) return BF_EINVAL;
     memset(c, 0, sizeof(*c));
     c->algo = algo;
     c->hop = 512;              // JACK period behind "1024-pt FFT" (util.h:261)
@@ -101,6 +101,8 @@ int bf_config_init(bf_config *c, int algo) {
     c->out_only_noise = 0; c->out_only_mcra = 0;
     if (algo == BF_PHASEMPF) { c->min_phase = 30.0; c->out_amp = 2.5; }
     if (algo == BF_MCRA) { c->mcra_L = 300; c->out_amp = 3.5; }  // launch/mcra.launch:6-12
+    // launch/gsc.launch:6-11
+    c->gsc_use_vad = 0; c->gsc_vad_threshold = 0.1; c->gsc_mu0 = 0.0001; c->gsc_mu_max = 0.1; c->gsc_filter_size = 128;
     c->device = 0;
     c->n_streams = 1;
     c->layout = BF_PLANAR;
@@ -165,6 +167,11 @@ int bf_config_parse_yaml(bf_config *c, const char *text) {
         if (key == "MPF_rev_gamma") { c->mpf_rev_gamma = d; continue; }
         if (key == "MPF_rev_delta") { c->mpf_rev_delta = d; continue; }
         BF_KEY_D(noise_floor) BF_KEY_I(out_only_noise) BF_KEY_I(out_only_mcra)
+        if (key == "use_vad") { c->gsc_use_vad = (int)d; continue; }  // gsc.cpp:203-256
+        if (key == "vad_threshold") { c->gsc_vad_threshold = d; continue; }
+        if (key == "mu0") { c->gsc_mu0 = d; continue; }
+        if (key == "mu_max") { c->gsc_mu_max = d; continue; }
+        if (key == "filter_size") { c->gsc_filter_size = (int)d; continue; }
         if (key == "rosjack_window_size") { c->hop = (int)d; continue; }
         if (key == "rosjack_sample_rate") { c->sample_rate = d; continue; }
 #undef BF_KEY_D

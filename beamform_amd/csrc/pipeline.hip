@@ -49,6 +49,7 @@ class BinPipelineImpl : public BinPipeline {
         NP_ = (MF_ + 1) / 2;
         S_ = c.n_streams;                                   // input streams
         D_ = c.n_dirs > 1 ? c.n_dirs : 1;                   // look directions per input stream
+        if (c.algo == BF_GSC) D_ = M_;                      // gsc: one aligned output per microphone (do_overlap_bymic)
         So_ = S_ * D_;                                      // output streams
         const bool multi = (c.algo == BF_LCMV || c.algo == BF_GSS);
         KP1_ = multi ? c.n_interf + 1 : 1;
@@ -68,6 +69,10 @@ class BinPipelineImpl : public BinPipeline {
         if ((cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV) && (Phist_ < 1 || Phist_ > 64)) {
             err_ = "past_windows must be in 1..64";
             return BF_EINVAL;
+        }
+        if (cfg_.algo == BF_GSC && (M_ > 16 || cfg_.gsc_filter_size < 1 || cfg_.gsc_filter_size > 256)) {
+            err_ = "gsc is built for up to 16 microphones and filter_size 1..256";
+            return M_ > 16 ? BF_ENOSYS : BF_EINVAL;
         }
         if (cfg_.algo == BF_PHASEMPF && (cfg_.smooth_size < 1 || cfg_.smooth_size > 64)) {
             err_ = "smooth_size must be in 1..64";
@@ -91,6 +96,7 @@ class BinPipelineImpl : public BinPipeline {
         if (cfg_.algo == BF_GSS) PIPE_HIP(hipMalloc((void **)&d_gssW_, gss_bytes()));
         if (cfg_.algo == BF_PHASEMPF || cfg_.algo == BF_MCRA) PIPE_HIP(hipMalloc((void **)&d_mpf_, mpf_bytes()));
         if (cfg_.algo == BF_PHASEMPF) PIPE_HIP(hipMalloc((void **)&d_smooth_, smooth_bytes()));
+        if (cfg_.algo == BF_GSC) PIPE_HIP(hipMalloc((void **)&d_nlms_, nlms_bytes()));
         return BF_OK;
     }
 
@@ -102,15 +108,16 @@ class BinPipelineImpl : public BinPipeline {
         if (d_zhist_) PIPE_HIP(hipMemset(d_zhist_, 0, zhist_bytes()));  // past_ffts setZero (mvdr.cpp:228-232)
         if (d_mpf_) PIPE_HIP(hipMemset(d_mpf_, 0, mpf_bytes()));          // phasempf.cpp:535-545, current_L=0/first_L
         if (d_smooth_) PIPE_HIP(hipMemset(d_smooth_, 0, smooth_bytes())); // calloc past_samples (phasempf.cpp:510)
+        if (d_nlms_) PIPE_HIP(hipMemset(d_nlms_, 0, nlms_bytes()));       // calloc block_matrix/filter/last_outputs (gsc.cpp:278-285)
         gss_reset_pending_ = true;  // sep_matrix = weights^H (gss.cpp:90-93), done on the stream at next run
         return BF_OK;
     }
 
     int upload_steering(const std::vector<SteeringSet> &dirs, hipStream_t stream) override {
         // device layout [dir][col][mic][bin] so that lanes (bins) read consecutive addresses
-        const int nc = dirs[0].n_cols;
-        std::vector<f64x2> t((size_t)D_ * 1024 * M_ * nc);
-        for (int d = 0; d < D_; ++d)
+        const int nc = dirs[0].n_cols, nd = (int)dirs.size();  // nd = look directions (gsc: 1, although D_ = M outputs)
+        std::vector<f64x2> t((size_t)nd * 1024 * M_ * nc);
+        for (int d = 0; d < nd; ++d)
             for (int c = 0; c < nc; ++c)
                 for (int m = 0; m < M_; ++m)
                     for (int j = 0; j < 1024; ++j) {
@@ -134,7 +141,8 @@ class BinPipelineImpl : public BinPipeline {
     int run(const float *x, long F, float *y, f64x2 *spectrum, hipStream_t stream, int layout, long mic_stride) override;
 
     size_t state_bytes() const override {
-        return (size_t)S_ * M_ * 512 * 4 + (size_t)So_ * 512 * 4 + zhist_bytes() + gss_bytes() + mpf_bytes() + smooth_bytes();
+        return (size_t)S_ * M_ * 512 * 4 + (size_t)So_ * 512 * 4 + zhist_bytes() + gss_bytes() + mpf_bytes() + smooth_bytes() +
+               nlms_bytes();
     }
     int get_state(void *host) override { return copy_state((char *)host, true); }
     int set_state(const void *host) override { return copy_state((char *)host, false); }
@@ -146,12 +154,15 @@ class BinPipelineImpl : public BinPipeline {
         return (cfg_.algo == BF_PHASEMPF || cfg_.algo == BF_MCRA) ? (size_t)S_ * (kMpfVecs * 1024 + 8) * sizeof(double) : 0;
     }
     size_t smooth_bytes() const { return cfg_.algo == BF_PHASEMPF ? (size_t)S_ * 64 * sizeof(double) : 0; }
+    size_t nlms_bytes() const {
+        return cfg_.algo == BF_GSC ? (size_t)S_ * (2 * (M_ - 1) + 1) * cfg_.gsc_filter_size * sizeof(float) : 0;
+    }
 
     int copy_state(char *p, bool to_host) {
         PIPE_HIP(hipDeviceSynchronize());
         struct Seg { void *d; size_t n; } segs[] = {
             {d_hist_, (size_t)S_ * M_ * 512 * 4}, {d_tail_[tail_cur_], (size_t)So_ * 512 * 4}, {d_zhist_, zhist_bytes()},
-            {d_gssW_, gss_bytes()}, {d_mpf_, mpf_bytes()}, {d_smooth_, smooth_bytes()}};
+            {d_gssW_, gss_bytes()}, {d_mpf_, mpf_bytes()}, {d_smooth_, smooth_bytes()}, {d_nlms_, nlms_bytes()}};
         for (auto &s : segs) {
             if (!s.n) continue;
             if (to_host)
@@ -176,7 +187,7 @@ class BinPipelineImpl : public BinPipeline {
 
     void free_all() {
         void *ptrs[] = {d_tw_, d_win_, d_freq_, d_steer_[0], d_steer_[1], d_hist_, d_tail_[0], d_tail_[1], d_zhist_,
-                        d_gssW_, d_mpf_, d_smooth_, d_Z_, d_Yh_, d_yraw_};
+                        d_gssW_, d_mpf_, d_smooth_, d_nlms_, d_Z_, d_Yh_, d_yraw_};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
     }
@@ -196,6 +207,7 @@ class BinPipelineImpl : public BinPipeline {
     f64x2 *d_gssW_ = nullptr;    // [stream][bin][KP1][M]
     double *d_mpf_ = nullptr;    // [stream][kMpfVecs*1024 + 8]
     double *d_smooth_ = nullptr; // [stream][64]
+    float *d_nlms_ = nullptr;    // gsc: [stream][(2(M-1)+1) * filter_size]
     bool gss_reset_pending_ = true;
     // workspaces (grown on demand)
     f64x2 *d_Z_ = nullptr;   size_t Z_cap_ = 0;   // [stream][Phist+F][NP][1024]
@@ -212,8 +224,8 @@ int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipS
     rc = ensure((void **)&d_Yh_, &Yh_cap_,
                 (size_t)So_ * F * kYhStride * (sizeof(f64x2) + (cfg_.algo == BF_PHASEMPF ? sizeof(double) : 0)));
     if (rc != BF_OK) return rc;
-    if (cfg_.algo == BF_PHASEMPF) {
-        rc = ensure((void **)&d_yraw_, &yraw_cap_, (size_t)S_ * F * 512 * sizeof(float));
+    if (cfg_.algo == BF_PHASEMPF || cfg_.algo == BF_GSC) {
+        rc = ensure((void **)&d_yraw_, &yraw_cap_, (size_t)So_ * F * 512 * sizeof(float));
         if (rc != BF_OK) return rc;
     }
     const size_t frame_elems = (size_t)NP_ * 1024;
@@ -251,6 +263,10 @@ int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipS
                                   hipMemcpyDeviceToDevice, stream));
     }
 
+    if (cfg_.algo == BF_GSC && spectrum) {  // time-domain node: there is no single y_fft; the dump reads as zeros
+        PIPE_HIP(hipMemsetAsync(spectrum, 0, (size_t)S_ * F * 1024 * sizeof(f64x2), stream));
+        spectrum = nullptr;
+    }
     BinsArgs ba;
     ba.Z = d_Z_; ba.Yh = d_Yh_; ba.spectrum = spectrum; ba.steer = d_steer_[steer_cur_]; ba.freqs = d_freq_;
     ba.n_frames = F; ba.frames_ws = FT; ba.frame_off = Phist_; ba.n_streams = So_; ba.n_mics = MF_; ba.kp1 = KP1_;
@@ -265,7 +281,7 @@ int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipS
                                   (size_t)S_, hipMemcpyDeviceToDevice, stream));
 
     IstftArgs ia;
-    ia.Yh = d_Yh_; ia.y = (cfg_.algo == BF_PHASEMPF) ? d_yraw_ : y; ia.tail_in = d_tail_[tail_cur_];
+    ia.Yh = d_Yh_; ia.y = (cfg_.algo == BF_PHASEMPF || cfg_.algo == BF_GSC) ? d_yraw_ : y; ia.tail_in = d_tail_[tail_cur_];
     ia.tail_out = d_tail_[tail_cur_ ^ 1]; ia.tw = d_tw_; ia.win = d_win_; ia.n_frames = F; ia.n_streams = So_;
     ia.post_amp = (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS) ? cfg_.out_amp : 1.0;
     ia.use_post_amp = (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS) ? 1 : 0;
@@ -274,6 +290,8 @@ int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipS
 
     if (cfg_.algo == BF_PHASEMPF)
         PIPE_HIP(launch_smooth(d_yraw_, y, d_smooth_, F, S_, cfg_.smooth_size, stream));
+    if (cfg_.algo == BF_GSC)
+        PIPE_HIP(launch_gsc_nlms(d_yraw_, y, d_nlms_, F * 512, S_, M_, cfg_, stream));
     return BF_OK;
 }
 

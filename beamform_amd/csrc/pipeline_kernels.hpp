@@ -61,6 +61,12 @@ struct IstftArgs {
 hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s);
 
 // phasempf.cpp:331-334: moving average over the output samples, state = last 63 raw samples
+// gsc.cpp:120-181: the sample-serial float32 NLMS sidelobe canceller over the phase-aligned microphone signals.
+// aligned = [stream][mic][n_samples] (ISTFT output of the align pass), y = [stream][n_samples],
+// state = [stream][(2*(M-1) + 1) * filter_size] floats: block_matrix rows, filter rows, last_outputs (reference order).
+hipError_t launch_gsc_nlms(const float *aligned, float *y, float *state, long n_samples, int n_streams, int n_mics,
+                           const bf_config &cfg, hipStream_t s);
+
 hipError_t launch_smooth(const float *yraw, float *y, double *state, long n_frames, int n_streams, int smooth_size,
                          hipStream_t s);
 

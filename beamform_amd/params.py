@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import copy
 
-ALGOS = ("das", "mvdr", "lcmv", "gss", "phase", "phasempf", "mcra")
+ALGOS = ("das", "mvdr", "lcmv", "gss", "phase", "phasempf", "mcra", "gsc")
 ALGO_ID = {name: i for i, name in enumerate(ALGOS)}
 
 #: beamform/beamform_config.yaml:20-35 ("aira16"), z dropped as util.h:82-92 does.
@@ -42,6 +42,8 @@ LAUNCH_DEFAULTS = {
     # launch/mcra.launch:6-12 (single-channel node)
     "mcra": dict(mcra_alphaS=0.95, mcra_alphaD=0.95, mcra_alphaD2=0.98, mcra_delta=0.001, mcra_L=300, out_amp=3.5,
                  out_only_noise=0),
+    # launch/gsc.launch:6-11; write_mu is file I/O, not part of the path
+    "gsc": dict(gsc_use_vad=0, gsc_vad_threshold=0.1, gsc_mu0=0.0001, gsc_mu_max=0.1, gsc_filter_size=128),
 }
 
 _BASE = dict(
@@ -51,6 +53,7 @@ _BASE = dict(
     mcra_alphaS=0.95, mcra_alphaD=0.95, mcra_alphaD2=0.98, mcra_delta=0.001, mcra_L=50,
     mpf_alphaS=0.7, mpf_eta=0.3, mpf_rev_gamma=0.9, mpf_rev_delta=1.0, noise_floor=0.001,
     out_only_noise=0, out_only_mcra=0,
+    gsc_use_vad=0, gsc_vad_threshold=0.1, gsc_mu0=0.0001, gsc_mu_max=0.1, gsc_filter_size=128,
 )
 
 

@@ -20,7 +20,7 @@ def halo_frames(params: dict):
         return 1                                  # overlap-add neighbour only
     if algo in ("mvdr", "lcmv"):
         return int(params["past_windows"]) + 1    # covariance history of frame lo-1, plus that frame
-    return None                                   # gss / phasempf / mcra: recursion over frames
+    return None                                   # gss / phasempf / mcra / gsc: recursion over frames (gsc: over samples)
 
 
 @dataclass

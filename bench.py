@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--algo", default="das", choices=["das", "mvdr", "lcmv", "gss", "phase", "phasempf", "mcra"])
+    ap.add_argument("--algo", default="das", choices=["das", "mvdr", "lcmv", "gss", "phase", "phasempf", "mcra", "gsc"])
     ap.add_argument("--mics", type=int, default=8)
     ap.add_argument("--frames", type=int, default=65536, help="frames per GPU per step")
     ap.add_argument("--streams", type=int, default=1)

@@ -1,6 +1,6 @@
 // file_node.cpp -- a beamformer "node" with files in place of JACK/ROS.
 //
-//   file_node <das|mvdr|lcmv|gss|phase|phasempf|mcra> <beamform_config.yaml> <in.f32> <out.f32> [theta_script]
+//   file_node <das|mvdr|lcmv|gss|phase|phasempf|mcra|gsc> <beamform_config.yaml> <in.f32> <out.f32> [theta_script]
 //
 // in.f32: planar float32 [n_mics][n_samples]; the node is driven exactly as JACK drives the
 // reference: one jack_callback(512, 0) per period, planar per-mic pointers in, 512 samples out.
@@ -32,9 +32,9 @@ int main(int argc, char **argv) {
         fprintf(stderr, "usage: %s <algo> <config.yaml> <in.f32> <out.f32> [theta_script]\n", argv[0]);
         return 2;
     }
-    const char *names[] = {"das", "mvdr", "lcmv", "gss", "phase", "phasempf", "mcra"};
+    const char *names[] = {"das", "mvdr", "lcmv", "gss", "phase", "phasempf", "mcra", "gsc"};
     int algo = -1;
-    for (int i = 0; i < 7; ++i)
+    for (int i = 0; i < 8; ++i)
         if (!strcmp(argv[1], names[i])) algo = i;
     bf_config cfg;
     if (algo < 0 || bf_config_init(&cfg, algo) != BF_OK || bf_config_load_yaml(&cfg, argv[2]) != BF_OK) {

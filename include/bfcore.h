@@ -35,6 +35,8 @@ enum bf_algo {
     BF_GSS = 3,      /* gss.cpp:96-156 */
     BF_PHASE = 4,    /* phase.cpp:70-134 */
     BF_PHASEMPF = 5, /* phasempf.cpp:193-302 + :331-334 */
+    BF_GSC = 7,      /* gsc.cpp:54-197: per-microphone phase alignment (STFT -> conj(w_m) -> ISTFT, do_overlap_bymic) followed by
+                        the sample-serial float32 NLMS sidelobe canceller; uses the gsc_* fields */
     BF_MCRA = 6      /* mcra.cpp:64-155: single-channel MCRA noise subtraction (channel 0 only; uses mcra_*, out_amp,
                         out_only_noise) */
 };
@@ -105,6 +107,10 @@ typedef struct bf_config {
                                       reference node).  Output stream index = stream * n_dirs + dir.  das, phase, mvdr,
                                       lcmv only (their state does not depend on the direction); SURVEY 8(e) "look
                                       directions" / 8(f) row 4 */
+    /* gsc (gsc.cpp:199-256, launch/gsc.launch:6-11); write_mu is file I/O and not part of the path */
+    int gsc_use_vad;
+    double gsc_vad_threshold, gsc_mu0, gsc_mu_max;
+    int gsc_filter_size;           /* 1..256 */
 } bf_config;
 #define BF_MAX_DIRS 64
 

@@ -18,7 +18,7 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 MAX_MICS = 32
 MAX_INTERF = 16
-ALGO_ID = {"das": 0, "mvdr": 1, "lcmv": 2, "gss": 3, "phase": 4, "phasempf": 5, "mcra": 6}
+ALGO_ID = {"das": 0, "mvdr": 1, "lcmv": 2, "gss": 3, "phase": 4, "phasempf": 5, "mcra": 6, "gsc": 7}
 
 
 class OrcParams(C.Structure):
@@ -33,7 +33,13 @@ class OrcParams(C.Structure):
         ("mcra_alphaD2", C.c_double), ("mcra_delta", C.c_double), ("mcra_L", C.c_int), ("mpf_alphaS", C.c_double),
         ("mpf_eta", C.c_double), ("mpf_rev_gamma", C.c_double), ("mpf_rev_delta", C.c_double),
         ("noise_floor", C.c_double), ("out_only_noise", C.c_int), ("out_only_mcra", C.c_int),
+        ("gsc_use_vad", C.c_int), ("gsc_vad_threshold", C.c_double), ("gsc_mu0", C.c_double), ("gsc_mu_max", C.c_double),
+        ("gsc_filter_size", C.c_int),
     ]
+
+
+#: defaults of parameters added after the first golden fixtures were written (launch/gsc.launch:6-11)
+_LATER_KEYS = dict(gsc_use_vad=0, gsc_vad_threshold=0.1, gsc_mu0=0.0001, gsc_mu_max=0.1, gsc_filter_size=128)
 
 
 def build(force: bool = False) -> str:
@@ -82,13 +88,14 @@ def to_struct(p: dict) -> OrcParams:
     for k in ("past_windows", "freq_mag_threshold", "freq_max", "freq_min", "out_amp", "mu", "lambda_", "min_phase",
               "mag_mult", "mag_threshold", "min_mag", "smooth_size", "mcra_alphaS", "mcra_alphaD", "mcra_alphaD2",
               "mcra_delta", "mcra_L", "mpf_alphaS", "mpf_eta", "mpf_rev_gamma", "mpf_rev_delta", "noise_floor",
-              "out_only_noise", "out_only_mcra"):
-        setattr(s, k, p[k])
+              "out_only_noise", "out_only_mcra", "gsc_use_vad", "gsc_vad_threshold", "gsc_mu0", "gsc_mu_max",
+              "gsc_filter_size"):
+        setattr(s, k, p[k] if k in p else _LATER_KEYS[k])  # fixtures written before a key existed
     return s
 
 
 class OracleNode:
-    """One reference node (das|mvdr|lcmv|gss|phase|phasempf|mcra) in double precision on the CPU."""
+    """One reference node (das|mvdr|lcmv|gss|phase|phasempf|mcra|gsc) in double precision on the CPU."""
 
     def __init__(self, params: dict):
         self.p = params

@@ -187,6 +187,10 @@ struct orc_node {
         lambda_mpf;
     int current_L;
     bool first_L;
+    /* gsc (gsc.cpp:24-27, util.h:316-347) */
+    std::vector<std::vector<float> > out_buff_mic[2]; /* [2][M][N] */
+    std::vector<std::vector<float> > block_matrix, filter;
+    std::vector<float> last_outputs;
 };
 
 /* util.h:136-161 calculate_delays and util.h:163-188 calculate_interf_delays */
@@ -589,6 +593,77 @@ static void apply_phasempf(orc_node *n) {
     }
 }
 
+
+/* ------------------------------------------------------------------ gsc -- */
+/* gsc.cpp:54-75: per-microphone phase alignment, weight_func of do_overlap_bymic */
+static void gsc_apply_weights(orc_node *n, int mic, float *out) {
+    prepare_input(n, mic, n->x_time.data());
+    dft_pow2(n->x_time.data(), n->x_fft.data(), n->N, -1);
+    for (int i = 0; i < n->N; i++) n->x_fft[i] *= std::conj(n->weights[i](mic, 0));
+    for (int i = 0; i < n->N; i++) n->y_fft[i] = n->x_fft[i];
+    dft_pow2(n->y_fft.data(), n->y_time.data(), n->N, +1);
+    prepare_output(n, n->y_time.data(), out);
+}
+
+/* gsc.cpp:77-82 */
+static void gsc_shift_data(float data, float *buf, int size) {
+    for (int i = 1; i < size; i++) buf[i - 1] = buf[i];
+    buf[size - 1] = data;
+}
+
+/* gsc.cpp:84-91 (rosjack_data = float: every product and sum is rounded to float) */
+static float gsc_calculate_power(const float *buf, int size) {
+    float p = 0.0;
+    for (int i = 0; i < size; i++) p += buf[i] * buf[i];
+    p /= (float)size;
+    return sqrt(p);
+}
+
+/* gsc.cpp:93-197: one jack_callback.  in = [M][H] planar, out = [H] */
+static void gsc_callback(orc_node *n, const float *in, float *out) {
+    const int M = n->M, H = n->H, fs = n->p.gsc_filter_size;
+    std::vector<std::vector<float> > overlap_out(M, std::vector<float>(H, 0.0f));
+    /* do_overlap_bymic (util.h:353-379) */
+    for (int i = 0; i < M; ++i) {
+        memcpy(n->in_ring[i].data() + H, in + (size_t)i * H, sizeof(float) * H);
+        gsc_apply_weights(n, i, n->out_buff_mic[1][i].data());
+        for (int j = 0; j < H; ++j) overlap_out[i][j] = n->out_buff_mic[0][i][j + H] + n->out_buff_mic[1][i][j];
+        n->out_buff_mic[0][i].swap(n->out_buff_mic[1][i]);
+    }
+    for (int i = 0; i < M; ++i) memmove(n->in_ring[i].data(), n->in_ring[i].data() + H, sizeof(float) * H);
+
+    for (int j = 0; j < H; ++j) { /* gsc.cpp:120-181 */
+        float das_out = 0.0;
+        for (int i = 0; i < M; ++i) das_out += overlap_out[i][j];
+        das_out /= M;
+        out[j] = das_out;
+        for (int i = 0; i < M - 1; ++i) {
+            gsc_shift_data(overlap_out[i + 1][j] - overlap_out[i][j], n->block_matrix[i].data(), fs);
+            float block_out = 0.0;
+            for (int k = 0; k < fs; ++k) block_out += n->filter[i][k] * n->block_matrix[i][k];
+            out[j] -= block_out;
+        }
+        gsc_shift_data(out[j], n->last_outputs.data(), fs);
+        float last_out_power = gsc_calculate_power(n->last_outputs.data(), fs);
+        if (last_out_power < n->p.gsc_vad_threshold || (!n->p.gsc_use_vad)) {
+            for (int i = 0; i < M - 1; i++) {
+                float block_power = gsc_calculate_power(n->block_matrix[i].data(), fs);
+                float this_mu;
+                if (n->p.gsc_mu0 * block_power / last_out_power < n->p.gsc_mu_max) {
+                    this_mu = n->p.gsc_mu0 / last_out_power;
+                } else {
+                    this_mu = n->p.gsc_mu0 / block_power;
+                }
+                if (std::isnan(this_mu) || std::isinf(this_mu)) this_mu = 0.0;
+                for (int k = 0; k < fs; ++k) {
+                    n->filter[i][k] += this_mu * out[j] * n->block_matrix[i][k];
+                    if (std::isnan(n->filter[i][k])) n->filter[i][k] = 0.0;
+                }
+            }
+        }
+    }
+}
+
 /* the node's apply_weights(in_buff, out_buff[1]) */
 static void apply_weights(orc_node *n, float *out, double *Ydump) {
     switch (n->p.algo) {
@@ -647,6 +722,12 @@ orc_node *orc_create(const orc_params *p) {
     }
     if (p->algo == ORC_GSS) n->sep_matrix.assign(n->N, Mat(n->S, n->M));
     n->phases_aligned.resize(n->M);
+    if (p->algo == ORC_GSC) { /* gsc.cpp:278-285, util.h:341-346: everything calloc'ed */
+        for (int b = 0; b < 2; b++) n->out_buff_mic[b].assign(n->M, std::vector<float>(n->N, 0.0f));
+        n->block_matrix.assign(n->M > 1 ? n->M - 1 : 0, std::vector<float>(p->gsc_filter_size, 0.0f));
+        n->filter = n->block_matrix;
+        n->last_outputs.assign(p->gsc_filter_size, 0.0f);
+    }
     if (p->algo == ORC_MCRA) { /* mcra.cpp:257-271 */
         std::vector<double> z(n->N, 0.0);
         n->soi2 = z; n->S_ = z; n->S_prev = z; n->S_f = z; n->S_tmp = z; n->S_min = z; n->lambda_noise = z;
@@ -709,6 +790,11 @@ int orc_set_interference(orc_node *n, unsigned id, double angle, double thr) {
 /* jack_callback -> do_overlap (util.h:289-314) */
 int orc_process_hop(orc_node *n, const float *in, float *out, double *Y) {
     const int H = n->H;
+    if (n->p.algo == ORC_GSC) { /* time-domain output: there is no single y_fft to report */
+        gsc_callback(n, in, out);
+        if (Y) memset(Y, 0, sizeof(double) * 2 * n->N);
+        return 0;
+    }
     for (int i = 0; i < n->M; ++i) /* jack_ringbuffer_write: ring now holds [prev hop, this hop] */
         memcpy(n->in_ring[i].data() + H, in + (size_t)i * H, sizeof(float) * H);
     apply_weights(n, n->out_buff[1].data(), Y);

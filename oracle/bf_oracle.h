@@ -24,7 +24,8 @@ extern "C" {
 #define ORC_MAX_INTERF 16
 
 enum { ORC_DAS = 0, ORC_MVDR = 1, ORC_LCMV = 2, ORC_GSS = 3, ORC_PHASE = 4, ORC_PHASEMPF = 5,
-       ORC_MCRA = 6 /* single-channel mcra node, mcra.cpp */ };
+       ORC_MCRA = 6 /* single-channel mcra node, mcra.cpp */,
+       ORC_GSC = 7  /* generalized sidelobe canceller, gsc.cpp */ };
 
 typedef struct orc_params {
     int algo;
@@ -50,6 +51,10 @@ typedef struct orc_params {
     double mpf_alphaS, mpf_eta, mpf_rev_gamma, mpf_rev_delta;
     double noise_floor;
     int out_only_noise, out_only_mcra;
+    /* gsc (gsc.cpp:17-21, launch/gsc.launch) */
+    int gsc_use_vad;
+    double gsc_vad_threshold, gsc_mu0, gsc_mu_max;
+    int gsc_filter_size;
 } orc_params;
 
 typedef struct orc_node orc_node;

@@ -286,6 +286,47 @@ def mcra_node_bins(p, X):
     return Y
 
 
+def gsc_process(p: dict, x: np.ndarray) -> np.ndarray:
+    """gsc.cpp:54-75 (per-mic alignment through the STFT) + gsc.cpp:120-181 (float32 NLMS, sample by sample).
+    Sequential float32 sums are np.cumsum(...)[-1] (cumsum accumulates left to right in the array dtype)."""
+    f32 = np.float32
+    M, fs = p["n_mics"], p["gsc_filter_size"]
+    X = stft(p, x)                      # [F, M, N]
+    w = steering(p, p["theta"])         # [M, N]
+    a = np.stack([istft_ola(p, np.conj(w[m]) * X[:, m, :]) for m in range(M)])  # [M, T] float32
+    T = a.shape[1]
+    bm = np.zeros((max(M - 1, 0), fs), f32); flt = np.zeros_like(bm); lo = np.zeros(fs, f32)
+    out = np.zeros(T, f32)
+    mu0, mu_max = p["gsc_mu0"], p["gsc_mu_max"]
+    with np.errstate(all="ignore"):
+        for j in range(T):
+            das = f32(0.0)
+            for m in range(M):
+                das = f32(das + a[m, j])
+            o = f32(das / f32(M))
+            if M > 1:
+                bm[:, :-1] = bm[:, 1:]
+                bm[:, -1] = a[1:, j] - a[:-1, j]
+                bo = np.cumsum(flt * bm, axis=1, dtype=f32)[:, -1]
+                for i in range(M - 1):
+                    o = f32(o - bo[i])
+            lo[:-1] = lo[1:]; lo[-1] = o
+            lop = f32(np.sqrt(f32(np.cumsum(lo * lo, dtype=f32)[-1] / f32(fs))))
+            out[j] = o
+            if lop < p["gsc_vad_threshold"] or not p["gsc_use_vad"]:
+                for i in range(M - 1):
+                    bp = f32(np.sqrt(f32(np.cumsum(bm[i] * bm[i], dtype=f32)[-1] / f32(fs))))
+                    if np.float64(mu0) * np.float64(bp) / np.float64(lop) < mu_max:
+                        mu = f32(np.float64(mu0) / np.float64(lop))
+                    else:
+                        mu = f32(np.float64(mu0) / np.float64(bp))
+                    if not np.isfinite(mu):
+                        mu = f32(0.0)
+                    upd = flt[i] + f32(mu * o) * bm[i]
+                    flt[i] = np.where(np.isnan(upd), f32(0.0), upd)
+    return out
+
+
 def constraint_matrices(p: dict, theta: float) -> np.ndarray:
     """lcmv.cpp:44-86: C_j = [steer, interferer_1..K] -> [N, M, S]."""
     cols = [steering(p, theta)] + [steering(p, a) for a in p["interf"]]
@@ -295,6 +336,9 @@ def constraint_matrices(p: dict, theta: float) -> np.ndarray:
 def process(p: dict, x: np.ndarray):
     """Whole stream from cold start: x [M, F*H] float32 -> (y [F*H] float32, Y [F, N] complex128)."""
     algo = p["algo"]
+    if algo == "gsc":  # time-domain node: no single output spectrum
+        y = gsc_process(p, x)
+        return y, np.zeros((len(y) // p["hop"], 2 * p["hop"]), np.complex128)
     X = stft(p, x)
     w = steering(p, p["theta"])
     post = None

@@ -31,7 +31,8 @@ CASES = [
     ("lcmv16", "lcmv", 16, (-60.0, 90.0, 150.0), 14, 20.0),  # config 5 shape
     ("gss8", "gss", 8, (-60.0, 90.0), 12, 20.0),
     ("phase8", "phase", 8, (), 10, 20.0),
-    ("mcra2", "mcra", 2, (), 24, 0.0, dict(mcra_L=8)),  # SURVEY 8(f) row 2; short L puts the minima reset inside the run
+    ("mcra2", "mcra", 2, (), 24, 0.0, dict(mcra_L=8)),
+    ("gsc4", "gsc", 4, (), 8, 20.0),  # SURVEY 8(f) row 1; time-domain node: Y is all zeros by definition  # SURVEY 8(f) row 2; short L puts the minima reset inside the run
 ]
 
 
@@ -50,7 +51,10 @@ def main():
         worst = max(np.linalg.norm(Y[t] - Y2[t]) / (np.linalg.norm(Y2[t]) or 1.0) for t in range(F) if fin[t])
         assert worst < 1e-10, (name, worst)
         ok = np.isfinite(y)
-        assert np.array_equal(y[ok], y2[ok]), name
+        if algo == "gsc":  # the two FFTs differ by ~1e-16 absolute on near-zero samples
+            assert np.abs(y[ok] - y2[ok]).max() < 1e-6 * np.abs(y[ok]).max(), name
+        else:
+            assert np.array_equal(y[ok], y2[ok]), name
         np.savez_compressed(os.path.join(out_dir, f"{name}.npz"), params=json.dumps(p), x=x, y=y, Y=Y)
         print(f"{name}: {F} frames, cross-check {worst:.1e}, finite frames {int(fin.sum())}/{F}")
 

@@ -58,6 +58,19 @@ def test_mcra_node_minima_reset_agrees_with_numpy_restatement():
     assert np.abs(Y[5:, 1:]).max() > 0    # and the rest is live
 
 
+@pytest.mark.parametrize("M,F,over", [(4, 5, {}), (8, 4, dict(gsc_filter_size=32)), (3, 5, dict(gsc_use_vad=1, gsc_vad_threshold=0.15))])
+def test_gsc_agrees_with_numpy_restatement(M, F, over):
+    """gsc.cpp:54-197: both restatements replay the float32 NLMS operation by operation."""
+    p = make_params("gsc", n_mics=M, theta=20.0, **over)
+    x = make_scene(M, F, seed=3)
+    y = oracle.OracleNode(p).process(x)[0]
+    y2 = np_oracle.process(p, x)[0]
+    assert np.isfinite(y).all() and np.abs(y).max() > 0.1
+    assert np.abs(y - y2).max() < 1e-6 * np.abs(y).max()
+    yd = oracle.OracleNode(make_params("das", n_mics=M, theta=20.0)).process(x)[0]
+    assert rel_l2(y, yd) > 1e-3  # the sidelobe canceller does something
+
+
 def test_fft_matches_numpy():
     rng = np.random.default_rng(0)
     x = rng.standard_normal(1024) + 1j * rng.standard_normal(1024)

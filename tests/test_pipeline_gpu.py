@@ -266,3 +266,49 @@ def test_interferer_update_add_remove(algo):
     assert rel_l2(y[ok], y_ref[ok]) < TOL_TIME
     with pytest.raises(Exception):
         bf.set_interference(9, -120.0)          # a 4th interferer is beyond this build (BF_ENOSYS)
+
+
+@pytest.mark.parametrize("M,F,over", [(4, 12, {}), (8, 10, {}), (2, 9, dict(gsc_filter_size=32)), (1, 6, {}),
+                                      (3, 10, dict(gsc_use_vad=1, gsc_vad_threshold=0.15)), (16, 6, dict(gsc_filter_size=64))])
+def test_gsc_matches_oracle(M, F, over):
+    """per-microphone alignment through the STFT + the sample-serial float32 NLMS of gsc.cpp:120-181.
+    The NLMS replays the reference's float32 operation order, so agreement is far inside the 1e-5 budget."""
+    import oracle
+    from beamform_amd.capi import Beamformer
+    _torch()
+    p = make_params("gsc", n_mics=M, theta=20.0, **over)
+    x = make_scene(M, F, seed=1200 + M)
+    y_ref, _ = oracle.OracleNode(p).process(x)
+    y = Beamformer(p).process(x)
+    assert np.isfinite(y).all()
+    assert rel_l2(y, y_ref) < TOL_TIME
+    assert np.abs(y - y_ref).max() < 1e-5 * np.abs(y_ref).max()
+
+
+def test_gsc_state_carries_across_batches_theta_and_streams():
+    import oracle
+    from beamform_amd.capi import Beamformer
+    _torch()
+    M, F, S = 4, 14, 3
+    p = make_params("gsc", n_mics=M, theta=20.0)
+    xs = np.stack([make_scene(M, F, seed=70 + s) for s in range(S)])
+    nodes = [oracle.OracleNode(p) for _ in range(S)]
+    bf = Beamformer(p, n_streams=S)
+    cuts = [0, 3, 4, 9, 14]
+    ys, refs = [], []
+    for n, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        if n == 2:
+            bf.set_theta(-50.0)
+            for nd in nodes:
+                nd.set_theta(-50.0)
+        if n == 3:  # checkpoint into a fresh handle
+            blob = bf.get_state()
+            bf = Beamformer(p, n_streams=S)
+            bf.set_theta(-50.0)
+            bf.set_state(blob)
+        seg = np.ascontiguousarray(xs[:, :, a * 512:b * 512])
+        ys.append(bf.process(seg))
+        refs.append(np.stack([nodes[s].process(seg[s])[0] for s in range(S)]))
+    y, r = np.concatenate(ys, axis=1), np.concatenate(refs, axis=1)
+    for s in range(S):
+        assert rel_l2(y[s], r[s]) < TOL_TIME
