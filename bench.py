@@ -74,8 +74,12 @@ def load_traffic(tag: str):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle-ms", type=float, default=80.0,
+                    help="keep the GPU busy with untimed steps for this long before the W warmup steps: the clock/power\n"
+                         "controller needs ~50 launches (25 ms) after an idle period before kernel durations are steady\n"
+                         "(profiles/README.md r01_g); 0 disables")
     ap.add_argument("--algo", default="das", choices=["das", "mvdr", "lcmv", "gss", "phase", "phasempf", "mcra", "gsc"])
     ap.add_argument("--mics", type=int, default=8)
     ap.add_argument("--frames", type=int, default=65536, help="frames per GPU per step")
@@ -148,6 +152,14 @@ def main():
         if world > 1 and args.gather == "step":
             gather_to_rank0(y, gathered)
 
+    settle_launches = 0
+    if args.settle_ms > 0:  # untimed: let DVFS settle (a cold chip runs the first ~50 launches up to 45 % slower)
+        ts = time.perf_counter()
+        while (time.perf_counter() - ts) * 1e3 < args.settle_ms:
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize(dev)
+            settle_launches += 8
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -216,7 +228,7 @@ def main():
                        "hop": HOP, "streams": S, "layout": args.layout, "gather": args.gather if world > 1 else "n/a",
                        "final_gather_ms": gather_dt * 1e3 if world > 1 and args.gather == "final" else None,
                        "value_including_final_gather": (frames_total / (dt + gather_dt)) if gather_dt > 0 else None,
-                       "parallelism": f"frame-sharded x{world}"},
+                       "parallelism": f"frame-sharded x{world}", "settle_launches_before_warmup": settle_launches},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          # PMC traffic exists for the headline workload only (profiles/traffic_das8.json)
