@@ -14,6 +14,7 @@ ap.add_argument("--streams", type=int, default=1)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--layout", default="planar")
 ap.add_argument("--warmup", type=int, default=10)
+ap.add_argument("--settle-ms", type=float, default=80.0)
 ap.add_argument("--dirs", type=int, default=1, help="look directions per input stream (same input, n_dirs outputs)")
 a = ap.parse_args()
 interf = (-60.0, 90.0, 150.0) if a.algo in ("lcmv", "gss") else ()
@@ -25,8 +26,14 @@ if a.dirs > 1:
 shape = (a.streams, a.mics, a.frames * 512) if lay == BF_PLANAR else (a.streams, a.frames * 512, a.mics)
 x = torch.rand(shape, device="cuda") - 0.5
 y = torch.empty((a.streams * a.dirs, a.frames * 512), device="cuda")
-for _ in range(a.warmup):
+import time
+t0 = time.perf_counter()
+n_warm = 0
+while n_warm < a.warmup or (time.perf_counter() - t0) < a.settle_ms * 1e-3:  # clocks settle ~50 launches after idle
     bf.process_device(x.data_ptr(), a.frames, y.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    n_warm += 1
+    if n_warm % 8 == 0:
+        torch.cuda.synchronize()
 torch.cuda.synchronize()
 ms, msk = bf.time_device(x.data_ptr(), a.frames, y.data_ptr(), a.iters, torch.cuda.current_stream().cuda_stream)
 print(f"{a.algo} M={a.mics} F={a.frames} S={a.streams} D={a.dirs}: call {ms:.4f} ms, kernel {msk:.4f} ms, "
