@@ -1,0 +1,55 @@
+"""bench.py contract on the GPU box: one JSON line with the agreed fields, at N=1 and through the N>1 launcher path.
+
+The N>1 case uses the BF_BENCH_ONE_DEVICE=1 hook (every rank on cuda:0, gloo for the host-staged gather) because the
+test box has one GPU; it exercises torch.distributed.run, the barriers, the max-over-ranks timing and the gather code."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--frames", "4096", "--steps", "3", "--warmup", "1", "--settle-ms", "0", "--no-extra"]
+
+
+def _last_json(out: str) -> dict:
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def _check_line(d, n):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "stft_frames_per_sec" and d["unit"] == "frames/s" and d["n_gpus"] == n
+    assert d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
+    assert abs(d["value"] - n * 4096 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_single_gpu_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--cpu-frames", "256"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    _check_line(d, 1)
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "frames/s"
+
+
+def test_bench_two_ranks_through_the_launcher():
+    env = dict(os.environ, BF_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29653", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL + ["--no-cpu"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    _check_line(d, 2)
+    assert d["config"]["final_gather_ms"] is not None and d["config"]["final_gather_ms"] >= 0
