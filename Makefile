@@ -11,7 +11,10 @@ CPP_SRCS := $(SRC)/capi.cpp $(SRC)/config.cpp
 OBJS := $(patsubst $(SRC)/%.hip,$(OBJ)/%.o,$(HIP_SRCS)) $(patsubst $(SRC)/%.cpp,$(OBJ)/%.o,$(CPP_SRCS))
 HDRS := $(wildcard $(SRC)/*.hpp) include/bfcore.h
 
-all: $(LIB) oracle examples/file_node
+all: $(LIB) oracle examples/file_node examples/theta_scan
+
+examples/theta_scan: examples/theta_scan.cpp include/bfcore.h $(LIB)
+	$(HIPCC) -O2 -std=c++17 -x hip --offload-arch=$(ARCH) examples/theta_scan.cpp -o $@ -Lbeamform_amd/lib -lbfcore -Wl,-rpath,'$$ORIGIN/../beamform_amd/lib'
 
 examples/file_node: examples/file_node.cpp include/bf_node_shim.hpp include/bfcore.h $(LIB)
 	$(HIPCC) -O2 -std=c++17 -x hip --offload-arch=$(ARCH) examples/file_node.cpp -o $@ -Lbeamform_amd/lib -lbfcore -Wl,-rpath,'$$ORIGIN/../beamform_amd/lib'
@@ -38,7 +41,7 @@ emul:
 	g++ -O2 -std=c++17 -fPIC -shared -o tests/host_emul/libemul.so tests/host_emul/emul.cpp
 
 clean:
-	rm -rf build $(LIB) tests/host_emul/libemul.so examples/file_node
+	rm -rf build $(LIB) tests/host_emul/libemul.so examples/file_node examples/theta_scan
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle emul ubench clean
