@@ -207,6 +207,9 @@ def main():
             torch.cuda.synchronize(dev)
             ms_m, _ = bm.time_device(x.data_ptr(), F, y.data_ptr(), 5, sptr)
             extra = {"mvdr_frames_per_s": F / (ms_m * 1e-3), "mvdr_ms_per_step": ms_m,
+                     # same algorithmic floor as das (spectra need never leave the chip in principle)
+                     "mvdr_frac_of_hbm_roofline_algorithmic_bytes":
+                         algorithmic_bytes_per_frame(M) * F / (ms_m * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "mvdr_workload": f"mvdr {M}-mic 1024-pt, {F}-frame batch, fp64 bin pipeline (compute-bound: "
                                       "per-bin covariance + Cholesky solve), launch-file parameters"}
             bm.close()
