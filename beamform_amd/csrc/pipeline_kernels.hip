@@ -516,20 +516,79 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
 #pragma unroll
     for (int m = 0; m < MP; ++m) st[m] = (m < M) ? ld(steer + (long)m * kN + j) : cd{0, 0};
 
+    // Spectra are prefetched one frame ahead by global->LDS DMA (global_load_lds_dwordx4: no VGPRs, 1 KB per
+    // instruction, lane l lands at row base + 16 l): a wavefront that owns its SIMD has nobody to hide HBM latency
+    // behind, and the PMC profile of the register-only version showed 57 % of its cycles in s_waitcnt.
+    // Row 2p / 2p+1 = Z_t[p][k] / Z_t[p][N-k]; rows MP + 2p, MP + 2p + 1 = the same of frame t - P (leaving the window).
+    __shared__ __attribute__((aligned(16))) f64x2 s_pf[2][2 * MP][64];
+    const int lane = threadIdx.x;
+    const int ksrc = q_src_bin(qq), kneg = (kN - ksrc) & (kN - 1);
+    auto dma_frame = [&](long t, bool with_old, int buf) {
+        const f64x2 *Zn = Zs + t * NP * kN, *Zo = Zs + (t - P) * NP * kN;
+#pragma unroll
+        for (int p = 0; p < MP / 2; ++p)
+            if (2 * p < M) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Zn + p * kN + ksrc),
+                                                 (__attribute__((address_space(3))) void *)&s_pf[buf][2 * p][0], 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Zn + p * kN + kneg),
+                                                 (__attribute__((address_space(3))) void *)&s_pf[buf][2 * p + 1][0], 16, 0, 0);
+                if (with_old) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Zo + p * kN + ksrc),
+                                                     (__attribute__((address_space(3))) void *)&s_pf[buf][MP + 2 * p][0], 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Zo + p * kN + kneg),
+                                                     (__attribute__((address_space(3))) void *)&s_pf[buf][MP + 2 * p + 1][0], 16, 0, 0);
+                }
+            }
+    };
+    auto unpack = [&](int buf, int base, cd (&X)[MP]) {  // load_X out of the prefetched rows
+#pragma unroll
+        for (int p = 0; p < MP / 2; ++p) {
+            if (2 * p < M) {
+                const cd z = ld(&s_pf[buf][base + 2 * p][lane]);
+                const cd zc = conj(ld(&s_pf[buf][base + 2 * p + 1][lane]));
+                cd xa = (z + zc) * 0.5;
+                const cd d = z - zc;
+                cd xb = cd{0.5 * d.y, -0.5 * d.x};
+                if (qq == 513) {
+                    xa = conj(xa);
+                    xb = conj(xb);
+                }
+                X[2 * p] = xa;
+                X[2 * p + 1] = xb;
+            } else {
+                X[2 * p] = cd{0, 0};
+                X[2 * p + 1] = cd{0, 0};
+            }
+        }
+    };
+#define BF_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
     cd R[NT];  // lower triangle, row-major: R[i*(i+1)/2 + c], c <= i
 #pragma unroll
     for (int e = 0; e < NT; ++e) R[e] = cd{0, 0};
-    for (int p = 1; p <= P; ++p) {
+    int pb = 0;  // buffer the next consumer reads
+    dma_frame(tA - 1, false, pb);
+    for (int p = 1; p <= P; ++p) {  // covariance of the P frames in front of the tile
+        BF_DMA_WAIT();
+        __builtin_amdgcn_wave_barrier();
+        if (p < P)
+            dma_frame(tA - p - 1, false, pb ^ 1);
+        else
+            dma_frame(tA, true, pb ^ 1);  // first frame of the tile
         cd X[MP];
-        load_X<MP>(Zs + (tA - p) * NP * kN, qq, M, X);
+        unpack(pb, 0, X);
 #pragma unroll
         for (int i = 0; i < MP; ++i)
 #pragma unroll
             for (int c = 0; c <= i; ++c) R[i * (i + 1) / 2 + c] = cfma_conj(R[i * (i + 1) / 2 + c], X[i], X[c]);
+        pb ^= 1;
     }
     for (long t = tA; t < tB; ++t) {
+        BF_DMA_WAIT();  // frame t (and t - P) have landed in s_pf[pb]
+        __builtin_amdgcn_wave_barrier();
+        if (t + 1 < tB) dma_frame(t + 1, true, pb ^ 1);
         cd X[MP];
-        load_X<MP>(Zs + t * NP * kN, qq, M, X);
+        unpack(pb, 0, X);
         double mag = 0.0;
 #pragma unroll
         for (int m = 0; m < MP; ++m)
@@ -581,13 +640,15 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
         if (live) yout[t * kYhStride] = f64x2{y.x, y.y};
         // slide the covariance window (mvdr.cpp:100-101)
         cd Xo[MP];
-        load_X<MP>(Zs + (t - P) * NP * kN, qq, M, Xo);
+        unpack(pb, MP, Xo);
 #pragma unroll
         for (int i = 0; i < MP; ++i)
 #pragma unroll
             for (int c = 0; c <= i; ++c)
                 R[i * (i + 1) / 2 + c] = cfms_conj(cfma_conj(R[i * (i + 1) / 2 + c], X[i], X[c]), Xo[i], Xo[c]);
+        pb ^= 1;
     }
+#undef BF_DMA_WAIT
 }
 
 template <int KM>
