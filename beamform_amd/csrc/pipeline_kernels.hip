@@ -662,10 +662,13 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
     constexpr int GPB = 256 / MP;          // problem groups per block
     constexpr int NB = KM + 1;             // right-hand sides: constraints + current frame
     constexpr int NE = GramIdx<KM>::NE;
-    __shared__ cd s_col[GPB][MP];
-    __shared__ cd s_x[GPB][MP];
-    __shared__ cd s_xo[GPB][MP];
-    __shared__ cd s_u[GPB][NB][MP];
+    // +1 element of padding per row: the groups of a wavefront read the same [row][k] at the same time (broadcast
+    // inside a group), and with a group stride that is a multiple of 128 B all of them would hit the same 4 banks
+    // (PMC before the padding: SQ_LDS_BANK_CONFLICT = 1.7x SQ_ACTIVE_INST_LDS; lcmv 16-mic 37.5 -> 34.0 ms)
+    __shared__ cd s_col[GPB][MP + 1];
+    __shared__ cd s_x[GPB][MP + 1];
+    __shared__ cd s_xo[GPB][MP + 1];
+    __shared__ cd s_u[GPB][NB][MP + 1];
     __shared__ cd s_e[GPB][NE + 1];
 
     const int grp = threadIdx.x / MP;
@@ -1320,8 +1323,8 @@ __global__ __launch_bounds__(64) void gsc_nlms_kernel(const float *aligned, floa
 template <int MP, int KM>
 __global__ __launch_bounds__(256) void gss_kernel(BinsArgs a) {
     constexpr int GPB = 256 / MP;
-    __shared__ cd s_x[GPB][MP];
-    __shared__ cd s_p[GPB][KM][MP];
+    __shared__ cd s_x[GPB][MP + 1];   // padded rows: see mvdr_lcmv_kernel (gss 256x256: 6.5 -> 5.8 ms)
+    __shared__ cd s_p[GPB][KM][MP + 1];
     const int grp = threadIdx.x / MP, m = threadIdx.x % MP;
     const int gq = blockIdx.x * GPB + grp;
     if (gq >= a.n_streams * kNQ) return;
