@@ -112,13 +112,13 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
     // planar layout: raw samples of mic pair p of frame tc into re (mic 2p) / im (mic 2p+1), natural order
     // j <-> sample 32*j + lane
     auto issue_loads = [&](long tc, int p) {
-        const int ma = 2 * p;
-        const int mb = (2 * p + 1 < M) ? 2 * p + 1 : ma;
+        const int ma = 2 * p, mb = 2 * p + 1;
+        const bool b_ok = mb < M;  // odd microphone count: the last pair's partner channel reads the zero buffer
         {
             const float *a1 = (tc >= 1 ? xs + (long)ma * a.mic_stride + (tc - 1) * kHop : hs + ma * kHop) + lane;
-            const float *b1 = (tc >= 1 ? xs + (long)mb * a.mic_stride + (tc - 1) * kHop : hs + mb * kHop) + lane;
+            const float *b1 = (!b_ok ? a.zeros : tc >= 1 ? xs + (long)mb * a.mic_stride + (tc - 1) * kHop : hs + mb * kHop) + lane;
             const float *a2 = xs + (long)ma * a.mic_stride + tc * kHop + lane;
-            const float *b2 = xs + (long)mb * a.mic_stride + tc * kHop + lane;
+            const float *b2 = (!b_ok ? a.zeros : xs + (long)mb * a.mic_stride + tc * kHop) + lane;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 re[j] = a1[32 * j];
@@ -140,7 +140,6 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
 
         for (int p = 0; p < n_pairs; ++p) {
             const bool b_ok = (2 * p + 1) < M;
-            const float bscale = b_ok ? 1.f : 0.f;
             if (LAYOUT != 0) {
                 // interleaved [sample][mic]: the two mics of a pair are adjacent -> one 8-byte load per sample
                 const int ma = 2 * p;
@@ -161,9 +160,9 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         re[j] = s1[(long)32 * j * M + ma];
-                        im[j] = s1[(long)32 * j * M + mb];
+                        im[j] = b_ok ? s1[(long)32 * j * M + mb] : 0.f;
                         re[j + 16] = s2[(long)32 * j * M + ma];
-                        im[j + 16] = s2[(long)32 * j * M + mb];
+                        im[j + 16] = b_ok ? s2[(long)32 * j * M + mb] : 0.f;
                     }
                 }
             } else if (p > 0) {
@@ -172,10 +171,10 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const float4 hv = wrow[g];
-                re[4 * g + 0] *= hv.x; im[4 * g + 0] *= hv.x * bscale;
-                re[4 * g + 1] *= hv.y; im[4 * g + 1] *= hv.y * bscale;
-                re[4 * g + 2] *= hv.z; im[4 * g + 2] *= hv.z * bscale;
-                re[4 * g + 3] *= hv.w; im[4 * g + 3] *= hv.w * bscale;
+                re[4 * g + 0] *= hv.x; im[4 * g + 0] *= hv.x;
+                re[4 * g + 1] *= hv.y; im[4 * g + 1] *= hv.y;
+                re[4 * g + 2] *= hv.z; im[4 * g + 2] *= hv.z;
+                re[4 * g + 3] *= hv.w; im[4 * g + 3] *= hv.w;
             }
 
             fft1024p_fwd_A<float>(re, im, lane, s_tw, pbuf);
