@@ -861,6 +861,277 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
     }
 }
 
+
+// ---- mvdr / lcmv "lanes" kernel: L lanes per problem, rows dealt cyclically, exchange by DPP -------------
+// For 9..16 microphones (and lcmv with up to 8) a problem does not fit one lane's registers.  Instead of one lane per
+// row (mvdr_lcmv_kernel: 16 lanes per problem, half of them idle on average, every column through LDS) lane q of an
+// L-lane group (L = 4 for M <= 16, 2 for M <= 8; a group never straddles a quad) owns rows i = r*L + q of R and of its
+// Cholesky factor.  Cyclic rows keep every lane busy until the last column, the column / pivot / right-hand-side
+// exchange is a quad_perm DPP broadcast, and a wavefront carries 64/L problems.  R (its stored rows: 40 complex per
+// lane at M = 16) lives in LDS, lane-contiguous, so the working copy and the right-hand sides fit the register file of
+// a wavefront that owns its SIMD.  Maths identical to mvdr_lcmv_kernel:
+//   R o whiteR = L L^H,  U = L^-1 [C | x],  G = U_C^H U_C,  g = U_C^H u_x,  y = (G^-1 g)_0.
+template <int L>
+struct LaneGrp;
+template <>
+struct LaneGrp<4> {
+    template <int SRC>
+    static __device__ __forceinline__ int bc(int v) { return __builtin_amdgcn_update_dpp(v, v, SRC * 0x55, 0xF, 0xF, false); }
+    static __device__ __forceinline__ int x1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false); }
+    static __device__ __forceinline__ int x2(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false); }
+};
+template <>
+struct LaneGrp<2> {
+    template <int SRC>
+    static __device__ __forceinline__ int bc(int v) {
+        return __builtin_amdgcn_update_dpp(v, v, SRC | (SRC << 2) | ((2 + SRC) << 4) | ((2 + SRC) << 6), 0xF, 0xF, false);
+    }
+    static __device__ __forceinline__ int x1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false); }
+    static __device__ __forceinline__ int x2(int v) { return v; }
+};
+template <int L, int SRC>
+__device__ __forceinline__ double bcast_d(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = LaneGrp<L>::template bc<SRC>((int)(b & 0xffffffffLL)), hi = LaneGrp<L>::template bc<SRC>((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <int L>
+__device__ __forceinline__ double bcast_from(int src, double v) {  // src is a compile-time constant after unrolling
+    if (L == 2) return src == 0 ? bcast_d<L, 0>(v) : bcast_d<L, 1>(v);
+    return src == 0 ? bcast_d<L, 0>(v) : src == 1 ? bcast_d<L, 1>(v) : src == 2 ? bcast_d<L, 2>(v) : bcast_d<L, 3>(v);
+}
+template <int L>
+__device__ __forceinline__ cd bcast_from(int src, cd v) { return cd{bcast_from<L>(src, v.x), bcast_from<L>(src, v.y)}; }
+template <int L>
+__device__ __forceinline__ double grp_sum(double v) {
+    auto sh = [](double x, bool second) {
+        const long long b = __builtin_bit_cast(long long, x);
+        const int lo = second ? LaneGrp<L>::x2((int)(b & 0xffffffffLL)) : LaneGrp<L>::x1((int)(b & 0xffffffffLL));
+        const int hi = second ? LaneGrp<L>::x2((int)(b >> 32)) : LaneGrp<L>::x1((int)(b >> 32));
+        return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+    };
+    v += sh(v, false);
+    if (L == 4) v += sh(v, true);
+    return v;
+}
+
+template <int MP, int L, int KM>
+__global__ __launch_bounds__(64, 1) void mvdr_lcmv_lanes_kernel(BinsArgs a, int tile, int tiles_per_stream) {
+    constexpr int RPL = MP / L;               // rows per lane
+    constexpr int PPW = 64 / L;               // problems per wavefront
+    constexpr int NB = KM + 1;
+    constexpr int NG = GramIdx<KM>::NG, NE = GramIdx<KM>::NE;
+    constexpr int NT = L * RPL * (RPL + 1) / 2;  // stored entries per lane: slot r keeps columns 0 .. r*L+L-1
+#define TIX(r, c) (L * (r) * ((r) + 1) / 2 + (c))
+    __shared__ __attribute__((aligned(16))) f64x2 s_R[NT][64];  // R rows of this lane: s_R[TIX(r, c)][lane]
+    const int lane = threadIdx.x;
+    const int q = lane % L;
+    const int pq = blockIdx.x * PPW + lane / L;  // problem (bin) index
+    const int s = blockIdx.y / tiles_per_stream;
+    const long tA = (long)(blockIdx.y % tiles_per_stream) * tile;
+    long tB = tA + tile;
+    if (tB > a.n_frames) tB = a.n_frames;
+    const int M = a.n_mics, NP = (M + 1) >> 1, KP1 = a.kp1, P = a.cfg.past_windows;
+    const bool live = pq < kNQ;
+    const int qq = live ? pq : kNQ - 1;
+    const int j = q_bin(qq);
+    const bool lcmv = a.cfg.algo == BF_LCMV;
+    const double f = fabs(a.freqs[j]);
+    const bool inband = live && f >= a.cfg.freq_min && f <= a.cfg.freq_max && !(j == 0 && !lcmv);
+    f64x2 *yout = a.Yh + ((long)s * a.n_frames) * kYhStride + qq;
+    const f64x2 *Zs = a.Z + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
+    const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
+    const int ksrc = q_src_bin(qq), kneg = (kN - ksrc) & (kN - 1);
+    auto load_mic = [&](long t, int m) -> cd {  // spectrum of microphone m at this bin, frame t
+        if (m >= M) return cd{0, 0};
+        const f64x2 *Zf = Zs + t * NP * kN + (m >> 1) * kN;
+        const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
+        cd x;
+        if ((m & 1) == 0) {
+            x = (z + zc) * 0.5;
+        } else {
+            const cd d = z - zc;
+            x = cd{0.5 * d.y, -0.5 * d.x};
+        }
+        return qq == 513 ? conj(x) : x;
+    };
+    if (__builtin_amdgcn_ballot_w64(inband) == 0) {  // nothing to solve in this wavefront
+        if (live && q == 0)
+            for (long t = tA; t < tB; ++t) {
+                cd y{0, 0};
+                if (j == 0 && !lcmv) y = load_mic(t, 0);  // mvdr.cpp:76
+                yout[t * kYhStride] = f64x2{y.x, y.y};
+            }
+        return;
+    }
+    // this lane's entries of the constraint columns (weights[j](i, c)) are re-read every frame (L2-resident table)
+    // straight into the right-hand sides: keeping them would cost 64 more registers at M = 16, K + 1 = 4
+    auto load_cst = [&](int r, int c) -> cd {
+        const int i = r * L + q;
+        return (c < KP1 && i < M) ? ld(steer + ((long)c * M + i) * kN + j) : cd{0, 0};
+    };
+#pragma unroll
+    for (int e = 0; e < NT; ++e) s_R[e][lane] = f64x2{0, 0};
+    // R[i][c] += x_i conj(x_c) (- xo_i conj(xo_c)) on the stored rows; x_c comes from its owner lane by DPP
+    auto rank1 = [&](const cd (&xl)[RPL], const cd (&xo)[RPL], bool with_old) {
+#pragma unroll
+        for (int c = 0; c < MP; ++c) {
+            const cd xc = bcast_from<L>(c % L, xl[c / L]);
+            const cd xoc = with_old ? bcast_from<L>(c % L, xo[c / L]) : cd{0, 0};
+#pragma unroll
+            for (int r = c / L; r < RPL; ++r) {
+                const int i = r * L + q;
+                if (c <= i) {
+                    cd v = ld(&s_R[TIX(r, c)][lane]);
+                    v = cfma_conj(v, xl[r], xc);
+                    if (with_old) v = cfms_conj(v, xo[r], xoc);
+                    s_R[TIX(r, c)][lane] = f64x2{v.x, v.y};
+                }
+            }
+        }
+    };
+    for (int p = 1; p <= P; ++p) {
+        cd xl[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) xl[r] = load_mic(tA - p, r * L + q);
+        rank1(xl, xl, false);
+    }
+
+    for (long t = tA; t < tB; ++t) {
+        cd xl[RPL], xo[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            xl[r] = load_mic(t, r * L + q);
+            xo[r] = load_mic(t - P, r * L + q);
+        }
+        double mag = 0.0;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) mag += sqrt(norm2(xl[r]));  // padded rows are 0
+        mag = grp_sum<L>(mag) / (double)((unsigned)M * 1024u);
+        const cd x0 = bcast_from<L>(0, xl[0]);
+        cd y;
+        if (mag > a.cfg.freq_mag_threshold) {
+            cd A[NT], b[RPL][NB];
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+#pragma unroll
+                for (int c = 0; c < KM; ++c) b[r][c] = load_cst(r, c);
+                b[r][KM] = xl[r];
+            }
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                const int i = r * L + q;
+#pragma unroll
+                for (int c = 0; c < (r + 1) * L; ++c) {
+                    cd v = ld(&s_R[TIX(r, c)][lane]);
+                    if (c == i) v = (i < M) ? v * 1.001 : cd{1.0, 0.0};  // whiteR diagonal; padding rows = identity
+                    if (i >= M && c != i) v = cd{0, 0};
+                    A[TIX(r, c)] = v;
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < MP; ++jj) {
+                const int ro = jj / L, qo = jj % L;  // owner slot / lane of row jj
+                const double inv = rsqrt(bcast_from<L>(qo, A[TIX(ro, jj)].x));
+                cd Lc[RPL];  // scaled column jj of the local rows (meaningful where row > jj)
+#pragma unroll
+                for (int r = ro; r < RPL; ++r) Lc[r] = A[TIX(r, jj)] * inv;
+#pragma unroll
+                for (int col = 0; col < NB; ++col) {  // right-hand sides: u_jj = b_jj / L_jj, then b_i -= L_ij u_jj
+                    const cd u = bcast_from<L>(qo, b[ro][col] * inv);
+                    if (q == qo) b[ro][col] = u;
+#pragma unroll
+                    for (int r = ro; r < RPL; ++r) {
+                        const int i = r * L + q;
+                        if (i > jj) b[r][col] = cfms(b[r][col], Lc[r], u);
+                    }
+                }
+#pragma unroll
+                for (int c = jj + 1; c < MP; ++c) {  // trailing update A_ic -= L_ij conj(L_cj), jj < c <= i
+                    const cd Lcj = bcast_from<L>(c % L, Lc[c / L]);
+#pragma unroll
+                    for (int r = c / L; r < RPL; ++r) {
+                        const int i = r * L + q;
+                        if (c <= i) A[TIX(r, c)] = cfms_conj(A[TIX(r, c)], Lc[r], Lcj);
+                    }
+                }
+            }
+            // b holds the local rows of U = L^-1 [C | x]; Gram entries, reduced over the group
+            cd ge[NE];
+            {
+                int e = 0;
+#pragma unroll
+                for (int r1 = 0; r1 < KM; ++r1)
+#pragma unroll
+                    for (int r2 = r1; r2 < KM; ++r2) {
+                        cd acc{0, 0};
+#pragma unroll
+                        for (int r = 0; r < RPL; ++r)
+                            if (r * L + q < M) acc = cfma_conj(acc, b[r][r2], b[r][r1]);
+                        ge[e++] = cd{grp_sum<L>(acc.x), grp_sum<L>(acc.y)};
+                    }
+#pragma unroll
+                for (int r1 = 0; r1 < KM; ++r1) {
+                    cd acc{0, 0};
+#pragma unroll
+                    for (int r = 0; r < RPL; ++r)
+                        if (r * L + q < M) acc = cfma_conj(acc, b[r][KM], b[r][r1]);
+                    ge[NG + r1] = cd{grp_sum<L>(acc.x), grp_sum<L>(acc.y)};
+                }
+            }
+            cd Gm[KM][KM], gv[KM];
+            {
+                int e = 0;
+#pragma unroll
+                for (int r1 = 0; r1 < KM; ++r1)
+#pragma unroll
+                    for (int r2 = r1; r2 < KM; ++r2) {
+                        const cd v = ge[e++];
+                        Gm[r1][r2] = v;
+                        Gm[r2][r1] = conj(v);
+                    }
+#pragma unroll
+                for (int r1 = 0; r1 < KM; ++r1) gv[r1] = ge[NG + r1];
+#pragma unroll
+                for (int r1 = 0; r1 < KM; ++r1)
+                    if (r1 >= KP1) {
+#pragma unroll
+                        for (int r2 = 0; r2 < KM; ++r2) {
+                            Gm[r1][r2] = cd{r1 == r2 ? 1.0 : 0.0, 0.0};
+                            Gm[r2][r1] = cd{r1 == r2 ? 1.0 : 0.0, 0.0};
+                        }
+                        gv[r1] = cd{0, 0};
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < KM; ++k) {  // Gaussian elimination (G is Hermitian positive definite)
+                const cd pinv = cdiv(cd{1, 0}, Gm[k][k]);
+#pragma unroll
+                for (int r1 = k + 1; r1 < KM; ++r1) {
+                    const cd fct = Gm[r1][k] * pinv;
+#pragma unroll
+                    for (int c = k + 1; c < KM; ++c) Gm[r1][c] = Gm[r1][c] - fct * Gm[k][c];
+                    gv[r1] = gv[r1] - fct * gv[k];
+                }
+            }
+#pragma unroll
+            for (int k = KM - 1; k >= 0; --k) {
+                cd acc = gv[k];
+#pragma unroll
+                for (int c = k + 1; c < KM; ++c) acc = acc - Gm[k][c] * gv[c];
+                gv[k] = cdiv(acc, Gm[k][k]);
+            }
+            y = gv[0];
+        } else {
+            y = x0 * 0.01;  // mvdr.cpp:96
+        }
+        if (!inband) y = (j == 0 && !lcmv) ? x0 : cd{0, 0};
+        if (live && q == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+        rank1(xl, xo, true);  // slide the covariance window (mvdr.cpp:100-101)
+    }
+#undef TIX
+}
+
 }  // namespace
 
 hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
@@ -869,6 +1140,25 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
     const int tps = (int)((a.n_frames + tile - 1) / tile);
     const int M = a.n_mics, km = a.kp1 <= 1 ? 1 : 4;
     static const bool no_fast = getenv("BF_MVDR_GROUP") && atoi(getenv("BF_MVDR_GROUP")) != 0;
+    // lanes kernel: mvdr with 9..16 microphones (12.7 vs 26 ms per 32 768 frames at 16) and lcmv with up to 8
+    // (9.4 vs 15.4 ms per 65 536 frames).  lcmv with 9..16 microphones keeps the row-per-lane kernel: 40 complex of
+    // working copy + 5 right-hand sides x 4 rows do not fit 512 registers (736 B of scratch, 5x slower).
+    if (!no_fast && ((a.cfg.algo == BF_MVDR && M > 8) || (a.cfg.algo == BF_LCMV && M <= 8))) {
+        int lt = 32;
+        if (a.n_frames < lt) lt = (int)a.n_frames;
+        const int ltps = (int)((a.n_frames + lt - 1) / lt);
+        if (M <= 4) {
+            const dim3 grid((kNQ + 31) / 32, ltps * a.n_streams);
+            hipLaunchKernelGGL((mvdr_lcmv_lanes_kernel<4, 2, 4>), grid, dim3(64), 0, s, a, lt, ltps);
+        } else if (M <= 8) {
+            const dim3 grid((kNQ + 31) / 32, ltps * a.n_streams);
+            hipLaunchKernelGGL((mvdr_lcmv_lanes_kernel<8, 2, 4>), grid, dim3(64), 0, s, a, lt, ltps);
+        } else {
+            const dim3 grid((kNQ + 15) / 16, ltps * a.n_streams);
+            hipLaunchKernelGGL((mvdr_lcmv_lanes_kernel<16, 4, 1>), grid, dim3(64), 0, s, a, lt, ltps);
+        }
+        return hipGetLastError();
+    }
     if (a.cfg.algo == BF_MVDR && M <= 8 && !no_fast) {
         int ft = 32;
         if (a.n_frames < ft) ft = (int)a.n_frames;
