@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cstdlib>
 
 #include "fft1024.hpp"
@@ -1132,6 +1134,208 @@ __global__ __launch_bounds__(64, 1) void mvdr_lcmv_lanes_kernel(BinsArgs a, int 
 #undef TIX
 }
 
+
+// ---- lcmv / mvdr, 9..16 microphones: one problem per 16-lane DPP row, exchange by row_newbcast ----------
+// Same row-per-lane factorisation as mvdr_lcmv_kernel<16, KM>, but a problem occupies exactly one DPP row, so the
+// pivot, the scaled column and the right-hand sides travel by `v_mov_b32_dpp row_newbcast:n` (lane n of every row to
+// the whole row, one instruction per dword, VALU latency) instead of an LDS write -> s_waitcnt -> read round trip per
+// column, and the Gram sums are row reductions (quad_perm xor 1/2, row_half_mirror, row_mirror).  No LDS at all.
+template <int N>
+__device__ __forceinline__ double rowbc(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x150 + N, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + N, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <int N>
+__device__ __forceinline__ cd rowbc(cd v) { return cd{rowbc<N>(v.x), rowbc<N>(v.y)}; }
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double row_sum(double v) {  // every lane of the 16-lane row gets the row total
+    v += dpp_d<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_d<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_d<0x141>(v);  // row_half_mirror
+    v += dpp_d<0x140>(v);  // row_mirror
+    return v;
+}
+template <int C, int MP>
+struct RowStep {  // compile-time loops over the broadcast source lane
+    template <typename F>
+    static __device__ __forceinline__ void run(F &&f) {
+        f(std::integral_constant<int, C>{});
+        RowStep<C + 1, MP>::run(f);
+    }
+};
+template <int MP>
+struct RowStep<MP, MP> {
+    template <typename F>
+    static __device__ __forceinline__ void run(F &&) {}
+};
+
+template <int KM>
+__global__ __launch_bounds__(256, 2) void mvdr_lcmv_row_kernel(BinsArgs a, int tile, int tiles_per_stream) {
+    constexpr int MP = 16, GPB = 256 / MP, NB = KM + 1;
+    constexpr int NG = GramIdx<KM>::NG, NE = GramIdx<KM>::NE;
+    const int grp = threadIdx.x / MP;
+    const int i = threadIdx.x % MP;
+    const int q = blockIdx.x * GPB + grp;
+    if (q >= kNQ) return;
+    const int s = blockIdx.y / tiles_per_stream;
+    const long tA = (long)(blockIdx.y % tiles_per_stream) * tile;
+    long tB = tA + tile;
+    if (tB > a.n_frames) tB = a.n_frames;
+    const int M = a.n_mics, NP = (M + 1) >> 1, KP1 = a.kp1, P = a.cfg.past_windows;
+    const int j = q_bin(q);
+    const bool lcmv = a.cfg.algo == BF_LCMV;
+    f64x2 *yout = a.Yh + ((long)s * a.n_frames) * kYhStride + q;
+    const f64x2 *Zs = a.Z + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
+    const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
+    const int ksrc = q_src_bin(q), kneg = (kN - ksrc) & (kN - 1);
+    auto load_xi = [&](long t) -> cd {
+        if (i >= M) return cd{0, 0};
+        const f64x2 *Zf = Zs + t * NP * kN + (i >> 1) * kN;
+        const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
+        cd x;
+        if ((i & 1) == 0) {
+            x = (z + zc) * 0.5;
+        } else {
+            const cd d = z - zc;
+            x = cd{0.5 * d.y, -0.5 * d.x};
+        }
+        return q == 513 ? conj(x) : x;
+    };
+    const double f = fabs(a.freqs[j]);
+    const bool inband = f >= a.cfg.freq_min && f <= a.cfg.freq_max;
+    if (!inband || (!lcmv && j == 0)) {  // uniform per row
+        for (long t = tA; t < tB; ++t) {
+            cd y{0, 0};
+            if (!lcmv && j == 0) y = rowbc<0>(load_xi(t));  // mvdr.cpp:76
+            if (i == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+        }
+        return;
+    }
+    // this microphone's entries of the constraint columns are re-read per frame (L2-resident) straight into the
+    // right-hand sides: holding them costs the 16 registers that decide between one and two wavefronts per SIMD
+    auto load_cst = [&](int r) -> cd { return (r < KP1 && i < M) ? ld(steer + ((long)r * M + i) * kN + j) : cd{0, 0}; };
+
+    cd R[MP];  // row i of R
+#pragma unroll
+    for (int c = 0; c < MP; ++c) R[c] = cd{0, 0};
+    for (int p = 1; p <= P; ++p) {
+        const cd x = load_xi(tA - p);
+        RowStep<0, MP>::run([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            R[c] = cfma_conj(R[c], x, rowbc<c>(x));
+        });
+    }
+    for (long t = tA; t < tB; ++t) {
+        const cd x = load_xi(t);
+        const double mag = row_sum(sqrt(norm2(x))) / (double)((unsigned)M * 1024u);
+        cd y;
+        if (mag > a.cfg.freq_mag_threshold) {  // uniform per row
+            cd A[MP], b[NB];
+#pragma unroll
+            for (int c = 0; c < MP; ++c) A[c] = R[c];
+            if (i < M) {
+#pragma unroll
+                for (int c = 0; c < MP; ++c)
+                    if (c == i) A[c] = A[c] * 1.001;  // cwiseProduct(whiteR) (mvdr.cpp:239-243)
+            } else {
+#pragma unroll
+                for (int c = 0; c < MP; ++c) A[c] = cd{c == i ? 1.0 : 0.0, 0.0};  // padding rows = identity
+            }
+#pragma unroll
+            for (int r = 0; r < KM; ++r) b[r] = load_cst(r);
+            b[KM] = x;
+            RowStep<0, MP>::run([&](auto jc) {
+                constexpr int jj = decltype(jc)::value;
+                const double inv = rsqrt(rowbc<jj>(A[jj].x));  // 1 / L_jj from the owner's diagonal
+                const cd Lij = A[jj] * inv;                   // my row's entry of the scaled column (valid for i > jj)
+#pragma unroll
+                for (int r = 0; r < NB; ++r) {
+                    const cd bs = b[r] * inv;
+                    const cd ujj = rowbc<jj>(bs);  // u_jj = b_jj / L_jj
+                    if (i > jj)
+                        b[r] = cfms(b[r], Lij, ujj);
+                    else if (i == jj)
+                        b[r] = bs;
+                }
+                RowStep<jj + 1, MP>::run([&](auto cc) {  // trailing update A_ic -= L_ij conj(L_cj), jj < c <= i
+                    constexpr int c = decltype(cc)::value;
+                    const cd Lcj = rowbc<c>(Lij);
+                    if (i >= c) A[c] = cfms_conj(A[c], Lij, Lcj);
+                });
+            });
+            // b[r] = row i of U = L^-1 [C | x]; Gram entries by row reduction
+            cd ge[NE];
+            {
+                int e = 0;
+#pragma unroll
+                for (int r1 = 0; r1 < KM; ++r1)
+#pragma unroll
+                    for (int r2 = r1; r2 < KM; ++r2) {
+                        cd pr = (i < M) ? cfma_conj(cd{0, 0}, b[r2], b[r1]) : cd{0, 0};
+                        ge[e++] = cd{row_sum(pr.x), row_sum(pr.y)};
+                    }
+#pragma unroll
+                for (int r1 = 0; r1 < KM; ++r1) {
+                    cd pr = (i < M) ? cfma_conj(cd{0, 0}, b[KM], b[r1]) : cd{0, 0};
+                    ge[NG + r1] = cd{row_sum(pr.x), row_sum(pr.y)};
+                }
+            }
+            // (K+1) x (K+1) system G y = g on the upper triangle only (G and every Schur complement are Hermitian):
+            // U[r][c], r <= c, is ge[] itself; rows / columns beyond the live constraints are the identity
+            cd gv[KM];
+            auto UI = [](int r, int c) { return r * KM - r * (r - 1) / 2 + (c - r); };
+#pragma unroll
+            for (int r1 = 0; r1 < KM; ++r1) gv[r1] = ge[NG + r1];
+#pragma unroll
+            for (int r1 = 0; r1 < KM; ++r1)
+                if (r1 >= KP1) {
+#pragma unroll
+                    for (int r2 = 0; r2 < r1; ++r2) ge[UI(r2, r1)] = cd{0, 0};
+                    ge[UI(r1, r1)] = cd{1.0, 0.0};
+#pragma unroll
+                    for (int c = r1 + 1; c < KM; ++c) ge[UI(r1, c)] = cd{0, 0};
+                    gv[r1] = cd{0, 0};
+                }
+#pragma unroll
+            for (int k = 0; k < KM; ++k) {
+                const cd pinv = cdiv(cd{1, 0}, ge[UI(k, k)]);
+#pragma unroll
+                for (int r1 = k + 1; r1 < KM; ++r1) {
+                    const cd fct = conj(ge[UI(k, r1)]) * pinv;  // G[r1][k] / G[k][k]
+#pragma unroll
+                    for (int c = r1; c < KM; ++c) ge[UI(r1, c)] = ge[UI(r1, c)] - fct * ge[UI(k, c)];
+                    gv[r1] = gv[r1] - fct * gv[k];
+                }
+            }
+#pragma unroll
+            for (int k = KM - 1; k >= 0; --k) {
+                cd acc = gv[k];
+#pragma unroll
+                for (int c = k + 1; c < KM; ++c) acc = acc - ge[UI(k, c)] * gv[c];
+                gv[k] = cdiv(acc, ge[UI(k, k)]);
+            }
+            y = gv[0];
+        } else {
+            y = rowbc<0>(x) * 0.01;  // in_fft(0,j)*0.01 (mvdr.cpp:96)
+        }
+        if (i == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+        // slide the covariance window: + x_t x_t^H - x_{t-P} x_{t-P}^H (mvdr.cpp:100-101)
+        const cd xo = load_xi(t - P);  // loaded late: 4 registers less across the factorisation
+        RowStep<0, MP>::run([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            R[c] = cfms_conj(cfma_conj(R[c], x, rowbc<c>(x)), xo, rowbc<c>(xo));
+        });
+    }
+}
+
 }  // namespace
 
 hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
@@ -1140,6 +1344,15 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
     const int tps = (int)((a.n_frames + tile - 1) / tile);
     const int M = a.n_mics, km = a.kp1 <= 1 ? 1 : 4;
     static const bool no_fast = getenv("BF_MVDR_GROUP") && atoi(getenv("BF_MVDR_GROUP")) != 0;
+    // lcmv with 9..16 microphones: one problem per DPP row, row_newbcast exchange (34.2 -> 27.6 ms per 32 768 frames at 16)
+    if (!no_fast && a.cfg.algo == BF_LCMV && M > 8) {
+        const dim3 grid((kNQ + 15) / 16, tps * a.n_streams);
+        if (km == 1)
+            hipLaunchKernelGGL((mvdr_lcmv_row_kernel<1>), grid, dim3(256), 0, s, a, tile, tps);
+        else
+            hipLaunchKernelGGL((mvdr_lcmv_row_kernel<4>), grid, dim3(256), 0, s, a, tile, tps);
+        return hipGetLastError();
+    }
     // lanes kernel: mvdr with 9..16 microphones (12.7 vs 26 ms per 32 768 frames at 16) and lcmv with up to 8
     // (9.4 vs 15.4 ms per 65 536 frames).  lcmv with 9..16 microphones keeps the row-per-lane kernel: 40 complex of
     // working copy + 5 right-hand sides x 4 rows do not fit 512 registers (736 B of scratch, 5x slower).
