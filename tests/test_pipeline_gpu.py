@@ -312,3 +312,29 @@ def test_gsc_state_carries_across_batches_theta_and_streams():
     y, r = np.concatenate(ys, axis=1), np.concatenate(refs, axis=1)
     for s in range(S):
         assert rel_l2(y[s], r[s]) < TOL_TIME
+
+
+def test_phasempf_config4_full_size_streams():
+    """BASELINE config 4 at its full shape: 256 independent streams x 256 frames in one call (the recursion runs per stream);
+    three of the streams are replayed through the oracle."""
+    import oracle
+    from beamform_amd.capi import Beamformer
+    torch = _torch()
+    M, S, F = 8, 256, 256
+    p = make_params("phasempf", n_mics=M, theta=20.0)
+    base = [make_scene(M, F, seed=500 + k) for k in range(4)]
+    # stream s = scene (s mod 4) scaled by a stream-specific gain: every stream has its own noise-floor history
+    gains = (0.25 + 0.75 * np.arange(S) / S).astype(np.float32)
+    bf = Beamformer(p, n_streams=S)
+    xd = torch.empty((S, M, F * 512), dtype=torch.float32, device="cuda")
+    bd = [torch.from_numpy(b).cuda() for b in base]
+    for s in range(S):
+        xd[s] = bd[s % 4] * float(gains[s])
+    yd = torch.empty((S, F * 512), dtype=torch.float32, device="cuda")
+    bf.process_device(xd.data_ptr(), F, yd.data_ptr())
+    torch.cuda.synchronize()
+    for s in (0, 101, 255):
+        y_ref = oracle.OracleNode(p).process((base[s % 4] * gains[s]).astype(np.float32))[0]
+        y = yd[s].cpu().numpy()
+        assert np.isfinite(y).all()
+        assert rel_l2(y, y_ref) < TOL_TIME
