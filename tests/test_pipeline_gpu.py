@@ -117,7 +117,7 @@ def windows_vs_oracle(p, x, y, n_windows=6, warm=14, span=6, seed=0):
     return worst
 
 
-@pytest.mark.parametrize("algo,M,interf,F", [("mvdr", 8, (), 65536), ("lcmv", 16, (-60.0, 90.0, 150.0), 8192)])
+@pytest.mark.parametrize("algo,M,interf,F", [("mvdr", 8, (), 65536), ("lcmv", 16, (-60.0, 90.0, 150.0), 32768)])
 def test_mvdr_lcmv_full_size_windows(algo, M, interf, F):
     """BASELINE configs 3 and 5 (per-GPU shard scaled to the test budget): random windows of the big
     batch against the oracle, plus chunk independence."""
