@@ -61,6 +61,7 @@ struct bf_handle {
     // staging for the host-buffer entry points
     float *d_x = nullptr, *d_y = nullptr;
     size_t d_x_cap = 0, d_y_cap = 0;
+    float *h_pin = nullptr;  // pinned [n_mics*hop | n_out*hop]: bf_process_hop stages through it (no pageable-copy detour)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -372,6 +373,7 @@ void bf_destroy(bf_handle *h) {
     if (h->d_sumsq) (void)hipFree(h->d_sumsq);
     if (h->d_x) (void)hipFree(h->d_x);
     if (h->d_y) (void)hipFree(h->d_y);
+    if (h->h_pin) (void)hipHostFree(h->h_pin);
     delete h->pipe;
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -516,18 +518,21 @@ int bf_process_hop(bf_handle *h, const float *const *in, float *out, uint32_t nf
     BF_HIP(h, hipSetDevice(h->device));
     int rc = ensure_staging(h, (size_t)h->M * h->H, (size_t)h->n_out * h->H);
     if (rc != BF_OK) return rc;
-    std::vector<float> packed((size_t)h->M * h->H);
+    const size_t n_in = (size_t)h->M * h->H, n_outv = (size_t)h->n_out * h->H;
+    if (!h->h_pin) BF_HIP(h, hipHostMalloc((void **)&h->h_pin, (n_in + n_outv) * sizeof(float), hipHostMallocDefault));
+    float *packed = h->h_pin, *res = h->h_pin + n_in;
     if (h->cfg.layout == BF_PLANAR) {
-        for (int m = 0; m < h->M; ++m) memcpy(packed.data() + (size_t)m * h->H, in[m], sizeof(float) * h->H);
+        for (int m = 0; m < h->M; ++m) memcpy(packed + (size_t)m * h->H, in[m], sizeof(float) * h->H);
     } else {
         for (int m = 0; m < h->M; ++m)
             for (int n = 0; n < h->H; ++n) packed[(size_t)n * h->M + m] = in[m][n];
     }
-    BF_HIP(h, hipMemcpyAsync(h->d_x, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    BF_HIP(h, hipMemcpyAsync(h->d_x, packed, n_in * sizeof(float), hipMemcpyHostToDevice, h->stream));
     rc = run_batch_device(h, h->d_x, 1, h->d_y, nullptr, h->stream, h->cfg.layout, (long)h->H);
     if (rc != BF_OK) return rc;
-    BF_HIP(h, hipMemcpyAsync(out, h->d_y, sizeof(float) * h->n_out * h->H, hipMemcpyDeviceToHost, h->stream));  // [dir][hop]
+    BF_HIP(h, hipMemcpyAsync(res, h->d_y, n_outv * sizeof(float), hipMemcpyDeviceToHost, h->stream));  // [dir][hop]
     BF_HIP(h, hipStreamSynchronize(h->stream));
+    memcpy(out, res, n_outv * sizeof(float));
     return BF_OK;
 }
 
