@@ -235,26 +235,53 @@ __global__ __launch_bounds__(kIstftBlock) void istft_kernel(IstftArgs a, int pai
         // Two frames share one complex IFFT (Ya + i*Yb -> re = frame a, im = frame b).  A frame the
         // reference turns into NaN/Inf (mvdr/lcmv: inverse of an all-zero covariance) would
         // poison its partner through the shared transform, so such pairs are transformed one at a time.
-        bool bad = false;
+        // Hermitian extension of both rows straight into Ya + i*Yb.  Position i holds bin k = lane + 32*brev5(i): even i
+        // are bins < 512 (the stored row), odd i are bins >= 512 (conjugate of row[1024 - k]); only three positions touch
+        // the irregular bins 0 / 511 / 512 / 513 (quirk Q1), so the rest is branch-free.
+        auto load_pair = [&](bool useA, bool useB) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const int k = lane + 32 * brev5(i);
-            const cd u = herm_at(ra, k), v = herm_at(rb, k);
-            bad = bad || (va && !(isfinite(u.x) && isfinite(u.y))) || (vb && !(isfinite(v.x) && isfinite(v.y)));
-        }
+            for (int i = 0; i < 32; ++i) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int kb = 32 * brev5(i);
+                cd u{0, 0}, v{0, 0};
+                if (kb < 512) {
+                    if (useA) u = ld(ra + kb + lane);
+                    if (useB) v = ld(rb + kb + lane);
+                } else {
+                    if (useA) u = conj(ld(ra + (kN - kb) - lane));
+                    if (useB) v = conj(ld(rb + (kN - kb) - lane));
+                }
+                if (i == 0 && lane == 0) {  // bin 0: real part only
+                    u.y = 0.0;
+                    v.y = 0.0;
+                }
+                if (i == 1) {  // bins 512 (lane 0: real part only) and 513 (lane 1: (Y[513] + conj Y[511]) / 2)
+                    if (lane == 0) {
+                        u.y = 0.0;
+                        v.y = 0.0;
+                    } else if (lane == 1) {
+                        if (useA) u = (ld(ra + 513) + u) * 0.5;
+                        if (useB) v = (ld(rb + 513) + v) * 0.5;
+                    }
+                }
+                if (i == 30 && lane == 31) {  // bin 511: (Y[511] + conj Y[513]) / 2
+                    if (useA) u = (u + conj(ld(ra + 513))) * 0.5;
+                    if (useB) v = (v + conj(ld(rb + 513))) * 0.5;
+                }
+                re[i] = u.x - v.y;  // Ya + i*Yb
+                im[i] = u.y + v.x;
+            }
+        };
+        load_pair(va, vb);
+        bool bad = false;  // a non-finite value in either frame makes the combination non-finite
+#pragma unroll
+        for (int i = 0; i < 32; ++i) bad = bad || !(isfinite(re[i]) && isfinite(im[i]));
         const bool split = __any(bad ? 1 : 0) != 0;
         for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
             const bool useA = va && (!split || pass == 0);
             const bool useB = vb && (!split || pass == 1);
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const int k = lane + 32 * brev5(i);
-                cd u = herm_at(ra, k), v = herm_at(rb, k);
-                if (!useA) u = cd{0, 0};
-                if (!useB) v = cd{0, 0};
-                re[i] = u.x - v.y;  // Ya + i*Yb
-                im[i] = u.y + v.x;
-            }
+            if (split) load_pair(useA, useB);  // rare: one frame at a time
             fft1024p_inv_A<double>(re, im, lane, s_tw, pbuf);
             __builtin_amdgcn_wave_barrier();
             fft1024p_B<double>(re, lane, pbuf);
