@@ -514,9 +514,9 @@ __global__ void smooth_state_kernel(const float *yraw, double *state, long n, in
 template <int MP>
 __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, int tiles_per_stream) {
     constexpr int NT = MP * (MP + 1) / 2;
-    const int q = blockIdx.x * 64 + threadIdx.x;
-    const int s = blockIdx.y / tiles_per_stream;
-    const long tA = (long)(blockIdx.y % tiles_per_stream) * tile;
+    const int q = blockIdx.y * 64 + threadIdx.x;
+    const int s = blockIdx.x / tiles_per_stream;
+    const long tA = (long)(blockIdx.x % tiles_per_stream) * tile;
     long tB = tA + tile;
     if (tB > a.n_frames) tB = a.n_frames;
     const int M = a.n_mics, NP = (M + 1) >> 1, P = a.cfg.past_windows;
@@ -702,10 +702,10 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
 
     const int grp = threadIdx.x / MP;
     const int i = threadIdx.x % MP;
-    const int q = blockIdx.x * GPB + grp;
+    const int q = blockIdx.y * GPB + grp;
     if (q >= kNQ) return;
-    const int s = blockIdx.y / tiles_per_stream;
-    const long tA = (long)(blockIdx.y % tiles_per_stream) * tile;
+    const int s = blockIdx.x / tiles_per_stream;
+    const long tA = (long)(blockIdx.x % tiles_per_stream) * tile;
     long tB = tA + tile;
     if (tB > a.n_frames) tB = a.n_frames;
     const int M = a.n_mics, NP = (M + 1) >> 1, KP1 = a.kp1, P = a.cfg.past_windows;
@@ -955,9 +955,9 @@ __global__ __launch_bounds__(64, 1) void mvdr_lcmv_lanes_kernel(BinsArgs a, int 
     __shared__ __attribute__((aligned(16))) f64x2 s_R[NT][64];  // R rows of this lane: s_R[TIX(r, c)][lane]
     const int lane = threadIdx.x;
     const int q = lane % L;
-    const int pq = blockIdx.x * PPW + lane / L;  // problem (bin) index
-    const int s = blockIdx.y / tiles_per_stream;
-    const long tA = (long)(blockIdx.y % tiles_per_stream) * tile;
+    const int pq = blockIdx.y * PPW + lane / L;  // problem (bin) index
+    const int s = blockIdx.x / tiles_per_stream;
+    const long tA = (long)(blockIdx.x % tiles_per_stream) * tile;
     long tB = tA + tile;
     if (tB > a.n_frames) tB = a.n_frames;
     const int M = a.n_mics, NP = (M + 1) >> 1, KP1 = a.kp1, P = a.cfg.past_windows;
@@ -1210,10 +1210,10 @@ __global__ __launch_bounds__(256, 2) void mvdr_lcmv_row_kernel(BinsArgs a, int t
     constexpr int NG = GramIdx<KM>::NG, NE = GramIdx<KM>::NE;
     const int grp = threadIdx.x / MP;
     const int i = threadIdx.x % MP;
-    const int q = blockIdx.x * GPB + grp;
+    const int q = blockIdx.y * GPB + grp;
     if (q >= kNQ) return;
-    const int s = blockIdx.y / tiles_per_stream;
-    const long tA = (long)(blockIdx.y % tiles_per_stream) * tile;
+    const int s = blockIdx.x / tiles_per_stream;
+    const long tA = (long)(blockIdx.x % tiles_per_stream) * tile;
     long tB = tA + tile;
     if (tB > a.n_frames) tB = a.n_frames;
     const int M = a.n_mics, NP = (M + 1) >> 1, KP1 = a.kp1, P = a.cfg.past_windows;
@@ -1373,7 +1373,7 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
     static const bool no_fast = getenv("BF_MVDR_GROUP") && atoi(getenv("BF_MVDR_GROUP")) != 0;
     // lcmv with 9..16 microphones: one problem per DPP row, row_newbcast exchange (34.2 -> 27.6 ms per 32 768 frames at 16)
     if (!no_fast && a.cfg.algo == BF_LCMV && M > 8) {
-        const dim3 grid((kNQ + 15) / 16, tps * a.n_streams);
+        const dim3 grid(tps * a.n_streams, (kNQ + 15) / 16);  // x: tile * stream (can exceed 65535), y: bin blocks
         if (km == 1)
             hipLaunchKernelGGL((mvdr_lcmv_row_kernel<1>), grid, dim3(256), 0, s, a, tile, tps);
         else
@@ -1388,13 +1388,13 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
         if (a.n_frames < lt) lt = (int)a.n_frames;
         const int ltps = (int)((a.n_frames + lt - 1) / lt);
         if (M <= 4) {
-            const dim3 grid((kNQ + 31) / 32, ltps * a.n_streams);
+            const dim3 grid(ltps * a.n_streams, (kNQ + 31) / 32);  // x: tile * stream (can exceed 65535), y: bin blocks
             hipLaunchKernelGGL((mvdr_lcmv_lanes_kernel<4, 2, 4>), grid, dim3(64), 0, s, a, lt, ltps);
         } else if (M <= 8) {
-            const dim3 grid((kNQ + 31) / 32, ltps * a.n_streams);
+            const dim3 grid(ltps * a.n_streams, (kNQ + 31) / 32);  // x: tile * stream (can exceed 65535), y: bin blocks
             hipLaunchKernelGGL((mvdr_lcmv_lanes_kernel<8, 2, 4>), grid, dim3(64), 0, s, a, lt, ltps);
         } else {
-            const dim3 grid((kNQ + 15) / 16, ltps * a.n_streams);
+            const dim3 grid(ltps * a.n_streams, (kNQ + 15) / 16);  // x: tile * stream (can exceed 65535), y: bin blocks
             hipLaunchKernelGGL((mvdr_lcmv_lanes_kernel<16, 4, 1>), grid, dim3(64), 0, s, a, lt, ltps);
         }
         return hipGetLastError();
@@ -1403,7 +1403,7 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
         int ft = 32;
         if (a.n_frames < ft) ft = (int)a.n_frames;
         const int ftps = (int)((a.n_frames + ft - 1) / ft);
-        const dim3 grid((kNQ + 63) / 64, ftps * a.n_streams);
+        const dim3 grid(ftps * a.n_streams, (kNQ + 63) / 64);  // x: tile * stream (can exceed 65535), y: bin blocks
         if (M <= 4)
             hipLaunchKernelGGL((mvdr_fast_kernel<4>), grid, dim3(64), 0, s, a, ft, ftps);
         else
@@ -1411,7 +1411,7 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
         return hipGetLastError();
     }
 #define BF_LAUNCH_ML(MP_, KM_)                                                                                   \
-    hipLaunchKernelGGL((mvdr_lcmv_kernel<MP_, KM_>), dim3((kNQ + (256 / MP_) - 1) / (256 / MP_), tps * a.n_streams), \
+    hipLaunchKernelGGL((mvdr_lcmv_kernel<MP_, KM_>), dim3(tps * a.n_streams, (kNQ + (256 / MP_) - 1) / (256 / MP_)), \
                        dim3(256), 0, s, a, tile, tps)
     if (M <= 4) {
         if (km == 1) BF_LAUNCH_ML(4, 1); else BF_LAUNCH_ML(4, 4);

@@ -142,3 +142,20 @@ def test_maximum_look_directions():
     assert y.shape == (D, F * 512)
     for d in (0, 17, 40, 63):
         assert rel_l2(y[d], oracle.OracleNode(dict(p, theta=thetas[d])).process(x)[0]) < TOL
+
+
+def test_mvdr_many_streams_times_tiles_exceeds_65535_blocks():
+    """tiles x streams goes into grid.x (2^31-1), not grid.y (65535): 40 streams x 2048-frame batches = 2560 tile-streams
+    here; the launch geometry is the same code path as 64 streams x 65536 frames = 131072."""
+    import oracle
+    from beamform_amd.capi import Beamformer
+    _torch()
+    M, S, F = 4, 40, 96
+    p = make_params("mvdr", n_mics=M, theta=10.0)
+    xs = np.stack([make_scene(M, F, seed=300 + (s % 3)) * (0.5 + 0.5 * s / S) for s in range(S)]).astype(np.float32)
+    y = Beamformer(p, n_streams=S).process(xs)
+    for s in (0, 17, 39):
+        y_ref = oracle.OracleNode(p).process(xs[s])[0]
+        ok = np.isfinite(y_ref)
+        assert (np.isfinite(y[s]) == ok).all()
+        assert rel_l2(y[s][ok], y_ref[ok]) < TOL
