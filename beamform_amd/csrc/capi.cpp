@@ -255,8 +255,8 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
     if (cfg->hop != 512) return fail(nullptr, BF_ENOSYS, "only hop 512 (fft_win 1024) is built");
     if (cfg->n_streams < 1) return fail(nullptr, BF_EINVAL, "n_streams < 1");
     if (cfg->n_dirs < 0 || cfg->n_dirs > BF_MAX_DIRS) return fail(nullptr, BF_EINVAL, "n_dirs out of range");
-    if (cfg->n_dirs > 1 && !(cfg->algo == BF_DAS || cfg->algo == BF_PHASE || cfg->algo == BF_MVDR || cfg->algo == BF_LCMV))
-        return fail(nullptr, BF_ENOSYS, "look-direction batches are built for das, phase, mvdr and lcmv");
+    if (cfg->n_dirs > 1 && (cfg->algo == BF_MCRA || cfg->algo == BF_GSC))
+        return fail(nullptr, BF_ENOSYS, "look-direction batches: mcra has no look direction, gsc is not built for them");
     if (cfg->n_interf < 0 || cfg->n_interf > BF_MAX_INTERF) return fail(nullptr, BF_EINVAL, "n_interf out of range");
     if (cfg->layout != BF_PLANAR && cfg->layout != BF_INTERLEAVED) return fail(nullptr, BF_EINVAL, "layout");
     int ndev = bf_device_count();
@@ -405,7 +405,7 @@ int bf_set_theta_dir(bf_handle *h, int dir, double degrees) {
     std::lock_guard<std::mutex> lk(h->mu);
     h->angle[dir] = degrees;
     rebuild_steering(h, false, dir);
-    if (h->pipe) h->pipe->on_theta_changed();  // gss resets its demixing matrices (gss.cpp:90-93)
+    if (h->pipe) h->pipe->on_theta_changed(dir);  // gss resets that beam's demixing matrices (gss.cpp:90-93)
     return BF_OK;
 }
 
@@ -418,8 +418,8 @@ int bf_set_thetas(bf_handle *h, const double *degrees, int n) {
     for (int d = 0; d < n; ++d) {
         h->angle[d] = degrees[d];
         rebuild_steering(h, false, d);
+        if (h->pipe) h->pipe->on_theta_changed(d);
     }
-    if (h->pipe) h->pipe->on_theta_changed();
     return BF_OK;
 }
 

@@ -109,7 +109,7 @@ class BinPipelineImpl : public BinPipeline {
         if (d_mpf_) PIPE_HIP(hipMemset(d_mpf_, 0, mpf_bytes()));          // phasempf.cpp:535-545, current_L=0/first_L
         if (d_smooth_) PIPE_HIP(hipMemset(d_smooth_, 0, smooth_bytes())); // calloc past_samples (phasempf.cpp:510)
         if (d_nlms_) PIPE_HIP(hipMemset(d_nlms_, 0, nlms_bytes()));       // calloc block_matrix/filter/last_outputs (gsc.cpp:278-285)
-        gss_reset_pending_ = true;  // sep_matrix = weights^H (gss.cpp:90-93), done on the stream at next run
+        gss_reset_mask_ = ~0ull;  // sep_matrix = weights^H (gss.cpp:90-93), done on the stream at next run
         return BF_OK;
     }
 
@@ -132,10 +132,10 @@ class BinPipelineImpl : public BinPipeline {
         return BF_OK;
     }
 
-    void on_theta_changed() override { gss_reset_pending_ = true; }
+    void on_theta_changed(int dir) override { gss_reset_mask_ |= dir < 0 ? ~0ull : (1ull << dir); }
     void set_columns(int kp1) override {
         KP1_ = kp1;
-        gss_reset_pending_ = true;
+        gss_reset_mask_ = ~0ull;
     }
 
     int run(const float *x, long F, float *y, f64x2 *spectrum, hipStream_t stream, int layout, long mic_stride) override;
@@ -149,11 +149,12 @@ class BinPipelineImpl : public BinPipeline {
 
    private:
     size_t zhist_bytes() const { return Phist_ ? (size_t)S_ * Phist_ * NP_ * 1024 * sizeof(f64x2) : 0; }
-    size_t gss_bytes() const { return cfg_.algo == BF_GSS ? (size_t)S_ * 1024 * kMaxCols * M_ * sizeof(f64x2) : 0; }
+    // recursive per-beam state is sized by OUTPUT streams (input streams x look directions)
+    size_t gss_bytes() const { return cfg_.algo == BF_GSS ? (size_t)So_ * 1024 * kMaxCols * M_ * sizeof(f64x2) : 0; }
     size_t mpf_bytes() const {
-        return (cfg_.algo == BF_PHASEMPF || cfg_.algo == BF_MCRA) ? (size_t)S_ * (kMpfVecs * 1024 + 8) * sizeof(double) : 0;
+        return (cfg_.algo == BF_PHASEMPF || cfg_.algo == BF_MCRA) ? (size_t)So_ * (kMpfVecs * 1024 + 8) * sizeof(double) : 0;
     }
-    size_t smooth_bytes() const { return cfg_.algo == BF_PHASEMPF ? (size_t)S_ * 64 * sizeof(double) : 0; }
+    size_t smooth_bytes() const { return cfg_.algo == BF_PHASEMPF ? (size_t)So_ * 64 * sizeof(double) : 0; }
     size_t nlms_bytes() const {
         return cfg_.algo == BF_GSC ? (size_t)S_ * (2 * (M_ - 1) + 1) * cfg_.gsc_filter_size * sizeof(float) : 0;
     }
@@ -171,7 +172,7 @@ class BinPipelineImpl : public BinPipeline {
                 PIPE_HIP(hipMemcpy(s.d, p, s.n, hipMemcpyHostToDevice));
             p += s.n;
         }
-        if (!to_host) gss_reset_pending_ = false;
+        if (!to_host) gss_reset_mask_ = 0;
         return BF_OK;
     }
 
@@ -208,7 +209,7 @@ class BinPipelineImpl : public BinPipeline {
     double *d_mpf_ = nullptr;    // [stream][kMpfVecs*1024 + 8]
     double *d_smooth_ = nullptr; // [stream][64]
     float *d_nlms_ = nullptr;    // gsc: [stream][(2(M-1)+1) * filter_size]
-    bool gss_reset_pending_ = true;
+    unsigned long long gss_reset_mask_ = ~0ull;  // look directions whose demixing matrices restart at the next run
     // workspaces (grown on demand)
     f64x2 *d_Z_ = nullptr;   size_t Z_cap_ = 0;   // [stream][Phist+F][NP][1024]
     f64x2 *d_Yh_ = nullptr;  size_t Yh_cap_ = 0;  // [stream][F][kYhStride]
@@ -271,9 +272,9 @@ int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipS
     ba.Z = d_Z_; ba.Yh = d_Yh_; ba.spectrum = spectrum; ba.steer = d_steer_[steer_cur_]; ba.freqs = d_freq_;
     ba.n_frames = F; ba.frames_ws = FT; ba.frame_off = Phist_; ba.n_streams = So_; ba.n_mics = MF_; ba.kp1 = KP1_;
     ba.n_dirs = D_; ba.steer_dir_stride = steer_dir_stride_;
-    ba.cfg = cfg_; ba.gssW = d_gssW_; ba.mpf = d_mpf_; ba.gss_reset = gss_reset_pending_ ? 1 : 0;
+    ba.cfg = cfg_; ba.gssW = d_gssW_; ba.mpf = d_mpf_; ba.gss_reset_mask = gss_reset_mask_;
     PIPE_HIP(launch_bins(ba, n_cus_, stream));
-    gss_reset_pending_ = false;
+    gss_reset_mask_ = 0;
 
     if (Phist_ > 0)  // keep the last Phist frames' spectra for the next call
         PIPE_HIP(hipMemcpy2DAsync(d_zhist_, (size_t)Phist_ * frame_elems * sizeof(f64x2), d_Z_ + (size_t)F * frame_elems,
@@ -289,7 +290,7 @@ int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipS
     tail_cur_ ^= 1;
 
     if (cfg_.algo == BF_PHASEMPF)
-        PIPE_HIP(launch_smooth(d_yraw_, y, d_smooth_, F, S_, cfg_.smooth_size, stream));
+        PIPE_HIP(launch_smooth(d_yraw_, y, d_smooth_, F, So_, cfg_.smooth_size, stream));
     if (cfg_.algo == BF_GSC)
         PIPE_HIP(launch_gsc_nlms(d_yraw_, y, d_nlms_, F * 512, S_, M_, cfg_, stream));
     return BF_OK;

@@ -22,7 +22,7 @@ class BinPipeline {
     virtual int init() = 0;
     virtual int reset() = 0;
     virtual int upload_steering(const std::vector<SteeringSet> &dirs, hipStream_t stream) = 0;  // one set per look direction
-    virtual void on_theta_changed() = 0;
+    virtual void on_theta_changed(int dir = -1) = 0;  // dir < 0: every look direction
     virtual void set_columns(int kp1) = 0;  // interferer added/removed (lcmv.cpp:266-305)
     virtual int run(const float *x_dev, long n_frames, float *y_dev, f64x2 *spectrum_dev, hipStream_t stream, int layout,
                     long mic_stride) = 0;

@@ -1441,7 +1441,8 @@ __global__ __launch_bounds__(256) void mpf_mask_kernel(BinsArgs a, double *aux) 
     const long t = st % a.n_frames;
     const int s = (int)(st / a.n_frames);
     const int M = a.n_mics, NP = (M + 1) >> 1;
-    const f64x2 *Zf = a.Z + (((long)s * a.frames_ws + a.frame_off + t) * NP) * kN;
+    const f64x2 *Zf = a.Z + (((long)(s / a.n_dirs) * a.frames_ws + a.frame_off + t) * NP) * kN;
+    const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
     cd X[MP];
     load_X<MP>(Zf, q, M, X);
     const int j = q_bin(q);
@@ -1456,7 +1457,7 @@ __global__ __launch_bounds__(256) void mpf_mask_kernel(BinsArgs a, double *aux) 
 #pragma unroll
     for (int m = 0; m < MP; ++m) {
         if (m < M) {
-            const cd u = conj(ld(a.steer + (long)m * kN + j)) * X[m];
+            const cd u = conj(ld(steer + (long)m * kN + j)) * X[m];
             ph[m] = atan2(u.y, u.x);
             mag += cabs(X[m]);
         } else {
@@ -1862,7 +1863,8 @@ __global__ __launch_bounds__(256) void gss_kernel(BinsArgs a) {
     const int j = q_bin(q);
     const int M = a.n_mics, NP = (M + 1) >> 1, S = a.kp1;
     f64x2 *yout = a.Yh + ((long)s * a.n_frames) * kYhStride + q;
-    const f64x2 *Zs = a.Z + ((long)s * a.frames_ws + a.frame_off) * NP * kN;
+    const f64x2 *Zs = a.Z + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
+    const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
     const double f = fabs(a.freqs[j]);
     const bool inband = f >= a.cfg.freq_min && f <= a.cfg.freq_max;
     if (!inband) {
@@ -1875,8 +1877,8 @@ __global__ __launch_bounds__(256) void gss_kernel(BinsArgs a) {
     f64x2 *Wg = a.gssW + (((long)s * kN + j) * S) * M;
 #pragma unroll
     for (int r = 0; r < KM; ++r) {
-        C[r] = (r < S && m < M) ? ld(a.steer + ((long)r * M + m) * kN + j) : cd{0, 0};
-        if (a.gss_reset)
+        C[r] = (r < S && m < M) ? ld(steer + ((long)r * M + m) * kN + j) : cd{0, 0};
+        if ((a.gss_reset_mask >> (s % a.n_dirs)) & 1ull)
             W[r] = conj(C[r]);  // sep_matrix[j] = weights[j].adjoint() (gss.cpp:92)
         else
             W[r] = (r < S && m < M) ? ld(Wg + (long)r * M + m) : cd{0, 0};

@@ -42,7 +42,7 @@ struct BinsArgs {
     bf_config cfg;
     f64x2 *gssW;         // [stream][1024][kp1][n_mics]
     double *mpf;         // [stream][kMpfVecs*1024 + 8] (the mcra node uses vectors 0..3 and the two scalars)
-    int gss_reset;
+    unsigned long long gss_reset_mask;  // bit d: look direction d re-initialises W = C^H (gss.cpp:90-93) in this batch
 };
 hipError_t launch_bins(const BinsArgs &a, int n_cus, hipStream_t s);
 

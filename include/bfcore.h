@@ -104,9 +104,9 @@ typedef struct bf_config {
     int layout;                    /* enum bf_layout for bf_process_batch* input */
     int das_impl;                  /* enum bf_das_impl */
     int n_dirs;                    /* look directions evaluated per input stream from the SAME samples (0/1 = one, the
-                                      reference node).  Output stream index = stream * n_dirs + dir.  das, phase, mvdr,
-                                      lcmv only (their state does not depend on the direction); SURVEY 8(e) "look
-                                      directions" / 8(f) row 4 */
+                                      reference node).  Output stream index = stream * n_dirs + dir.  Every node except mcra
+                                      (no look direction) and gsc; gss / phasempf keep their recursive state per beam.
+                                      SURVEY 8(e) "look directions" / 8(f) row 4 */
     /* gsc (gsc.cpp:199-256, launch/gsc.launch:6-11); write_mu is file I/O and not part of the path */
     int gsc_use_vad;
     double gsc_vad_threshold, gsc_mu0, gsc_mu_max;

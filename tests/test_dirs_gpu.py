@@ -101,14 +101,26 @@ def test_bin_pipeline_look_directions(algo, M, interf, F):
         check_dir(y[d], Y[d], y_ref, Y_ref, hermitian=False)
 
 
-@pytest.mark.parametrize("algo", ["das", "mvdr"])
+@pytest.mark.parametrize("algo,M,interf,F", [("phasempf", 8, (), 60), ("gss", 8, (-60.0, 90.0), 40), ("gss", 4, (), 30)])
+def test_recursive_nodes_keep_their_state_per_beam(algo, M, interf, F):
+    """gss and phasempf recurse on their own output: every beam carries its own demixing matrices / noise estimates."""
+    thetas = [20.0, -35.0, 110.0]
+    p = make_params(algo, n_mics=M, interf=interf)
+    x = make_scene(M, F, seed=1300 + M)
+    _, y, Y, _ = run_dirs(p, x, thetas)
+    for d, th in enumerate(thetas):
+        y_ref, Y_ref = oracle_dir(p, x, th)
+        check_dir(y[d], Y[d], y_ref, Y_ref, hermitian=False)
+
+
+@pytest.mark.parametrize("algo", ["das", "mvdr", "gss"])
 def test_directions_retarget_between_batches(algo):
     """bf_set_theta_dir between batches == set_theta on that direction's reference node; the others are untouched."""
     import oracle
     from beamform_amd.capi import Beamformer
     _torch()
     M, F = 8, 30
-    p = make_params(algo, n_mics=M)
+    p = make_params(algo, n_mics=M, interf=(-60.0,) if algo == "gss" else ())
     x = make_scene(M, F, seed=77)
     thetas = [0.0, 50.0]
     nodes = [oracle.OracleNode(dict(p, theta=t)) for t in thetas]
@@ -155,10 +167,10 @@ def test_hop_by_hop_with_directions_and_checkpoint():
         assert rel_l2(y[d], oracle_dir(p, x, th)[0]) < TOL_TIME
 
 
-def test_directions_rejected_for_recursive_nodes():
+def test_directions_rejected_where_meaningless():
     from beamform_amd.capi import Beamformer, BfError
     _torch()
-    for algo in ("gss", "phasempf", "mcra"):
+    for algo in ("mcra", "gsc"):
         with pytest.raises(BfError) as e:
             Beamformer(make_params(algo, n_mics=4), n_dirs=2)
         assert e.value.code == -38  # BF_ENOSYS
