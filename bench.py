@@ -111,6 +111,8 @@ def main():
     one_dev = os.environ.get("BF_BENCH_ONE_DEVICE", "0") == "1"
     if one_dev:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():  # launcher narrowed the visible devices per rank (HIP_VISIBLE_DEVICES)
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
