@@ -6,7 +6,8 @@ SRC := beamform_amd/csrc
 OBJ := build/obj
 LIB := beamform_amd/lib/libbfcore.so
 
-HIP_SRCS := $(SRC)/das_fused.hip $(SRC)/das_fused_w64.hip $(SRC)/pipeline.hip $(SRC)/pipeline_kernels.hip
+HIP_SRCS := $(SRC)/das_fused.hip $(SRC)/das_fused_w64.hip $(SRC)/pipeline.hip $(SRC)/pipeline_kernels.hip \
+            $(SRC)/stft_istft.hip $(SRC)/mask_kernels.hip $(SRC)/cov_kernels.hip $(SRC)/gsc_gss_kernels.hip
 CPP_SRCS := $(SRC)/capi.cpp $(SRC)/config.cpp
 OBJS := $(patsubst $(SRC)/%.hip,$(OBJ)/%.o,$(HIP_SRCS)) $(patsubst $(SRC)/%.cpp,$(OBJ)/%.o,$(CPP_SRCS))
 HDRS := $(wildcard $(SRC)/*.hpp) include/bfcore.h

@@ -1,0 +1,944 @@
+// cov_kernels.hip -- mvdr / lcmv: sliding per-bin covariance + Cholesky-based constrained solve, four mappings of a problem
+// onto lanes (thread-per-problem, row-per-lane over LDS, cyclic rows over DPP quads, row-per-lane over DPP rows).
+#include "bins_common.hpp"
+
+namespace bf {
+
+namespace {
+
+// ======================================================================================
+//                     mvdr / lcmv: covariance, Cholesky solve, constraints
+// ======================================================================================
+// One group of MP lanes per (stream, bin) problem, lane i <-> microphone i; the group walks a
+// tile of consecutive frames so the sample covariance of the previous P frames
+//   R = past_ffts[j] * past_ffts[j]^H                     (mvdr.cpp:87, lcmv.cpp:112)
+// is slid by one rank-1 update and one downdate per frame (recomputed from scratch at the tile
+// start).  The reference inverts R o whiteR with PartialPivLU and forms
+//   mvdr:  w = R^-1 a / (a^H R^-1 a),   y = w^H x                     (mvdr.cpp:88-94)
+//   lcmv:  W = R^-1 C (C^H R^-1 C)^-1,  y = W(:,0)^H x                (lcmv.cpp:113-119)
+// R o whiteR is Hermitian positive definite whenever every mic has history energy, so with
+// R = L L^H, U = L^-1 [C | x]:   G = U_C^H U_C,  g = U_C^H u_x,  y = (G^-1 g)_0
+// (mvdr is the KP1 = 1 case: y = u_a^H u_x / u_a^H u_a).  Lane i owns row i of the
+// factorisation; columns are exchanged through LDS (one wavefront executes its LDS operations
+// in order, so only compiler barriers separate the phases).  A zero covariance (frame 0 of a
+// cold start) yields 0 * inf = NaN, the same NaN frame the reference emits.
+// ---- mvdr fast path: one thread per (stream, bin), whole problem in registers -----------------
+// For M <= 8 the lower triangle of R (36 complex) and of its working copy fit the 512-entry
+// register file of a wavefront that has a SIMD to itself (fp64 FMA issues every 4 cycles, so one
+// wavefront per SIMD already keeps the fp64 pipe busy).  Lanes are consecutive bins: spectra
+// loads are coalesced, no LDS, no idle lanes.  Same maths as mvdr_lcmv_kernel with KP1 = 1:
+//   R o whiteR = L L^H,  u = L^-1 a,  v = L^-1 x,  y = u^H v / u^H u.
+template <int MP>
+__global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, int tiles_per_stream) {
+    constexpr int NT = MP * (MP + 1) / 2;
+    const int q = blockIdx.y * 64 + threadIdx.x;
+    const int s = blockIdx.x / tiles_per_stream;
+    const long tA = (long)(blockIdx.x % tiles_per_stream) * tile;
+    long tB = tA + tile;
+    if (tB > a.n_frames) tB = a.n_frames;
+    const int M = a.n_mics, NP = (M + 1) >> 1, P = a.cfg.past_windows;
+    const bool live = q < kNQ;
+    const int qq = live ? q : kNQ - 1;
+    const int j = q_bin(qq);
+    const double f = fabs(a.freqs[j]);
+    const bool inband = live && f >= a.cfg.freq_min && f <= a.cfg.freq_max;
+    f64x2 *yout = a.Yh + ((long)s * a.n_frames) * kYhStride + qq;
+    const f64x2 *Zs = a.Z + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
+    const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
+    if (__builtin_amdgcn_ballot_w64(inband) == 0) {  // whole wavefront out of band (mvdr.cpp:103) or bin 0 (:76)
+        if (live)
+            for (long t = tA; t < tB; ++t) {
+                cd y{0, 0};
+                if (j == 0) {
+                    cd X[MP];
+                    load_X<MP>(Zs + t * NP * kN, qq, M, X);
+                    y = X[0];
+                }
+                yout[t * kYhStride] = f64x2{y.x, y.y};
+            }
+        return;
+    }
+    cd st[MP];
+#pragma unroll
+    for (int m = 0; m < MP; ++m) st[m] = (m < M) ? ld(steer + (long)m * kN + j) : cd{0, 0};
+
+    // Spectra are prefetched one frame ahead by global->LDS DMA (global_load_lds_dwordx4: no VGPRs, 1 KB per
+    // instruction, lane l lands at row base + 16 l): a wavefront that owns its SIMD has nobody to hide HBM latency
+    // behind, and the PMC profile of the register-only version showed 57 % of its cycles in s_waitcnt.
+    // Row 2p / 2p+1 = Z_t[p][k] / Z_t[p][N-k]; rows MP + 2p, MP + 2p + 1 = the same of frame t - P (leaving the window).
+    __shared__ __attribute__((aligned(16))) f64x2 s_pf[2][2 * MP][64];
+    const int lane = threadIdx.x;
+    const int ksrc = q_src_bin(qq), kneg = (kN - ksrc) & (kN - 1);
+    auto dma_frame = [&](long t, bool with_old, int buf) {
+        const f64x2 *Zn = Zs + t * NP * kN, *Zo = Zs + (t - P) * NP * kN;
+#pragma unroll
+        for (int p = 0; p < MP / 2; ++p)
+            if (2 * p < M) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Zn + p * kN + ksrc),
+                                                 (__attribute__((address_space(3))) void *)&s_pf[buf][2 * p][0], 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Zn + p * kN + kneg),
+                                                 (__attribute__((address_space(3))) void *)&s_pf[buf][2 * p + 1][0], 16, 0, 0);
+                if (with_old) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Zo + p * kN + ksrc),
+                                                     (__attribute__((address_space(3))) void *)&s_pf[buf][MP + 2 * p][0], 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Zo + p * kN + kneg),
+                                                     (__attribute__((address_space(3))) void *)&s_pf[buf][MP + 2 * p + 1][0], 16, 0, 0);
+                }
+            }
+    };
+    auto unpack = [&](int buf, int base, cd (&X)[MP]) {  // load_X out of the prefetched rows
+#pragma unroll
+        for (int p = 0; p < MP / 2; ++p) {
+            if (2 * p < M) {
+                const cd z = ld(&s_pf[buf][base + 2 * p][lane]);
+                const cd zc = conj(ld(&s_pf[buf][base + 2 * p + 1][lane]));
+                cd xa = (z + zc) * 0.5;
+                const cd d = z - zc;
+                cd xb = cd{0.5 * d.y, -0.5 * d.x};
+                if (qq == 513) {
+                    xa = conj(xa);
+                    xb = conj(xb);
+                }
+                X[2 * p] = xa;
+                X[2 * p + 1] = xb;
+            } else {
+                X[2 * p] = cd{0, 0};
+                X[2 * p + 1] = cd{0, 0};
+            }
+        }
+    };
+#define BF_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+    cd R[NT];  // lower triangle, row-major: R[i*(i+1)/2 + c], c <= i
+#pragma unroll
+    for (int e = 0; e < NT; ++e) R[e] = cd{0, 0};
+    int pb = 0;  // buffer the next consumer reads
+    dma_frame(tA - 1, false, pb);
+    for (int p = 1; p <= P; ++p) {  // covariance of the P frames in front of the tile
+        BF_DMA_WAIT();
+        __builtin_amdgcn_wave_barrier();
+        if (p < P)
+            dma_frame(tA - p - 1, false, pb ^ 1);
+        else
+            dma_frame(tA, true, pb ^ 1);  // first frame of the tile
+        cd X[MP];
+        unpack(pb, 0, X);
+#pragma unroll
+        for (int i = 0; i < MP; ++i)
+#pragma unroll
+            for (int c = 0; c <= i; ++c) R[i * (i + 1) / 2 + c] = cfma_conj(R[i * (i + 1) / 2 + c], X[i], X[c]);
+        pb ^= 1;
+    }
+    for (long t = tA; t < tB; ++t) {
+        BF_DMA_WAIT();  // frame t (and t - P) have landed in s_pf[pb]
+        __builtin_amdgcn_wave_barrier();
+        if (t + 1 < tB) dma_frame(t + 1, true, pb ^ 1);
+        cd X[MP];
+        unpack(pb, 0, X);
+        double mag = 0.0;
+#pragma unroll
+        for (int m = 0; m < MP; ++m)
+            if (m < M) mag += sqrt(norm2(X[m]));  // |X| well inside double range: no hypot scaling needed
+        mag /= (double)((unsigned)M * 1024u);
+        cd A[NT], ua[MP], ux[MP];
+#pragma unroll
+        for (int i = 0; i < MP; ++i) {
+#pragma unroll
+            for (int c = 0; c <= i; ++c) {
+                cd v = R[i * (i + 1) / 2 + c];
+                if (c == i) v = (i < M) ? v * 1.001 : cd{1.0, 0.0};  // whiteR diagonal (mvdr.cpp:239-243); padding = identity
+                A[i * (i + 1) / 2 + c] = v;
+            }
+            ua[i] = st[i];
+            ux[i] = X[i];
+        }
+#pragma unroll
+        for (int jj = 0; jj < MP; ++jj) {
+            const double inv = rsqrt(A[jj * (jj + 1) / 2 + jj].x);  // 1/L_jj; L_jj itself is never needed
+            ua[jj] = ua[jj] * inv;
+            ux[jj] = ux[jj] * inv;
+#pragma unroll
+            for (int i = jj + 1; i < MP; ++i) {
+                const cd Lij = A[i * (i + 1) / 2 + jj] * inv;
+                A[i * (i + 1) / 2 + jj] = Lij;
+                ua[i] = cfms(ua[i], Lij, ua[jj]);
+                ux[i] = cfms(ux[i], Lij, ux[jj]);
+            }
+#pragma unroll
+            for (int c = jj + 1; c < MP; ++c) {
+                const cd Lc = A[c * (c + 1) / 2 + jj];
+#pragma unroll
+                for (int i = c; i < MP; ++i)
+                    A[i * (i + 1) / 2 + c] = cfms_conj(A[i * (i + 1) / 2 + c], A[i * (i + 1) / 2 + jj], Lc);
+            }
+        }
+        cd num{0, 0};
+        double den = 0.0;
+#pragma unroll
+        for (int i = 0; i < MP; ++i) {
+            num = cfma_conj(num, ux[i], ua[i]);
+            den += norm2(ua[i]);
+        }
+        cd y = cd{num.x / den, num.y / den};
+        if (!(mag > a.cfg.freq_mag_threshold)) y = X[0] * 0.01;  // mvdr.cpp:96
+        if (!inband) y = cd{0, 0};
+        if (j == 0) y = X[0];
+        if (live) yout[t * kYhStride] = f64x2{y.x, y.y};
+        // slide the covariance window (mvdr.cpp:100-101)
+        cd Xo[MP];
+        unpack(pb, MP, Xo);
+#pragma unroll
+        for (int i = 0; i < MP; ++i)
+#pragma unroll
+            for (int c = 0; c <= i; ++c)
+                R[i * (i + 1) / 2 + c] = cfms_conj(cfma_conj(R[i * (i + 1) / 2 + c], X[i], X[c]), Xo[i], Xo[c]);
+        pb ^= 1;
+    }
+#undef BF_DMA_WAIT
+}
+
+template <int KM>
+struct GramIdx {  // entries of the Hermitian upper triangle of G followed by g
+    static constexpr int NG = KM * (KM + 1) / 2;
+    static constexpr int NE = NG + KM;
+};
+
+template <int MP, int KM>
+__global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, int tiles_per_stream) {
+    constexpr int GPB = 256 / MP;          // problem groups per block
+    constexpr int NB = KM + 1;             // right-hand sides: constraints + current frame
+    constexpr int NE = GramIdx<KM>::NE;
+    // +1 element of padding per row: the groups of a wavefront read the same [row][k] at the same time (broadcast
+    // inside a group), and with a group stride that is a multiple of 128 B all of them would hit the same 4 banks
+    // (PMC before the padding: SQ_LDS_BANK_CONFLICT = 1.7x SQ_ACTIVE_INST_LDS; lcmv 16-mic 37.5 -> 34.0 ms)
+    __shared__ cd s_col[GPB][MP + 1];
+    __shared__ cd s_x[GPB][MP + 1];
+    __shared__ cd s_xo[GPB][MP + 1];
+    __shared__ cd s_u[GPB][NB][MP + 1];
+    __shared__ cd s_e[GPB][NE + 1];
+
+    const int grp = threadIdx.x / MP;
+    const int i = threadIdx.x % MP;
+    const int q = blockIdx.y * GPB + grp;
+    if (q >= kNQ) return;
+    const int s = blockIdx.x / tiles_per_stream;
+    const long tA = (long)(blockIdx.x % tiles_per_stream) * tile;
+    long tB = tA + tile;
+    if (tB > a.n_frames) tB = a.n_frames;
+    const int M = a.n_mics, NP = (M + 1) >> 1, KP1 = a.kp1, P = a.cfg.past_windows;
+    const int j = q_bin(q);
+    const bool lcmv = a.cfg.algo == BF_LCMV;
+    f64x2 *yout = a.Yh + ((long)s * a.n_frames) * kYhStride + q;
+    const f64x2 *Zs = a.Z + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;  // frame 0 of this batch
+    const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
+
+    // one microphone's spectrum at this problem's bin, frame t (may be negative: history)
+    const int ksrc = q_src_bin(q), kneg = (kN - ksrc) & (kN - 1);
+    auto load_xi = [&](long t) -> cd {
+        if (i >= M) return cd{0, 0};
+        const f64x2 *Zf = Zs + t * NP * kN + (i >> 1) * kN;
+        const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
+        cd x;
+        if ((i & 1) == 0) {
+            x = (z + zc) * 0.5;
+        } else {
+            const cd d = z - zc;
+            x = cd{0.5 * d.y, -0.5 * d.x};
+        }
+        return q == 513 ? conj(x) : x;
+    };
+
+    const double f = fabs(a.freqs[j]);
+    const bool inband = f >= a.cfg.freq_min && f <= a.cfg.freq_max;
+    if (!inband || (!lcmv && j == 0)) {
+        // mvdr.cpp:76 y_fft[0] = in_fft(0,0); out of band: y_fft[j] = 0 (mvdr.cpp:103)
+        for (long t = tA; t < tB; ++t) {
+            cd y{0, 0};
+            if (!lcmv && j == 0) {
+                const cd x = load_xi(t);
+                s_x[grp][i] = x;
+                __builtin_amdgcn_wave_barrier();
+                y = s_x[grp][0];
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (i == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+        }
+        return;
+    }
+
+    cd cst[KM];  // this mic's entries of the constraint columns (weights[j](i, r))
+#pragma unroll
+    for (int r = 0; r < KM; ++r)
+        cst[r] = (r < KP1 && i < M) ? ld(steer + ((long)r * M + i) * kN + j) : cd{0, 0};
+
+    // R row i (lower triangle c <= i is what the factorisation reads)
+    cd R[MP];
+#pragma unroll
+    for (int c = 0; c < MP; ++c) R[c] = cd{0, 0};
+    for (int p = 1; p <= P; ++p) {
+        const cd x = load_xi(tA - p);
+        s_x[grp][i] = x;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < MP; ++c) R[c] = cfma_conj(R[c], x, s_x[grp][c]);
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    for (long t = tA; t < tB; ++t) {
+        const cd x = load_xi(t);
+        const cd xo = load_xi(t - P);
+        s_x[grp][i] = x;
+        s_xo[grp][i] = xo;
+        __builtin_amdgcn_wave_barrier();
+        double mag = 0.0;
+        for (int m = 0; m < M; ++m) mag += sqrt(norm2(s_x[grp][m]));
+        mag /= (double)((unsigned)M * 1024u);
+        cd y;
+        if (mag > a.cfg.freq_mag_threshold) {
+            cd A[MP], b[NB];
+#pragma unroll
+            for (int c = 0; c < MP; ++c) A[c] = R[c];
+            if (i < M) {
+                // cwiseProduct(whiteR): diagonal * 1.001 (mvdr.cpp:239-243)
+#pragma unroll
+                for (int c = 0; c < MP; ++c)
+                    if (c == i) A[c] = A[c] * 1.001;
+            } else {
+#pragma unroll
+                for (int c = 0; c < MP; ++c) A[c] = cd{c == i ? 1.0 : 0.0, 0.0};
+            }
+#pragma unroll
+            for (int r = 0; r < KM; ++r) b[r] = cst[r];
+            b[KM] = x;
+#pragma unroll
+            for (int jj = 0; jj < MP; ++jj) {
+                s_col[grp][i] = A[jj];  // raw column jj, row i
+                if (i == jj) {
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) s_u[grp][r][0] = b[r];
+                }
+                __builtin_amdgcn_wave_barrier();
+                const double inv = rsqrt(s_col[grp][jj].x);  // 1 / L_jj
+                const cd Lij = A[jj] * inv;
+                if (i > jj) {
+#pragma unroll
+                    for (int c = jj + 1; c < MP; ++c)
+                        if (c <= i) A[c] = cfms_conj(A[c], Lij, s_col[grp][c] * inv);
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) b[r] = cfms(b[r], Lij, s_u[grp][r][0] * inv);
+                } else if (i == jj) {
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) b[r] = b[r] * inv;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            // b[r] is now row i of U = L^-1 [C | x]
+#pragma unroll
+            for (int r = 0; r < NB; ++r) s_u[grp][r][i] = (i < M) ? b[r] : cd{0, 0};
+            __builtin_amdgcn_wave_barrier();
+            // Gram entries: e < NG: G(r,r2) with r <= r2; e >= NG: g(r)
+            for (int e = i; e < NE; e += MP) {
+                int r = 0, r2 = 0;
+                if (e < GramIdx<KM>::NG) {
+                    int rem = e;
+                    while (rem >= KM - r) { rem -= KM - r; ++r; }
+                    r2 = r + rem;
+                } else {
+                    r = e - GramIdx<KM>::NG;
+                    r2 = KM;
+                }
+                cd acc{0, 0};
+                for (int m = 0; m < M; ++m) acc = cfma_conj(acc, s_u[grp][r2][m], s_u[grp][r][m]);
+                s_e[grp][e] = acc;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // every lane solves the (KP1 x KP1) system G y = g redundantly; padding rows are identity
+            cd Gm[KM][KM], gv[KM];
+            {
+                int e = 0;
+#pragma unroll
+                for (int r = 0; r < KM; ++r)
+#pragma unroll
+                    for (int r2 = r; r2 < KM; ++r2) {
+                        const cd v = s_e[grp][e++];
+                        Gm[r][r2] = v;
+                        Gm[r2][r] = conj(v);
+                    }
+#pragma unroll
+                for (int r = 0; r < KM; ++r) gv[r] = s_e[grp][GramIdx<KM>::NG + r];
+#pragma unroll
+                for (int r = 0; r < KM; ++r)
+                    if (r >= KP1) {
+#pragma unroll
+                        for (int r2 = 0; r2 < KM; ++r2) {
+                            Gm[r][r2] = cd{r == r2 ? 1.0 : 0.0, 0.0};
+                            Gm[r2][r] = cd{r == r2 ? 1.0 : 0.0, 0.0};
+                        }
+                        gv[r] = cd{0, 0};
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < KM; ++k) {  // Gaussian elimination (G is Hermitian positive definite)
+                const cd pinv = cdiv(cd{1, 0}, Gm[k][k]);
+#pragma unroll
+                for (int r = k + 1; r < KM; ++r) {
+                    const cd fct = Gm[r][k] * pinv;
+#pragma unroll
+                    for (int c = k + 1; c < KM; ++c) Gm[r][c] = Gm[r][c] - fct * Gm[k][c];
+                    gv[r] = gv[r] - fct * gv[k];
+                }
+            }
+#pragma unroll
+            for (int k = KM - 1; k >= 0; --k) {
+                cd acc = gv[k];
+#pragma unroll
+                for (int c = k + 1; c < KM; ++c) acc = acc - Gm[k][c] * gv[c];
+                gv[k] = cdiv(acc, Gm[k][k]);
+            }
+            y = gv[0];
+        } else {
+            y = s_x[grp][0] * 0.01;  // in_fft(0,j)*0.01 (mvdr.cpp:96)
+        }
+        if (i == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+        // slide the covariance window: + x_t x_t^H - x_{t-P} x_{t-P}^H (mvdr.cpp:100-101)
+#pragma unroll
+        for (int c = 0; c < MP; ++c) R[c] = cfms_conj(cfma_conj(R[c], x, s_x[grp][c]), xo, s_xo[grp][c]);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+
+// ---- mvdr / lcmv "lanes" kernel: L lanes per problem, rows dealt cyclically, exchange by DPP -------------
+// For 9..16 microphones (and lcmv with up to 8) a problem does not fit one lane's registers.  Instead of one lane per
+// row (mvdr_lcmv_kernel: 16 lanes per problem, half of them idle on average, every column through LDS) lane q of an
+// L-lane group (L = 4 for M <= 16, 2 for M <= 8; a group never straddles a quad) owns rows i = r*L + q of R and of its
+// Cholesky factor.  Cyclic rows keep every lane busy until the last column, the column / pivot / right-hand-side
+// exchange is a quad_perm DPP broadcast, and a wavefront carries 64/L problems.  R (its stored rows: 40 complex per
+// lane at M = 16) lives in LDS, lane-contiguous, so the working copy and the right-hand sides fit the register file of
+// a wavefront that owns its SIMD.  Maths identical to mvdr_lcmv_kernel:
+//   R o whiteR = L L^H,  U = L^-1 [C | x],  G = U_C^H U_C,  g = U_C^H u_x,  y = (G^-1 g)_0.
+template <int L>
+struct LaneGrp;
+template <>
+struct LaneGrp<4> {
+    template <int SRC>
+    static __device__ __forceinline__ int bc(int v) { return __builtin_amdgcn_update_dpp(v, v, SRC * 0x55, 0xF, 0xF, false); }
+    static __device__ __forceinline__ int x1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false); }
+    static __device__ __forceinline__ int x2(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false); }
+};
+template <>
+struct LaneGrp<2> {
+    template <int SRC>
+    static __device__ __forceinline__ int bc(int v) {
+        return __builtin_amdgcn_update_dpp(v, v, SRC | (SRC << 2) | ((2 + SRC) << 4) | ((2 + SRC) << 6), 0xF, 0xF, false);
+    }
+    static __device__ __forceinline__ int x1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false); }
+    static __device__ __forceinline__ int x2(int v) { return v; }
+};
+template <int L, int SRC>
+__device__ __forceinline__ double bcast_d(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = LaneGrp<L>::template bc<SRC>((int)(b & 0xffffffffLL)), hi = LaneGrp<L>::template bc<SRC>((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <int L>
+__device__ __forceinline__ double bcast_from(int src, double v) {  // src is a compile-time constant after unrolling
+    if (L == 2) return src == 0 ? bcast_d<L, 0>(v) : bcast_d<L, 1>(v);
+    return src == 0 ? bcast_d<L, 0>(v) : src == 1 ? bcast_d<L, 1>(v) : src == 2 ? bcast_d<L, 2>(v) : bcast_d<L, 3>(v);
+}
+template <int L>
+__device__ __forceinline__ cd bcast_from(int src, cd v) { return cd{bcast_from<L>(src, v.x), bcast_from<L>(src, v.y)}; }
+template <int L>
+__device__ __forceinline__ double grp_sum(double v) {
+    auto sh = [](double x, bool second) {
+        const long long b = __builtin_bit_cast(long long, x);
+        const int lo = second ? LaneGrp<L>::x2((int)(b & 0xffffffffLL)) : LaneGrp<L>::x1((int)(b & 0xffffffffLL));
+        const int hi = second ? LaneGrp<L>::x2((int)(b >> 32)) : LaneGrp<L>::x1((int)(b >> 32));
+        return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+    };
+    v += sh(v, false);
+    if (L == 4) v += sh(v, true);
+    return v;
+}
+
+template <int MP, int L, int KM>
+__global__ __launch_bounds__(64, 1) void mvdr_lcmv_lanes_kernel(BinsArgs a, int tile, int tiles_per_stream) {
+    constexpr int RPL = MP / L;               // rows per lane
+    constexpr int PPW = 64 / L;               // problems per wavefront
+    constexpr int NB = KM + 1;
+    constexpr int NG = GramIdx<KM>::NG, NE = GramIdx<KM>::NE;
+    constexpr int NT = L * RPL * (RPL + 1) / 2;  // stored entries per lane: slot r keeps columns 0 .. r*L+L-1
+#define TIX(r, c) (L * (r) * ((r) + 1) / 2 + (c))
+    __shared__ __attribute__((aligned(16))) f64x2 s_R[NT][64];  // R rows of this lane: s_R[TIX(r, c)][lane]
+    const int lane = threadIdx.x;
+    const int q = lane % L;
+    const int pq = blockIdx.y * PPW + lane / L;  // problem (bin) index
+    const int s = blockIdx.x / tiles_per_stream;
+    const long tA = (long)(blockIdx.x % tiles_per_stream) * tile;
+    long tB = tA + tile;
+    if (tB > a.n_frames) tB = a.n_frames;
+    const int M = a.n_mics, NP = (M + 1) >> 1, KP1 = a.kp1, P = a.cfg.past_windows;
+    const bool live = pq < kNQ;
+    const int qq = live ? pq : kNQ - 1;
+    const int j = q_bin(qq);
+    const bool lcmv = a.cfg.algo == BF_LCMV;
+    const double f = fabs(a.freqs[j]);
+    const bool inband = live && f >= a.cfg.freq_min && f <= a.cfg.freq_max && !(j == 0 && !lcmv);
+    f64x2 *yout = a.Yh + ((long)s * a.n_frames) * kYhStride + qq;
+    const f64x2 *Zs = a.Z + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
+    const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
+    const int ksrc = q_src_bin(qq), kneg = (kN - ksrc) & (kN - 1);
+    auto load_mic = [&](long t, int m) -> cd {  // spectrum of microphone m at this bin, frame t
+        if (m >= M) return cd{0, 0};
+        const f64x2 *Zf = Zs + t * NP * kN + (m >> 1) * kN;
+        const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
+        cd x;
+        if ((m & 1) == 0) {
+            x = (z + zc) * 0.5;
+        } else {
+            const cd d = z - zc;
+            x = cd{0.5 * d.y, -0.5 * d.x};
+        }
+        return qq == 513 ? conj(x) : x;
+    };
+    if (__builtin_amdgcn_ballot_w64(inband) == 0) {  // nothing to solve in this wavefront
+        if (live && q == 0)
+            for (long t = tA; t < tB; ++t) {
+                cd y{0, 0};
+                if (j == 0 && !lcmv) y = load_mic(t, 0);  // mvdr.cpp:76
+                yout[t * kYhStride] = f64x2{y.x, y.y};
+            }
+        return;
+    }
+    // this lane's entries of the constraint columns (weights[j](i, c)) are re-read every frame (L2-resident table)
+    // straight into the right-hand sides: keeping them would cost 64 more registers at M = 16, K + 1 = 4
+    auto load_cst = [&](int r, int c) -> cd {
+        const int i = r * L + q;
+        return (c < KP1 && i < M) ? ld(steer + ((long)c * M + i) * kN + j) : cd{0, 0};
+    };
+#pragma unroll
+    for (int e = 0; e < NT; ++e) s_R[e][lane] = f64x2{0, 0};
+    // R[i][c] += x_i conj(x_c) (- xo_i conj(xo_c)) on the stored rows; x_c comes from its owner lane by DPP
+    auto rank1 = [&](const cd (&xl)[RPL], const cd (&xo)[RPL], bool with_old) {
+#pragma unroll
+        for (int c = 0; c < MP; ++c) {
+            const cd xc = bcast_from<L>(c % L, xl[c / L]);
+            const cd xoc = with_old ? bcast_from<L>(c % L, xo[c / L]) : cd{0, 0};
+#pragma unroll
+            for (int r = c / L; r < RPL; ++r) {
+                const int i = r * L + q;
+                if (c <= i) {
+                    cd v = ld(&s_R[TIX(r, c)][lane]);
+                    v = cfma_conj(v, xl[r], xc);
+                    if (with_old) v = cfms_conj(v, xo[r], xoc);
+                    s_R[TIX(r, c)][lane] = f64x2{v.x, v.y};
+                }
+            }
+        }
+    };
+    for (int p = 1; p <= P; ++p) {
+        cd xl[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) xl[r] = load_mic(tA - p, r * L + q);
+        rank1(xl, xl, false);
+    }
+
+    for (long t = tA; t < tB; ++t) {
+        cd xl[RPL], xo[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            xl[r] = load_mic(t, r * L + q);
+            xo[r] = load_mic(t - P, r * L + q);
+        }
+        double mag = 0.0;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) mag += sqrt(norm2(xl[r]));  // padded rows are 0
+        mag = grp_sum<L>(mag) / (double)((unsigned)M * 1024u);
+        const cd x0 = bcast_from<L>(0, xl[0]);
+        cd y;
+        if (mag > a.cfg.freq_mag_threshold) {
+            cd A[NT], b[RPL][NB];
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+#pragma unroll
+                for (int c = 0; c < KM; ++c) b[r][c] = load_cst(r, c);
+                b[r][KM] = xl[r];
+            }
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                const int i = r * L + q;
+#pragma unroll
+                for (int c = 0; c < (r + 1) * L; ++c) {
+                    cd v = ld(&s_R[TIX(r, c)][lane]);
+                    if (c == i) v = (i < M) ? v * 1.001 : cd{1.0, 0.0};  // whiteR diagonal; padding rows = identity
+                    if (i >= M && c != i) v = cd{0, 0};
+                    A[TIX(r, c)] = v;
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < MP; ++jj) {
+                const int ro = jj / L, qo = jj % L;  // owner slot / lane of row jj
+                const double inv = rsqrt(bcast_from<L>(qo, A[TIX(ro, jj)].x));
+                cd Lc[RPL];  // scaled column jj of the local rows (meaningful where row > jj)
+#pragma unroll
+                for (int r = ro; r < RPL; ++r) Lc[r] = A[TIX(r, jj)] * inv;
+#pragma unroll
+                for (int col = 0; col < NB; ++col) {  // right-hand sides: u_jj = b_jj / L_jj, then b_i -= L_ij u_jj
+                    const cd u = bcast_from<L>(qo, b[ro][col] * inv);
+                    if (q == qo) b[ro][col] = u;
+#pragma unroll
+                    for (int r = ro; r < RPL; ++r) {
+                        const int i = r * L + q;
+                        if (i > jj) b[r][col] = cfms(b[r][col], Lc[r], u);
+                    }
+                }
+#pragma unroll
+                for (int c = jj + 1; c < MP; ++c) {  // trailing update A_ic -= L_ij conj(L_cj), jj < c <= i
+                    const cd Lcj = bcast_from<L>(c % L, Lc[c / L]);
+#pragma unroll
+                    for (int r = c / L; r < RPL; ++r) {
+                        const int i = r * L + q;
+                        if (c <= i) A[TIX(r, c)] = cfms_conj(A[TIX(r, c)], Lc[r], Lcj);
+                    }
+                }
+            }
+            // b holds the local rows of U = L^-1 [C | x]; Gram entries, reduced over the group
+            cd ge[NE];
+            {
+                int e = 0;
+#pragma unroll
+                for (int r1 = 0; r1 < KM; ++r1)
+#pragma unroll
+                    for (int r2 = r1; r2 < KM; ++r2) {
+                        cd acc{0, 0};
+#pragma unroll
+                        for (int r = 0; r < RPL; ++r)
+                            if (r * L + q < M) acc = cfma_conj(acc, b[r][r2], b[r][r1]);
+                        ge[e++] = cd{grp_sum<L>(acc.x), grp_sum<L>(acc.y)};
+                    }
+#pragma unroll
+                for (int r1 = 0; r1 < KM; ++r1) {
+                    cd acc{0, 0};
+#pragma unroll
+                    for (int r = 0; r < RPL; ++r)
+                        if (r * L + q < M) acc = cfma_conj(acc, b[r][KM], b[r][r1]);
+                    ge[NG + r1] = cd{grp_sum<L>(acc.x), grp_sum<L>(acc.y)};
+                }
+            }
+            cd Gm[KM][KM], gv[KM];
+            {
+                int e = 0;
+#pragma unroll
+                for (int r1 = 0; r1 < KM; ++r1)
+#pragma unroll
+                    for (int r2 = r1; r2 < KM; ++r2) {
+                        const cd v = ge[e++];
+                        Gm[r1][r2] = v;
+                        Gm[r2][r1] = conj(v);
+                    }
+#pragma unroll
+                for (int r1 = 0; r1 < KM; ++r1) gv[r1] = ge[NG + r1];
+#pragma unroll
+                for (int r1 = 0; r1 < KM; ++r1)
+                    if (r1 >= KP1) {
+#pragma unroll
+                        for (int r2 = 0; r2 < KM; ++r2) {
+                            Gm[r1][r2] = cd{r1 == r2 ? 1.0 : 0.0, 0.0};
+                            Gm[r2][r1] = cd{r1 == r2 ? 1.0 : 0.0, 0.0};
+                        }
+                        gv[r1] = cd{0, 0};
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < KM; ++k) {  // Gaussian elimination (G is Hermitian positive definite)
+                const cd pinv = cdiv(cd{1, 0}, Gm[k][k]);
+#pragma unroll
+                for (int r1 = k + 1; r1 < KM; ++r1) {
+                    const cd fct = Gm[r1][k] * pinv;
+#pragma unroll
+                    for (int c = k + 1; c < KM; ++c) Gm[r1][c] = Gm[r1][c] - fct * Gm[k][c];
+                    gv[r1] = gv[r1] - fct * gv[k];
+                }
+            }
+#pragma unroll
+            for (int k = KM - 1; k >= 0; --k) {
+                cd acc = gv[k];
+#pragma unroll
+                for (int c = k + 1; c < KM; ++c) acc = acc - Gm[k][c] * gv[c];
+                gv[k] = cdiv(acc, Gm[k][k]);
+            }
+            y = gv[0];
+        } else {
+            y = x0 * 0.01;  // mvdr.cpp:96
+        }
+        if (!inband) y = (j == 0 && !lcmv) ? x0 : cd{0, 0};
+        if (live && q == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+        rank1(xl, xo, true);  // slide the covariance window (mvdr.cpp:100-101)
+    }
+#undef TIX
+}
+
+
+// ---- lcmv / mvdr, 9..16 microphones: one problem per 16-lane DPP row, exchange by row_newbcast ----------
+// Same row-per-lane factorisation as mvdr_lcmv_kernel<16, KM>, but a problem occupies exactly one DPP row, so the
+// pivot, the scaled column and the right-hand sides travel by `v_mov_b32_dpp row_newbcast:n` (lane n of every row to
+// the whole row, one instruction per dword, VALU latency) instead of an LDS write -> s_waitcnt -> read round trip per
+// column, and the Gram sums are row reductions (quad_perm xor 1/2, row_half_mirror, row_mirror).  No LDS at all.
+template <int N>
+__device__ __forceinline__ double rowbc(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x150 + N, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + N, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <int N>
+__device__ __forceinline__ cd rowbc(cd v) { return cd{rowbc<N>(v.x), rowbc<N>(v.y)}; }
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double row_sum(double v) {  // every lane of the 16-lane row gets the row total
+    v += dpp_d<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_d<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_d<0x141>(v);  // row_half_mirror
+    v += dpp_d<0x140>(v);  // row_mirror
+    return v;
+}
+template <int C, int MP>
+struct RowStep {  // compile-time loops over the broadcast source lane
+    template <typename F>
+    static __device__ __forceinline__ void run(F &&f) {
+        f(std::integral_constant<int, C>{});
+        RowStep<C + 1, MP>::run(f);
+    }
+};
+template <int MP>
+struct RowStep<MP, MP> {
+    template <typename F>
+    static __device__ __forceinline__ void run(F &&) {}
+};
+
+template <int KM>
+__global__ __launch_bounds__(256, 2) void mvdr_lcmv_row_kernel(BinsArgs a, int tile, int tiles_per_stream) {
+    constexpr int MP = 16, GPB = 256 / MP, NB = KM + 1;
+    constexpr int NG = GramIdx<KM>::NG, NE = GramIdx<KM>::NE;
+    const int grp = threadIdx.x / MP;
+    const int i = threadIdx.x % MP;
+    const int q = blockIdx.y * GPB + grp;
+    if (q >= kNQ) return;
+    const int s = blockIdx.x / tiles_per_stream;
+    const long tA = (long)(blockIdx.x % tiles_per_stream) * tile;
+    long tB = tA + tile;
+    if (tB > a.n_frames) tB = a.n_frames;
+    const int M = a.n_mics, NP = (M + 1) >> 1, KP1 = a.kp1, P = a.cfg.past_windows;
+    const int j = q_bin(q);
+    const bool lcmv = a.cfg.algo == BF_LCMV;
+    f64x2 *yout = a.Yh + ((long)s * a.n_frames) * kYhStride + q;
+    const f64x2 *Zs = a.Z + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
+    const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
+    const int ksrc = q_src_bin(q), kneg = (kN - ksrc) & (kN - 1);
+    auto load_xi = [&](long t) -> cd {
+        if (i >= M) return cd{0, 0};
+        const f64x2 *Zf = Zs + t * NP * kN + (i >> 1) * kN;
+        const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
+        cd x;
+        if ((i & 1) == 0) {
+            x = (z + zc) * 0.5;
+        } else {
+            const cd d = z - zc;
+            x = cd{0.5 * d.y, -0.5 * d.x};
+        }
+        return q == 513 ? conj(x) : x;
+    };
+    const double f = fabs(a.freqs[j]);
+    const bool inband = f >= a.cfg.freq_min && f <= a.cfg.freq_max;
+    if (!inband || (!lcmv && j == 0)) {  // uniform per row
+        for (long t = tA; t < tB; ++t) {
+            cd y{0, 0};
+            if (!lcmv && j == 0) y = rowbc<0>(load_xi(t));  // mvdr.cpp:76
+            if (i == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+        }
+        return;
+    }
+    // this microphone's entries of the constraint columns are re-read per frame (L2-resident) straight into the
+    // right-hand sides: holding them costs the 16 registers that decide between one and two wavefronts per SIMD
+    auto load_cst = [&](int r) -> cd { return (r < KP1 && i < M) ? ld(steer + ((long)r * M + i) * kN + j) : cd{0, 0}; };
+
+    cd R[MP];  // row i of R
+#pragma unroll
+    for (int c = 0; c < MP; ++c) R[c] = cd{0, 0};
+    for (int p = 1; p <= P; ++p) {
+        const cd x = load_xi(tA - p);
+        RowStep<0, MP>::run([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            R[c] = cfma_conj(R[c], x, rowbc<c>(x));
+        });
+    }
+    for (long t = tA; t < tB; ++t) {
+        const cd x = load_xi(t);
+        const double mag = row_sum(sqrt(norm2(x))) / (double)((unsigned)M * 1024u);
+        cd y;
+        if (mag > a.cfg.freq_mag_threshold) {  // uniform per row
+            cd A[MP], b[NB];
+#pragma unroll
+            for (int c = 0; c < MP; ++c) A[c] = R[c];
+            if (i < M) {
+#pragma unroll
+                for (int c = 0; c < MP; ++c)
+                    if (c == i) A[c] = A[c] * 1.001;  // cwiseProduct(whiteR) (mvdr.cpp:239-243)
+            } else {
+#pragma unroll
+                for (int c = 0; c < MP; ++c) A[c] = cd{c == i ? 1.0 : 0.0, 0.0};  // padding rows = identity
+            }
+#pragma unroll
+            for (int r = 0; r < KM; ++r) b[r] = load_cst(r);
+            b[KM] = x;
+            RowStep<0, MP>::run([&](auto jc) {
+                constexpr int jj = decltype(jc)::value;
+                const double inv = rsqrt(rowbc<jj>(A[jj].x));  // 1 / L_jj from the owner's diagonal
+                const cd Lij = A[jj] * inv;                   // my row's entry of the scaled column (valid for i > jj)
+#pragma unroll
+                for (int r = 0; r < NB; ++r) {
+                    const cd bs = b[r] * inv;
+                    const cd ujj = rowbc<jj>(bs);  // u_jj = b_jj / L_jj
+                    if (i > jj)
+                        b[r] = cfms(b[r], Lij, ujj);
+                    else if (i == jj)
+                        b[r] = bs;
+                }
+                RowStep<jj + 1, MP>::run([&](auto cc) {  // trailing update A_ic -= L_ij conj(L_cj), jj < c <= i
+                    constexpr int c = decltype(cc)::value;
+                    const cd Lcj = rowbc<c>(Lij);
+                    if (i >= c) A[c] = cfms_conj(A[c], Lij, Lcj);
+                });
+            });
+            // b[r] = row i of U = L^-1 [C | x]; Gram entries by row reduction
+            cd ge[NE];
+            {
+                int e = 0;
+#pragma unroll
+                for (int r1 = 0; r1 < KM; ++r1)
+#pragma unroll
+                    for (int r2 = r1; r2 < KM; ++r2) {
+                        cd pr = (i < M) ? cfma_conj(cd{0, 0}, b[r2], b[r1]) : cd{0, 0};
+                        ge[e++] = cd{row_sum(pr.x), row_sum(pr.y)};
+                    }
+#pragma unroll
+                for (int r1 = 0; r1 < KM; ++r1) {
+                    cd pr = (i < M) ? cfma_conj(cd{0, 0}, b[KM], b[r1]) : cd{0, 0};
+                    ge[NG + r1] = cd{row_sum(pr.x), row_sum(pr.y)};
+                }
+            }
+            // (K+1) x (K+1) system G y = g on the upper triangle only (G and every Schur complement are Hermitian):
+            // U[r][c], r <= c, is ge[] itself; rows / columns beyond the live constraints are the identity
+            cd gv[KM];
+            auto UI = [](int r, int c) { return r * KM - r * (r - 1) / 2 + (c - r); };
+#pragma unroll
+            for (int r1 = 0; r1 < KM; ++r1) gv[r1] = ge[NG + r1];
+#pragma unroll
+            for (int r1 = 0; r1 < KM; ++r1)
+                if (r1 >= KP1) {
+#pragma unroll
+                    for (int r2 = 0; r2 < r1; ++r2) ge[UI(r2, r1)] = cd{0, 0};
+                    ge[UI(r1, r1)] = cd{1.0, 0.0};
+#pragma unroll
+                    for (int c = r1 + 1; c < KM; ++c) ge[UI(r1, c)] = cd{0, 0};
+                    gv[r1] = cd{0, 0};
+                }
+#pragma unroll
+            for (int k = 0; k < KM; ++k) {
+                const cd pinv = cdiv(cd{1, 0}, ge[UI(k, k)]);
+#pragma unroll
+                for (int r1 = k + 1; r1 < KM; ++r1) {
+                    const cd fct = conj(ge[UI(k, r1)]) * pinv;  // G[r1][k] / G[k][k]
+#pragma unroll
+                    for (int c = r1; c < KM; ++c) ge[UI(r1, c)] = ge[UI(r1, c)] - fct * ge[UI(k, c)];
+                    gv[r1] = gv[r1] - fct * gv[k];
+                }
+            }
+#pragma unroll
+            for (int k = KM - 1; k >= 0; --k) {
+                cd acc = gv[k];
+#pragma unroll
+                for (int c = k + 1; c < KM; ++c) acc = acc - ge[UI(k, c)] * gv[c];
+                gv[k] = cdiv(acc, ge[UI(k, k)]);
+            }
+            y = gv[0];
+        } else {
+            y = rowbc<0>(x) * 0.01;  // in_fft(0,j)*0.01 (mvdr.cpp:96)
+        }
+        if (i == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+        // slide the covariance window: + x_t x_t^H - x_{t-P} x_{t-P}^H (mvdr.cpp:100-101)
+        const cd xo = load_xi(t - P);  // loaded late: 4 registers less across the factorisation
+        RowStep<0, MP>::run([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            R[c] = cfms_conj(cfma_conj(R[c], x, rowbc<c>(x)), xo, rowbc<c>(xo));
+        });
+    }
+}
+
+}  // namespace
+
+hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
+    int tile = 64;
+    if (a.n_frames < tile) tile = (int)a.n_frames;
+    const int tps = (int)((a.n_frames + tile - 1) / tile);
+    const int M = a.n_mics, km = a.kp1 <= 1 ? 1 : 4;
+    static const bool no_fast = getenv("BF_MVDR_GROUP") && atoi(getenv("BF_MVDR_GROUP")) != 0;
+    // lcmv with 9..16 microphones: one problem per DPP row, row_newbcast exchange (34.2 -> 27.6 ms per 32 768 frames at 16)
+    if (!no_fast && a.cfg.algo == BF_LCMV && M > 8) {
+        const dim3 grid(tps * a.n_streams, (kNQ + 15) / 16);  // x: tile * stream (can exceed 65535), y: bin blocks
+        if (km == 1)
+            hipLaunchKernelGGL((mvdr_lcmv_row_kernel<1>), grid, dim3(256), 0, s, a, tile, tps);
+        else
+            hipLaunchKernelGGL((mvdr_lcmv_row_kernel<4>), grid, dim3(256), 0, s, a, tile, tps);
+        return hipGetLastError();
+    }
+    // lanes kernel: mvdr with 9..16 microphones (12.7 vs 26 ms per 32 768 frames at 16) and lcmv with up to 8
+    // (9.4 vs 15.4 ms per 65 536 frames).  lcmv with 9..16 microphones keeps the row-per-lane kernel: 40 complex of
+    // working copy + 5 right-hand sides x 4 rows do not fit 512 registers (736 B of scratch, 5x slower).
+    if (!no_fast && ((a.cfg.algo == BF_MVDR && M > 8) || (a.cfg.algo == BF_LCMV && M <= 8))) {
+        int lt = 32;
+        if (a.n_frames < lt) lt = (int)a.n_frames;
+        const int ltps = (int)((a.n_frames + lt - 1) / lt);
+        if (M <= 4) {
+            const dim3 grid(ltps * a.n_streams, (kNQ + 31) / 32);  // x: tile * stream (can exceed 65535), y: bin blocks
+            hipLaunchKernelGGL((mvdr_lcmv_lanes_kernel<4, 2, 4>), grid, dim3(64), 0, s, a, lt, ltps);
+        } else if (M <= 8) {
+            const dim3 grid(ltps * a.n_streams, (kNQ + 31) / 32);  // x: tile * stream (can exceed 65535), y: bin blocks
+            hipLaunchKernelGGL((mvdr_lcmv_lanes_kernel<8, 2, 4>), grid, dim3(64), 0, s, a, lt, ltps);
+        } else {
+            const dim3 grid(ltps * a.n_streams, (kNQ + 15) / 16);  // x: tile * stream (can exceed 65535), y: bin blocks
+            hipLaunchKernelGGL((mvdr_lcmv_lanes_kernel<16, 4, 1>), grid, dim3(64), 0, s, a, lt, ltps);
+        }
+        return hipGetLastError();
+    }
+    if (a.cfg.algo == BF_MVDR && M <= 8 && !no_fast) {
+        int ft = 32;
+        if (a.n_frames < ft) ft = (int)a.n_frames;
+        const int ftps = (int)((a.n_frames + ft - 1) / ft);
+        const dim3 grid(ftps * a.n_streams, (kNQ + 63) / 64);  // x: tile * stream (can exceed 65535), y: bin blocks
+        if (M <= 4)
+            hipLaunchKernelGGL((mvdr_fast_kernel<4>), grid, dim3(64), 0, s, a, ft, ftps);
+        else
+            hipLaunchKernelGGL((mvdr_fast_kernel<8>), grid, dim3(64), 0, s, a, ft, ftps);
+        return hipGetLastError();
+    }
+#define BF_LAUNCH_ML(MP_, KM_)                                                                                   \
+    hipLaunchKernelGGL((mvdr_lcmv_kernel<MP_, KM_>), dim3(tps * a.n_streams, (kNQ + (256 / MP_) - 1) / (256 / MP_)), \
+                       dim3(256), 0, s, a, tile, tps)
+    if (M <= 4) {
+        if (km == 1) BF_LAUNCH_ML(4, 1); else BF_LAUNCH_ML(4, 4);
+    } else if (M <= 8) {
+        if (km == 1) BF_LAUNCH_ML(8, 1); else BF_LAUNCH_ML(8, 4);
+    } else {
+        if (km == 1) BF_LAUNCH_ML(16, 1); else BF_LAUNCH_ML(16, 4);
+    }
+#undef BF_LAUNCH_ML
+    return hipGetLastError();
+}
+
+}  // namespace bf

@@ -1,0 +1,383 @@
+// gsc_gss_kernels.hip -- the two adaptive nodes: gss (per-bin demixing-matrix recursion) and gsc (per-microphone alignment
+// + sample-serial float32 NLMS).
+#include "bins_common.hpp"
+
+namespace bf {
+
+namespace {
+
+// ======================================================================================
+//                 gsc: generalized sidelobe canceller (gsc.cpp:54-197)
+// ======================================================================================
+// Pass 1 (align): output stream s*M + m carries microphone m of input stream s steered to the look direction,
+// y_fft = x_fft * conj(weights[m]) over all bins (gsc.cpp:62-70); the ISTFT then does the per-microphone
+// overlap-add of do_overlap_bymic (util.h:353-379).
+__global__ __launch_bounds__(256) void gsc_align_kernel(BinsArgs a) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)a.n_streams * a.n_frames * kNQ;
+    if (idx >= total) return;
+    const int q = (int)(idx % kNQ);
+    const long st = idx / kNQ;
+    const long t = st % a.n_frames;
+    const int so = (int)(st / a.n_frames);
+    const int M = a.n_mics, NP = (M + 1) >> 1;
+    const int si = so / M, m = so - si * M;
+    const f64x2 *Zf = a.Z + (((long)si * a.frames_ws + a.frame_off + t) * NP + (m >> 1)) * kN;
+    const int k = q_src_bin(q), kn = (kN - k) & (kN - 1);
+    const cd z = ld(Zf + k), zc = conj(ld(Zf + kn));
+    cd x;
+    if ((m & 1) == 0) {
+        x = (z + zc) * 0.5;
+    } else {
+        const cd d = z - zc;
+        x = cd{0.5 * d.y, -0.5 * d.x};
+    }
+    if (q == 513) x = conj(x);
+    const cd y = x * conj(ld(a.steer + (long)m * kN + q_bin(q)));
+    a.Yh[((long)so * a.n_frames + t) * kYhStride + q] = f64x2{y.x, y.y};
+}
+
+// Pass 2 (NLMS): one wavefront per stream, strictly sample by sample.  The reference does this arithmetic in
+// float32 (rosjack_data) with every product and sum rounded separately and the 128-tap sums taken in order, and
+// it branches on the results (mu selection, NaN guards), so the kernel keeps exactly that order: lane i owns
+// blocking branch i and walks its taps sequentially (__fmul_rn/__fadd_rn: no FMA contraction), lane M-1 does
+// the same for the output-power window.  Only what is elementwise is spread over the lanes: the upper beamformer
+// and the neighbour differences of a 64-sample tile (lane = sample), and the filter update (lane = tap), whose
+// coefficients live in registers with a write-through copy in LDS for the serial walk.
+// Windows are mirrored rings in LDS (each sample stored at p and p + fs) so a window is always contiguous.
+// A block is one wavefront: its LDS operations complete in issue order, so phases are separated by compiler
+// fences (wave_barrier), not s_barrier.
+template <int NBM, int KPL>  // NBM >= blocking branches (M - 1), KPL >= ceil(filter_size / 64)
+__global__ __launch_bounds__(64) void gsc_nlms_kernel(const float *aligned, float *y, float *state, long n, int M, int fs,
+                                                      int use_vad, double vad_threshold, double mu0, double mu_max) {
+    extern __shared__ float gl[];
+    const int lane = threadIdx.x;
+    const int nb = M - 1;                 // blocking branches
+    const int nbr = nb > 0 ? nb : 1;
+    // row lengths are padded to a whole number of 64-tap lane groups (+8 for the staged loads of the serial walk) and
+    // made odd, so neither the walk nor the update needs a per-lane bounds guard and lane i / row i hit distinct banks
+    const int bstride = (fs + 64 * KPL + 8) | 1;  // mirrored ring: a window starts at h1 < fs
+    const int fstride = (64 * KPL + 8) | 1;
+    float *s_bm = gl;                     // [nb][bstride]
+    float *s_f = s_bm + nbr * bstride;    // [nb][fstride]
+    float *s_lo = s_f + nbr * fstride;    // [2*fs]
+    float *s_d = s_lo + 2 * fs + 16;      // [nb][64] neighbour differences of the current tile (16 words of slack first)
+    float *s_das = s_d + nbr * 64;        // [64] upper beamformer of the current tile
+    float *s_c = s_das + 64;              // [16] mu_i * out
+    float *s_out = s_c + 16;              // [64]
+    const int s = blockIdx.x;
+    const float *as = aligned + (long)s * M * n;
+    float *ys = y + (long)s * n;
+    float *sv = state + (long)s * (2 * nb + 1) * fs;
+    float freg[NBM][KPL];  // filter taps k = lane + 64 c of every branch
+#pragma unroll
+    for (int i = 0; i < NBM; ++i)
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) {
+            const int k = lane + 64 * c;
+            float v = 0.f;
+            if (i < nb && k < fs) {
+                const float b = sv[i * fs + k];
+                s_bm[i * bstride + k] = b;
+                s_bm[i * bstride + k + fs] = b;
+                v = sv[nb * fs + i * fs + k];
+                s_f[i * fstride + k] = v;
+            }
+            freg[i][c] = v;
+        }
+    for (int k = lane; k < fs; k += 64) {
+        const float v = sv[2 * nb * fs + k];
+        s_lo[k] = v;
+        s_lo[k + fs] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    int h = 0;  // ring position of the oldest element (same for every window: all advance once per sample)
+    const float fsz = (float)fs;
+    const bool is_branch = lane < nb, is_lo = lane == nb;
+    const float *myrow = is_branch ? s_bm + lane * bstride : s_lo;  // lane nb (= M-1) walks the output window
+    const float *myflt = is_branch ? s_f + lane * fstride : s_f;
+    for (long n0 = 0; n0 < n; n0 += 64) {
+        {   // tile prologue, lane = sample: das_out (gsc.cpp:122-127) and the blocking-matrix inputs (gsc.cpp:131)
+            const bool ok = n0 + lane < n;
+            float prev = ok ? as[n0 + lane] : 0.f, das = 0.f;
+            das = __fadd_rn(das, prev);
+            for (int m = 1; m < M; ++m) {
+                const float cur = ok ? as[(long)m * n + n0 + lane] : 0.f;
+                das = __fadd_rn(das, cur);
+                s_d[(m - 1) * 64 + lane] = __fsub_rn(cur, prev);
+                prev = cur;
+            }
+            s_das[lane] = __fdiv_rn(das, (float)M);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int cnt = (n - n0) < 64 ? (int)(n - n0) : 64;
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float das = s_das[jj];
+            if (is_branch) {
+                const float d = s_d[lane * 64 + jj];
+                s_bm[lane * bstride + h] = d;
+                s_bm[lane * bstride + h + fs] = d;
+            }
+            const int h1 = (h + 1 == fs) ? 0 : h + 1;  // window = [h1, h1 + fs)
+            __builtin_amdgcn_wave_barrier();
+            // lane i: block_out_i and the sum of squares of its window; lane nb: sum of squares of the output
+            // window WITHOUT its newest element (added below, last, as the reference's loop order has it).
+            // Loads are unconditional (every row is fs words long) and staged one group of 8 taps ahead of the
+            // two dependent add chains.
+            float bo = 0.f, pw = 0.f;
+            {
+                const float *u = myrow + h1;
+                float un[8], wn[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    un[r] = u[r];
+                    wn[r] = myflt[r];
+                }
+                // taps 0 .. fs-2 are common to all lanes; tap fs-1 belongs to the branch lanes only (the output
+                // window's newest element is not known yet)
+                int k = 0;
+                for (; k + 8 <= fs - 1; k += 8) {
+                    float uv[8], wv[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        uv[r] = un[r];
+                        wv[r] = wn[r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {  // next group (reads past the window end land in the row padding)
+                        un[r] = u[k + 8 + r];
+                        wn[r] = myflt[k + 8 + r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        bo = __fadd_rn(bo, __fmul_rn(wv[r], uv[r]));
+                        pw = __fadd_rn(pw, __fmul_rn(uv[r], uv[r]));
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {  // leftover taps, already staged
+                    if (k + r < fs - 1 || (k + r == fs - 1 && !is_lo)) {
+                        bo = __fadd_rn(bo, __fmul_rn(wn[r], un[r]));
+                        pw = __fadd_rn(pw, __fmul_rn(un[r], un[r]));
+                    }
+                }
+            }
+            float out = das;
+            for (int i = 0; i < nb; ++i)
+                out = __fsub_rn(out, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bo), i)));
+            const float pwl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pw), nb));
+            const float lop = __fsqrt_rn(__fdiv_rn(__fadd_rn(pwl, __fmul_rn(out, out)), fsz));  // calculate_power(last_outputs)
+            if (lane == 0) {
+                s_lo[h] = out;
+                s_lo[h + fs] = out;
+                s_out[jj] = out;
+            }
+            const bool adapt = ((double)lop < vad_threshold) || !use_vad;  // gsc.cpp:147
+            if (adapt && nb > 0) {
+                if (is_branch) {
+                    const float bp = __fsqrt_rn(__fdiv_rn(pw, fsz));
+                    float mu;
+                    if (mu0 * (double)bp / (double)lop < mu_max)  // gsc.cpp:153-157 (double arithmetic: mu0 is a double)
+                        mu = (float)(mu0 / (double)lop);
+                    else
+                        mu = (float)(mu0 / (double)bp);
+                    if (isnan(mu) || isinf(mu)) mu = 0.f;
+                    s_c[lane] = __fmul_rn(mu, out);
+                }
+                __builtin_amdgcn_wave_barrier();
+                // filter[i][k] += this_mu*out[j]*block_matrix[i][k] (gsc.cpp:163-170), taps over the lanes:
+                // all loads first, then the arithmetic and the write-through stores
+                float bmv[NBM][KPL], cv[NBM];
+#pragma unroll
+                for (int i = 0; i < NBM; ++i) {
+                    const int ic = i < nb ? i : 0;
+                    cv[i] = s_c[ic];
+#pragma unroll
+                    for (int c = 0; c < KPL; ++c) bmv[i][c] = s_bm[ic * bstride + h1 + lane + 64 * c];
+                }
+#pragma unroll
+                for (int i = 0; i < NBM; ++i)
+                    if (i < nb) {  // uniform
+#pragma unroll
+                        for (int c = 0; c < KPL; ++c) {  // lanes past filter_size work on row padding nobody reads
+                            float fv = __fadd_rn(freg[i][c], __fmul_rn(cv[i], bmv[i][c]));
+                            if (isnan(fv)) fv = 0.f;
+                            freg[i][c] = fv;
+                            s_f[i * fstride + lane + 64 * c] = fv;
+                        }
+                    }
+            }
+            __builtin_amdgcn_wave_barrier();
+            h = h1;
+        }
+        if (lane < cnt) ys[n0 + lane] = s_out[lane];
+        __builtin_amdgcn_wave_barrier();
+    }
+    // carried state in the reference's (shifted, oldest-first) order
+    for (int e = lane; e < nb * fs; e += 64) {
+        const int i = e / fs, k = e - i * fs;
+        sv[e] = s_bm[i * bstride + h + k];
+        sv[nb * fs + e] = s_f[i * fstride + k];
+    }
+    for (int k = lane; k < fs; k += 64) sv[2 * nb * fs + k] = s_lo[h + k];
+}
+
+// ======================================================================================
+//                              gss: geometric source separation
+// ======================================================================================
+// One group of MP lanes per (stream, problem), lane m owns column m of the demixing matrix
+// W_j (S x M) and walks the frames in order (the update is recursive, gss.cpp:136).
+template <int MP, int KM>
+__global__ __launch_bounds__(256) void gss_kernel(BinsArgs a) {
+    constexpr int GPB = 256 / MP;
+    __shared__ cd s_x[GPB][MP + 1];   // padded rows: see mvdr_lcmv_kernel (gss 256x256: 6.5 -> 5.8 ms)
+    __shared__ cd s_p[GPB][KM][MP + 1];
+    const int grp = threadIdx.x / MP, m = threadIdx.x % MP;
+    const int gq = blockIdx.x * GPB + grp;
+    if (gq >= a.n_streams * kNQ) return;
+    const int s = gq / kNQ, q = gq % kNQ;
+    const int j = q_bin(q);
+    const int M = a.n_mics, NP = (M + 1) >> 1, S = a.kp1;
+    f64x2 *yout = a.Yh + ((long)s * a.n_frames) * kYhStride + q;
+    const f64x2 *Zs = a.Z + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
+    const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
+    const double f = fabs(a.freqs[j]);
+    const bool inband = f >= a.cfg.freq_min && f <= a.cfg.freq_max;
+    if (!inband) {
+        if (m == 0)
+            for (long t = 0; t < a.n_frames; ++t) yout[t * kYhStride] = f64x2{0, 0};
+        return;
+    }
+    const int ksrc = q_src_bin(q), kneg = (kN - ksrc) & (kN - 1);
+    cd C[KM], W[KM];
+    f64x2 *Wg = a.gssW + (((long)s * kN + j) * S) * M;
+#pragma unroll
+    for (int r = 0; r < KM; ++r) {
+        C[r] = (r < S && m < M) ? ld(steer + ((long)r * M + m) * kN + j) : cd{0, 0};
+        if ((a.gss_reset_mask >> (s % a.n_dirs)) & 1ull)
+            W[r] = conj(C[r]);  // sep_matrix[j] = weights[j].adjoint() (gss.cpp:92)
+        else
+            W[r] = (r < S && m < M) ? ld(Wg + (long)r * M + m) : cd{0, 0};
+    }
+    const double mu = a.cfg.mu, keep = 1 - a.cfg.lambda_ * a.cfg.mu;
+    const double c2 = (double)(size_t)(2 * (1 / (size_t)S));  // integer arithmetic, quirk Q13
+    for (long t = 0; t < a.n_frames; ++t) {
+        cd x{0, 0};
+        if (m < M) {
+            const f64x2 *Zf = Zs + t * NP * kN + (m >> 1) * kN;
+            const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
+            if ((m & 1) == 0) {
+                x = (z + zc) * 0.5;
+            } else {
+                const cd d = z - zc;
+                x = cd{0.5 * d.y, -0.5 * d.x};
+            }
+            if (q == 513) x = conj(x);
+        }
+        s_x[grp][m] = x;
+#pragma unroll
+        for (int r = 0; r < KM; ++r) s_p[grp][r][m] = W[r] * x;
+        __builtin_amdgcn_wave_barrier();
+        double mag = 0.0, alpha = 0.0;
+        for (int k = 0; k < M; ++k) {
+            const cd v = s_x[grp][k];
+            mag += cabs(v);
+            alpha += norm2(v);
+        }
+        mag /= (double)((unsigned)M * 1024u);
+        cd y;
+        if (mag > a.cfg.freq_mag_threshold) {
+            cd yf[KM];
+#pragma unroll
+            for (int r = 0; r < KM; ++r) {
+                cd acc{0, 0};
+                for (int k = 0; k < M; ++k) acc = acc + s_p[grp][r][k];
+                yf[r] = acc;
+            }
+            y = yf[0];
+            alpha *= alpha;
+            const double c1 = (double)(4 * (size_t)S) * (1 / alpha);
+            cd Ey[KM];
+#pragma unroll
+            for (int r = 0; r < KM; ++r) {
+                cd acc{0, 0};
+#pragma unroll
+                for (int r2 = 0; r2 < KM; ++r2)
+                    if (r2 != r && r < S && r2 < S) acc = acc + (yf[r] * conj(yf[r2])) * yf[r2];
+                Ey[r] = acc;
+            }
+            cd d2[KM];
+#pragma unroll
+            for (int r = 0; r < KM; ++r) d2[r] = cd{0, 0};
+            if (c2 != 0.0) {  // only S == 1: dj2 = 2 (W C - I) C^H
+                __builtin_amdgcn_wave_barrier();
+                s_p[grp][0][m] = W[0] * C[0];
+                __builtin_amdgcn_wave_barrier();
+                cd wc{0, 0};
+                for (int k = 0; k < M; ++k) wc = wc + s_p[grp][0][k];
+                wc.x -= 1.0;
+                d2[0] = (wc * conj(C[0])) * c2;
+            }
+#pragma unroll
+            for (int r = 0; r < KM; ++r)
+                if (r < S) W[r] = (W[r] * keep) - ((Ey[r] * conj(x)) * c1 + d2[r]) * mu;
+        } else {
+            y = s_x[grp][0] * 0.01;
+        }
+        if (m == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int r = 0; r < KM; ++r)
+        if (r < S && m < M) Wg[(long)r * M + m] = f64x2{W[r].x, W[r].y};
+}
+
+}  // namespace
+
+hipError_t launch_gss(const BinsArgs &a, int n_cus, hipStream_t s) {
+    const int M = a.n_mics, km = a.kp1 <= 1 ? 1 : 4;
+    const int groups = a.n_streams * kNQ;
+#define BF_LAUNCH_GSS(MP_, KM_) \
+    hipLaunchKernelGGL((gss_kernel<MP_, KM_>), dim3((groups + (256 / MP_) - 1) / (256 / MP_)), dim3(256), 0, s, a)
+    if (M <= 4) {
+        if (km == 1) BF_LAUNCH_GSS(4, 1); else BF_LAUNCH_GSS(4, 4);
+    } else if (M <= 8) {
+        if (km == 1) BF_LAUNCH_GSS(8, 1); else BF_LAUNCH_GSS(8, 4);
+    } else {
+        if (km == 1) BF_LAUNCH_GSS(16, 1); else BF_LAUNCH_GSS(16, 4);
+    }
+#undef BF_LAUNCH_GSS
+    return hipGetLastError();
+}
+
+hipError_t launch_gsc_nlms(const float *aligned, float *y, float *state, long n_samples, int n_streams, int n_mics,
+                           const bf_config &cfg, hipStream_t s) {
+    const int fs = cfg.gsc_filter_size, nb = n_mics - 1, nbr = nb > 0 ? nb : 1;
+    const int kpl = (fs + 63) / 64, kp = kpl <= 1 ? 1 : kpl <= 2 ? 2 : 4;
+    const size_t lds = sizeof(float) * ((size_t)nbr * ((fs + 64 * kp + 8) | 1) + (size_t)nbr * ((64 * kp + 8) | 1) + 2 * fs + 16 +
+                                        (size_t)nbr * 64 + 64 + 16 + 64);
+#define BF_NLMS(NBM_, KPL_)                                                                                              \
+    hipLaunchKernelGGL((gsc_nlms_kernel<NBM_, KPL_>), dim3((unsigned)n_streams), dim3(64), lds, s, aligned, y, state,    \
+                       n_samples, n_mics, fs, cfg.gsc_use_vad, cfg.gsc_vad_threshold, cfg.gsc_mu0, cfg.gsc_mu_max)
+#define BF_NLMS_K(NBM_)                     \
+    do {                                    \
+        if (kpl <= 1) BF_NLMS(NBM_, 1);     \
+        else if (kpl <= 2) BF_NLMS(NBM_, 2);\
+        else BF_NLMS(NBM_, 4);              \
+    } while (0)
+    if (nb <= 1) BF_NLMS_K(1);
+    else if (nb <= 3) BF_NLMS_K(3);
+    else if (nb <= 7) BF_NLMS_K(7);
+    else BF_NLMS_K(15);
+#undef BF_NLMS_K
+#undef BF_NLMS
+    return hipGetLastError();
+}
+
+hipError_t launch_gsc_align(const BinsArgs &a, hipStream_t s) {
+    const long total = (long)a.n_streams * a.n_frames * kNQ;
+    hipLaunchKernelGGL(gsc_align_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace bf

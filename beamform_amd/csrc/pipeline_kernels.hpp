@@ -45,6 +45,14 @@ struct BinsArgs {
     unsigned long long gss_reset_mask;  // bit d: look direction d re-initialises W = C^H (gss.cpp:90-93) in this batch
 };
 hipError_t launch_bins(const BinsArgs &a, int n_cus, hipStream_t s);
+// per-node launchers behind launch_bins (one translation unit per kernel family)
+hipError_t launch_pointwise(const BinsArgs &a, hipStream_t s);              // das (fp64), phase: mask_kernels.hip
+hipError_t launch_phasempf(const BinsArgs &a, int n_cus, hipStream_t s);    // mask_kernels.hip
+hipError_t launch_mcra_node(const BinsArgs &a, hipStream_t s);              // mask_kernels.hip
+hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s);   // cov_kernels.hip
+hipError_t launch_gss(const BinsArgs &a, int n_cus, hipStream_t s);         // gsc_gss_kernels.hip
+hipError_t launch_gsc_align(const BinsArgs &a, hipStream_t s);              // gsc_gss_kernels.hip
+hipError_t launch_expand_spectrum(const f64x2 *Yh, f64x2 *spectrum, long frames, hipStream_t s);  // stft_istft.hip
 
 struct IstftArgs {
     const f64x2 *Yh;

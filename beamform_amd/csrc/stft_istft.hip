@@ -1,0 +1,347 @@
+// stft_istft.hip -- the two ends of the fp64 bin pipeline: STFT (window + forward FFTs, packed pair spectra to HBM), ISTFT
+// (Hermitian extension, backward FFT, synthesis window, overlap-add), the full-spectrum dump and phasempf's output smoothing.
+#include "bins_common.hpp"
+
+namespace bf {
+
+namespace {
+
+// ======================================================================================
+//                                        STFT
+// ======================================================================================
+constexpr int kStftBlock = 256;
+constexpr int kStftHalves = kStftBlock / 32;
+
+template <int LAYOUT>
+__global__ __launch_bounds__(kStftBlock) void stft_kernel(StftArgs a) {
+    __shared__ __attribute__((aligned(16))) double lds[2048 + kStftHalves * 32 * kPSd + 32 * kPSd];
+    const cx<double> *s_tw = reinterpret_cast<const cx<double> *>(lds);
+    double *s_win = lds + 2048 + kStftHalves * 32 * kPSd;
+    const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
+    double *pbuf = lds + 2048 + hw * 32 * kPSd;
+    {
+        const double *twf = reinterpret_cast<const double *>(a.tw);
+        for (int i = tid; i < 2048; i += kStftBlock) lds[i] = twf[i];
+        for (int i = tid; i < kN; i += kStftBlock) s_win[(i & 31) * kPSd + (i >> 5)] = a.win[i];
+    }
+    __syncthreads();
+    const int M = a.n_mics, MF = a.n_fft_mics, NP = (MF + 1) >> 1;
+    const long total = (long)a.n_streams * a.n_frames * NP;
+    const long stride = (long)gridDim.x * kStftHalves;
+    const long rounds = (total + stride - 1) / stride;
+    double re[32], im[32];
+    for (long r = 0; r < rounds; ++r) {
+        long item = r * stride + (long)blockIdx.x * kStftHalves + hw;
+        const bool ok = item < total;
+        if (!ok) item = total - 1;
+        const int p = (int)(item % NP);
+        const long st = item / NP;
+        const long t = st % a.n_frames;
+        const int s = (int)(st / a.n_frames);
+        const float *xs = a.x + (long)s * a.stream_stride_x;
+        const float *hs = a.hist + (long)s * M * kHop;
+        const int ma = 2 * p;
+        const bool b_ok = 2 * p + 1 < MF;
+        const int mb = b_ok ? 2 * p + 1 : ma;
+        if (LAYOUT == 0) {
+            const float *a1 = (t >= 1 ? xs + (long)ma * a.mic_stride + (t - 1) * kHop : hs + ma * kHop) + lane;
+            const float *b1 = (t >= 1 ? xs + (long)mb * a.mic_stride + (t - 1) * kHop : hs + mb * kHop) + lane;
+            const float *a2 = xs + (long)ma * a.mic_stride + t * kHop + lane;
+            const float *b2 = xs + (long)mb * a.mic_stride + t * kHop + lane;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                re[j] = (double)a1[32 * j];
+                im[j] = (double)b1[32 * j];
+                re[j + 16] = (double)a2[32 * j];
+                im[j + 16] = (double)b2[32 * j];
+            }
+        } else {
+            const float *s1 = (t >= 1 ? xs + (t - 1) * (long)kHop * M : hs) + (long)lane * M;
+            const float *s2 = xs + t * (long)kHop * M + (long)lane * M;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                re[j] = (double)s1[(long)32 * j * M + ma];
+                im[j] = (double)s1[(long)32 * j * M + mb];
+                re[j + 16] = (double)s2[(long)32 * j * M + ma];
+                im[j + 16] = (double)s2[(long)32 * j * M + mb];
+            }
+        }
+        const double bs = b_ok ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const double h = s_win[lane * kPSd + j];
+            re[j] *= h;          // buf[j]*hann_win[i]  (util.h:235)
+            im[j] *= h * bs;
+        }
+        fft1024p_fwd_A<double>(re, im, lane, s_tw, pbuf);
+        __builtin_amdgcn_wave_barrier();
+        fft1024p_B<double>(re, lane, pbuf);
+        __builtin_amdgcn_wave_barrier();
+        fft1024p_C<double, false>(im, lane, pbuf);
+        __builtin_amdgcn_wave_barrier();
+        fft1024p_D<double, -1>(re, im, lane, pbuf);
+        __builtin_amdgcn_wave_barrier();
+        if (ok) {
+            f64x2 *zo = a.Z + (((long)s * a.frames_ws + a.frame_off + t) * NP + p) * kN + lane;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int row = 32 * brev5(i);  // bins row .. row+31 of this store
+                if (row > a.skip_lo && row + 31 < a.skip_hi) continue;  // band-limited nodes never read these bins
+                zo[row] = f64x2{re[i], im[i]};
+            }
+        }
+    }
+}
+
+// ======================================================================================
+//                                        ISTFT
+// ======================================================================================
+constexpr int kIstftBlock = 256;
+constexpr int kIstftHalves = kIstftBlock / 32;
+
+// Hermitian part of y_fft at bin k (0..1023) from the per-bin kernels' output row.
+__device__ __forceinline__ cd herm_at(const f64x2 *row, int k) {
+    if (k == 0 || k == 512) return cd{row[k].x, 0.0};
+    if (k == 511) {
+        const cd u = ld(row + 511), v = conj(ld(row + 513));
+        return (u + v) * 0.5;
+    }
+    if (k == 513) {
+        const cd u = ld(row + 513), v = conj(ld(row + 511));
+        return (u + v) * 0.5;
+    }
+    if (k < 512) return ld(row + k);
+    return conj(ld(row + (kN - k)));
+}
+
+__global__ __launch_bounds__(kIstftBlock) void istft_kernel(IstftArgs a, int pairs_per_chunk, int chunks_per_stream) {
+    __shared__ __attribute__((aligned(16))) double lds[2048 + kIstftHalves * 32 * kPSd + 32 * kPSd];
+    const cx<double> *s_tw = reinterpret_cast<const cx<double> *>(lds);
+    double *s_win = lds + 2048 + kIstftHalves * 32 * kPSd;
+    const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
+    double *pbuf = lds + 2048 + hw * 32 * kPSd;
+    {
+        const double *twf = reinterpret_cast<const double *>(a.tw);
+        for (int i = tid; i < 2048; i += kIstftBlock) lds[i] = twf[i];
+        for (int i = tid; i < kN; i += kIstftBlock) s_win[(i & 31) * kPSd + (i >> 5)] = a.win[i];
+    }
+    __syncthreads();
+    const long chunk = (long)blockIdx.x * kIstftHalves + hw;
+    int s = (int)(chunk / chunks_per_stream);
+    const long c_in_s = chunk - (long)s * chunks_per_stream;
+    const bool chunk_ok = s < a.n_streams;
+    if (!chunk_ok) s = a.n_streams - 1;
+    const long t0 = c_in_s * 2L * pairs_per_chunk;  // first frame of this run (even)
+    const f64x2 *Ys = a.Yh + (long)s * a.n_frames * kYhStride;
+    float *ys = a.y + (long)s * a.n_frames * kHop;
+
+    float tail[16];  // second half of the previous frame, as float (out_buff[0], util.h:302)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tail[q] = 0.f;
+    double re[32], im[32];
+
+    for (int it = 0; it <= pairs_per_chunk; ++it) {
+        const long ta = t0 - 2 + 2L * it;  // frames (ta, ta+1); it == 0 is the warm-up pair
+        const bool va = ta >= 0 && ta < a.n_frames;
+        const bool vb = ta + 1 >= 0 && ta + 1 < a.n_frames;
+        const f64x2 *ra = Ys + (va ? ta : 0) * kYhStride;
+        const f64x2 *rb = Ys + (vb ? ta + 1 : 0) * kYhStride;
+        float oa[32], ob[32];
+        // Two frames share one complex IFFT (Ya + i*Yb -> re = frame a, im = frame b).  A frame the
+        // reference turns into NaN/Inf (mvdr/lcmv: inverse of an all-zero covariance) would
+        // poison its partner through the shared transform, so such pairs are transformed one at a time.
+        // Hermitian extension of both rows straight into Ya + i*Yb.  Position i holds bin k = lane + 32*brev5(i): even i
+        // are bins < 512 (the stored row), odd i are bins >= 512 (conjugate of row[1024 - k]); only three positions touch
+        // the irregular bins 0 / 511 / 512 / 513 (quirk Q1), so the rest is branch-free.
+        auto load_pair = [&](bool useA, bool useB) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int kb = 32 * brev5(i);
+                cd u{0, 0}, v{0, 0};
+                if (kb < 512) {
+                    if (useA) u = ld(ra + kb + lane);
+                    if (useB) v = ld(rb + kb + lane);
+                } else {
+                    if (useA) u = conj(ld(ra + (kN - kb) - lane));
+                    if (useB) v = conj(ld(rb + (kN - kb) - lane));
+                }
+                if (i == 0 && lane == 0) {  // bin 0: real part only
+                    u.y = 0.0;
+                    v.y = 0.0;
+                }
+                if (i == 1) {  // bins 512 (lane 0: real part only) and 513 (lane 1: (Y[513] + conj Y[511]) / 2)
+                    if (lane == 0) {
+                        u.y = 0.0;
+                        v.y = 0.0;
+                    } else if (lane == 1) {
+                        if (useA) u = (ld(ra + 513) + u) * 0.5;
+                        if (useB) v = (ld(rb + 513) + v) * 0.5;
+                    }
+                }
+                if (i == 30 && lane == 31) {  // bin 511: (Y[511] + conj Y[513]) / 2
+                    if (useA) u = (u + conj(ld(ra + 513))) * 0.5;
+                    if (useB) v = (v + conj(ld(rb + 513))) * 0.5;
+                }
+                re[i] = u.x - v.y;  // Ya + i*Yb
+                im[i] = u.y + v.x;
+            }
+        };
+        load_pair(va, vb);
+        bool bad = false;  // a non-finite value in either frame makes the combination non-finite
+#pragma unroll
+        for (int i = 0; i < 32; ++i) bad = bad || !(isfinite(re[i]) && isfinite(im[i]));
+        const bool split = __any(bad ? 1 : 0) != 0;
+        for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
+            const bool useA = va && (!split || pass == 0);
+            const bool useB = vb && (!split || pass == 1);
+            if (split) load_pair(useA, useB);  // rare: one frame at a time
+            fft1024p_inv_A<double>(re, im, lane, s_tw, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_B<double>(re, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_C<double, true>(im, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_D<double, +1>(re, im, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+
+            // position i: sample n = 32*brev5(i) + lane.  re -> frame ta, im -> frame ta+1.
+            // overlap_and_add_prepare_output (util.h:247-252) with the reference's float stores.
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const double h = s_win[lane * kPSd + brev5(i)];
+                float fa = (float)(re[i] / 1024.0);
+                fa = (float)((double)fa * h);
+                float fb = (float)(im[i] / 1024.0);
+                fb = (float)((double)fb * h);
+                if (a.use_post_amp) {  // mvdr.cpp:112-114
+                    fa = (float)((double)fa * a.post_amp);
+                    fb = (float)((double)fb * a.post_amp);
+                }
+                if (useA || (!va && pass == 0)) oa[i] = fa;
+                if (useB || (!vb && pass == 0)) ob[i] = fb;
+            }
+        }
+        const bool st_a = chunk_ok && it > 0 && va;
+        const bool st_b = chunk_ok && it > 0 && vb;
+        if (it == 0 && t0 == 0) {  // stream start: tail comes from the carried state, not from frame -1
+            const float *ti = a.tail_in + (long)s * kHop + lane;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tail[q] = ti[32 * brev5(2 * q)];
+        } else if (it == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tail[q] = ob[2 * q + 1];
+        }
+        if (it > 0) {
+            if (st_a) {
+                float *yo = ys + ta * kHop + lane;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) yo[32 * brev5(2 * q)] = tail[q] + oa[2 * q];
+            }
+            if (st_b) {
+                float *yo = ys + (ta + 1) * kHop + lane;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) yo[32 * brev5(2 * q)] = oa[2 * q + 1] + ob[2 * q];
+            }
+            if (st_a && ta == a.n_frames - 1) {  // odd frame count: the batch ends on frame a
+                float *to = a.tail_out + (long)s * kHop + lane;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) to[32 * brev5(2 * q)] = oa[2 * q + 1];
+            }
+            if (st_b && ta + 1 == a.n_frames - 1) {
+                float *to = a.tail_out + (long)s * kHop + lane;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) to[32 * brev5(2 * q)] = ob[2 * q + 1];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tail[q] = ob[2 * q + 1];
+        }
+    }
+}
+
+// full 1024-bin y_fft dump from the per-problem rows
+__global__ void expand_spectrum_kernel(const f64x2 *Yh, f64x2 *out, long frames_total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= frames_total * kN) return;
+    const long f = idx / kN;
+    const int j = (int)(idx - f * kN);
+    const f64x2 *row = Yh + f * kYhStride;
+    f64x2 v;
+    if (j <= 513) {
+        v = row[j];
+    } else {
+        v = row[kN - j];
+        v.y = -v.y;
+    }
+    out[idx] = v;
+}
+
+__global__ void smooth_kernel(const float *yraw, float *y, const double *state, long n, int n_streams, int sz) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n_streams) return;
+    const int s = (int)(idx / n);
+    const long i = idx - (long)s * n;
+    const float *yr = yraw + (long)s * n;
+    const double *st = state + (long)s * 64;  // st[63] = most recent raw sample before this batch
+    double acc = 0.0;
+    for (int k = sz - 1; k >= 0; --k) {  // oldest first, as get_mean() sums past_samples[0..]
+        const long src = i - k;
+        const double v = src >= 0 ? (double)yr[src] : st[64 + src];
+        acc += v;
+    }
+    y[idx] = (float)(acc / (double)sz);
+}
+__global__ void smooth_state_kernel(const float *yraw, double *state, long n, int n_streams) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 64 * n_streams) return;
+    const int s = idx / 64, k = idx % 64;
+    const long src = n - 64 + k;
+    // n >= 512 always (one hop), so the new state is entirely inside this batch
+    state[(long)s * 64 + k] = (double)yraw[(long)s * n + src];
+}
+
+}  // namespace
+
+hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
+    const long total = (long)a.n_streams * a.n_frames * ((a.n_fft_mics + 1) / 2);
+    long blocks = (total + kStftHalves - 1) / kStftHalves;
+    const long cap = (long)n_cus * 4;
+    if (blocks > cap) blocks = cap;
+    if (a.layout == 0)
+        hipLaunchKernelGGL(stft_kernel<0>, dim3((unsigned)blocks), dim3(kStftBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL(stft_kernel<1>, dim3((unsigned)blocks), dim3(kStftBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s) {
+    const long pairs = (a.n_frames + 1) / 2;
+    long slots = (long)n_cus * kIstftHalves * 2 / a.n_streams;
+    if (slots < 1) slots = 1;
+    long cps = slots < pairs ? slots : pairs;
+    const long ppc = (pairs + cps - 1) / cps;
+    cps = (pairs + ppc - 1) / ppc;
+    const long chunks = cps * a.n_streams;
+    hipLaunchKernelGGL(istft_kernel, dim3((unsigned)((chunks + kIstftHalves - 1) / kIstftHalves)), dim3(kIstftBlock), 0, s, a,
+                       (int)ppc, (int)cps);
+    return hipGetLastError();
+}
+
+hipError_t launch_smooth(const float *yraw, float *y, double *state, long n_frames, int n_streams, int smooth_size,
+                         hipStream_t s) {
+    const long n = n_frames * kHop;
+    const long total = n * n_streams;
+    hipLaunchKernelGGL(smooth_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, yraw, y, state, n, n_streams,
+                       smooth_size);
+    hipLaunchKernelGGL(smooth_state_kernel, dim3((unsigned)((64 * n_streams + 255) / 256)), dim3(256), 0, s, yraw, state, n,
+                       n_streams);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand_spectrum(const f64x2 *Yh, f64x2 *spectrum, long frames, hipStream_t s) {
+    hipLaunchKernelGGL(expand_spectrum_kernel, dim3((unsigned)((frames * kN + 255) / 256)), dim3(256), 0, s, Yh, spectrum, frames);
+    return hipGetLastError();
+}
+
+}  // namespace bf
