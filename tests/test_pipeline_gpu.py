@@ -72,7 +72,11 @@ def test_phase_matches_oracle(M, theta, F):
 
 @pytest.mark.parametrize("algo,M,interf,F", [("mvdr", 8, (), 48), ("mvdr", 3, (), 30), ("mvdr", 16, (), 26),
                                               ("lcmv", 8, (-60.0, 90.0), 40), ("lcmv", 16, (-60.0, 90.0, 150.0), 26),
-                                              ("lcmv", 4, (), 20)])
+                                              ("lcmv", 4, (), 20),
+                                              # padded microphone counts of every kernel mapping
+                                              ("mvdr", 7, (), 30), ("mvdr", 5, (), 24), ("mvdr", 12, (), 24), ("mvdr", 9, (), 22),
+                                              ("lcmv", 6, (-60.0,), 30), ("lcmv", 3, (90.0,), 24), ("lcmv", 12, (-60.0, 90.0), 24),
+                                              ("lcmv", 11, (150.0,), 22), ("lcmv", 16, (), 20), ("lcmv", 4, (-60.0, 90.0, 150.0), 20)])  # K + 1 = M: the most constraints that leave G = C^H R^-1 C regular
 def test_mvdr_lcmv_match_oracle(algo, M, interf, F):
     import oracle
     p = make_params(algo, n_mics=M, interf=interf, theta=20.0)
