@@ -35,13 +35,14 @@ def _check_line(d, n):
 
 
 def test_bench_single_gpu_line():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--cpu-frames", "256"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--cpu-frames", "256", "--cpu-all-cores-frames", "512"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
     _check_line(d, 1)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "frames/s"
+    assert c["all_cores"]["cores"] == os.cpu_count() and c["all_cores"]["value"] > c["value"]
 
 
 def test_bench_two_ranks_through_the_launcher():
@@ -53,3 +54,4 @@ def test_bench_two_ranks_through_the_launcher():
     d = _last_json(out.stdout)
     _check_line(d, 2)
     assert d["config"]["final_gather_ms"] is not None and d["config"]["final_gather_ms"] >= 0
+    assert d["cpu_baseline"] is None  # rank 0 at N = 1 only
