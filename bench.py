@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=81920,
                     help="frames in the CPU-baseline sample (0 = skip); the default is ~11 s of single-core work")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-all-cores-frames", type=int, default=4096,
+    ap.add_argument("--cpu-all-cores-frames", type=int, default=2048,
                     help="frames per host core in the all-cores CPU baseline (0 = skip)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary mvdr measurement")
     args = ap.parse_args()
