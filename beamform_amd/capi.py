@@ -26,7 +26,7 @@ EXPORTS = (
     "bf_version", "bf_strerror", "bf_last_error", "bf_device_count", "bf_config_init", "bf_config_load_yaml",
     "bf_config_parse_yaml", "bf_create", "bf_destroy", "bf_set_theta", "bf_set_interference", "bf_process_hop",
     "bf_process_batch", "bf_process_batch_device", "bf_get_weights", "bf_state_size", "bf_get_state", "bf_set_state",
-    "bf_reset", "bf_time_batch_device", "bf_n_interferers", "bf_set_theta_dir", "bf_set_thetas", "bf_stream_rms",
+    "bf_reset", "bf_time_batch_device", "bf_n_interferers", "bf_set_theta_dir", "bf_set_thetas", "bf_stream_rms", "bf_host_alloc", "bf_host_free",
 )
 
 
@@ -92,6 +92,10 @@ def load():
     L.bf_n_interferers.argtypes = [C.c_void_p]
     L.bf_process_hop.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32]
     L.bf_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.bf_host_alloc.restype = C.c_void_p
+    L.bf_host_alloc.argtypes = [C.c_size_t]
+    L.bf_host_free.argtypes = [C.c_void_p]
+    L.bf_host_free.restype = None
     L.bf_process_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bf_get_weights.argtypes = [C.c_void_p, C.c_void_p]
     L.bf_state_size.restype = C.c_size_t
@@ -130,6 +134,20 @@ def config_from_params(p: dict, device: int = 0, n_streams: int = 1, layout: int
         setattr(c, k, p[k] if k in p else _LATER_KEYS[k])  # fixtures written before a key existed
     c.device, c.n_streams, c.layout, c.das_impl, c.n_dirs = device, n_streams, layout, das_impl, n_dirs
     return c
+
+
+def host_array(shape, dtype=np.float32):
+    """numpy array over page-locked memory from bf_host_alloc (freed when the array is collected)."""
+    L = load()
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    ptr = L.bf_host_alloc(n)
+    if not ptr:
+        raise MemoryError("bf_host_alloc failed")
+    buf = (C.c_char * n).from_address(ptr)
+    arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+    import weakref
+    weakref.finalize(buf, L.bf_host_free, ptr)
+    return arr
 
 
 class Beamformer:
@@ -202,12 +220,14 @@ class Beamformer:
         self._chk(self._L.bf_process_hop(self._h, ptrs, out.ctypes.data, self.H), "bf_process_hop")
         return out[0] if self.n_dirs == 1 else out
 
-    def process(self, x: np.ndarray) -> np.ndarray:
+    def process(self, x: np.ndarray, out: np.ndarray = None) -> np.ndarray:
         """Host batch. planar: x [S, M, F*H] (or [M, F*H] when S == 1); interleaved: [S, F*H, M]."""
         x = np.ascontiguousarray(x, np.float32)
         n = x.size // (self.n_streams * self.M * self.H)
-        y = np.empty((self.n_out, n * self.H), np.float32)
+        y = np.empty((self.n_out, n * self.H), np.float32) if out is None else out
+        assert y.dtype == np.float32 and y.size == self.n_out * n * self.H and y.flags.c_contiguous
         self._chk(self._L.bf_process_batch(self._h, x.ctypes.data, n, y.ctypes.data), "bf_process_batch")
+        y = y.reshape(self.n_out, n * self.H)
         return y[0] if self.n_out == 1 else y
 
     def process_device(self, x_ptr: int, n_frames: int, y_ptr: int, spectrum_ptr: int = 0, stream: int = 0):

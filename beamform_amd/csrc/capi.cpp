@@ -61,6 +61,9 @@ struct bf_handle {
     // staging for the host-buffer entry points
     float *d_x = nullptr, *d_y = nullptr;
     size_t d_x_cap = 0, d_y_cap = 0;
+    // bf_process_batch pipelining: copies on their own streams, chunk by chunk, around the compute stream
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    std::vector<hipEvent_t> ev_in, ev_out;
     float *h_pin = nullptr;  // pinned [n_mics*hop | n_out*hop]: bf_process_hop stages through it (no pageable-copy detour)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -374,6 +377,10 @@ void bf_destroy(bf_handle *h) {
     if (h->d_x) (void)hipFree(h->d_x);
     if (h->d_y) (void)hipFree(h->d_y);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
+    for (hipEvent_t e : h->ev_in) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_out) (void)hipEventDestroy(e);
+    if (h->s_h2d) (void)hipStreamDestroy(h->s_h2d);
+    if (h->s_d2h) (void)hipStreamDestroy(h->s_d2h);
     delete h->pipe;
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -495,6 +502,16 @@ int bf_process_batch_device(bf_handle *h, const float *x_dev, size_t n_frames, f
                             (long)n_frames * h->H);
 }
 
+void *bf_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void bf_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int bf_process_batch(bf_handle *h, const float *x_host, size_t n_frames, float *y_host) {
     if (!h || !x_host || !y_host) return BF_EINVAL;
     if (n_frames == 0) return BF_OK;
@@ -503,6 +520,49 @@ int bf_process_batch(bf_handle *h, const float *x_host, size_t n_frames, float *
     const size_t ye = (size_t)h->n_out * n_frames * h->H;
     int rc = ensure_staging(h, xe, ye);
     if (rc != BF_OK) return rc;
+    constexpr int kChunks = 8;
+    if (h->n_out == 1 && n_frames >= 8192) {
+        // One stream of a long batch: H2D of chunk c+1, compute of chunk c and D2H of chunk c-1 overlap (three HIP streams,
+        // events in between).  Consecutive chunks are consecutive batches of the same stream, so the carried state does the
+        // rest.  (Only page-locked host buffers -- bf_host_alloc -- make the copies truly asynchronous.)
+        if (!h->s_h2d) {
+            BF_HIP(h, hipStreamCreateWithFlags(&h->s_h2d, hipStreamNonBlocking));
+            BF_HIP(h, hipStreamCreateWithFlags(&h->s_d2h, hipStreamNonBlocking));
+            h->ev_in.resize(kChunks);
+            h->ev_out.resize(kChunks);
+            for (int c = 0; c < kChunks; ++c) {
+                BF_HIP(h, hipEventCreateWithFlags(&h->ev_in[c], hipEventDisableTiming));
+                BF_HIP(h, hipEventCreateWithFlags(&h->ev_out[c], hipEventDisableTiming));
+            }
+        }
+        const size_t F = n_frames, H = (size_t)h->H, M = (size_t)h->M;
+        const size_t cf = (F + kChunks - 1) / kChunks;
+        for (int c = 0; c < kChunks; ++c) {
+            const size_t c0 = (size_t)c * cf;
+            if (c0 >= F) break;
+            const size_t n = (c0 + cf <= F) ? cf : F - c0;
+            const float *xd;
+            if (h->cfg.layout == BF_PLANAR) {  // M rows of F*H samples: a chunk is a column block
+                BF_HIP(h, hipMemcpy2DAsync(h->d_x + c0 * H, F * H * sizeof(float), x_host + c0 * H, F * H * sizeof(float),
+                                           n * H * sizeof(float), M, hipMemcpyHostToDevice, h->s_h2d));
+                xd = h->d_x + c0 * H;
+            } else {
+                BF_HIP(h, hipMemcpyAsync(h->d_x + c0 * H * M, x_host + c0 * H * M, n * H * M * sizeof(float), hipMemcpyHostToDevice,
+                                         h->s_h2d));
+                xd = h->d_x + c0 * H * M;
+            }
+            BF_HIP(h, hipEventRecord(h->ev_in[c], h->s_h2d));
+            BF_HIP(h, hipStreamWaitEvent(h->stream, h->ev_in[c], 0));
+            rc = run_batch_device(h, xd, n, h->d_y + c0 * H, nullptr, h->stream, h->cfg.layout, (long)(F * H));
+            if (rc != BF_OK) return rc;
+            BF_HIP(h, hipEventRecord(h->ev_out[c], h->stream));
+            BF_HIP(h, hipStreamWaitEvent(h->s_d2h, h->ev_out[c], 0));
+            BF_HIP(h, hipMemcpyAsync(y_host + c0 * H, h->d_y + c0 * H, n * H * sizeof(float), hipMemcpyDeviceToHost, h->s_d2h));
+        }
+        BF_HIP(h, hipStreamSynchronize(h->s_d2h));
+        BF_HIP(h, hipStreamSynchronize(h->stream));
+        return BF_OK;
+    }
     BF_HIP(h, hipMemcpyAsync(h->d_x, x_host, xe * sizeof(float), hipMemcpyHostToDevice, h->stream));
     rc = run_batch_device(h, h->d_x, n_frames, h->d_y, nullptr, h->stream, h->cfg.layout, (long)n_frames * h->H);
     if (rc != BF_OK) return rc;

@@ -252,7 +252,12 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                 asm volatile("" ::: "memory");
                 const float *prev = s_tails + pv * kHop + lane;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) yo[32 * brev5(2 * q)] = prev[32 * brev5(2 * q)] + Sr[2 * q] * h[brev5(2 * q)];
+                for (int q = 0; q < 16; ++q) {
+                    // product and sum rounded separately, as the reference's two float stores (util.h:250-252, 302) and as the
+                    // atomic run-boundary path does: results do not depend on how a stream is cut into batches and runs
+#pragma clang fp contract(off)
+                    yo[32 * brev5(2 * q)] = prev[32 * brev5(2 * q)] + Sr[2 * q] * h[brev5(2 * q)];
+                }
             }
             if (t == T1 - 1) {
                 if (T1 < a.n_frames) {  // last frame of the run: its second half belongs to the next run's first hop

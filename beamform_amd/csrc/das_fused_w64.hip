@@ -240,7 +240,10 @@ __global__ __launch_bounds__(kBlock) void das_fused_w64_kernel(DasFusedArgs a) {
                 for (int j = 0; j < 8; ++j) atomicAdd(yo + 64 * j, Sr[j] * h[j]);
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) yo[64 * j] = prev[64 * j] + Sr[j] * h[j];
+                for (int j = 0; j < 8; ++j) {
+#pragma clang fp contract(off)
+                    yo[64 * j] = prev[64 * j] + Sr[j] * h[j];
+                }
             }
             if (t == T1 - 1) {
                 if (T1 < a.n_frames) {

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void gsc_align_kernel(BinsArgs a) {
 // Pass 2 (NLMS): one wavefront per stream, strictly sample by sample.  The reference does this arithmetic in
 // float32 (rosjack_data) with every product and sum rounded separately and the 128-tap sums taken in order, and
 // it branches on the results (mu selection, NaN guards), so the kernel keeps exactly that order: lane i owns
-// blocking branch i and walks its taps sequentially (__fmul_rn/__fadd_rn: no FMA contraction), lane M-1 does
+// blocking branch i and walks its taps sequentially (plain * and + under `#pragma clang fp contract(off)`: no FMA contraction), lane M-1 does
 // the same for the output-power window.  Only what is elementwise is spread over the lanes: the upper beamformer
 // and the neighbour differences of a 64-sample tile (lane = sample), and the filter update (lane = tap), whose
 // coefficients live in registers with a write-through copy in LDS for the serial walk.
@@ -50,6 +50,9 @@ __global__ __launch_bounds__(256) void gsc_align_kernel(BinsArgs a) {
 template <int NBM, int KPL>  // NBM >= blocking branches (M - 1), KPL >= ceil(filter_size / 64)
 __global__ __launch_bounds__(64) void gsc_nlms_kernel(const float *aligned, float *y, float *state, long n, int M, int fs,
                                                       int use_vad, double vad_threshold, double mu0, double mu_max) {
+    // every float product and sum below must round on its own, as the reference's x86 build does; the __fmul_rn / __fadd_rn
+    // intrinsics do NOT guarantee that (they inline to a*b / a+b with the caller's contraction allowed), this pragma does
+#pragma clang fp contract(off)
     extern __shared__ float gl[];
     const int lane = threadIdx.x;
     const int nb = M - 1;                 // blocking branches
@@ -100,11 +103,11 @@ __global__ __launch_bounds__(64) void gsc_nlms_kernel(const float *aligned, floa
         {   // tile prologue, lane = sample: das_out (gsc.cpp:122-127) and the blocking-matrix inputs (gsc.cpp:131)
             const bool ok = n0 + lane < n;
             float prev = ok ? as[n0 + lane] : 0.f, das = 0.f;
-            das = __fadd_rn(das, prev);
+            das = (das + prev);
             for (int m = 1; m < M; ++m) {
                 const float cur = ok ? as[(long)m * n + n0 + lane] : 0.f;
-                das = __fadd_rn(das, cur);
-                s_d[(m - 1) * 64 + lane] = __fsub_rn(cur, prev);
+                das = (das + cur);
+                s_d[(m - 1) * 64 + lane] = (cur - prev);
                 prev = cur;
             }
             s_das[lane] = __fdiv_rn(das, (float)M);
@@ -150,23 +153,23 @@ __global__ __launch_bounds__(64) void gsc_nlms_kernel(const float *aligned, floa
                     }
 #pragma unroll
                     for (int r = 0; r < 8; ++r) {
-                        bo = __fadd_rn(bo, __fmul_rn(wv[r], uv[r]));
-                        pw = __fadd_rn(pw, __fmul_rn(uv[r], uv[r]));
+                        bo = (bo + (wv[r] * uv[r]));
+                        pw = (pw + (uv[r] * uv[r]));
                     }
                 }
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {  // leftover taps, already staged
                     if (k + r < fs - 1 || (k + r == fs - 1 && !is_lo)) {
-                        bo = __fadd_rn(bo, __fmul_rn(wn[r], un[r]));
-                        pw = __fadd_rn(pw, __fmul_rn(un[r], un[r]));
+                        bo = (bo + (wn[r] * un[r]));
+                        pw = (pw + (un[r] * un[r]));
                     }
                 }
             }
             float out = das;
             for (int i = 0; i < nb; ++i)
-                out = __fsub_rn(out, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bo), i)));
+                out = out - __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bo), i));
             const float pwl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pw), nb));
-            const float lop = __fsqrt_rn(__fdiv_rn(__fadd_rn(pwl, __fmul_rn(out, out)), fsz));  // calculate_power(last_outputs)
+            const float lop = __fsqrt_rn(__fdiv_rn((pwl + (out * out)), fsz));  // calculate_power(last_outputs)
             if (lane == 0) {
                 s_lo[h] = out;
                 s_lo[h + fs] = out;
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(64) void gsc_nlms_kernel(const float *aligned, floa
                     else
                         mu = (float)(mu0 / (double)bp);
                     if (isnan(mu) || isinf(mu)) mu = 0.f;
-                    s_c[lane] = __fmul_rn(mu, out);
+                    s_c[lane] = (mu * out);
                 }
                 __builtin_amdgcn_wave_barrier();
                 // filter[i][k] += this_mu*out[j]*block_matrix[i][k] (gsc.cpp:163-170), taps over the lanes:
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(64) void gsc_nlms_kernel(const float *aligned, floa
                     if (i < nb) {  // uniform
 #pragma unroll
                         for (int c = 0; c < KPL; ++c) {  // lanes past filter_size work on row padding nobody reads
-                            float fv = __fadd_rn(freg[i][c], __fmul_rn(cv[i], bmv[i][c]));
+                            float fv = (freg[i][c] + (cv[i] * bmv[i][c]));
                             if (isnan(fv)) fv = 0.f;
                             freg[i][c] = fv;
                             s_f[i * fstride + lane + 64 * c] = fv;
