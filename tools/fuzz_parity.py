@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""One-off randomized parity sweep against the oracle (not part of the test suite): random node, microphone count,
+angles, interferers, batch splits, layouts."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import oracle
+from beamform_amd.capi import Beamformer, BF_PLANAR, BF_INTERLEAVED
+from beamform_amd.params import make_params
+from beamform_amd.synth import make_scene
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+worst = {}
+for case in range(n_cases):
+    algo = rng.choice(["das", "mvdr", "lcmv", "gss", "phase", "phasempf", "mcra", "gsc"])
+    M = int(rng.integers(1 if algo in ("das", "mcra", "gsc", "phase") else 2, 17))
+    K = int(rng.integers(0, min(3, M - 1) + 1)) if algo in ("lcmv", "gss") else 0
+    interf = tuple(float(a) for a in rng.choice([-150.0, -100.0, -60.0, -20.0, 45.0, 90.0, 150.0], size=K, replace=False))
+    theta = float(rng.uniform(-180, 180))
+    F = int(rng.integers(3, 40 if algo != "gsc" else 10))
+    over = {}
+    if algo in ("phasempf", "mcra") and rng.random() < 0.5:
+        over["mcra_L"] = int(rng.integers(3, 15))
+    if algo == "gsc":
+        over["gsc_filter_size"] = int(rng.choice([16, 50, 64, 128, 200]))
+    p = make_params(algo, n_mics=M, theta=theta, interf=interf, **over)
+    x = make_scene(M, F, seed=int(rng.integers(1 << 30)), theta_s=float(rng.uniform(-180, 180)))
+    layout = BF_INTERLEAVED if rng.random() < 0.3 else BF_PLANAR
+    node = oracle.OracleNode(p)
+    bf = Beamformer(p, layout=layout)
+    cuts = sorted(set([0, F] + [int(c) for c in rng.integers(1, F, size=int(rng.integers(0, 3)))]))
+    ys, refs = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if rng.random() < 0.3:
+            t2 = float(rng.uniform(-180, 180))
+            node.set_theta(t2); bf.set_theta(t2)
+        seg = np.ascontiguousarray(x[:, a * 512:b * 512])
+        refs.append(node.process(seg)[0])
+        ys.append(bf.process(seg if layout == BF_PLANAR else np.ascontiguousarray(seg.T)))
+    y, r = np.concatenate(ys), np.concatenate(refs)
+    ok = np.isfinite(r)
+    same_nan = bool((np.isfinite(y) == ok).all())
+    err = float(np.linalg.norm(y[ok] - r[ok]) / (np.linalg.norm(r[ok]) + 1e-300))
+    tag = "ok" if (same_nan and err < 1e-5) else "FAIL"
+    worst[algo] = max(worst.get(algo, 0.0), err)
+    if tag == "FAIL":
+        print(f"{tag} case {case}: {algo} M={M} K={K} theta={theta:.1f} F={F} cuts={cuts} layout={layout} over={over} err={err:.2e} nan_ok={same_nan}")
+print("worst relative L2 per node:", {k: f"{v:.1e}" for k, v in sorted(worst.items())})
