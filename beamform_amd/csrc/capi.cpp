@@ -105,9 +105,12 @@ void rebuild_steering(bf_handle *h, bool first, int only_dir = -1) {
 
 // Upload whatever set_theta changed; stream-ordered, double-buffered so a batch
 // already in flight keeps reading the table it was launched with.
-int sync_tables(bf_handle *h, hipStream_t s) {
+int sync_tables(bf_handle *h, hipStream_t s, RunSnapshot *snap) {
     std::lock_guard<std::mutex> lk(h->mu);
-    if (!h->tables_dirty) return BF_OK;
+    if (!h->tables_dirty) {
+        if (h->pipe) *snap = h->pipe->snapshot_for_run();
+        return BF_OK;
+    }
     if (uses_fused_das(h)) {
         const int np = (h->M + 1) / 2;
         std::vector<f32x2> g, g64;  // [dir][pair][1024]
@@ -131,6 +134,8 @@ int sync_tables(bf_handle *h, hipStream_t s) {
         if (rc != BF_OK) return fail(h, rc, h->pipe->error().c_str());
     }
     h->tables_dirty = false;
+    // one consistent view of {columns, table, pending gss resets} for this batch, taken under the same lock
+    if (h->pipe) *snap = h->pipe->snapshot_for_run();
     return BF_OK;
 }
 
@@ -197,10 +202,11 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
 int run_batch_device(bf_handle *h, const float *x_dev, size_t n_frames, float *y_dev, void *spectrum_dev, hipStream_t s,
                      int layout, long mic_stride) {
     if (n_frames == 0) return BF_OK;
-    int rc = sync_tables(h, s);
+    RunSnapshot snap;
+    int rc = sync_tables(h, s, &snap);
     if (rc != BF_OK) return rc;
     if (uses_fused_das(h)) return run_das_fused(h, x_dev, n_frames, y_dev, spectrum_dev, s, layout, mic_stride);
-    rc = h->pipe->run(x_dev, (long)n_frames, y_dev, (f64x2 *)spectrum_dev, s, layout, mic_stride);
+    rc = h->pipe->run(x_dev, (long)n_frames, y_dev, (f64x2 *)spectrum_dev, s, layout, mic_stride, snap);
     if (rc != BF_OK) return fail(h, rc, h->pipe->error().c_str());
     return BF_OK;
 }
@@ -400,6 +406,7 @@ int bf_reset(bf_handle *h) {
         BF_HIP(h, hipMemset(h->d_tail[1], 0, (size_t)h->n_out * h->H * sizeof(float)));
         h->tail_cur = 0;
     } else if (h->pipe) {
+        std::lock_guard<std::mutex> lk(h->mu);  // reset() re-arms the gss demixing reset, which /theta also writes
         int rc = h->pipe->reset();
         if (rc != BF_OK) return fail(h, rc, h->pipe->error().c_str());
     }
@@ -526,41 +533,66 @@ int bf_process_batch(bf_handle *h, const float *x_host, size_t n_frames, float *
         // events in between).  Consecutive chunks are consecutive batches of the same stream, so the carried state does the
         // rest.  (Only page-locked host buffers -- bf_host_alloc -- make the copies truly asynchronous.)
         if (!h->s_h2d) {
-            BF_HIP(h, hipStreamCreateWithFlags(&h->s_h2d, hipStreamNonBlocking));
-            BF_HIP(h, hipStreamCreateWithFlags(&h->s_d2h, hipStreamNonBlocking));
-            h->ev_in.resize(kChunks);
-            h->ev_out.resize(kChunks);
-            for (int c = 0; c < kChunks; ++c) {
-                BF_HIP(h, hipEventCreateWithFlags(&h->ev_in[c], hipEventDisableTiming));
-                BF_HIP(h, hipEventCreateWithFlags(&h->ev_out[c], hipEventDisableTiming));
+            // all-or-nothing: a half-built set must not survive a failed create (later calls would record on null events)
+            hipStream_t a = nullptr, b = nullptr;
+            std::vector<hipEvent_t> ei(kChunks, nullptr), eo(kChunks, nullptr);
+            hipError_t e = hipStreamCreateWithFlags(&a, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&b, hipStreamNonBlocking);
+            for (int c = 0; c < kChunks && e == hipSuccess; ++c) {
+                e = hipEventCreateWithFlags(&ei[c], hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&eo[c], hipEventDisableTiming);
             }
+            if (e != hipSuccess) {
+                for (hipEvent_t v : ei) if (v) (void)hipEventDestroy(v);
+                for (hipEvent_t v : eo) if (v) (void)hipEventDestroy(v);
+                if (a) (void)hipStreamDestroy(a);
+                if (b) (void)hipStreamDestroy(b);
+                return fail(h, BF_EIO, "bf_process_batch: copy streams / events", e);
+            }
+            h->s_h2d = a;
+            h->s_d2h = b;
+            h->ev_in.swap(ei);
+            h->ev_out.swap(eo);
         }
         const size_t F = n_frames, H = (size_t)h->H, M = (size_t)h->M;
         const size_t cf = (F + kChunks - 1) / kChunks;
-        for (int c = 0; c < kChunks; ++c) {
+        hipError_t e = hipSuccess;
+        rc = BF_OK;
+        const char *what = "";
+#define BF_CHUNK(call)                                   \
+        if (e == hipSuccess && rc == BF_OK) {            \
+            e = (call);                                  \
+            if (e != hipSuccess) what = #call;           \
+        }
+        for (int c = 0; c < kChunks && e == hipSuccess && rc == BF_OK; ++c) {
             const size_t c0 = (size_t)c * cf;
             if (c0 >= F) break;
             const size_t n = (c0 + cf <= F) ? cf : F - c0;
             const float *xd;
             if (h->cfg.layout == BF_PLANAR) {  // M rows of F*H samples: a chunk is a column block
-                BF_HIP(h, hipMemcpy2DAsync(h->d_x + c0 * H, F * H * sizeof(float), x_host + c0 * H, F * H * sizeof(float),
-                                           n * H * sizeof(float), M, hipMemcpyHostToDevice, h->s_h2d));
+                BF_CHUNK(hipMemcpy2DAsync(h->d_x + c0 * H, F * H * sizeof(float), x_host + c0 * H, F * H * sizeof(float),
+                                          n * H * sizeof(float), M, hipMemcpyHostToDevice, h->s_h2d));
                 xd = h->d_x + c0 * H;
             } else {
-                BF_HIP(h, hipMemcpyAsync(h->d_x + c0 * H * M, x_host + c0 * H * M, n * H * M * sizeof(float), hipMemcpyHostToDevice,
-                                         h->s_h2d));
+                BF_CHUNK(hipMemcpyAsync(h->d_x + c0 * H * M, x_host + c0 * H * M, n * H * M * sizeof(float), hipMemcpyHostToDevice,
+                                        h->s_h2d));
                 xd = h->d_x + c0 * H * M;
             }
-            BF_HIP(h, hipEventRecord(h->ev_in[c], h->s_h2d));
-            BF_HIP(h, hipStreamWaitEvent(h->stream, h->ev_in[c], 0));
-            rc = run_batch_device(h, xd, n, h->d_y + c0 * H, nullptr, h->stream, h->cfg.layout, (long)(F * H));
-            if (rc != BF_OK) return rc;
-            BF_HIP(h, hipEventRecord(h->ev_out[c], h->stream));
-            BF_HIP(h, hipStreamWaitEvent(h->s_d2h, h->ev_out[c], 0));
-            BF_HIP(h, hipMemcpyAsync(y_host + c0 * H, h->d_y + c0 * H, n * H * sizeof(float), hipMemcpyDeviceToHost, h->s_d2h));
+            BF_CHUNK(hipEventRecord(h->ev_in[c], h->s_h2d));
+            BF_CHUNK(hipStreamWaitEvent(h->stream, h->ev_in[c], 0));
+            if (e == hipSuccess)
+                rc = run_batch_device(h, xd, n, h->d_y + c0 * H, nullptr, h->stream, h->cfg.layout, (long)(F * H));
+            BF_CHUNK(hipEventRecord(h->ev_out[c], h->stream));
+            BF_CHUNK(hipStreamWaitEvent(h->s_d2h, h->ev_out[c], 0));
+            BF_CHUNK(hipMemcpyAsync(y_host + c0 * H, h->d_y + c0 * H, n * H * sizeof(float), hipMemcpyDeviceToHost, h->s_d2h));
         }
-        BF_HIP(h, hipStreamSynchronize(h->s_d2h));
-        BF_HIP(h, hipStreamSynchronize(h->stream));
+#undef BF_CHUNK
+        // success or not: nothing may still be copying from / into the caller's buffers when this returns
+        const hipError_t e1 = hipStreamSynchronize(h->s_h2d), e2 = hipStreamSynchronize(h->stream), e3 = hipStreamSynchronize(h->s_d2h);
+        if (rc != BF_OK) return rc;
+        if (e != hipSuccess) return fail(h, BF_EIO, what, e);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
+            return fail(h, BF_EIO, "bf_process_batch: stream synchronisation", e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3));
         return BF_OK;
     }
     BF_HIP(h, hipMemcpyAsync(h->d_x, x_host, xe * sizeof(float), hipMemcpyHostToDevice, h->stream));
@@ -630,7 +662,15 @@ struct bf_state_header {
     uint32_t magic, algo, n_mics, n_streams, hop, das_impl;
     uint64_t payload;
 };
-static const uint32_t kStateMagic = 0x42465354;  // "BFST"
+static const uint32_t kStateMagic = 0x42465332;  // "BFS2"
+// control-plane part of a checkpoint: what /theta and /theta_interference have made of the node since start-up
+struct bf_state_control {
+    uint32_t kp1;              // constraint columns (1 + interferers)
+    uint32_t row0_written;     // reference-mic weight row: 1 after a cold start, 0 after a structural change (quirk Q3)
+    uint64_t gss_pending;      // look directions whose demixing matrices restart at the next run (gss.cpp:90-93)
+    double theta[BF_MAX_DIRS];
+    double interf[BF_MAX_INTERF];
+};
 
 size_t bf_state_size(const bf_handle *h) {
     if (!h) return 0;
@@ -639,7 +679,7 @@ size_t bf_state_size(const bf_handle *h) {
         payload = ((size_t)h->n_streams * h->M * h->H + (size_t)h->n_out * h->H) * sizeof(float);
     else
         payload = h->pipe ? h->pipe->state_bytes() : 0;
-    return sizeof(bf_state_header) + payload;
+    return sizeof(bf_state_header) + sizeof(bf_state_control) + payload;
 }
 
 int bf_get_state(bf_handle *h, void *blob, size_t size) {
@@ -649,7 +689,18 @@ int bf_get_state(bf_handle *h, void *blob, size_t size) {
     bf_state_header hd = {kStateMagic, (uint32_t)h->cfg.algo, (uint32_t)h->M, (uint32_t)h->n_streams | ((uint32_t)h->n_dirs << 20),
                           (uint32_t)h->H, (uint32_t)h->cfg.das_impl, (uint64_t)(bf_state_size(h) - sizeof(bf_state_header))};
     memcpy(blob, &hd, sizeof(hd));
-    char *p = (char *)blob + sizeof(hd);
+    bf_state_control ct;
+    memset(&ct, 0, sizeof(ct));
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        ct.kp1 = (uint32_t)h->S;
+        ct.row0_written = h->steer[0].at(0, 0, 0) == cplxd(1.0, 0.0) ? 1u : 0u;
+        ct.gss_pending = h->pipe ? h->pipe->pending_resets() : 0ull;
+        for (int d = 0; d < h->n_dirs; ++d) ct.theta[d] = h->angle[d];
+        for (size_t k = 0; k < h->interf.size(); ++k) ct.interf[k] = h->interf[k];
+    }
+    memcpy((char *)blob + sizeof(hd), &ct, sizeof(ct));
+    char *p = (char *)blob + sizeof(hd) + sizeof(ct);
     if (uses_fused_das(h)) {
         const size_t hb = (size_t)h->n_streams * h->M * h->H * sizeof(float), tb = (size_t)h->n_out * h->H * sizeof(float);
         BF_HIP(h, hipMemcpy(p, h->d_hist[h->tail_cur], hb, hipMemcpyDeviceToHost));
@@ -667,9 +718,24 @@ int bf_set_state(bf_handle *h, const void *blob, size_t size) {
     if (hd.magic != kStateMagic || hd.algo != (uint32_t)h->cfg.algo || hd.n_mics != (uint32_t)h->M ||
         hd.n_streams != ((uint32_t)h->n_streams | ((uint32_t)h->n_dirs << 20)) || hd.hop != (uint32_t)h->H || hd.das_impl != (uint32_t)h->cfg.das_impl)
         return fail(h, BF_EINVAL, "state blob does not match this handle");
+    bf_state_control ct;
+    memcpy(&ct, (const char *)blob + sizeof(hd), sizeof(ct));
     BF_HIP(h, hipSetDevice(h->device));
     BF_HIP(h, hipDeviceSynchronize());
-    const char *p = (const char *)blob + sizeof(hd);
+    {
+        // the per-bin state (covariance history, demixing matrices) only means something together with the steering it
+        // was built under: restore the angles, the interferer list and the pending demixing resets with it
+        std::lock_guard<std::mutex> lk(h->mu);
+        if ((int)ct.kp1 != h->S) return fail(h, BF_EINVAL, "state blob was taken with a different number of interferers");
+        for (int d = 0; d < h->n_dirs; ++d) h->angle[d] = ct.theta[d];
+        for (size_t k = 0; k < h->interf.size(); ++k) h->interf[k] = ct.interf[k];
+        for (auto &st : h->steer)
+            for (int c = 0; c < st.n_cols; ++c)
+                for (int j = 0; j < st.n_fft; ++j) st.at(j, 0, c) = ct.row0_written ? cplxd(1.0, 0.0) : cplxd(0.0, 0.0);
+        rebuild_steering(h, false);
+        if (h->pipe) h->pipe->set_pending_resets(ct.gss_pending);
+    }
+    const char *p = (const char *)blob + sizeof(hd) + sizeof(ct);
     if (uses_fused_das(h)) {
         const size_t hb = (size_t)h->n_streams * h->M * h->H * sizeof(float), tb = (size_t)h->n_out * h->H * sizeof(float);
         BF_HIP(h, hipMemcpy(h->d_hist[h->tail_cur], p, hb, hipMemcpyHostToDevice));

@@ -93,7 +93,10 @@ class BinPipelineImpl : public BinPipeline {
         PIPE_HIP(hipMalloc((void **)&d_tail_[0], (size_t)So_ * 512 * sizeof(float)));
         PIPE_HIP(hipMalloc((void **)&d_tail_[1], (size_t)So_ * 512 * sizeof(float)));
         if (Phist_ > 0) PIPE_HIP(hipMalloc((void **)&d_zhist_, zhist_bytes()));
-        if (cfg_.algo == BF_GSS) PIPE_HIP(hipMalloc((void **)&d_gssW_, gss_bytes()));
+        if (cfg_.algo == BF_GSS) {
+            PIPE_HIP(hipMalloc((void **)&d_gssW_, gss_bytes()));
+            PIPE_HIP(hipMemset(d_gssW_, 0, gss_bytes()));  // defined content until the first run applies W = C^H
+        }
         if (cfg_.algo == BF_PHASEMPF || cfg_.algo == BF_MCRA) PIPE_HIP(hipMalloc((void **)&d_mpf_, mpf_bytes()));
         if (cfg_.algo == BF_PHASEMPF) PIPE_HIP(hipMalloc((void **)&d_smooth_, smooth_bytes()));
         if (cfg_.algo == BF_GSC) PIPE_HIP(hipMalloc((void **)&d_nlms_, nlms_bytes()));
@@ -138,7 +141,21 @@ class BinPipelineImpl : public BinPipeline {
         gss_reset_mask_ = ~0ull;
     }
 
-    int run(const float *x, long F, float *y, f64x2 *spectrum, hipStream_t stream, int layout, long mic_stride) override;
+    RunSnapshot snapshot_for_run() override {
+        RunSnapshot sn;
+        sn.kp1 = KP1_;
+        sn.gss_reset_mask = gss_reset_mask_;
+        sn.steer = d_steer_[steer_cur_];
+        sn.steer_dir_stride = steer_dir_stride_;
+        gss_reset_mask_ = 0;
+        return sn;
+    }
+    int columns() const override { return KP1_; }
+    unsigned long long pending_resets() const override { return gss_reset_mask_; }
+    void set_pending_resets(unsigned long long mask) override { gss_reset_mask_ = mask; }
+
+    int run(const float *x, long F, float *y, f64x2 *spectrum, hipStream_t stream, int layout, long mic_stride,
+            const RunSnapshot &snap) override;
 
     size_t state_bytes() const override {
         return (size_t)S_ * M_ * 512 * 4 + (size_t)So_ * 512 * 4 + zhist_bytes() + gss_bytes() + mpf_bytes() + smooth_bytes() +
@@ -172,8 +189,7 @@ class BinPipelineImpl : public BinPipeline {
                 PIPE_HIP(hipMemcpy(s.d, p, s.n, hipMemcpyHostToDevice));
             p += s.n;
         }
-        if (!to_host) gss_reset_mask_ = 0;
-        return BF_OK;
+        return BF_OK;  // the pending-reset mask travels in the blob's control-plane section (capi.cpp)
     }
 
     int ensure(void **ptr, size_t *cap, size_t need) {
@@ -217,7 +233,7 @@ class BinPipelineImpl : public BinPipeline {
 };
 
 int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipStream_t stream, int layout,
-                         long mic_stride) {
+                         long mic_stride, const RunSnapshot &snap) {
     const long FT = Phist_ + F;  // frames in the Z workspace per stream
     int rc = ensure((void **)&d_Z_, &Z_cap_, (size_t)S_ * FT * NP_ * 1024 * sizeof(f64x2));
     if (rc != BF_OK) return rc;
@@ -269,12 +285,11 @@ int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipS
         spectrum = nullptr;
     }
     BinsArgs ba;
-    ba.Z = d_Z_; ba.Yh = d_Yh_; ba.spectrum = spectrum; ba.steer = d_steer_[steer_cur_]; ba.freqs = d_freq_;
-    ba.n_frames = F; ba.frames_ws = FT; ba.frame_off = Phist_; ba.n_streams = So_; ba.n_mics = MF_; ba.kp1 = KP1_;
-    ba.n_dirs = D_; ba.steer_dir_stride = steer_dir_stride_;
-    ba.cfg = cfg_; ba.gssW = d_gssW_; ba.mpf = d_mpf_; ba.gss_reset_mask = gss_reset_mask_;
+    ba.Z = d_Z_; ba.Yh = d_Yh_; ba.spectrum = spectrum; ba.steer = snap.steer; ba.freqs = d_freq_;
+    ba.n_frames = F; ba.frames_ws = FT; ba.frame_off = Phist_; ba.n_streams = So_; ba.n_mics = MF_; ba.kp1 = snap.kp1;
+    ba.n_dirs = D_; ba.steer_dir_stride = snap.steer_dir_stride;
+    ba.cfg = cfg_; ba.gssW = d_gssW_; ba.mpf = d_mpf_; ba.gss_reset_mask = snap.gss_reset_mask;
     PIPE_HIP(launch_bins(ba, n_cus_, stream));
-    gss_reset_mask_ = 0;
 
     if (Phist_ > 0)  // keep the last Phist frames' spectra for the next call
         PIPE_HIP(hipMemcpy2DAsync(d_zhist_, (size_t)Phist_ * frame_elems * sizeof(f64x2), d_Z_ + (size_t)F * frame_elems,

@@ -14,6 +14,17 @@
 
 namespace bf {
 
+// What one run() reads of the state the control plane (bf_set_theta / bf_set_interference, another thread) may change:
+// taken under the handle's mutex right after the table upload, so a batch sees ONE consistent
+// {column count, steering table, pending demixing resets} (the reference guards the same window with READY=false
+// plus a sleep, lcmv.cpp:262-307).
+struct RunSnapshot {
+    int kp1 = 1;
+    unsigned long long gss_reset_mask = 0;
+    const f64x2 *steer = nullptr;
+    long steer_dir_stride = 0;
+};
+
 class BinPipeline {
    public:
     // nullptr when the algorithm is not built
@@ -24,8 +35,14 @@ class BinPipeline {
     virtual int upload_steering(const std::vector<SteeringSet> &dirs, hipStream_t stream) = 0;  // one set per look direction
     virtual void on_theta_changed(int dir = -1) = 0;  // dir < 0: every look direction
     virtual void set_columns(int kp1) = 0;  // interferer added/removed (lcmv.cpp:266-305)
+    // caller holds the control-plane mutex: hands the pending demixing resets to this run and clears them
+    virtual RunSnapshot snapshot_for_run() = 0;
     virtual int run(const float *x_dev, long n_frames, float *y_dev, f64x2 *spectrum_dev, hipStream_t stream, int layout,
-                    long mic_stride) = 0;
+                    long mic_stride, const RunSnapshot &snap) = 0;
+    // checkpoint of the control-plane side (caller holds the mutex)
+    virtual int columns() const = 0;
+    virtual unsigned long long pending_resets() const = 0;
+    virtual void set_pending_resets(unsigned long long mask) = 0;
     virtual size_t state_bytes() const = 0;
     virtual int get_state(void *host) = 0;
     virtual int set_state(const void *host) = 0;

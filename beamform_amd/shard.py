@@ -3,10 +3,25 @@
 The path shards naturally: frames are independent except for
   * the overlap-add neighbour (1 frame) and
   * mvdr/lcmv's covariance of the previous P frames,
-so rank r recomputes `halo` warm-up frames in front of its range locally and drops their output;
+so rank r recomputes `warm` frames in front of its range locally and drops their output;
 no data-path collective is needed.  The only collective is the final gather of the output hops
 (RCCL over xGMI on GPUs; gloo in the CPU tests).  gss, phasempf and the mcra node recurse over frames and shard
 by stream only (halo = None).
+
+What a rank must FEED for its owned hops to equal the single-stream result bit for bit
+(util.h:272-277,292-308: frame t = [hop t-1 | hop t], output hop t = tail(frame t-1) + head(frame t), a cold node's
+ring buffer holds one hop of zeros):
+
+    hops  lo-warm-lead .. lo-warm-1 | lo-warm .. lo-1 | lo .. hi-1
+          `lead` (1 hop, or 0 at    | `warm` frames   | owned
+          the stream start): only   | recomputed,     |
+          seeds the ring buffer so  | output dropped  |
+          that frame lo-warm has    |                 |
+          its true first half       |                 |
+
+Without the lead hop frame lo-warm would start from the cold node's zero hop and (das/phase) the tail added into
+hop lo, or (mvdr/lcmv) the oldest covariance column of frame lo-1, would be wrong.  `Shard.first_feed_frame`,
+`n_feed` and `n_drop` include it; `run_shard` below drives the HIP path with exactly that.
 """
 from __future__ import annotations
 
@@ -25,43 +40,111 @@ def halo_frames(params: dict):
 
 @dataclass
 class Shard:
-    lo: int      # first frame whose output this rank owns
-    hi: int      # one past the last
-    warm: int    # frames recomputed in front of lo (clipped at the stream start)
+    lo: int        # first frame (= output hop) this rank owns
+    hi: int        # one past the last
+    warm: int      # frames recomputed in front of lo (clipped at the stream start)
+    lead: int = 0  # hops fed in front of the first recomputed frame to seed the ring buffer (0 at the stream start)
 
     @property
     def first_input_frame(self) -> int:
+        """First frame that is recomputed correctly (its first half comes from the lead hop)."""
         return self.lo - self.warm
 
     @property
-    def n_process(self) -> int:
+    def first_feed_frame(self) -> int:
+        """First hop of the global stream a cold node on this rank is fed."""
+        return self.lo - self.warm - self.lead
+
+    @property
+    def n_feed(self) -> int:
+        """Hops fed to the cold node: lead + warm + owned."""
+        return self.hi - self.first_feed_frame
+
+    @property
+    def n_drop(self) -> int:
+        """Output hops in front of the owned range that are discarded."""
+        return self.warm + self.lead
+
+    @property
+    def n_own(self) -> int:
+        return self.hi - self.lo
+
+    @property
+    def n_process(self) -> int:  # round-1 name: recomputed + owned frames, WITHOUT the lead hop
         return self.hi - self.lo + self.warm
 
 
 def plan(n_frames: int, world: int, rank: int, halo: int) -> Shard:
-    """Contiguous, near-equal frame ranges; rank 0 starts from the true stream state (no warm-up)."""
+    """Contiguous, near-equal frame ranges; rank 0 starts from the true stream state (no warm-up, no lead)."""
     if halo is None:
         raise ValueError("this node recurses over frames: shard by stream, not by frame range")
     base, rem = divmod(n_frames, world)
     lo = rank * base + min(rank, rem)
     hi = lo + base + (1 if rank < rem else 0)
-    return Shard(lo, hi, min(halo, lo))
+    warm = min(halo, lo)
+    lead = 1 if (halo > 0 and lo - warm > 0) else 0
+    return Shard(lo, hi, warm, lead)
 
 
-def gather_hops(y_local, n_frames: int, world: int, rank: int, hop: int = 512, dst: int = 0):
+def run_shard(bf, x_feed_ptr: int, sh: Shard, y_feed_ptr: int, stream: int = 0, reset: bool = True) -> int:
+    """Drive the HIP path (beamform_amd.capi.Beamformer `bf`, one input stream) over this rank's part of the stream.
+
+    x_feed_ptr: device pointer of the rank's slice of the global stream, hops [first_feed_frame, hi)
+                (planar [M][n_feed*hop] or interleaved [n_feed*hop][M], per the handle's layout).
+    y_feed_ptr: device buffer of n_feed*hop floats; the owned hops start at element n_drop*hop.
+    The handle is put back to the reference's cold start first (the rank's node knows nothing about the frames
+    before its slice).  Enqueued on `stream` without host synchronisation.
+    Returns the element offset of the first owned output sample in y_feed.
+    """
+    if bf.n_streams != 1 or bf.n_dirs != 1:
+        raise ValueError("frame-range sharding drives one input stream and one look direction per handle")
+    if reset:
+        bf.reset()
+    if sh.n_feed > 0:
+        bf.process_device(x_feed_ptr, sh.n_feed, y_feed_ptr, 0, stream)
+    return sh.n_drop * bf.H
+
+
+def run_sharded(bf, x_feed, n_frames: int, world: int, rank: int, halo: int, dst: int = 0, stream: int = 0,
+                gather: bool = True):
+    """One rank's whole job: plan -> cold node -> feed lead + warm + owned hops -> drop -> final gather.
+
+    x_feed: torch tensor on the rank's GPU holding hops [first_feed_frame, hi) of the global stream
+            (planar [M, n_feed*hop]).  Returns the full output [n_frames*hop] on `dst` (None elsewhere), or the
+            owned slab when gather=False.
+    """
+    import torch
+    sh = plan(n_frames, world, rank, halo)
+    assert x_feed.is_contiguous() and x_feed.numel() == bf.M * sh.n_feed * bf.H, "x_feed must hold exactly the fed hops"
+    y_feed = torch.empty(sh.n_feed * bf.H, dtype=torch.float32, device=x_feed.device)
+    off = run_shard(bf, x_feed.data_ptr(), sh, y_feed.data_ptr(), stream)
+    y_own = y_feed[off:]
+    if not gather:
+        return y_own
+    return gather_hops(y_own, n_frames, world, rank, bf.H, dst)
+
+
+def gather_hops(y_local, n_frames: int, world: int, rank: int, hop: int = 512, dst: int = 0, out=None):
     """Collect per-rank output slabs [frames_r*hop] on `dst` in frame order; one collective.
 
-    Works on any torch.distributed backend (nccl = RCCL on GPUs, gloo on CPU)."""
+    Works on any torch.distributed backend (nccl = RCCL on GPUs, gloo on CPU).  `out` (dst only, optional):
+    preallocated list of `world` receive buffers of max-slab size, reused across calls."""
     import torch
     import torch.distributed as dist
-    sizes = [plan(n_frames, world, r, 0).hi - plan(n_frames, world, r, 0).lo for r in range(world)]
+    sizes = [plan(n_frames, world, r, 0).n_own for r in range(world)]
     pad = max(sizes) * hop
-    buf = torch.zeros(pad, dtype=y_local.dtype, device=y_local.device)
-    buf[: y_local.numel()] = y_local
-    out = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
-    dist.gather(buf, out, dst=dst)
+    if y_local.numel() == pad:
+        buf = y_local.contiguous()
+    else:
+        buf = torch.zeros(pad, dtype=y_local.dtype, device=y_local.device)
+        buf[: y_local.numel()] = y_local
+    if rank == dst and out is None:
+        out = [torch.empty_like(buf) for _ in range(world)]
+    dist.gather(buf, out if rank == dst else None, dst=dst)
     if rank != dst:
         return None
+    if all(n == sizes[0] for n in sizes):
+        return torch.cat(out)
     return torch.cat([o[: n * hop] for o, n in zip(out, sizes)])
 
 

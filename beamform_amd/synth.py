@@ -58,3 +58,21 @@ def make_scene(n_mics: int = 8, n_frames: int = 64, hop: int = 512, sr: float = 
     if n_sil:
         x[:, T - n_sil:] *= 1e-4 / max(sigma_s, 1e-12)
     return np.clip(x, -1.0, 1.0).astype(np.float32)
+
+
+def stream_noise(seed: int, n_mics: int, s0: int, s1: int, device="cpu"):
+    """Samples [s0, s1) of every channel of ONE global uniform-noise stream in [-0.5, 0.5) -> torch [n_mics, s1-s0] f32.
+
+    Counter-based (a 32-bit integer hash of (seed, mic, sample index)), so any rank can materialise any slice of the
+    same stream on its own GPU: the halo a shard re-reads equals the samples its neighbour owns, with no exchange.
+    Bench / full-size shard tests only (uniform noise opens every magnitude gate: the worst case for mvdr/lcmv)."""
+    import torch
+    idx = torch.arange(s0, s1, dtype=torch.int64, device=device)
+    out = torch.empty((n_mics, s1 - s0), dtype=torch.float32, device=device)
+    for m in range(n_mics):
+        h = (idx + ((m + 1) * 0x632BE5AB + (seed + 1) * 0x85157AF5)) & 0xFFFFFFFF
+        h = ((h ^ (h >> 16)) * 0x45D9F3B) & 0xFFFFFFFF
+        h = ((h ^ (h >> 16)) * 0x45D9F3B) & 0xFFFFFFFF
+        h = h ^ (h >> 16)
+        out[m] = (h >> 8).to(torch.float32) * (1.0 / 16777216.0) - 0.5
+    return out

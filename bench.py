@@ -3,15 +3,19 @@
 
 A "step" is one pass of the hot path (window -> FFTs -> per-bin weight-and-sum
 -> IFFT -> overlap-add) over one batch of synthetic multichannel audio that is
-already resident in HBM.  Workload at N=1: BASELINE.json configs[1]
-(das, 8 mics, 1024-pt FFT / hop 512, 65536-frame batch).  With --gpus N the
-launcher starts one rank per GPU (torch.distributed over RCCL); every rank
-processes its own 65536-frame shard (weak scaling: independent frame ranges, no
-data-path collective).  The timed region is the K steps of the hot path; after
-it the per-rank output slabs of the last step are collected on rank 0 with one
-RCCL gather ("final gather"), timed separately and reported as
-config.final_gather_ms / value_including_final_gather (--gather step puts a
-gather inside every step instead; --gather none skips it).
+already resident in HBM.
+
+N = 1 (default): BASELINE.json configs[1] -- das, 8 mics, 1024-pt FFT / hop 512, one
+65 536-frame batch.  `extra` carries one line per other BASELINE config (mvdr 8-mic,
+phasempf 256 x 256, lcmv 16-mic K = 3 per-GPU shard) and the double-precision das.
+
+N > 1 (`--gpus N`, one rank per GPU over torch.distributed / RCCL): ONE global stream is cut into
+contiguous frame ranges by beamform_amd.shard.plan; every rank holds only its slice (its owned hops
+plus the lead hop and the warm-up frames in front of them), starts from a COLD handle each step and drops the
+warm-up output -- no data-path collective.  By default the stream has N x 65 536 frames (weak scaling: 65 536
+owned frames per GPU); `--strong` keeps the total at --total-frames for every N.  `value` times the K compute
+steps; `value_including_final_gather` times K steps that each end with the one RCCL gather of the owned slabs
+onto rank 0 (north_star: "RCCL over xGMI only for the final gather").
 
 Prints ONE JSON line on rank 0.  See DESIGN.md "Measurement" for definitions.
 """
@@ -19,7 +23,10 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,12 +35,52 @@ sys.path.insert(0, ROOT)
 
 HOP = 512
 NFFT = 1024
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+FP64_VECTOR_PEAK_TF = 78.6  # AMD's public MI355X FP64 vector figure (not in the guide)
 
 
 def algorithmic_bytes_per_frame(n_mics: int) -> int:
     """M*H*4 B of new input + H*4 B of output per frame."""
     return n_mics * HOP * 4 + HOP * 4
+
+
+def model_flops_per_frame(algo: str, M: int, K: int = 0, P: int = 10, in_band_bins: int = 339) -> float:
+    """Algorithmic fp64 flop model: packed-real FFTs + the per-bin work in its Hermitian /
+    Cholesky form.  8 flops per complex multiply-add.  Used only for the '% of FP64 vector peak' figures."""
+    fft = 5.0 * NFFT * math.log2(NFFT)                       # 51 200 flops per complex FFT-1024
+    flops = (M / 2.0 + 0.5) * fft                            # two real mics per forward FFT, two frames per inverse
+    if algo in ("mvdr", "lcmv"):
+        rhs = (K + 1) + 1                                    # constraint columns + the frame's x
+        cmac = (2 * M * (M + 1) / 2                          # slide the covariance: one update + one downdate (lower triangle)
+                + M ** 3 / 6.0                               # Cholesky of R o whiteR
+                + rhs * M * M / 2.0                          # forward substitution of [C | x]
+                + (K + 1) * (K + 2) / 2.0 * M + (K + 1) * M  # Gram U_C^H U_C and U_C^H u_x
+                + (K + 1) ** 3 / 3.0)                        # the small (K+1)^2 solve
+        flops += in_band_bins * cmac * 8.0
+    elif algo == "das":
+        flops += 514 * M * 8.0
+    return flops
+
+
+def host_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota when there is one."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:           # cgroup v2
+            q, per = f.read().split()
+            if q != "max":
+                quota = float(q) / float(per)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / per
+        except Exception:
+            pass
+    usable = aff if quota is None else max(1, min(aff, int(math.floor(quota + 1e-9)) or 1))
+    return {"os_cpu_count": os.cpu_count(), "affinity": aff, "cgroup_quota_cpus": quota, "usable": usable}
 
 
 def cpu_baseline(algo: str, n_mics: int, frames: int):
@@ -47,16 +94,19 @@ def cpu_baseline(algo: str, n_mics: int, frames: int):
     x = make_scene(n_mics, 512, seed=11)  # 512 frames, fed `reps` times as one continuing stream
     F = reps * (x.shape[1] // HOP)
     node = oracle.OracleNode(p)
-    node.process(np.ascontiguousarray(x[:, : 64 * HOP]))  # warm caches / page in
+    node.process(np.ascontiguousarray(x[:, : 64 * HOP]))  # warm caches / page in / build the FFT plan
     t0 = time.perf_counter()
     for _ in range(reps):
         node.process(x)
     dt = time.perf_counter() - t0
+    hc = host_cores()
     return {
         "value": F / dt, "unit": "frames/s", "cores": 1, "kind": "port",
         "sample": f"{algo} {n_mics}-mic hop512 fft1024, {F} frames of the seeded synthetic scene, "
-                  f"{dt:.1f} s on 1 of {os.cpu_count()} host cores (oracle/bf_oracle.cpp; FFTW/Eigen/JACK/ROS absent "
-                  "from the image, so the reference binary itself cannot be timed)",
+                  f"{dt:.1f} s on 1 host core (affinity {hc['affinity']}, cgroup quota {hc['cgroup_quota_cpus']}, "
+                  f"os.cpu_count {hc['os_cpu_count']}); oracle/bf_oracle.cpp -O2 with a per-node FFT plan (radix-2, tables built "
+                  "once like an FFTW plan); FFTW/Eigen/JACK/ROS are absent from the image, so the reference binary itself "
+                  "cannot be timed",
     }
 
 
@@ -77,10 +127,11 @@ def _cpu_worker(job):
 
 
 def cpu_baseline_all_cores(algo: str, n_mics: int, frames_per_core: int):
-    """The same oracle, one process per host core, each on its own stream; must run BEFORE this process touches the GPU
-    (the pool forks)."""
+    """The same oracle, one process per USABLE host core (affinity mask capped by the cgroup quota), each on its own
+    stream; must run BEFORE this process touches the GPU (the pool forks)."""
     import multiprocessing as mp
-    cores = os.cpu_count() or 1
+    hc = host_cores()
+    cores = hc["usable"]
     reps = max(1, frames_per_core // 512)
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
@@ -89,7 +140,7 @@ def cpu_baseline_all_cores(algo: str, n_mics: int, frames_per_core: int):
     wall = time.perf_counter() - t0
     frames = sum(r[0] for r in res)
     busy = max(r[1] for r in res)
-    return {"value": frames / busy, "unit": "frames/s", "cores": cores,
+    return {"value": frames / busy, "unit": "frames/s", "cores": cores, "host": hc,
             "sample": f"{cores} processes x {reps * 512} frames each ({algo} {n_mics}-mic), slowest worker {busy:.1f} s, "
                       f"{wall:.1f} s wall incl. pool start-up and scene synthesis"}
 
@@ -106,6 +157,18 @@ def load_traffic(tag: str):
     return None
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children through torch.distributed.run
+    (this parent has not touched the GPU) and hand back their exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,29 +180,41 @@ def main():
                          "(profiles/README.md r01_g); 0 disables")
     ap.add_argument("--algo", default="das", choices=["das", "mvdr", "lcmv", "gss", "phase", "phasempf", "mcra", "gsc"])
     ap.add_argument("--mics", type=int, default=8)
-    ap.add_argument("--frames", type=int, default=65536, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=65536, help="frames per GPU per step (per stream)")
     ap.add_argument("--streams", type=int, default=1)
     ap.add_argument("--layout", default="planar", choices=["planar", "interleaved"])
-    ap.add_argument("--gather", default="final", choices=["final", "step", "none"])
+    ap.add_argument("--das-f64", action="store_true", help="das through the fp64 bin pipeline (BF_DAS_BINS_F64)")
+    ap.add_argument("--strong", action="store_true",
+                    help="N > 1: keep the global stream at --total-frames for every N (strong scaling)")
+    ap.add_argument("--total-frames", type=int, default=0,
+                    help="--strong: frames of the global stream (default 262144 = BASELINE config 5's batch)")
+    ap.add_argument("--independent", action="store_true",
+                    help="N > 1: round-1 behaviour, every rank an independent random batch (no shard plan)")
+    ap.add_argument("--gather", default="final", choices=["final", "none"])
     ap.add_argument("--cpu-frames", type=int, default=81920,
-                    help="frames in the CPU-baseline sample (0 = skip); the default is ~11 s of single-core work")
+                    help="frames in the CPU-baseline sample (0 = skip); the default is ~10 s of single-core work")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-all-cores-frames", type=int, default=2048,
                     help="frames per host core in the all-cores CPU baseline (0 = skip)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary mvdr measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary lines (other BASELINE configs)")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-
-    from beamform_amd.capi import BF_INTERLEAVED, BF_PLANAR, Beamformer
-    from beamform_amd.params import make_params
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))          # nothing has touched the GPU in this process
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+
+    from beamform_amd import shard
+    from beamform_amd.capi import BF_DAS_BINS_F64, BF_DAS_FUSED_F32, BF_INTERLEAVED, BF_PLANAR, Beamformer
+    from beamform_amd.params import make_params
+    from beamform_amd.synth import stream_noise
+
     # CPU baselines first (rank 0, N = 1 only): the all-cores pool forks, which must happen before this process
     # initialises the GPU; the untimed settle phase below brings the clocks back up afterwards
     cpu_line = None
@@ -153,7 +228,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
     # test hook for single-GPU boxes: BF_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and uses gloo for the
-    # (host-staged) gather, so the launcher / barrier / gather code path can be exercised without 2 GPUs
+    # (host-staged) gather, so the launcher / barrier / shard-plan / gather code path can be exercised without 2 GPUs
     one_dev = os.environ.get("BF_BENCH_ONE_DEVICE", "0") == "1"
     if one_dev:
         local_rank = 0
@@ -168,13 +243,6 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    def gather_to_rank0(t, out_list):
-        if one_dev:
-            host = t.cpu()
-            dist.gather(host, [torch.empty_like(host) for _ in range(world)] if rank == 0 else None, dst=0)
-        else:
-            dist.gather(t, out_list, dst=0)
-
     def all_max(vals):
         t = torch.tensor(vals, device="cpu" if one_dev else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -184,23 +252,70 @@ def main():
     interf = (-60.0, 90.0, 150.0) if args.algo in ("lcmv", "gss") else ()
     p = make_params(args.algo, n_mics=M, interf=interf)
     layout = BF_PLANAR if args.layout == "planar" else BF_INTERLEAVED
-    bf = Beamformer(p, device=local_rank, n_streams=S, layout=layout)
-
-    # synthetic input, resident in HBM before the timed region: uniform noise in [-0.5, 0.5)
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    shape = (S, M, F * HOP) if layout == BF_PLANAR else (S, F * HOP, M)
-    x = torch.rand(shape, device=dev, generator=g, dtype=torch.float32) - 0.5
-    y = torch.empty((S, F * HOP), device=dev, dtype=torch.float32)
-    gathered = None
-    if world > 1 and args.gather != "none" and rank == 0 and not one_dev:
-        gathered = [torch.empty_like(y) for _ in range(world)]
+    das_impl = BF_DAS_BINS_F64 if (args.das_f64 and args.algo == "das") else BF_DAS_FUSED_F32
+    bf = Beamformer(p, device=local_rank, n_streams=S, layout=layout, das_impl=das_impl)
     stream = torch.cuda.current_stream(dev)
     sptr = stream.cuda_stream
 
-    def step():
-        bf.process_device(x.data_ptr(), F, y.data_ptr(), 0, sptr)
-        if world > 1 and args.gather == "step":
-            gather_to_rank0(y, gathered)
+    # ---- what this rank processes ------------------------------------------------------------------------------
+    sharded = world > 1 and not args.independent
+    sh = None
+    if sharded:
+        halo = shard.halo_frames(p)
+        if halo is None or S != 1 or layout != BF_PLANAR:
+            raise SystemExit(f"{args.algo} recurses over frames (or streams/layout given): shards by stream only -- use --independent")
+        F_total = (args.total_frames or 262144) if args.strong else world * F
+        sh = shard.plan(F_total, world, rank, halo)
+        # the rank's slice of the ONE global stream: lead hop + warm frames + owned frames (counter-based noise, so the
+        # halo a rank re-reads is bit-identical to what its neighbour owns)
+        x = stream_noise(1234, M, sh.first_feed_frame * HOP, sh.hi * HOP, device=dev)
+        n_feed, n_own = sh.n_feed, sh.n_own
+        y = torch.empty(n_feed * HOP, device=dev, dtype=torch.float32)
+        own_max = max(shard.plan(F_total, world, r, halo).n_own for r in range(world))
+        y_own = y[sh.n_drop * HOP: sh.n_drop * HOP + n_own * HOP]
+        gathered = None
+        if rank == 0 and args.gather != "none" and not one_dev:
+            gathered = [torch.empty(own_max * HOP, device=dev, dtype=torch.float32) for _ in range(world)]
+        frames_per_step_all_ranks = F_total
+    else:
+        # synthetic input, resident in HBM before the timed region: uniform noise in [-0.5, 0.5)
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        shape = (S, M, F * HOP) if layout == BF_PLANAR else (S, F * HOP, M)
+        x = torch.rand(shape, device=dev, generator=g, dtype=torch.float32) - 0.5
+        y = torch.empty((S, F * HOP), device=dev, dtype=torch.float32)
+        n_feed = n_own = F
+        frames_per_step_all_ranks = world * S * F
+
+    def gather_owned():
+        if one_dev:
+            host = torch.zeros(own_max * HOP, dtype=torch.float32)
+            host[: n_own * HOP] = y_own.cpu()
+            dist.gather(host, [torch.empty_like(host) for _ in range(world)] if rank == 0 else None, dst=0)
+        else:
+            shard.gather_hops(y_own, F_total, world, rank, HOP, 0, out=gathered)
+
+    def step(with_gather=False):
+        if sharded:
+            shard.run_shard(bf, x.data_ptr(), sh, y.data_ptr(), sptr)   # cold handle, lead + warm + owned hops
+            if with_gather:
+                gather_owned()
+        else:
+            bf.process_device(x.data_ptr(), F, y.data_ptr(), 0, sptr)
+
+    def timed(n_steps, with_gather=False):
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step(with_gather)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        return all_max([dt])[0] if world > 1 else dt
 
     settle_launches = 0
     if args.settle_ms > 0:  # untimed: let DVFS settle (a cold chip runs the first ~50 launches up to 45 % slower)
@@ -212,83 +327,114 @@ def main():
             settle_launches += 8
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    gather_dt = 0.0
-    if world > 1 and args.gather == "final":  # output delivery, outside the hot path: timed on its own
-        gather_to_rank0(y, gathered)           # first call also builds the RCCL channels
-        torch.cuda.synchronize(dev)
-        dist.barrier()
-        torch.cuda.synchronize(dev)
-        g0 = time.perf_counter()
-        gather_to_rank0(y, gathered)
-        torch.cuda.synchronize(dev)
-        dist.barrier()
-        torch.cuda.synchronize(dev)
-        gather_dt = time.perf_counter() - g0
-    if world > 1:
-        dt, gather_dt = all_max([dt, gather_dt])
+    dt = timed(args.steps)
+    dt_g = None
+    if sharded and args.gather == "final":
+        step(True)                                  # first gather also builds the RCCL channels
+        dt_g = timed(args.steps, with_gather=True)  # K steps, each ending with the final gather onto rank 0
 
     # dominant-kernel duration: HIP events on the launch stream, one pair per launch
     k_iters = max(5, min(args.steps, 50))
-    ms_call, ms_kernel = bf.time_device(x.data_ptr(), F, y.data_ptr(), k_iters, sptr)
+    if sharded:
+        bf.reset()
+    ms_call, ms_kernel = bf.time_device(x.data_ptr(), n_feed, y.data_ptr(), k_iters, sptr)
     torch.cuda.synchronize(dev)
 
-    # secondary line of the BASELINE metric ("DAS+MVDR"): mvdr 8-mic on the same input, rank 0, few steps
+    # ---- secondary lines: the other BASELINE configs, rank 0 at N = 1 -------------------------------------------
+    def node_line(algo, M_, F_, S_, interf_=(), das_impl_=BF_DAS_FUSED_F32, iters=5, xin=None, note=""):
+        pm = make_params(algo, n_mics=M_, interf=interf_)
+        bm = Beamformer(pm, device=local_rank, n_streams=S_, das_impl=das_impl_)
+        if xin is None:
+            gg = torch.Generator(device=dev).manual_seed(4321)
+            xin = torch.rand((S_, M_, F_ * HOP), device=dev, generator=gg, dtype=torch.float32) - 0.5
+        yo = torch.empty((S_, F_ * HOP), device=dev, dtype=torch.float32)
+        for _ in range(2):
+            bm.process_device(xin.data_ptr(), F_, yo.data_ptr(), 0, sptr)
+        torch.cuda.synchronize(dev)
+        ms, _ = bm.time_device(xin.data_ptr(), F_, yo.data_ptr(), iters, sptr)
+        bm.close()
+        fr = S_ * F_
+        bpf = algorithmic_bytes_per_frame(M_)
+        line = {"workload": f"{algo} {M_}-mic 1024-pt, {S_} stream(s) x {F_} frames" + (f", {len(interf_)} interferers" if interf_ else "")
+                            + ("" if not note else "; " + note),
+                "ms_per_step": ms, "frames_per_s": fr / (ms * 1e-3),
+                "frac_of_hbm_roofline_algorithmic_bytes": bpf * fr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_frame": bpf}
+        if algo in ("mvdr", "lcmv") or das_impl_ == BF_DAS_BINS_F64:
+            fl = model_flops_per_frame(algo, M_, len(interf_), pm["past_windows"])
+            line["model_flops_per_frame"] = fl
+            line["frac_of_fp64_vector_peak"] = fl * fr / (ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TF
+        tag = {"das": "das8_f64", "mvdr": "mvdr8", "phasempf": "phasempf8", "phase": "phase8", "lcmv": "lcmv16"}.get(algo)
+        tr = load_traffic(tag) if tag else None
+        if tr is not None:
+            line["traffic"] = tr
+        return line
+
     extra = None
-    if rank == 0 and args.algo == "das" and not args.no_extra and S == 1 and layout == BF_PLANAR:
-        try:
-            pm = make_params("mvdr", n_mics=M)
-            bm = Beamformer(pm, device=local_rank)
-            for _ in range(2):
-                bm.process_device(x.data_ptr(), F, y.data_ptr(), 0, sptr)
-            torch.cuda.synchronize(dev)
-            ms_m, _ = bm.time_device(x.data_ptr(), F, y.data_ptr(), 5, sptr)
-            extra = {"mvdr_frames_per_s": F / (ms_m * 1e-3), "mvdr_ms_per_step": ms_m,
-                     # same algorithmic floor as das (spectra need never leave the chip in principle)
-                     "mvdr_frac_of_hbm_roofline_algorithmic_bytes":
-                         algorithmic_bytes_per_frame(M) * F / (ms_m * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "mvdr_workload": f"mvdr {M}-mic 1024-pt, {F}-frame batch, fp64 bin pipeline (compute-bound: "
-                                      "per-bin covariance + Cholesky solve), launch-file parameters"}
-            bm.close()
-        except Exception as e:  # the headline must not die on the secondary measurement
-            extra = {"mvdr_error": str(e)}
+    if rank == 0 and world == 1 and args.algo == "das" and das_impl == BF_DAS_FUSED_F32 and not args.no_extra and S == 1 \
+            and layout == BF_PLANAR:
+        extra = {}
+        noise = ("input = uniform noise in [-0.5, 0.5): every in-band bin passes the magnitude gate, so every bin-frame "
+                 "takes the covariance solve (the worst case; real scenes close part of the gates)")
+        jobs = [
+            ("mvdr", lambda: node_line("mvdr", M, F, 1, xin=x, note="BASELINE config 3; fp64 bin pipeline; " + noise)),
+            ("das_f64", lambda: node_line("das", M, F, 1, das_impl_=BF_DAS_BINS_F64, xin=x,
+                                          note="same precision as the reference (double spectra): the fp64 bin pipeline")),
+            ("phasempf", lambda: node_line("phasempf", 8, 256, 256, note="BASELINE config 4: 256 streams x 256 frames, recursion per stream")),
+            ("phase", lambda: node_line("phase", M, F, 1, xin=x)),
+            ("lcmv16", lambda: node_line("lcmv", 16, 32768, 1, (-60.0, 90.0, 150.0), iters=3,
+                                         note="BASELINE config 5, one GPU's shard of the 262144-frame stream; " + noise)),
+        ]
+        for name, job in jobs:
+            try:
+                extra[name] = job()
+            except Exception as e:  # the headline must not die on a secondary measurement
+                extra[name] = {"error": str(e)}
+        # round-1 field names kept for continuity
+        if "ms_per_step" in extra.get("mvdr", {}):
+            extra["mvdr_ms_per_step"] = extra["mvdr"]["ms_per_step"]
+            extra["mvdr_frames_per_s"] = extra["mvdr"]["frames_per_s"]
+            extra["mvdr_frac_of_hbm_roofline_algorithmic_bytes"] = extra["mvdr"]["frac_of_hbm_roofline_algorithmic_bytes"]
+            extra["mvdr_frac_of_fp64_vector_peak"] = extra["mvdr"]["frac_of_fp64_vector_peak"]
 
     if rank == 0:
-        frames_total = world * S * F * args.steps
+        frames_total = frames_per_step_all_ranks * args.steps
         value = frames_total / dt
         bpf = algorithmic_bytes_per_frame(M)
-        units_per_launch = S * F
+        units_per_launch = S * n_feed
         # fused das: its one kernel; the other nodes run a chain of kernels (stft -> per-bin -> istft): the chain's duration
         k_ms = ms_kernel if ms_kernel > 0 else ms_call
         achieved = bpf * units_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        tag = f"{args.algo}{M}"
+        tag = f"{args.algo}{M}" + ("_f64" if das_impl == BF_DAS_BINS_F64 else "")
+        if sharded:
+            shl = shard.plan(F_total, world, world - 1, halo)
+            wl = (f"{args.algo} {M}-mic 1024-pt (hop 512), ONE {F_total}-frame stream frame-sharded x{world} by shard.plan "
+                  f"(last rank: {shl.n_own} owned + {shl.warm} warm-up frames + {shl.lead} lead hop), cold handle per step, "
+                  f"planar slices resident in HBM")
+        else:
+            wl = (f"{args.algo} {M}-mic 1024-pt (hop 512), {F}-frame batch per GPU, {S} stream(s), {args.layout} input resident in HBM")
         out = {
             "metric": "stft_frames_per_sec", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.algo == "das" else "f64", "data": "synthetic",
-            "config": {"workload": f"{args.algo} {M}-mic 1024-pt (hop 512), {F}-frame batch per GPU, {S} stream(s), "
-                                   f"{args.layout} input resident in HBM", "frames_per_gpu": F, "mics": M, "fft": NFFT,
-                       "hop": HOP, "streams": S, "layout": args.layout, "gather": args.gather if world > 1 else "n/a",
-                       "final_gather_ms": gather_dt * 1e3 if world > 1 and args.gather == "final" else None,
-                       "value_including_final_gather": (frames_total / (dt + gather_dt)) if gather_dt > 0 else None,
-                       "parallelism": f"frame-sharded x{world}", "settle_launches_before_warmup": settle_launches},
+            "higher_is_better": True, "scaling": "strong" if (sharded and args.strong) else "weak", "vs_baseline": None,
+            "dtype": "f32" if (args.algo == "das" and das_impl == BF_DAS_FUSED_F32) else "f64", "data": "synthetic",
+            "value_including_final_gather": (frames_total / dt_g) if dt_g else None,
+            "ms_per_step_including_final_gather": (dt_g / args.steps * 1e3) if dt_g else None,
+            "config": {"workload": wl, "frames_per_gpu": n_own, "frames_fed_per_gpu": n_feed,
+                       "global_stream_frames": frames_per_step_all_ranks if sharded else None, "mics": M, "fft": NFFT,
+                       "hop": HOP, "streams": S, "layout": args.layout,
+                       "gather": (args.gather if sharded else "n/a"),
+                       "final_gather_bytes_into_rank0": ((world - 1) * own_max * HOP * 4) if sharded else None,
+                       "parallelism": (f"frame-sharded x{world} (shard.plan: halo recomputed locally, no data-path collective)"
+                                       if sharded else f"independent batches x{world}"),
+                       "input": "uniform noise in [-0.5, 0.5) (counter-based global stream)" if sharded else "uniform noise in [-0.5, 0.5)",
+                       "settle_launches_before_warmup": settle_launches},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         # PMC traffic exists for the headline workload only (profiles/traffic_das8.json)
-                         "traffic": load_traffic(tag) if (F == 65536 and S == 1 and args.layout == "planar") else None,
-                         "kernel": "das_fused_kernel" if args.algo == "das" else "bin pipeline (stft + per-bin kernel + istft)",
+                         # PMC traffic exists for the profiled workloads only (profiles/traffic_<tag>.json)
+                         "traffic": load_traffic(tag) if (n_feed == 65536 and S == 1 and args.layout == "planar") else None,
+                         "kernel": "das_fused_kernel" if (args.algo == "das" and das_impl == BF_DAS_FUSED_F32)
+                                   else "bin pipeline (stft + per-bin kernel + istft)",
                          "kernel_ms": k_ms, "call_ms": ms_call, "algorithmic_bytes_per_frame": bpf,
                          "frames_per_launch": units_per_launch, "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
         }

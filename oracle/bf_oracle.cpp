@@ -46,22 +46,45 @@ static const double rad2deg = 180.0 / ORC_PI;
 static const double deg2rad = ORC_PI / 180.0;
 
 /* ---------------------------------------------------------------- FFT -- */
-/* Stand-in for fftw_execute on a fftw_plan_dft_1d plan (das.cpp:127-128).
+/* Stand-in for fftw_plan_dft_1d + fftw_execute (das.cpp:127-128): like an FFTW plan, the bit-reversal permutation and
+ * the twiddle table of a (size, direction) pair are built ONCE (first use, then cached for the life of the process --
+ * the reference plans once in main()) and every execute only runs the butterflies.
  * sign = -1: FFTW_FORWARD, +1: FFTW_BACKWARD (unnormalised). */
+struct DftPlan {
+    int n, sign;
+    std::vector<int> rev;
+    std::vector<cd> tw;
+    DftPlan(int n_, int sign_) : n(n_), sign(sign_), rev(n_), tw(n_ / 2 > 0 ? n_ / 2 : 1) {
+        int lg = 0;
+        while ((1 << lg) < n) lg++;
+        for (int i = 0; i < n; i++) {
+            int r = 0;
+            for (int b = 0; b < lg; b++)
+                if (i & (1 << b)) r |= 1 << (lg - 1 - b);
+            rev[i] = r;
+        }
+        for (int k = 0; k < n / 2; k++) {
+            double a = sign * 2.0 * M_PI * (double)k / (double)n;
+            tw[k] = cd(std::cos(a), std::sin(a));
+        }
+    }
+};
+
+static const DftPlan &dft_plan(int n, int sign) {
+    /* one plan per (size, direction); thread_local so concurrent oracle nodes (bench.py's all-cores baseline uses
+     * processes, tests may use threads) never share a half-built table */
+    static thread_local std::vector<DftPlan *> plans;
+    for (DftPlan *p : plans)
+        if (p->n == n && p->sign == sign) return *p;
+    plans.push_back(new DftPlan(n, sign));
+    return *plans.back();
+}
+
 static void dft_pow2(const cd *in, cd *out, int n, int sign) {
-    int lg = 0;
-    while ((1 << lg) < n) lg++;
-    for (int i = 0; i < n; i++) {
-        int r = 0;
-        for (int b = 0; b < lg; b++)
-            if (i & (1 << b)) r |= 1 << (lg - 1 - b);
-        out[r] = in[i];
-    }
-    std::vector<cd> tw(n / 2 > 0 ? n / 2 : 1);
-    for (int k = 0; k < n / 2; k++) {
-        double a = sign * 2.0 * M_PI * (double)k / (double)n;
-        tw[k] = cd(std::cos(a), std::sin(a));
-    }
+    const DftPlan &pl = dft_plan(n, sign);
+    const int *rev = pl.rev.data();
+    const cd *tw = pl.tw.data();
+    for (int i = 0; i < n; i++) out[rev[i]] = in[i];
     for (int len = 2; len <= n; len <<= 1) {
         int half = len >> 1, step = n / len;
         for (int i = 0; i < n; i += len)

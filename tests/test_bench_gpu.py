@@ -42,7 +42,9 @@ def test_bench_single_gpu_line():
     _check_line(d, 1)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "frames/s"
-    assert c["all_cores"]["cores"] == os.cpu_count() and c["all_cores"]["value"] > c["value"]
+    usable = c["all_cores"]["host"]["usable"]
+    assert c["all_cores"]["cores"] == usable <= len(os.sched_getaffinity(0))
+    assert usable == 1 or c["all_cores"]["value"] > c["value"]
 
 
 def test_bench_two_ranks_through_the_launcher():
@@ -53,5 +55,19 @@ def test_bench_two_ranks_through_the_launcher():
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
     _check_line(d, 2)
-    assert d["config"]["final_gather_ms"] is not None and d["config"]["final_gather_ms"] >= 0
+    # the two ranks ran ONE 8192-frame stream through shard.plan (halo 1 + lead hop on rank 1), gather inside the second timing
+    assert d["config"]["global_stream_frames"] == 8192 and d["config"]["frames_per_gpu"] == 4096
+    assert d["value_including_final_gather"] is not None and 0 < d["value_including_final_gather"] <= d["value"] * 1.5
     assert d["cpu_baseline"] is None  # rank 0 at N = 1 only
+
+
+def test_bench_spawns_its_own_ranks_when_no_launcher_is_present():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must not silently run one rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(BF_BENCH_ONE_DEVICE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--strong", "--total-frames", "6000"] + SMALL
+                         + ["--no-cpu"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_stream_frames"] == 6000
+    assert abs(d["value"] - 6000 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]

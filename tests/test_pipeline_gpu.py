@@ -342,3 +342,36 @@ def test_phasempf_config4_full_size_streams():
         y = yd[s].cpu().numpy()
         assert np.isfinite(y).all()
         assert rel_l2(y, y_ref) < TOL_TIME
+
+
+def test_checkpoint_carries_the_control_plane():
+    """A blob taken before the first run (gss: demixing reset still pending), after /theta and after an interferer was
+    appended restores a handle that continues exactly like the original; a blob with another interferer count is refused."""
+    from beamform_amd.capi import Beamformer, BfError
+    _torch()
+    M, F = 4, 12
+    p = make_params("gss", n_mics=M, theta=10.0, interf=(-60.0,))
+    x = make_scene(M, 2 * F, seed=12)
+    a = Beamformer(p)
+    blob0 = a.get_state()                                   # nothing has run: W = C^H is still pending
+    b = Beamformer(p)
+    b.process(np.ascontiguousarray(x[:, : 5 * 512]))        # b's demixing matrices have adapted ...
+    b.set_state(blob0)                                      # ... and must restart from C^H like a's
+    ya, yb = a.process(np.ascontiguousarray(x[:, : F * 512])), b.process(np.ascontiguousarray(x[:, : F * 512]))
+    assert np.array_equal(ya, yb, equal_nan=True)
+    a.set_theta(-35.0)
+    a.process(np.ascontiguousarray(x[:, : 3 * 512]))
+    blob1 = a.get_state()                                   # carries theta = -35 and the adapted matrices
+    c = Beamformer(p)                                       # still steered to 10 degrees
+    c.set_state(blob1)
+    assert np.abs(c.weights() - a.weights()).max() == 0.0
+    ya, yc = a.process(np.ascontiguousarray(x[:, F * 512:])), c.process(np.ascontiguousarray(x[:, F * 512:]))
+    assert np.array_equal(ya, yc, equal_nan=True)
+    a.set_interference(5, 120.0)                            # structural change: K = 2 now
+    with pytest.raises(BfError):
+        c.set_state(a.get_state())                          # c still has K = 1
+    c.set_interference(5, 100.0)
+    c.set_state(a.get_state())                              # same K: accepted, angles and the zeroed row 0 (Q3) come along
+    assert np.abs(c.weights() - a.weights()).max() == 0.0
+    ya, yc = a.process(np.ascontiguousarray(x[:, : F * 512])), c.process(np.ascontiguousarray(x[:, : F * 512]))
+    assert np.array_equal(ya, yc, equal_nan=True)

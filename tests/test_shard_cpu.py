@@ -1,6 +1,6 @@
-"""world_size-2 gloo test of the N > 1 path: frame-range sharding with halo + the final gather.
-The compute stand-in on CPU is the oracle (test infrastructure); on GPUs bench.py runs the same plan
-with the HIP path and RCCL."""
+"""world_size-2 gloo test of the N > 1 path: frame-range sharding with halo + lead hop + the final gather.
+The compute stand-in on CPU is the oracle (test infrastructure); on GPUs shard.run_shard / bench.py drive the same
+plan through the HIP path (tests/test_shard_gpu.py) and RCCL."""
 import os
 import socket
 
@@ -18,6 +18,8 @@ def test_plan_partitions_exactly():
         for r in range(W):
             s = shard.plan(F, W, r, 11)
             assert s.warm == min(11, s.lo) and s.first_input_frame >= 0
+            assert s.lead == (1 if s.first_input_frame > 0 else 0) and s.first_feed_frame >= 0
+            assert s.n_feed == s.lead + s.warm + s.n_own and s.n_drop == s.lead + s.warm
             cover += list(range(s.lo, s.hi))
         assert cover == list(range(F))
     assert shard.halo_frames(make_params("das")) == 1
@@ -37,13 +39,12 @@ def _worker(rank, world, port, algo, M, F, ret):
     p = make_params(algo, n_mics=M, theta=20.0)
     x = make_scene(M, F, seed=123)
     sh = shard.plan(F, world, rank, shard.halo_frames(p))
-    # the rank's node starts cold at its first input frame except for the hop in front of it, which the
-    # oracle takes from its ring buffer: feed that hop first (one extra callback) when it exists
+    # a cold node fed exactly what the plan says: lead hop (seeds the ring buffer) + warm frames + owned frames
     node = oracle.OracleNode(p)
-    lead = 1 if sh.first_input_frame > 0 else 0
-    seg = np.ascontiguousarray(x[:, (sh.first_input_frame - lead) * 512: sh.hi * 512])
+    seg = np.ascontiguousarray(x[:, sh.first_feed_frame * 512: sh.hi * 512])
+    assert seg.shape[1] == sh.n_feed * 512
     y, _ = node.process(seg)
-    y_own = torch.from_numpy(y[(lead + sh.warm) * 512:].copy())
+    y_own = torch.from_numpy(y[sh.n_drop * 512:].copy())
     full = shard.gather_hops(y_own, F, world, rank)
     if rank == 0:
         ret.put(full.numpy())
