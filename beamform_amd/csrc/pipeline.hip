@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -81,6 +82,9 @@ class BinPipelineImpl : public BinPipeline {
         std::vector<f64x2> tw = twiddle_table_32x32<f64x2>();
         PIPE_HIP(hipMalloc((void **)&d_tw_, tw.size() * sizeof(f64x2)));
         PIPE_HIP(hipMemcpy(d_tw_, tw.data(), tw.size() * sizeof(f64x2), hipMemcpyHostToDevice));
+        std::vector<f32x2> tw32 = twiddle_table_32x32<f32x2>();
+        PIPE_HIP(hipMalloc((void **)&d_tw32_, tw32.size() * sizeof(f32x2)));
+        PIPE_HIP(hipMemcpy(d_tw32_, tw32.data(), tw32.size() * sizeof(f32x2), hipMemcpyHostToDevice));
         std::vector<double> h = sqrt_hann(1024);
         PIPE_HIP(hipMalloc((void **)&d_win_, h.size() * sizeof(double)));
         PIPE_HIP(hipMemcpy(d_win_, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -156,6 +160,8 @@ class BinPipelineImpl : public BinPipeline {
 
     int run(const float *x, long F, float *y, f64x2 *spectrum, hipStream_t stream, int layout, long mic_stride,
             const RunSnapshot &snap) override;
+    int run_one(const float *x, long F, float *y, f64x2 *spectrum, hipStream_t stream, int layout, long mic_stride,
+                const RunSnapshot &snap);
 
     size_t state_bytes() const override {
         return (size_t)S_ * M_ * 512 * 4 + (size_t)So_ * 512 * 4 + zhist_bytes() + gss_bytes() + mpf_bytes() + smooth_bytes() +
@@ -203,7 +209,7 @@ class BinPipelineImpl : public BinPipeline {
     }
 
     void free_all() {
-        void *ptrs[] = {d_tw_, d_win_, d_freq_, d_steer_[0], d_steer_[1], d_hist_, d_tail_[0], d_tail_[1], d_zhist_,
+        void *ptrs[] = {d_tw32_, d_tw_, d_win_, d_freq_, d_steer_[0], d_steer_[1], d_hist_, d_tail_[0], d_tail_[1], d_zhist_,
                         d_gssW_, d_mpf_, d_smooth_, d_nlms_, d_Z_, d_Yh_, d_yraw_};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
@@ -214,6 +220,7 @@ class BinPipelineImpl : public BinPipeline {
     long steer_dir_stride_ = 0;
     std::vector<double> freqs_;
     f64x2 *d_tw_ = nullptr;
+    f32x2 *d_tw32_ = nullptr;
     double *d_win_ = nullptr, *d_freq_ = nullptr;
     f64x2 *d_steer_[2] = {nullptr, nullptr};
     int steer_cur_ = 0;
@@ -234,6 +241,24 @@ class BinPipelineImpl : public BinPipeline {
 
 int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipStream_t stream, int layout,
                          long mic_stride, const RunSnapshot &snap) {
+    // experiment hook: BF_PIPE_TILE=n cuts a single-stream batch into consecutive n-frame runs (state carries as between calls)
+    static const long pipe_tile = getenv("BF_PIPE_TILE") ? atol(getenv("BF_PIPE_TILE")) : 0;
+    if (pipe_tile > 0 && F > pipe_tile && S_ == 1 && So_ == 1) {
+        RunSnapshot sn = snap;
+        for (long t0 = 0; t0 < F; t0 += pipe_tile) {
+            const long n = (F - t0 < pipe_tile) ? F - t0 : pipe_tile;
+            const float *xt = x + (layout == BF_PLANAR ? t0 * 512 : t0 * 512 * M_);
+            int rc = run_one(xt, n, y + t0 * 512, spectrum ? spectrum + t0 * 1024 : nullptr, stream, layout, mic_stride, sn);
+            if (rc != BF_OK) return rc;
+            sn.gss_reset_mask = 0;
+        }
+        return BF_OK;
+    }
+    return run_one(x, F, y, spectrum, stream, layout, mic_stride, snap);
+}
+
+int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, hipStream_t stream, int layout,
+                             long mic_stride, const RunSnapshot &snap) {
     const long FT = Phist_ + F;  // frames in the Z workspace per stream
     int rc = ensure((void **)&d_Z_, &Z_cap_, (size_t)S_ * FT * NP_ * 1024 * sizeof(f64x2));
     if (rc != BF_OK) return rc;
@@ -299,6 +324,10 @@ int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipS
     IstftArgs ia;
     ia.Yh = d_Yh_; ia.y = (cfg_.algo == BF_PHASEMPF || cfg_.algo == BF_GSC) ? d_yraw_ : y; ia.tail_in = d_tail_[tail_cur_];
     ia.tail_out = d_tail_[tail_cur_ ^ 1]; ia.tw = d_tw_; ia.win = d_win_; ia.n_frames = F; ia.n_streams = So_;
+    // backward transform in fp32 (no error amplification behind the per-bin stage; output is float32), except for gsc, whose
+    // sample-serial NLMS branches on the aligned signals
+    static const bool istft_f64 = getenv("BF_ISTFT_F64") && atoi(getenv("BF_ISTFT_F64")) != 0;
+    ia.tw32 = (cfg_.algo == BF_GSC || istft_f64) ? nullptr : d_tw32_;
     ia.post_amp = (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS) ? cfg_.out_amp : 1.0;
     ia.use_post_amp = (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS) ? 1 : 0;
     PIPE_HIP(launch_istft(ia, n_cus_, stream));

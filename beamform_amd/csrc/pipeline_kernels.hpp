@@ -60,6 +60,7 @@ struct IstftArgs {
     const float *tail_in;  // [stream][512]
     float *tail_out;
     const f64x2 *tw;
+    const f32x2 *tw32;     // non-null: backward FFT in fp32, one frame per transform (istft32_kernel)
     const double *win;
     long n_frames;
     int n_streams;

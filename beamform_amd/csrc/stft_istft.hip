@@ -9,22 +9,24 @@ namespace {
 // ======================================================================================
 //                                        STFT
 // ======================================================================================
-constexpr int kStftBlock = 256;
-constexpr int kStftHalves = kStftBlock / 32;
-
-template <int LAYOUT>
+// One 512-thread block per CU: 16 half-wavefronts = two wavefronts per SIMD (the 256-thread version ran one, and its PMC
+// profile showed 34 % of the wave cycles in s_waitcnt: nobody to hide the input loads / spectrum stores behind).
+// LDS = 16 KB inter-pass twiddles + 16 x 8.5 KB transpose planes = 152 KB; the window comes from global memory in natural
+// order (lane l reads win[32 j + l]: coalesced, 8 KB, L1-resident), which is what made room for the second half.
+template <int LAYOUT, int kStftBlock, bool TW_LDS>
 __global__ __launch_bounds__(kStftBlock) void stft_kernel(StftArgs a) {
-    __shared__ __attribute__((aligned(16))) double lds[2048 + kStftHalves * 32 * kPSd + 32 * kPSd];
-    const cx<double> *s_tw = reinterpret_cast<const cx<double> *>(lds);
-    double *s_win = lds + 2048 + kStftHalves * 32 * kPSd;
+    constexpr int kStftHalves = kStftBlock / 32;
+    constexpr int kTw = TW_LDS ? 2048 : 0;
+    __shared__ __attribute__((aligned(16))) double lds[kTw + kStftHalves * 32 * kPSd];
+    const cx<double> *s_tw = TW_LDS ? reinterpret_cast<const cx<double> *>(lds) : reinterpret_cast<const cx<double> *>(a.tw);
     const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
-    double *pbuf = lds + 2048 + hw * 32 * kPSd;
-    {
+    double *pbuf = lds + kTw + hw * 32 * kPSd;
+    if (TW_LDS) {
         const double *twf = reinterpret_cast<const double *>(a.tw);
         for (int i = tid; i < 2048; i += kStftBlock) lds[i] = twf[i];
-        for (int i = tid; i < kN; i += kStftBlock) s_win[(i & 31) * kPSd + (i >> 5)] = a.win[i];
+        __syncthreads();
     }
-    __syncthreads();
+    const double *gwin = a.win + lane;
     const int M = a.n_mics, MF = a.n_fft_mics, NP = (MF + 1) >> 1;
     const long total = (long)a.n_streams * a.n_frames * NP;
     const long stride = (long)gridDim.x * kStftHalves;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(kStftBlock) void stft_kernel(StftArgs a) {
         const double bs = b_ok ? 1.0 : 0.0;
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
-            const double h = s_win[lane * kPSd + j];
+            const double h = gwin[32 * j];
             re[j] *= h;          // buf[j]*hann_win[i]  (util.h:235)
             im[j] *= h * bs;
         }
@@ -115,17 +117,16 @@ __device__ __forceinline__ cd herm_at(const f64x2 *row, int k) {
 }
 
 __global__ __launch_bounds__(kIstftBlock) void istft_kernel(IstftArgs a, int pairs_per_chunk, int chunks_per_stream) {
-    __shared__ __attribute__((aligned(16))) double lds[2048 + kIstftHalves * 32 * kPSd + 32 * kPSd];
+    __shared__ __attribute__((aligned(16))) double lds[2048 + kIstftHalves * 32 * kPSd];
     const cx<double> *s_tw = reinterpret_cast<const cx<double> *>(lds);
-    double *s_win = lds + 2048 + kIstftHalves * 32 * kPSd;
     const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
     double *pbuf = lds + 2048 + hw * 32 * kPSd;
     {
         const double *twf = reinterpret_cast<const double *>(a.tw);
         for (int i = tid; i < 2048; i += kIstftBlock) lds[i] = twf[i];
-        for (int i = tid; i < kN; i += kIstftBlock) s_win[(i & 31) * kPSd + (i >> 5)] = a.win[i];
     }
     __syncthreads();
+    const double *gwin = a.win + lane;
     const long chunk = (long)blockIdx.x * kIstftHalves + hw;
     int s = (int)(chunk / chunks_per_stream);
     const long c_in_s = chunk - (long)s * chunks_per_stream;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(kIstftBlock) void istft_kernel(IstftArgs a, int pai
             // overlap_and_add_prepare_output (util.h:247-252) with the reference's float stores.
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
-                const double h = s_win[lane * kPSd + brev5(i)];
+                const double h = gwin[32 * brev5(i)];
                 float fa = (float)(re[i] / 1024.0);
                 fa = (float)((double)fa * h);
                 float fb = (float)(im[i] / 1024.0);
@@ -260,6 +261,104 @@ __global__ __launch_bounds__(kIstftBlock) void istft_kernel(IstftArgs a, int pai
     }
 }
 
+
+// ======================================================================================
+//                          ISTFT, single-precision transform
+// ======================================================================================
+// The inverse path has no error amplification (the output is a float32 sample; the reference rounds Re(ifft)/N to float,
+// util.h:249), so the backward FFT runs in fp32: 64 data registers instead of 128, three 256-thread blocks per CU instead
+// of one (the fp64 kernel above spends 70 % of its wave cycles in s_waitcnt at one wavefront per SIMD), a third of the
+// VALU cycles.  ONE frame per transform: the two-frames-per-IFFT packing of the fp64 kernel would leak a loud frame's
+// rounding error (1e-7 of ITS level) into a quiet partner.  Observed against the oracle: <= 2e-7 relative L2 (bound 1e-5).
+constexpr int kI32Block = 256;
+constexpr int kI32Halves = kI32Block / 32;
+constexpr int kPSf = plane_stride<float>::value;  // 36
+
+__global__ __launch_bounds__(kI32Block) void istft32_kernel(IstftArgs a, int frames_per_chunk, int chunks_per_stream) {
+    __shared__ __attribute__((aligned(16))) float lds[2048 + kI32Halves * 32 * kPSf];
+    const cx<float> *s_tw = reinterpret_cast<const cx<float> *>(lds);
+    const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
+    float *pbuf = lds + 2048 + hw * 32 * kPSf;
+    {
+        const float *twf = reinterpret_cast<const float *>(a.tw32);
+        for (int i = tid; i < 2048; i += kI32Block) lds[i] = twf[i];
+    }
+    __syncthreads();
+    const double *gwin = a.win + lane;
+    const long chunk = (long)blockIdx.x * kI32Halves + hw;
+    int s = (int)(chunk / chunks_per_stream);
+    const long c_in_s = chunk - (long)s * chunks_per_stream;
+    const bool chunk_ok = s < a.n_streams;
+    if (!chunk_ok) s = a.n_streams - 1;
+    const long t0 = c_in_s * (long)frames_per_chunk;
+    long t1 = t0 + frames_per_chunk;
+    if (t1 > a.n_frames) t1 = a.n_frames;
+    const f64x2 *Ys = a.Yh + (long)s * a.n_frames * kYhStride;
+    float *ys = a.y + (long)s * a.n_frames * kHop;
+
+    float tail[16];  // second half of the previous frame (out_buff[0], util.h:302)
+    if (t0 == 0) {   // stream start: carried state
+        const float *ti = a.tail_in + (long)s * kHop + lane;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tail[q] = ti[32 * brev5(2 * q)];
+    }
+    float re[32], im[32];
+    for (long t = (t0 == 0 ? 0 : t0 - 1); t < t1; ++t) {  // t0 - 1: warm-up frame, only its second half is used
+        const f64x2 *row = Ys + t * kYhStride;
+        // Hermitian extension of the stored row: position i holds bin k = lane + 32*brev5(i); even i are bins < 512, odd i
+        // bins >= 512 (conjugate of row[1024 - k]); bins 0 / 511 / 512 / 513 are irregular (quirk Q1)
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int kb = 32 * brev5(i);
+            cd u;
+            if (kb < 512)
+                u = ld(row + kb + lane);
+            else
+                u = conj(ld(row + (kN - kb) - lane));
+            if (i == 0 && lane == 0) u.y = 0.0;
+            if (i == 1) {
+                if (lane == 0)
+                    u.y = 0.0;
+                else if (lane == 1)
+                    u = (ld(row + 513) + u) * 0.5;
+            }
+            if (i == 30 && lane == 31) u = (u + conj(ld(row + 513))) * 0.5;
+            re[i] = (float)u.x;
+            im[i] = (float)u.y;
+        }
+        fft1024p_inv_A<float>(re, im, lane, s_tw, pbuf);
+        __builtin_amdgcn_wave_barrier();
+        fft1024p_B<float>(re, lane, pbuf);
+        __builtin_amdgcn_wave_barrier();
+        fft1024p_C<float, true>(im, lane, pbuf);
+        __builtin_amdgcn_wave_barrier();
+        fft1024p_D<float, +1>(re, im, lane, pbuf);
+        __builtin_amdgcn_wave_barrier();
+        // position i: sample n = 32*brev5(i) + lane (even i: first half, odd i: second half).
+        // overlap_and_add_prepare_output (util.h:247-252) with the reference's float stores.
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const double h = gwin[32 * brev5(i)];
+            float f = re[i] * (1.0f / 1024.0f);
+            f = (float)((double)f * h);
+            if (a.use_post_amp) f = (float)((double)f * a.post_amp);  // mvdr.cpp:112-114
+            re[i] = f;
+        }
+        if (chunk_ok && t >= t0) {
+            float *yo = ys + t * kHop + lane;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) yo[32 * brev5(2 * q)] = tail[q] + re[2 * q];
+            if (t == a.n_frames - 1) {
+                float *to = a.tail_out + (long)s * kHop + lane;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) to[32 * brev5(2 * q)] = re[2 * q + 1];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tail[q] = re[2 * q + 1];
+    }
+}
+
 // full 1024-bin y_fft dump from the per-problem rows
 __global__ void expand_spectrum_kernel(const f64x2 *Yh, f64x2 *out, long frames_total) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -304,18 +403,35 @@ __global__ void smooth_state_kernel(const float *yraw, double *state, long n, in
 }  // namespace
 
 hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
+    static const int variant = getenv("BF_STFT_VARIANT") ? atoi(getenv("BF_STFT_VARIANT")) : 0;
+    const int nb = variant == 1 ? 512 : 256, halves = nb / 32;
     const long total = (long)a.n_streams * a.n_frames * ((a.n_fft_mics + 1) / 2);
-    long blocks = (total + kStftHalves - 1) / kStftHalves;
-    const long cap = (long)n_cus * 4;
+    long blocks = (total + halves - 1) / halves;
+    const long cap = (long)n_cus * (variant == 1 ? 2 : 4);
     if (blocks > cap) blocks = cap;
-    if (a.layout == 0)
-        hipLaunchKernelGGL(stft_kernel<0>, dim3((unsigned)blocks), dim3(kStftBlock), 0, s, a);
-    else
-        hipLaunchKernelGGL(stft_kernel<1>, dim3((unsigned)blocks), dim3(kStftBlock), 0, s, a);
+#define BF_STFT_GO(L_) \
+    do { \
+        if (variant == 1) hipLaunchKernelGGL((stft_kernel<L_, 512, true>), dim3((unsigned)blocks), dim3(nb), 0, s, a); \
+        else if (variant == 2) hipLaunchKernelGGL((stft_kernel<L_, 256, false>), dim3((unsigned)blocks), dim3(nb), 0, s, a); \
+        else hipLaunchKernelGGL((stft_kernel<L_, 256, true>), dim3((unsigned)blocks), dim3(nb), 0, s, a); \
+    } while (0)
+    if (a.layout == 0) BF_STFT_GO(0); else BF_STFT_GO(1);
+#undef BF_STFT_GO
     return hipGetLastError();
 }
 
 hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s) {
+    if (a.tw32 != nullptr) {  // fp32 backward transform, one frame per FFT
+        long slots = (long)n_cus * kI32Halves * 3 / a.n_streams;  // three blocks per CU
+        if (slots < 1) slots = 1;
+        long cps = slots < a.n_frames ? slots : a.n_frames;
+        const long fpc = (a.n_frames + cps - 1) / cps;
+        cps = (a.n_frames + fpc - 1) / fpc;
+        const long chunks = cps * a.n_streams;
+        hipLaunchKernelGGL(istft32_kernel, dim3((unsigned)((chunks + kI32Halves - 1) / kI32Halves)), dim3(kI32Block), 0, s, a,
+                           (int)fpc, (int)cps);
+        return hipGetLastError();
+    }
     const long pairs = (a.n_frames + 1) / 2;
     long slots = (long)n_cus * kIstftHalves * 2 / a.n_streams;
     if (slots < 1) slots = 1;

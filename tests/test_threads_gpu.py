@@ -58,7 +58,8 @@ def hammer_and_check(p, x, F, make_nodes, update):
         stop.set()
         th.join()
     assert count[0] > 200, "the control thread hardly ran"
-    rms = float(np.sqrt(np.mean(np.concatenate([h for h, _ in pieces]).astype(np.float64) ** 2)))
+    allh = np.concatenate([h for h, _ in pieces]).astype(np.float64)
+    rms = float(np.sqrt(np.mean(allh[np.isfinite(allh)] ** 2)))       # mvdr/lcmv: frame 0 of a cold node is NaN
     used = set()
     for t in range(1, F):
         best, arg = None, None
