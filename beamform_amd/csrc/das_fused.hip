@@ -45,6 +45,90 @@ constexpr int kLdsPlane = 32 * kPS;          // floats per half-wavefront
 constexpr int kLdsWin = 32 * kPS;            // floats
 constexpr int kLdsFixed = kLdsTw + kHalves * kLdsPlane + kLdsWin;
 
+
+// ---- wave-interleaved transposes (WT variant) ---------------------------------------------------------------------------
+// The plane-split transpose of fft1024.hpp writes one dword per lane with ds_write(2)_b32 (64 B/clk/CU) -- 58 % of this
+// kernel's LDS cycles.  ds_write_addtid_b32 (address = M0 + offset + 4*lane, no address VGPR) stores at twice that rate, but
+// its address pattern is fixed: 64 consecutive dwords per instruction.  So the two half-wavefronts of a wavefront share one
+// plane whose rows are [half 0: 32 floats | half 1: 32 floats | 4 pad] (272 B): one store per register position writes the
+// same row of both halves; lane l of half h then reads row l, columns 32 h .. 32 h + 31, as eight ds_read_b128 (the 16-lane
+// read groups stay inside one half, lanes 4 banks apart: conflict-free).  Same arithmetic, bit-identical output.
+constexpr int kWRow = 68;                 // floats per row of the shared plane
+constexpr int kWPlane = 32 * kWRow;       // floats per wavefront
+
+template <bool NATURAL>
+__device__ constexpr int wt_row_off(int i) { return (NATURAL ? i : brev5(i)) * kWRow * 4; }
+
+// eight register positions I0 .. I0+7 of `v` -> rows of the plane at LDS byte address `base` (wave-uniform).
+// M0 is compiler-reserved: saved and restored inside the statement that uses it.
+template <int I0, bool NATURAL>
+__device__ __forceinline__ void wt_store8(const float (&v)[32], unsigned base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %9\n\ts_nop 0\n\t"
+        "ds_write_addtid_b32 %1 offset:%c10\n\tds_write_addtid_b32 %2 offset:%c11\n\t"
+        "ds_write_addtid_b32 %3 offset:%c12\n\tds_write_addtid_b32 %4 offset:%c13\n\t"
+        "ds_write_addtid_b32 %5 offset:%c14\n\tds_write_addtid_b32 %6 offset:%c15\n\t"
+        "ds_write_addtid_b32 %7 offset:%c16\n\tds_write_addtid_b32 %8 offset:%c17\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(v[I0]), "v"(v[I0 + 1]), "v"(v[I0 + 2]), "v"(v[I0 + 3]), "v"(v[I0 + 4]), "v"(v[I0 + 5]), "v"(v[I0 + 6]),
+          "v"(v[I0 + 7]), "s"(base), "i"(wt_row_off<NATURAL>(I0)), "i"(wt_row_off<NATURAL>(I0 + 1)),
+          "i"(wt_row_off<NATURAL>(I0 + 2)), "i"(wt_row_off<NATURAL>(I0 + 3)), "i"(wt_row_off<NATURAL>(I0 + 4)),
+          "i"(wt_row_off<NATURAL>(I0 + 5)), "i"(wt_row_off<NATURAL>(I0 + 6)), "i"(wt_row_off<NATURAL>(I0 + 7))
+        : "memory");
+}
+template <bool NATURAL>
+__device__ __forceinline__ void wt_store_plane(const float (&v)[32], unsigned base) {
+    wt_store8<0, NATURAL>(v, base);
+    wt_store8<8, NATURAL>(v, base);
+    wt_store8<16, NATURAL>(v, base);
+    wt_store8<24, NATURAL>(v, base);
+}
+// row `lane` of this half: rp = plane + lane * kWRow + 32 * half.  LDS operations of one wavefront execute in issue order,
+// so the reads see the stores above without a wait (the "memory" clobber keeps the compiler from moving them).
+__device__ __forceinline__ void wt_load_row(float (&v)[32], const float *rp) {
+    const float4 *r4 = reinterpret_cast<const float4 *>(rp);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const float4 q = r4[g];
+        v[4 * g + 0] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
+    }
+}
+// forward / backward FFT-1024 of the half-wavefront's 32 x 32 points (same arithmetic as fft1024p_{fwd,inv}_A .. D)
+__device__ __forceinline__ void wt_fft_fwd(float (&re)[32], float (&im)[32], int lane, const cx<float> *tw, unsigned base,
+                                           const float *rp) {
+    fft32_dif<float, -1>(re, im);
+#pragma unroll
+    for (int i = 1; i < 32; ++i) {
+        const cx<float> w = tw[brev5(i) * 32 + lane];
+        const float xr = re[i], xi = im[i];
+        re[i] = xr * w.x - xi * w.y;
+        im[i] = xr * w.y + xi * w.x;
+    }
+    wt_store_plane<false>(re, base);
+    wt_load_row(re, rp);
+    wt_store_plane<false>(im, base);
+    wt_load_row(im, rp);
+    fft32_dif<float, -1>(re, im);
+}
+__device__ __forceinline__ void wt_fft_inv(float (&re)[32], float (&im)[32], int lane, const cx<float> *tw, unsigned base,
+                                           const float *rp) {
+    fft32_dit<float, +1>(re, im);
+#pragma unroll
+    for (int n2 = 1; n2 < 32; ++n2) {
+        const cx<float> w = tw[n2 * 32 + lane];
+        const float xr = re[n2], xi = im[n2];
+        re[n2] = xr * w.x + xi * w.y;
+        im[n2] = xi * w.x - xr * w.y;
+    }
+    wt_store_plane<true>(re, base);
+    wt_load_row(re, rp);
+    wt_store_plane<true>(im, base);
+    wt_load_row(im, rp);
+    fft32_dif<float, +1>(re, im);
+}
+
 // NPL = number of pair-gain tables held in LDS (0: read gains from global memory)
 //
 // Work split: one 512-thread block (16 half-wavefronts) owns a run of consecutive frames of one
@@ -55,7 +139,7 @@ constexpr int kLdsFixed = kLdsTw + kHalves * kLdsPlane + kLdsWin;
 // partner (second half of frame t-1) comes from the neighbour through a 17-slot LDS ring; only the
 // first hop of a run needs the previous run's last frame, and that one hop is completed by two
 // float atomic adds into a pre-zeroed hop (sum of two terms: order-independent, bit-exact).
-template <int LAYOUT, int NPL>
+template <int LAYOUT, int NPL, bool WT>
 __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFixed + NPL * 2048 + 17 * kHop + 32];
     const cx<float> *s_tw = reinterpret_cast<const cx<float> *>(lds);
@@ -71,6 +155,10 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
     const int lane = tid & 31;
     const int hw = tid >> 5;
     float *pbuf = lds + kLdsTw + hw * kLdsPlane;
+    // WT: the two halves of a wavefront share one interleaved plane (8 x 8.5 KiB inside the same 72 KiB region)
+    float *wplane = lds + kLdsTw + (hw >> 1) * kWPlane;
+    const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float *)wplane);
+    const float *wrowp = wplane + lane * kWRow + 32 * (hw & 1);
     const int M = a.n_mics;
     const int n_pairs = (M + 1) >> 1;
 
@@ -177,14 +265,18 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                 re[4 * g + 3] *= hv.w; im[4 * g + 3] *= hv.w;
             }
 
-            fft1024p_fwd_A<float>(re, im, lane, s_tw, pbuf);
-            __builtin_amdgcn_wave_barrier();
-            fft1024p_B<float>(re, lane, pbuf);
-            __builtin_amdgcn_wave_barrier();
-            fft1024p_C<float, false>(im, lane, pbuf);
-            __builtin_amdgcn_wave_barrier();
-            fft1024p_D<float, -1>(re, im, lane, pbuf);
-            __builtin_amdgcn_wave_barrier();
+            if (WT) {
+                wt_fft_fwd(re, im, lane, s_tw, wbase, wrowp);
+            } else {
+                fft1024p_fwd_A<float>(re, im, lane, s_tw, pbuf);
+                __builtin_amdgcn_wave_barrier();
+                fft1024p_B<float>(re, lane, pbuf);
+                __builtin_amdgcn_wave_barrier();
+                fft1024p_C<float, false>(im, lane, pbuf);
+                __builtin_amdgcn_wave_barrier();
+                fft1024p_D<float, -1>(re, im, lane, pbuf);
+                __builtin_amdgcn_wave_barrier();
+            }
 
             const cx<float> *gp = (NPL > 0 ? s_gain : reinterpret_cast<const cx<float> *>(gains)) + (long)p * 1024 + lane;
             if (p == 0) {
@@ -213,14 +305,18 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
         // the next frame's first pair streams in while the inverse transform runs on (Sr, Si)
         if (LAYOUT == 0 && it + 1 < n_iter) issue_loads(frame_of(it + 1), 0);
 
-        fft1024p_inv_A<float>(Sr, Si, lane, s_tw, pbuf);
-        __builtin_amdgcn_wave_barrier();
-        fft1024p_B<float>(Sr, lane, pbuf);
-        __builtin_amdgcn_wave_barrier();
-        fft1024p_C<float, true>(Si, lane, pbuf);
-        __builtin_amdgcn_wave_barrier();
-        fft1024p_D<float, +1>(Sr, Si, lane, pbuf);
-        __builtin_amdgcn_wave_barrier();
+        if (WT) {
+            wt_fft_inv(Sr, Si, lane, s_tw, wbase, wrowp);
+        } else {
+            fft1024p_inv_A<float>(Sr, Si, lane, s_tw, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_B<float>(Sr, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_C<float, true>(Si, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_D<float, +1>(Sr, Si, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+        }
 
         // position i holds sample n = 32*brev5(i) + lane; even i -> first half, odd i -> n + 512
         float h[32];
@@ -294,17 +390,17 @@ __global__ void das_hermitian_dump_kernel(const f32x2 *s, f64x2 *out, long total
     out[idx] = f64x2{0.5 * kNfft * ((double)u.x + (double)v.x), 0.5 * kNfft * ((double)u.y - (double)v.y)};
 }
 
-template <int LAYOUT>
+template <int LAYOUT, bool WT>
 void launch_layout(const DasFusedArgs &a, unsigned blocks, hipStream_t stream) {
     const int np = (a.n_mics + 1) / 2;
     if (np <= 1)
-        hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 1>), dim3(blocks), dim3(kBlock), 0, stream, a);
+        hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 1, WT>), dim3(blocks), dim3(kBlock), 0, stream, a);
     else if (np <= 2)
-        hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 2>), dim3(blocks), dim3(kBlock), 0, stream, a);
+        hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 2, WT>), dim3(blocks), dim3(kBlock), 0, stream, a);
     else if (np <= 4)
-        hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 4>), dim3(blocks), dim3(kBlock), 0, stream, a);
+        hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 4, WT>), dim3(blocks), dim3(kBlock), 0, stream, a);
     else  // > 8 mics: the gain tables no longer fit beside the transpose buffers and the tail ring
-        hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 0>), dim3(blocks), dim3(kBlock), 0, stream, a);
+        hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 0, WT>), dim3(blocks), dim3(kBlock), 0, stream, a);
 }
 
 // Sum of squares of every output stream (double accumulation): bf_stream_rms.
@@ -342,9 +438,9 @@ hipError_t prepare_das_fused(const DasFusedArgs &a, hipStream_t stream) {
 hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t stream) {
     const unsigned blocks = (unsigned)((long)a.chunks_per_stream * a.n_streams);
     if (a.layout == 0)
-        launch_layout<0>(a, blocks, stream);
+        { if (a.variant & 1) launch_layout<0, true>(a, blocks, stream); else launch_layout<0, false>(a, blocks, stream); }
     else
-        launch_layout<1>(a, blocks, stream);
+        { if (a.variant & 1) launch_layout<1, true>(a, blocks, stream); else launch_layout<1, false>(a, blocks, stream); }
     return hipGetLastError();
 }
 

@@ -29,6 +29,7 @@ struct DasFusedArgs {
     int frames_per_chunk;
     int chunks_per_stream;
     int layout;            // bf_layout
+    int variant;           // bit 0: wave-interleaved transposes stored with ds_write_addtid_b32 (default on)
 };
 // 64-lane variant (das_fused_w64.hip): `gains` / `twiddle` must be the *_w64 tables
 hipError_t launch_das_fused_w64(const DasFusedArgs &a, hipStream_t stream);
