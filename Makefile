@@ -6,10 +6,13 @@ SRC := beamform_amd/csrc
 OBJ := build/obj
 LIB := beamform_amd/lib/libbfcore.so
 
-HIP_SRCS := $(SRC)/das_fused.hip $(SRC)/das_fused_w64.hip $(SRC)/pipeline.hip $(SRC)/pipeline_kernels.hip \
-            $(SRC)/stft_istft.hip $(SRC)/mask_kernels.hip $(SRC)/cov_kernels.hip $(SRC)/gsc_gss_kernels.hip
+HIP_SRCS := $(SRC)/das_fused.hip $(SRC)/das_fused_w64.hip $(SRC)/pipeline.hip
+# bin-pipeline kernels: one object per supported FFT size (hop 256 / 512 / 1024 -> -DBF_NFFT=512 / 1024 / 2048)
+BIN_SRCS := pipeline_kernels stft_istft mask_kernels cov_kernels gsc_gss_kernels
+NFFTS := 512 1024 2048
 CPP_SRCS := $(SRC)/capi.cpp $(SRC)/config.cpp
-OBJS := $(patsubst $(SRC)/%.hip,$(OBJ)/%.o,$(HIP_SRCS)) $(patsubst $(SRC)/%.cpp,$(OBJ)/%.o,$(CPP_SRCS))
+OBJS := $(patsubst $(SRC)/%.hip,$(OBJ)/%.o,$(HIP_SRCS)) $(patsubst $(SRC)/%.cpp,$(OBJ)/%.o,$(CPP_SRCS)) \
+        $(foreach n,$(NFFTS),$(foreach b,$(BIN_SRCS),$(OBJ)/$(b)_n$(n).o))
 HDRS := $(wildcard $(SRC)/*.hpp) include/bfcore.h
 
 all: $(LIB) oracle examples/file_node examples/theta_scan
@@ -23,6 +26,13 @@ examples/file_node: examples/file_node.cpp include/bf_node_shim.hpp include/bfco
 $(OBJ)/%.o: $(SRC)/%.hip $(HDRS)
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+define BIN_RULE
+$(OBJ)/%_n$(1).o: $(SRC)/%.hip $(HDRS)
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -DBF_NFFT=$(1) -c $$< -o $$@
+endef
+$(foreach n,$(NFFTS),$(eval $(call BIN_RULE,$(n))))
 
 $(OBJ)/%.o: $(SRC)/%.cpp $(HDRS)
 	@mkdir -p $(OBJ)

@@ -10,12 +10,14 @@
 #include "fft1024.hpp"
 #include "pipeline_kernels.hpp"
 
+#ifndef BF_NFFT
+#error "kernel translation units are compiled per FFT size: -DBF_NFFT=512|1024|2048"
+#endif
+
 namespace bf {
+namespace BF_NTAG {
 namespace {
 
-
-constexpr int kHop = 512;
-constexpr int kN = 1024;
 constexpr int kPSd = plane_stride<double>::value;  // 34
 
 // ---- tiny complex helpers (double) ---------------------------------------------------
@@ -63,7 +65,7 @@ __device__ __forceinline__ cd ld(const f64x2 *p) {
 }
 
 // problem index -> FFT bin whose packed spectrum is read, and whether X must be conjugated
-__device__ __forceinline__ int q_src_bin(int q) { return q == 513 ? 511 : q; }
+__device__ __forceinline__ int q_src_bin(int q) { return q == kQX ? kN / 2 - 1 : q; }
 __device__ __forceinline__ int q_bin(int q) { return q; }
 
 // X_m for problem q out of the packed pair spectra of one frame (Zf = [NP][1024]).
@@ -79,7 +81,7 @@ __device__ __forceinline__ void load_X(const f64x2 *Zf, int q, int M, cd (&X)[MP
             cd xa = (z + zc) * 0.5;                 // (Z[k] + conj Z[N-k]) / 2
             const cd d = z - zc;                    // (Z[k] - conj Z[N-k]) / (2i) = -i/2 * d
             cd xb = cd{0.5 * d.y, -0.5 * d.x};
-            if (q == 513) {
+            if (q == kQX) {
                 xa = conj(xa);
                 xb = conj(xb);
             }
@@ -93,4 +95,5 @@ __device__ __forceinline__ void load_X(const f64x2 *Zf, int q, int M, cd (&X)[MP
 }
 
 }  // namespace
+}  // namespace BF_NTAG
 }  // namespace bf

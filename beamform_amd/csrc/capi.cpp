@@ -91,7 +91,11 @@ int fail(bf_handle *h, int code, const char *what, hipError_t e = hipSuccess) {
         if (e_ != hipSuccess) return fail((h), BF_EIO, #call, e_);       \
     } while (0)
 
-bool uses_fused_das(const bf_handle *h) { return h->cfg.algo == BF_DAS && h->cfg.das_impl == BF_DAS_FUSED_F32; }
+// the fused fp32 kernel is built for the 512-frame period (32 x 32 in-register FFT-1024); 256- and 1024-frame periods run das
+// through the fp64 bin pipeline
+bool uses_fused_das(const bf_handle *h) {
+    return h->cfg.algo == BF_DAS && h->cfg.das_impl == BF_DAS_FUSED_F32 && h->cfg.hop == 512;
+}
 
 // update_weights(): recompute every steering column from the current angles.
 void rebuild_steering(bf_handle *h, bool first, int only_dir = -1) {
@@ -264,7 +268,8 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
     *out = nullptr;
     if (cfg->algo < BF_DAS || cfg->algo > BF_GSC) return fail(nullptr, BF_EINVAL, "algo out of range");
     if (cfg->n_mics < 1 || cfg->n_mics > BF_MAX_MICS) return fail(nullptr, BF_EINVAL, "n_mics out of range");
-    if (cfg->hop != 512) return fail(nullptr, BF_ENOSYS, "only hop 512 (fft_win 1024) is built");
+    if (cfg->hop != 256 && cfg->hop != 512 && cfg->hop != 1024)
+        return fail(nullptr, BF_ENOSYS, "hop (JACK period) must be 256, 512 or 1024 frames: fft_win 512 / 1024 / 2048");
     if (cfg->n_streams < 1) return fail(nullptr, BF_EINVAL, "n_streams < 1");
     if (cfg->n_dirs < 0 || cfg->n_dirs > BF_MAX_DIRS) return fail(nullptr, BF_EINVAL, "n_dirs out of range");
     if (cfg->n_dirs > 1 && (cfg->algo == BF_MCRA || cfg->algo == BF_GSC))
@@ -474,7 +479,7 @@ int bf_set_interference(bf_handle *h, unsigned id, double degrees) {
         for (i = 0; i < ia.size(); ++i)
             if (std::abs(ia[i] - degrees) < thr) break;
         if (i != ia.size()) return BF_OK;  // too close to an existing interferer: ignored, as the reference does
-        if (ia.size() + 1 > 3) return fail(h, BF_ENOSYS, "per-bin kernels are built for up to 3 interferers");
+        if (ia.size() + 1 > BF_MAX_INTERF) return fail(h, BF_ENOSYS, "per-bin kernels are built for up to 15 interferers");
         ia.push_back(degrees);
         structural = true;
     } else {

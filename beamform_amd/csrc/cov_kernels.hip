@@ -3,6 +3,7 @@
 #include "bins_common.hpp"
 
 namespace bf {
+namespace BF_NTAG {
 
 namespace {
 
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
                 cd xa = (z + zc) * 0.5;
                 const cd d = z - zc;
                 cd xb = cd{0.5 * d.y, -0.5 * d.x};
-                if (qq == 513) {
+                if (qq == kQX) {
                     xa = conj(xa);
                     xb = conj(xb);
                 }
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
 #pragma unroll
         for (int m = 0; m < MP; ++m)
             if (m < M) mag += sqrt(norm2(X[m]));  // |X| well inside double range: no hypot scaling needed
-        mag /= (double)((unsigned)M * 1024u);
+        mag /= (double)((unsigned)M * (unsigned)kN);
         cd A[NT], ua[MP], ux[MP];
 #pragma unroll
         for (int i = 0; i < MP; ++i) {
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
             const cd d = z - zc;
             x = cd{0.5 * d.y, -0.5 * d.x};
         }
-        return q == 513 ? conj(x) : x;
+        return q == kQX ? conj(x) : x;
     };
 
     const double f = fabs(a.freqs[j]);
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
         __builtin_amdgcn_wave_barrier();
         double mag = 0.0;
         for (int m = 0; m < M; ++m) mag += sqrt(norm2(s_x[grp][m]));
-        mag /= (double)((unsigned)M * 1024u);
+        mag /= (double)((unsigned)M * (unsigned)kN);
         cd y;
         if (mag > a.cfg.freq_mag_threshold) {
             cd A[MP], b[NB];
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(64, 1) void mvdr_lcmv_lanes_kernel(BinsArgs a, int 
             const cd d = z - zc;
             x = cd{0.5 * d.y, -0.5 * d.x};
         }
-        return qq == 513 ? conj(x) : x;
+        return qq == kQX ? conj(x) : x;
     };
     if (__builtin_amdgcn_ballot_w64(inband) == 0) {  // nothing to solve in this wavefront
         if (live && q == 0)
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(64, 1) void mvdr_lcmv_lanes_kernel(BinsArgs a, int 
         double mag = 0.0;
 #pragma unroll
         for (int r = 0; r < RPL; ++r) mag += sqrt(norm2(xl[r]));  // padded rows are 0
-        mag = grp_sum<L>(mag) / (double)((unsigned)M * 1024u);
+        mag = grp_sum<L>(mag) / (double)((unsigned)M * (unsigned)kN);
         const cd x0 = bcast_from<L>(0, xl[0]);
         cd y;
         if (mag > a.cfg.freq_mag_threshold) {
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(256, 2) void mvdr_lcmv_row_kernel(BinsArgs a, int t
             const cd d = z - zc;
             x = cd{0.5 * d.y, -0.5 * d.x};
         }
-        return q == 513 ? conj(x) : x;
+        return q == kQX ? conj(x) : x;
     };
     const double f = fabs(a.freqs[j]);
     const bool inband = f >= a.cfg.freq_min && f <= a.cfg.freq_max;
@@ -779,7 +780,7 @@ __global__ __launch_bounds__(256, 2) void mvdr_lcmv_row_kernel(BinsArgs a, int t
     }
     for (long t = tA; t < tB; ++t) {
         const cd x = load_xi(t);
-        const double mag = row_sum(sqrt(norm2(x))) / (double)((unsigned)M * 1024u);
+        const double mag = row_sum(sqrt(norm2(x))) / (double)((unsigned)M * (unsigned)kN);
         cd y;
         if (mag > a.cfg.freq_mag_threshold) {  // uniform per row
             cd A[MP], b[NB];
@@ -888,6 +889,28 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
     const int tps = (int)((a.n_frames + tile - 1) / tile);
     const int M = a.n_mics, km = a.kp1 <= 1 ? 1 : 4;
     static const bool no_fast = getenv("BF_MVDR_GROUP") && atoi(getenv("BF_MVDR_GROUP")) != 0;
+#define BF_LAUNCH_ML(MP_, KM_)                                                                                   \
+    hipLaunchKernelGGL((mvdr_lcmv_kernel<MP_, KM_>), dim3(tps * a.n_streams, (kNQ + (256 / MP_) - 1) / (256 / MP_)), \
+                       dim3(256), 0, s, a, tile, tps)
+    // beyond the tuned shapes -- more than 3 interferers (lcmv.cpp:258-309 appends without a cap; the yaml lists
+    // angle_interf1..15) or more than 16 microphones -- the row-per-lane group kernel runs with the next larger
+    // (lanes per problem, constraint columns) instantiation; padding rows / columns are identity
+    if (a.kp1 > 4 || M > 16) {
+        if (a.kp1 > 16 || M > 32) return hipErrorInvalidValue;
+        if (a.kp1 <= 1) {
+            BF_LAUNCH_ML(32, 1);
+        } else if (a.kp1 <= 4) {
+            BF_LAUNCH_ML(32, 4);
+        } else if (a.kp1 <= 8) {
+            if (M <= 8) BF_LAUNCH_ML(8, 8);
+            else if (M <= 16) BF_LAUNCH_ML(16, 8);
+            else BF_LAUNCH_ML(32, 8);
+        } else {
+            if (M <= 16) BF_LAUNCH_ML(16, 16);
+            else BF_LAUNCH_ML(32, 16);
+        }
+        return hipGetLastError();
+    }
     // lcmv with 9..16 microphones: one problem per DPP row, row_newbcast exchange (34.2 -> 27.6 ms per 32 768 frames at 16)
     if (!no_fast && a.cfg.algo == BF_LCMV && M > 8) {
         const dim3 grid(tps * a.n_streams, (kNQ + 15) / 16);  // x: tile * stream (can exceed 65535), y: bin blocks
@@ -928,9 +951,6 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
             hipLaunchKernelGGL((mvdr_fast_kernel<8>), grid, dim3(64), 0, s, a, ft, ftps);
         return hipGetLastError();
     }
-#define BF_LAUNCH_ML(MP_, KM_)                                                                                   \
-    hipLaunchKernelGGL((mvdr_lcmv_kernel<MP_, KM_>), dim3(tps * a.n_streams, (kNQ + (256 / MP_) - 1) / (256 / MP_)), \
-                       dim3(256), 0, s, a, tile, tps)
     if (M <= 4) {
         if (km == 1) BF_LAUNCH_ML(4, 1); else BF_LAUNCH_ML(4, 4);
     } else if (M <= 8) {
@@ -942,4 +962,5 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
     return hipGetLastError();
 }
 
+}  // namespace BF_NTAG
 }  // namespace bf

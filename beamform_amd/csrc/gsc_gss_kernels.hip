@@ -3,6 +3,7 @@
 #include "bins_common.hpp"
 
 namespace bf {
+namespace BF_NTAG {
 
 namespace {
 
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(256) void gsc_align_kernel(BinsArgs a) {
         const cd d = z - zc;
         x = cd{0.5 * d.y, -0.5 * d.x};
     }
-    if (q == 513) x = conj(x);
+    if (q == kQX) x = conj(x);
     const cd y = x * conj(ld(a.steer + (long)m * kN + q_bin(q)));
     a.Yh[((long)so * a.n_frames + t) * kYhStride + q] = f64x2{y.x, y.y};
 }
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256) void gss_kernel(BinsArgs a) {
                 const cd d = z - zc;
                 x = cd{0.5 * d.y, -0.5 * d.x};
             }
-            if (q == 513) x = conj(x);
+            if (q == kQX) x = conj(x);
         }
         s_x[grp][m] = x;
 #pragma unroll
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void gss_kernel(BinsArgs a) {
             mag += cabs(v);
             alpha += norm2(v);
         }
-        mag /= (double)((unsigned)M * 1024u);
+        mag /= (double)((unsigned)M * (unsigned)kN);
         cd y;
         if (mag > a.cfg.freq_mag_threshold) {
             cd yf[KM];
@@ -342,7 +343,13 @@ hipError_t launch_gss(const BinsArgs &a, int n_cus, hipStream_t s) {
     const int groups = a.n_streams * kNQ;
 #define BF_LAUNCH_GSS(MP_, KM_) \
     hipLaunchKernelGGL((gss_kernel<MP_, KM_>), dim3((groups + (256 / MP_) - 1) / (256 / MP_)), dim3(256), 0, s, a)
-    if (M <= 4) {
+    if (a.kp1 > 4 || M > 16) {  // beyond the tuned shapes: more interferers (up to 15) or microphones (up to 32)
+        if (a.kp1 > 16 || M > 32) return hipErrorInvalidValue;
+        if (a.kp1 <= 1) BF_LAUNCH_GSS(32, 1);
+        else if (a.kp1 <= 4) BF_LAUNCH_GSS(32, 4);
+        else if (a.kp1 <= 8) { if (M <= 8) BF_LAUNCH_GSS(8, 8); else if (M <= 16) BF_LAUNCH_GSS(16, 8); else BF_LAUNCH_GSS(32, 8); }
+        else { if (M <= 16) BF_LAUNCH_GSS(16, 16); else BF_LAUNCH_GSS(32, 16); }
+    } else if (M <= 4) {
         if (km == 1) BF_LAUNCH_GSS(4, 1); else BF_LAUNCH_GSS(4, 4);
     } else if (M <= 8) {
         if (km == 1) BF_LAUNCH_GSS(8, 1); else BF_LAUNCH_GSS(8, 4);
@@ -383,4 +390,5 @@ hipError_t launch_gsc_align(const BinsArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+}  // namespace BF_NTAG
 }  // namespace bf

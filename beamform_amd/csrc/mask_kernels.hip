@@ -2,6 +2,7 @@
 #include "bins_common.hpp"
 
 namespace bf {
+namespace BF_NTAG {
 
 namespace {
 
@@ -66,7 +67,7 @@ __device__ __forceinline__ cd phase_bin(const BinCtx &c, const bf_config &cfg) {
         if (m < c.M) mag += cabs(X[m]);
     mag /= (double)c.M;
     bool keep = false;
-    if (mag / 1024.0 > cfg.mag_threshold) {
+    if (mag / (double)kN > cfg.mag_threshold) {
         double ph[MP];
 #pragma unroll
         for (int m = 0; m < MP; ++m) {
@@ -361,4 +362,5 @@ hipError_t launch_mcra_node(const BinsArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+}  // namespace BF_NTAG
 }  // namespace bf

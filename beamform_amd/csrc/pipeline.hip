@@ -42,10 +42,15 @@ namespace {
     } while (0)
 
 class BinPipelineImpl : public BinPipeline {
-    static constexpr int kMaxCols = 4;  // look direction + up to 3 interferers (per-bin kernels: KM = 4)
+    static constexpr int kMaxCols = BF_MAX_INTERF + 1;  // look direction + up to 15 interferers (per-bin kernels: KM <= 16)
    public:
     BinPipelineImpl(const bf_config &c, int n_cus) : cfg_(c), n_cus_(n_cus) {
         M_ = c.n_mics;
+        H_ = c.hop;
+        N_ = 2 * c.hop;
+        NQ_ = problems_per_frame(N_);
+        YS_ = yh_stride(N_);
+        ks_ = kernel_set(N_);
         MF_ = (c.algo == BF_MCRA) ? 1 : M_;  // the mcra node only transforms channel 0 (mcra.cpp:72-73)
         NP_ = (MF_ + 1) / 2;
         S_ = c.n_streams;                                   // input streams
@@ -59,12 +64,16 @@ class BinPipelineImpl : public BinPipeline {
     ~BinPipelineImpl() override { free_all(); }
 
     int init() override {
-        if (M_ > 16 && (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS)) {
-            err_ = "mvdr/lcmv/gss kernels are built for up to 16 microphones";
+        if (ks_ == nullptr) {
+            err_ = "hop must be 256, 512 or 1024 (FFT 512 / 1024 / 2048)";
             return BF_ENOSYS;
         }
-        if (KP1_ > 4 && (cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS)) {
-            err_ = "lcmv/gss kernels are built for up to 3 interferers";
+        if (M_ > 32 && (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS)) {
+            err_ = "mvdr/lcmv/gss kernels are built for up to 32 microphones";
+            return BF_ENOSYS;
+        }
+        if (KP1_ > kMaxCols && (cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS)) {
+            err_ = "lcmv/gss kernels are built for up to 15 interferers";
             return BF_ENOSYS;
         }
         if ((cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV) && (Phist_ < 1 || Phist_ > 64)) {
@@ -79,23 +88,31 @@ class BinPipelineImpl : public BinPipeline {
             err_ = "smooth_size must be in 1..64";
             return BF_EINVAL;
         }
+        // N = 1024: inter-pass twiddles of the 32 x 32 factorisation; other sizes: exp(-2 pi i m / N), m < N/2 (Stockham passes)
         std::vector<f64x2> tw = twiddle_table_32x32<f64x2>();
+        if (N_ != 1024) {
+            tw.resize(N_ / 2);
+            for (int m = 0; m < N_ / 2; ++m) {
+                const double a = -2.0 * kPi * (double)m / (double)N_;
+                tw[m] = f64x2{std::cos(a), std::sin(a)};
+            }
+        }
         PIPE_HIP(hipMalloc((void **)&d_tw_, tw.size() * sizeof(f64x2)));
         PIPE_HIP(hipMemcpy(d_tw_, tw.data(), tw.size() * sizeof(f64x2), hipMemcpyHostToDevice));
         std::vector<f32x2> tw32 = twiddle_table_32x32<f32x2>();
         PIPE_HIP(hipMalloc((void **)&d_tw32_, tw32.size() * sizeof(f32x2)));
         PIPE_HIP(hipMemcpy(d_tw32_, tw32.data(), tw32.size() * sizeof(f32x2), hipMemcpyHostToDevice));
-        std::vector<double> h = sqrt_hann(1024);
+        std::vector<double> h = sqrt_hann(N_);
         PIPE_HIP(hipMalloc((void **)&d_win_, h.size() * sizeof(double)));
         PIPE_HIP(hipMemcpy(d_win_, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
-        freqs_ = frequency_vector(1024, cfg_.sample_rate);
-        PIPE_HIP(hipMalloc((void **)&d_freq_, 1024 * sizeof(double)));
-        PIPE_HIP(hipMemcpy(d_freq_, freqs_.data(), 1024 * sizeof(double), hipMemcpyHostToDevice));
+        freqs_ = frequency_vector(N_, cfg_.sample_rate);
+        PIPE_HIP(hipMalloc((void **)&d_freq_, N_ * sizeof(double)));
+        PIPE_HIP(hipMemcpy(d_freq_, freqs_.data(), N_ * sizeof(double), hipMemcpyHostToDevice));
         for (int i = 0; i < 2; ++i)
-            PIPE_HIP(hipMalloc((void **)&d_steer_[i], (size_t)D_ * 1024 * M_ * kMaxCols * sizeof(f64x2)));
-        PIPE_HIP(hipMalloc((void **)&d_hist_, (size_t)S_ * M_ * 512 * sizeof(float)));
-        PIPE_HIP(hipMalloc((void **)&d_tail_[0], (size_t)So_ * 512 * sizeof(float)));
-        PIPE_HIP(hipMalloc((void **)&d_tail_[1], (size_t)So_ * 512 * sizeof(float)));
+            PIPE_HIP(hipMalloc((void **)&d_steer_[i], steer_bytes()));
+        PIPE_HIP(hipMalloc((void **)&d_hist_, (size_t)S_ * M_ * H_ * sizeof(float)));
+        PIPE_HIP(hipMalloc((void **)&d_tail_[0], (size_t)So_ * H_ * sizeof(float)));
+        PIPE_HIP(hipMalloc((void **)&d_tail_[1], (size_t)So_ * H_ * sizeof(float)));
         if (Phist_ > 0) PIPE_HIP(hipMalloc((void **)&d_zhist_, zhist_bytes()));
         if (cfg_.algo == BF_GSS) {
             PIPE_HIP(hipMalloc((void **)&d_gssW_, gss_bytes()));
@@ -108,9 +125,9 @@ class BinPipelineImpl : public BinPipeline {
     }
 
     int reset() override {
-        PIPE_HIP(hipMemset(d_hist_, 0, (size_t)S_ * M_ * 512 * sizeof(float)));
-        PIPE_HIP(hipMemset(d_tail_[0], 0, (size_t)So_ * 512 * sizeof(float)));
-        PIPE_HIP(hipMemset(d_tail_[1], 0, (size_t)So_ * 512 * sizeof(float)));
+        PIPE_HIP(hipMemset(d_hist_, 0, (size_t)S_ * M_ * H_ * sizeof(float)));
+        PIPE_HIP(hipMemset(d_tail_[0], 0, (size_t)So_ * H_ * sizeof(float)));
+        PIPE_HIP(hipMemset(d_tail_[1], 0, (size_t)So_ * H_ * sizeof(float)));
         tail_cur_ = 0;
         if (d_zhist_) PIPE_HIP(hipMemset(d_zhist_, 0, zhist_bytes()));  // past_ffts setZero (mvdr.cpp:228-232)
         if (d_mpf_) PIPE_HIP(hipMemset(d_mpf_, 0, mpf_bytes()));          // phasempf.cpp:535-545, current_L=0/first_L
@@ -123,19 +140,23 @@ class BinPipelineImpl : public BinPipeline {
     int upload_steering(const std::vector<SteeringSet> &dirs, hipStream_t stream) override {
         // device layout [dir][col][mic][bin] so that lanes (bins) read consecutive addresses
         const int nc = dirs[0].n_cols, nd = (int)dirs.size();  // nd = look directions (gsc: 1, although D_ = M outputs)
-        std::vector<f64x2> t((size_t)nd * 1024 * M_ * nc);
+        if ((size_t)nd * nc * M_ * N_ * sizeof(f64x2) > steer_bytes()) {
+            err_ = "steering table larger than the device buffer";
+            return BF_EINVAL;
+        }
+        std::vector<f64x2> t((size_t)nd * N_ * M_ * nc);
         for (int d = 0; d < nd; ++d)
             for (int c = 0; c < nc; ++c)
                 for (int m = 0; m < M_; ++m)
-                    for (int j = 0; j < 1024; ++j) {
+                    for (int j = 0; j < N_; ++j) {
                         const cplxd w = dirs[d].at(j, m, c);
-                        t[(((size_t)d * nc + c) * M_ + m) * 1024 + j] = f64x2{w.real(), w.imag()};
+                        t[(((size_t)d * nc + c) * M_ + m) * N_ + j] = f64x2{w.real(), w.imag()};
                     }
         const int nxt = steer_cur_ ^ 1;
         PIPE_HIP(hipMemcpyAsync(d_steer_[nxt], t.data(), t.size() * sizeof(f64x2), hipMemcpyHostToDevice, stream));
         PIPE_HIP(hipStreamSynchronize(stream));  // `t` is pageable and about to go out of scope
         steer_cur_ = nxt;
-        steer_dir_stride_ = (long)nc * M_ * 1024;
+        steer_dir_stride_ = (long)nc * M_ * N_;
         return BF_OK;
     }
 
@@ -164,18 +185,19 @@ class BinPipelineImpl : public BinPipeline {
                 const RunSnapshot &snap);
 
     size_t state_bytes() const override {
-        return (size_t)S_ * M_ * 512 * 4 + (size_t)So_ * 512 * 4 + zhist_bytes() + gss_bytes() + mpf_bytes() + smooth_bytes() +
+        return (size_t)S_ * M_ * H_ * 4 + (size_t)So_ * H_ * 4 + zhist_bytes() + gss_bytes() + mpf_bytes() + smooth_bytes() +
                nlms_bytes();
     }
     int get_state(void *host) override { return copy_state((char *)host, true); }
     int set_state(const void *host) override { return copy_state((char *)host, false); }
 
    private:
-    size_t zhist_bytes() const { return Phist_ ? (size_t)S_ * Phist_ * NP_ * 1024 * sizeof(f64x2) : 0; }
+    size_t steer_bytes() const { return (size_t)D_ * N_ * M_ * kMaxCols * sizeof(f64x2); }
+    size_t zhist_bytes() const { return Phist_ ? (size_t)S_ * Phist_ * NP_ * N_ * sizeof(f64x2) : 0; }
     // recursive per-beam state is sized by OUTPUT streams (input streams x look directions)
-    size_t gss_bytes() const { return cfg_.algo == BF_GSS ? (size_t)So_ * 1024 * kMaxCols * M_ * sizeof(f64x2) : 0; }
+    size_t gss_bytes() const { return cfg_.algo == BF_GSS ? (size_t)So_ * N_ * kMaxCols * M_ * sizeof(f64x2) : 0; }
     size_t mpf_bytes() const {
-        return (cfg_.algo == BF_PHASEMPF || cfg_.algo == BF_MCRA) ? (size_t)So_ * (kMpfVecs * 1024 + 8) * sizeof(double) : 0;
+        return (cfg_.algo == BF_PHASEMPF || cfg_.algo == BF_MCRA) ? (size_t)So_ * (kMpfVecs * N_ + 8) * sizeof(double) : 0;
     }
     size_t smooth_bytes() const { return cfg_.algo == BF_PHASEMPF ? (size_t)So_ * 64 * sizeof(double) : 0; }
     size_t nlms_bytes() const {
@@ -185,7 +207,7 @@ class BinPipelineImpl : public BinPipeline {
     int copy_state(char *p, bool to_host) {
         PIPE_HIP(hipDeviceSynchronize());
         struct Seg { void *d; size_t n; } segs[] = {
-            {d_hist_, (size_t)S_ * M_ * 512 * 4}, {d_tail_[tail_cur_], (size_t)So_ * 512 * 4}, {d_zhist_, zhist_bytes()},
+            {d_hist_, (size_t)S_ * M_ * H_ * 4}, {d_tail_[tail_cur_], (size_t)So_ * H_ * 4}, {d_zhist_, zhist_bytes()},
             {d_gssW_, gss_bytes()}, {d_mpf_, mpf_bytes()}, {d_smooth_, smooth_bytes()}, {d_nlms_, nlms_bytes()}};
         for (auto &s : segs) {
             if (!s.n) continue;
@@ -210,13 +232,15 @@ class BinPipelineImpl : public BinPipeline {
 
     void free_all() {
         void *ptrs[] = {d_tw32_, d_tw_, d_win_, d_freq_, d_steer_[0], d_steer_[1], d_hist_, d_tail_[0], d_tail_[1], d_zhist_,
-                        d_gssW_, d_mpf_, d_smooth_, d_nlms_, d_Z_, d_Yh_, d_yraw_};
+                        d_gssW_, d_mpf_, d_smooth_, d_nlms_, d_Z_, d_Yh_, d_yraw_, d_frames_};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
     }
 
     bf_config cfg_;
     int n_cus_, M_, MF_, NP_, S_, D_, So_, KP1_, Phist_;
+    int H_ = 512, N_ = 1024, NQ_ = 514, YS_ = 516;  // hop, FFT size, problems per frame, row stride of Yh
+    const KernelSet *ks_ = nullptr;                 // launchers compiled for N_
     long steer_dir_stride_ = 0;
     std::vector<double> freqs_;
     f64x2 *d_tw_ = nullptr;
@@ -237,6 +261,7 @@ class BinPipelineImpl : public BinPipeline {
     f64x2 *d_Z_ = nullptr;   size_t Z_cap_ = 0;   // [stream][Phist+F][NP][1024]
     f64x2 *d_Yh_ = nullptr;  size_t Yh_cap_ = 0;  // [stream][F][kYhStride]
     float *d_yraw_ = nullptr; size_t yraw_cap_ = 0;
+    float *d_frames_ = nullptr; size_t frames_cap_ = 0;  // N != 1024: windowed frames between the generic ISTFT and its overlap-add
 };
 
 int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipStream_t stream, int layout,
@@ -247,8 +272,8 @@ int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipS
         RunSnapshot sn = snap;
         for (long t0 = 0; t0 < F; t0 += pipe_tile) {
             const long n = (F - t0 < pipe_tile) ? F - t0 : pipe_tile;
-            const float *xt = x + (layout == BF_PLANAR ? t0 * 512 : t0 * 512 * M_);
-            int rc = run_one(xt, n, y + t0 * 512, spectrum ? spectrum + t0 * 1024 : nullptr, stream, layout, mic_stride, sn);
+            const float *xt = x + (layout == BF_PLANAR ? t0 * H_ : t0 * H_ * M_);
+            int rc = run_one(xt, n, y + t0 * H_, spectrum ? spectrum + t0 * N_ : nullptr, stream, layout, mic_stride, sn);
             if (rc != BF_OK) return rc;
             sn.gss_reset_mask = 0;
         }
@@ -260,17 +285,21 @@ int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipS
 int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, hipStream_t stream, int layout,
                              long mic_stride, const RunSnapshot &snap) {
     const long FT = Phist_ + F;  // frames in the Z workspace per stream
-    int rc = ensure((void **)&d_Z_, &Z_cap_, (size_t)S_ * FT * NP_ * 1024 * sizeof(f64x2));
+    int rc = ensure((void **)&d_Z_, &Z_cap_, (size_t)S_ * FT * NP_ * N_ * sizeof(f64x2));
     if (rc != BF_OK) return rc;
     // phasempf keeps |out_int|^2 (one double per problem) behind the spectrum rows
     rc = ensure((void **)&d_Yh_, &Yh_cap_,
-                (size_t)So_ * F * kYhStride * (sizeof(f64x2) + (cfg_.algo == BF_PHASEMPF ? sizeof(double) : 0)));
+                (size_t)So_ * F * YS_ * (sizeof(f64x2) + (cfg_.algo == BF_PHASEMPF ? sizeof(double) : 0)));
     if (rc != BF_OK) return rc;
     if (cfg_.algo == BF_PHASEMPF || cfg_.algo == BF_GSC) {
-        rc = ensure((void **)&d_yraw_, &yraw_cap_, (size_t)So_ * F * 512 * sizeof(float));
+        rc = ensure((void **)&d_yraw_, &yraw_cap_, (size_t)So_ * F * H_ * sizeof(float));
         if (rc != BF_OK) return rc;
     }
-    const size_t frame_elems = (size_t)NP_ * 1024;
+    if (N_ != 1024) {
+        rc = ensure((void **)&d_frames_, &frames_cap_, (size_t)So_ * F * N_ * sizeof(float));
+        if (rc != BF_OK) return rc;
+    }
+    const size_t frame_elems = (size_t)NP_ * N_;
 
     // covariance history in front of the new frames
     if (Phist_ > 0)
@@ -281,32 +310,32 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     StftArgs sa;
     sa.x = x; sa.hist = d_hist_; sa.Z = d_Z_; sa.tw = d_tw_; sa.win = d_win_;
     sa.n_frames = F; sa.frames_ws = FT; sa.frame_off = Phist_; sa.mic_stride = mic_stride;
-    sa.stream_stride_x = (long)M_ * F * 512; sa.n_streams = S_; sa.n_mics = M_; sa.n_fft_mics = MF_; sa.layout = layout;
-    sa.skip_lo = 1024; sa.skip_hi = 0;  // store everything ...
+    sa.stream_stride_x = (long)M_ * F * H_; sa.n_streams = S_; sa.n_mics = M_; sa.n_fft_mics = MF_; sa.layout = layout;
+    sa.skip_lo = N_; sa.skip_hi = 0;  // store everything ...
     if (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS) {
         // ... except, for the band-limited nodes, the bins between the highest in-band bin k and its mirror N-k
         // (quirk Q1 makes bins 511..513 irregular: only skip when the band ends below them)
         int kmax = 0;
-        for (int k = 0; k <= 513; ++k) {
+        for (int k = 0; k <= N_ / 2 + 1; ++k) {
             const double f = std::fabs(freqs_[k]);
             if (f >= cfg_.freq_min && f <= cfg_.freq_max) kmax = k;
         }
-        if (kmax < 510) { sa.skip_lo = kmax; sa.skip_hi = 1024 - kmax; }
+        if (kmax < N_ / 2 - 2) { sa.skip_lo = kmax; sa.skip_hi = N_ - kmax; }
     }
-    PIPE_HIP(launch_stft(sa, n_cus_, stream));
+    PIPE_HIP(ks_->stft(sa, n_cus_, stream));
 
     // ring-buffer carry (util.h:305-308)
     if (layout == BF_PLANAR) {
-        PIPE_HIP(hipMemcpy2DAsync(d_hist_, 512 * sizeof(float), x + (F - 1) * 512, (size_t)mic_stride * sizeof(float),
-                                  512 * sizeof(float), (size_t)S_ * M_, hipMemcpyDeviceToDevice, stream));
+        PIPE_HIP(hipMemcpy2DAsync(d_hist_, H_ * sizeof(float), x + (F - 1) * H_, (size_t)mic_stride * sizeof(float),
+                                  H_ * sizeof(float), (size_t)S_ * M_, hipMemcpyDeviceToDevice, stream));
     } else {
-        PIPE_HIP(hipMemcpy2DAsync(d_hist_, (size_t)512 * M_ * sizeof(float), x + (F - 1) * 512L * M_,
-                                  (size_t)F * 512 * M_ * sizeof(float), (size_t)512 * M_ * sizeof(float), (size_t)S_,
+        PIPE_HIP(hipMemcpy2DAsync(d_hist_, (size_t)H_ * M_ * sizeof(float), x + (F - 1) * (long)H_ * M_,
+                                  (size_t)F * H_ * M_ * sizeof(float), (size_t)H_ * M_ * sizeof(float), (size_t)S_,
                                   hipMemcpyDeviceToDevice, stream));
     }
 
     if (cfg_.algo == BF_GSC && spectrum) {  // time-domain node: there is no single y_fft; the dump reads as zeros
-        PIPE_HIP(hipMemsetAsync(spectrum, 0, (size_t)S_ * F * 1024 * sizeof(f64x2), stream));
+        PIPE_HIP(hipMemsetAsync(spectrum, 0, (size_t)S_ * F * N_ * sizeof(f64x2), stream));
         spectrum = nullptr;
     }
     BinsArgs ba;
@@ -314,7 +343,7 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     ba.n_frames = F; ba.frames_ws = FT; ba.frame_off = Phist_; ba.n_streams = So_; ba.n_mics = MF_; ba.kp1 = snap.kp1;
     ba.n_dirs = D_; ba.steer_dir_stride = snap.steer_dir_stride;
     ba.cfg = cfg_; ba.gssW = d_gssW_; ba.mpf = d_mpf_; ba.gss_reset_mask = snap.gss_reset_mask;
-    PIPE_HIP(launch_bins(ba, n_cus_, stream));
+    PIPE_HIP(ks_->bins(ba, n_cus_, stream));
 
     if (Phist_ > 0)  // keep the last Phist frames' spectra for the next call
         PIPE_HIP(hipMemcpy2DAsync(d_zhist_, (size_t)Phist_ * frame_elems * sizeof(f64x2), d_Z_ + (size_t)F * frame_elems,
@@ -327,16 +356,17 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     // backward transform in fp32 (no error amplification behind the per-bin stage; output is float32), except for gsc, whose
     // sample-serial NLMS branches on the aligned signals
     static const bool istft_f64 = getenv("BF_ISTFT_F64") && atoi(getenv("BF_ISTFT_F64")) != 0;
-    ia.tw32 = (cfg_.algo == BF_GSC || istft_f64) ? nullptr : d_tw32_;
+    ia.tw32 = (cfg_.algo == BF_GSC || istft_f64 || N_ != 1024) ? nullptr : d_tw32_;
+    ia.frames = d_frames_;
     ia.post_amp = (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS) ? cfg_.out_amp : 1.0;
     ia.use_post_amp = (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS) ? 1 : 0;
-    PIPE_HIP(launch_istft(ia, n_cus_, stream));
+    PIPE_HIP(ks_->istft(ia, n_cus_, stream));
     tail_cur_ ^= 1;
 
     if (cfg_.algo == BF_PHASEMPF)
-        PIPE_HIP(launch_smooth(d_yraw_, y, d_smooth_, F, So_, cfg_.smooth_size, stream));
+        PIPE_HIP(ks_->smooth(d_yraw_, y, d_smooth_, F, So_, cfg_.smooth_size, stream));
     if (cfg_.algo == BF_GSC)
-        PIPE_HIP(launch_gsc_nlms(d_yraw_, y, d_nlms_, F * 512, S_, M_, cfg_, stream));
+        PIPE_HIP(ks_->gsc_nlms(d_yraw_, y, d_nlms_, F * H_, S_, M_, cfg_, stream));
     return BF_OK;
 }
 

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 namespace bf {
+namespace BF_NTAG {
 
 hipError_t launch_bins(const BinsArgs &a, int n_cus, hipStream_t s) {
     hipError_t e = hipSuccess;
@@ -25,4 +26,16 @@ hipError_t launch_bins(const BinsArgs &a, int n_cus, hipStream_t s) {
     return e;
 }
 
+}  // namespace BF_NTAG
+
+// the launchers of this FFT size, as the host pipeline sees them
+const KernelSet *BF_CAT2(kernel_set_n, BF_NFFT)() {
+    static const KernelSet ks = {BF_NFFT, &BF_NTAG::launch_stft, &BF_NTAG::launch_bins, &BF_NTAG::launch_istft,
+                                 &BF_NTAG::launch_smooth, &BF_NTAG::launch_gsc_nlms};
+    return &ks;
+}
+
+namespace BF_NTAG {
+
+}  // namespace BF_NTAG
 }  // namespace bf

@@ -3,9 +3,11 @@
 #include "bins_common.hpp"
 
 namespace bf {
+namespace BF_NTAG {
 
 namespace {
 
+#if BF_NFFT == 1024
 // ======================================================================================
 //                                        STFT
 // ======================================================================================
@@ -359,7 +361,128 @@ __global__ __launch_bounds__(kI32Block) void istft32_kernel(IstftArgs a, int fra
     }
 }
 
-// full 1024-bin y_fft dump from the per-problem rows
+#else
+
+// ======================================================================================
+//          generic sizes (N = 512, 2048): LDS-staged radix-2 Stockham transforms
+// ======================================================================================
+// JACK periods other than 512 frames (rosjack.cpp:131; fft_win = 2 * period, util.h:261).  One 256-thread block per
+// transform, the whole signal in LDS (two N-point complex double buffers), log2(N) autosort passes with a barrier each,
+// twiddles exp(-2 pi i m / N) from a double-precision table built on the host.  Correctness first: these sizes are not the
+// benchmark shape; the 1024-point path keeps its in-register 32 x 32 kernels.
+constexpr int kGenBlock = 256;
+
+// in-place-looking wrapper: data starts in buf0, result ends in the returned buffer.  DIR = -1 forward, +1 backward.
+template <int DIR>
+__device__ __forceinline__ cd *stockham(cd *buf0, cd *buf1, const f64x2 *tw, int tid) {
+    cd *in = buf0, *out = buf1;
+    for (int ns = 1; ns < kN; ns <<= 1) {
+        for (int j = tid; j < kN / 2; j += kGenBlock) {
+            const int k = j & (ns - 1);
+            const f64x2 w0 = tw[k * (kN / (2 * ns))];          // exp(-2 pi i k / (2 ns))
+            const cd w{w0.x, DIR < 0 ? w0.y : -w0.y};
+            const cd a = in[j], b = in[j + kN / 2] * w;
+            const int j0 = ((j - k) << 1) + k;
+            out[j0] = a + b;
+            out[j0 + ns] = a - b;
+        }
+        __syncthreads();
+        cd *t = in; in = out; out = t;
+    }
+    return in;
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(kGenBlock) void stft_generic_kernel(StftArgs a) {
+    __shared__ cd s_a[kN], s_b[kN];
+    const int tid = threadIdx.x;
+    const int M = a.n_mics, MF = a.n_fft_mics, NP = (MF + 1) >> 1;
+    const long total = (long)a.n_streams * a.n_frames * NP;
+    for (long item = blockIdx.x; item < total; item += gridDim.x) {
+        const int p = (int)(item % NP);
+        const long st = item / NP;
+        const long t = st % a.n_frames;
+        const int s = (int)(st / a.n_frames);
+        const float *xs = a.x + (long)s * a.stream_stride_x;
+        const float *hs = a.hist + (long)s * M * kHop;
+        const int ma = 2 * p;
+        const bool b_ok = 2 * p + 1 < MF;
+        const int mb = b_ok ? 2 * p + 1 : ma;
+        for (int n = tid; n < kN; n += kGenBlock) {
+            const bool first = n < kHop;          // first half of the frame = the hop before hop t
+            const int i = first ? n : n - kHop;
+            float va, vb;
+            if (LAYOUT == 0) {
+                const float *ba = first ? (t >= 1 ? xs + (long)ma * a.mic_stride + (t - 1) * kHop : hs + ma * kHop)
+                                        : xs + (long)ma * a.mic_stride + t * kHop;
+                const float *bb = first ? (t >= 1 ? xs + (long)mb * a.mic_stride + (t - 1) * kHop : hs + mb * kHop)
+                                        : xs + (long)mb * a.mic_stride + t * kHop;
+                va = ba[i];
+                vb = bb[i];
+            } else {
+                const float *bs = first ? (t >= 1 ? xs + (t - 1) * (long)kHop * M : hs) : xs + t * (long)kHop * M;
+                va = bs[(long)i * M + ma];
+                vb = bs[(long)i * M + mb];
+            }
+            const double h = a.win[n];
+            s_a[n] = cd{(double)va * h, b_ok ? (double)vb * h : 0.0};   // buf[j]*hann_win[i]  (util.h:235)
+        }
+        __syncthreads();
+        const cd *res = stockham<-1>(s_a, s_b, a.tw, tid);
+        f64x2 *zo = a.Z + (((long)s * a.frames_ws + a.frame_off + t) * NP + p) * kN;
+        for (int k = tid; k < kN; k += kGenBlock) zo[k] = f64x2{res[k].x, res[k].y};
+        __syncthreads();
+    }
+}
+
+// Hermitian part of y_fft at bin k (0..N-1) from the per-bin kernels' output row.
+__device__ __forceinline__ cd herm_gen(const f64x2 *row, int k) {
+    if (k == 0 || k == kN / 2) return cd{row[k].x, 0.0};
+    if (k == kN / 2 - 1) return (ld(row + k) + conj(ld(row + kQX))) * 0.5;
+    if (k == kQX) return (ld(row + kQX) + conj(ld(row + kN / 2 - 1))) * 0.5;
+    if (k < kN / 2) return ld(row + k);
+    return conj(ld(row + (kN - k)));
+}
+
+// one frame per block: backward transform + synthesis window, windowed frame to a.frames (float, reference rounding)
+__global__ __launch_bounds__(kGenBlock) void istft_generic_kernel(IstftArgs a) {
+    __shared__ cd s_a[kN], s_b[kN];
+    const int tid = threadIdx.x;
+    const long total = (long)a.n_streams * a.n_frames;
+    for (long f = blockIdx.x; f < total; f += gridDim.x) {
+        const f64x2 *row = a.Yh + f * kYhStride;
+        for (int k = tid; k < kN; k += kGenBlock) s_a[k] = herm_gen(row, k);
+        __syncthreads();
+        const cd *res = stockham<+1>(s_a, s_b, a.tw, tid);
+        float *fo = a.frames + f * kN;
+        for (int n = tid; n < kN; n += kGenBlock) {
+            float v = (float)(res[n].x / (double)kN);            // util.h:249
+            v = (float)((double)v * a.win[n]);                    // util.h:250
+            if (a.use_post_amp) v = (float)((double)v * a.post_amp);  // mvdr.cpp:112-114
+            fo[n] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// do_overlap's overlap-add (util.h:301-302): out hop t = second half of frame t-1 + first half of frame t
+__global__ void ola_generic_kernel(IstftArgs a) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = a.n_frames * kHop;
+    if (idx >= per * a.n_streams) return;
+    const int s = (int)(idx / per);
+    const long r = idx - (long)s * per;
+    const long t = r / kHop;
+    const int n = (int)(r - t * kHop);
+    const float *fr = a.frames + ((long)s * a.n_frames) * kN;
+    const float prev = t >= 1 ? fr[(t - 1) * kN + kHop + n] : a.tail_in[(long)s * kHop + n];
+    a.y[idx] = prev + fr[t * kN + n];
+    if (t == a.n_frames - 1) a.tail_out[(long)s * kHop + n] = fr[t * kN + kHop + n];
+}
+
+#endif  // BF_NFFT == 1024
+
+// full N-bin y_fft dump from the per-problem rows
 __global__ void expand_spectrum_kernel(const f64x2 *Yh, f64x2 *out, long frames_total) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= frames_total * kN) return;
@@ -367,7 +490,7 @@ __global__ void expand_spectrum_kernel(const f64x2 *Yh, f64x2 *out, long frames_
     const int j = (int)(idx - f * kN);
     const f64x2 *row = Yh + f * kYhStride;
     f64x2 v;
-    if (j <= 513) {
+    if (j <= kQX) {
         v = row[j];
     } else {
         v = row[kN - j];
@@ -402,6 +525,7 @@ __global__ void smooth_state_kernel(const float *yraw, double *state, long n, in
 
 }  // namespace
 
+#if BF_NFFT == 1024
 hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
     static const int variant = getenv("BF_STFT_VARIANT") ? atoi(getenv("BF_STFT_VARIANT")) : 0;
     const int nb = variant == 1 ? 512 : 256, halves = nb / 32;
@@ -444,6 +568,31 @@ hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s) {
     return hipGetLastError();
 }
 
+#else
+hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
+    const long total = (long)a.n_streams * a.n_frames * ((a.n_fft_mics + 1) / 2);
+    long blocks = total < (long)n_cus * 8 ? total : (long)n_cus * 8;
+    if (blocks < 1) blocks = 1;
+    if (a.layout == 0)
+        hipLaunchKernelGGL(stft_generic_kernel<0>, dim3((unsigned)blocks), dim3(kGenBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL(stft_generic_kernel<1>, dim3((unsigned)blocks), dim3(kGenBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s) {
+    if (a.frames == nullptr) return hipErrorInvalidValue;
+    const long total = (long)a.n_streams * a.n_frames;
+    long blocks = total < (long)n_cus * 8 ? total : (long)n_cus * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(istft_generic_kernel, dim3((unsigned)blocks), dim3(kGenBlock), 0, s, a);
+    const long samples = total * kHop;
+    hipLaunchKernelGGL(ola_generic_kernel, dim3((unsigned)((samples + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+#endif
+
 hipError_t launch_smooth(const float *yraw, float *y, double *state, long n_frames, int n_streams, int smooth_size,
                          hipStream_t s) {
     const long n = n_frames * kHop;
@@ -460,4 +609,5 @@ hipError_t launch_expand_spectrum(const f64x2 *Yh, f64x2 *spectrum, long frames,
     return hipGetLastError();
 }
 
+}  // namespace BF_NTAG
 }  // namespace bf

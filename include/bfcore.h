@@ -72,7 +72,10 @@ enum bf_das_impl {
 typedef struct bf_config {
     int algo;                      /* enum bf_algo */
     int n_mics;                    /* number_of_microphones (util.h:122) */
-    int hop;                       /* rosjack_window_size; fft_win = 2*hop (util.h:261). 512 only in this build */
+    int hop;                       /* rosjack_window_size = the JACK period (rosjack.cpp:131); fft_win = 2*hop (util.h:261).
+                                      256, 512 or 1024.  512 is the tuned shape (in-register 32 x 32 FFT-1024, fused fp32 das);
+                                      256 / 1024 run every node, das included, through the fp64 bin pipeline with LDS-staged
+                                      radix-2 transforms */
     double sample_rate;            /* rosjack_sample_rate */
     double mic_x[BF_MAX_MICS];     /* RAW mic<i>.x / .y from beamform_config.yaml (util.h:82-92) */
     double mic_y[BF_MAX_MICS];
@@ -157,7 +160,9 @@ int bf_stream_rms(bf_handle *h, const float *y_dev, size_t n_frames, double *rms
  * interferer (and removes it when it lands within interf_angle_threshold of another one); id > count appends a
  * new interferer unless it is that close to an existing one.  As in the reference, a structural change rebuilds
  * the weight matrices zeroed and re-runs update_weights() without ini, so the reference-mic row is 0 afterwards
- * (quirk Q3).  Up to 3 interferers in this build (BF_ENOSYS beyond).  Takes effect at the next hop/batch. */
+ * (quirk Q3).  Up to BF_MAX_INTERF interferers.  With more constraints than microphones (K + 1 > n_mics) the constraint
+ * Gram matrix is singular and the reference's inverse() returns rounding noise: no parity is claimed there.
+ * Takes effect at the next hop/batch. */
 int bf_set_interference(bf_handle *h, unsigned id, double degrees);
 /* Current number of interferers (interference_angles.size()). */
 int bf_n_interferers(bf_handle *h);

@@ -13,16 +13,15 @@ std::atomic<long> g_launches{0};
 
 namespace bf {
 
-hipError_t launch_stft(const StftArgs &, int, hipStream_t) { return hipSuccess; }
-hipError_t launch_istft(const IstftArgs &, int, hipStream_t) { return hipSuccess; }
-hipError_t launch_smooth(const float *, float *, double *, long, int, int, hipStream_t) { return hipSuccess; }
-hipError_t launch_gsc_nlms(const float *, float *, float *, long, int, int, const bf_config &, hipStream_t) { return hipSuccess; }
-hipError_t launch_expand_spectrum(const f64x2 *, f64x2 *, long, hipStream_t) { return hipSuccess; }
+static hipError_t launch_stft(const StftArgs &, int, hipStream_t) { return hipSuccess; }
+static hipError_t launch_istft(const IstftArgs &, int, hipStream_t) { return hipSuccess; }
+static hipError_t launch_smooth(const float *, float *, double *, long, int, int, hipStream_t) { return hipSuccess; }
+static hipError_t launch_gsc_nlms(const float *, float *, float *, long, int, int, const bf_config &, hipStream_t) { return hipSuccess; }
 
 // The per-bin stage: the batch must see ONE consistent {column count, steering table}.  The table is laid out
 // [dir][col][mic][bin] with kp1 columns; every uploaded steering entry of mic >= 1 has modulus 1, memory that was never
 // uploaded reads 0 (the stub's hipMalloc zero-fills).
-hipError_t launch_bins(const BinsArgs &a, int, hipStream_t) {
+static hipError_t launch_bins(const BinsArgs &a, int, hipStream_t) {
     g_launches++;
     const int M = a.n_mics, kp1 = a.kp1;
     if (a.steer_dir_stride != (long)kp1 * M * 1024) g_inconsistent++;
@@ -35,6 +34,12 @@ hipError_t launch_bins(const BinsArgs &a, int, hipStream_t) {
                 }
     return hipSuccess;
 }
+
+// the harness runs at hop 512; the other sizes share the same host code
+static const KernelSet g_stub_set = {1024, &launch_stft, &launch_bins, &launch_istft, &launch_smooth, &launch_gsc_nlms};
+const KernelSet *kernel_set_n512() { return &g_stub_set; }
+const KernelSet *kernel_set_n1024() { return &g_stub_set; }
+const KernelSet *kernel_set_n2048() { return &g_stub_set; }
 
 hipError_t prepare_das_fused(const DasFusedArgs &, hipStream_t) { return hipSuccess; }
 hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t) {

@@ -1,0 +1,149 @@
+"""Boundary generality on the GPU: JACK periods of 256 and 1024 frames (rosjack.cpp:131; fft_win = 2 * period, util.h:261),
+more than three interferers (lcmv.cpp:258-309 appends without a cap; beamform_config.yaml:43-57 lists 15) and more than
+16 microphones -- every case against the oracle through the C ABI."""
+import numpy as np
+import pytest
+
+from beamform_amd.params import make_params
+from beamform_amd.synth import make_scene
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # north_star tolerance: relative L2, per frame on the complex spectrum and on the time signal
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def run(p, x, n_streams=1):
+    torch = _torch()
+    from beamform_amd.capi import Beamformer
+    H = p["hop"]
+    F = x.shape[-1] // H
+    bf = Beamformer(p, n_streams=n_streams)
+    xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    yd = torch.empty((n_streams, F * H), dtype=torch.float32, device="cuda")
+    Yd = torch.empty((n_streams, F, 2 * H, 2), dtype=torch.float64, device="cuda")
+    bf.process_device(xd.data_ptr(), F, yd.data_ptr(), Yd.data_ptr())
+    torch.cuda.synchronize()
+    return bf, yd.cpu().numpy(), Yd.cpu().numpy().view(np.complex128)[..., 0]
+
+
+def check(y, Y, y_ref, Y_ref):
+    fin = np.isfinite(Y_ref).all(axis=1)
+    assert (np.isfinite(Y).all(axis=1) == fin).all()
+    worst = max(rel_l2(Y[t], Y_ref[t]) for t in range(len(fin)) if fin[t] and np.abs(Y_ref[t]).max() > 0)
+    assert worst < TOL, worst
+    ok = np.isfinite(y_ref)
+    assert (np.isfinite(y) == ok).all()
+    assert rel_l2(y[ok], y_ref[ok]) < TOL
+
+
+@pytest.mark.parametrize("hop", [256, 1024])
+@pytest.mark.parametrize("algo,M,interf", [("das", 8, ()), ("das", 3, ()), ("mvdr", 8, ()), ("mvdr", 4, ()), ("lcmv", 8, (-60.0, 90.0)),
+                                           ("lcmv", 16, (-60.0, 90.0, 150.0)), ("gss", 8, (-60.0,)), ("phase", 8, ()),
+                                           ("phasempf", 8, ()), ("mcra", 2, ())])
+def test_nodes_at_other_jack_periods(hop, algo, M, interf):
+    import oracle
+    p = make_params(algo, n_mics=M, interf=interf, theta=20.0, hop=hop)
+    F = 48 if hop == 256 else 30
+    x = make_scene(M, F, hop=hop, seed=300 + M + hop // 256)
+    y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
+    _, y, Y = run(p, x)
+    check(y[0], Y[0], y_ref, Y_ref)
+
+
+@pytest.mark.parametrize("hop", [256, 1024])
+@pytest.mark.parametrize("algo", ["das", "mvdr", "phasempf"])
+def test_streaming_callbacks_at_other_jack_periods(hop, algo):
+    """bf_process_hop with nframes = the configured period, one callback at a time == batch == oracle; theta in between."""
+    import oracle
+    from beamform_amd.capi import Beamformer
+    _torch()
+    M, F = 4, 14
+    p = make_params(algo, n_mics=M, theta=10.0, hop=hop)
+    x = make_scene(M, F, hop=hop, seed=9)
+    node = oracle.OracleNode(p)
+    bf = Beamformer(p)
+    ys, refs = [], []
+    for t in range(F):
+        if t == 6:
+            node.set_theta(-50.0)
+            bf.set_theta(-50.0)
+        seg = np.ascontiguousarray(x[:, t * hop:(t + 1) * hop])
+        refs.append(node.process(seg)[0])
+        ys.append(bf.process_hop(seg))
+    y, y_ref = np.concatenate(ys), np.concatenate(refs)
+    ok = np.isfinite(y_ref)
+    assert (np.isfinite(y) == ok).all() and rel_l2(y[ok], y_ref[ok]) < TOL
+    with pytest.raises(Exception):
+        bf.process_hop(np.zeros((M, 512), np.float32)) if hop != 512 else None
+
+
+def test_unsupported_period_is_refused():
+    from beamform_amd.capi import Beamformer, BfError
+    _torch()
+    with pytest.raises(BfError):
+        Beamformer(make_params("das", n_mics=4, hop=384))
+
+
+@pytest.mark.parametrize("algo,M,interf", [
+    ("lcmv", 8, (-60.0, 90.0, 150.0, -120.0, 45.0)),                               # K = 5 at M = 8
+    ("lcmv", 8, (-60.0, 90.0, 150.0, -120.0, 45.0, -20.0, 120.0)),                 # K = 7: K + 1 = M
+    ("lcmv", 16, (-60.0, 90.0, 150.0, -120.0, 45.0, -20.0, 120.0, 70.0, -90.0)),   # K = 9 at M = 16
+    ("gss", 8, (-60.0, 90.0, 150.0, -120.0, 45.0)),
+    ("gss", 16, tuple(-170.0 + 22.0 * k for k in range(15))),                      # K = 15, the yaml's angle_interf1..15
+])
+def test_more_than_three_interferers(algo, M, interf):
+    import oracle
+    p = make_params(algo, n_mics=M, interf=interf, theta=20.0)
+    F = 40
+    x = make_scene(M, F, seed=500 + len(interf))
+    y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
+    bf, y, Y = run(p, x)
+    assert bf.weights().shape == (1024, M, len(interf) + 1)
+    check(y[0], Y[0], y_ref, Y_ref)
+
+
+def test_interferers_appended_at_run_time_beyond_three():
+    """/theta_interference keeps appending (lcmv.cpp:282-305): 2 -> 6 interferers one callback apart, then one removed."""
+    import oracle
+    from beamform_amd.capi import Beamformer
+    _torch()
+    M, F = 8, 36
+    p = make_params("lcmv", n_mics=M, interf=(-60.0, 90.0), theta=20.0)
+    x = make_scene(M, F, seed=77)
+    node, bf = oracle.OracleNode(p), Beamformer(p)
+    script = {6: (9, 150.0), 10: (9, -120.0), 14: (9, 45.0), 18: (9, -20.0), 24: (3, 89.7)}
+    ys, refs = [], []
+    for t in range(F):
+        if t in script:
+            assert bf.set_interference(*script[t]) == node.set_interference(*script[t])
+            assert np.abs(bf.weights() - node.weights()).max() < 1e-14
+        seg = np.ascontiguousarray(x[:, t * 512:(t + 1) * 512])
+        refs.append(node.process(seg)[0])
+        ys.append(bf.process(seg))
+    assert bf.weights().shape[2] == 6
+    y, y_ref = np.concatenate(ys), np.concatenate(refs)
+    ok = np.isfinite(y_ref)
+    assert (np.isfinite(y) == ok).all() and rel_l2(y[ok], y_ref[ok]) < TOL
+
+
+@pytest.mark.parametrize("algo,M,interf", [("mvdr", 24, ()), ("lcmv", 20, (-60.0, 90.0)), ("gss", 32, (-60.0,))])
+def test_more_than_sixteen_microphones(algo, M, interf):
+    import oracle
+    rng = np.random.default_rng(4)
+    ang = np.sort(rng.uniform(-np.pi, np.pi, M))
+    mics = [(float(0.2 * np.cos(a) * (0.6 + 0.4 * rng.random())), float(0.2 * np.sin(a) * (0.6 + 0.4 * rng.random()))) for a in ang]
+    # P = 10 frames give a rank-10 covariance: with M > 10 only the 1.001 diagonal loading keeps R invertible (cond ~ 1e3 * M),
+    # exactly as in the reference; a longer window keeps the comparison meaningful
+    p = make_params(algo, n_mics=M, interf=interf, theta=20.0, mics=mics, past_windows=40)
+    F = 70
+    x = make_scene(M, F, seed=600 + M, mics=mics)
+    y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
+    _, y, Y = run(p, x)
+    check(y[0], Y[0], y_ref, Y_ref)

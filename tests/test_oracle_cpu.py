@@ -198,3 +198,28 @@ def test_streaming_hop_by_hop_equals_batch():
     node = oracle.OracleNode(p)
     y2 = np.concatenate([node.process_hop(x[:, t * 512:(t + 1) * 512])[0] for t in range(F)])
     assert np.array_equal(y, y2)
+
+
+@pytest.mark.parametrize("hop", [256, 1024])
+@pytest.mark.parametrize("algo,M,interf", [("das", 4, ()), ("mvdr", 4, ()), ("lcmv", 8, (-60.0, 90.0, 150.0, -120.0, 45.0)),
+                                           ("phasempf", 3, ())])
+def test_other_jack_periods_and_more_interferers_agree_with_numpy_restatement(hop, algo, M, interf):
+    """rosjack.cpp:131 takes whatever period the JACK server runs (fft_win = 2 * period, util.h:261); lcmv.cpp:258-309 appends
+    interferers without a cap.  The two restatements must agree there too."""
+    p = make_params(algo, n_mics=M, interf=interf, theta=25.0, hop=hop)
+    F = 16 if hop == 256 else 14
+    x = make_scene(M, F, hop=hop, seed=31)
+    y, Y = oracle.OracleNode(p).process(x, want_spectrum=True)
+    assert Y.shape == (F, 2 * hop)
+    y2, Y2 = np_oracle.process(p, x)
+    fin = np.isfinite(Y).all(axis=1)
+    assert (np.isfinite(Y2).all(axis=1) == fin).all()
+    # six constraints on eight microphones: C^H R^-1 C is far worse conditioned than the launch-file shapes, and the two
+    # restatements invert it differently (own LU vs LAPACK): agreement to 1e-7 instead of 1e-12, float output to the last bits
+    loose = len(interf) > 3
+    assert max(rel_l2(Y[t], Y2[t]) for t in range(F) if fin[t]) < (1e-6 if loose else 1e-9)
+    ok = np.isfinite(y)
+    if loose:
+        assert rel_l2(y[ok], y2[ok]) < 1e-6
+    else:
+        assert np.array_equal(y[ok], y2[ok])
