@@ -6,11 +6,11 @@ SRC := beamform_amd/csrc
 OBJ := build/obj
 LIB := beamform_amd/lib/libbfcore.so
 
-HIP_SRCS := $(SRC)/das_fused.hip $(SRC)/das_fused_w64.hip $(SRC)/pipeline.hip
+HIP_SRCS := $(SRC)/das_fused.hip $(SRC)/das_fused_w64.hip $(SRC)/pipeline.hip $(SRC)/convert.hip
 # bin-pipeline kernels: one object per supported FFT size (hop 256 / 512 / 1024 -> -DBF_NFFT=512 / 1024 / 2048)
 BIN_SRCS := pipeline_kernels stft_istft mask_kernels cov_kernels gsc_gss_kernels
 NFFTS := 512 1024 2048
-CPP_SRCS := $(SRC)/capi.cpp $(SRC)/config.cpp
+CPP_SRCS := $(SRC)/capi.cpp $(SRC)/config.cpp $(SRC)/wavio.cpp
 OBJS := $(patsubst $(SRC)/%.hip,$(OBJ)/%.o,$(HIP_SRCS)) $(patsubst $(SRC)/%.cpp,$(OBJ)/%.o,$(CPP_SRCS)) \
         $(foreach n,$(NFFTS),$(foreach b,$(BIN_SRCS),$(OBJ)/$(b)_n$(n).o))
 HDRS := $(wildcard $(SRC)/*.hpp) include/bfcore.h

@@ -27,6 +27,8 @@ EXPORTS = (
     "bf_config_parse_yaml", "bf_create", "bf_destroy", "bf_set_theta", "bf_set_interference", "bf_process_hop",
     "bf_process_batch", "bf_process_batch_device", "bf_get_weights", "bf_state_size", "bf_get_state", "bf_set_state",
     "bf_reset", "bf_time_batch_device", "bf_n_interferers", "bf_set_theta_dir", "bf_set_thetas", "bf_stream_rms", "bf_host_alloc", "bf_host_free",
+    "bf_wav_writer_open", "bf_wav_writer_write", "bf_wav_writer_write_pcm16", "bf_wav_writer_close", "bf_float_to_pcm16",
+    "bf_float_to_pcm16_device", "bf_wav_read", "bf_planar_f32_read", "bf_wav_free",
 )
 
 
@@ -105,8 +107,96 @@ def load():
     L.bf_reset.argtypes = [C.c_void_p]
     L.bf_time_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int,
                                        C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.bf_wav_writer_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.bf_wav_writer_write.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.bf_wav_writer_write_pcm16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.bf_wav_writer_close.argtypes = [C.c_void_p]
+    L.bf_float_to_pcm16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.bf_float_to_pcm16.restype = None
+    L.bf_float_to_pcm16_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.bf_wav_read.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int), C.POINTER(C.c_size_t),
+                              C.POINTER(C.c_int)]
+    L.bf_planar_f32_read.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t)]
+    L.bf_wav_free.argtypes = [C.POINTER(C.c_float)]
+    L.bf_wav_free.restype = None
     _lib = L
     return L
+
+
+# ---- rosjack output stage, file half (rosjack.cpp:189-210, 404-409) and the batch front-end ---------------------------------
+class WavWriter:
+    """sf_open(..., SFM_WRITE, WAV | PCM_16, mono) / sf_write_float per callback / sf_close."""
+
+    def __init__(self, path: str, sample_rate: int = 48000):
+        self._L = load()
+        self._w = C.c_void_p()
+        rc = self._L.bf_wav_writer_open(os.fsencode(path), int(sample_rate), C.byref(self._w))
+        if rc:
+            raise BfError(rc, "bf_wav_writer_open", self._L.bf_strerror(rc).decode())
+
+    def write(self, samples: np.ndarray):
+        a = np.ascontiguousarray(samples, np.float32)
+        rc = self._L.bf_wav_writer_write(self._w, a.ctypes.data, a.size)
+        if rc:
+            raise BfError(rc, "bf_wav_writer_write", self._L.bf_strerror(rc).decode())
+
+    def write_pcm16(self, pcm: np.ndarray):
+        a = np.ascontiguousarray(pcm, np.int16)
+        rc = self._L.bf_wav_writer_write_pcm16(self._w, a.ctypes.data, a.size)
+        if rc:
+            raise BfError(rc, "bf_wav_writer_write_pcm16", self._L.bf_strerror(rc).decode())
+
+    def close(self):
+        if self._w:
+            rc = self._L.bf_wav_writer_close(self._w)
+            self._w = None
+            if rc:
+                raise BfError(rc, "bf_wav_writer_close", self._L.bf_strerror(rc).decode())
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def float_to_pcm16(x: np.ndarray) -> np.ndarray:
+    """The sample rule of sf_write_float on a PCM_16 file (host)."""
+    a = np.ascontiguousarray(x, np.float32)
+    out = np.empty(a.shape, np.int16)
+    load().bf_float_to_pcm16(a.ctypes.data, out.ctypes.data, a.size)
+    return out
+
+
+def float_to_pcm16_device(src_ptr: int, dst_ptr: int, n: int, stream: int = 0):
+    rc = load().bf_float_to_pcm16_device(src_ptr, dst_ptr, n, stream or None)
+    if rc:
+        raise BfError(rc, "bf_float_to_pcm16_device", load().bf_strerror(rc).decode())
+
+
+def _take_planar(L, p, ch, n):
+    arr = np.ctypeslib.as_array(p, shape=(ch * n,)).reshape(ch, n).copy() if ch * n else np.zeros((ch, 0), np.float32)
+    L.bf_wav_free(p)
+    return arr
+
+
+def read_wav(path: str):
+    """WAV file -> (planar float32 [channels, samples], sample_rate)."""
+    L = load()
+    p, ch, n, sr = C.POINTER(C.c_float)(), C.c_int(), C.c_size_t(), C.c_int()
+    rc = L.bf_wav_read(os.fsencode(path), C.byref(p), C.byref(ch), C.byref(n), C.byref(sr))
+    if rc:
+        raise BfError(rc, "bf_wav_read", L.bf_strerror(rc).decode())
+    return _take_planar(L, p, ch.value, n.value), sr.value
+
+
+def read_planar_f32(path: str, n_channels: int) -> np.ndarray:
+    L = load()
+    p, n = C.POINTER(C.c_float)(), C.c_size_t()
+    rc = L.bf_planar_f32_read(os.fsencode(path), n_channels, C.byref(p), C.byref(n))
+    if rc:
+        raise BfError(rc, "bf_planar_f32_read", L.bf_strerror(rc).decode())
+    return _take_planar(L, p, n_channels, n.value)
 
 
 def config_from_params(p: dict, device: int = 0, n_streams: int = 1, layout: int = BF_PLANAR,

@@ -1,9 +1,11 @@
 // file_node.cpp -- a beamformer "node" with files in place of JACK/ROS.
 //
-//   file_node <das|mvdr|lcmv|gss|phase|phasempf|mcra|gsc> <beamform_config.yaml> <in.f32> <out.f32> [theta_script]
+//   file_node <das|mvdr|lcmv|gss|phase|phasempf|mcra|gsc> <beamform_config.yaml> <in.f32|in.wav> <out.f32|out.wav> [theta_script]
 //
-// in.f32: planar float32 [n_mics][n_samples]; the node is driven exactly as JACK drives the
-// reference: one jack_callback(512, 0) per period, planar per-mic pointers in, 512 samples out.
+// in.f32: planar float32 [n_mics][n_samples]; in.wav: a multichannel WAV file (bf_wav_read: PCM 16/24/32 or float32).
+// The node is driven exactly as JACK drives the reference: one jack_callback(period, 0) per period, planar per-mic
+// pointers in, one period of samples out.  out.wav is what rosjack's write_file option produces (rosjack.cpp:189-210,
+// 404-409: mono PCM16, one sf_write_float per callback); out.f32 keeps the raw float32 samples.
 // theta_script (optional): lines "<callback_index> <degrees>" = /theta messages.
 #include <cstdio>
 #include <cstdlib>
@@ -19,13 +21,23 @@ static std::vector<float *> g_ptrs;
 static size_t g_samples_per_mic = 0, g_pos = 0;
 static int g_mics = 0;
 static FILE *g_out = nullptr;
+static bf_wav_writer *g_wav = nullptr;
 
 static float **input_from_files(int n) {            // stands in for rosjack.cpp:538-547
     for (int m = 0; m < g_mics; ++m) g_ptrs[m] = g_in.data() + (size_t)m * g_samples_per_mic + g_pos;
     g_pos += n;
     return g_ptrs.data();
 }
-static void output_to_file(float *data, int n, int) { fwrite(data, sizeof(float), n, g_out); }  // rosjack.cpp:356
+static void output_to_file(float *data, int n, int) {  // rosjack.cpp:356 output_to_rosjack, write_file branch :404-409
+    if (g_wav)
+        bf_wav_writer_write(g_wav, data, (size_t)n);
+    else
+        fwrite(data, sizeof(float), n, g_out);
+}
+static bool ends_with(const char *s, const char *suf) {
+    const size_t a = strlen(s), b = strlen(suf);
+    return a >= b && !strcmp(s + a - b, suf);
+}
 
 int main(int argc, char **argv) {
     if (argc < 5) {
@@ -41,17 +53,24 @@ int main(int argc, char **argv) {
         fprintf(stderr, "bad algo or config\n");
         return 2;
     }
-    FILE *fi = fopen(argv[3], "rb");
-    g_out = fopen(argv[4], "wb");
-    if (!fi || !g_out) return 2;
-    fseek(fi, 0, SEEK_END);
-    const size_t bytes = ftell(fi);
-    fseek(fi, 0, SEEK_SET);
     g_mics = cfg.n_mics;
-    g_samples_per_mic = bytes / sizeof(float) / g_mics;
-    g_in.resize((size_t)g_mics * g_samples_per_mic);
-    if (fread(g_in.data(), sizeof(float), g_in.size(), fi) != g_in.size()) return 2;
-    fclose(fi);
+    float *planar = nullptr;
+    int ch = 0, rate = (int)cfg.sample_rate;
+    int rc = ends_with(argv[3], ".wav") ? bf_wav_read(argv[3], &planar, &ch, &g_samples_per_mic, &rate)
+                                        : bf_planar_f32_read(argv[3], g_mics, &planar, &g_samples_per_mic);
+    if (rc != BF_OK || (ends_with(argv[3], ".wav") && ch < g_mics)) {
+        fprintf(stderr, "cannot read %s (%s)\n", argv[3], bf_strerror(rc));
+        return 2;
+    }
+    if (ends_with(argv[3], ".wav")) cfg.sample_rate = rate;  // rosjack_sample_rate = what the "server" runs at
+    g_in.assign(planar, planar + (size_t)g_mics * g_samples_per_mic);  // the first n_mics channels
+    bf_wav_free(planar);
+    if (ends_with(argv[4], ".wav")) {
+        if (bf_wav_writer_open(argv[4], (int)cfg.sample_rate, &g_wav) != BF_OK) return 2;
+    } else {
+        g_out = fopen(argv[4], "wb");
+        if (!g_out) return 2;
+    }
     g_ptrs.resize(g_mics);
     std::map<long, float> thetas;
     if (argc > 5) {
@@ -69,7 +88,8 @@ int main(int argc, char **argv) {
         node.jack_callback((uint32_t)cfg.hop, nullptr);
     }
     node.stop();
-    fclose(g_out);
+    if (g_wav) bf_wav_writer_close(g_wav);
+    if (g_out) fclose(g_out);
     fprintf(stderr, "%s: %ld callbacks, %d mics\n", names[algo], periods, g_mics);
     return 0;
 }

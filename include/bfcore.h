@@ -212,6 +212,27 @@ int bf_reset(bf_handle *h);
 int bf_time_batch_device(bf_handle *h, const float *x_dev, size_t n_frames, float *y_dev, void *hip_stream,
                          int iters, float *ms_per_call, float *ms_kernel);
 
+/* ---- rosjack output stage, file half, and the batch front-end ----------------------------------------
+ * rosjack.cpp:189-210: sf_open(audio_file_path, SFM_WRITE, {WAV | PCM_16, 1 channel, JACK or resampled rate});
+ * rosjack.cpp:404-409: sf_write_float(audio_file, write_file_buffer, data_length) once per callback; closed with the node.
+ * libsndfile (1.0.28 on the reference's Ubuntu 20.04) is neither vendored in the reference nor installed here; its header
+ * layout and its float -> short rule on this call path (lrintf(x * 32767.0f), no clipping: beyond +-1.0 it wraps) are
+ * restated in csrc/wavio.cpp.  Host functions: no HIP device needed.  The resampler (rosjack.cpp:311-350) is not built:
+ * libsamplerate's SINC_FASTEST coefficient table is not available. */
+typedef struct bf_wav_writer bf_wav_writer;
+int bf_wav_writer_open(const char *path, int sample_rate, bf_wav_writer **out);        /* sf_open(..., SFM_WRITE, ...) */
+int bf_wav_writer_write(bf_wav_writer *w, const float *samples, size_t n);             /* sf_write_float */
+int bf_wav_writer_write_pcm16(bf_wav_writer *w, const int16_t *pcm, size_t n);         /* samples already converted (device) */
+int bf_wav_writer_close(bf_wav_writer *w);                                             /* sf_close: patches the lengths */
+/* The sample rule of sf_write_float on a PCM_16 file, on the host and on a batch resident in HBM (16-byte aligned buffers). */
+void bf_float_to_pcm16(const float *src, int16_t *dst, size_t n);
+int bf_float_to_pcm16_device(const float *src_dev, int16_t *dst_dev, size_t n, void *hip_stream);
+/* Front-end: a WAV file (PCM 16/24/32 or float32, any channel count; sf_read_float's scaling) or a raw planar float32 file
+ * -> planar float32 [channel][sample], the BF_PLANAR layout of bf_process_batch.  Release with bf_wav_free. */
+int bf_wav_read(const char *path, float **planar, int *n_channels, size_t *n_samples, int *sample_rate);
+int bf_planar_f32_read(const char *path, int n_channels, float **planar, size_t *n_samples);
+void bf_wav_free(float *planar);
+
 #ifdef __cplusplus
 }
 #endif
