@@ -333,7 +333,7 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
             BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle_w64, tw64.size() * sizeof(f32x2)));
             BF_CREATE_HIP(hipMemcpy(h->d_twiddle_w64, tw64.data(), tw64.size() * sizeof(f32x2), hipMemcpyHostToDevice));
         }
-        h->use_w64 = getenv("BF_DAS_W64") && atoi(getenv("BF_DAS_W64")) != 0 && h->n_dirs == 1;
+        h->use_w64 = getenv("BF_DAS_W64") && atoi(getenv("BF_DAS_W64")) != 0;
         std::vector<f32x2> tw = twiddle_table_32x32<f32x2>();
         BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle, tw.size() * sizeof(f32x2)));
         BF_CREATE_HIP(hipMemcpy(h->d_twiddle, tw.data(), tw.size() * sizeof(f32x2), hipMemcpyHostToDevice));

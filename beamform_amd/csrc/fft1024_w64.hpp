@@ -7,21 +7,25 @@
 // VALU.  16 points per lane halves the register footprint (4 wavefronts per SIMD) at the price
 // of a third pass:
 //
-//   n = 64*n1 + 4*a + b   (n1 in [0,16) registers, lane = 4*a + b, a in [0,16), b in [0,4))
+//   n = 64*n1 + m,  m = 4*a + b   (n1 in [0,16) registers; a in [0,16), b in [0,4))
+//   first pass: lane = m (global loads and stores stay lane-contiguous: a permuted lane order costs 8x the TA/TCP work);
+//   after T1:   lane = 16*b + k1: the 16-lane DPP row is b, the lane inside the row is k1
 //   k = k1 + 16*k2 + 256*k3
-//   P1  16-point FFT over n1 (registers)            -> k1          lane (a,b),   reg k1
-//   TW1 multiply by W1024^((4a+b)*k1)
-//   T1  LDS transpose: reg k1 <-> lane field a                      lane (k1,b),  reg a
-//   P2  16-point FFT over a (registers)             -> k2          lane (k1,b),  reg k2
+//   P1  16-point FFT over n1 (registers)            -> k1          lane 4a+b,    reg k1
+//   TW1 multiply by W1024^(m*k1)
+//   T1  LDS transpose: reg k1 <-> lane field a                      lane (b,k1),  reg a
+//       (writer 4a+b stores register k1 at row k1, column 16 b + a; the reader takes columns 16 b .. 16 b + 15 of row
+//        k1 = its lane & 15 as four ds_read_b128)
+//   P2  16-point FFT over a (registers)             -> k2          lane (b,k1),  reg k2
 //   TW2 multiply by W64^(b*k2)
-//   T2  4x4 transpose inside every quad of lanes (DPP quad_perm), reg field k2&3 <-> lane field b
-//                                                                   lane (k1,k2&3), reg (k2>>2, b)
-//   P3  four 4-point FFTs over b (registers)        -> k3          lane (k1,k2&3), reg (k2>>2, k3)
+//   T2  4x4 transpose across the four 16-lane rows (v_permlane32_swap, v_permlane16_swap), reg field k2&3 <-> row b
+//                                                                   lane (k2&3,k1), reg (k2>>2, b)
+//   P3  four 4-point FFTs over b (registers)        -> k3          lane (k2&3,k1), reg (k2>>2, k3)
 //
 // The backward transform runs the exact mirror (P3^-1, T2, conj TW2, P2^-1, T1^-1, conj TW1, P1^-1),
 // so the forward output layout is the backward input layout: spectra are weighted and summed in
 // place.  Register index of bin k after the forward transform:  r = 4*(k2>>2) + k3,
-// lane = 4*k1 + (k2&3).
+// lane = 16*(k2&3) + k1.
 //
 // This header holds the per-lane arithmetic (host + device); the two cross-lane steps are
 // supplied by the caller (LDS + DPP on the GPU, plain index permutations in the CPU emulation).
@@ -81,9 +85,12 @@ BF_HD void fft4(T &r0, T &i0, T &r1, T &i1, T &r2, T &i2, T &r3, T &i3) {
 // Register conventions: all 16-point passes take natural input and leave bit-reversed output
 // (fft16_core<.., true>) or the reverse; the maps below say where each logical index lives.
 
+// column of the T1 plane that first-pass lane 4a+b exchanges with the second-pass lanes: 16 b + a
+constexpr int w64_col(int lane) { return 16 * (lane & 3) + (lane >> 2); }
+
 // forward P1 + TW1.  in: reg j = x[64*j + lane].  out: position i holds A[k1 = brev4(i)] * W1024^(lane*k1)
 template <typename T, typename TW>
-BF_HD void w64_fwd_p1(T (&re)[16], T (&im)[16], int lane, const TW *tw1 /* [k1][64] */) {
+BF_HD void w64_fwd_p1(T (&re)[16], T (&im)[16], int lane, const TW *tw1 /* [k1][lane] = W1024^(lane*k1) */) {
     fft16_core<T, -1, true>(re, im);
 #pragma unroll
     for (int i = 1; i < 16; ++i) {
@@ -94,11 +101,11 @@ BF_HD void w64_fwd_p1(T (&re)[16], T (&im)[16], int lane, const TW *tw1 /* [k1][
         im[i] = xr * w.y + xi * w.x;
     }
 }
-// after T1 (reg a natural): forward P2 + TW2.  out: position i holds C[k2 = brev4(i)] * W64^(b*k2), b = lane & 3
+// after T1 (reg a natural): forward P2 + TW2.  out: position i holds C[k2 = brev4(i)] * W64^(b*k2), b = lane >> 4
 template <typename T, typename TW>
 BF_HD void w64_fwd_p2(T (&re)[16], T (&im)[16], int lane, const TW *tw2 /* [b][16] = W64^(b*k2) */) {
     fft16_core<T, -1, true>(re, im);
-    const int b = lane & 3;
+    const int b = lane >> 4;
 #pragma unroll
     for (int i = 1; i < 16; ++i) {
         const int k2 = brev4(i);
@@ -123,11 +130,11 @@ BF_HD void w64_inv_p3(T (&re)[16], T (&im)[16]) {
     for (int g = 0; g < 4; ++g)
         fft4<T, +1>(re[4 * g], im[4 * g], re[4 * g + 1], im[4 * g + 1], re[4 * g + 2], im[4 * g + 2], re[4 * g + 3], im[4 * g + 3]);
 }
-// after T2 (back): position i holds element k2 = brev4(i) (same register map the forward P2 left), b = lane & 3.
+// after T2 (back): position i holds element k2 = brev4(i) (same register map the forward P2 left), b = lane >> 4.
 // conj TW2 then inverse 16-point over k2 (bit-reversed in, natural out): reg a natural.
 template <typename T, typename TW>
 BF_HD void w64_inv_p2(T (&re)[16], T (&im)[16], int lane, const TW *tw2) {
-    const int b = lane & 3;
+    const int b = lane >> 4;
 #pragma unroll
     for (int i = 1; i < 16; ++i) {
         const int k2 = brev4(i);
@@ -153,6 +160,6 @@ BF_HD void w64_inv_p1(T (&re)[16], T (&im)[16], int lane, const TW *tw1) {
 }
 
 // Bin held by (lane, register r) after the forward transform, and its inverse map.
-constexpr int w64_bin(int lane, int r) { return (lane >> 2) + 16 * ((lane & 3) + 4 * (r >> 2)) + 256 * (r & 3); }
+constexpr int w64_bin(int lane, int r) { return (lane & 15) + 16 * ((lane >> 4) + 4 * (r >> 2)) + 256 * (r & 3); }
 
 }  // namespace bf

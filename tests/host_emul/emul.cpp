@@ -64,31 +64,32 @@ namespace {
 constexpr int kRS64 = 68;
 inline int brev2(int i) { return ((i & 1) << 1) | ((i >> 1) & 1); }
 
-// T1 forward: reg-position i (k1 = brev4(i)), lane 4a+b  ->  reg a, lane 4*k1+b
+// T1 forward: reg-position i (k1 = brev4(i)), lane 4a+b  ->  reg a, lane 16b+k1.  The writer stores at row k1, column
+// w64_col(lane) = 16 b + a; the reader takes columns 16 b .. 16 b + 15 of row (lane & 15).
 template <typename T>
 void w64_T1_fwd(T (*re)[16], T (*im)[16]) {
     static T br[16 * kRS64], bi[16 * kRS64];
     for (int l = 0; l < 64; ++l)
-        for (int i = 0; i < 16; ++i) { br[brev4(i) * kRS64 + l] = re[l][i]; bi[brev4(i) * kRS64 + l] = im[l][i]; }
+        for (int i = 0; i < 16; ++i) { br[brev4(i) * kRS64 + w64_col(l)] = re[l][i]; bi[brev4(i) * kRS64 + w64_col(l)] = im[l][i]; }
     for (int l = 0; l < 64; ++l)
-        for (int a = 0; a < 16; ++a) { re[l][a] = br[(l >> 2) * kRS64 + 4 * a + (l & 3)]; im[l][a] = bi[(l >> 2) * kRS64 + 4 * a + (l & 3)]; }
+        for (int a = 0; a < 16; ++a) { re[l][a] = br[(l & 15) * kRS64 + 16 * (l >> 4) + a]; im[l][a] = bi[(l & 15) * kRS64 + 16 * (l >> 4) + a]; }
 }
 template <typename T>
 void w64_T1_inv(T (*re)[16], T (*im)[16]) {
     static T br[16 * kRS64], bi[16 * kRS64];
     for (int l = 0; l < 64; ++l)
-        for (int a = 0; a < 16; ++a) { br[(l >> 2) * kRS64 + 4 * a + (l & 3)] = re[l][a]; bi[(l >> 2) * kRS64 + 4 * a + (l & 3)] = im[l][a]; }
+        for (int a = 0; a < 16; ++a) { br[(l & 15) * kRS64 + 16 * (l >> 4) + a] = re[l][a]; bi[(l & 15) * kRS64 + 16 * (l >> 4) + a] = im[l][a]; }
     for (int l = 0; l < 64; ++l)
-        for (int i = 0; i < 16; ++i) { re[l][i] = br[brev4(i) * kRS64 + l]; im[l][i] = bi[brev4(i) * kRS64 + l]; }
+        for (int i = 0; i < 16; ++i) { re[l][i] = br[brev4(i) * kRS64 + w64_col(l)]; im[l][i] = bi[brev4(i) * kRS64 + w64_col(l)]; }
 }
-// T2 forward: position g' + 4*brev2(q) at lane (.., b)  ->  register 4*g + b at lane (.., q); g' = brev2(g)
+// T2 forward: position g' + 4*brev2(q) at lane (row b, ..)  ->  register 4*g + b at lane (row q, ..); g' = brev2(g)
 template <typename T>
 void w64_T2_fwd(T (*re)[16], T (*im)[16]) {
     static T nr[64][16], ni[64][16];
     for (int l = 0; l < 64; ++l)
         for (int g = 0; g < 4; ++g)
             for (int q = 0; q < 4; ++q) {
-                const int b = l & 3, src_pos = brev2(g) + 4 * brev2(q), dl = (l & ~3) | q;
+                const int b = l >> 4, src_pos = brev2(g) + 4 * brev2(q), dl = (l & 15) | (q << 4);
                 nr[dl][4 * g + b] = re[l][src_pos];
                 ni[dl][4 * g + b] = im[l][src_pos];
             }
@@ -101,7 +102,7 @@ void w64_T2_inv(T (*re)[16], T (*im)[16]) {
     for (int l = 0; l < 64; ++l)
         for (int g = 0; g < 4; ++g)
             for (int b = 0; b < 4; ++b) {
-                const int q = l & 3, dst_pos = brev2(g) + 4 * brev2(q), dl = (l & ~3) | b;
+                const int q = l >> 4, dst_pos = brev2(g) + 4 * brev2(q), dl = (l & 15) | (b << 4);
                 nr[dl][dst_pos] = re[l][4 * g + b];
                 ni[dl][dst_pos] = im[l][4 * g + b];
             }
