@@ -423,17 +423,17 @@ struct LaneGrp;
 template <>
 struct LaneGrp<4> {
     template <int SRC>
-    static __device__ __forceinline__ int bc(int v) { return __builtin_amdgcn_update_dpp(v, v, SRC * 0x55, 0xF, 0xF, false); }
-    static __device__ __forceinline__ int x1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false); }
-    static __device__ __forceinline__ int x2(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false); }
+    static __device__ __forceinline__ int bc(int v) { return __builtin_amdgcn_update_dpp(0, v, SRC * 0x55, 0xF, 0xF, true); }
+    static __device__ __forceinline__ int x1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
+    static __device__ __forceinline__ int x2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true); }
 };
 template <>
 struct LaneGrp<2> {
     template <int SRC>
     static __device__ __forceinline__ int bc(int v) {
-        return __builtin_amdgcn_update_dpp(v, v, SRC | (SRC << 2) | ((2 + SRC) << 4) | ((2 + SRC) << 6), 0xF, 0xF, false);
+        return __builtin_amdgcn_update_dpp(0, v, SRC | (SRC << 2) | ((2 + SRC) << 4) | ((2 + SRC) << 6), 0xF, 0xF, true);
     }
-    static __device__ __forceinline__ int x1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false); }
+    static __device__ __forceinline__ int x1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
     static __device__ __forceinline__ int x2(int v) { return v; }
 };
 template <int L, int SRC>
@@ -686,10 +686,13 @@ __global__ __launch_bounds__(64, 1) void mvdr_lcmv_lanes_kernel(BinsArgs a, int 
 // the whole row, one instruction per dword, VALU latency) instead of an LDS write -> s_waitcnt -> read round trip per
 // column, and the Gram sums are row reductions (quad_perm xor 1/2, row_half_mirror, row_mirror).  No LDS at all.
 template <int N>
+// DPP note: every pattern in this file (quad_perm, row_newbcast, row mirrors) reads a valid source lane for every destination
+// lane, so the `old` operand is dead.  With bound_ctrl = false hipcc still materialises it (v_mov_b32 old, 0 in front of every
+// v_mov_b32_dpp: 812 + 812 instructions in the lcmv-16 solve block = 44 % of it); bound_ctrl = true drops the initialisation.
 __device__ __forceinline__ double rowbc(double v) {
     const long long b = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x150 + N, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + N, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x150 + N, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + N, 0xF, 0xF, true);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 template <int N>
@@ -697,8 +700,8 @@ __device__ __forceinline__ cd rowbc(cd v) { return cd{rowbc<N>(v.x), rowbc<N>(v.
 template <int CTRL>
 __device__ __forceinline__ double dpp_d(double v) {
     const long long b = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 __device__ __forceinline__ double row_sum(double v) {  // every lane of the 16-lane row gets the row total
