@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round profile set, run on the GPU box from the repo root: tools/gpu_profile_all.sh <tag>   -> gpurun_out/<tag>_*
+tag=$1
+export TMPDIR=/tmp
+P="rocprofv3 --kernel-trace --output-format csv"
+# 1. the driver-shaped bench line, un-profiled and under the kernel trace
+python bench.py > gpurun_out/${tag}_bench_das8.json 2> gpurun_out/${tag}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_trace_bench -- python bench.py --no-cpu > gpurun_out/${tag}_bench_das8_profiled.json 2>> gpurun_out/${tag}_bench.err
+for f in $(find gpurun_out/${tag}_trace_bench -name "*kernel_stats*"); do cp $f gpurun_out/${tag}_bench_kernel_stats.csv; done
+# 2. calibration of FETCH_SIZE / WRITE_SIZE
+$P --pmc FETCH_SIZE -d gpurun_out/${tag}_cal_f -- ./tools/ubench/fetch_calib.bin > gpurun_out/${tag}_cal.log 2>&1
+$P --pmc WRITE_SIZE -d gpurun_out/${tag}_cal_w -- ./tools/ubench/fetch_calib.bin >> gpurun_out/${tag}_cal.log 2>&1
+# 3. traffic of every BASELINE config's chain
+run() {  # name, step kernel, run_das args...
+  name=$1; step=$2; shift 2
+  $P --pmc FETCH_SIZE -d gpurun_out/${tag}_${name}_f -- python tools/run_das.py "$@" --iters 3 --warmup 2 --settle-ms 0 > gpurun_out/${tag}_${name}.log 2>&1
+  $P --pmc WRITE_SIZE -d gpurun_out/${tag}_${name}_w -- python tools/run_das.py "$@" --iters 3 --warmup 2 --settle-ms 0 >> gpurun_out/${tag}_${name}.log 2>&1
+  python tools/pmc_traffic_chain.py gpurun_out/${tag}_cal_f gpurun_out/${tag}_cal_w gpurun_out/${tag}_${name}_f gpurun_out/${tag}_${name}_w $step gpurun_out/traffic_${name}.json | tail -4
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_${name}_trace -- python tools/run_das.py "$@" --iters 10 >> gpurun_out/${tag}_${name}.log 2>&1
+  for f in $(find gpurun_out/${tag}_${name}_trace -name "*kernel_stats*"); do cp $f gpurun_out/${tag}_${name}_kernel_stats.csv; done
+  tail -1 gpurun_out/${tag}_${name}.log
+}
+run das8 das_fused --algo das
+run das8_f64 stft_kernel --algo das --das-f64
+run mvdr8 stft_kernel --algo mvdr
+run phase8 stft_kernel --algo phase
+run phasempf8 stft_kernel --algo phasempf --streams 256 --frames 256
+run lcmv16 stft_kernel --algo lcmv --mics 16 --frames 32768

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""HBM-side traffic of a kernel chain (stft -> per-bin -> istft, or the one fused kernel) from two rocprofv3 --pmc passes.
+
+Usage: pmc_traffic_chain.py <calib_fetch_dir> <calib_write_dir> <fetch_dir> <write_dir> <step_kernel_substr> <out.json>
+FETCH_SIZE / WRITE_SIZE are in KiB, per dispatch.  They come from the L2's fabric-side request counters: Infinity-Cache hits
+are counted too (MI355X_MICROARCH.md), so this is "bytes that left the XCD's L2", an upper bound of the HBM bytes.
+gfx950 reports 1/2 of a wide coalesced read: the factor is calibrated on a known 1 GiB stream (tools/ubench/fetch_calib.hip).
+A "step" = one dispatch of the kernel whose name contains <step_kernel_substr> (the chain's first kernel)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def per_kernel(d, name):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(d + "/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == name:
+                acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+cf, cw, kf, kw, step, out = sys.argv[1:7]
+GiB = float(1 << 30)
+calf, calw = per_kernel(cf, "FETCH_SIZE"), per_kernel(cw, "WRITE_SIZE")
+mean = lambda v: sum(v) / len(v)
+pick = lambda acc, sub: mean([x for k, v in acc.items() if sub in k for x in v])
+fetch_factor = GiB / (pick(calf, "copy_x4") * 1024.0)      # 16 B / lane, the bin pipeline's access width
+fetch_factor_dword = GiB / (pick(calf, "read_dword") * 1024.0)
+write_factor = GiB / (pick(calw, "copy_x4") * 1024.0)
+F, W = per_kernel(kf, "FETCH_SIZE"), per_kernel(kw, "WRITE_SIZE")
+ours = sorted(k for k in set(F) | set(W) if "bf::" in k or "das_fused" in k)
+steps = max(len(v) for k, v in F.items() if step in k)
+res = {"calibration": {"known_bytes": GiB, "fetch_factor_x4": fetch_factor, "fetch_factor_dword": fetch_factor_dword,
+                       "write_factor_x4": write_factor},
+       "steps_profiled": steps, "kernels": {}}
+tr = tw = 0.0
+for k in ours:
+    r = sum(F.get(k, [])) * 1024.0 * fetch_factor / steps
+    w = sum(W.get(k, [])) * 1024.0 * write_factor / steps
+    res["kernels"][k[:90]] = {"dispatches_per_step": len(F.get(k, [])) / steps, "read_bytes_per_step": r, "write_bytes_per_step": w}
+    tr += r
+    tw += w
+res["hbm_read_bytes_per_launch"] = tr
+res["hbm_write_bytes_per_launch"] = tw
+res["hbm_bytes_per_launch"] = tr + tw
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))
