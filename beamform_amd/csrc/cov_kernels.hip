@@ -685,10 +685,10 @@ __global__ __launch_bounds__(64, 1) void mvdr_lcmv_lanes_kernel(BinsArgs a, int 
 // pivot, the scaled column and the right-hand sides travel by `v_mov_b32_dpp row_newbcast:n` (lane n of every row to
 // the whole row, one instruction per dword, VALU latency) instead of an LDS write -> s_waitcnt -> read round trip per
 // column, and the Gram sums are row reductions (quad_perm xor 1/2, row_half_mirror, row_mirror).  No LDS at all.
-template <int N>
 // DPP note: every pattern in this file (quad_perm, row_newbcast, row mirrors) reads a valid source lane for every destination
 // lane, so the `old` operand is dead.  With bound_ctrl = false hipcc still materialises it (v_mov_b32 old, 0 in front of every
 // v_mov_b32_dpp: 812 + 812 instructions in the lcmv-16 solve block = 44 % of it); bound_ctrl = true drops the initialisation.
+template <int N>
 __device__ __forceinline__ double rowbc(double v) {
     const long long b = __builtin_bit_cast(long long, v);
     const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x150 + N, 0xF, 0xF, true);
@@ -884,6 +884,266 @@ __global__ __launch_bounds__(256, 2) void mvdr_lcmv_row_kernel(BinsArgs a, int t
     }
 }
 
+
+// ---- lcmv / mvdr, 9..16 microphones: 2-D cyclic 4 x 4 lanes per problem -------------------------------------------------
+// One problem (stream, bin) per 16-lane DPP row, like mvdr_lcmv_row_kernel, but the lanes form a 4 x 4 grid (p = lane >> 2,
+// q = lane & 3 inside the row) and matrix entry (i, c) lives in lane (i mod 4, c mod 4) at local index (i / 4, c / 4):
+// every lane owns a 4 x 4 block of R and of the working copy (its lower triangle + diagonal: 10 entries), so
+//   * the triangular trailing update keeps all 16 lanes busy until the last 4 x 4 block (the row-per-lane kernel idles half
+//     of them on average: 1 020 fp64 instructions per wavefront-frame where 455 would do),
+//   * a lane carries 10 + 10 matrix entries and 4 x 2 right-hand-side entries instead of 16 + 16 + 5: ~130 VGPRs, four
+//     wavefronts per SIMD instead of two.
+// Exchange per elimination step jj (column jj = 4 bj + qj):
+//   pivot            lane (qj, qj)        -> whole row        DPP row_newbcast
+//   scaled column    lanes (p, qj)        -> their quad       DPP quad_perm broadcast          Lrow[a] = L(4a+p, jj)
+//   its transpose    lane (q, p)          -> lane (p, q)      ds_bpermute, fixed address       Lcol[b] = L(4b+q, jj)
+//   right-hand side  lane (qj, q)         -> lanes (., q)     ds_bpermute                      u = b(jj, col) / L(jj, jj)
+// Right-hand-side column r belongs to the lanes with q = r mod 4 (slot r / 4): constraints 0..3 in slot 0, the frame's x in
+// slot 1 of the q = 0 lanes.  Rows that are already final (i <= jj) are switched off by zeroing their Lrow entry, so the
+// updates run unconditionally.  Maths as everywhere in this file: R o whiteR = L L^H, U = L^-1 [C | x], G = U_C^H U_C,
+// g = U_C^H u_x, y = (G^-1 g)_0.
+template <int SRC>
+__device__ __forceinline__ double quadbc(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), SRC * 0x55, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), SRC * 0x55, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <int SRC>
+__device__ __forceinline__ cd quadbc(cd v) { return cd{quadbc<SRC>(v.x), quadbc<SRC>(v.y)}; }
+__device__ __forceinline__ double bperm_d(int addr, double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, (int)(b & 0xffffffffLL));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, (int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ cd bperm_c(int addr, cd v) { return cd{bperm_d(addr, v.x), bperm_d(addr, v.y)}; }
+// sum over the four quads of a 16-lane row (same q): row_ror 4 and 8
+__device__ __forceinline__ double quads_sum(double v) {
+    v += dpp_d<0x124>(v);  // row_ror:4
+    v += dpp_d<0x128>(v);  // row_ror:8
+    return v;
+}
+// local lower triangle (a >= b) of a 4 x 4 block, row-major
+__device__ constexpr int LT(int a, int b) { return a * (a + 1) / 2 + b; }
+
+template <int KM, int WPS>
+__global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, int tiles_per_stream) {
+    constexpr int NB = KM + 1, NS = (NB + 3) / 4;  // right-hand sides, slots per lane
+    constexpr int NG = GramIdx<KM>::NG, NE = GramIdx<KM>::NE;
+    __shared__ __attribute__((aligned(16))) f64x2 s_x[4][2][4][16];   // [wave][new / old][problem][mic]
+    __shared__ __attribute__((aligned(16))) f64x2 s_u[4][4][NB][16];  // [wave][problem][column][row]: U = L^-1 [C | x]
+    __shared__ __attribute__((aligned(16))) f64x2 s_g[4][4][16];      // [wave][problem][Gram entry]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l16 = lane & 15, grp = lane >> 4, p = l16 >> 2, q = l16 & 3;
+    const int pq = blockIdx.y * 16 + wv * 4 + grp;
+    const int s = blockIdx.x / tiles_per_stream;
+    const long tA = (long)(blockIdx.x % tiles_per_stream) * tile;
+    long tB = tA + tile;
+    if (tB > a.n_frames) tB = a.n_frames;
+    const int M = a.n_mics, NP = (M + 1) >> 1, KP1 = a.kp1, P = a.cfg.past_windows;
+    const bool live = pq < kNQ;
+    const int qq = live ? pq : kNQ - 1;
+    const int j = q_bin(qq);
+    const bool lcmv = a.cfg.algo == BF_LCMV;
+    f64x2 *yout = a.Yh + ((long)s * a.n_frames) * kYhStride + qq;
+    const f64x2 *Zs = a.Z + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
+    const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
+    const int ksrc = q_src_bin(qq), kneg = (kN - ksrc) & (kN - 1);
+    const int addrT = 4 * ((lane & ~15) | (q << 2) | p);  // my transpose partner (q, p)
+
+    // microphone l16's spectrum at this bin, frame t (may be negative: history)
+    auto load_mic = [&](long t) -> cd {
+        if (l16 >= M) return cd{0, 0};
+        const f64x2 *Zf = Zs + t * NP * kN + (l16 >> 1) * kN;
+        const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
+        cd x;
+        if ((l16 & 1) == 0) {
+            x = (z + zc) * 0.5;
+        } else {
+            const cd d = z - zc;
+            x = cd{0.5 * d.y, -0.5 * d.x};
+        }
+        return qq == kQX ? conj(x) : x;
+    };
+    // one microphone per lane -> LDS -> this lane's four row entries x(4a+p) and four column entries x(4b+q).
+    // LDS operations of one wavefront execute in issue order: compiler barriers only.
+    auto spread = [&](cd x, int slot, cd (&xr)[4], cd (&xc)[4]) {
+        s_x[wv][slot][grp][l16] = f64x2{x.x, x.y};
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            xr[k] = ld(&s_x[wv][slot][grp][4 * k + p]);
+            xc[k] = ld(&s_x[wv][slot][grp][4 * k + q]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    const double f = fabs(a.freqs[j]);
+    const bool inband = live && f >= a.cfg.freq_min && f <= a.cfg.freq_max && !(j == 0 && !lcmv);
+    if (__builtin_amdgcn_ballot_w64(inband) == 0) {  // nothing to solve in this wavefront
+        for (long t = tA; t < tB; ++t) {
+            cd y{0, 0};
+            if (j == 0 && !lcmv) y = rowbc<0>(load_mic(t));  // mvdr.cpp:76
+            if (live && l16 == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+        }
+        return;
+    }
+    // Right-hand sides: lane (p, q) holds rows 4a + q (a = 0..3) of column p + 4 sl -- rows by q, columns by p -- so that
+    // the per-step u = b(jj, col) / L_jj comes from lane (p, qj) of the SAME quad (one DPP broadcast) and the update uses
+    // Lcol.  Columns 0..KM-1 = constraints, column KM = the frame's x.
+    auto rhs_init = [&](int arow, int col, const cd (&xc)[4]) -> cd {
+        const int i = 4 * arow + q;
+        if (col == KM) return xc[arow];
+        return (col < KP1 && col < KM && i < M) ? ld(steer + ((long)col * M + i) * kN + j) : cd{0, 0};
+    };
+
+    cd R[10];
+#pragma unroll
+    for (int e = 0; e < 10; ++e) R[e] = cd{0, 0};
+    for (int pp = 1; pp <= P; ++pp) {  // covariance of the P frames in front of the tile
+        cd xr[4], xc[4];
+        spread(load_mic(tA - pp), 0, xr, xc);
+#pragma unroll
+        for (int ar = 0; ar < 4; ++ar)
+#pragma unroll
+            for (int bc = 0; bc <= ar; ++bc) R[LT(ar, bc)] = cfma_conj(R[LT(ar, bc)], xr[ar], xc[bc]);
+    }
+    for (long t = tA; t < tB; ++t) {
+        const cd xm = load_mic(t);
+        cd xr[4], xc[4];
+        spread(xm, 0, xr, xc);
+        const double mag = row_sum(sqrt(norm2(xm))) / (double)((unsigned)M * (unsigned)kN);
+        const cd x0 = rowbc<0>(xm);
+        cd y;
+        if (mag > a.cfg.freq_mag_threshold) {  // uniform per row
+            cd A[10], b[4][NS];
+#pragma unroll
+            for (int ar = 0; ar < 4; ++ar) {
+#pragma unroll
+                for (int bc = 0; bc <= ar; ++bc) {
+                    cd v = R[LT(ar, bc)];
+                    if (ar == bc) {
+                        const int i = 4 * ar + p;
+                        if (p == q) v = (i < M) ? v * 1.001 : cd{1.0, 0.0};  // whiteR diagonal (mvdr.cpp:239-243); padding = identity
+                    }
+                    A[LT(ar, bc)] = v;
+                }
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) b[ar][sl] = (p + 4 * sl < NB) ? rhs_init(ar, p + 4 * sl, xc) : cd{0, 0};
+            }
+            RowStep<0, 16>::run([&](auto jc) {
+                constexpr int jj = decltype(jc)::value, bj = jj >> 2, qj = jj & 3;
+                const double inv = rsqrt(rowbc<5 * qj>(A[LT(bj, bj)].x));  // 1 / L_jj from lane (qj, qj)
+                cd Lrow[4], Lcol[4], u[NS];
+#pragma unroll
+                for (int ar = bj; ar < 4; ++ar) Lrow[ar] = quadbc<qj>(A[LT(ar, bj)] * inv);  // L(4ar+p, jj) from lane (p, qj)
+                if (p <= qj) Lrow[bj] = cd{0, 0};                                              // rows i <= jj are final
+#pragma unroll
+                for (int bc = bj; bc < 4; ++bc) Lcol[bc] = bperm_c(addrT, Lrow[bc]);            // L(4bc+q, jj), 0 for rows <= jj
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) {  // meanwhile: u_jj of my column(s), from lane (p, qj) of my quad
+                    const cd bs = b[bj][sl] * inv;
+                    u[sl] = quadbc<qj>(bs);
+                    if (q == qj) b[bj][sl] = bs;   // row jj itself: U(jj, col)
+                }
+#pragma unroll
+                for (int ar = bj; ar < 4; ++ar)
+#pragma unroll
+                    for (int bc = bj; bc <= ar; ++bc) A[LT(ar, bc)] = cfms_conj(A[LT(ar, bc)], Lrow[ar], Lcol[bc]);
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+                    for (int ar = bj; ar < 4; ++ar) b[ar][sl] = cfms(b[ar][sl], Lcol[ar], u[sl]);
+            });
+            // b = rows 4a + q of U for column(s) p + 4 sl.  Through LDS: [column][row]; Gram entry e is summed by lane e of
+            // the row over the 16 rows, published, and read back by every lane (the small solve runs redundantly).
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl)
+                if (p + 4 * sl < NB) {
+#pragma unroll
+                    for (int ar = 0; ar < 4; ++ar) {
+                        const cd v = (4 * ar + q < M) ? b[ar][sl] : cd{0, 0};
+                        s_u[wv][grp][p + 4 * sl][4 * ar + q] = f64x2{v.x, v.y};
+                    }
+                }
+            __builtin_amdgcn_wave_barrier();
+            {
+                // entry l16 < NG: G(r1, r2), r1 <= r2, row-major upper triangle; NG <= l16 < NE: g(r1) = U(:, r1)^H u_x
+                int r1 = 0, r2 = KM;
+                if (l16 < NG) {
+                    int rem = l16;
+                    while (rem >= KM - r1) { rem -= KM - r1; ++r1; }
+                    r2 = r1 + rem;
+                } else {
+                    r1 = l16 - NG;
+                }
+                cd acc{0, 0};
+                if (l16 < NE) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc = cfma_conj(acc, ld(&s_u[wv][grp][r2][i]), ld(&s_u[wv][grp][r1][i]));
+                }
+                s_g[wv][grp][l16] = f64x2{acc.x, acc.y};
+            }
+            __builtin_amdgcn_wave_barrier();
+            cd ge[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) ge[e] = ld(&s_g[wv][grp][e]);
+            __builtin_amdgcn_wave_barrier();
+            // (K+1) x (K+1) system G y = g on the upper triangle (as in mvdr_lcmv_row_kernel)
+            cd gv[KM];
+            auto UI = [](int r, int c) { return r * KM - r * (r - 1) / 2 + (c - r); };
+#pragma unroll
+            for (int r1 = 0; r1 < KM; ++r1) gv[r1] = ge[NG + r1];
+#pragma unroll
+            for (int r1 = 0; r1 < KM; ++r1)
+                if (r1 >= KP1) {
+#pragma unroll
+                    for (int r2 = 0; r2 < r1; ++r2) ge[UI(r2, r1)] = cd{0, 0};
+                    ge[UI(r1, r1)] = cd{1.0, 0.0};
+#pragma unroll
+                    for (int c = r1 + 1; c < KM; ++c) ge[UI(r1, c)] = cd{0, 0};
+                    gv[r1] = cd{0, 0};
+                }
+#pragma unroll
+            for (int k = 0; k < KM; ++k) {
+                const cd pinv = cdiv(cd{1, 0}, ge[UI(k, k)]);
+#pragma unroll
+                for (int r1 = k + 1; r1 < KM; ++r1) {
+                    const cd fct = conj(ge[UI(k, r1)]) * pinv;
+#pragma unroll
+                    for (int c = r1; c < KM; ++c) ge[UI(r1, c)] = ge[UI(r1, c)] - fct * ge[UI(k, c)];
+                    gv[r1] = gv[r1] - fct * gv[k];
+                }
+            }
+#pragma unroll
+            for (int k = KM - 1; k >= 0; --k) {
+                cd acc = gv[k];
+#pragma unroll
+                for (int c = k + 1; c < KM; ++c) acc = acc - ge[UI(k, c)] * gv[c];
+                gv[k] = cdiv(acc, ge[UI(k, k)]);
+            }
+            y = gv[0];
+        } else {
+            y = x0 * 0.01;  // in_fft(0,j)*0.01 (mvdr.cpp:96)
+        }
+        if (!inband) y = (j == 0 && !lcmv) ? x0 : cd{0, 0};
+        if (live && l16 == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+        // slide the covariance window: + x_t x_t^H - x_{t-P} x_{t-P}^H (mvdr.cpp:100-101).  x_t is read back from its LDS slot
+        // (still there) instead of being kept in 32 registers across the factorisation.
+        cd xor_[4], xoc[4];
+        spread(load_mic(t - P), 1, xor_, xoc);
+#pragma unroll
+        for (int ar = 0; ar < 4; ++ar) {
+            const cd xra = ld(&s_x[wv][0][grp][4 * ar + p]);
+#pragma unroll
+            for (int bc = 0; bc <= ar; ++bc) {
+                const cd xcb = ld(&s_x[wv][0][grp][4 * bc + q]);
+                R[LT(ar, bc)] = cfms_conj(cfma_conj(R[LT(ar, bc)], xra, xcb), xor_[ar], xoc[bc]);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
@@ -911,6 +1171,27 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
         } else {
             if (M <= 16) BF_LAUNCH_ML(16, 16);
             else BF_LAUNCH_ML(32, 16);
+        }
+        return hipGetLastError();
+    }
+    // 9..16 microphones, up to 3 interferers: 2-D cyclic 4 x 4 lanes per problem (lcmv 16-mic K=3 19.5 -> 15.8 ms per 32 768 frames,
+    // lcmv 12-mic 19.0 -> 14.7, mvdr 16-mic 11.0 -> 10.2).  BF_COV2D=0 selects the row / lanes kernels below for A/B runs, =2 the
+    // two-wavefronts-per-SIMD build.
+    static const int cov2d = getenv("BF_COV2D") ? atoi(getenv("BF_COV2D")) : 3;
+    static const int tile2d_env = getenv("BF_COV2D_TILE") ? atoi(getenv("BF_COV2D_TILE")) : 0;
+    if (cov2d && !no_fast && M > 8 && M <= 16) {
+        if (tile2d_env > 0) {
+            tile = tile2d_env;
+            if (a.n_frames < tile) tile = (int)a.n_frames;
+        }
+        const int tps = (int)((a.n_frames + tile - 1) / tile);
+        const dim3 grid(tps * a.n_streams, (kNQ + 15) / 16);
+        if (km == 1) {
+            if (cov2d == 3) hipLaunchKernelGGL((cov2d_kernel<1, 3>), grid, dim3(256), 0, s, a, tile, tps);
+            else hipLaunchKernelGGL((cov2d_kernel<1, 2>), grid, dim3(256), 0, s, a, tile, tps);
+        } else {
+            if (cov2d == 3) hipLaunchKernelGGL((cov2d_kernel<4, 3>), grid, dim3(256), 0, s, a, tile, tps);
+            else hipLaunchKernelGGL((cov2d_kernel<4, 2>), grid, dim3(256), 0, s, a, tile, tps);
         }
         return hipGetLastError();
     }
