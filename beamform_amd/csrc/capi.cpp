@@ -187,8 +187,9 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     a.frames_per_chunk = (int)fpc;
     a.chunks_per_stream = (int)cps;
     a.layout = layout;
-    // BF_DAS_VARIANT=0 selects the ds_write_b32 transposes for A/B runs (same arithmetic, bit-identical output)
-    static const int das_variant = getenv("BF_DAS_VARIANT") ? atoi(getenv("BF_DAS_VARIANT")) : 1;
+    // BF_DAS_VARIANT bit 0: ds_write_addtid transposes, bit 1: unrolled pair loop with in-loop prefetch; 0 / 1 select the older
+    // forms for A/B runs (same arithmetic, bit-identical output)
+    static const int das_variant = getenv("BF_DAS_VARIANT") ? atoi(getenv("BF_DAS_VARIANT")) : 3;
     a.variant = das_variant;
     BF_HIP(h, prepare_das_fused(a, s));
     hipEvent_t k0 = nullptr, k1 = nullptr;

@@ -139,7 +139,7 @@ __device__ __forceinline__ void wt_fft_inv(float (&re)[32], float (&im)[32], int
 // partner (second half of frame t-1) comes from the neighbour through a 17-slot LDS ring; only the
 // first hop of a run needs the previous run's last frame, and that one hop is completed by two
 // float atomic adds into a pre-zeroed hop (sum of two terms: order-independent, bit-exact).
-template <int LAYOUT, int NPL, bool WT>
+template <int LAYOUT, int NPL, bool WT, int UNR = 0>
 __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFixed + NPL * 2048 + 17 * kHop + 32];
     const cx<float> *s_tw = reinterpret_cast<const cx<float> *>(lds);
@@ -226,6 +226,55 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
         const bool valid = t < T1;
         const long tc = valid ? t : T1 - 1;
 
+        if constexpr (UNR > 0 && LAYOUT == 0 && NPL > 0 && WT) {
+#ifndef BF_DAS_CHUNK
+#define BF_DAS_CHUNK 8
+#endif
+            constexpr int kChunk = BF_DAS_CHUNK;  // register positions whose loads are issued together (4 / 8 / 16 measured: see DESIGN.md)
+            // exact pair count, planar input: the pair loop is unrolled and the loads of pair p + 1 are issued from inside
+            // pair p's gain loop, eight register positions at a time, into the registers that loop has just consumed
+            auto rows = [&](int p, int i0) {
+                const int ma = 2 * p, mb = 2 * p + 1;
+                const bool b_ok = mb < M;  // odd microphone count: the last pair's partner channel reads the zero buffer
+                const float *a1 = (tc >= 1 ? xs + (long)ma * a.mic_stride + (tc - 1) * kHop : hs + ma * kHop) + lane;
+                const float *b1 = (!b_ok ? a.zeros : tc >= 1 ? xs + (long)mb * a.mic_stride + (tc - 1) * kHop : hs + mb * kHop) + lane;
+                const float *a2 = xs + (long)ma * a.mic_stride + tc * kHop + lane;
+                const float *b2 = (!b_ok ? a.zeros : xs + (long)mb * a.mic_stride + tc * kHop) + lane;
+#pragma unroll
+                for (int jx = i0; jx < i0 + kChunk; ++jx) {
+                    re[jx] = jx < 16 ? a1[32 * jx] : a2[32 * (jx - 16)];
+                    im[jx] = jx < 16 ? b1[32 * jx] : b2[32 * (jx - 16)];
+                }
+            };
+#pragma unroll
+            for (int p = 0; p < UNR; ++p) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const float4 hv = wrow[g];
+                    re[4 * g + 0] *= hv.x; im[4 * g + 0] *= hv.x;
+                    re[4 * g + 1] *= hv.y; im[4 * g + 1] *= hv.y;
+                    re[4 * g + 2] *= hv.z; im[4 * g + 2] *= hv.z;
+                    re[4 * g + 3] *= hv.w; im[4 * g + 3] *= hv.w;
+                }
+                wt_fft_fwd(re, im, lane, s_tw, wbase, wrowp);
+                const cx<float> *gp = s_gain + (long)p * 1024 + lane;
+#pragma unroll
+                for (int c = 0; c < 32 / kChunk; ++c) {
+#pragma unroll
+                    for (int i = kChunk * c; i < kChunk * c + kChunk; ++i) {
+                        const cx<float> g = gp[32 * i];
+                        const float ar = g.x * re[i] - g.y * im[i], ai = g.x * im[i] + g.y * re[i];
+                        Sr[i] = (p == 0) ? ar : Sr[i] + ar;
+                        Si[i] = (p == 0) ? ai : Si[i] + ai;
+                    }
+                    if (p + 1 < UNR) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        rows(p + 1, kChunk * c);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        } else
         for (int p = 0; p < n_pairs; ++p) {
             const bool b_ok = (2 * p + 1) < M;
             if (LAYOUT != 0) {
@@ -393,14 +442,22 @@ __global__ void das_hermitian_dump_kernel(const f32x2 *s, f64x2 *out, long total
 template <int LAYOUT, bool WT>
 void launch_layout(const DasFusedArgs &a, unsigned blocks, hipStream_t stream) {
     const int np = (a.n_mics + 1) / 2;
-    if (np <= 1)
-        hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 1, WT>), dim3(blocks), dim3(kBlock), 0, stream, a);
-    else if (np <= 2)
-        hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 2, WT>), dim3(blocks), dim3(kBlock), 0, stream, a);
-    else if (np <= 4)
-        hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 4, WT>), dim3(blocks), dim3(kBlock), 0, stream, a);
-    else  // > 8 mics: the gain tables no longer fit beside the transpose buffers and the tail ring
-        hipLaunchKernelGGL((das_fused_kernel<LAYOUT, 0, WT>), dim3(blocks), dim3(kBlock), 0, stream, a);
+    // planar input with the wave-interleaved transposes: pair loop unrolled for the exact pair count, next pair's loads issued
+    // from inside the gain loop (BF_DAS_VARIANT bit 1; same arithmetic, bit-identical output)
+    const bool unr = LAYOUT == 0 && WT && (a.variant & 2);
+#define BF_DAS_GO(NPL_, UNR_) hipLaunchKernelGGL((das_fused_kernel<LAYOUT, NPL_, WT, UNR_>), dim3(blocks), dim3(kBlock), 0, stream, a)
+    if (np <= 1) {
+        if (unr) BF_DAS_GO(1, 1); else BF_DAS_GO(1, 0);
+    } else if (np <= 2) {
+        if (unr) BF_DAS_GO(2, 2); else BF_DAS_GO(2, 0);
+    } else if (np == 3) {
+        if (unr) BF_DAS_GO(4, 3); else BF_DAS_GO(4, 0);
+    } else if (np == 4) {
+        if (unr) BF_DAS_GO(4, 4); else BF_DAS_GO(4, 0);
+    } else {  // > 8 mics: the gain tables no longer fit beside the transpose buffers and the tail ring
+        BF_DAS_GO(0, 0);
+    }
+#undef BF_DAS_GO
 }
 
 // Sum of squares of every output stream (double accumulation): bf_stream_rms.
