@@ -129,6 +129,58 @@ __device__ __forceinline__ void wt_fft_inv(float (&re)[32], float (&im)[32], int
     fft32_dif<float, +1>(re, im);
 }
 
+// ---- paired tables (unrolled kernels) -------------------------------------------------------------------------------------
+// hipcc merges two ds_read_b64 of one table (twiddle rows k1 and k1', gains of positions i and i') into one ds_read2_b64, which
+// the LDS serves at HALF the rate of the two separate reads (8 cycles per 1 KiB instead of 2 x 2: MI355X guide, LDS table).
+// So the unrolled kernels re-pack both tables while filling the LDS: two entries a lane needs back to back become 16
+// contiguous bytes -> one ds_read_b128 at the full 256 B/clk.
+//   twiddles: [k < 16][lane][2] = { W1024^(k lane), W1024^((k + 16) lane) }   (forward: positions brev5(k), brev5(k) + 1;
+//                                                                             backward: positions k, k + 16)
+//   gains:    [pair][m < 16][lane][2] = { D[2m][lane], D[2m + 1][lane] }
+__device__ __forceinline__ void wt_fft_fwd_p2(float (&re)[32], float (&im)[32], int lane, const float4 *tw2, unsigned base,
+                                              const float *rp) {
+    fft32_dif<float, -1>(re, im);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float4 w = tw2[k * 32 + lane];
+        const int i = brev5(k);  // even position: k1 = k; i + 1: k1 = k + 16
+        if (k > 0) {
+            const float xr = re[i], xi = im[i];
+            re[i] = xr * w.x - xi * w.y;
+            im[i] = xr * w.y + xi * w.x;
+        }
+        const float yr = re[i + 1], yi = im[i + 1];
+        re[i + 1] = yr * w.z - yi * w.w;
+        im[i + 1] = yr * w.w + yi * w.z;
+    }
+    wt_store_plane<false>(re, base);
+    wt_load_row(re, rp);
+    wt_store_plane<false>(im, base);
+    wt_load_row(im, rp);
+    fft32_dif<float, -1>(re, im);
+}
+__device__ __forceinline__ void wt_fft_inv_p2(float (&re)[32], float (&im)[32], int lane, const float4 *tw2, unsigned base,
+                                              const float *rp) {
+    fft32_dit<float, +1>(re, im);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float4 w = tw2[k * 32 + lane];
+        if (k > 0) {
+            const float xr = re[k], xi = im[k];
+            re[k] = xr * w.x + xi * w.y;
+            im[k] = xi * w.x - xr * w.y;
+        }
+        const float yr = re[k + 16], yi = im[k + 16];
+        re[k + 16] = yr * w.z + yi * w.w;
+        im[k + 16] = yi * w.z - yr * w.w;
+    }
+    wt_store_plane<true>(re, base);
+    wt_load_row(re, rp);
+    wt_store_plane<true>(im, base);
+    wt_load_row(im, rp);
+    fft32_dif<float, +1>(re, im);
+}
+
 // NPL = number of pair-gain tables held in LDS (0: read gains from global memory)
 //
 // Work split: one 512-thread block (16 half-wavefronts) owns a run of consecutive frames of one
@@ -166,13 +218,21 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
     const long c_in_s = blockIdx.x - (long)stream * a.chunks_per_stream;
     const int in_stream = stream / a.n_dirs;
     const f32x2 *gains = a.gains + (long)(stream - in_stream * a.n_dirs) * n_pairs * 1024;
+    constexpr bool kP2 = UNR > 0 && LAYOUT == 0 && NPL > 0 && WT;  // paired tables (see wt_fft_fwd_p2)
     {
-        const float *twf = reinterpret_cast<const float *>(a.twiddle);
-        for (int i = tid; i < kLdsTw; i += kBlock) lds[i] = twf[i];
+        const f32x2 *twc = a.twiddle;
+        f32x2 *ltw = reinterpret_cast<f32x2 *>(lds);
+        for (int i = tid; i < kLdsTw / 2; i += kBlock) {  // i = k1 * 32 + lane
+            const int k1 = i >> 5, l = i & 31;
+            ltw[kP2 ? (((k1 & 15) * 32 + l) * 2 + (k1 >> 4)) : i] = twc[i];
+        }
         for (int i = tid; i < kNfft; i += kBlock) s_win[(i & 31) * kPS + (i >> 5)] = a.window[i];  // [lane][j]
         if (NPL > 0) {
-            const float *gf = reinterpret_cast<const float *>(gains);
-            for (int i = tid; i < n_pairs * 2048; i += kBlock) lds[kLdsFixed + i] = gf[i];
+            f32x2 *lg = reinterpret_cast<f32x2 *>(lds + kLdsFixed);
+            for (int i = tid; i < n_pairs * 1024; i += kBlock) {  // i = (pair * 32 + pos) * 32 + lane
+                const int l = i & 31, pos = (i >> 5) & 31, pr = i >> 10;
+                lg[kP2 ? (((pr * 16 + (pos >> 1)) * 32 + l) * 2 + (pos & 1)) : i] = gains[i];
+            }
         }
     }
     const long T0 = c_in_s * a.frames_per_chunk;
@@ -256,16 +316,19 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                     re[4 * g + 2] *= hv.z; im[4 * g + 2] *= hv.z;
                     re[4 * g + 3] *= hv.w; im[4 * g + 3] *= hv.w;
                 }
-                wt_fft_fwd(re, im, lane, s_tw, wbase, wrowp);
-                const cx<float> *gp = s_gain + (long)p * 1024 + lane;
+                wt_fft_fwd_p2(re, im, lane, reinterpret_cast<const float4 *>(lds), wbase, wrowp);
+                const float4 *gp2 = reinterpret_cast<const float4 *>(lds + kLdsFixed) + p * 512 + lane;
 #pragma unroll
                 for (int c = 0; c < 32 / kChunk; ++c) {
 #pragma unroll
-                    for (int i = kChunk * c; i < kChunk * c + kChunk; ++i) {
-                        const cx<float> g = gp[32 * i];
+                    for (int i = kChunk * c; i < kChunk * c + kChunk; i += 2) {
+                        const float4 g = gp2[16 * i];  // gains of positions i and i + 1
                         const float ar = g.x * re[i] - g.y * im[i], ai = g.x * im[i] + g.y * re[i];
+                        const float br = g.z * re[i + 1] - g.w * im[i + 1], bi = g.z * im[i + 1] + g.w * re[i + 1];
                         Sr[i] = (p == 0) ? ar : Sr[i] + ar;
                         Si[i] = (p == 0) ? ai : Si[i] + ai;
+                        Sr[i + 1] = (p == 0) ? br : Sr[i + 1] + br;
+                        Si[i + 1] = (p == 0) ? bi : Si[i + 1] + bi;
                     }
                     if (p + 1 < UNR) {
                         __builtin_amdgcn_sched_barrier(0);
@@ -354,7 +417,9 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
         // the next frame's first pair streams in while the inverse transform runs on (Sr, Si)
         if (LAYOUT == 0 && it + 1 < n_iter) issue_loads(frame_of(it + 1), 0);
 
-        if (WT) {
+        if (kP2) {
+            wt_fft_inv_p2(Sr, Si, lane, reinterpret_cast<const float4 *>(lds), wbase, wrowp);
+        } else if (WT) {
             wt_fft_inv(Sr, Si, lane, s_tw, wbase, wrowp);
         } else {
             fft1024p_inv_A<float>(Sr, Si, lane, s_tw, pbuf);
