@@ -26,6 +26,7 @@
 // 5 FFT-1024 per frame need about half of the fp32 VALU peak.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "fft1024.hpp"
@@ -35,6 +36,32 @@ namespace bf {
 
 namespace {
 
+// Debug build only (-DBF_DAS_STAMPS): per-phase wall-clock sums of the unrolled scalar kernel, printed after every launch.
+#ifdef BF_DAS_STAMPS
+constexpr int kStampBlocks = 4096;
+__device__ unsigned long long g_stamps[kStampBlocks][20];  // per block (wave 0 reports; plain stores, summed on the host)
+#if BF_DAS_STAMPS >= 2
+#define BF_STAMP(slot)                                                                  \
+    do {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        const unsigned long long now_ = __builtin_readcyclecounter();                   \
+        st_acc[slot] += now_ - st_prev;                                                 \
+        st_prev = now_;                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+    } while (0)
+#else  // 1: whole-loop cycles and clock only (no stamp inside the loop)
+#define BF_STAMP(slot) ((void)0)
+#endif
+#define BF_STAMP_PARAMS , unsigned long long (&st_acc)[16], unsigned long long &st_prev
+#define BF_STAMP_ARGS , st_acc, st_prev
+#else
+#define BF_STAMP(slot) ((void)0)
+#define BF_STAMP_PARAMS
+#define BF_STAMP_ARGS
+#endif
+#ifndef BF_DAS_CHUNK
+#define BF_DAS_CHUNK 8
+#endif
 constexpr int kBlock = 512;
 constexpr int kHalves = kBlock / 32;
 constexpr int kPS = plane_stride<float>::value;  // 36
@@ -138,8 +165,9 @@ __device__ __forceinline__ void wt_fft_inv(float (&re)[32], float (&im)[32], int
 //                                                                             backward: positions k, k + 16)
 //   gains:    [pair][m < 16][lane][2] = { D[2m][lane], D[2m + 1][lane] }
 __device__ __forceinline__ void wt_fft_fwd_p2(float (&re)[32], float (&im)[32], int lane, const float4 *tw2, unsigned base,
-                                              const float *rp) {
+                                              const float *rp BF_STAMP_PARAMS) {
     fft32_dif<float, -1>(re, im);
+    BF_STAMP(1);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const float4 w = tw2[k * 32 + lane];
@@ -153,15 +181,19 @@ __device__ __forceinline__ void wt_fft_fwd_p2(float (&re)[32], float (&im)[32], 
         re[i + 1] = yr * w.z - yi * w.w;
         im[i + 1] = yr * w.w + yi * w.z;
     }
+    BF_STAMP(2);
     wt_store_plane<false>(re, base);
     wt_load_row(re, rp);
     wt_store_plane<false>(im, base);
     wt_load_row(im, rp);
+    BF_STAMP(3);
     fft32_dif<float, -1>(re, im);
+    BF_STAMP(4);
 }
 __device__ __forceinline__ void wt_fft_inv_p2(float (&re)[32], float (&im)[32], int lane, const float4 *tw2, unsigned base,
-                                              const float *rp) {
+                                              const float *rp BF_STAMP_PARAMS) {
     fft32_dit<float, +1>(re, im);
+    BF_STAMP(6);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const float4 w = tw2[k * 32 + lane];
@@ -174,11 +206,14 @@ __device__ __forceinline__ void wt_fft_inv_p2(float (&re)[32], float (&im)[32], 
         re[k + 16] = yr * w.z + yi * w.w;
         im[k + 16] = yi * w.z - yr * w.w;
     }
+    BF_STAMP(7);
     wt_store_plane<true>(re, base);
     wt_load_row(re, rp);
     wt_store_plane<true>(im, base);
     wt_load_row(im, rp);
+    BF_STAMP(8);
     fft32_dif<float, +1>(re, im);
+    BF_STAMP(9);
 }
 
 // NPL = number of pair-gain tables held in LDS (0: read gains from global memory)
@@ -202,6 +237,9 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
     // only hazard is read-after-write: one flag per slot (= the frame whose tail it holds) replaces block barriers.
     float *s_tails = lds + kLdsFixed + NPL * 2048;
     volatile int *s_flag = reinterpret_cast<volatile int *>(lds + kLdsFixed + NPL * 2048 + 17 * kHop);
+#ifdef BF_DAS_STAMPS
+    const unsigned long long st_k0 = __builtin_readcyclecounter();
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 31;
@@ -251,6 +289,11 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
 
     float re[32], im[32], Sr[32], Si[32];
     const int n_iter = (int)((T1 - T0 + kHalves - 1) / kHalves);
+#ifdef BF_DAS_STAMPS
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_prev = __builtin_readcyclecounter();
+    const unsigned long long st_c0 = st_prev, st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // frame handled by this half-wavefront at iteration `it` (clamped into the run: invalid slots redo its last frame)
     auto frame_of = [&](int it) -> long {
@@ -269,8 +312,13 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             const float *b2 = (!b_ok ? a.zeros : xs + (long)mb * a.mic_stride + tc * kHop) + lane;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
+#ifdef BF_DAS_HACK
+                re[j] = __builtin_bit_cast(float, 0x3c000000 + tid + j);
+                im[j] = __builtin_bit_cast(float, 0x3c100000 + tid + j);
+#else
                 re[j] = a1[32 * j];
                 im[j] = b1[32 * j];
+#endif
                 re[j + 16] = a2[32 * j];
                 im[j + 16] = b2[32 * j];
             }
@@ -287,9 +335,6 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
         const long tc = valid ? t : T1 - 1;
 
         if constexpr (UNR > 0 && LAYOUT == 0 && NPL > 0 && WT) {
-#ifndef BF_DAS_CHUNK
-#define BF_DAS_CHUNK 8
-#endif
             constexpr int kChunk = BF_DAS_CHUNK;  // register positions whose loads are issued together (4 / 8 / 16 measured: see DESIGN.md)
             // exact pair count, planar input: the pair loop is unrolled and the loads of pair p + 1 are issued from inside
             // pair p's gain loop, eight register positions at a time, into the registers that loop has just consumed
@@ -302,6 +347,9 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                 const float *b2 = (!b_ok ? a.zeros : xs + (long)mb * a.mic_stride + tc * kHop) + lane;
 #pragma unroll
                 for (int jx = i0; jx < i0 + kChunk; ++jx) {
+#ifdef BF_DAS_HACK  // timing experiment only: the shared hop is not loaded (WRONG results)
+                    if (jx < 16) { re[jx] = __builtin_bit_cast(float, 0x3c000000 + tid + jx); im[jx] = __builtin_bit_cast(float, 0x3c100000 + tid + jx); continue; }
+#endif
                     re[jx] = jx < 16 ? a1[32 * jx] : a2[32 * (jx - 16)];
                     im[jx] = jx < 16 ? b1[32 * jx] : b2[32 * (jx - 16)];
                 }
@@ -316,19 +364,19 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                     re[4 * g + 2] *= hv.z; im[4 * g + 2] *= hv.z;
                     re[4 * g + 3] *= hv.w; im[4 * g + 3] *= hv.w;
                 }
-                wt_fft_fwd_p2(re, im, lane, reinterpret_cast<const float4 *>(lds), wbase, wrowp);
+                BF_STAMP(0);
+                wt_fft_fwd_p2(re, im, lane, reinterpret_cast<const float4 *>(lds), wbase, wrowp BF_STAMP_ARGS);
                 const float4 *gp2 = reinterpret_cast<const float4 *>(lds + kLdsFixed) + p * 512 + lane;
 #pragma unroll
                 for (int c = 0; c < 32 / kChunk; ++c) {
 #pragma unroll
                     for (int i = kChunk * c; i < kChunk * c + kChunk; i += 2) {
                         const float4 g = gp2[16 * i];  // gains of positions i and i + 1
-                        const float ar = g.x * re[i] - g.y * im[i], ai = g.x * im[i] + g.y * re[i];
-                        const float br = g.z * re[i + 1] - g.w * im[i + 1], bi = g.z * im[i + 1] + g.w * re[i + 1];
-                        Sr[i] = (p == 0) ? ar : Sr[i] + ar;
-                        Si[i] = (p == 0) ? ai : Si[i] + ai;
-                        Sr[i + 1] = (p == 0) ? br : Sr[i + 1] + br;
-                        Si[i + 1] = (p == 0) ? bi : Si[i + 1] + bi;
+                        // accumulate with two chained FMAs per component (4 instructions per position instead of 6)
+                        Sr[i] = bf_fma(-g.y, im[i], bf_fma(g.x, re[i], (p == 0) ? 0.f : Sr[i]));
+                        Si[i] = bf_fma(g.y, re[i], bf_fma(g.x, im[i], (p == 0) ? 0.f : Si[i]));
+                        Sr[i + 1] = bf_fma(-g.w, im[i + 1], bf_fma(g.z, re[i + 1], (p == 0) ? 0.f : Sr[i + 1]));
+                        Si[i + 1] = bf_fma(g.w, re[i + 1], bf_fma(g.z, im[i + 1], (p == 0) ? 0.f : Si[i + 1]));
                     }
                     if (p + 1 < UNR) {
                         __builtin_amdgcn_sched_barrier(0);
@@ -336,6 +384,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                BF_STAMP(5);
             }
         } else
         for (int p = 0; p < n_pairs; ++p) {
@@ -416,9 +465,10 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
 
         // the next frame's first pair streams in while the inverse transform runs on (Sr, Si)
         if (LAYOUT == 0 && it + 1 < n_iter) issue_loads(frame_of(it + 1), 0);
+        BF_STAMP(13);
 
         if (kP2) {
-            wt_fft_inv_p2(Sr, Si, lane, reinterpret_cast<const float4 *>(lds), wbase, wrowp);
+            wt_fft_inv_p2(Sr, Si, lane, reinterpret_cast<const float4 *>(lds), wbase, wrowp BF_STAMP_ARGS);
         } else if (WT) {
             wt_fft_inv(Sr, Si, lane, s_tw, wbase, wrowp);
         } else {
@@ -450,6 +500,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             asm volatile("" ::: "memory");
             if (lane == 0) s_flag[my] = (int)t;
         }
+        BF_STAMP(10);
         if (valid) {
             float *yo = ys + t * kHop + lane;
             if (t == T0 && T0 > 0) {
@@ -460,6 +511,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                 // wait for frame t-1's tail (neighbouring half-wavefront, or the last one of the previous iteration)
                 while (s_flag[pv] != (int)(t - 1)) __builtin_amdgcn_s_sleep(1);
                 asm volatile("" ::: "memory");
+                BF_STAMP(11);
                 const float *prev = s_tails + pv * kHop + lane;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
@@ -490,8 +542,26 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                 }
             }
         }
+        BF_STAMP(12);
+#ifdef BF_DAS_STAMPS
+        st_acc[15] += 1;
+#endif
     }
+#ifdef BF_DAS_STAMPS
+    if (tid == 0 && blockIdx.x < kStampBlocks) {
+        unsigned long long *g = g_stamps[blockIdx.x];
+        const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+        for (int i = 0; i < 14; ++i) g[i] += st_acc[i];
+        g[14] += c1 - st_c0;   // shader cycles of the main loop
+        g[15] += st_acc[15];   // iterations
+        g[16] += r1 - st_r0;   // 100 MHz ticks of the main loop
+        g[17] += c1 - st_k0;   // kernel entry to end of loop
+        g[18] = st_r0;         // absolute 100 MHz time at loop start / end of the LAST launch
+        g[19] = r1;
+    }
+#endif
 }
+
 
 __global__ void das_hermitian_dump_kernel(const f32x2 *s, f64x2 *out, long total) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -563,6 +633,45 @@ hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t stream) {
         { if (a.variant & 1) launch_layout<0, true>(a, blocks, stream); else launch_layout<0, false>(a, blocks, stream); }
     else
         { if (a.variant & 1) launch_layout<1, true>(a, blocks, stream); else launch_layout<1, false>(a, blocks, stream); }
+#ifdef BF_DAS_STAMPS
+    {
+        static int n_launch = 0;  // sums accumulate over back-to-back launches; read out only when asked (no sync otherwise)
+        ++n_launch;
+        if (getenv("BF_DAS_STAMPS_PRINT")) {
+            (void)hipStreamSynchronize(stream);
+            static unsigned long long hb[kStampBlocks][20];
+            (void)hipMemcpyFromSymbol(hb, HIP_SYMBOL(g_stamps), sizeof(hb));
+            unsigned long long h[18] = {0};
+            const int nb = (int)(a.chunks_per_stream * a.n_streams) < kStampBlocks ? (int)(a.chunks_per_stream * a.n_streams) : kStampBlocks;
+            for (int b = 0; b < nb; ++b)
+                for (int i = 0; i < 18; ++i) h[i] += hb[b][i];
+            void *sym = nullptr;
+            (void)hipGetSymbolAddress(&sym, HIP_SYMBOL(g_stamps));
+            (void)hipMemset(sym, 0, sizeof(hb));
+            fprintf(stderr, "stamps over %d launches (cycles per wave-iteration, wave 0 of each block):", n_launch);
+            for (int i = 0; i < 14; ++i) fprintf(stderr, " [%d]=%.0f", i, (double)h[i] / (double)(h[15] ? h[15] : 1));
+            {
+                unsigned long long r0min = ~0ull, r1max = 0, dmin = ~0ull, dmax = 0, dsum = 0, r0max = 0, r1min = ~0ull;
+                for (int b = 0; b < nb; ++b) {
+                    const unsigned long long d = hb[b][19] - hb[b][18];
+                    r0min = hb[b][18] < r0min ? hb[b][18] : r0min; r0max = hb[b][18] > r0max ? hb[b][18] : r0max;
+                    r1max = hb[b][19] > r1max ? hb[b][19] : r1max; r1min = hb[b][19] < r1min ? hb[b][19] : r1min;
+                    dmin = d < dmin ? d : dmin; dmax = d > dmax ? d : dmax; dsum += d;
+                }
+                fprintf(stderr, "\n  last launch, loop of wave 0 per block (us): min %.1f mean %.1f max %.1f; first start -> last end %.1f; start spread %.1f, end spread %.1f",
+                        dmin * 0.01, dsum * 0.01 / nb, dmax * 0.01, (r1max - r0min) * 0.01, (r0max - r0min) * 0.01, (r1max - r1min) * 0.01);
+            }
+            if (getenv("BF_DAS_STAMPS_BLOCKS")) {
+                fprintf(stderr, "\n  per-block loop us:");
+                for (int b = 0; b < nb; ++b) fprintf(stderr, " %.1f", (hb[b][19] - hb[b][18]) * 0.01);
+            }
+            const double nw = (double)n_launch * nb;
+            fprintf(stderr, "  clock %.3f GHz  loop %.0f cycles/wave  kernel %.0f cycles/wave\n",
+                    h[16] ? 0.1 * (double)h[14] / (double)h[16] : 0.0, (double)h[14] / nw, (double)h[17] / nw);
+            n_launch = 0;
+        }
+    }
+#endif
     return hipGetLastError();
 }
 

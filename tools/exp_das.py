@@ -31,7 +31,7 @@ for rep in range(5):
 print(f"kernel {best:.4f} ms  frac {18432*65536/(best*1e-3)/8e12*(M*2048+2048)/18432:.4f}  sha {h}")
 ''' % ROOT
 for M in (8, 4):
-    for variant, w64 in [(3, "_prev"), (3, ""), (3, "_prev"), (3, ""), (3, "_prev"), (3, "")]:
+    for variant, w64 in [(int(v), t) for t in os.environ.get("EXP_LIBS", ",_prev").split(",") for v in os.environ.get("EXP_VARIANTS", "3").split(",")] * 3:
         env = dict(os.environ, BF_DAS_VARIANT=str(variant), BFCORE_LIB=os.path.join(ROOT, "beamform_amd", "lib", f"libbfcore{w64}.so"))
         out = subprocess.run([sys.executable, "-c", child, str(M)], env=env, capture_output=True, text=True)
         print(f"M={M} variant={variant} w64={w64}: {out.stdout.strip()} {out.stderr.strip()[-300:] if out.returncode else ''}", flush=True)
