@@ -6,7 +6,7 @@ SRC := beamform_amd/csrc
 OBJ := build/obj
 LIB := beamform_amd/lib/libbfcore.so
 
-HIP_SRCS := $(SRC)/das_fused.hip $(SRC)/das_fused_w64.hip $(SRC)/pipeline.hip $(SRC)/convert.hip
+HIP_SRCS := $(SRC)/das_fused.hip $(SRC)/das_fused_w64.hip $(SRC)/pipeline.hip $(SRC)/convert.hip $(SRC)/resample.hip
 # bin-pipeline kernels: one object per supported FFT size (hop 256 / 512 / 1024 -> -DBF_NFFT=512 / 1024 / 2048)
 BIN_SRCS := pipeline_kernels stft_istft mask_kernels cov_kernels gsc_gss_kernels
 NFFTS := 512 1024 2048
@@ -46,7 +46,7 @@ oracle:
 	$(MAKE) -C oracle -s
 
 ubench:
-	for f in valu_rate fetch_calib w64_test rowbc; do $(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fno-slp-vectorize -Wno-unused-result tools/ubench/$$f.hip -o tools/ubench/$$f.bin; done
+	for f in valu_rate fetch_calib w64_test rowbc vmem_issue; do $(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fno-slp-vectorize -Wno-unused-result tools/ubench/$$f.hip -o tools/ubench/$$f.bin; done
 
 emul:
 	g++ -O2 -std=c++17 -fPIC -shared -o tests/host_emul/libemul.so tests/host_emul/emul.cpp

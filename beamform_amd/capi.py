@@ -29,6 +29,8 @@ EXPORTS = (
     "bf_reset", "bf_time_batch_device", "bf_n_interferers", "bf_set_theta_dir", "bf_set_thetas", "bf_stream_rms", "bf_host_alloc", "bf_host_free",
     "bf_wav_writer_open", "bf_wav_writer_write", "bf_wav_writer_write_pcm16", "bf_wav_writer_close", "bf_float_to_pcm16",
     "bf_float_to_pcm16_device", "bf_wav_read", "bf_planar_f32_read", "bf_wav_free",
+    "bf_resampler_create", "bf_resampler_set_table", "bf_resampler_reset", "bf_resampler_out_count", "bf_resampler_latency",
+    "bf_resampler_process_device", "bf_resampler_process", "bf_resampler_destroy", "bf_resampler_default_table",
 )
 
 
@@ -119,6 +121,17 @@ def load():
     L.bf_planar_f32_read.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t)]
     L.bf_wav_free.argtypes = [C.POINTER(C.c_float)]
     L.bf_wav_free.restype = None
+    L.bf_resampler_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.bf_resampler_set_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.bf_resampler_reset.argtypes = [C.c_void_p]
+    L.bf_resampler_out_count.argtypes = [C.c_void_p, C.c_size_t]
+    L.bf_resampler_out_count.restype = C.c_size_t
+    L.bf_resampler_latency.argtypes = [C.c_void_p]
+    L.bf_resampler_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
+    L.bf_resampler_process.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.bf_resampler_destroy.argtypes = [C.c_void_p]
+    L.bf_resampler_destroy.restype = None
+    L.bf_resampler_default_table.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -197,6 +210,71 @@ def read_planar_f32(path: str, n_channels: int) -> np.ndarray:
     if rc:
         raise BfError(rc, "bf_planar_f32_read", L.bf_strerror(rc).decode())
     return _take_planar(L, p, n_channels, n.value)
+
+
+# ---- rosjack output stage, sample-rate half (rosjack.cpp:159-184, 311-338) ----------------------------------------------------
+class Resampler:
+    """src_new(SRC_SINC_FASTEST, 1) with src_ratio = out_rate / in_rate; process() is src_process with end_of_input = 0."""
+
+    def __init__(self, in_rate: int, out_rate: int):
+        self._L = load()
+        self._r = C.c_void_p()
+        rc = self._L.bf_resampler_create(int(in_rate), int(out_rate), C.byref(self._r))
+        if rc:
+            raise BfError(rc, "bf_resampler_create", self._L.bf_strerror(rc).decode())
+
+    def _check(self, rc, what):
+        if rc:
+            raise BfError(rc, what, self._L.bf_strerror(rc).decode())
+
+    def set_table(self, coeffs: np.ndarray, index_inc: int):
+        a = np.ascontiguousarray(coeffs, np.float32)
+        self._check(self._L.bf_resampler_set_table(self._r, a.ctypes.data, a.size, int(index_inc)), "bf_resampler_set_table")
+
+    def reset(self):
+        self._check(self._L.bf_resampler_reset(self._r), "bf_resampler_reset")
+
+    @property
+    def latency(self) -> int:
+        return self._L.bf_resampler_latency(self._r)
+
+    def out_count(self, n_in: int) -> int:
+        return self._L.bf_resampler_out_count(self._r, n_in)
+
+    def process(self, x: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(x, np.float32)
+        n = C.c_size_t()
+        out = np.empty(self.out_count(a.size), np.float32)
+        self._check(self._L.bf_resampler_process(self._r, a.ctypes.data, a.size, out.ctypes.data, out.size, C.byref(n)),
+                    "bf_resampler_process")
+        return out[:n.value]
+
+    def process_device(self, in_ptr: int, n_in: int, out_ptr: int, out_cap: int, stream: int = 0) -> int:
+        n = C.c_size_t()
+        self._check(self._L.bf_resampler_process_device(self._r, in_ptr, n_in, out_ptr, out_cap, C.byref(n), stream or None),
+                    "bf_resampler_process_device")
+        return n.value
+
+    def close(self):
+        if self._r:
+            self._L.bf_resampler_destroy(self._r)
+            self._r = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def resampler_default_table():
+    """(built-in coefficient table, index_inc)."""
+    L = load()
+    inc = C.c_int()
+    n = L.bf_resampler_default_table(None, 0, C.byref(inc))
+    t = np.empty(n, np.float32)
+    L.bf_resampler_default_table(t.ctypes.data, n, C.byref(inc))
+    return t, inc.value
 
 
 def config_from_params(p: dict, device: int = 0, n_streams: int = 1, layout: int = BF_PLANAR,

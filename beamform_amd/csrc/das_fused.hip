@@ -563,6 +563,184 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
 }
 
 
+
+// ---- interleaved input [sample][mic], 4 or 8 microphones (BF_DAS_VARIANT bit 1) ---------------------------------------------
+// The generic kernel reads one pair (8 bytes) of every 4 M-byte sample per pass: at M = 8 a wave-instruction touches sixteen
+// 128-byte lines and uses a quarter of each, and the four passes of a frame fetch every line four times through the TCP
+// (0.69 ms per 65 536-frame batch against 0.35 planar).  Here one 16-byte load brings the two pairs of a group (microphones
+// 4g .. 4g+3) of a sample: pair 2g lands in (ar, ai), pair 2g+1 waits in (br, bi) and is transformed in place there, so every
+// line is touched twice per frame at M = 8 and once at M = 4.  Register budget: two data sets + the accumulator = 192.
+// Same transform, tables and ring as das_fused_kernel<0, NPL, true, UNR>; NG = number of groups (M / 4).
+template <int NPL, int NG>
+__global__ __launch_bounds__(kBlock, 2) void das_fused_il_kernel(DasFusedArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[kLdsFixed + NPL * 2048 + 17 * kHop + 32];
+    float *s_win = lds + kLdsTw + kHalves * kLdsPlane;
+    float *s_tails = lds + kLdsFixed + NPL * 2048;
+    volatile int *s_flag = reinterpret_cast<volatile int *>(lds + kLdsFixed + NPL * 2048 + 17 * kHop);
+    constexpr int M = 4 * NG, UNR = 2 * NG;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 31;
+    const int hw = tid >> 5;
+    float *wplane = lds + kLdsTw + (hw >> 1) * kWPlane;
+    const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float *)wplane);
+    const float *wrowp = wplane + lane * kWRow + 32 * (hw & 1);
+
+    const int stream = blockIdx.x / a.chunks_per_stream;
+    const long c_in_s = blockIdx.x - (long)stream * a.chunks_per_stream;
+    const int in_stream = stream / a.n_dirs;
+    const f32x2 *gains = a.gains + (long)(stream - in_stream * a.n_dirs) * UNR * 1024;
+    {
+        const f32x2 *twc = a.twiddle;
+        f32x2 *ltw = reinterpret_cast<f32x2 *>(lds);
+        for (int i = tid; i < kLdsTw / 2; i += kBlock) {  // paired tables, as the unrolled planar kernel
+            const int k1 = i >> 5, l = i & 31;
+            ltw[((k1 & 15) * 32 + l) * 2 + (k1 >> 4)] = twc[i];
+        }
+        for (int i = tid; i < kNfft; i += kBlock) s_win[(i & 31) * kPS + (i >> 5)] = a.window[i];
+        f32x2 *lg = reinterpret_cast<f32x2 *>(lds + kLdsFixed);
+        for (int i = tid; i < UNR * 1024; i += kBlock) {
+            const int l = i & 31, pos = (i >> 5) & 31, pr = i >> 10;
+            lg[((pr * 16 + (pos >> 1)) * 32 + l) * 2 + (pos & 1)] = gains[i];
+        }
+    }
+    const long T0 = c_in_s * a.frames_per_chunk;
+    long T1 = T0 + a.frames_per_chunk;
+    if (T1 > a.n_frames) T1 = a.n_frames;
+    if (T0 == 0) {
+        for (int i = tid; i < kHop; i += kBlock) s_tails[i] = a.tail_in[(long)stream * kHop + i];
+    }
+    if (tid < 17) s_flag[tid] = (tid == 0) ? (int)(T0 - 1) : -2;
+    __syncthreads();
+    const float4 *wrow = reinterpret_cast<const float4 *>(s_win + lane * kPS);
+    const float4 *tw2 = reinterpret_cast<const float4 *>(lds);
+
+    const float *xs = a.x + (long)in_stream * a.stream_stride_x;
+    const float *hs = a.hist_in + (long)in_stream * M * kHop;
+    float *ys = a.y + (long)stream * a.n_frames * kHop;
+
+    float ar[32], ai[32], br[32], bi[32], Sr[32], Si[32];
+    const int n_iter = (int)((T1 - T0 + kHalves - 1) / kHalves);
+
+    // the two pairs of group g of frame tc: register position j <-> sample 32 j + lane of the frame
+    auto load_group = [&](long tc, int g) {
+        const float *s1 = (tc >= 1 ? xs + (tc - 1) * (long)kHop * M : hs) + (long)lane * M + 4 * g;
+        const float *s2 = xs + tc * (long)kHop * M + (long)lane * M + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 u = *reinterpret_cast<const float4 *>(s1 + 32 * j * M);
+            const float4 w = *reinterpret_cast<const float4 *>(s2 + 32 * j * M);
+            ar[j] = u.x; ai[j] = u.y; br[j] = u.z; bi[j] = u.w;
+            ar[j + 16] = w.x; ai[j + 16] = w.y; br[j + 16] = w.z; bi[j + 16] = w.w;
+        }
+    };
+    // window -> FFT-1024 -> weight-and-sum of the pair held in (re, im)
+    auto do_pair = [&](float (&re)[32], float (&im)[32], int p) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 hv = wrow[g];
+            re[4 * g + 0] *= hv.x; im[4 * g + 0] *= hv.x;
+            re[4 * g + 1] *= hv.y; im[4 * g + 1] *= hv.y;
+            re[4 * g + 2] *= hv.z; im[4 * g + 2] *= hv.z;
+            re[4 * g + 3] *= hv.w; im[4 * g + 3] *= hv.w;
+        }
+#ifdef BF_DAS_STAMPS
+        unsigned long long st_acc[16], st_prev = 0;
+#endif
+        wt_fft_fwd_p2(re, im, lane, tw2, wbase, wrowp BF_STAMP_ARGS);
+        const float4 *gp2 = reinterpret_cast<const float4 *>(lds + kLdsFixed) + p * 512 + lane;
+#pragma unroll
+        for (int i = 0; i < 32; i += 2) {
+            const float4 g = gp2[16 * i];  // gains of positions i and i + 1
+            Sr[i] = bf_fma(-g.y, im[i], bf_fma(g.x, re[i], (p == 0) ? 0.f : Sr[i]));
+            Si[i] = bf_fma(g.y, re[i], bf_fma(g.x, im[i], (p == 0) ? 0.f : Si[i]));
+            Sr[i + 1] = bf_fma(-g.w, im[i + 1], bf_fma(g.z, re[i + 1], (p == 0) ? 0.f : Sr[i + 1]));
+            Si[i + 1] = bf_fma(g.w, re[i + 1], bf_fma(g.z, im[i + 1], (p == 0) ? 0.f : Si[i + 1]));
+        }
+    };
+
+    {
+        const long t0 = T0 + hw;
+        load_group(t0 < T1 ? t0 : T1 - 1, 0);
+    }
+    for (int it = 0; it < n_iter; ++it) {
+        const long t = T0 + (long)it * kHalves + hw;
+        const bool valid = t < T1;
+        const long tc = valid ? t : T1 - 1;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            // group 1: the same lines group 0 brought in (a 32-byte sample holds both), so these are L1 / L2 hits.  Issuing them
+            // from inside pair 1's weight-and-sum was measured: the 16-byte register tuples fragment the file (153 scratch
+            // operations per iteration), 1.06 ms instead of 0.50.
+            if (g > 0) load_group(tc, g);
+            do_pair(ar, ai, 2 * g);
+            do_pair(br, bi, 2 * g + 1);
+        }
+
+        if (a.sdump != nullptr && valid) {
+            f32x2 *sd = a.sdump + ((long)stream * a.n_frames + t) * kNfft + lane;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) sd[32 * brev5(i)] = f32x2{Sr[i], Si[i]};
+        }
+        // the next frame's first group streams in while the inverse transform runs on (Sr, Si)
+        if (it + 1 < n_iter) {
+            const long tn = T0 + (long)(it + 1) * kHalves + hw;
+            load_group(tn < T1 ? tn : T1 - 1, 0);
+        }
+        {
+#ifdef BF_DAS_STAMPS
+            unsigned long long st_acc[16], st_prev = 0;
+#endif
+            wt_fft_inv_p2(Sr, Si, lane, tw2, wbase, wrowp BF_STAMP_ARGS);
+        }
+
+        float h[32];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 hv = wrow[g];
+            h[4 * g + 0] = hv.x; h[4 * g + 1] = hv.y; h[4 * g + 2] = hv.z; h[4 * g + 3] = hv.w;
+        }
+        const int r = (int)(tc - T0);
+        const int my = (r + 1) % 17, pv = r % 17;
+        if (valid) {
+            float *my_slot = s_tails + my * kHop + lane;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) my_slot[32 * brev5(2 * q)] = Sr[2 * q + 1] * h[brev5(2 * q + 1)];
+            asm volatile("" ::: "memory");
+            if (lane == 0) s_flag[my] = (int)t;
+        }
+        if (valid) {
+            float *yo = ys + t * kHop + lane;
+            if (t == T0 && T0 > 0) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) atomicAdd(yo + 32 * brev5(2 * q), Sr[2 * q] * h[brev5(2 * q)]);
+            } else {
+                while (s_flag[pv] != (int)(t - 1)) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+                const float *prev = s_tails + pv * kHop + lane;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+#pragma clang fp contract(off)
+                    yo[32 * brev5(2 * q)] = prev[32 * brev5(2 * q)] + Sr[2 * q] * h[brev5(2 * q)];
+                }
+            }
+            if (t == T1 - 1) {
+                if (T1 < a.n_frames) {
+                    float *yn = ys + T1 * kHop + lane;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) atomicAdd(yn + 32 * brev5(2 * q), Sr[2 * q + 1] * h[brev5(2 * q + 1)]);
+                } else {
+                    float *to = a.tail_out + (long)stream * kHop + lane;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) to[32 * brev5(2 * q)] = Sr[2 * q + 1] * h[brev5(2 * q + 1)];
+                    float *ho = a.hist_out + (long)in_stream * M * kHop;
+                    for (int j = 0; j < 16 * M; ++j) ho[32 * j + lane] = xs[t * (long)kHop * M + 32 * j + lane];
+                }
+            }
+        }
+    }
+}
+
 __global__ void das_hermitian_dump_kernel(const f32x2 *s, f64x2 *out, long total) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -580,6 +758,13 @@ void launch_layout(const DasFusedArgs &a, unsigned blocks, hipStream_t stream) {
     // planar input with the wave-interleaved transposes: pair loop unrolled for the exact pair count, next pair's loads issued
     // from inside the gain loop (BF_DAS_VARIANT bit 1; same arithmetic, bit-identical output)
     const bool unr = LAYOUT == 0 && WT && (a.variant & 2);
+    if (LAYOUT == 1 && WT && (a.variant & 2) && (a.n_mics == 4 || a.n_mics == 8)) {  // 16-byte loads: two pairs per sample access
+        if (a.n_mics == 4)
+            hipLaunchKernelGGL((das_fused_il_kernel<2, 1>), dim3(blocks), dim3(kBlock), 0, stream, a);
+        else
+            hipLaunchKernelGGL((das_fused_il_kernel<4, 2>), dim3(blocks), dim3(kBlock), 0, stream, a);
+        return;
+    }
 #define BF_DAS_GO(NPL_, UNR_) hipLaunchKernelGGL((das_fused_kernel<LAYOUT, NPL_, WT, UNR_>), dim3(blocks), dim3(kBlock), 0, stream, a)
     if (np <= 1) {
         if (unr) BF_DAS_GO(1, 1); else BF_DAS_GO(1, 0);

@@ -217,8 +217,7 @@ int bf_time_batch_device(bf_handle *h, const float *x_dev, size_t n_frames, floa
  * rosjack.cpp:404-409: sf_write_float(audio_file, write_file_buffer, data_length) once per callback; closed with the node.
  * libsndfile (1.0.28 on the reference's Ubuntu 20.04) is neither vendored in the reference nor installed here; its header
  * layout and its float -> short rule on this call path (lrintf(x * 32767.0f), no clipping: beyond +-1.0 it wraps) are
- * restated in csrc/wavio.cpp.  Host functions: no HIP device needed.  The resampler (rosjack.cpp:311-350) is not built:
- * libsamplerate's SINC_FASTEST coefficient table is not available. */
+ * restated in csrc/wavio.cpp.  Host functions: no HIP device needed. */
 typedef struct bf_wav_writer bf_wav_writer;
 int bf_wav_writer_open(const char *path, int sample_rate, bf_wav_writer **out);        /* sf_open(..., SFM_WRITE, ...) */
 int bf_wav_writer_write(bf_wav_writer *w, const float *samples, size_t n);             /* sf_write_float */
@@ -232,6 +231,29 @@ int bf_float_to_pcm16_device(const float *src_dev, int16_t *dst_dev, size_t n, v
 int bf_wav_read(const char *path, float **planar, int *n_channels, size_t *n_samples, int *sample_rate);
 int bf_planar_f32_read(const char *path, int n_channels, float **planar, size_t *n_samples);
 void bf_wav_free(float *planar);
+
+/* ---- rosjack output stage, sample-rate half ----------------------------------------------------------------------------------
+ * rosjack.cpp:159-184: samplerate_conv = src_new(SRC_SINC_FASTEST, 1, ..), src_ratio = ros_output_sample_rate / rosjack_sample_rate,
+ * refused when src_is_valid_ratio fails; rosjack.cpp:311-338 (convert_to_sample_rate): one src_process per JACK period with
+ * end_of_input = 0, the generated samples queued and emitted one period at a time (:340-349).  bf_resampler_* is that converter
+ * as a stream operator on the GPU: every call takes the next piece of the mono stream and returns the output samples that
+ * have become available (an output exists once bf_resampler_latency input samples beyond its position have been seen; what
+ * libsamplerate holds back in the same way).  Results do not depend on how the stream is cut into calls.
+ * libsamplerate (un-vendored; 0.1.9 on the reference's Ubuntu 20.04) is not in this image: csrc/resample.hip restates
+ * src_sinc.c's mono converter; the built-in coefficient table is a Kaiser-windowed sinc of SINC_FASTEST's geometry, NOT
+ * libsamplerate's fastest_coeffs.h (parity unpinned) -- bf_resampler_set_table installs any table of that form, e.g. the
+ * original one. */
+typedef struct bf_resampler bf_resampler;
+int bf_resampler_create(int in_rate, int out_rate, bf_resampler **out);               /* src_new + src_ratio; BF_EINVAL outside 1/256..256 */
+int bf_resampler_set_table(bf_resampler *r, const float *coeffs, int n_coeffs, int index_inc); /* half table incl. 2 guard entries; resets */
+int bf_resampler_reset(bf_resampler *r);                                              /* src_reset */
+size_t bf_resampler_out_count(bf_resampler *r, size_t n_in);                          /* outputs the next call with n_in samples yields */
+int bf_resampler_latency(bf_resampler *r);                                            /* look-ahead in input samples */
+int bf_resampler_process_device(bf_resampler *r, const float *in_dev, size_t n_in, float *out_dev, size_t out_cap, size_t *n_out,
+                                void *hip_stream);                                    /* src_process on buffers resident in HBM */
+int bf_resampler_process(bf_resampler *r, const float *in, size_t n_in, float *out, size_t out_cap, size_t *n_out); /* host buffers */
+void bf_resampler_destroy(bf_resampler *r);                                           /* src_delete */
+int bf_resampler_default_table(float *dst, int cap, int *index_inc);                  /* copy of the built-in table; returns its length */
 
 #ifdef __cplusplus
 }

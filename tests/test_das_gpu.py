@@ -91,18 +91,20 @@ def test_das_set_theta_takes_effect_next_batch():
     assert np.abs(bf.weights() - node.weights()).max() < 1e-14
 
 
-def test_das_interleaved_layout_and_streams():
+@pytest.mark.parametrize("M,F,S", [(8, 9, 3), (4, 40, 2), (8, 300, 1), (6, 21, 2), (3, 10, 1)])
+def test_das_interleaved_layout_and_streams(M, F, S):
+    """[sample][mic] input: 4 and 8 microphones take the 16-byte-load kernel (two pairs per access), the rest the generic one;
+    F = 300 crosses run boundaries (atomic first hops) and ends inside a 16-frame iteration."""
     import oracle
     from beamform_amd.capi import Beamformer, BF_INTERLEAVED
     _torch()
-    M, F, S = 8, 9, 3
     p = make_params("das", n_mics=M, theta=33.0)
     xs = [make_scene(M, F, seed=20 + s) for s in range(S)]
     refs = [oracle.OracleNode(p).process(x)[0] for x in xs]
     planar = np.stack(xs)                          # [S, M, T]
-    y = Beamformer(p, n_streams=S).process(planar)
+    y = np.atleast_2d(Beamformer(p, n_streams=S).process(planar))
     inter = np.ascontiguousarray(planar.transpose(0, 2, 1))  # [S, T, M]
-    yi = Beamformer(p, n_streams=S, layout=BF_INTERLEAVED).process(inter)
+    yi = np.atleast_2d(Beamformer(p, n_streams=S, layout=BF_INTERLEAVED).process(inter))
     for s in range(S):
         assert rel_l2(y[s], refs[s]) < TOL_TIME
         assert rel_l2(yi[s], refs[s]) < TOL_TIME

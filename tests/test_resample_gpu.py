@@ -1,0 +1,106 @@
+"""bf_resampler_* (csrc/resample.hip) against the oracle's restatement of libsamplerate's mono sinc converter."""
+import numpy as np
+import pytest
+
+from beamform_amd import capi
+from oracle.resample_oracle import SincResampler, resample_vectorised
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _torch_first():
+    """torch brings its own HIP runtime: it has to initialise before libbfcore's first HIP call in this process."""
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize("rates", [(48000, 16000), (48000, 44100), (44100, 48000), (16000, 48000), (48000, 48000), (48000, 8000), (48000, 22050)])
+def test_matches_oracle_period_by_period(rates):
+    rng = np.random.default_rng(11)
+    x = (0.2 * rng.standard_normal(9 * 512 + 131)).astype(np.float32)
+    o = SincResampler(*rates)
+    g = capi.Resampler(*rates)
+    assert g.latency == o.half_len
+    yo, yg = [], []
+    for i in range(0, len(x), 512):                       # one call per JACK period, as convert_to_sample_rate
+        yo.append(o.process(x[i:i + 512]))
+        yg.append(g.process(x[i:i + 512]))
+        assert len(yo[-1]) == len(yg[-1])
+    yo, yg = np.concatenate(yo), np.concatenate(yg)
+    assert len(yo) > 700
+    # tolerance: 1e-6 of the signal scale (fp64 accumulation on both sides; the oracle's accumulated position drifts by ~1e-16/step)
+    assert np.max(np.abs(yo - yg)) <= 1e-6 * np.max(np.abs(yo))
+
+
+def test_cut_invariance_is_bit_exact():
+    rng = np.random.default_rng(12)
+    x = (0.3 * rng.standard_normal(20000)).astype(np.float32)
+    whole = capi.Resampler(48000, 16000).process(x)
+    for step in (1, 37, 512, 4096):
+        g = capi.Resampler(48000, 16000)
+        parts = [g.process(x[i:i + step]) for i in range(0, len(x), step)] if step > 1 else \
+            [g.process(x[:5]), g.process(x[5:6]), g.process(x[6:6]), g.process(x[6:])]
+        y = np.concatenate(parts)
+        assert np.array_equal(y, whole)
+    assert np.array_equal(whole, resample_vectorised(x, 48000, 16000)) or \
+        np.max(np.abs(whole - resample_vectorised(x, 48000, 16000))) <= 1e-6 * np.max(np.abs(whole))
+
+
+def test_reset_and_custom_table():
+    rng = np.random.default_rng(13)
+    x = (0.2 * rng.standard_normal(3000)).astype(np.float32)
+    g = capi.Resampler(48000, 32000)
+    a = g.process(x)
+    g.reset()
+    assert np.array_equal(g.process(x), a)
+    # any half table of the same form: here a short triangular (linear-interpolation) kernel with 8 entries per zero crossing
+    inc = 8
+    tri = np.concatenate([1.0 - np.arange(inc) / inc, np.zeros(3)]).astype(np.float32)
+    g.set_table(tri, inc)
+    y = g.process(x)
+    ref = resample_vectorised(x, 48000, 32000, coeffs=tri, index_inc=inc)
+    assert len(y) == len(ref) and np.max(np.abs(y - ref)) <= 1e-6
+    o = SincResampler(48000, 32000, coeffs=tri, index_inc=inc)
+    assert np.max(np.abs(o.process(x) - y)) <= 1e-6
+
+
+def test_errors():
+    with pytest.raises(capi.BfError):
+        capi.Resampler(48000, 100)                         # ratio below 1/256: src_is_valid_ratio fails (rosjack.cpp:170-172)
+    with pytest.raises(capi.BfError):
+        capi.Resampler(0, 16000)
+    g = capi.Resampler(48000, 16000)
+    import ctypes as C
+    L = capi.load()
+    x = np.zeros(4096, np.float32)
+    out = np.zeros(8, np.float32)
+    n = C.c_size_t()
+    rc = L.bf_resampler_process(g._r, x.ctypes.data, x.size, out.ctypes.data, out.size, C.byref(n))
+    assert rc == -22 and n.value == g.out_count(4096) > 8   # too little room: nothing consumed, the needed count reported
+    assert len(g.process(x)) == n.value
+
+
+def test_device_buffers_full_batch_properties():
+    torch = pytest.importorskip("torch")
+    F = 4096                                                # output hops of a 4096-frame batch
+    n = np.arange(F * 512)
+    x = (0.5 * np.sin(2 * np.pi * 997.0 * n / 48000) + 0.25 * np.sin(2 * np.pi * 3001.0 * n / 48000)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    g = capi.Resampler(48000, 16000)
+    cap = g.out_count(x.size)
+    yd = torch.empty(cap, device="cuda")
+    got = g.process_device(xd.data_ptr(), x.size, yd.data_ptr(), cap, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert got == cap == (x.size - g.latency) * 16000 // 48000 + (1 if ((x.size - g.latency) * 16000) % 48000 else 0)
+    y = yd.cpu().numpy()
+    m = np.arange(cap)
+    ref = 0.5 * np.sin(2 * np.pi * 997.0 * m / 16000) + 0.25 * np.sin(2 * np.pi * 3001.0 * m / 16000)
+    err = (y - ref)[500:-500]
+    assert np.sqrt(np.mean(err ** 2)) < 1e-4               # both tones are in the pass band: the output is the same signal at 16 kHz
+    # linearity: resample(a + b) = resample(a) + resample(b) to fp32 rounding
+    a = (0.5 * np.sin(2 * np.pi * 997.0 * n / 48000)).astype(np.float32)
+    b = x - a
+    ya = capi.Resampler(48000, 16000).process(a)
+    yb = capi.Resampler(48000, 16000).process(b)
+    assert np.max(np.abs((ya + yb) - y)) < 2e-6

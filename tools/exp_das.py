@@ -6,14 +6,15 @@ child = r'''
 import os, sys, time, hashlib
 sys.path.insert(0, %r)
 import torch
-from beamform_amd.capi import Beamformer
+from beamform_amd.capi import Beamformer, BF_INTERLEAVED, BF_PLANAR
 from beamform_amd.params import make_params
 M, F = int(sys.argv[1]), 65536
 p = make_params("das", n_mics=M, theta=20.0)
 g = torch.Generator(device="cuda").manual_seed(7)
 x = torch.rand((M, F * 512), device="cuda", generator=g) - 0.5
 y = torch.empty(F * 512, device="cuda")
-bf = Beamformer(p)
+IL = os.environ.get("EXP_LAYOUT", "planar") == "interleaved"   # same random numbers, read as [sample][mic]
+bf = Beamformer(p, layout=BF_INTERLEAVED if IL else BF_PLANAR)
 s = torch.cuda.current_stream().cuda_stream
 t0 = time.perf_counter()
 while time.perf_counter() - t0 < 0.3:
