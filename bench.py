@@ -341,9 +341,9 @@ def main():
     torch.cuda.synchronize(dev)
 
     # ---- secondary lines: the other BASELINE configs, rank 0 at N = 1 -------------------------------------------
-    def node_line(algo, M_, F_, S_, interf_=(), das_impl_=BF_DAS_FUSED_F32, iters=5, xin=None, note=""):
+    def node_line(algo, M_, F_, S_, interf_=(), das_impl_=BF_DAS_FUSED_F32, iters=5, xin=None, note="", layout_=BF_PLANAR):
         pm = make_params(algo, n_mics=M_, interf=interf_)
-        bm = Beamformer(pm, device=local_rank, n_streams=S_, das_impl=das_impl_)
+        bm = Beamformer(pm, device=local_rank, n_streams=S_, das_impl=das_impl_, layout=layout_)
         if xin is None:
             gg = torch.Generator(device=dev).manual_seed(4321)
             xin = torch.rand((S_, M_, F_ * HOP), device=dev, generator=gg, dtype=torch.float32) - 0.5
@@ -364,6 +364,8 @@ def main():
             fl = model_flops_per_frame(algo, M_, len(interf_), pm["past_windows"])
             line["model_flops_per_frame"] = fl
             line["frac_of_fp64_vector_peak"] = fl * fr / (ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TF
+        if layout_ != BF_PLANAR:
+            return line
         tag = {"das": "das8_f64", "mvdr": "mvdr8", "phasempf": "phasempf8", "phase": "phase8", "lcmv": "lcmv16"}.get(algo)
         tr = load_traffic(tag) if tag else None
         if tr is not None:
@@ -380,11 +382,40 @@ def main():
             ("mvdr", lambda: node_line("mvdr", M, F, 1, xin=x, note="BASELINE config 3; fp64 bin pipeline; " + noise)),
             ("das_f64", lambda: node_line("das", M, F, 1, das_impl_=BF_DAS_BINS_F64, xin=x,
                                           note="same precision as the reference (double spectra): the fp64 bin pipeline")),
+            ("das_interleaved", lambda: node_line("das", M, F, 1, xin=x.reshape(1, F * HOP, M), layout_=BF_INTERLEAVED, iters=20,
+                                                  note="the headline workload with [sample][mic] input (same bytes read as interleaved samples)")),
             ("phasempf", lambda: node_line("phasempf", 8, 256, 256, note="BASELINE config 4: 256 streams x 256 frames, recursion per stream")),
             ("phase", lambda: node_line("phase", M, F, 1, xin=x)),
             ("lcmv16", lambda: node_line("lcmv", 16, 32768, 1, (-60.0, 90.0, 150.0), iters=3,
                                          note="BASELINE config 5, one GPU's shard of the 262144-frame stream; " + noise)),
         ]
+        def resample_line():
+            # the output stage's sample-rate converter on the batch the headline step just produced (rosjack.cpp:311-338)
+            from beamform_amd.capi import Resampler
+            rs = Resampler(48000, 16000)
+            n_in = F * HOP
+            cap = rs.out_count(n_in)
+            yo = torch.empty(cap, device=dev, dtype=torch.float32)
+            ysrc = y.reshape(-1)[:n_in]
+            for _ in range(2):
+                rs.reset()
+                rs.process_device(ysrc.data_ptr(), n_in, yo.data_ptr(), cap, sptr)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(dev))
+            for _ in range(5):
+                rs.reset()
+                rs.process_device(ysrc.data_ptr(), n_in, yo.data_ptr(), cap, sptr)
+            e1.record(torch.cuda.current_stream(dev))
+            torch.cuda.synchronize(dev)
+            ms = e0.elapsed_time(e1) / 5
+            rs.close()
+            return {"workload": f"sinc sample-rate converter 48 kHz -> 16 kHz of one {F}-hop output batch ({2 * rs_lat(48000, 16000)} fp64 taps per output sample)",
+                    "ms_per_step": ms, "hops_per_s": F / (ms * 1e-3), "GBps_in_plus_out": (n_in + cap) * 4 / (ms * 1e-3) / 1e9}
+
+        def rs_lat(a_, b_):
+            return int(round(2464 / 128 * max(1.0, a_ / b_))) + 1
+
+        jobs.append(("resample_48k_16k", resample_line))
         for name, job in jobs:
             try:
                 extra[name] = job()
