@@ -21,8 +21,10 @@
 // libsamplerate accumulates 1 / ratio in a double (its drift is ~1e-16 per sample); results do not depend on how the stream is
 // cut into calls.
 //
-// Kernel: one output sample per thread, the table in LDS, taps read through L1/L2 (neighbouring outputs share all but one or
-// two taps).  Streaming bound: 4 B in / ratio + 4 B out per output sample; fp64 FMA work 2 * half_taps per output.
+// Kernels: one output sample per thread, taps read through L1/L2 (neighbouring outputs share all but one or two taps).  When
+// the rates give few distinct fractional positions (48000 -> 16000: 1, 48000 -> 44100: 147) the interpolated coefficients are
+// tabulated per position once (polyphase form, tables in LDS, one FMA per tap); otherwise the table is interpolated per tap.
+// Streaming bound: 4 B in / ratio + 4 B out per output sample; fp64 FMA work 2 * half_taps per output.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -119,6 +121,88 @@ __global__ void hist_roll_kernel(const float *hist, const float *in, long hist_l
     hist_new[i] = r >= 0 ? in[r] : hist[hist_len + r];
 }
 
+// ---- polyphase form ---------------------------------------------------------------------------------------------------------------
+// With integer rates the fractional position of output K takes only L = out_rate / gcd values, so the interpolated coefficients
+// of every tap can be tabulated once per converter: row m holds, in libsamplerate's order of evaluation, the left wing (far tap
+// first, ending at the tap on `cur`) and then the right wing (far tap first, ending at `cur + 1`).  The per-output loop is then
+// one LDS read, one sample and one FMA per tap instead of two table reads, two conversions and the interpolation.
+struct PolyArgs {
+    double *poly;     // [L][row] doubles: left wing at 0, right wing at `right_off`
+    int2 *count;      // [L] taps per wing
+    int L, row, right_off;
+    long in_rate, out_rate, g;
+    int coeff_half_len, index_inc;
+    const float *table;
+};
+
+__global__ void poly_build_kernel(PolyArgs a) {
+    const int m = blockIdx.x;
+    const double ratio = (double)a.out_rate / (double)a.in_rate;
+    const double float_increment = (double)a.index_inc * (ratio < 1.0 ? ratio : 1.0);
+    const int increment = (int)llrint(float_increment * (double)(1 << kShift));
+    const int max_filter_index = a.coeff_half_len << kShift;
+    const double inv_fp = 1.0 / (double)(1 << kShift);
+    const double frac = (double)((long)m * a.g) / (double)a.out_rate;
+    const int start = (int)llrint(frac * float_increment * (double)(1 << kShift));
+    const int ccl = (max_filter_index - start) / increment;
+    const int fr0 = increment - start;
+    const int ccr = (max_filter_index - fr0) / increment;
+    if (threadIdx.x == 0) a.count[m] = int2{ccl + 1, ccr + 1};
+    for (int e = threadIdx.x; e <= ccl; e += blockDim.x) {
+        const int fi = start + (ccl - e) * increment;
+        const double fr = (double)(fi & ((1 << kShift) - 1)) * inv_fp;
+        const int ix = fi >> kShift;
+        const double c0 = (double)a.table[ix], c1 = (double)a.table[ix + 1];
+        a.poly[(long)m * a.row + e] = c0 + fr * (c1 - c0);
+    }
+    for (int e = threadIdx.x; e <= ccr; e += blockDim.x) {
+        const int fi = fr0 + (ccr - e) * increment;
+        const double fr = (double)(fi & ((1 << kShift) - 1)) * inv_fp;
+        const int ix = fi >> kShift;
+        const double c0 = (double)a.table[ix], c1 = (double)a.table[ix + 1];
+        a.poly[(long)m * a.row + a.right_off + e] = c0 + fr * (c1 - c0);
+    }
+}
+
+constexpr int kPolyLdsDoubles = 7936;  // 62 KiB of coefficients per block
+
+__global__ __launch_bounds__(256) void sinc_poly_kernel(ResampleArgs a, PolyArgs q) {
+    __shared__ double s_poly[kPolyLdsDoubles];
+    __shared__ int2 s_cnt[512];
+    for (int i = threadIdx.x; i < q.L * q.row; i += 256) s_poly[i] = q.poly[i];
+    for (int i = threadIdx.x; i < q.L; i += 256) s_cnt[i] = q.count[i];
+    __syncthreads();
+    const double ratio = (double)a.out_rate / (double)a.in_rate;
+    const double scale = ((double)a.index_inc * (ratio < 1.0 ? ratio : 1.0)) / (double)a.index_inc;
+    for (long k0 = (long)blockIdx.x * 256; k0 < a.n_out; k0 += (long)gridDim.x * 256) {
+        const long k = k0 + threadIdx.x;
+        const bool live = k < a.n_out;
+        const long K = a.first_out + (live ? k : a.n_out - 1);
+        const unsigned long long num = (unsigned long long)K * (unsigned long long)a.in_rate;
+        const long cur = (long)(num / (unsigned long long)a.out_rate);
+        const int m = (int)((num % (unsigned long long)a.out_rate) / (unsigned long long)q.g);
+        const int2 cnt = s_cnt[m];
+        const double *rowp = s_poly + m * q.row;
+        // does every tap of this block's outputs lie inside the new input?  (block-uniform: first and last output of the block)
+        const long Kf = a.first_out + k0, Kl = a.first_out + (k0 + 255 < a.n_out ? k0 + 255 : a.n_out - 1);
+        const long lo = (long)((unsigned long long)Kf * (unsigned long long)a.in_rate / (unsigned long long)a.out_rate) - q.right_off - a.in_base;
+        const long hi = (long)((unsigned long long)Kl * (unsigned long long)a.in_rate / (unsigned long long)a.out_rate) + (q.row - q.right_off) + 1 - a.in_base;
+        double left = 0.0, right = 0.0;
+        if (lo >= 0 && hi < a.n_in) {
+            const float *xl = a.in + (cur - a.in_base) - (cnt.x - 1);
+            for (int e = 0; e < cnt.x; ++e) left += rowp[e] * (double)xl[e];
+            const float *xr = a.in + (cur - a.in_base) + cnt.y;
+            const double *rr = rowp + q.right_off;
+            for (int e = 0; e < cnt.y; ++e) right += rr[e] * (double)xr[-e];
+        } else {
+            for (int e = 0; e < cnt.x; ++e) left += rowp[e] * tap(a, cur - (cnt.x - 1) + e);
+            const double *rr = rowp + q.right_off;
+            for (int e = 0; e < cnt.y; ++e) right += rr[e] * tap(a, cur + cnt.y - e);
+        }
+        if (live) a.out[k] = (float)(scale * (left + right));
+    }
+}
+
 double bessel_i0(double x) {
     double sum = 1.0, term = 1.0;
     for (int k = 1; k < 200; ++k) {
@@ -157,6 +241,11 @@ struct bf_resampler {
     long hist_len = 0;
     long consumed = 0;   // input samples taken so far
     long generated = 0;  // output samples produced so far
+    // polyphase tables (built when the rates give few enough phases to fit the LDS; otherwise the generic kernel runs)
+    double *d_poly = nullptr;
+    int2 *d_count = nullptr;
+    int poly_L = 0, poly_row = 0, poly_right_off = 0;
+    long poly_g = 1;
     float *d_in = nullptr, *d_out = nullptr;  // staging for the host entry point
     size_t cap_in = 0, cap_out = 0;
 
@@ -175,6 +264,64 @@ struct bf_resampler {
         return (long)(((unsigned long long)lim * (unsigned long long)out_rate - 1ull) / (unsigned long long)in_rate) + 1;
     }
 };
+
+static long gcd_l(long a, long b) {
+    while (b) {
+        const long t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+// Polyphase tables for the current rates and coefficient table (none when they would not fit the LDS).
+static int build_poly(bf_resampler *r) {
+    if (r->d_poly) (void)hipFree(r->d_poly);
+    if (r->d_count) (void)hipFree(r->d_count);
+    r->d_poly = nullptr;
+    r->d_count = nullptr;
+    r->poly_L = 0;
+    const long g = gcd_l(r->in_rate, r->out_rate);
+    const long L = r->out_rate / g;
+    if (L > 512) return BF_OK;
+    const double ratio = r->ratio();
+    const double float_increment = (double)r->index_inc * (ratio < 1.0 ? ratio : 1.0);
+    const int increment = (int)llrint(float_increment * (double)(1 << kShift));
+    const int max_filter_index = (r->table_len - 2) << kShift;
+    int max_l = 0, max_r = 0;
+    for (long m = 0; m < L; ++m) {  // the tap counts of poly_build_kernel
+        const double frac = (double)(m * g) / (double)r->out_rate;
+        const int start = (int)llrint(frac * float_increment * (double)(1 << kShift));
+        const int nl = (max_filter_index - start) / increment + 1;
+        const int nr = (max_filter_index - (increment - start)) / increment + 1;
+        max_l = nl > max_l ? nl : max_l;
+        max_r = nr > max_r ? nr : max_r;
+    }
+    const int row = max_l + max_r;
+    if (L * row > kPolyLdsDoubles) return BF_OK;
+    if (hipMalloc(&r->d_poly, sizeof(double) * (size_t)(L * row)) != hipSuccess) return BF_ENOMEM;
+    if (hipMalloc(&r->d_count, sizeof(int2) * (size_t)L) != hipSuccess) return BF_ENOMEM;
+    if (hipMemset(r->d_poly, 0, sizeof(double) * (size_t)(L * row)) != hipSuccess) return BF_EIO;
+    PolyArgs q;
+    q.poly = r->d_poly;
+    q.count = r->d_count;
+    q.L = (int)L;
+    q.row = row;
+    q.right_off = max_l;
+    q.in_rate = r->in_rate;
+    q.out_rate = r->out_rate;
+    q.g = g;
+    q.coeff_half_len = r->table_len - 2;
+    q.index_inc = r->index_inc;
+    q.table = r->d_table;
+    hipLaunchKernelGGL(poly_build_kernel, dim3((unsigned)L), dim3(64), 0, nullptr, q);
+    if (hipDeviceSynchronize() != hipSuccess) return BF_EIO;
+    r->poly_L = (int)L;
+    r->poly_row = row;
+    r->poly_right_off = max_l;
+    r->poly_g = g;
+    return BF_OK;
+}
 
 static int upload_table(bf_resampler *r, const float *coeffs, int len, int inc) {
     if (len < 4 || len > kMaxTable || inc < 1) return BF_EINVAL;
@@ -202,7 +349,7 @@ static int upload_table(bf_resampler *r, const float *coeffs, int len, int inc) 
         if (hipMemset(r->d_hist[b], 0, sizeof(float) * (size_t)r->hist_len) != hipSuccess) return BF_EIO;
     r->hist_cur = 0;
     r->consumed = r->generated = 0;
-    return BF_OK;
+    return build_poly(r);
 }
 
 extern "C" int bf_resampler_create(int in_rate, int out_rate, bf_resampler **out) {
@@ -271,8 +418,25 @@ static int process_locked(bf_resampler *r, const float *d_in, size_t n_in, float
         a.table_len = r->table_len;
         a.table = r->d_table;
         long blocks = (want + 255) / 256;
-        if (blocks > 256 * 32) blocks = 256 * 32;
-        hipLaunchKernelGGL(sinc_resample_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        if (r->poly_L > 0) {
+            PolyArgs q;
+            q.poly = r->d_poly;
+            q.count = r->d_count;
+            q.L = r->poly_L;
+            q.row = r->poly_row;
+            q.right_off = r->poly_right_off;
+            q.in_rate = r->in_rate;
+            q.out_rate = r->out_rate;
+            q.g = r->poly_g;
+            q.coeff_half_len = r->table_len - 2;
+            q.index_inc = r->index_inc;
+            q.table = r->d_table;
+            if (blocks > 256 * 8) blocks = 256 * 8;  // every block copies the tables into its LDS first
+            hipLaunchKernelGGL(sinc_poly_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, q);
+        } else {
+            if (blocks > 256 * 32) blocks = 256 * 32;
+            hipLaunchKernelGGL(sinc_resample_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        }
     }
     if (n_in > 0) {
         hipLaunchKernelGGL(hist_roll_kernel, dim3((unsigned)((r->hist_len + 255) / 256)), dim3(256), 0, s, r->d_hist[r->hist_cur], d_in,
@@ -326,6 +490,8 @@ extern "C" void bf_resampler_destroy(bf_resampler *r) {
         if (r->d_hist[b]) (void)hipFree(r->d_hist[b]);
     if (r->d_in) (void)hipFree(r->d_in);
     if (r->d_out) (void)hipFree(r->d_out);
+    if (r->d_poly) (void)hipFree(r->d_poly);
+    if (r->d_count) (void)hipFree(r->d_count);
     delete r;
 }
 

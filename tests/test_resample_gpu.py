@@ -104,3 +104,24 @@ def test_device_buffers_full_batch_properties():
     ya = capi.Resampler(48000, 16000).process(a)
     yb = capi.Resampler(48000, 16000).process(b)
     assert np.max(np.abs((ya + yb) - y)) < 2e-6
+
+
+def test_polyphase_and_generic_paths_agree():
+    """48000 -> 16000 / 44100 run the tabulated (polyphase) kernel, 48000 -> 44101 has 44101 distinct positions and runs the
+    generic one: both against the oracle."""
+    rng = np.random.default_rng(21)
+    x = (0.2 * rng.standard_normal(30000)).astype(np.float32)
+    for rates in [(48000, 44101), (44100, 48000), (48000, 47999)]:
+        y = capi.Resampler(*rates).process(x)
+        ref = resample_vectorised(x, *rates)
+        assert len(y) == len(ref) and np.max(np.abs(y - ref)) <= 1e-6 * np.max(np.abs(ref))
+    # a finer table (3 x the entries per zero crossing) through both kernels
+    from oracle.resample_oracle import default_table
+    t = default_table()
+    fine = np.interp(np.arange(3 * (len(t) - 1) + 1) / 3.0, np.arange(len(t)), t).astype(np.float32)
+    for rates in [(48000, 44100), (48000, 44101)]:
+        g = capi.Resampler(*rates)
+        g.set_table(fine, 128 * 3)
+        y = g.process(x)
+        ref = resample_vectorised(x, *rates, coeffs=fine, index_inc=384)
+        assert len(y) == len(ref) and np.max(np.abs(y - ref)) <= 1e-6 * np.max(np.abs(ref))
