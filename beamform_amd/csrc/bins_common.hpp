@@ -48,6 +48,23 @@ __device__ __forceinline__ cd cdiv(cd a, cd b) {
     const double r = b.x / b.y, d = b.x * r + b.y;
     return cd{(a.x * r + a.y) / d, (a.y * r - a.x) / d};
 }
+// 1/sqrt(x), sqrt(x) and 1/x for x well inside the double range (sums of squared spectra of [-1,1] audio): the hardware estimate
+// (v_rsq_f64 / v_rcp_f64, ~2^-26 relative) and two Newton steps, without the subnormal rescaling and class tests of the library
+// versions (x = 0 gives inf / NaN like they do: a zero covariance still yields the reference's NaN frame).  Relative error < 1e-15.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    return y;
+}
+__device__ __forceinline__ double fast_sqrt(double x) { return x == 0.0 ? 0.0 : x * fast_rsqrt(x); }
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(y, fma(-x, y, 1.0), y);
+    y = fma(y, fma(-x, y, 1.0), y);
+    return y;
+}
 // acc - a * conj(b) and acc + a * conj(b), four FMAs each
 __device__ __forceinline__ cd cfms_conj(cd acc, cd a, cd b) {
     return cd{fma(-a.y, b.y, fma(-a.x, b.x, acc.x)), fma(a.x, b.y, fma(-a.y, b.x, acc.y))};

@@ -110,9 +110,12 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
     };
 #define BF_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-    cd R[NT];  // lower triangle, row-major: R[i*(i+1)/2 + c], c <= i
+    cd R[NT];       // strict lower triangle, row-major: R[i*(i+1)/2 + c], c < i (the diagonal slots are unused)
+    double Rd[MP];  // the diagonal is real: kept and updated as such (two FMAs per rank-1 term instead of four)
 #pragma unroll
     for (int e = 0; e < NT; ++e) R[e] = cd{0, 0};
+#pragma unroll
+    for (int i = 0; i < MP; ++i) Rd[i] = 0.0;
     int pb = 0;  // buffer the next consumer reads
     dma_frame(tA - 1, false, pb);
     for (int p = 1; p <= P; ++p) {  // covariance of the P frames in front of the tile
@@ -125,9 +128,11 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
         cd X[MP];
         unpack(pb, 0, X);
 #pragma unroll
-        for (int i = 0; i < MP; ++i)
+        for (int i = 0; i < MP; ++i) {
 #pragma unroll
-            for (int c = 0; c <= i; ++c) R[i * (i + 1) / 2 + c] = cfma_conj(R[i * (i + 1) / 2 + c], X[i], X[c]);
+            for (int c = 0; c < i; ++c) R[i * (i + 1) / 2 + c] = cfma_conj(R[i * (i + 1) / 2 + c], X[i], X[c]);
+            Rd[i] = fma(X[i].y, X[i].y, fma(X[i].x, X[i].x, Rd[i]));
+        }
         pb ^= 1;
     }
     for (long t = tA; t < tB; ++t) {
@@ -139,23 +144,20 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
         double mag = 0.0;
 #pragma unroll
         for (int m = 0; m < MP; ++m)
-            if (m < M) mag += sqrt(norm2(X[m]));  // |X| well inside double range: no hypot scaling needed
+            if (m < M) mag += fast_sqrt(norm2(X[m]));  // |X| well inside double range: no hypot scaling needed
         mag /= (double)((unsigned)M * (unsigned)kN);
         cd A[NT], ua[MP], ux[MP];
 #pragma unroll
         for (int i = 0; i < MP; ++i) {
 #pragma unroll
-            for (int c = 0; c <= i; ++c) {
-                cd v = R[i * (i + 1) / 2 + c];
-                if (c == i) v = (i < M) ? v * 1.001 : cd{1.0, 0.0};  // whiteR diagonal (mvdr.cpp:239-243); padding = identity
-                A[i * (i + 1) / 2 + c] = v;
-            }
+            for (int c = 0; c < i; ++c) A[i * (i + 1) / 2 + c] = R[i * (i + 1) / 2 + c];
+            A[i * (i + 1) / 2 + i] = cd{(i < M) ? Rd[i] * 1.001 : 1.0, 0.0};  // whiteR diagonal (mvdr.cpp:239-243); padding = identity
             ua[i] = st[i];
             ux[i] = X[i];
         }
 #pragma unroll
         for (int jj = 0; jj < MP; ++jj) {
-            const double inv = rsqrt(A[jj * (jj + 1) / 2 + jj].x);  // 1/L_jj; L_jj itself is never needed
+            const double inv = fast_rsqrt(A[jj * (jj + 1) / 2 + jj].x);  // 1/L_jj; L_jj itself is never needed
             ua[jj] = ua[jj] * inv;
             ux[jj] = ux[jj] * inv;
 #pragma unroll
@@ -169,8 +171,12 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
             for (int c = jj + 1; c < MP; ++c) {
                 const cd Lc = A[c * (c + 1) / 2 + jj];
 #pragma unroll
-                for (int i = c; i < MP; ++i)
-                    A[i * (i + 1) / 2 + c] = cfms_conj(A[i * (i + 1) / 2 + c], A[i * (i + 1) / 2 + jj], Lc);
+                for (int i = c; i < MP; ++i) {
+                    if (i == c)  // diagonal: only the real part is ever read
+                        A[i * (i + 1) / 2 + c].x = fma(-Lc.y, Lc.y, fma(-Lc.x, Lc.x, A[i * (i + 1) / 2 + c].x));
+                    else
+                        A[i * (i + 1) / 2 + c] = cfms_conj(A[i * (i + 1) / 2 + c], A[i * (i + 1) / 2 + jj], Lc);
+                }
             }
         }
         cd num{0, 0};
@@ -180,7 +186,8 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
             num = cfma_conj(num, ux[i], ua[i]);
             den += norm2(ua[i]);
         }
-        cd y = cd{num.x / den, num.y / den};
+        const double rden = fast_rcp(den);
+        cd y = cd{num.x * rden, num.y * rden};
         if (!(mag > a.cfg.freq_mag_threshold)) y = X[0] * 0.01;  // mvdr.cpp:96
         if (!inband) y = cd{0, 0};
         if (j == 0) y = X[0];
@@ -189,10 +196,12 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
         cd Xo[MP];
         unpack(pb, MP, Xo);
 #pragma unroll
-        for (int i = 0; i < MP; ++i)
+        for (int i = 0; i < MP; ++i) {
 #pragma unroll
-            for (int c = 0; c <= i; ++c)
+            for (int c = 0; c < i; ++c)
                 R[i * (i + 1) / 2 + c] = cfms_conj(cfma_conj(R[i * (i + 1) / 2 + c], X[i], X[c]), Xo[i], Xo[c]);
+            Rd[i] = fma(-Xo[i].y, Xo[i].y, fma(-Xo[i].x, Xo[i].x, fma(X[i].y, X[i].y, fma(X[i].x, X[i].x, Rd[i]))));
+        }
         pb ^= 1;
     }
 #undef BF_DMA_WAIT
@@ -292,7 +301,7 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
         s_xo[grp][i] = xo;
         __builtin_amdgcn_wave_barrier();
         double mag = 0.0;
-        for (int m = 0; m < M; ++m) mag += sqrt(norm2(s_x[grp][m]));
+        for (int m = 0; m < M; ++m) mag += fast_sqrt(norm2(s_x[grp][m]));
         mag /= (double)((unsigned)M * (unsigned)kN);
         cd y;
         if (mag > a.cfg.freq_mag_threshold) {
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
                     for (int r = 0; r < NB; ++r) s_u[grp][r][0] = b[r];
                 }
                 __builtin_amdgcn_wave_barrier();
-                const double inv = rsqrt(s_col[grp][jj].x);  // 1 / L_jj
+                const double inv = fast_rsqrt(s_col[grp][jj].x);  // 1 / L_jj
                 const cd Lij = A[jj] * inv;
                 if (i > jj) {
 #pragma unroll
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(64, 1) void mvdr_lcmv_lanes_kernel(BinsArgs a, int 
         }
         double mag = 0.0;
 #pragma unroll
-        for (int r = 0; r < RPL; ++r) mag += sqrt(norm2(xl[r]));  // padded rows are 0
+        for (int r = 0; r < RPL; ++r) mag += fast_sqrt(norm2(xl[r]));  // padded rows are 0
         mag = grp_sum<L>(mag) / (double)((unsigned)M * (unsigned)kN);
         const cd x0 = bcast_from<L>(0, xl[0]);
         cd y;
@@ -579,7 +588,7 @@ __global__ __launch_bounds__(64, 1) void mvdr_lcmv_lanes_kernel(BinsArgs a, int 
 #pragma unroll
             for (int jj = 0; jj < MP; ++jj) {
                 const int ro = jj / L, qo = jj % L;  // owner slot / lane of row jj
-                const double inv = rsqrt(bcast_from<L>(qo, A[TIX(ro, jj)].x));
+                const double inv = fast_rsqrt(bcast_from<L>(qo, A[TIX(ro, jj)].x));
                 cd Lc[RPL];  // scaled column jj of the local rows (meaningful where row > jj)
 #pragma unroll
                 for (int r = ro; r < RPL; ++r) Lc[r] = A[TIX(r, jj)] * inv;
@@ -783,7 +792,7 @@ __global__ __launch_bounds__(256, 2) void mvdr_lcmv_row_kernel(BinsArgs a, int t
     }
     for (long t = tA; t < tB; ++t) {
         const cd x = load_xi(t);
-        const double mag = row_sum(sqrt(norm2(x))) / (double)((unsigned)M * (unsigned)kN);
+        const double mag = row_sum(fast_sqrt(norm2(x))) / (double)((unsigned)M * (unsigned)kN);
         cd y;
         if (mag > a.cfg.freq_mag_threshold) {  // uniform per row
             cd A[MP], b[NB];
@@ -802,7 +811,7 @@ __global__ __launch_bounds__(256, 2) void mvdr_lcmv_row_kernel(BinsArgs a, int t
             b[KM] = x;
             RowStep<0, MP>::run([&](auto jc) {
                 constexpr int jj = decltype(jc)::value;
-                const double inv = rsqrt(rowbc<jj>(A[jj].x));  // 1 / L_jj from the owner's diagonal
+                const double inv = fast_rsqrt(rowbc<jj>(A[jj].x));  // 1 / L_jj from the owner's diagonal
                 const cd Lij = A[jj] * inv;                   // my row's entry of the scaled column (valid for i > jj)
 #pragma unroll
                 for (int r = 0; r < NB; ++r) {
@@ -1012,7 +1021,7 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
         const cd xm = load_mic(t);
         cd xr[4], xc[4];
         spread(xm, 0, xr, xc);
-        const double mag = row_sum(sqrt(norm2(xm))) / (double)((unsigned)M * (unsigned)kN);
+        const double mag = row_sum(fast_sqrt(norm2(xm))) / (double)((unsigned)M * (unsigned)kN);
         const cd x0 = rowbc<0>(xm);
         cd y;
         if (mag > a.cfg.freq_mag_threshold) {  // uniform per row
@@ -1033,7 +1042,7 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
             }
             RowStep<0, 16>::run([&](auto jc) {
                 constexpr int jj = decltype(jc)::value, bj = jj >> 2, qj = jj & 3;
-                const double inv = rsqrt(rowbc<5 * qj>(A[LT(bj, bj)].x));  // 1 / L_jj from lane (qj, qj)
+                const double inv = fast_rsqrt(rowbc<5 * qj>(A[LT(bj, bj)].x));  // 1 / L_jj from lane (qj, qj)
                 cd Lrow[4], Lcol[4], u[NS];
 #pragma unroll
                 for (int ar = bj; ar < 4; ++ar) Lrow[ar] = quadbc<qj>(A[LT(ar, bj)] * inv);  // L(4ar+p, jj) from lane (p, qj)
