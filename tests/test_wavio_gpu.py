@@ -53,3 +53,26 @@ def test_wav_in_wav_out_node(tmp_path):
         got = np.frombuffer(f.readframes(F * 512), "<i2")
     # the node's float output is within 1e-5 of the reference's; one PCM step is 3e-5: almost every sample is identical
     assert np.abs(got.astype(int) - want.astype(int)).max() <= 1 and (got == want).mean() > 0.99
+
+
+def test_wav_out_at_ros_output_sample_rate(tmp_path):
+    """file_node with out_rate = 16000: every period goes through the converter (rosjack.cpp:410-427) and the WAV header carries
+    the resampled rate (rosjack.cpp:192-195)."""
+    import oracle
+    from oracle.resample_oracle import SincResampler
+    exe = os.path.join(ROOT, "examples", "file_node")
+    M, F = 4, 24
+    lines = ["initial_angle: 15.0"] + [f"mic{i}: {{id: {i}, x: {x:.3f}, y: {y:.3f}, z: 0.000}}" for i, (x, y) in enumerate(AIRA16_XY[:M])]
+    cfg = tmp_path / "beamform_config.yaml"
+    cfg.write_text("\n".join(lines) + "\n")
+    x = make_scene(M, F, seed=67)
+    x.astype("<f4").tofile(str(tmp_path / "in.f32"))
+    subprocess.check_call([exe, "das", str(cfg), str(tmp_path / "in.f32"), str(tmp_path / "out.wav"), "-", "16000"])
+    y_ref, _ = oracle.OracleNode(make_params("das", n_mics=M, theta=15.0)).process(x)
+    rs = SincResampler(48000, 16000)
+    want = wav_oracle.float_to_pcm16(np.concatenate([rs.process(y_ref[i:i + 512].astype(np.float32)) for i in range(0, F * 512, 512)]))
+    with wave.open(str(tmp_path / "out.wav"), "rb") as f:
+        assert (f.getnchannels(), f.getsampwidth(), f.getframerate()) == (1, 2, 16000)
+        got = np.frombuffer(f.readframes(f.getnframes()), "<i2")
+    assert len(got) == len(want) == (F * 512 - rs.half_len + 2) // 3
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1 and (got == want).mean() > 0.98
