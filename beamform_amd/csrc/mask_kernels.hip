@@ -1,4 +1,6 @@
 // mask_kernels.hip -- the pointwise nodes (das in fp64, phase), phasempf (mask + MCRA/MPF recursion) and the mcra node.
+#include <cstdlib>
+
 #include "bins_common.hpp"
 
 namespace bf {
@@ -15,17 +17,26 @@ struct BinCtx {
     int M, q;
 };
 
-// das.cpp:60-63
+// das.cpp:60-63 on the unpacked spectra X[m] and steering entries w[m] of one bin
 template <int MP>
-__device__ __forceinline__ cd das_bin(const BinCtx &c) {
-    cd X[MP];
-    load_X<MP>(c.Zf, c.q, c.M, X);
-    const int j = q_bin(c.q);
+__device__ __forceinline__ cd das_core(const cd (&X)[MP], const cd (&w)[MP], int M) {
     cd acc{0, 0};
 #pragma unroll
     for (int m = 0; m < MP; ++m)
-        if (m < c.M) acc = acc + conj(ld(c.steer + (long)m * kN + j)) * X[m];
-    return cd{acc.x / (double)c.M, acc.y / (double)c.M};
+        if (m < M) acc = acc + conj(w[m]) * X[m];
+    return cd{acc.x / (double)M, acc.y / (double)M};
+}
+template <int MP>
+__device__ __forceinline__ void load_steer(const f64x2 *steer, int j, int M, cd (&w)[MP]) {
+#pragma unroll
+    for (int m = 0; m < MP; ++m) w[m] = (m < M) ? ld(steer + (long)m * kN + j) : cd{0, 0};
+}
+template <int MP>
+__device__ __forceinline__ cd das_bin(const BinCtx &c) {
+    cd X[MP], w[MP];
+    load_X<MP>(c.Zf, c.q, c.M, X);
+    load_steer<MP>(c.steer, q_bin(c.q), c.M, w);
+    return das_core<MP>(X, w, c.M);
 }
 
 // mean over mic pairs of the wrapped |p_m - p_m'| with the reference's summation order
@@ -54,35 +65,66 @@ __device__ __forceinline__ double pair_phase_mean(const double (&ph)[MP], int M)
     return tot / (double)num;  // 0/0 = NaN when M == 1, as the reference
 }
 
-// phase.cpp:87-127
+// phase.cpp:87-127 on the unpacked spectra X[m] and steering entries w[m] of bin j
 template <int MP>
-__device__ __forceinline__ cd phase_bin(const BinCtx &c, const bf_config &cfg) {
-    cd X[MP];
-    load_X<MP>(c.Zf, c.q, c.M, X);
-    const int j = q_bin(c.q);
+__device__ __forceinline__ cd phase_core(const cd (&X)[MP], const cd (&w)[MP], int M, int j, const bf_config &cfg) {
     if (j == 0) return X[0];
     double mag = 0.0;
 #pragma unroll
     for (int m = 0; m < MP; ++m)
-        if (m < c.M) mag += cabs(X[m]);
-    mag /= (double)c.M;
+        if (m < M) mag += cabs(X[m]);
+    mag /= (double)M;
     bool keep = false;
     if (mag / (double)kN > cfg.mag_threshold) {
         double ph[MP];
 #pragma unroll
         for (int m = 0; m < MP; ++m) {
-            if (m < c.M) {
-                const cd u = conj(ld(c.steer + (long)m * kN + j)) * X[m];
+            if (m < M) {
+                const cd u = conj(w[m]) * X[m];
                 ph[m] = atan2(u.y, u.x);
             } else {
                 ph[m] = 0.0;
             }
         }
-        const double mean = pair_phase_mean<MP>(ph, c.M);
+        const double mean = pair_phase_mean<MP>(ph, M);
         keep = mean < cfg.min_phase * M_PI / 180;
     }
     if (!keep) mag *= cfg.mag_mult;
     return with_phase_of(mag, X[0]);  // mag * (cos, sin)(arg X_0)  (phase.cpp:115-122)
+}
+template <int MP>
+__device__ __forceinline__ cd phase_bin(const BinCtx &c, const bf_config &cfg) {
+    cd X[MP], w[MP];
+    load_X<MP>(c.Zf, c.q, c.M, X);
+    const int j = q_bin(c.q);
+    if (j == 0) return X[0];
+    load_steer<MP>(c.steer, j, c.M, w);
+    return phase_core<MP>(X, w, c.M, j, cfg);
+}
+
+// the binary phase mask of phasempf.cpp:210-248 for bin j >= 1: out_soi and |out_int|^2
+template <int MP>
+__device__ __forceinline__ void mpf_mask_core(const cd (&X)[MP], const cd (&w)[MP], int M, const bf_config &cfg, cd &soi_out,
+                                              double &int2_out) {
+    double ph[MP];
+    double mag = 0.0;
+#pragma unroll
+    for (int m = 0; m < MP; ++m) {
+        if (m < M) {
+            const cd u = conj(w[m]) * X[m];
+            ph[m] = atan2(u.y, u.x);
+            mag += cabs(X[m]);
+        } else {
+            ph[m] = 0.0;
+        }
+    }
+    const double mean = pair_phase_mean<MP>(ph, M);
+    mag /= (double)M;
+    const bool is_soi = mean < cfg.min_phase * M_PI / 180;
+    const double lo = mag * cfg.min_mag;
+    const double msoi = is_soi ? mag : lo, mint = is_soi ? lo : mag;
+    soi_out = with_phase_of(msoi, X[0]);
+    int2_out = norm2(with_phase_of(mint, X[0]));
 }
 
 template <int MP, int ALGO>
@@ -135,26 +177,12 @@ __global__ __launch_bounds__(256) void mpf_mask_kernel(BinsArgs a, double *aux) 
         aux[o] = 0.0;
         return;
     }
-    double ph[MP];
-    double mag = 0.0;
-#pragma unroll
-    for (int m = 0; m < MP; ++m) {
-        if (m < M) {
-            const cd u = conj(ld(steer + (long)m * kN + j)) * X[m];
-            ph[m] = atan2(u.y, u.x);
-            mag += cabs(X[m]);
-        } else {
-            ph[m] = 0.0;
-        }
-    }
-    const double mean = pair_phase_mean<MP>(ph, M);
-    mag /= (double)M;
-    const bool is_soi = mean < a.cfg.min_phase * M_PI / 180;
-    const double lo = mag * a.cfg.min_mag;
-    const double msoi = is_soi ? mag : lo, mint = is_soi ? lo : mag;
-    const cd soi = with_phase_of(msoi, X[0]), in = with_phase_of(mint, X[0]);
+    cd w[MP], soi;
+    double int2;
+    load_steer<MP>(steer, j, M, w);
+    mpf_mask_core<MP>(X, w, M, a.cfg, soi, int2);
     a.Yh[o] = f64x2{soi.x, soi.y};
-    aux[o] = norm2(in);
+    aux[o] = int2;
 }
 
 struct MpfState {
@@ -313,7 +341,247 @@ __global__ __launch_bounds__(64) void mcra_node_kernel(BinsArgs a) {
     }
 }
 
+
+#if BF_NFFT == 1024
+// ======================================================================================
+//            STFT + pointwise per-bin stage in one kernel (das fp64, phase, phasempf mask)
+// ======================================================================================
+// The nodes without a frame history need a frame's spectra exactly once, so they never have to reach HBM: a 256-thread block
+// transforms the microphone pairs of FPR frames (8 half-wavefronts = FPR frames x MP/2 pairs, one 1024-point fp64 FFT each, as
+// stft_kernel) into LDS -- 16 KB of packed pair spectrum per half-wavefront, the slot doubling as its transpose plane during
+// the transform -- and then turns to the per-bin arithmetic of those frames with one (frame, bin) item per thread and pass,
+// reading the spectra back from LDS through the same load_X / *_core functions the unfused kernels use (bit-identical results).
+// HBM sees the input samples, the per-bin output rows (8 KB per frame) and nothing else: 2.3 GB instead of 11.6 GB per
+// 65 536-frame batch at 8 microphones.  LDS = 16 KB twiddles + 128 KB spectra: one block, one wavefront per SIMD, so the
+// kernel hides its own latencies: the next frames' samples are requested before the per-bin pass starts (they sit in
+// otherwise idle registers as float), and every thread keeps the steering entries of its bins in registers for the whole run
+// (the (frame, bin) items of a thread are the same in every round).  LDS: 16 KB twiddles + 128 KB spectra + 8 KB window.
+template <int LAYOUT, int MP, int ALGO>
+__global__ __launch_bounds__(256, 1) void stft_bins_fused_kernel(StftArgs a, BinsArgs b, long groups_per_stream, long total_groups,
+                                                                 long groups_per_block, double *aux, f64x2 *xtail) {
+    constexpr int NPc = MP / 2;            // pair slots per frame
+    constexpr int FPR = 8 / NPc;           // frames per round
+    // problems 0 .. N/2-1 of the FPR frames fill whole 256-thread passes; the two odd ones per frame (bins N/2 and N/2+1) would
+    // cost every wavefront one more pass for a handful of lanes (a fifth on top of four at 8 microphones), so their unpacked
+    // spectra go to `xtail` and fused_tail_kernel finishes them
+    constexpr int kQMain = kN / 2;
+    constexpr int NIT = FPR * kQMain / 256;
+    __shared__ __attribute__((aligned(16))) double lds[2048 + 8 * 2048 + 32 * 33];
+    const cx<double> *s_tw = reinterpret_cast<const cx<double> *>(lds);
+    const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
+    double *slot = lds + 2048 + hw * 2048;  // this half-wavefront's spectrum [1024] c128; transpose plane while it transforms
+    double *s_win = lds + 2048 + 8 * 2048;  // analysis window, [lane][j], rows padded to 33 doubles (a 256-byte row stride would put every lane on one bank)
+    {
+        const double *twf = reinterpret_cast<const double *>(a.tw);
+        for (int i = tid; i < 2048; i += 256) lds[i] = twf[i];
+        for (int i = tid; i < kN; i += 256) s_win[(i & 31) * 33 + (i >> 5)] = a.win[i];
+    }
+    const int M = a.n_mics, NP = (M + 1) >> 1;
+    const int fs = hw / NPc, p = hw % NPc;
+    const bool has_pair = p < NP;
+    const double *hwin = s_win + lane * 33;  // window of this lane's samples 32 j + lane
+
+    // the (frame slot, problem) items of this thread and their steering entries: the same in every round
+    int it_f[NIT], it_q[NIT];
+    cd st[NIT][MP];
+#pragma unroll
+    for (int n = 0; n < NIT; ++n) {
+        const int idx = tid + 256 * n;
+        it_f[n] = idx / kQMain;
+        it_q[n] = idx % kQMain;
+        load_steer<MP>(b.steer, q_bin(it_q[n]), M, st[n]);
+    }
+
+    const long g0 = (long)blockIdx.x * groups_per_block;
+    long g1 = g0 + groups_per_block;
+    if (g1 > total_groups) g1 = total_groups;
+
+    float fr[32], fi[32];  // raw samples of this half-wavefront's next (frame, pair)
+    auto request = [&](long g) {
+        const int s = (int)(g / groups_per_stream);
+        const long t = (g % groups_per_stream) * FPR + fs;
+        if (!has_pair || t >= a.n_frames) return;
+        const float *xs = a.x + (long)s * a.stream_stride_x;
+        const float *hs = a.hist + (long)s * M * kHop;
+        const int ma = 2 * p;
+        const int mb = (2 * p + 1 < M) ? 2 * p + 1 : ma;
+        if (LAYOUT == 0) {
+            const float *a1 = (t >= 1 ? xs + (long)ma * a.mic_stride + (t - 1) * kHop : hs + ma * kHop) + lane;
+            const float *b1 = (t >= 1 ? xs + (long)mb * a.mic_stride + (t - 1) * kHop : hs + mb * kHop) + lane;
+            const float *a2 = xs + (long)ma * a.mic_stride + t * kHop + lane;
+            const float *b2 = xs + (long)mb * a.mic_stride + t * kHop + lane;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                fr[j] = a1[32 * j];
+                fi[j] = b1[32 * j];
+                fr[j + 16] = a2[32 * j];
+                fi[j + 16] = b2[32 * j];
+            }
+        } else {
+            const float *s1 = (t >= 1 ? xs + (t - 1) * (long)kHop * M : hs) + (long)lane * M;
+            const float *s2 = xs + t * (long)kHop * M + (long)lane * M;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                fr[j] = s1[(long)32 * j * M + ma];
+                fi[j] = s1[(long)32 * j * M + mb];
+                fr[j + 16] = s2[(long)32 * j * M + ma];
+                fi[j + 16] = s2[(long)32 * j * M + mb];
+            }
+        }
+    };
+    if (g0 < g1) request(g0);
+    __syncthreads();  // twiddles
+
+    for (long g = g0; g < g1; ++g) {
+        const int s = (int)(g / groups_per_stream);
+        const long f0 = (g % groups_per_stream) * FPR;
+        // ---- pass 1: window + forward FFT of (frame f0 + fs, pair p) into this half-wavefront's slot -------------------------
+        if (has_pair && f0 + fs < a.n_frames) {
+            double re[32], im[32];
+            const double bs = (2 * p + 1 < M) ? 1.0 : 0.0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                re[j] = (double)fr[j] * hwin[j];          // buf[j]*hann_win[i]  (util.h:235)
+                im[j] = (double)fi[j] * (hwin[j] * bs);
+            }
+            fft1024p_fwd_A<double>(re, im, lane, s_tw, slot);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_B<double>(re, lane, slot);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_C<double, false>(im, lane, slot);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_D<double, -1>(re, im, lane, slot);
+            __builtin_amdgcn_wave_barrier();
+            f64x2 *zo = reinterpret_cast<f64x2 *>(slot) + lane;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) zo[32 * brev5(i)] = f64x2{re[i], im[i]};
+        }
+        __syncthreads();
+        if (g + 1 < g1) request(g + 1);  // lands while the per-bin pass runs
+        // ---- pass 2: the per-bin stage of the FPR frames, spectra read back from LDS ----------------------------------------
+        const f64x2 *zs = reinterpret_cast<const f64x2 *>(lds + 2048);
+#pragma unroll
+        for (int n = 0; n < NIT; ++n) {
+            const int f = it_f[n];
+            if (f0 + f >= a.n_frames) continue;
+            const int q = it_q[n], j = q_bin(q);
+            cd X[MP];
+            load_X<MP>(zs + (long)f * NPc * kN, q, M, X);
+            const long o = ((long)s * b.n_frames + f0 + f) * kYhStride + q;
+            if (ALGO == BF_DAS) {
+                const cd y = das_core<MP>(X, st[n], M);
+                b.Yh[o] = f64x2{y.x, y.y};
+            } else if (ALGO == BF_PHASE) {
+                const cd y = phase_core<MP>(X, st[n], M, j, b.cfg);
+                b.Yh[o] = f64x2{y.x, y.y};
+            } else {  // phasempf mask
+                if (j == 0) {
+                    b.Yh[o] = f64x2{X[0].x, X[0].y};
+                    aux[o] = 0.0;
+                } else {
+                    cd soi;
+                    double int2;
+                    mpf_mask_core<MP>(X, st[n], M, b.cfg, soi, int2);
+                    b.Yh[o] = f64x2{soi.x, soi.y};
+                    aux[o] = int2;
+                }
+            }
+        }
+        if (tid < 2 * FPR && f0 + (tid >> 1) < a.n_frames) {  // bins N/2 and N/2+1 of every frame of the round: X only
+            const int f = tid >> 1, q = kQMain + (tid & 1);
+            cd X[MP];
+            load_X<MP>(zs + (long)f * NPc * kN, q, M, X);
+            f64x2 *xt = xtail + (((long)s * b.n_frames + f0 + f) * 2 + (tid & 1)) * MP;
+#pragma unroll
+            for (int m = 0; m < MP; ++m) xt[m] = f64x2{X[m].x, X[m].y};
+        }
+        __syncthreads();  // the slots are rewritten by the next round
+    }
+}
+
+// the two deferred problems per frame of stft_bins_fused_kernel: one thread per (stream, frame, q in {N/2, N/2+1})
+template <int MP, int ALGO>
+__global__ __launch_bounds__(256) void fused_tail_kernel(BinsArgs b, const f64x2 *xtail, double *aux) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)b.n_streams * b.n_frames * 2;
+    if (idx >= total) return;
+    const int q = kN / 2 + (int)(idx & 1), j = q_bin(q);
+    const long sf = idx >> 1;  // stream * n_frames + frame
+    cd X[MP], w[MP];
+#pragma unroll
+    for (int m = 0; m < MP; ++m) X[m] = ld(xtail + idx * MP + m);
+    load_steer<MP>(b.steer, j, b.n_mics, w);
+    const long o = sf * kYhStride + q;
+    if (ALGO == BF_DAS) {
+        const cd y = das_core<MP>(X, w, b.n_mics);
+        b.Yh[o] = f64x2{y.x, y.y};
+    } else if (ALGO == BF_PHASE) {
+        const cd y = phase_core<MP>(X, w, b.n_mics, j, b.cfg);
+        b.Yh[o] = f64x2{y.x, y.y};
+    } else {
+        cd soi;
+        double int2;
+        mpf_mask_core<MP>(X, w, b.n_mics, b.cfg, soi, int2);
+        b.Yh[o] = f64x2{soi.x, soi.y};
+        aux[o] = int2;
+    }
+}
+#endif
+
 }  // namespace
+
+// stft + per-bin stage of the history-free nodes in one launch; hipErrorNotSupported = use the two-kernel chain
+hipError_t launch_stft_bins_fused(const StftArgs &a, const BinsArgs &b, int n_cus, hipStream_t s) {
+#if BF_NFFT == 1024
+    const int algo = b.cfg.algo;
+    if (!(algo == BF_DAS || algo == BF_PHASE || algo == BF_PHASEMPF)) return hipErrorNotSupported;
+    if (a.n_mics > 8 || a.n_fft_mics != a.n_mics || b.n_dirs != 1 || a.frame_off != 0 || b.n_streams != a.n_streams)
+        return hipErrorNotSupported;
+    const int fpr = a.n_mics <= 4 ? 4 : 2;
+    const long gps = (a.n_frames + fpr - 1) / fpr;
+    const long total = gps * a.n_streams;
+    long blocks = total < n_cus ? total : n_cus;
+    if (blocks < 1) blocks = 1;
+    const long gpb = (total + blocks - 1) / blocks;
+    blocks = (total + gpb - 1) / gpb;
+    double *aux = reinterpret_cast<double *>(b.Yh + (long)b.n_streams * b.n_frames * kYhStride);
+    f64x2 *xtail = a.Z;  // [stream][frame][2][MP]: the caller sizes the Z workspace for it (fused_tail_elems)
+    if (!xtail) return hipErrorInvalidValue;
+    const long tail_items = (long)b.n_streams * b.n_frames * 2;
+    const unsigned tail_blocks = (unsigned)((tail_items + 255) / 256);
+#define BF_FUSED_GO(L_, MP_, A_)                                                                                             \
+    do {                                                                                                                      \
+        hipLaunchKernelGGL((stft_bins_fused_kernel<L_, MP_, A_>), dim3((unsigned)blocks), dim3(256), 0, s, a, b, gps, total, gpb, \
+                           aux, xtail);                                                                                       \
+        hipLaunchKernelGGL((fused_tail_kernel<MP_, A_>), dim3(tail_blocks), dim3(256), 0, s, b, (const f64x2 *)xtail, aux);   \
+    } while (0)
+#define BF_FUSED_ALGO(L_, MP_)                                   \
+    do {                                                          \
+        if (algo == BF_DAS) BF_FUSED_GO(L_, MP_, BF_DAS);         \
+        else if (algo == BF_PHASE) BF_FUSED_GO(L_, MP_, BF_PHASE); \
+        else BF_FUSED_GO(L_, MP_, BF_PHASEMPF);                   \
+    } while (0)
+    if (a.layout == 0) {
+        if (a.n_mics <= 4) BF_FUSED_ALGO(0, 4); else BF_FUSED_ALGO(0, 8);
+    } else {
+        if (a.n_mics <= 4) BF_FUSED_ALGO(1, 4); else BF_FUSED_ALGO(1, 8);
+    }
+#undef BF_FUSED_ALGO
+#undef BF_FUSED_GO
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (algo == BF_PHASEMPF) {  // second pass of launch_phasempf: the recursion over frames
+        const int nthr = b.n_streams * kNQ;
+        hipLaunchKernelGGL(mpf_recursion_kernel, dim3((nthr + 63) / 64), dim3(64), 0, s, b, (const double *)aux);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && b.spectrum) e = launch_expand_spectrum(b.Yh, b.spectrum, (long)b.n_streams * b.n_frames, s);
+    return e;
+#else
+    (void)a; (void)b; (void)n_cus; (void)s;
+    return hipErrorNotSupported;
+#endif
+}
 
 hipError_t launch_phasempf(const BinsArgs &a, int n_cus, hipStream_t s) {
     // aux (|out_int|^2 per problem) lives behind the Yh rows: Yh was allocated with 2x room by the pipeline

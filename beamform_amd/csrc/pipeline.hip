@@ -274,7 +274,16 @@ int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipS
 int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, hipStream_t stream, int layout,
                              long mic_stride, const RunSnapshot &snap) {
     const long FT = Phist_ + F;  // frames in the Z workspace per stream
-    int rc = ensure((void **)&d_Z_, &Z_cap_, (size_t)S_ * FT * NP_ * N_ * sizeof(f64x2));
+    // nodes without a frame history: STFT and per-bin stage in one launch, spectra never leave the CU (launch_stft_bins_fused;
+    // BF_FUSED_BINS=0 selects the two-kernel chain) -- then the Z workspace (64 KB per frame at 8 microphones) is not needed at all
+    static const int fuse_env = getenv("BF_FUSED_BINS") ? atoi(getenv("BF_FUSED_BINS")) : 1;
+    const bool try_fused = fuse_env != 0 && Phist_ == 0 && N_ == 1024 && M_ <= 8 && MF_ == M_ && D_ == 1 &&
+                           (cfg_.algo == BF_DAS || cfg_.algo == BF_PHASE || cfg_.algo == BF_PHASEMPF);
+    int rc = BF_OK;
+    if (!try_fused)
+        rc = ensure((void **)&d_Z_, &Z_cap_, (size_t)S_ * FT * NP_ * N_ * sizeof(f64x2));
+    else  // the fused kernel parks the unpacked spectra of two bins per frame here (stream x frame x 2 x 8 microphones)
+        rc = ensure((void **)&d_Z_, &Z_cap_, (size_t)S_ * F * 2 * 8 * sizeof(f64x2));
     if (rc != BF_OK) return rc;
     // phasempf keeps |out_int|^2 (one double per problem) behind the spectrum rows
     rc = ensure((void **)&d_Yh_, &Yh_cap_,
@@ -311,7 +320,31 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
         }
         if (kmax < N_ / 2 - 2) { sa.skip_lo = kmax; sa.skip_hi = N_ - kmax; }
     }
-    PIPE_HIP(ks_->stft(sa, n_cus_, stream));
+    if (cfg_.algo == BF_GSC && spectrum) {  // time-domain node: there is no single y_fft; the dump reads as zeros
+        PIPE_HIP(hipMemsetAsync(spectrum, 0, (size_t)S_ * F * N_ * sizeof(f64x2), stream));
+        spectrum = nullptr;
+    }
+    BinsArgs ba;
+    ba.Z = d_Z_; ba.Yh = d_Yh_; ba.spectrum = spectrum; ba.steer = snap.steer; ba.freqs = d_freq_;
+    ba.n_frames = F; ba.frames_ws = FT; ba.frame_off = Phist_; ba.n_streams = So_; ba.n_mics = MF_; ba.kp1 = snap.kp1;
+    ba.n_dirs = D_; ba.steer_dir_stride = snap.steer_dir_stride;
+    ba.cfg = cfg_; ba.gssW = d_gssW_; ba.mpf = d_mpf_; ba.gss_reset_mask = snap.gss_reset_mask;
+    bool fused = false;
+    if (try_fused) {
+        const hipError_t fe = ks_->stft_bins(sa, ba, n_cus_, stream);
+        if (fe == hipSuccess) {
+            fused = true;
+        } else if (fe != hipErrorNotSupported) {
+            PIPE_HIP(fe);
+        } else {  // the launcher declined: fall back to the two-kernel chain
+            (void)hipGetLastError();
+            rc = ensure((void **)&d_Z_, &Z_cap_, (size_t)S_ * FT * NP_ * N_ * sizeof(f64x2));
+            if (rc != BF_OK) return rc;
+            sa.Z = d_Z_;
+            ba.Z = d_Z_;
+        }
+    }
+    if (!fused) PIPE_HIP(ks_->stft(sa, n_cus_, stream));
 
     // ring-buffer carry (util.h:305-308)
     if (layout == BF_PLANAR) {
@@ -323,16 +356,7 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
                                   hipMemcpyDeviceToDevice, stream));
     }
 
-    if (cfg_.algo == BF_GSC && spectrum) {  // time-domain node: there is no single y_fft; the dump reads as zeros
-        PIPE_HIP(hipMemsetAsync(spectrum, 0, (size_t)S_ * F * N_ * sizeof(f64x2), stream));
-        spectrum = nullptr;
-    }
-    BinsArgs ba;
-    ba.Z = d_Z_; ba.Yh = d_Yh_; ba.spectrum = spectrum; ba.steer = snap.steer; ba.freqs = d_freq_;
-    ba.n_frames = F; ba.frames_ws = FT; ba.frame_off = Phist_; ba.n_streams = So_; ba.n_mics = MF_; ba.kp1 = snap.kp1;
-    ba.n_dirs = D_; ba.steer_dir_stride = snap.steer_dir_stride;
-    ba.cfg = cfg_; ba.gssW = d_gssW_; ba.mpf = d_mpf_; ba.gss_reset_mask = snap.gss_reset_mask;
-    PIPE_HIP(ks_->bins(ba, n_cus_, stream));
+    if (!fused) PIPE_HIP(ks_->bins(ba, n_cus_, stream));
 
     if (Phist_ > 0)  // keep the last Phist frames' spectra for the next call
         PIPE_HIP(hipMemcpy2DAsync(d_zhist_, (size_t)Phist_ * frame_elems * sizeof(f64x2), d_Z_ + (size_t)F * frame_elems,

@@ -80,6 +80,9 @@ struct IstftArgs {
 namespace BF_NTAG {
 hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s);
 hipError_t launch_bins(const BinsArgs &a, int n_cus, hipStream_t s);
+// stft + per-bin stage in one launch for the nodes without a frame history (das fp64, phase, phasempf; N = 1024, <= 8 mics,
+// one look direction): the spectra stay in LDS.  hipErrorNotSupported = run launch_stft + launch_bins instead.  mask_kernels.hip
+hipError_t launch_stft_bins_fused(const StftArgs &a, const BinsArgs &b, int n_cus, hipStream_t s);
 // per-node launchers behind launch_bins (one translation unit per kernel family)
 hipError_t launch_pointwise(const BinsArgs &a, hipStream_t s);              // das (fp64), phase: mask_kernels.hip
 hipError_t launch_phasempf(const BinsArgs &a, int n_cus, hipStream_t s);    // mask_kernels.hip
@@ -105,6 +108,7 @@ struct KernelSet {
     int nfft;
     hipError_t (*stft)(const StftArgs &, int, hipStream_t);
     hipError_t (*bins)(const BinsArgs &, int, hipStream_t);
+    hipError_t (*stft_bins)(const StftArgs &, const BinsArgs &, int, hipStream_t);
     hipError_t (*istft)(const IstftArgs &, int, hipStream_t);
     hipError_t (*smooth)(const float *, float *, double *, long, int, int, hipStream_t);
     hipError_t (*gsc_nlms)(const float *, float *, float *, long, int, int, const bf_config &, hipStream_t);
