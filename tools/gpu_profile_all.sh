@@ -21,8 +21,8 @@ run() {  # name, step kernel, run_das args...
   tail -1 gpurun_out/${tag}_${name}.log
 }
 run das8 das_fused --algo das
-run das8_f64 stft_kernel --algo das --das-f64
+run das8_f64 stft_bins_fused --algo das --das-f64
 run mvdr8 stft_kernel --algo mvdr
-run phase8 stft_kernel --algo phase
-run phasempf8 stft_kernel --algo phasempf --streams 256 --frames 256
+run phase8 stft_bins_fused --algo phase
+run phasempf8 stft_bins_fused --algo phasempf --streams 256 --frames 256
 run lcmv16 stft_kernel --algo lcmv --mics 16 --frames 32768
