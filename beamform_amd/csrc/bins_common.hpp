@@ -65,6 +65,119 @@ __device__ __forceinline__ double fast_rcp(double x) {
     y = fma(y, fma(-x, y, 1.0), y);
     return y;
 }
+// atan2 for the phase masks (phase.cpp:101, phasempf.cpp:221: arg of conj(w) X), about half the instructions of the library
+// routine: one division instead of two, no special-case ladder.  With mx = max(|x|,|y|), mn = min(|x|,|y|) the octant angle is
+//   atan(mn / mx) = atan(c) + atan(z),  z = (mn - c mx) / (mx + c mn),  c in {0, 1/2, 1} chosen so that |z| <= 1/4,
+// atan(z) = z + z^3 Q(z^2) with a degree-8 Q (least-squares fit in long double at 600 Chebyshev nodes, max relative error of the
+// evaluated polynomial 1.7e-16); atan(c), pi/4, pi/2 and pi enter as hi + lo pairs.  Measured on the device over 1.7e7 points spanning 18 decades
+// (tools/ubench/atan2_test.hip): within 1.82 ulp of the exact value (the library routine: 1.62 ulp).  Signed zeros follow the IEEE rules (a silent channel gives arg(0) as std::arg does);
+// magnitudes outside 1e-280 .. 1e280 are rescaled by an exact power of two first; NaN in, NaN out.
+__device__ __forceinline__ double atan2_fast(double y, double x) {
+    const double ax = fabs(x), ay = fabs(y);
+    double mx = fmax(ax, ay), mn = fmin(ax, ay);
+    // keep the quotient's reciprocal estimate in range: exact power-of-two rescaling of both magnitudes (no branch, no library call)
+    const double sc = mx < 1e-280 ? 0x1p600 : (mx > 1e280 ? 0x1p-600 : 1.0);
+    mx *= sc;
+    mn *= sc;
+    const bool b1 = mn > 0.25 * mx, b2 = mn > 0.75 * mx;
+    const double c = b2 ? 1.0 : (b1 ? 0.5 : 0.0);
+    const double chi = b2 ? 0.7853981633974483 : (b1 ? 0.4636476090008061 : 0.0);
+    const double clo = b2 ? 3.061616997868383e-17 : (b1 ? 2.268693045925918e-17 : 0.0);
+    const double num = fma(-c, mx, mn), den = fma(c, mn, mx);
+    const double r = fast_rcp(den);
+    double z = num * r;
+    z = fma(fma(-den, z, num), r, z);  // one correction step on the quotient
+    const double s = z * z;
+    double q = -0.040008015363946665;
+    q = fma(q, s, 0.05724708565692529);
+    q = fma(q, s, -0.066554543402443);
+    q = fma(q, s, 0.07691819902065834);
+    q = fma(q, s, -0.09090895876111414);
+    q = fma(q, s, 0.1111111089272362);
+    q = fma(q, s, -0.14285714283649867);
+    q = fma(q, s, 0.19999999999990273);
+    q = fma(q, s, -0.33333333333333315);
+    double a = fma(z * s, q, z);
+    a = chi + (a + clo);
+    if (mx == 0.0) a = 0.0;  // atan2(+-0, +-0): 0 in the right half plane, pi in the left (decided by the sign of x below)
+    if (ay > ax) a = 1.5707963267948966 - (a - 6.123233995736766e-17);
+    if (__builtin_signbit(x)) a = 3.141592653589793 - (a - 1.2246467991473532e-16);
+    return copysign(a, y);
+}
+// |X_m| of N spectra, stage by stage across the N values (same reason as atan2_fast_n below); each value = fast_sqrt(norm2(X_m)).
+template <int N>
+__device__ __forceinline__ void cabs_n(const cd (&X)[N], double (&out)[N]) {
+    double n2[N], y[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) n2[i] = fma(X[i].y, X[i].y, X[i].x * X[i].x);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = __builtin_amdgcn_rsq(n2[i]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int i = 0; i < N; ++i) y[i] = fma(y[i], fma(-0.5 * n2[i] * y[i], y[i], 0.5), y[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = n2[i] == 0.0 ? 0.0 : n2[i] * y[i];
+}
+// atan2_fast of N independent arguments, written stage by stage across the N values: a per-bin kernel that runs one wavefront
+// per SIMD has no second wavefront to cover the ~10-cycle latency of dependent fp64 operations, and one atan2 is a single chain
+// of ~45 of them; interleaving the N chains keeps the pipe busy.  Element for element the same operations as atan2_fast.
+template <int N>
+__device__ __forceinline__ void atan2_fast_n(const double (&y)[N], const double (&x)[N], double (&out)[N]) {
+    double mx[N], mn[N], chi[N], clo[N], num[N], den[N], r[N], z[N], s[N], q[N];
+    bool swap_[N], zero_[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double ax = fabs(x[i]), ay = fabs(y[i]);
+        swap_[i] = ay > ax;
+        double a = fmax(ax, ay), b = fmin(ax, ay);
+        const double sc = a < 1e-280 ? 0x1p600 : (a > 1e280 ? 0x1p-600 : 1.0);
+        a *= sc;
+        b *= sc;
+        zero_[i] = a == 0.0;
+        mx[i] = a;
+        mn[i] = b;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const bool b1 = mn[i] > 0.25 * mx[i], b2 = mn[i] > 0.75 * mx[i];
+        const double c = b2 ? 1.0 : (b1 ? 0.5 : 0.0);
+        chi[i] = b2 ? 0.7853981633974483 : (b1 ? 0.4636476090008061 : 0.0);
+        clo[i] = b2 ? 3.061616997868383e-17 : (b1 ? 2.268693045925918e-17 : 0.0);
+        num[i] = fma(-c, mx[i], mn[i]);
+        den[i] = fma(c, mn[i], mx[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = __builtin_amdgcn_rcp(den[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = fma(r[i], fma(-den[i], r[i], 1.0), r[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = fma(r[i], fma(-den[i], r[i], 1.0), r[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) z[i] = num[i] * r[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) z[i] = fma(fma(-den[i], z[i], num[i]), r[i], z[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        s[i] = z[i] * z[i];
+        q[i] = -0.040008015363946665;
+    }
+    constexpr double kC[8] = {0.05724708565692529, -0.066554543402443, 0.07691819902065834, -0.09090895876111414,
+                              0.1111111089272362, -0.14285714283649867, 0.19999999999990273, -0.33333333333333315};
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int i = 0; i < N; ++i) q[i] = fma(q[i], s[i], kC[k]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double a = fma(z[i] * s[i], q[i], z[i]);
+        a = chi[i] + (a + clo[i]);
+        if (zero_[i]) a = 0.0;
+        if (swap_[i]) a = 1.5707963267948966 - (a - 6.123233995736766e-17);
+        if (__builtin_signbit(x[i])) a = 3.141592653589793 - (a - 1.2246467991473532e-16);
+        out[i] = copysign(a, y[i]);
+    }
+}
 // acc - a * conj(b) and acc + a * conj(b), four FMAs each
 __device__ __forceinline__ cd cfms_conj(cd acc, cd a, cd b) {
     return cd{fma(-a.y, b.y, fma(-a.x, b.x, acc.x)), fma(a.x, b.y, fma(-a.y, b.x, acc.y))};

@@ -69,28 +69,30 @@ __device__ __forceinline__ double pair_phase_mean(const double (&ph)[MP], int M)
 template <int MP>
 __device__ __forceinline__ cd phase_core(const cd (&X)[MP], const cd (&w)[MP], int M, int j, const bf_config &cfg) {
     if (j == 0) return X[0];
-    double mag = 0.0;
+    double ab[MP], mag = 0.0;
+    cabs_n<MP>(X, ab);
 #pragma unroll
     for (int m = 0; m < MP; ++m)
-        if (m < M) mag += cabs(X[m]);
+        if (m < M) mag += ab[m];
     mag /= (double)M;
     bool keep = false;
     if (mag / (double)kN > cfg.mag_threshold) {
-        double ph[MP];
+        double ph[MP], uy[MP], ux[MP];
 #pragma unroll
         for (int m = 0; m < MP; ++m) {
-            if (m < M) {
-                const cd u = conj(w[m]) * X[m];
-                ph[m] = atan2(u.y, u.x);
-            } else {
-                ph[m] = 0.0;
-            }
+            const cd u = conj(w[m]) * X[m];  // padding channels: w = X = 0 -> their phase is never read
+            uy[m] = u.y;
+            ux[m] = u.x;
         }
+        atan2_fast_n<MP>(uy, ux, ph);
         const double mean = pair_phase_mean<MP>(ph, M);
         keep = mean < cfg.min_phase * M_PI / 180;
     }
     if (!keep) mag *= cfg.mag_mult;
-    return with_phase_of(mag, X[0]);  // mag * (cos, sin)(arg X_0)  (phase.cpp:115-122)
+    // mag * (cos, sin)(arg X_0) = mag * X_0 / |X_0|  (phase.cpp:115-122); arg(0) = 0
+    if (ab[0] == 0.0) return cd{mag, 0.0};
+    const double sc = mag * fast_rcp(ab[0]);
+    return cd{sc * X[0].x, sc * X[0].y};
 }
 template <int MP>
 __device__ __forceinline__ cd phase_bin(const BinCtx &c, const bf_config &cfg) {
@@ -106,25 +108,35 @@ __device__ __forceinline__ cd phase_bin(const BinCtx &c, const bf_config &cfg) {
 template <int MP>
 __device__ __forceinline__ void mpf_mask_core(const cd (&X)[MP], const cd (&w)[MP], int M, const bf_config &cfg, cd &soi_out,
                                               double &int2_out) {
-    double ph[MP];
+    double ph[MP], uy[MP], ux[MP], ab[MP];
     double mag = 0.0;
+    cabs_n<MP>(X, ab);
 #pragma unroll
     for (int m = 0; m < MP; ++m) {
-        if (m < M) {
-            const cd u = conj(w[m]) * X[m];
-            ph[m] = atan2(u.y, u.x);
-            mag += cabs(X[m]);
-        } else {
-            ph[m] = 0.0;
-        }
+        const cd u = conj(w[m]) * X[m];  // padding channels: w = X = 0 -> their phase is never read
+        uy[m] = u.y;
+        ux[m] = u.x;
+        if (m < M) mag += ab[m];
     }
+    atan2_fast_n<MP>(uy, ux, ph);
     const double mean = pair_phase_mean<MP>(ph, M);
     mag /= (double)M;
     const bool is_soi = mean < cfg.min_phase * M_PI / 180;
     const double lo = mag * cfg.min_mag;
     const double msoi = is_soi ? mag : lo, mint = is_soi ? lo : mag;
-    soi_out = with_phase_of(msoi, X[0]);
-    int2_out = norm2(with_phase_of(mint, X[0]));
+    // m * (cos, sin)(arg X_0) = m * X_0 / |X_0| for both magnitudes; arg(0) = 0
+    cd soi, in;
+    if (ab[0] == 0.0) {
+        soi = cd{msoi, 0.0};
+        in = cd{mint, 0.0};
+    } else {
+        const double inv = fast_rcp(ab[0]);
+        const cd unit = cd{X[0].x * inv, X[0].y * inv};
+        soi = cd{msoi * unit.x, msoi * unit.y};
+        in = cd{mint * unit.x, mint * unit.y};
+    }
+    soi_out = soi;
+    int2_out = norm2(in);
 }
 
 template <int MP, int ALGO>
