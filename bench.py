@@ -385,7 +385,11 @@ def main():
             ("das_interleaved", lambda: node_line("das", M, F, 1, xin=x.reshape(1, F * HOP, M), layout_=BF_INTERLEAVED, iters=20,
                                                   note="the headline workload with [sample][mic] input (same bytes read as interleaved samples)")),
             ("phasempf", lambda: node_line("phasempf", 8, 256, 256, note="BASELINE config 4: 256 streams x 256 frames, recursion per stream")),
-            ("phase", lambda: node_line("phase", M, F, 1, xin=x)),
+            ("phase", lambda: node_line("phase", M, F, 1, xin=x,
+                                        note="uniform noise of this level stays below the node's mag_threshold (0.05): every bin takes the cheap branch "
+                                             "without the phase-difference test; see phase_gate_open for the other extreme")),
+            ("phase_gate_open", lambda: node_line("phase", M, F, 1, xin=x * 8.0,
+                                                  note="the same noise 8x louder: every bin passes mag_threshold and runs the 8 atan2 + 28 wrapped differences")),
             ("lcmv16", lambda: node_line("lcmv", 16, 32768, 1, (-60.0, 90.0, 150.0), iters=3,
                                          note="BASELINE config 5, one GPU's shard of the 262144-frame stream; " + noise)),
         ]
