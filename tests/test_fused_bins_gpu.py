@@ -1,0 +1,94 @@
+"""stft_bins_fused_kernel (das fp64, phase, phasempf: STFT and per-bin stage in one launch, spectra in LDS) against the oracle
+over the shapes its index arithmetic distinguishes: odd microphone counts (idle pair slots), 4-microphone blocks (four frames per
+round), frame counts that do not fill a round, several streams, interleaved input, hop-by-hop streaming; and against the
+two-kernel chain (BF_FUSED_BINS=0, a separate process: the switch is read once)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from beamform_amd.params import make_params
+from beamform_amd.synth import make_scene
+from test_pipeline_gpu import check, run_gpu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _node(algo, M, theta, **over):
+    p = make_params("das" if algo == "das_f64" else algo, n_mics=M, theta=theta)
+    if algo == "phase":
+        p["mag_threshold"] = 0.0005        # open the magnitude gate on part of the bins of the test scene
+    p.update(over)
+    return p
+
+
+@pytest.mark.parametrize("algo", ["das_f64", "phase", "phasempf"])
+@pytest.mark.parametrize("M,F", [(8, 33), (7, 5), (5, 18), (4, 27), (3, 9), (2, 40), (1, 6), (8, 1), (4, 3)])
+def test_fused_matches_oracle(algo, M, F):
+    import oracle
+    from beamform_amd.capi import BF_DAS_BINS_F64, BF_DAS_FUSED_F32
+    p = _node(algo, M, 25.0)
+    x = make_scene(M, F, seed=900 + 10 * M + F)
+    y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
+    y, Y = run_gpu(p, x, das_impl=BF_DAS_BINS_F64 if algo == "das_f64" else BF_DAS_FUSED_F32)
+    check(y, Y, y_ref, Y_ref)
+
+
+@pytest.mark.parametrize("algo", ["das_f64", "phase", "phasempf"])
+def test_fused_streams_and_interleaved(algo):
+    import oracle
+    from beamform_amd.capi import BF_DAS_BINS_F64, BF_DAS_FUSED_F32, BF_INTERLEAVED
+    M, F, S = 6, 11, 3
+    p = _node(algo, M, -40.0)
+    impl = BF_DAS_BINS_F64 if algo == "das_f64" else BF_DAS_FUSED_F32
+    xs = np.stack([make_scene(M, F, seed=950 + s) for s in range(S)])           # [S, M, T]
+    refs = [oracle.OracleNode(p).process(xs[s], want_spectrum=True) for s in range(S)]
+    y, Y = run_gpu(p, xs, n_streams=S, F=F, das_impl=impl)
+    yi, Yi = run_gpu(p, np.ascontiguousarray(xs.transpose(0, 2, 1)), n_streams=S, F=F, das_impl=impl, layout=BF_INTERLEAVED)
+    for s in range(S):
+        check(y[s], Y[s], *refs[s])
+        check(yi[s], Yi[s], *refs[s])
+        assert np.array_equal(y[s], yi[s])          # same arithmetic whatever the input layout
+
+
+@pytest.mark.parametrize("algo", ["phase", "phasempf"])
+def test_fused_streaming_equals_batch(algo):
+    from beamform_amd.capi import Beamformer
+    M, F = 8, 14
+    p = _node(algo, M, 10.0)
+    x = make_scene(M, F, seed=977)
+    whole = Beamformer(p).process(x)
+    bf = Beamformer(p)
+    parts = [bf.process(x[:, :512 * 5]), bf.process(x[:, 512 * 5:512 * 6]), bf.process(x[:, 512 * 6:])]   # 5 + 1 + 8 frames
+    assert np.array_equal(np.concatenate(parts), whole)
+
+
+CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import torch
+from beamform_amd.capi import Beamformer, BF_DAS_BINS_F64, BF_DAS_FUSED_F32
+from beamform_amd.params import make_params
+from beamform_amd.synth import make_scene
+out = {}
+for algo, M, F in [("das", 8, 21), ("phase", 8, 21), ("phasempf", 5, 30), ("phase", 4, 13)]:
+    p = make_params(algo, n_mics=M, theta=33.0)
+    if algo == "phase":
+        p["mag_threshold"] = 0.0005
+    x = make_scene(M, F, seed=990 + M)
+    out[f"{algo}{M}"] = Beamformer(p, das_impl=BF_DAS_BINS_F64 if algo == "das" else BF_DAS_FUSED_F32).process(x)
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_fused_is_bit_identical_to_the_two_kernel_chain(tmp_path):
+    res = {}
+    for mode in ("1", "0"):
+        f = str(tmp_path / f"out{mode}.npz")
+        subprocess.check_call([sys.executable, "-c", CHILD % ROOT, f], env=dict(os.environ, BF_FUSED_BINS=mode))
+        res[mode] = np.load(f)
+    for k in res["1"].files:
+        assert np.array_equal(res["1"][k], res["0"][k]), k
