@@ -9,7 +9,7 @@
 #include <cstring>
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotSupported = 801 };
 typedef struct bf_stub_stream *hipStream_t;
 typedef struct bf_stub_event *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
@@ -19,6 +19,7 @@ struct hipDeviceProp_t {
 };
 
 static inline const char *hipGetErrorString(hipError_t) { return "stub"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 256; return hipSuccess; }
