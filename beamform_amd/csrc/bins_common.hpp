@@ -104,6 +104,13 @@ __device__ __forceinline__ double atan2_fast(double y, double x) {
     if (__builtin_signbit(x)) a = 3.141592653589793 - (a - 1.2246467991473532e-16);
     return copysign(a, y);
 }
+// x / d with a reciprocal that was formed once (rd ~ 1/d) and one correction step: the quotient is within half an ulp of the
+// correctly rounded one for finite x and d (exact for d = 0: x * inf, 0 * inf = NaN as the division gives).
+__device__ __forceinline__ double div_rcp(double x, double d, double rd) {
+    const double q = x * rd;
+    const double r = fma(-d, q, x);
+    return (d == 0.0 || r != r) ? q : fma(r, rd, q);
+}
 // |X_m| of N spectra, stage by stage across the N values (same reason as atan2_fast_n below); each value = fast_sqrt(norm2(X_m)).
 template <int N>
 __device__ __forceinline__ void cabs_n(const cd (&X)[N], double (&out)[N]) {

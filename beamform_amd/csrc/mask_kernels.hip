@@ -24,7 +24,8 @@ __device__ __forceinline__ cd das_core(const cd (&X)[MP], const cd (&w)[MP], int
 #pragma unroll
     for (int m = 0; m < MP; ++m)
         if (m < M) acc = acc + conj(w[m]) * X[m];
-    return cd{acc.x / (double)M, acc.y / (double)M};
+    const double dM = (double)M, rM = 1.0 / dM;  // M is uniform: one division per thread, hoisted out of the item loop
+    return cd{div_rcp(acc.x, dM, rM), div_rcp(acc.y, dM, rM)};
 }
 template <int MP>
 __device__ __forceinline__ void load_steer(const f64x2 *steer, int j, int M, cd (&w)[MP]) {
@@ -62,7 +63,8 @@ __device__ __forceinline__ double pair_phase_mean(const double (&ph)[MP], int M)
     for (int i = MP - 1; i >= 0; --i)
         if (i < M - 1) tot = d[i] + tot;
     const int num = M * (M - 1) / 2;
-    return tot / (double)num;  // 0/0 = NaN when M == 1, as the reference
+    const double dn = (double)num;
+    return div_rcp(tot, dn, 1.0 / dn);  // 0/0 = NaN when M == 1, as the reference
 }
 
 // phase.cpp:87-127 on the unpacked spectra X[m] and steering entries w[m] of bin j
@@ -74,7 +76,7 @@ __device__ __forceinline__ cd phase_core(const cd (&X)[MP], const cd (&w)[MP], i
 #pragma unroll
     for (int m = 0; m < MP; ++m)
         if (m < M) mag += ab[m];
-    mag /= (double)M;
+    mag = div_rcp(mag, (double)M, 1.0 / (double)M);
     bool keep = false;
     if (mag / (double)kN > cfg.mag_threshold) {
         double ph[MP], uy[MP], ux[MP];
@@ -120,7 +122,7 @@ __device__ __forceinline__ void mpf_mask_core(const cd (&X)[MP], const cd (&w)[M
     }
     atan2_fast_n<MP>(uy, ux, ph);
     const double mean = pair_phase_mean<MP>(ph, M);
-    mag /= (double)M;
+    mag = div_rcp(mag, (double)M, 1.0 / (double)M);
     const bool is_soi = mean < cfg.min_phase * M_PI / 180;
     const double lo = mag * cfg.min_mag;
     const double msoi = is_soi ? mag : lo, mint = is_soi ? lo : mag;
