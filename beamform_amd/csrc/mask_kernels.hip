@@ -237,19 +237,20 @@ __device__ __forceinline__ cd mpf_step(MpfState &st, const bf_config &c, int j, 
     const double kq = 1 - c.mpf_rev_gamma / c.mpf_rev_delta;  // quirk Q15i
     st.rev0 = c.mpf_rev_gamma * st.rev0 + kq * soi2;
     st.rev1 = c.mpf_rev_gamma * st.rev1 + kq * int2;
-    const double Lam = sqrt(st.lam + leak + st.rev0 + st.rev1);
+    const double Lam = fast_sqrt(st.lam + leak + st.rev0 + st.rev1);
     if (j == 0) return cd{0, 0};  // quirk Q15d: y_fft[0] is never written; defined 0
-    const double as = cabs(soi);
+    const double as = fast_sqrt(soi2);
     double mg;
     if (c.out_only_noise) {
         mg = Lam * c.out_amp;
     } else {
-        mg = (as - (c.out_only_mcra ? sqrt(st.lam) : Lam)) * c.out_amp;
+        mg = (as - (c.out_only_mcra ? fast_sqrt(st.lam) : Lam)) * c.out_amp;
         if (mg < 0) mg = c.noise_floor;
     }
     // mag * (cos, sin)(arg(soi)) == mag * soi/|soi|; arg(0) = 0
     if (as == 0.0) return cd{mg, 0.0};
-    return cd{mg * (soi.x / as), mg * (soi.y / as)};
+    const double sc = mg * fast_rcp(as);
+    return cd{sc * soi.x, sc * soi.y};
 }
 
 // Pass 2, one thread per (stream, problem), sequential over frames.
