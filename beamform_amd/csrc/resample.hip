@@ -338,11 +338,16 @@ static int upload_table(bf_resampler *r, const float *coeffs, int len, int inc) 
     r->index_inc = inc;
     const long hl = 2 * r->half_taps() + 8;
     if (hl != old_hist) {
+        r->hist_len = 0;
         for (int b = 0; b < 2; ++b) {
             if (r->d_hist[b]) (void)hipFree(r->d_hist[b]);
             r->d_hist[b] = nullptr;
-            if (hipMalloc(&r->d_hist[b], sizeof(float) * (size_t)hl) != hipSuccess) return BF_ENOMEM;
         }
+        for (int b = 0; b < 2; ++b)
+            if (hipMalloc(&r->d_hist[b], sizeof(float) * (size_t)hl) != hipSuccess) {
+                r->d_hist[b] = nullptr;
+                return BF_ENOMEM;  // process_* refuses to run until a set_table succeeds
+            }
         r->hist_len = hl;
     }
     for (int b = 0; b < 2; ++b)
@@ -394,13 +399,18 @@ extern "C" size_t bf_resampler_out_count(bf_resampler *r, size_t n_in) {
     return (size_t)(r->outputs_for(r->consumed + (long)n_in) - r->generated);
 }
 
-extern "C" int bf_resampler_latency(bf_resampler *r) { return r ? (int)r->half_taps() : 0; }
+extern "C" int bf_resampler_latency(bf_resampler *r) {
+    if (!r) return 0;
+    std::lock_guard<std::mutex> lk(r->mu);
+    return (int)r->half_taps();
+}
 
 static int process_locked(bf_resampler *r, const float *d_in, size_t n_in, float *d_out, size_t out_cap, size_t *n_out, hipStream_t s) {
+    if (!r->d_table || !r->d_hist[0] || !r->d_hist[1]) return BF_ENOMEM;  // an earlier set_table ran out of memory half way
     const long total = r->outputs_for(r->consumed + (long)n_in);
     const long want = total - r->generated;
     if (n_out) *n_out = (size_t)want;
-    if ((size_t)want > out_cap) return BF_EINVAL;  // *n_out says how much room the call needs
+    if ((size_t)want > out_cap || (want > 0 && !d_out)) return BF_EINVAL;  // *n_out says how much room the call needs
     if (want > 0) {
         ResampleArgs a;
         a.hist = r->d_hist[r->hist_cur];
