@@ -191,8 +191,8 @@ def main():
     ap.add_argument("--independent", action="store_true",
                     help="N > 1: round-1 behaviour, every rank an independent random batch (no shard plan)")
     ap.add_argument("--gather", default="final", choices=["final", "none"])
-    ap.add_argument("--cpu-frames", type=int, default=81920,
-                    help="frames in the CPU-baseline sample (0 = skip); the default is ~10 s of single-core work")
+    ap.add_argument("--cpu-frames", type=int, default=196608,
+                    help="frames in the CPU-baseline sample (0 = skip); the default is ~12 s of single-core work (its oracle, with the FFT plan cached, does ~16 k frames per second)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-all-cores-frames", type=int, default=2048,
                     help="frames per host core in the all-cores CPU baseline (0 = skip)")
