@@ -203,6 +203,47 @@ __global__ __launch_bounds__(256) void sinc_poly_kernel(ResampleArgs a, PolyArgs
     }
 }
 
+// Polyphase form with the block's input window staged in LDS: the 256 outputs of a block read 256 * in/out + taps consecutive
+// input samples (886 floats at 48 -> 16 kHz), fetched once, coalesced, through tap() -- history, new input and the zeros beyond
+// the data all look the same afterwards, so there is ONE summation path whatever the position of the block in the stream
+// (results stay independent of how the stream is cut into calls).  Dynamic LDS: coefficients + tap counts + window.
+__global__ __launch_bounds__(256) void sinc_poly_lds_kernel(ResampleArgs a, PolyArgs q, int win_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    double *s_poly = reinterpret_cast<double *>(dyn_lds);
+    int2 *s_cnt = reinterpret_cast<int2 *>(s_poly + q.L * q.row);
+    float *s_x = reinterpret_cast<float *>(s_cnt + q.L);
+    for (int i = threadIdx.x; i < q.L * q.row; i += 256) s_poly[i] = q.poly[i];
+    for (int i = threadIdx.x; i < q.L; i += 256) s_cnt[i] = q.count[i];
+    const double ratio = (double)a.out_rate / (double)a.in_rate;
+    const double scale = ((double)a.index_inc * (ratio < 1.0 ? ratio : 1.0)) / (double)a.index_inc;
+    const int max_l = q.right_off, max_r = q.row - q.right_off;
+    for (long k0 = (long)blockIdx.x * 256; k0 < a.n_out; k0 += (long)gridDim.x * 256) {
+        const long Kf = a.first_out + k0, Kl = a.first_out + (k0 + 255 < a.n_out ? k0 + 255 : a.n_out - 1);
+        const long win0 = (long)((unsigned long long)Kf * (unsigned long long)a.in_rate / (unsigned long long)a.out_rate) - (max_l - 1);
+        const long win1 = (long)((unsigned long long)Kl * (unsigned long long)a.in_rate / (unsigned long long)a.out_rate) + max_r;
+        const int W = (int)(win1 - win0 + 1);  // <= win_cap by the launcher's choice of this kernel
+        __syncthreads();                        // previous window fully consumed (and, first time, the tables are in place)
+        for (int i = threadIdx.x; i < W && i < win_cap; i += 256) s_x[i] = (float)tap(a, win0 + i);
+        __syncthreads();
+        const long k = k0 + threadIdx.x;
+        if (k < a.n_out) {
+            const long K = a.first_out + k;
+            const unsigned long long num = (unsigned long long)K * (unsigned long long)a.in_rate;
+            const long cur = (long)(num / (unsigned long long)a.out_rate);
+            const int m = (int)((num % (unsigned long long)a.out_rate) / (unsigned long long)q.g);
+            const int2 cnt = s_cnt[m];
+            const double *rowp = s_poly + m * q.row;
+            const float *xl = s_x + (cur - win0) - (cnt.x - 1);
+            double left = 0.0, right = 0.0;
+            for (int e = 0; e < cnt.x; ++e) left += rowp[e] * (double)xl[e];
+            const float *xr = s_x + (cur - win0) + cnt.y;
+            const double *rr = rowp + q.right_off;
+            for (int e = 0; e < cnt.y; ++e) right += rr[e] * (double)xr[-e];
+            a.out[k] = (float)(scale * (left + right));
+        }
+    }
+}
+
 double bessel_i0(double x) {
     double sum = 1.0, term = 1.0;
     for (int k = 1; k < 200; ++k) {
@@ -442,7 +483,13 @@ static int process_locked(bf_resampler *r, const float *d_in, size_t n_in, float
             q.index_inc = r->index_inc;
             q.table = r->d_table;
             if (blocks > 256 * 8) blocks = 256 * 8;  // every block copies the tables into its LDS first
-            hipLaunchKernelGGL(sinc_poly_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, q);
+            // input samples under one block's 256 outputs (+ both wings): staged in LDS when everything fits 64 KB of dynamic LDS
+            const long win = (255 * r->in_rate) / r->out_rate + 2 + r->poly_row;
+            const size_t lds_bytes = (size_t)r->poly_L * r->poly_row * sizeof(double) + (size_t)r->poly_L * sizeof(int2) + (size_t)win * sizeof(float);
+            if (lds_bytes <= 64 * 1024)
+                hipLaunchKernelGGL(sinc_poly_lds_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, s, a, q, (int)win);
+            else
+                hipLaunchKernelGGL(sinc_poly_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, q);
         } else {
             if (blocks > 256 * 32) blocks = 256 * 32;
             hipLaunchKernelGGL(sinc_resample_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
