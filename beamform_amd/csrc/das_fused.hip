@@ -312,13 +312,8 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             const float *b2 = (!b_ok ? a.zeros : xs + (long)mb * a.mic_stride + tc * kHop) + lane;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-#ifdef BF_DAS_HACK
-                re[j] = __builtin_bit_cast(float, 0x3c000000 + tid + j);
-                im[j] = __builtin_bit_cast(float, 0x3c100000 + tid + j);
-#else
                 re[j] = a1[32 * j];
                 im[j] = b1[32 * j];
-#endif
                 re[j + 16] = a2[32 * j];
                 im[j + 16] = b2[32 * j];
             }
@@ -347,9 +342,6 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                 const float *b2 = (!b_ok ? a.zeros : xs + (long)mb * a.mic_stride + tc * kHop) + lane;
 #pragma unroll
                 for (int jx = i0; jx < i0 + kChunk; ++jx) {
-#ifdef BF_DAS_HACK  // timing experiment only: the shared hop is not loaded (WRONG results)
-                    if (jx < 16) { re[jx] = __builtin_bit_cast(float, 0x3c000000 + tid + jx); im[jx] = __builtin_bit_cast(float, 0x3c100000 + tid + jx); continue; }
-#endif
                     re[jx] = jx < 16 ? a1[32 * jx] : a2[32 * (jx - 16)];
                     im[jx] = jx < 16 ? b1[32 * jx] : b2[32 * (jx - 16)];
                 }
