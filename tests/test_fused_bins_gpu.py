@@ -92,3 +92,32 @@ def test_fused_is_bit_identical_to_the_two_kernel_chain(tmp_path):
         res[mode] = np.load(f)
     for k in res["1"].files:
         assert np.array_equal(res["1"][k], res["0"][k]), k
+
+
+CHILD_FULL = r"""
+import sys, hashlib, numpy as np
+sys.path.insert(0, %r)
+import torch
+from beamform_amd.capi import Beamformer, BF_DAS_BINS_F64, BF_DAS_FUSED_F32
+from beamform_amd.params import make_params
+M, F = 8, 65536
+g = torch.Generator(device="cuda").manual_seed(5)
+x = (torch.rand((M, F * 512), device="cuda", generator=g) - 0.5) * 6.0     # loud enough to open phase's magnitude gate
+y = torch.empty(F * 512, device="cuda")
+for algo in ("das", "phase"):
+    bf = Beamformer(make_params(algo, n_mics=M, theta=-15.0), das_impl=BF_DAS_BINS_F64 if algo == "das" else BF_DAS_FUSED_F32)
+    bf.process_device(x.data_ptr(), F, y.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    print(algo, hashlib.sha1(y.cpu().numpy().tobytes()).hexdigest(), float(y.abs().mean()))
+"""
+
+
+def test_fused_equals_two_kernel_chain_at_the_baseline_size():
+    """BASELINE batch (8 microphones x 65 536 frames): the fused kernel and the two-kernel chain give the same bytes."""
+    outs = []
+    for mode in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", CHILD_FULL % ROOT], env=dict(os.environ, BF_FUSED_BINS=mode),
+                           capture_output=True, text=True, check=True)
+        outs.append([ln.split() for ln in r.stdout.strip().splitlines()])
+    assert len(outs[0]) == 2 and outs[0] == outs[1], outs
+    assert all(float(ln[2]) > 1e-3 for ln in outs[0])
