@@ -189,3 +189,22 @@ def test_das_w64_variant_matches_oracle(monkeypatch):
         assert rel_l2(yd.cpu().numpy(), y_ref) < TOL_TIME
         Yh = Yd.cpu().numpy().view(np.complex128)[..., 0]
         assert max(rel_l2(Yh[t], _herm(Y_ref)[t]) for t in range(F)) < TOL_SPECTRUM
+
+
+@pytest.mark.parametrize("M", [8, 4])
+def test_das_interleaved_equals_planar_at_the_baseline_size(M):
+    """65 536 frames: the 16-byte-load kernel for [sample][mic] input against the planar kernel on the transposed data
+    (same transform; the two kernels round the window multiply differently, hence a tolerance of a few float ulps)."""
+    torch = _torch()
+    from beamform_amd.capi import Beamformer, BF_INTERLEAVED
+    F = 65536
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand((M, F * 512), device="cuda", generator=g) - 0.5
+    xi = x.t().contiguous()
+    y, yi = torch.empty(F * 512, device="cuda"), torch.empty(F * 512, device="cuda")
+    p = make_params("das", n_mics=M, theta=-15.0)
+    s = torch.cuda.current_stream().cuda_stream
+    Beamformer(p).process_device(x.data_ptr(), F, y.data_ptr(), 0, s)
+    Beamformer(p, layout=BF_INTERLEAVED).process_device(xi.data_ptr(), F, yi.data_ptr(), 0, s)
+    torch.cuda.synchronize()
+    assert float((y - yi).abs().max()) <= 4e-7 * float(y.abs().max())
