@@ -164,6 +164,9 @@ __device__ __forceinline__ void wt_fft_inv(float (&re)[32], float (&im)[32], int
 //   twiddles: [k < 16][lane][2] = { W1024^(k lane), W1024^((k + 16) lane) }   (forward: positions brev5(k), brev5(k) + 1;
 //                                                                             backward: positions k, k + 16)
 //   gains:    [pair][m < 16][lane][2] = { D[2m][lane], D[2m + 1][lane] }
+// SPLIT: the second 32-point pass stops after its stages 0..2 (fft32_dif_head); the caller finishes it four positions at a time
+// with fft32_dif_tail and takes every finished group straight into the weight-and-sum
+template <bool SPLIT = false>
 __device__ __forceinline__ void wt_fft_fwd_p2(float (&re)[32], float (&im)[32], int lane, const float4 *tw2, unsigned base,
                                               const float *rp BF_STAMP_PARAMS) {
     fft32_dif<float, -1>(re, im);
@@ -187,7 +190,12 @@ __device__ __forceinline__ void wt_fft_fwd_p2(float (&re)[32], float (&im)[32], 
     wt_store_plane<false>(im, base);
     wt_load_row(im, rp);
     BF_STAMP(3);
-    fft32_dif<float, -1>(re, im);
+    if (SPLIT) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) fft32_dif_head<float, -1>(re, im, g);
+    } else {
+        fft32_dif<float, -1>(re, im);
+    }
     BF_STAMP(4);
 }
 __device__ __forceinline__ void wt_fft_inv_p2(float (&re)[32], float (&im)[32], int lane, const float4 *tw2, unsigned base,
@@ -330,10 +338,9 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
         const long tc = valid ? t : T1 - 1;
 
         if constexpr (UNR > 0 && LAYOUT == 0 && NPL > 0 && WT) {
-            constexpr int kChunk = BF_DAS_CHUNK;  // register positions whose loads are issued together (4 / 8 / 16 measured: see DESIGN.md)
             // exact pair count, planar input: the pair loop is unrolled and the loads of pair p + 1 are issued from inside
             // pair p's gain loop, eight register positions at a time, into the registers that loop has just consumed
-            auto rows = [&](int p, int i0) {
+            auto rows = [&](int p, int i0, int n) {
                 const int ma = 2 * p, mb = 2 * p + 1;
                 const bool b_ok = mb < M;  // odd microphone count: the last pair's partner channel reads the zero buffer
                 const float *a1 = (tc >= 1 ? xs + (long)ma * a.mic_stride + (tc - 1) * kHop : hs + ma * kHop) + lane;
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                 const float *a2 = xs + (long)ma * a.mic_stride + tc * kHop + lane;
                 const float *b2 = (!b_ok ? a.zeros : xs + (long)mb * a.mic_stride + tc * kHop) + lane;
 #pragma unroll
-                for (int jx = i0; jx < i0 + kChunk; ++jx) {
+                for (int jx = i0; jx < i0 + n; ++jx) {
                     re[jx] = jx < 16 ? a1[32 * jx] : a2[32 * (jx - 16)];
                     im[jx] = jx < 16 ? b1[32 * jx] : b2[32 * (jx - 16)];
                 }
@@ -357,12 +364,18 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                     re[4 * g + 3] *= hv.w; im[4 * g + 3] *= hv.w;
                 }
                 BF_STAMP(0);
-                wt_fft_fwd_p2(re, im, lane, reinterpret_cast<const float4 *>(lds), wbase, wrowp BF_STAMP_ARGS);
+                wt_fft_fwd_p2<true>(re, im, lane, reinterpret_cast<const float4 *>(lds), wbase, wrowp BF_STAMP_ARGS);
                 const float4 *gp2 = reinterpret_cast<const float4 *>(lds + kLdsFixed) + p * 512 + lane;
+                // the last two stages of the second pass run four register positions at a time; every finished group goes straight
+                // into the weight-and-sum and its registers to the next pair's loads, so those are spread over stages 3-4 AND the
+                // weight-and-sum (same butterflies, bit-identical output; -0.4 % at 8 microphones, -1.5 % at 4).  Taking the FIRST
+                // pass set by set in the order of those loads as well (so that the last-issued ones are needed last) was measured:
+                // the scheduling fences it needs cost more than the deferred wait saves (0.377 vs 0.347 ms).
 #pragma unroll
-                for (int c = 0; c < 32 / kChunk; ++c) {
+                for (int m = 0; m < 8; ++m) {
+                    fft32_dif_tail<float, -1>(re, im, m);
 #pragma unroll
-                    for (int i = kChunk * c; i < kChunk * c + kChunk; i += 2) {
+                    for (int i = 4 * m; i < 4 * m + 4; i += 2) {
                         const float4 g = gp2[16 * i];  // gains of positions i and i + 1
                         // accumulate with two chained FMAs per component (4 instructions per position instead of 6)
                         Sr[i] = bf_fma(-g.y, im[i], bf_fma(g.x, re[i], (p == 0) ? 0.f : Sr[i]));
@@ -372,7 +385,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                     }
                     if (p + 1 < UNR) {
                         __builtin_amdgcn_sched_barrier(0);
-                        rows(p + 1, kChunk * c);
+                        rows(p + 1, 4 * m, 4);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }

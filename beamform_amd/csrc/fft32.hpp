@@ -142,6 +142,31 @@ BF_HD void fft32_core(T (&re)[32], T (&im)[32]) {
     }
 }
 
+// fft32_dif (= fft32_core<T, DIR, true>) cut into pieces that touch disjoint register sets, so that a caller can interleave other work
+// (loads into registers that have just been released, gains on outputs that have just been finished) between them.  In that core
+// stage s pairs physical positions a and a + (16 >> s) (a's bit 4 - s clear) with twiddle (brev5(a) & ((1 << s) - 1)) * (16 >> s):
+//   stages 0..2 stay inside the four sets { g, g + 4, ..., g + 28 }   -> fft32_dif_head(g)
+//   stages 3..4 stay inside the eight sets { 4 m, ..., 4 m + 3 }      -> fft32_dif_tail(m)
+// head(0..3) followed by tail(0..7) is fft32_dif: the same butterflies with the same operands, only their order differs.
+template <typename T, int DIR>
+BF_HD void fft32_dif_piece(T (&re)[32], T (&im)[32], int s_lo, int s_hi, int first, int count, int stride) {
+#pragma unroll
+    for (int s = s_lo; s <= s_hi; ++s) {
+#pragma unroll
+        for (int n = 0; n < count; ++n) {
+            const int a = first + n * stride;
+            if (((a >> (4 - s)) & 1) == 0) {
+                const int b = a + (16 >> s);
+                bfly_dit<T, DIR>((brev5(a) & ((1 << s) - 1)) * (16 >> s), re[a], im[a], re[b], im[b]);
+            }
+        }
+    }
+}
+template <typename T, int DIR>
+BF_HD void fft32_dif_head(T (&re)[32], T (&im)[32], int g) { fft32_dif_piece<T, DIR>(re, im, 0, 2, g, 8, 4); }
+template <typename T, int DIR>
+BF_HD void fft32_dif_tail(T (&re)[32], T (&im)[32], int m) { fft32_dif_piece<T, DIR>(re, im, 3, 4, 4 * m, 4, 1); }
+
 // natural-order input, output X[brev5(i)] at position i
 template <typename T, int DIR>
 BF_HD void fft32_dif(T (&re)[32], T (&im)[32]) {
