@@ -369,8 +369,8 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                 // the last two stages of the second pass run four register positions at a time; every finished group goes straight
                 // into the weight-and-sum and its registers to the next pair's loads, so those are spread over stages 3-4 AND the
                 // weight-and-sum (same butterflies, bit-identical output; -0.4 % at 8 microphones, -1.5 % at 4).  Taking the FIRST
-                // pass set by set in the order of those loads as well (so that the last-issued ones are needed last) was measured:
-                // the scheduling fences it needs cost more than the deferred wait saves (0.377 vs 0.347 ms).
+                // pass set by set in the order of those loads as well (so that the last-issued ones are needed last) needs a second
+                // register set for the incoming pair: built and measured, 256 VGPRs + 17 scratch operations, 0.349 vs 0.334 ms.
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     fft32_dif_tail<float, -1>(re, im, m);
