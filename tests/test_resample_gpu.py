@@ -125,3 +125,39 @@ def test_polyphase_and_generic_paths_agree():
         y = g.process(x)
         ref = resample_vectorised(x, *rates, coeffs=fine, index_inc=384)
         assert len(y) == len(ref) and np.max(np.abs(y - ref)) <= 1e-6 * np.max(np.abs(ref))
+
+
+def test_handle_is_safe_against_a_second_thread():
+    """process() from one thread while another polls latency / out_count and resets now and then: no crash, no torn state
+    (every returned block has the length the handle announced for it, and after a final reset the stream restarts exactly)."""
+    import threading
+    rng = np.random.default_rng(31)
+    x = (0.2 * rng.standard_normal(512)).astype(np.float32)
+    g = capi.Resampler(48000, 16000)
+    stop = threading.Event()
+    errors = []
+
+    def poll():
+        k = 0
+        while not stop.is_set():
+            try:
+                assert g.latency == 59
+                g.out_count(512)
+                k += 1
+                if k % 50 == 0:
+                    g.reset()
+            except Exception as e:  # pragma: no cover
+                errors.append(e)
+
+    t = threading.Thread(target=poll)
+    t.start()
+    try:
+        for _ in range(300):
+            y = g.process(x)
+            assert len(y) in (151, 170, 171)      # 512 / 3 samples per period, or the first period after a reset (59 held back)
+    finally:
+        stop.set()
+        t.join()
+    assert not errors
+    g.reset()
+    assert np.array_equal(g.process(x), capi.Resampler(48000, 16000).process(x))
