@@ -419,7 +419,28 @@ def main():
         def rs_lat(a_, b_):
             return int(round(2464 / 128 * max(1.0, a_ / b_))) + 1
 
+        def hop_line():
+            # the drop-in path itself: one jack_callback per call (host buffers in, host buffer out), 512-frame period
+            import numpy as np
+            out = {"workload": "bf_process_hop, one 512-frame period per call from host buffers (the reference's jack_callback); "
+                               "median wall time per call; the JACK real-time budget at 48 kHz is 10 667 us"}
+            for algo_ in ("das", "mvdr", "phasempf"):
+                bh = Beamformer(make_params(algo_, n_mics=M), device=local_rank)
+                seg = np.random.default_rng(3).standard_normal((M, HOP)).astype(np.float32) * 0.1
+                for _ in range(30):
+                    bh.process_hop(seg)
+                ts = []
+                for _ in range(200):
+                    t0 = time.perf_counter()
+                    bh.process_hop(seg)
+                    ts.append(time.perf_counter() - t0)
+                bh.close()
+                ts.sort()
+                out[f"{algo_}_us_per_callback"] = ts[len(ts) // 2] * 1e6
+            return out
+
         jobs.append(("resample_48k_16k", resample_line))
+        jobs.append(("streaming_callback", hop_line))
         for name, job in jobs:
             try:
                 extra[name] = job()
