@@ -43,8 +43,8 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
     const int j = q_bin(qq);
     const double f = fabs(a.freqs[j]);
     const bool inband = live && f >= a.cfg.freq_min && f <= a.cfg.freq_max;
-    f64x2 *yout = a.Yh + ((long)s * a.n_frames) * kYhStride + qq;
-    const f64x2 *Zs = a.Z + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
+    const long yidx = ((long)s * a.n_frames) * kYhStride + qq;
+    const z48 *Zs = reinterpret_cast<const z48 *>(a.Z) + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
     const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
     if (__builtin_amdgcn_ballot_w64(inband) == 0) {  // whole wavefront out of band (mvdr.cpp:103) or bin 0 (:76)
         if (live)
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
                     load_X<MP>(Zs + t * NP * kN, qq, M, X);
                     y = X[0];
                 }
-                yout[t * kYhStride] = f64x2{y.x, y.y};
+                st_y(a, yidx + t * kYhStride, qq, y);
             }
         return;
     }
@@ -67,23 +67,28 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
     // instruction, lane l lands at row base + 16 l): a wavefront that owns its SIMD has nobody to hide HBM latency
     // behind, and the PMC profile of the register-only version showed 57 % of its cycles in s_waitcnt.
     // Row 2p / 2p+1 = Z_t[p][k] / Z_t[p][N-k]; rows MP + 2p, MP + 2p + 1 = the same of frame t - P (leaving the window).
-    __shared__ __attribute__((aligned(16))) f64x2 s_pf[2][2 * MP][64];
+    // global_load_lds_dwordx3 puts lane l's 12 bytes at row base + 16 l (measured: tools/ubench/lds_dma_x3.hip), so a row is 64 slots of 16 bytes
+    struct alignas(16) z48slot {
+        z48 v;
+        unsigned pad;
+    };
+    __shared__ z48slot s_pf[2][2 * MP][64];
     const int lane = threadIdx.x;
     const int ksrc = q_src_bin(qq), kneg = (kN - ksrc) & (kN - 1);
     auto dma_frame = [&](long t, bool with_old, int buf) {
-        const f64x2 *Zn = Zs + t * NP * kN, *Zo = Zs + (t - P) * NP * kN;
+        const z48 *Zn = Zs + t * NP * kN, *Zo = Zs + (t - P) * NP * kN;
 #pragma unroll
         for (int p = 0; p < MP / 2; ++p)
             if (2 * p < M) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Zn + p * kN + ksrc),
-                                                 (__attribute__((address_space(3))) void *)&s_pf[buf][2 * p][0], 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)&s_pf[buf][2 * p][0], 12, 0, 0);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Zn + p * kN + kneg),
-                                                 (__attribute__((address_space(3))) void *)&s_pf[buf][2 * p + 1][0], 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)&s_pf[buf][2 * p + 1][0], 12, 0, 0);
                 if (with_old) {
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Zo + p * kN + ksrc),
-                                                     (__attribute__((address_space(3))) void *)&s_pf[buf][MP + 2 * p][0], 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void *)&s_pf[buf][MP + 2 * p][0], 12, 0, 0);
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Zo + p * kN + kneg),
-                                                     (__attribute__((address_space(3))) void *)&s_pf[buf][MP + 2 * p + 1][0], 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void *)&s_pf[buf][MP + 2 * p + 1][0], 12, 0, 0);
                 }
             }
     };
@@ -91,8 +96,8 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
 #pragma unroll
         for (int p = 0; p < MP / 2; ++p) {
             if (2 * p < M) {
-                const cd z = ld(&s_pf[buf][base + 2 * p][lane]);
-                const cd zc = conj(ld(&s_pf[buf][base + 2 * p + 1][lane]));
+                const cd z = ld(&s_pf[buf][base + 2 * p][lane].v);
+                const cd zc = conj(ld(&s_pf[buf][base + 2 * p + 1][lane].v));
                 cd xa = (z + zc) * 0.5;
                 const cd d = z - zc;
                 cd xb = cd{0.5 * d.y, -0.5 * d.x};
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
         if (!(mag > a.cfg.freq_mag_threshold)) y = X[0] * 0.01;  // mvdr.cpp:96
         if (!inband) y = cd{0, 0};
         if (j == 0) y = X[0];
-        if (live) yout[t * kYhStride] = f64x2{y.x, y.y};
+        if (live) st_y(a, yidx + t * kYhStride, qq, y);
         // slide the covariance window (mvdr.cpp:100-101)
         cd Xo[MP];
         unpack(pb, MP, Xo);
@@ -238,15 +243,15 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
     const int M = a.n_mics, NP = (M + 1) >> 1, KP1 = a.kp1, P = a.cfg.past_windows;
     const int j = q_bin(q);
     const bool lcmv = a.cfg.algo == BF_LCMV;
-    f64x2 *yout = a.Yh + ((long)s * a.n_frames) * kYhStride + q;
-    const f64x2 *Zs = a.Z + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;  // frame 0 of this batch
+    const long yidx = ((long)s * a.n_frames) * kYhStride + q;
+    const z48 *Zs = reinterpret_cast<const z48 *>(a.Z) + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;  // frame 0 of this batch
     const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
 
     // one microphone's spectrum at this problem's bin, frame t (may be negative: history)
     const int ksrc = q_src_bin(q), kneg = (kN - ksrc) & (kN - 1);
     auto load_xi = [&](long t) -> cd {
         if (i >= M) return cd{0, 0};
-        const f64x2 *Zf = Zs + t * NP * kN + (i >> 1) * kN;
+        const z48 *Zf = Zs + t * NP * kN + (i >> 1) * kN;
         const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
         cd x;
         if ((i & 1) == 0) {
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
                 y = s_x[grp][0];
                 __builtin_amdgcn_wave_barrier();
             }
-            if (i == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+            if (i == 0) st_y(a, yidx + t * kYhStride, q, y);
         }
         return;
     }
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
         } else {
             y = s_x[grp][0] * 0.01;  // in_fft(0,j)*0.01 (mvdr.cpp:96)
         }
-        if (i == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+        if (i == 0) st_y(a, yidx + t * kYhStride, q, y);
         // slide the covariance window: + x_t x_t^H - x_{t-P} x_{t-P}^H (mvdr.cpp:100-101)
 #pragma unroll
         for (int c = 0; c < MP; ++c) R[c] = cfms_conj(cfma_conj(R[c], x, s_x[grp][c]), xo, s_xo[grp][c]);
@@ -496,13 +501,13 @@ __global__ __launch_bounds__(64, 1) void mvdr_lcmv_lanes_kernel(BinsArgs a, int 
     const bool lcmv = a.cfg.algo == BF_LCMV;
     const double f = fabs(a.freqs[j]);
     const bool inband = live && f >= a.cfg.freq_min && f <= a.cfg.freq_max && !(j == 0 && !lcmv);
-    f64x2 *yout = a.Yh + ((long)s * a.n_frames) * kYhStride + qq;
-    const f64x2 *Zs = a.Z + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
+    const long yidx = ((long)s * a.n_frames) * kYhStride + qq;
+    const z48 *Zs = reinterpret_cast<const z48 *>(a.Z) + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
     const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
     const int ksrc = q_src_bin(qq), kneg = (kN - ksrc) & (kN - 1);
     auto load_mic = [&](long t, int m) -> cd {  // spectrum of microphone m at this bin, frame t
         if (m >= M) return cd{0, 0};
-        const f64x2 *Zf = Zs + t * NP * kN + (m >> 1) * kN;
+        const z48 *Zf = Zs + t * NP * kN + (m >> 1) * kN;
         const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
         cd x;
         if ((m & 1) == 0) {
@@ -518,7 +523,7 @@ __global__ __launch_bounds__(64, 1) void mvdr_lcmv_lanes_kernel(BinsArgs a, int 
             for (long t = tA; t < tB; ++t) {
                 cd y{0, 0};
                 if (j == 0 && !lcmv) y = load_mic(t, 0);  // mvdr.cpp:76
-                yout[t * kYhStride] = f64x2{y.x, y.y};
+                st_y(a, yidx + t * kYhStride, qq, y);
             }
         return;
     }
@@ -686,7 +691,7 @@ __global__ __launch_bounds__(64, 1) void mvdr_lcmv_lanes_kernel(BinsArgs a, int 
             y = x0 * 0.01;  // mvdr.cpp:96
         }
         if (!inband) y = (j == 0 && !lcmv) ? x0 : cd{0, 0};
-        if (live && q == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+        if (live && q == 0) st_y(a, yidx + t * kYhStride, qq, y);
         rank1(xl, xo, true);  // slide the covariance window (mvdr.cpp:100-101)
     }
 #undef TIX
@@ -753,13 +758,13 @@ __global__ __launch_bounds__(256, 2) void mvdr_lcmv_row_kernel(BinsArgs a, int t
     const int M = a.n_mics, NP = (M + 1) >> 1, KP1 = a.kp1, P = a.cfg.past_windows;
     const int j = q_bin(q);
     const bool lcmv = a.cfg.algo == BF_LCMV;
-    f64x2 *yout = a.Yh + ((long)s * a.n_frames) * kYhStride + q;
-    const f64x2 *Zs = a.Z + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
+    const long yidx = ((long)s * a.n_frames) * kYhStride + q;
+    const z48 *Zs = reinterpret_cast<const z48 *>(a.Z) + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
     const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
     const int ksrc = q_src_bin(q), kneg = (kN - ksrc) & (kN - 1);
     auto load_xi = [&](long t) -> cd {
         if (i >= M) return cd{0, 0};
-        const f64x2 *Zf = Zs + t * NP * kN + (i >> 1) * kN;
+        const z48 *Zf = Zs + t * NP * kN + (i >> 1) * kN;
         const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
         cd x;
         if ((i & 1) == 0) {
@@ -776,7 +781,7 @@ __global__ __launch_bounds__(256, 2) void mvdr_lcmv_row_kernel(BinsArgs a, int t
         for (long t = tA; t < tB; ++t) {
             cd y{0, 0};
             if (!lcmv && j == 0) y = rowbc<0>(load_xi(t));  // mvdr.cpp:76
-            if (i == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+            if (i == 0) st_y(a, yidx + t * kYhStride, q, y);
         }
         return;
     }
@@ -889,7 +894,7 @@ __global__ __launch_bounds__(256, 2) void mvdr_lcmv_row_kernel(BinsArgs a, int t
         } else {
             y = rowbc<0>(x) * 0.01;  // in_fft(0,j)*0.01 (mvdr.cpp:96)
         }
-        if (i == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+        if (i == 0) st_y(a, yidx + t * kYhStride, q, y);
         // slide the covariance window: + x_t x_t^H - x_{t-P} x_{t-P}^H (mvdr.cpp:100-101)
         const cd xo = load_xi(t - P);  // loaded late: 4 registers less across the factorisation
         RowStep<0, MP>::run([&](auto cc) {
@@ -961,8 +966,8 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
     const int qq = live ? pq : kNQ - 1;
     const int j = q_bin(qq);
     const bool lcmv = a.cfg.algo == BF_LCMV;
-    f64x2 *yout = a.Yh + ((long)s * a.n_frames) * kYhStride + qq;
-    const f64x2 *Zs = a.Z + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
+    const long yidx = ((long)s * a.n_frames) * kYhStride + qq;
+    const z48 *Zs = reinterpret_cast<const z48 *>(a.Z) + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
     const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
     const int ksrc = q_src_bin(qq), kneg = (kN - ksrc) & (kN - 1);
     const int addrT = 4 * ((lane & ~15) | (q << 2) | p);  // my transpose partner (q, p)
@@ -970,7 +975,7 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
     // microphone l16's spectrum at this bin, frame t (may be negative: history)
     auto load_mic = [&](long t) -> cd {
         if (l16 >= M) return cd{0, 0};
-        const f64x2 *Zf = Zs + t * NP * kN + (l16 >> 1) * kN;
+        const z48 *Zf = Zs + t * NP * kN + (l16 >> 1) * kN;
         const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
         cd x;
         if ((l16 & 1) == 0) {
@@ -999,7 +1004,7 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
         for (long t = tA; t < tB; ++t) {
             cd y{0, 0};
             if (j == 0 && !lcmv) y = rowbc<0>(load_mic(t));  // mvdr.cpp:76
-            if (live && l16 == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+            if (live && l16 == 0) st_y(a, yidx + t * kYhStride, qq, y);
         }
         return;
     }
@@ -1144,7 +1149,7 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
             y = x0 * 0.01;  // in_fft(0,j)*0.01 (mvdr.cpp:96)
         }
         if (!inband) y = (j == 0 && !lcmv) ? x0 : cd{0, 0};
-        if (live && l16 == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
+        if (live && l16 == 0) st_y(a, yidx + t * kYhStride, qq, y);
         // slide the covariance window: + x_t x_t^H - x_{t-P} x_{t-P}^H (mvdr.cpp:100-101).  x_t is read back from its LDS slot
         // (still there) instead of being kept in 32 registers across the factorisation.
         cd xor_[4], xoc[4];

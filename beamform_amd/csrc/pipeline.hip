@@ -60,6 +60,8 @@ class BinPipelineImpl : public BinPipeline {
         const bool multi = (c.algo == BF_LCMV || c.algo == BF_GSS);
         KP1_ = multi ? c.n_interf + 1 : 1;
         Phist_ = (c.algo == BF_MVDR || c.algo == BF_LCMV) ? c.past_windows : 0;
+        z48_ = (c.algo == BF_MVDR || c.algo == BF_LCMV);  // packed spectra as 12-byte z48 elements (pipeline_kernels.hpp)
+        zsz_ = z48_ ? sizeof(z48) : sizeof(f64x2);
     }
     ~BinPipelineImpl() override { free_all(); }
 
@@ -193,7 +195,7 @@ class BinPipelineImpl : public BinPipeline {
 
    private:
     size_t steer_bytes() const { return (size_t)D_ * N_ * M_ * kMaxCols * sizeof(f64x2); }
-    size_t zhist_bytes() const { return Phist_ ? (size_t)S_ * Phist_ * NP_ * N_ * sizeof(f64x2) : 0; }
+    size_t zhist_bytes() const { return Phist_ ? (size_t)S_ * Phist_ * NP_ * N_ * zsz_ : 0; }
     // recursive per-beam state is sized by OUTPUT streams (input streams x look directions)
     size_t gss_bytes() const { return cfg_.algo == BF_GSS ? (size_t)So_ * N_ * kMaxCols * M_ * sizeof(f64x2) : 0; }
     size_t mpf_bytes() const {
@@ -239,6 +241,8 @@ class BinPipelineImpl : public BinPipeline {
 
     bf_config cfg_;
     int n_cus_, M_, MF_, NP_, S_, D_, So_, KP1_, Phist_;
+    bool z48_ = false;
+    size_t zsz_ = sizeof(f64x2);  // bytes per packed-spectrum element
     int H_ = 512, N_ = 1024, NQ_ = 514, YS_ = 516;  // hop, FFT size, problems per frame, row stride of Yh
     const KernelSet *ks_ = nullptr;                 // launchers compiled for N_
     long steer_dir_stride_ = 0;
@@ -251,7 +255,7 @@ class BinPipelineImpl : public BinPipeline {
     float *d_hist_ = nullptr;
     float *d_tail_[2] = {nullptr, nullptr};
     int tail_cur_ = 0;
-    f64x2 *d_zhist_ = nullptr;   // [stream][Phist][NP][1024]: packed spectra of the previous Phist frames
+    f64x2 *d_zhist_ = nullptr;   // [stream][Phist][NP][1024] elements of zsz_ bytes: packed spectra of the previous Phist frames
     f64x2 *d_gssW_ = nullptr;    // [stream][bin][KP1][M]
     double *d_mpf_ = nullptr;    // [stream][kMpfVecs*1024 + 8]
     double *d_smooth_ = nullptr; // [stream][64]
@@ -281,7 +285,7 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
                            (cfg_.algo == BF_DAS || cfg_.algo == BF_PHASE || cfg_.algo == BF_PHASEMPF);
     int rc = BF_OK;
     if (!try_fused)
-        rc = ensure((void **)&d_Z_, &Z_cap_, (size_t)S_ * FT * NP_ * N_ * sizeof(f64x2));
+        rc = ensure((void **)&d_Z_, &Z_cap_, (size_t)S_ * FT * NP_ * N_ * zsz_);
     else  // the fused kernel parks the unpacked spectra of two bins per frame here (stream x frame x 2 x 8 microphones)
         rc = ensure((void **)&d_Z_, &Z_cap_, (size_t)S_ * F * 2 * 8 * sizeof(f64x2));
     if (rc != BF_OK) return rc;
@@ -301,15 +305,15 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
 
     // covariance history in front of the new frames
     if (Phist_ > 0)
-        PIPE_HIP(hipMemcpy2DAsync(d_Z_, (size_t)FT * frame_elems * sizeof(f64x2), d_zhist_,
-                                  (size_t)Phist_ * frame_elems * sizeof(f64x2), (size_t)Phist_ * frame_elems * sizeof(f64x2),
-                                  (size_t)S_, hipMemcpyDeviceToDevice, stream));
+        PIPE_HIP(hipMemcpy2DAsync(d_Z_, (size_t)FT * frame_elems * zsz_, d_zhist_, (size_t)Phist_ * frame_elems * zsz_,
+                                  (size_t)Phist_ * frame_elems * zsz_, (size_t)S_, hipMemcpyDeviceToDevice, stream));
 
     StftArgs sa;
     sa.x = x; sa.hist = d_hist_; sa.Z = d_Z_; sa.tw = d_tw_; sa.win = d_win_;
     sa.n_frames = F; sa.frames_ws = FT; sa.frame_off = Phist_; sa.mic_stride = mic_stride;
     sa.stream_stride_x = (long)M_ * F * H_; sa.n_streams = S_; sa.n_mics = M_; sa.n_fft_mics = MF_; sa.layout = layout;
     sa.skip_lo = N_; sa.skip_hi = 0;  // store everything ...
+    sa.z48 = z48_ ? 1 : 0; sa.run_len = 1;
     if (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS) {
         // ... except, for the band-limited nodes, the bins between the highest in-band bin k and its mirror N-k
         // (quirk Q1 makes bins 511..513 irregular: only skip when the band ends below them)
@@ -329,6 +333,23 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     ba.n_frames = F; ba.frames_ws = FT; ba.frame_off = Phist_; ba.n_streams = So_; ba.n_mics = MF_; ba.kp1 = snap.kp1;
     ba.n_dirs = D_; ba.steer_dir_stride = snap.steer_dir_stride;
     ba.cfg = cfg_; ba.gssW = d_gssW_; ba.mpf = d_mpf_; ba.gss_reset_mask = snap.gss_reset_mask;
+    // backward transform in fp32 (no error amplification behind the per-bin stage; output is float32), except for gsc, whose
+    // sample-serial NLMS branches on the aligned signals
+    static const bool istft_f64 = getenv("BF_ISTFT_F64") && atoi(getenv("BF_ISTFT_F64")) != 0;
+    const bool istft32 = !(cfg_.algo == BF_GSC || istft_f64 || N_ != 1024);
+    // mvdr / lcmv hand the fp32 transform f32x2 rows holding only problem 0 and the in-band problems (everything else is zero,
+    // mvdr.cpp:103); a spectrum dump keeps the f64x2 rows
+    ba.yh32 = (z48_ && istft32 && spectrum == nullptr) ? 1 : 0;
+    ba.yh_lo = 0; ba.yh_hi = NQ_ - 1;
+    if (ba.yh32) {
+        int klo = N_, khi = 0;
+        for (int q = 1; q < NQ_; ++q) {
+            const double f = std::fabs(freqs_[q]);  // problem q = bin q for q <= N/2 + 1
+            if (f >= cfg_.freq_min && f <= cfg_.freq_max) { if (q < klo) klo = q; if (q > khi) khi = q; }
+        }
+        if (khi < N_ / 2 - 1 && klo <= khi) { ba.yh_lo = klo; ba.yh_hi = khi; }
+        else if (klo > khi) { ba.yh_lo = 1; ba.yh_hi = 0; }  // empty band: only problem 0
+    }
     bool fused = false;
     if (try_fused) {
         const hipError_t fe = ks_->stft_bins(sa, ba, n_cus_, stream);
@@ -359,17 +380,15 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     if (!fused) PIPE_HIP(ks_->bins(ba, n_cus_, stream));
 
     if (Phist_ > 0)  // keep the last Phist frames' spectra for the next call
-        PIPE_HIP(hipMemcpy2DAsync(d_zhist_, (size_t)Phist_ * frame_elems * sizeof(f64x2), d_Z_ + (size_t)F * frame_elems,
-                                  (size_t)FT * frame_elems * sizeof(f64x2), (size_t)Phist_ * frame_elems * sizeof(f64x2),
-                                  (size_t)S_, hipMemcpyDeviceToDevice, stream));
+        PIPE_HIP(hipMemcpy2DAsync(d_zhist_, (size_t)Phist_ * frame_elems * zsz_, (const char *)d_Z_ + (size_t)F * frame_elems * zsz_,
+                                  (size_t)FT * frame_elems * zsz_, (size_t)Phist_ * frame_elems * zsz_, (size_t)S_,
+                                  hipMemcpyDeviceToDevice, stream));
 
     IstftArgs ia;
     ia.Yh = d_Yh_; ia.y = (cfg_.algo == BF_PHASEMPF || cfg_.algo == BF_GSC) ? d_yraw_ : y; ia.tail_in = d_tail_[tail_cur_];
     ia.tail_out = d_tail_[tail_cur_ ^ 1]; ia.tw = d_tw_; ia.win = d_win_; ia.n_frames = F; ia.n_streams = So_;
-    // backward transform in fp32 (no error amplification behind the per-bin stage; output is float32), except for gsc, whose
-    // sample-serial NLMS branches on the aligned signals
-    static const bool istft_f64 = getenv("BF_ISTFT_F64") && atoi(getenv("BF_ISTFT_F64")) != 0;
-    ia.tw32 = (cfg_.algo == BF_GSC || istft_f64 || N_ != 1024) ? nullptr : d_tw32_;
+    ia.tw32 = istft32 ? d_tw32_ : nullptr;
+    ia.yh32 = ba.yh32; ia.yh_lo = ba.yh_lo; ia.yh_hi = ba.yh_hi;
     ia.frames = d_frames_;
     ia.post_amp = (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS) ? cfg_.out_amp : 1.0;
     ia.use_post_amp = (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS) ? 1 : 0;

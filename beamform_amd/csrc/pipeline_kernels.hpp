@@ -35,21 +35,35 @@ constexpr int kQX = kN / 2 + 1;   // the extra problem: bin N/2+1, whose X is th
 }  // namespace BF_NTAG
 #endif
 
+// Packed pair spectrum element of the covariance nodes (mvdr / lcmv): the top 48 bits of each component of a complex double
+// (sign, exponent, 36 mantissa bits; round to nearest), 12 bytes instead of 16.  Every in-band spectrum crosses the fabric three
+// times (stored once, read as the newest and as the oldest frame of the sliding covariance), so the element size sets the
+// chain's traffic; 2^-37 relative on X moves the solved spectrum by < 1e-10 relative L2 at cond(R) = 3e4 (tools/z48_precision.py),
+// and the magnitude gate (mvdr.cpp:85) flips with probability ~1e-11 per bin-frame.  Decoding is two 32-bit operations.
+struct z48 {
+    unsigned re_hi, im_hi, lo;  // lo = re's bits 16..31 of the low dword | im's bits 16..31 << 16
+};
+
 struct StftArgs {
     const float *x;
     const float *hist;  // hop before frame 0, layout as x
-    f64x2 *Z;           // [stream][frames_ws][NP][N]
+    f64x2 *Z;           // [stream][frames_ws][NP][N] f64x2 -- or z48 elements (reinterpret) when `z48` is set
     const f64x2 *tw;
     const double *win;
     long n_frames, frames_ws, frame_off, mic_stride, stream_stride_x;
     int n_streams, n_mics, layout;
     int n_fft_mics;        // channels actually transformed (= n_mics; 1 for the single-channel mcra node)
     int skip_lo, skip_hi;  // packed-spectrum bins in (skip_lo, skip_hi) are never read by the per-bin kernel: not stored
+    int z48;               // store z48 elements (mvdr / lcmv)
+    int run_len;           // consecutive frames one half-wavefront walks (N = 1024): the shared hop stays in registers
 };
 
 struct BinsArgs {
-    const f64x2 *Z;      // [stream][frames_ws][NP][N]
-    f64x2 *Yh;           // [stream][n_frames][kYhStride]: y_fft of problems q = 0..N/2+1
+    const f64x2 *Z;      // [stream][frames_ws][NP][N] f64x2 (z48 elements for mvdr / lcmv: reinterpret)
+    f64x2 *Yh;           // [stream][n_frames][kYhStride]: y_fft of problems q = 0..N/2+1 (f32x2 rows when yh32)
+    int yh32;            // mvdr / lcmv in front of the fp32 backward transform: rows are f32x2 and only the problems
+                         // 0 and yh_lo..yh_hi are written (the rest is zero by definition: mvdr.cpp:103) -- istft32 knows
+    int yh_lo, yh_hi;
     f64x2 *spectrum;     // nullable: [stream][n_frames][N] full y_fft dump
     const f64x2 *steer;  // [dir][col][mic][N]
     const double *freqs; // [N]
@@ -64,6 +78,8 @@ struct BinsArgs {
 };
 struct IstftArgs {
     const f64x2 *Yh;
+    int yh32;              // rows are f32x2; problems outside {0} + [yh_lo, yh_hi] are zero and were never written
+    int yh_lo, yh_hi;
     float *y;              // [stream][n_frames*hop]
     const float *tail_in;  // [stream][hop]
     float *tail_out;

@@ -11,87 +11,112 @@ namespace {
 // ======================================================================================
 //                                        STFT
 // ======================================================================================
-// One 512-thread block per CU: 16 half-wavefronts = two wavefronts per SIMD (the 256-thread version ran one, and its PMC
-// profile showed 34 % of the wave cycles in s_waitcnt: nobody to hide the input loads / spectrum stores behind).
-// LDS = 16 KB inter-pass twiddles + 16 x 8.5 KB transpose planes = 152 KB; the window comes from global memory in natural
-// order (lane l reads win[32 j + l]: coalesced, 8 KB, L1-resident), which is what made room for the second half.
-template <int LAYOUT, int kStftBlock, bool TW_LDS>
-__global__ __launch_bounds__(kStftBlock) void stft_kernel(StftArgs a) {
-    constexpr int kStftHalves = kStftBlock / 32;
-    constexpr int kTw = TW_LDS ? 2048 : 0;
-    __shared__ __attribute__((aligned(16))) double lds[kTw + kStftHalves * 32 * kPSd];
-    const cx<double> *s_tw = TW_LDS ? reinterpret_cast<const cx<double> *>(lds) : reinterpret_cast<const cx<double> *>(a.tw);
+// One 256-thread block per CU (LDS = 16 KB inter-pass twiddles + 8 x 8.5 KB transpose planes = 84 KB; a 512-thread block
+// spills at 256 registers).  A half-wavefront owns (stream, microphone pair, run of `run_len` consecutive frames) and walks
+// the run: the hop two consecutive frames share (50 % overlap, util.h:217-242) stays in registers as raw float samples, so
+// every input sample is fetched ONCE (the item-per-frame version fetched 1.5x: counters, profiles/traffic_mvdr8.json of
+// round 2), and the next hop is requested before the current frame is transformed -- a wavefront alone on its SIMD has
+// nobody else to hide the load latency behind.  The window lives in registers for the whole run.
+// Z48: the packed pair spectrum leaves as z48 elements (mvdr / lcmv).
+template <int LAYOUT, bool Z48>
+__global__ __launch_bounds__(256) void stft_kernel(StftArgs a) {
+    constexpr int kStftBlock = 256, kStftHalves = kStftBlock / 32;
+    __shared__ __attribute__((aligned(16))) double lds[2048 + kStftHalves * 32 * kPSd];
+    const cx<double> *s_tw = reinterpret_cast<const cx<double> *>(lds);
     const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
-    double *pbuf = lds + kTw + hw * 32 * kPSd;
-    if (TW_LDS) {
+    double *pbuf = lds + 2048 + hw * 32 * kPSd;
+    {
         const double *twf = reinterpret_cast<const double *>(a.tw);
         for (int i = tid; i < 2048; i += kStftBlock) lds[i] = twf[i];
         __syncthreads();
     }
-    const double *gwin = a.win + lane;
-    const int M = a.n_mics, MF = a.n_fft_mics, NP = (MF + 1) >> 1;
-    const long total = (long)a.n_streams * a.n_frames * NP;
+    double win[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) win[j] = a.win[32 * j + lane];
+    const int M = a.n_mics, MF = a.n_fft_mics, NP = (MF + 1) >> 1, L = a.run_len;
+    const long runs = (a.n_frames + L - 1) / L;
+    const long total = (long)a.n_streams * runs * NP;
     const long stride = (long)gridDim.x * kStftHalves;
     const long rounds = (total + stride - 1) / stride;
-    double re[32], im[32];
     for (long r = 0; r < rounds; ++r) {
         long item = r * stride + (long)blockIdx.x * kStftHalves + hw;
         const bool ok = item < total;
         if (!ok) item = total - 1;
         const int p = (int)(item % NP);
-        const long st = item / NP;
-        const long t = st % a.n_frames;
-        const int s = (int)(st / a.n_frames);
+        const long sr = item / NP;
+        const long run = sr % runs;
+        const int s = (int)(sr / runs);
+        const long t0 = run * L;
         const float *xs = a.x + (long)s * a.stream_stride_x;
         const float *hs = a.hist + (long)s * M * kHop;
         const int ma = 2 * p;
         const bool b_ok = 2 * p + 1 < MF;
         const int mb = b_ok ? 2 * p + 1 : ma;
-        if (LAYOUT == 0) {
-            const float *a1 = (t >= 1 ? xs + (long)ma * a.mic_stride + (t - 1) * kHop : hs + ma * kHop) + lane;
-            const float *b1 = (t >= 1 ? xs + (long)mb * a.mic_stride + (t - 1) * kHop : hs + mb * kHop) + lane;
-            const float *a2 = xs + (long)ma * a.mic_stride + t * kHop + lane;
-            const float *b2 = xs + (long)mb * a.mic_stride + t * kHop + lane;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                re[j] = (double)a1[32 * j];
-                im[j] = (double)b1[32 * j];
-                re[j + 16] = (double)a2[32 * j];
-                im[j + 16] = (double)b2[32 * j];
-            }
-        } else {
-            const float *s1 = (t >= 1 ? xs + (t - 1) * (long)kHop * M : hs) + (long)lane * M;
-            const float *s2 = xs + t * (long)kHop * M + (long)lane * M;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                re[j] = (double)s1[(long)32 * j * M + ma];
-                im[j] = (double)s1[(long)32 * j * M + mb];
-                re[j + 16] = (double)s2[(long)32 * j * M + ma];
-                im[j + 16] = (double)s2[(long)32 * j * M + mb];
-            }
-        }
         const double bs = b_ok ? 1.0 : 0.0;
+        // hop h of this pair (h = -1: the carried hop in front of the batch) as raw samples, lane l <- sample 32 j + l
+        auto load_hop = [&](long h, float (&va)[16], float (&vb)[16]) {
+            if (LAYOUT == 0) {
+                const float *pa = (h >= 0 ? xs + (long)ma * a.mic_stride + h * kHop : hs + ma * kHop) + lane;
+                const float *pb = (h >= 0 ? xs + (long)mb * a.mic_stride + h * kHop : hs + mb * kHop) + lane;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const double h = gwin[32 * j];
-            re[j] *= h;          // buf[j]*hann_win[i]  (util.h:235)
-            im[j] *= h * bs;
-        }
-        fft1024p_fwd_A<double>(re, im, lane, s_tw, pbuf);
-        __builtin_amdgcn_wave_barrier();
-        fft1024p_B<double>(re, lane, pbuf);
-        __builtin_amdgcn_wave_barrier();
-        fft1024p_C<double, false>(im, lane, pbuf);
-        __builtin_amdgcn_wave_barrier();
-        fft1024p_D<double, -1>(re, im, lane, pbuf);
-        __builtin_amdgcn_wave_barrier();
-        if (ok) {
-            f64x2 *zo = a.Z + (((long)s * a.frames_ws + a.frame_off + t) * NP + p) * kN + lane;
+                for (int j = 0; j < 16; ++j) {
+                    va[j] = pa[32 * j];
+                    vb[j] = pb[32 * j];
+                }
+            } else {
+                const float *ps = (h >= 0 ? xs + h * (long)kHop * M : hs) + (long)lane * M;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const int row = 32 * brev5(i);  // bins row .. row+31 of this store
-                if (row > a.skip_lo && row + 31 < a.skip_hi) continue;  // band-limited nodes never read these bins
-                zo[row] = f64x2{re[i], im[i]};
+                for (int j = 0; j < 16; ++j) {
+                    va[j] = ps[(long)32 * j * M + ma];
+                    vb[j] = ps[(long)32 * j * M + mb];
+                }
+            }
+        };
+        float pa[16], pb[16], ca[16], cb[16], na[16], nb[16];
+        load_hop(t0 - 1, pa, pb);
+        load_hop(t0, ca, cb);
+        for (int it = 0; it < L; ++it) {
+            const long t = t0 + it;
+            const bool t_ok = ok && t < a.n_frames;
+            {  // next hop: in flight during this frame's transform
+                long tn = t + 1;
+                if (tn >= a.n_frames) tn = a.n_frames - 1;
+                load_hop(tn, na, nb);
+            }
+            double re[32], im[32];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                re[j] = (double)pa[j] * win[j];  // buf[j]*hann_win[i]  (util.h:235)
+                im[j] = (double)pb[j] * (win[j] * bs);
+                re[j + 16] = (double)ca[j] * win[j + 16];
+                im[j + 16] = (double)cb[j] * (win[j + 16] * bs);
+            }
+            fft1024p_fwd_A<double>(re, im, lane, s_tw, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_B<double>(re, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_C<double, false>(im, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_D<double, -1>(re, im, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            if (t_ok) {
+                const long zoff = (((long)s * a.frames_ws + a.frame_off + t) * NP + p) * kN + lane;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const int row = 32 * brev5(i);  // bins row .. row+31 of this store
+                    if (row > a.skip_lo && row + 31 < a.skip_hi) continue;  // band-limited nodes never read these bins
+                    if (Z48)
+                        reinterpret_cast<z48 *>(a.Z)[zoff + row] = enc48(re[i], im[i]);
+                    else
+                        a.Z[zoff + row] = f64x2{re[i], im[i]};
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                pa[j] = ca[j];
+                pb[j] = cb[j];
+                ca[j] = na[j];
+                cb[j] = nb[j];
             }
         }
     }
@@ -276,6 +301,7 @@ constexpr int kI32Block = 256;
 constexpr int kI32Halves = kI32Block / 32;
 constexpr int kPSf = plane_stride<float>::value;  // 36
 
+template <bool YH32>
 __global__ __launch_bounds__(kI32Block) void istft32_kernel(IstftArgs a, int frames_per_chunk, int chunks_per_stream) {
     __shared__ __attribute__((aligned(16))) float lds[2048 + kI32Halves * 32 * kPSf];
     const cx<float> *s_tw = reinterpret_cast<const cx<float> *>(lds);
@@ -309,24 +335,58 @@ __global__ __launch_bounds__(kI32Block) void istft32_kernel(IstftArgs a, int fra
         const f64x2 *row = Ys + t * kYhStride;
         // Hermitian extension of the stored row: position i holds bin k = lane + 32*brev5(i); even i are bins < 512, odd i
         // bins >= 512 (conjugate of row[1024 - k]); bins 0 / 511 / 512 / 513 are irregular (quirk Q1)
+        if (YH32) {
+            // f32x2 rows of the band-limited covariance nodes: only problems 0 and yh_lo..yh_hi exist, the rest is zero
+            // (mvdr.cpp:103) and was never written -- groups of 32 bins outside the band cost no load at all
+            const f32x2 *row32 = reinterpret_cast<const f32x2 *>(a.Yh) + ((long)s * a.n_frames + t) * kYhStride;
+            const int ylo = a.yh_lo, yhi = a.yh_hi;
+            auto ldr = [&](int k) -> f32x2 {
+                if (k == 0 || (k >= ylo && k <= yhi)) return row32[k];
+                return f32x2{0.f, 0.f};
+            };
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const int kb = 32 * brev5(i);
-            cd u;
-            if (kb < 512)
-                u = ld(row + kb + lane);
-            else
-                u = conj(ld(row + (kN - kb) - lane));
-            if (i == 0 && lane == 0) u.y = 0.0;
-            if (i == 1) {
-                if (lane == 0)
-                    u.y = 0.0;
-                else if (lane == 1)
-                    u = (ld(row + 513) + u) * 0.5;
+            for (int i = 0; i < 32; ++i) {
+                const int kb = 32 * brev5(i);
+                const int glo = kb < 512 ? kb : kN - kb - 31;  // rows this position reads: glo .. glo + 31
+                f32x2 u{0.f, 0.f};
+                if (!(glo > yhi || (glo + 31 < ylo && glo > 0))) u = ldr(kb < 512 ? kb + lane : (kN - kb) - lane);
+                if (kb >= 512) u.y = -u.y;
+                if (i == 0 && lane == 0) u.y = 0.f;
+                if (i == 1) {
+                    if (lane == 0) {
+                        u.y = 0.f;
+                    } else if (lane == 1 && yhi >= 511) {
+                        const f32x2 v = ldr(513);
+                        u = f32x2{(v.x + u.x) * 0.5f, (v.y + u.y) * 0.5f};
+                    }
+                }
+                if (i == 30 && lane == 31 && yhi >= 511) {
+                    const f32x2 v = ldr(513);
+                    u = f32x2{(u.x + v.x) * 0.5f, (u.y - v.y) * 0.5f};
+                }
+                re[i] = u.x;
+                im[i] = u.y;
             }
-            if (i == 30 && lane == 31) u = (u + conj(ld(row + 513))) * 0.5;
-            re[i] = (float)u.x;
-            im[i] = (float)u.y;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int kb = 32 * brev5(i);
+                cd u;
+                if (kb < 512)
+                    u = ld(row + kb + lane);
+                else
+                    u = conj(ld(row + (kN - kb) - lane));
+                if (i == 0 && lane == 0) u.y = 0.0;
+                if (i == 1) {
+                    if (lane == 0)
+                        u.y = 0.0;
+                    else if (lane == 1)
+                        u = (ld(row + 513) + u) * 0.5;
+                }
+                if (i == 30 && lane == 31) u = (u + conj(ld(row + 513))) * 0.5;
+                re[i] = (float)u.x;
+                im[i] = (float)u.y;
+            }
         }
         fft1024p_inv_A<float>(re, im, lane, s_tw, pbuf);
         __builtin_amdgcn_wave_barrier();
@@ -429,8 +489,13 @@ __global__ __launch_bounds__(kGenBlock) void stft_generic_kernel(StftArgs a) {
         }
         __syncthreads();
         const cd *res = stockham<-1>(s_a, s_b, a.tw, tid);
-        f64x2 *zo = a.Z + (((long)s * a.frames_ws + a.frame_off + t) * NP + p) * kN;
-        for (int k = tid; k < kN; k += kGenBlock) zo[k] = f64x2{res[k].x, res[k].y};
+        const long zoff = (((long)s * a.frames_ws + a.frame_off + t) * NP + p) * kN;
+        for (int k = tid; k < kN; k += kGenBlock) {
+            if (a.z48)
+                reinterpret_cast<z48 *>(a.Z)[zoff + k] = enc48(res[k].x, res[k].y);
+            else
+                a.Z[zoff + k] = f64x2{res[k].x, res[k].y};
+        }
         __syncthreads();
     }
 }
@@ -529,14 +594,26 @@ __global__ void smooth_state_kernel(const float *yraw, double *state, long n, in
 hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
     // 256 threads, twiddles in LDS: a 512-thread block spills (44 VGPRs) and twiddles read from global memory cost 40 % (measured)
     constexpr int nb = 256, halves = nb / 32;
-    const long total = (long)a.n_streams * a.n_frames * ((a.n_fft_mics + 1) / 2);
+    const long np = (a.n_fft_mics + 1) / 2;
+    // frames per run: two runs per half-wavefront slot (one block per CU) when the batch is long enough -- the first frame of a
+    // run fetches its leading hop a second time (1/run_len of the input), shorter runs balance better
+    StftArgs b = a;
+    const long slots = (long)n_cus * halves * 2;
+    long L = ((long)a.n_streams * a.n_frames * np + slots - 1) / slots;
+    if (L < 1) L = 1;
+    if (L > 256) L = 256;
+    b.run_len = (int)L;
+    const long total = (long)a.n_streams * ((a.n_frames + L - 1) / L) * np;
     long blocks = (total + halves - 1) / halves;
     const long cap = (long)n_cus * 4;
     if (blocks > cap) blocks = cap;
-    if (a.layout == 0)
-        hipLaunchKernelGGL((stft_kernel<0, 256, true>), dim3((unsigned)blocks), dim3(nb), 0, s, a);
-    else
-        hipLaunchKernelGGL((stft_kernel<1, 256, true>), dim3((unsigned)blocks), dim3(nb), 0, s, a);
+    if (a.layout == 0) {
+        if (a.z48) hipLaunchKernelGGL((stft_kernel<0, true>), dim3((unsigned)blocks), dim3(nb), 0, s, b);
+        else hipLaunchKernelGGL((stft_kernel<0, false>), dim3((unsigned)blocks), dim3(nb), 0, s, b);
+    } else {
+        if (a.z48) hipLaunchKernelGGL((stft_kernel<1, true>), dim3((unsigned)blocks), dim3(nb), 0, s, b);
+        else hipLaunchKernelGGL((stft_kernel<1, false>), dim3((unsigned)blocks), dim3(nb), 0, s, b);
+    }
     return hipGetLastError();
 }
 
@@ -548,8 +625,11 @@ hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s) {
         const long fpc = (a.n_frames + cps - 1) / cps;
         cps = (a.n_frames + fpc - 1) / fpc;
         const long chunks = cps * a.n_streams;
-        hipLaunchKernelGGL(istft32_kernel, dim3((unsigned)((chunks + kI32Halves - 1) / kI32Halves)), dim3(kI32Block), 0, s, a,
-                           (int)fpc, (int)cps);
+        const dim3 grid((unsigned)((chunks + kI32Halves - 1) / kI32Halves));
+        if (a.yh32)
+            hipLaunchKernelGGL(istft32_kernel<true>, grid, dim3(kI32Block), 0, s, a, (int)fpc, (int)cps);
+        else
+            hipLaunchKernelGGL(istft32_kernel<false>, grid, dim3(kI32Block), 0, s, a, (int)fpc, (int)cps);
         return hipGetLastError();
     }
     const long pairs = (a.n_frames + 1) / 2;
