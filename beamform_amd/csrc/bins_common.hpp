@@ -212,15 +212,12 @@ __device__ __forceinline__ cd ld(const f64x2 *p) {
 __device__ __forceinline__ z48 enc48(double re, double im) {
     const unsigned long long ur = (unsigned long long)__double_as_longlong(re) + 0x8000ull;
     const unsigned long long ui = (unsigned long long)__double_as_longlong(im) + 0x8000ull;
-    return z48{(unsigned)(ur >> 32), (unsigned)(ui >> 32), (((unsigned)ur) >> 16) | (((unsigned)ui) & 0xFFFF0000u)};
+    return z48{(((unsigned)ur) & 0xFFFF0000u) | (((unsigned)ui) >> 16), (unsigned)(ur >> 32), (unsigned)(ui >> 32)};
 }
-__device__ __forceinline__ cd dec48(unsigned re_hi, unsigned im_hi, unsigned lo) {
-    return cd{__hiloint2double((int)re_hi, (int)(lo << 16)), __hiloint2double((int)im_hi, (int)(lo & 0xFFFF0000u))};
+__device__ __forceinline__ cd dec48(z48 v) {
+    return cd{__hiloint2double((int)v.re_hi, (int)(v.lo & 0xFFFF0000u)), __hiloint2double((int)v.im_hi, (int)(v.lo << 16))};
 }
-__device__ __forceinline__ cd ld(const z48 *p) {
-    const z48 v = *p;
-    return dec48(v.re_hi, v.im_hi, v.lo);
-}
+__device__ __forceinline__ cd ld(const z48 *p) { return dec48(*p); }
 // y_fft of one problem into its row: f64x2 rows, or f32x2 rows in front of the fp32 backward transform (BinsArgs::yh32)
 // (then only problem 0 and the in-band problems yh_lo..yh_hi exist: the others are zero by definition and nobody reads them)
 __device__ __forceinline__ void st_y(const BinsArgs &a, long idx, int q, cd y) {
@@ -234,6 +231,7 @@ __device__ __forceinline__ void st_y(const BinsArgs &a, long idx, int q, cd y) {
 // problem index -> FFT bin whose packed spectrum is read, and whether X must be conjugated
 __device__ __forceinline__ int q_src_bin(int q) { return q == kQX ? kN / 2 - 1 : q; }
 __device__ __forceinline__ int q_bin(int q) { return q; }
+inline int q_bin_host(int q) { return q; }
 
 // X_m for problem q out of the packed pair spectra of one frame (Zf = [NP][1024]).
 template <int MP, typename ZT>

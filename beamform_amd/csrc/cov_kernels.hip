@@ -2,6 +2,9 @@
 // onto lanes (thread-per-problem, row-per-lane over LDS, cyclic rows over DPP quads, row-per-lane over DPP rows).
 #include "bins_common.hpp"
 
+#include <cmath>
+#include <vector>
+
 namespace bf {
 namespace BF_NTAG {
 
@@ -23,94 +26,88 @@ namespace {
 // factorisation; columns are exchanged through LDS (one wavefront executes its LDS operations
 // in order, so only compiler barriers separate the phases).  A zero covariance (frame 0 of a
 // cold start) yields 0 * inf = NaN, the same NaN frame the reference emits.
-// ---- mvdr fast path: one thread per (stream, bin), whole problem in registers -----------------
-// For M <= 8 the lower triangle of R (36 complex) and of its working copy fit the 512-entry
-// register file of a wavefront that has a SIMD to itself (fp64 FMA issues every 4 cycles, so one
-// wavefront per SIMD already keeps the fp64 pipe busy).  Lanes are consecutive bins: spectra
-// loads are coalesced, no LDS, no idle lanes.  Same maths as mvdr_lcmv_kernel with KP1 = 1:
+// ---- mvdr fast path: one thread per (stream, tile, in-band problem), whole problem in registers -------------
+// For M <= 8 the lower triangle of R (36 complex) and of its working copy fit the 512-entry register file of a
+// wavefront that has a SIMD to itself (fp64 FMA issues every 4 cycles, so one wavefront per SIMD already keeps the
+// fp64 pipe busy).  No LDS exchange, no idle lanes.  Same maths as mvdr_lcmv_kernel with KP1 = 1:
 //   R o whiteR = L L^H,  u = L^-1 a,  v = L^-1 x,  y = u^H v / u^H u.
-template <int MP>
-__global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, int tiles_per_stream) {
-    constexpr int NT = MP * (MP + 1) / 2;
-    const int q = blockIdx.y * 64 + threadIdx.x;
-    const int s = blockIdx.x / tiles_per_stream;
-    const long tA = (long)(blockIdx.x % tiles_per_stream) * tile;
-    long tB = tA + tile;
-    if (tB > a.n_frames) tB = a.n_frames;
-    const int M = a.n_mics, NP = (M + 1) >> 1, P = a.cfg.past_windows;
-    const bool live = q < kNQ;
-    const int qq = live ? q : kNQ - 1;
-    const int j = q_bin(qq);
-    const double f = fabs(a.freqs[j]);
-    const bool inband = live && f >= a.cfg.freq_min && f <= a.cfg.freq_max;
-    const long yidx = ((long)s * a.n_frames) * kYhStride + qq;
-    const z48 *Zs = reinterpret_cast<const z48 *>(a.Z) + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
-    const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
-    if (__builtin_amdgcn_ballot_w64(inband) == 0) {  // whole wavefront out of band (mvdr.cpp:103) or bin 0 (:76)
-        if (live)
-            for (long t = tA; t < tB; ++t) {
-                cd y{0, 0};
-                if (j == 0) {
-                    cd X[MP];
-                    load_X<MP>(Zs + t * NP * kN, qq, M, X);
-                    y = X[0];
-                }
-                st_y(a, yidx + t * kYhStride, qq, y);
-            }
-        return;
-    }
-    cd st[MP];
-#pragma unroll
-    for (int m = 0; m < MP; ++m) st[m] = (m < M) ? ld(steer + (long)m * kN + j) : cd{0, 0};
+// Lanes enumerate (time tile, problem) pairs of ONE output stream, problem fastest, over the problems that need a solve
+// only: k = 0 is problem 0 (y = X_0, mvdr.cpp:76), then the in-band problems (FastPlan).  Out-of-band problems (34 % of
+// the rows at the launch-file band) occupy no lane at all, and the host picks the tile length so that the wavefronts
+// fill the chip's 4 x CUs slots a whole number of times (65 536 frames, 340 problems: 2 040 wavefronts of 171 frames
+// = two rounds, where one wavefront per (128-frame tile, 64 consecutive problems) took three).
+// MP = 2 x microphone pairs (2, 4, 6, 8): an odd count's last pair has a zero partner channel, whose row is pinned to the
+// identity (its spectrum is the transform's ~1e-16 rounding residue, not an exact zero).
+struct FastPlan {
+    int q_lo, n_main;  // problems q_lo .. q_lo + n_main - 1 are in band (a contiguous run inside 1 .. N/2-1)
+    int nb;            // 1 + n_main (a band that reaches the irregular problems N/2, N/2+1 -- quirk Q1 -- takes the group kernel)
+    int tile, tiles, waves_per_stream;
+};
 
-    // Spectra are prefetched one frame ahead by global->LDS DMA (global_load_lds_dwordx4: no VGPRs, 1 KB per
-    // instruction, lane l lands at row base + 16 l): a wavefront that owns its SIMD has nobody to hide HBM latency
-    // behind, and the PMC profile of the register-only version showed 57 % of its cycles in s_waitcnt.
-    // Row 2p / 2p+1 = Z_t[p][k] / Z_t[p][N-k]; rows MP + 2p, MP + 2p + 1 = the same of frame t - P (leaving the window).
-    // global_load_lds_dwordx3 puts lane l's 12 bytes at row base + 16 l (measured: tools/ubench/lds_dma_x3.hip), so a row is 64 slots of 16 bytes
+template <int MP>
+__global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan fp) {
+    constexpr int NT = MP * (MP + 1) / 2;
+    const int lane = threadIdx.x;
+    const int s = blockIdx.x / fp.waves_per_stream;  // output stream: uniform per wavefront
+    const int id0 = (blockIdx.x - s * fp.waves_per_stream) * 64;
+    int id = id0 + lane;
+    const bool live = id < fp.tiles * fp.nb;
+    if (!live) id = fp.tiles * fp.nb - 1;
+    const int tl0 = id0 / fp.nb, tl = id / fp.nb;  // time tile of lane 0 / of this lane
+    const int k = id - tl * fp.nb;
+    const int q = k == 0 ? 0 : fp.q_lo + k - 1;
+    const int j = q_bin(q);
+    const long tA0 = (long)tl0 * fp.tile;          // first frame of lane 0's tile: the wavefront's time origin (uniform)
+    const int dt = (tl - tl0) * fp.tile;           // this lane's tile starts dt frames later
+    long n_it = a.n_frames - tA0;                  // frames the wavefront walks (lane 0 has the longest tile)
+    if (n_it > fp.tile) n_it = fp.tile;
+    long cnt = a.n_frames - (tA0 + dt);            // frames this lane owns
+    if (cnt > fp.tile) cnt = fp.tile;
+    if (!live) cnt = 0;
+    const int M = a.n_mics, NP = (M + 1) >> 1, P = a.cfg.past_windows;
+    // frame tA0 of this stream's packed spectra (uniform) + a 32-bit per-lane byte offset: SGPR base + VGPR offset addressing
+    const char *Zu = reinterpret_cast<const char *>(reinterpret_cast<const z48 *>(a.Z) +
+                                                    ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off + tA0) * NP * kN);
+    const int ksrc = q_src_bin(q), kneg = (kN - ksrc) & (kN - 1);
+    const unsigned vk = (unsigned)(((long)dt * NP * kN + ksrc) * (long)sizeof(z48));
+    const unsigned vn = (unsigned)(((long)dt * NP * kN + kneg) * (long)sizeof(z48));
+    const long frame_bytes = (long)NP * kN * (long)sizeof(z48);
+    const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride + j;
+    const long yidx = ((long)s * a.n_frames + tA0 + dt) * kYhStride + q;
+
+    // Spectra are prefetched one frame ahead by global->LDS DMA (global_load_lds_dwordx3: no VGPRs; lane l's 12 bytes
+    // land at row base + 16 l -- measured, tools/ubench/lds_dma_x3.hip -- so a row is 64 slots of 16 bytes): a wavefront
+    // that owns its SIMD has nobody to hide HBM latency behind (PMC of the register-only version: 57 % of its cycles in
+    // s_waitcnt).  Row 2p / 2p+1 = Z_t[p][k] / Z_t[p][N-k]; rows MP + 2p, MP + 2p + 1 = the same of frame t - P.
     struct alignas(16) z48slot {
         z48 v;
         unsigned pad;
     };
     __shared__ z48slot s_pf[2][2 * MP][64];
-    const int lane = threadIdx.x;
-    const int ksrc = q_src_bin(qq), kneg = (kN - ksrc) & (kN - 1);
-    auto dma_frame = [&](long t, bool with_old, int buf) {
-        const z48 *Zn = Zs + t * NP * kN, *Zo = Zs + (t - P) * NP * kN;
+    auto dma_frame = [&](long i, bool with_old, int buf) {  // frame tA0 + i (+ dt per lane) into s_pf[buf]
+        const char *bn = Zu + i * frame_bytes, *bo = Zu + (i - P) * frame_bytes;
 #pragma unroll
-        for (int p = 0; p < MP / 2; ++p)
-            if (2 * p < M) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Zn + p * kN + ksrc),
+        for (int p = 0; p < MP / 2; ++p) {
+                const long po = (long)p * kN * (long)sizeof(z48);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bn + po + vk),
                                                  (__attribute__((address_space(3))) void *)&s_pf[buf][2 * p][0], 12, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Zn + p * kN + kneg),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bn + po + vn),
                                                  (__attribute__((address_space(3))) void *)&s_pf[buf][2 * p + 1][0], 12, 0, 0);
                 if (with_old) {
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Zo + p * kN + ksrc),
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bo + po + vk),
                                                      (__attribute__((address_space(3))) void *)&s_pf[buf][MP + 2 * p][0], 12, 0, 0);
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Zo + p * kN + kneg),
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bo + po + vn),
                                                      (__attribute__((address_space(3))) void *)&s_pf[buf][MP + 2 * p + 1][0], 12, 0, 0);
                 }
             }
     };
-    auto unpack = [&](int buf, int base, cd (&X)[MP]) {  // load_X out of the prefetched rows
+    auto unpack = [&](int buf, int base, cd (&X)[MP]) {  // microphone spectra out of the prefetched rows (z48 is stored halved)
 #pragma unroll
         for (int p = 0; p < MP / 2; ++p) {
-            if (2 * p < M) {
-                const cd z = ld(&s_pf[buf][base + 2 * p][lane].v);
-                const cd zc = conj(ld(&s_pf[buf][base + 2 * p + 1][lane].v));
-                cd xa = (z + zc) * 0.5;
-                const cd d = z - zc;
-                cd xb = cd{0.5 * d.y, -0.5 * d.x};
-                if (qq == kQX) {
-                    xa = conj(xa);
-                    xb = conj(xb);
-                }
-                X[2 * p] = xa;
-                X[2 * p + 1] = xb;
-            } else {
-                X[2 * p] = cd{0, 0};
-                X[2 * p + 1] = cd{0, 0};
-            }
+            const cd z = dec48(s_pf[buf][base + 2 * p][lane].v);
+            const cd c = dec48(s_pf[buf][base + 2 * p + 1][lane].v);  // Z[N-k], conjugated on the fly
+            X[2 * p] = cd{z.x + c.x, z.y - c.y};      // (Z[k] + conj Z[N-k]) / 2
+            X[2 * p + 1] = cd{z.y + c.y, c.x - z.x};  // (Z[k] - conj Z[N-k]) / (2i)
         }
     };
 #define BF_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -122,14 +119,14 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
 #pragma unroll
     for (int i = 0; i < MP; ++i) Rd[i] = 0.0;
     int pb = 0;  // buffer the next consumer reads
-    dma_frame(tA - 1, false, pb);
+    dma_frame(-1, false, pb);
     for (int p = 1; p <= P; ++p) {  // covariance of the P frames in front of the tile
         BF_DMA_WAIT();
         __builtin_amdgcn_wave_barrier();
         if (p < P)
-            dma_frame(tA - p - 1, false, pb ^ 1);
+            dma_frame(-p - 1, false, pb ^ 1);
         else
-            dma_frame(tA, true, pb ^ 1);  // first frame of the tile
+            dma_frame(0, true, pb ^ 1);  // first frame of the tile
         cd X[MP];
         unpack(pb, 0, X);
 #pragma unroll
@@ -140,73 +137,97 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, int tile, 
         }
         pb ^= 1;
     }
-    for (long t = tA; t < tB; ++t) {
-        BF_DMA_WAIT();  // frame t (and t - P) have landed in s_pf[pb]
+    const float thr32 = (float)(a.cfg.freq_mag_threshold * (double)((unsigned)M * (unsigned)kN));
+    for (long it = 0; it < n_it; ++it) {
+        BF_DMA_WAIT();  // frame it (and it - P) have landed in s_pf[pb]
         __builtin_amdgcn_wave_barrier();
-        if (t + 1 < tB) dma_frame(t + 1, true, pb ^ 1);
+        if (it > 0) {
+            // slide the covariance window over the PREVIOUS frame (mvdr.cpp:100-101), whose rows still sit in the other buffer:
+            // done here, not behind the solve, so that the updated R is at once the factorisation's working copy -- R itself
+            // then rests (in the accumulator half of the register file) while the solve has the 256 arithmetic registers
+            cd Xn[MP], Xo[MP];
+#pragma unroll
+            for (int m = 0; m < MP; ++m) Xn[m] = ld(reinterpret_cast<const f64x2 *>(&s_pf[pb ^ 1][m][lane]));  // parked by the previous iteration
+            unpack(pb ^ 1, MP, Xo);
+#pragma unroll
+            for (int i = 0; i < MP; ++i) {
+#pragma unroll
+                for (int c = 0; c < i; ++c)
+                    R[i * (i + 1) / 2 + c] = cfms_conj(cfma_conj(R[i * (i + 1) / 2 + c], Xn[i], Xn[c]), Xo[i], Xo[c]);
+                Rd[i] = fma(-Xo[i].y, Xo[i].y, fma(-Xo[i].x, Xo[i].x, fma(Xn[i].y, Xn[i].y, fma(Xn[i].x, Xn[i].x, Rd[i]))));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows have been read: the next DMA may overwrite them
+        }
+        if (it + 1 < n_it) dma_frame(it + 1, true, pb ^ 1);
+        cd ua[MP];  // the steering column: re-read per frame (L2-resident, consecutive lanes = consecutive bins) instead of
+                    // living in 32 registers that the factorisation needs
+#pragma unroll
+        for (int m = 0; m < MP; ++m) ua[m] = (m < M) ? ld(steer + (long)m * kN) : cd{0, 0};
         cd X[MP];
         unpack(pb, 0, X);
-        double mag = 0.0;
+        // park the unpacked spectra in the slots their packed form came from (a 16-byte slot holds one complex double): the
+        // next iteration's slide reads them back with one LDS read each instead of unpacking the frame again
 #pragma unroll
-        for (int m = 0; m < MP; ++m)
-            if (m < M) mag += fast_sqrt(norm2(X[m]));  // |X| well inside double range: no hypot scaling needed
-        mag /= (double)((unsigned)M * (unsigned)kN);
-        cd A[NT], ua[MP], ux[MP];
+        for (int m = 0; m < MP; ++m) *reinterpret_cast<f64x2 *>(&s_pf[pb][m][lane]) = f64x2{X[m].x, X[m].y};
+        // magnitude gate (mvdr.cpp:85,95): sum |X_m| / (M N) > threshold.  Decided in fp32 unless the fp32 sum is within 1e-4
+        // of the threshold (its own error is < 1e-6): then, for that wavefront and frame, in the reference's double arithmetic.
+        float m32 = 0.f;  // (a zero partner channel of an odd microphone count adds its ~1e-16 |X| rounding residue: irrelevant here)
 #pragma unroll
-        for (int i = 0; i < MP; ++i) {
+        for (int m = 0; m < MP; ++m) m32 += __builtin_amdgcn_sqrtf((float)norm2(X[m]));
+        bool open = m32 > thr32;
+        if (__builtin_amdgcn_ballot_w64(__builtin_fabsf(m32 - thr32) <= 1e-4f * thr32) != 0) {
+            double mag = 0.0;
 #pragma unroll
-            for (int c = 0; c < i; ++c) A[i * (i + 1) / 2 + c] = R[i * (i + 1) / 2 + c];
-            A[i * (i + 1) / 2 + i] = cd{(i < M) ? Rd[i] * 1.001 : 1.0, 0.0};  // whiteR diagonal (mvdr.cpp:239-243); padding = identity
-            ua[i] = st[i];
-            ux[i] = X[i];
+            for (int m = 0; m < MP; ++m)
+                if (m < M) mag += fast_sqrt(norm2(X[m]));  // |X| well inside double range: no hypot scaling needed
+            mag /= (double)((unsigned)M * (unsigned)kN);
+            open = mag > a.cfg.freq_mag_threshold;
         }
+        cd y = X[0] * 0.01;  // gate closed: mvdr.cpp:96
+        if (q == 0) y = X[0];  // mvdr.cpp:76
+        if (__builtin_amdgcn_ballot_w64(open && q != 0) != 0) {
+            cd A[NT];
 #pragma unroll
-        for (int jj = 0; jj < MP; ++jj) {
-            const double inv = fast_rsqrt(A[jj * (jj + 1) / 2 + jj].x);  // 1/L_jj; L_jj itself is never needed
-            ua[jj] = ua[jj] * inv;
-            ux[jj] = ux[jj] * inv;
+            for (int i = 0; i < MP; ++i) {
 #pragma unroll
-            for (int i = jj + 1; i < MP; ++i) {
-                const cd Lij = A[i * (i + 1) / 2 + jj] * inv;
-                A[i * (i + 1) / 2 + jj] = Lij;
-                ua[i] = cfms(ua[i], Lij, ua[jj]);
-                ux[i] = cfms(ux[i], Lij, ux[jj]);
+                for (int c = 0; c < i; ++c) A[i * (i + 1) / 2 + c] = R[i * (i + 1) / 2 + c];
+                A[i * (i + 1) / 2 + i] = cd{(i < M) ? Rd[i] * 1.001 : 1.0, 0.0};  // whiteR diagonal (mvdr.cpp:239-243); padding = identity
             }
 #pragma unroll
-            for (int c = jj + 1; c < MP; ++c) {
-                const cd Lc = A[c * (c + 1) / 2 + jj];
+            for (int jj = 0; jj < MP; ++jj) {
+                const double inv = fast_rsqrt(A[jj * (jj + 1) / 2 + jj].x);  // 1/L_jj; L_jj itself is never needed
+                ua[jj] = ua[jj] * inv;
+                X[jj] = X[jj] * inv;  // X turns into v = L^-1 x in place
 #pragma unroll
-                for (int i = c; i < MP; ++i) {
-                    if (i == c)  // diagonal: only the real part is ever read
-                        A[i * (i + 1) / 2 + c].x = fma(-Lc.y, Lc.y, fma(-Lc.x, Lc.x, A[i * (i + 1) / 2 + c].x));
-                    else
-                        A[i * (i + 1) / 2 + c] = cfms_conj(A[i * (i + 1) / 2 + c], A[i * (i + 1) / 2 + jj], Lc);
+                for (int i = jj + 1; i < MP; ++i) {
+                    const cd Lij = A[i * (i + 1) / 2 + jj] * inv;
+                    A[i * (i + 1) / 2 + jj] = Lij;
+                    ua[i] = cfms(ua[i], Lij, ua[jj]);
+                    X[i] = cfms(X[i], Lij, X[jj]);
+                }
+#pragma unroll
+                for (int c = jj + 1; c < MP; ++c) {
+                    const cd Lc = A[c * (c + 1) / 2 + jj];
+#pragma unroll
+                    for (int i = c; i < MP; ++i) {
+                        if (i == c)  // diagonal: only the real part is ever read
+                            A[i * (i + 1) / 2 + c].x = fma(-Lc.y, Lc.y, fma(-Lc.x, Lc.x, A[i * (i + 1) / 2 + c].x));
+                        else
+                            A[i * (i + 1) / 2 + c] = cfms_conj(A[i * (i + 1) / 2 + c], A[i * (i + 1) / 2 + jj], Lc);
+                    }
                 }
             }
-        }
-        cd num{0, 0};
-        double den = 0.0;
+            cd num{0, 0};
+            double den = 0.0;
 #pragma unroll
-        for (int i = 0; i < MP; ++i) {
-            num = cfma_conj(num, ux[i], ua[i]);
-            den += norm2(ua[i]);
+            for (int i = 0; i < MP; ++i) {
+                num = cfma_conj(num, X[i], ua[i]);
+                den += norm2(ua[i]);
+            }
+            const double rden = fast_rcp(den);
+            if (open && q != 0) y = cd{num.x * rden, num.y * rden};
         }
-        const double rden = fast_rcp(den);
-        cd y = cd{num.x * rden, num.y * rden};
-        if (!(mag > a.cfg.freq_mag_threshold)) y = X[0] * 0.01;  // mvdr.cpp:96
-        if (!inband) y = cd{0, 0};
-        if (j == 0) y = X[0];
-        if (live) st_y(a, yidx + t * kYhStride, qq, y);
-        // slide the covariance window (mvdr.cpp:100-101)
-        cd Xo[MP];
-        unpack(pb, MP, Xo);
-#pragma unroll
-        for (int i = 0; i < MP; ++i) {
-#pragma unroll
-            for (int c = 0; c < i; ++c)
-                R[i * (i + 1) / 2 + c] = cfms_conj(cfma_conj(R[i * (i + 1) / 2 + c], X[i], X[c]), Xo[i], Xo[c]);
-            Rd[i] = fma(-Xo[i].y, Xo[i].y, fma(-Xo[i].x, Xo[i].x, fma(X[i].y, X[i].y, fma(X[i].x, X[i].x, Rd[i]))));
-        }
+        if (it < cnt) st_y(a, yidx + it * kYhStride, q, y);
         pb ^= 1;
     }
 #undef BF_DMA_WAIT
@@ -255,10 +276,10 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
         const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
         cd x;
         if ((i & 1) == 0) {
-            x = (z + zc) * 0.5;
+            x = z + zc;  // z48 spectra are stored halved
         } else {
             const cd d = z - zc;
-            x = cd{0.5 * d.y, -0.5 * d.x};
+            x = cd{d.y, -d.x};
         }
         return q == kQX ? conj(x) : x;
     };
@@ -511,10 +532,10 @@ __global__ __launch_bounds__(64, 1) void mvdr_lcmv_lanes_kernel(BinsArgs a, int 
         const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
         cd x;
         if ((m & 1) == 0) {
-            x = (z + zc) * 0.5;
+            x = z + zc;  // z48 spectra are stored halved
         } else {
             const cd d = z - zc;
-            x = cd{0.5 * d.y, -0.5 * d.x};
+            x = cd{d.y, -d.x};
         }
         return qq == kQX ? conj(x) : x;
     };
@@ -768,10 +789,10 @@ __global__ __launch_bounds__(256, 2) void mvdr_lcmv_row_kernel(BinsArgs a, int t
         const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
         cd x;
         if ((i & 1) == 0) {
-            x = (z + zc) * 0.5;
+            x = z + zc;  // z48 spectra are stored halved
         } else {
             const cd d = z - zc;
-            x = cd{0.5 * d.y, -0.5 * d.x};
+            x = cd{d.y, -d.x};
         }
         return q == kQX ? conj(x) : x;
     };
@@ -979,10 +1000,10 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
         const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
         cd x;
         if ((l16 & 1) == 0) {
-            x = (z + zc) * 0.5;
+            x = z + zc;  // z48 spectra are stored halved
         } else {
             const cd d = z - zc;
-            x = cd{0.5 * d.y, -0.5 * d.x};
+            x = cd{d.y, -d.x};
         }
         return qq == kQX ? conj(x) : x;
     };
@@ -1174,6 +1195,9 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
     const int tps = (int)((a.n_frames + tile - 1) / tile);
     const int M = a.n_mics, km = a.kp1 <= 1 ? 1 : 4;
     static const bool no_fast = getenv("BF_MVDR_GROUP") && atoi(getenv("BF_MVDR_GROUP")) != 0;
+    // frequencies of the irregular problems (quirk Q1, util.h:190-199): f[N/2] = 0, f[N/2+1] = -(N/2-1) sr/N
+    const double f_qx = (double)(kN / 2 - 1) * a.cfg.sample_rate / (double)kN;
+    const bool band_hits_nyquist = (0.0 >= a.cfg.freq_min && 0.0 <= a.cfg.freq_max) || (f_qx >= a.cfg.freq_min && f_qx <= a.cfg.freq_max);
 #define BF_LAUNCH_ML(MP_, KM_)                                                                                   \
     hipLaunchKernelGGL((mvdr_lcmv_kernel<MP_, KM_>), dim3(tps * a.n_streams, (kNQ + (256 / MP_) - 1) / (256 / MP_)), \
                        dim3(256), 0, s, a, tile, tps)
@@ -1245,16 +1269,49 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
         }
         return hipGetLastError();
     }
-    if (a.cfg.algo == BF_MVDR && M <= 8 && !no_fast) {
+    if (a.cfg.algo == BF_MVDR && M <= 8 && !no_fast && !band_hits_nyquist) {
+        // the problems that need a solve (FastPlan): 0, the in-band run inside 1 .. N/2-1, and N/2 / N/2+1 when in band
+        const std::vector<double> fr = frequency_vector(kN, a.cfg.sample_rate);  // the table the other kernels read (a.freqs)
+        auto inb = [&](int q) {
+            const double f = std::fabs(fr[q_bin_host(q)]);
+            return f >= a.cfg.freq_min && f <= a.cfg.freq_max;
+        };
+        FastPlan fp;
+        fp.q_lo = 1;
+        while (fp.q_lo < kN / 2 && !inb(fp.q_lo)) ++fp.q_lo;
+        fp.n_main = 0;
+        while (fp.q_lo + fp.n_main < kN / 2 && inb(fp.q_lo + fp.n_main)) ++fp.n_main;
+        for (int q = fp.q_lo + fp.n_main; q < kN / 2; ++q)
+            if (inb(q)) return hipErrorInvalidValue;  // cannot happen: |f| rises with q below N/2
+        fp.nb = 1 + fp.n_main;
+        // tile length: the wavefronts (64 lanes = 64 (tile, problem) pairs) should fill the 4 x CUs slots a whole number of times;
+        // cost of a choice = rounds x (frames walked + P warm-up frames)
         static const int ft_env = getenv("BF_MVDR_TILE") ? atoi(getenv("BF_MVDR_TILE")) : 0;
-        int ft = ft_env > 0 ? ft_env : 128;  // frames per wavefront: the P = 10 warm-up frames re-read per tile are 8 % of its loads (31 % at 32)
-        if (a.n_frames < ft) ft = (int)a.n_frames;
-        const int ftps = (int)((a.n_frames + ft - 1) / ft);
-        const dim3 grid(ftps * a.n_streams, (kNQ + 63) / 64);  // x: tile * stream (can exceed 65535), y: bin blocks
-        if (M <= 4)
-            hipLaunchKernelGGL((mvdr_fast_kernel<4>), grid, dim3(64), 0, s, a, ft, ftps);
+        const long slots = (long)n_cus * 4, F = a.n_frames;
+        long best_t = 1;
+        double best_c = 1e300;
+        for (long t = 1; t <= 512 && t <= F; ++t) {
+            const long tiles = (F + t - 1) / t;
+            const long waves = (long)a.n_streams * ((tiles * fp.nb + 63) / 64);
+            const long rounds = (waves + slots - 1) / slots;
+            const double c = (double)rounds * (double)(t + a.cfg.past_windows + 2);
+            if (c <= best_c) { best_c = c; best_t = t; }
+        }
+        if (ft_env > 0) best_t = ft_env < F ? ft_env : F;
+        fp.tile = (int)best_t;
+        fp.tiles = (int)((F + best_t - 1) / best_t);
+        fp.waves_per_stream = (int)(((long)fp.tiles * fp.nb + 63) / 64);
+        if (!a.yh32)  // f64x2 rows (spectrum dump / fp64 backward transform): the rows nobody solves read as zero (mvdr.cpp:103)
+            (void)hipMemsetAsync(a.Yh, 0, (size_t)a.n_streams * a.n_frames * kYhStride * sizeof(f64x2), s);
+        const dim3 grid((unsigned)((long)fp.waves_per_stream * a.n_streams));
+        if (M <= 2)
+            hipLaunchKernelGGL((mvdr_fast_kernel<2>), grid, dim3(64), 0, s, a, fp);
+        else if (M <= 4)
+            hipLaunchKernelGGL((mvdr_fast_kernel<4>), grid, dim3(64), 0, s, a, fp);
+        else if (M <= 6)
+            hipLaunchKernelGGL((mvdr_fast_kernel<6>), grid, dim3(64), 0, s, a, fp);
         else
-            hipLaunchKernelGGL((mvdr_fast_kernel<8>), grid, dim3(64), 0, s, a, ft, ftps);
+            hipLaunchKernelGGL((mvdr_fast_kernel<8>), grid, dim3(64), 0, s, a, fp);
         return hipGetLastError();
     }
     if (M <= 4) {

@@ -40,8 +40,10 @@ constexpr int kQX = kN / 2 + 1;   // the extra problem: bin N/2+1, whose X is th
 // times (stored once, read as the newest and as the oldest frame of the sliding covariance), so the element size sets the
 // chain's traffic; 2^-37 relative on X moves the solved spectrum by < 1e-10 relative L2 at cond(R) = 3e4 (tools/z48_precision.py),
 // and the magnitude gate (mvdr.cpp:85) flips with probability ~1e-11 per bin-frame.  Decoding is two 32-bit operations.
+// Stored HALVED (the stft kernel scales its window by 1/2: exact), so that unpacking a microphone pair is X_a = Z[k] + conj Z[N-k],
+// X_b = -i (Z[k] - conj Z[N-k]) without the two multiplications.
 struct z48 {
-    unsigned re_hi, im_hi, lo;  // lo = re's bits 16..31 of the low dword | im's bits 16..31 << 16
+    unsigned lo, re_hi, im_hi;  // lo = (re's low dword & 0xFFFF0000) | (im's low dword >> 16)
 };
 
 struct StftArgs {

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void stft_kernel(StftArgs a) {
     }
     double win[32];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) win[j] = a.win[32 * j + lane];
+    for (int j = 0; j < 32; ++j) win[j] = a.win[32 * j + lane] * (Z48 ? 0.5 : 1.0);  // z48 spectra are stored halved (exact)
     const int M = a.n_mics, MF = a.n_fft_mics, NP = (MF + 1) >> 1, L = a.run_len;
     const long runs = (a.n_frames + L - 1) / L;
     const long total = (long)a.n_streams * runs * NP;
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(kGenBlock) void stft_generic_kernel(StftArgs a) {
                 va = bs[(long)i * M + ma];
                 vb = bs[(long)i * M + mb];
             }
-            const double h = a.win[n];
+            const double h = a.win[n] * (a.z48 ? 0.5 : 1.0);  // z48 spectra are stored halved (exact)
             s_a[n] = cd{(double)va * h, b_ok ? (double)vb * h : 0.0};   // buf[j]*hann_win[i]  (util.h:235)
         }
         __syncthreads();
