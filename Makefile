@@ -15,7 +15,10 @@ OBJS := $(patsubst $(SRC)/%.hip,$(OBJ)/%.o,$(HIP_SRCS)) $(patsubst $(SRC)/%.cpp,
         $(foreach n,$(NFFTS),$(foreach b,$(BIN_SRCS),$(OBJ)/$(b)_n$(n).o))
 HDRS := $(wildcard $(SRC)/*.hpp) include/bfcore.h
 
-all: $(LIB) oracle examples/file_node examples/theta_scan
+all: $(LIB) oracle examples/file_node examples/theta_scan examples/shard_node
+
+examples/shard_node: examples/shard_node.cpp include/bfcore.h $(LIB)
+	$(HIPCC) -O2 -std=c++17 -x hip --offload-arch=$(ARCH) examples/shard_node.cpp -o $@ -Lbeamform_amd/lib -lbfcore -L/opt/rocm/lib -lrccl -Wl,-rpath,'$$ORIGIN/../beamform_amd/lib'
 
 examples/theta_scan: examples/theta_scan.cpp include/bfcore.h $(LIB)
 	$(HIPCC) -O2 -std=c++17 -x hip --offload-arch=$(ARCH) examples/theta_scan.cpp -o $@ -Lbeamform_amd/lib -lbfcore -Wl,-rpath,'$$ORIGIN/../beamform_amd/lib'
@@ -52,7 +55,7 @@ emul:
 	g++ -O2 -std=c++17 -fPIC -shared -o tests/host_emul/libemul.so tests/host_emul/emul.cpp
 
 clean:
-	rm -rf build $(LIB) tests/host_emul/libemul.so examples/file_node examples/theta_scan
+	rm -rf build $(LIB) tests/host_emul/libemul.so examples/file_node examples/theta_scan examples/shard_node
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle emul ubench clean

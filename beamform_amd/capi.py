@@ -26,7 +26,7 @@ EXPORTS = (
     "bf_version", "bf_strerror", "bf_last_error", "bf_device_count", "bf_config_init", "bf_config_load_yaml",
     "bf_config_parse_yaml", "bf_create", "bf_destroy", "bf_set_theta", "bf_set_interference", "bf_process_hop",
     "bf_process_batch", "bf_process_batch_device", "bf_get_weights", "bf_state_size", "bf_get_state", "bf_set_state",
-    "bf_reset", "bf_time_batch_device", "bf_n_interferers", "bf_set_theta_dir", "bf_set_thetas", "bf_stream_rms", "bf_host_alloc", "bf_host_free",
+    "bf_reset", "bf_reset_async", "bf_shard_halo", "bf_shard_plan", "bf_shard_run", "bf_process_batch_device_strided", "bf_kernel_timing_begin", "bf_kernel_timing_end", "bf_time_batch_device", "bf_n_interferers", "bf_set_theta_dir", "bf_set_thetas", "bf_stream_rms", "bf_host_alloc", "bf_host_free",
     "bf_wav_writer_open", "bf_wav_writer_write", "bf_wav_writer_write_pcm16", "bf_wav_writer_close", "bf_float_to_pcm16",
     "bf_float_to_pcm16_device", "bf_wav_read", "bf_planar_f32_read", "bf_wav_free",
     "bf_resampler_create", "bf_resampler_set_table", "bf_resampler_reset", "bf_resampler_out_count", "bf_resampler_latency",
@@ -107,6 +107,10 @@ def load():
     L.bf_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.bf_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.bf_reset.argtypes = [C.c_void_p]
+    L.bf_reset_async.argtypes = [C.c_void_p, C.c_void_p]
+    L.bf_process_batch_device_strided.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_long]
+    L.bf_kernel_timing_begin.argtypes = [C.c_void_p]
+    L.bf_kernel_timing_end.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.bf_time_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int,
                                        C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.bf_wav_writer_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
@@ -374,6 +378,19 @@ class Beamformer:
     def reset(self):
         self._chk(self._L.bf_reset(self._h), "bf_reset")
 
+    def reset_async(self, stream: int = 0):
+        """Cold start enqueued on `stream` (no host synchronisation)."""
+        self._chk(self._L.bf_reset_async(self._h, stream or None), "bf_reset_async")
+
+    def kernel_timing_begin(self):
+        self._chk(self._L.bf_kernel_timing_begin(self._h), "bf_kernel_timing_begin")
+
+    def kernel_timing_end(self):
+        """(mean ms per launch of the dominant kernel since begin, launches)"""
+        ms, n = C.c_float(), C.c_int()
+        self._chk(self._L.bf_kernel_timing_end(self._h, C.byref(ms), C.byref(n)), "bf_kernel_timing_end")
+        return float(ms.value), int(n.value)
+
     def weights(self) -> np.ndarray:
         w = np.empty((self.N, self.M, self.S), np.complex128)
         self._chk(self._L.bf_get_weights(self._h, w.ctypes.data), "bf_get_weights")
@@ -401,6 +418,11 @@ class Beamformer:
     def process_device(self, x_ptr: int, n_frames: int, y_ptr: int, spectrum_ptr: int = 0, stream: int = 0):
         self._chk(self._L.bf_process_batch_device(self._h, x_ptr, n_frames, y_ptr, spectrum_ptr or None, stream or None),
                   "bf_process_batch_device")
+
+    def process_device_strided(self, x_ptr: int, n_frames: int, y_ptr: int, mic_stride: int, stream: int = 0):
+        """process_device on a column range of a longer planar buffer (microphone m at x_ptr + m * mic_stride samples)."""
+        self._chk(self._L.bf_process_batch_device_strided(self._h, x_ptr, n_frames, y_ptr, stream or None, mic_stride),
+                  "bf_process_batch_device_strided")
 
     def time_device(self, x_ptr: int, n_frames: int, y_ptr: int, iters: int, stream: int = 0):
         """(mean ms per call, mean ms per launch of the dominant kernel), HIP events on `stream`."""

@@ -70,6 +70,7 @@ struct bf_handle {
 
     // per-launch timing of the dominant kernel (bf_time_batch_device)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> *kernel_events = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> own_events;  // bf_kernel_timing_begin / _end
 };
 
 namespace {
@@ -403,22 +404,36 @@ void bf_destroy(bf_handle *h) {
     delete h;
 }
 
-int bf_reset(bf_handle *h) {
+// The clears are enqueued on `s` (hipMemsetAsync): they order against the batches the caller runs on the same stream -- a plain
+// hipMemset goes to the NULL stream, which does not order against non-blocking streams (every torch.cuda.Stream is one).
+int bf_reset_async(bf_handle *h, void *hip_stream) {
     if (!h) return BF_EINVAL;
     BF_HIP(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)hip_stream;
     const size_t S = h->n_streams;
     if (uses_fused_das(h)) {
         // prepare_overlap_and_add: ring pre-filled with one hop of zeros, out_buff calloc'ed (util.h:272-286)
-        BF_HIP(h, hipMemset(h->d_hist[0], 0, S * h->M * h->H * sizeof(float)));
-        BF_HIP(h, hipMemset(h->d_hist[1], 0, S * h->M * h->H * sizeof(float)));
-        BF_HIP(h, hipMemset(h->d_tail[0], 0, (size_t)h->n_out * h->H * sizeof(float)));
-        BF_HIP(h, hipMemset(h->d_tail[1], 0, (size_t)h->n_out * h->H * sizeof(float)));
+        BF_HIP(h, hipMemsetAsync(h->d_hist[0], 0, S * h->M * h->H * sizeof(float), s));
+        BF_HIP(h, hipMemsetAsync(h->d_hist[1], 0, S * h->M * h->H * sizeof(float), s));
+        BF_HIP(h, hipMemsetAsync(h->d_tail[0], 0, (size_t)h->n_out * h->H * sizeof(float), s));
+        BF_HIP(h, hipMemsetAsync(h->d_tail[1], 0, (size_t)h->n_out * h->H * sizeof(float), s));
         h->tail_cur = 0;
     } else if (h->pipe) {
         std::lock_guard<std::mutex> lk(h->mu);  // reset() re-arms the gss demixing reset, which /theta also writes
-        int rc = h->pipe->reset();
+        int rc = h->pipe->reset(s);
         if (rc != BF_OK) return fail(h, rc, h->pipe->error().c_str());
     }
+    return BF_OK;
+}
+
+// Host-synchronous form: the device is idle with respect to this handle before and after.
+int bf_reset(bf_handle *h) {
+    if (!h) return BF_EINVAL;
+    BF_HIP(h, hipSetDevice(h->device));
+    BF_HIP(h, hipDeviceSynchronize());
+    const int rc = bf_reset_async(h, nullptr);
+    if (rc != BF_OK) return rc;
+    BF_HIP(h, hipStreamSynchronize(nullptr));
     return BF_OK;
 }
 
@@ -634,6 +649,80 @@ int bf_process_hop(bf_handle *h, const float *const *in, float *out, uint32_t nf
     BF_HIP(h, hipMemcpyAsync(res, h->d_y, n_outv * sizeof(float), hipMemcpyDeviceToHost, h->stream));  // [dir][hop]
     BF_HIP(h, hipStreamSynchronize(h->stream));
     memcpy(out, res, n_outv * sizeof(float));
+    return BF_OK;
+}
+
+// ---- frame-range sharding (beamform_amd/shard.py is the same plan in Python) ------------------------------------------------
+// A column range of a longer planar buffer: microphone m starts at x_dev + m * mic_stride (samples).  One input stream.
+int bf_process_batch_device_strided(bf_handle *h, const float *x_dev, size_t n_frames, float *y_dev, void *hip_stream,
+                                    long mic_stride) {
+    if (!h || !x_dev || !y_dev || mic_stride < (long)(n_frames * (size_t)h->H)) return BF_EINVAL;
+    if (h->cfg.layout != BF_PLANAR || h->n_streams != 1) return fail(h, BF_EINVAL, "strided batches: planar layout, one input stream");
+    BF_HIP(h, hipSetDevice(h->device));
+    return run_batch_device(h, x_dev, n_frames, y_dev, nullptr, (hipStream_t)hip_stream, h->cfg.layout, mic_stride);
+}
+
+int bf_shard_halo(const bf_config *cfg) {
+    if (!cfg) return -1;
+    switch (cfg->algo) {
+        case BF_DAS:
+        case BF_PHASE: return 1;                       // overlap-add neighbour only (util.h:301-302)
+        case BF_MVDR:
+        case BF_LCMV: return cfg->past_windows + 1;    // covariance history of frame lo-1, plus that frame (mvdr.cpp:87,100-101)
+        default: return -1;                            // gss / phasempf / mcra recurse over frames, gsc over samples
+    }
+}
+
+int bf_shard_plan(size_t n_frames, int world, int rank, int halo, bf_shard *out) {
+    if (!out || world < 1 || rank < 0 || rank >= world || halo < 0) return BF_EINVAL;
+    const long long n = (long long)n_frames, base = n / world, rem = n % world;
+    out->lo = rank * base + (rank < rem ? rank : rem);
+    out->hi = out->lo + base + (rank < rem ? 1 : 0);
+    out->warm = (int)(halo < out->lo ? halo : out->lo);
+    out->lead = (halo > 0 && out->lo - out->warm > 0) ? 1 : 0;
+    return BF_OK;
+}
+
+int bf_shard_run(bf_handle *h, const float *x_feed_dev, const bf_shard *sh, float *y_feed_dev, void *hip_stream) {
+    if (!h || !sh) return BF_EINVAL;
+    if (h->n_streams != 1 || h->n_dirs != 1)
+        return fail(h, BF_EINVAL, "frame-range sharding drives one input stream and one look direction per handle");
+    const long long n_feed = bf_shard_n_feed(sh);
+    if (n_feed < 0 || sh->warm < 0 || sh->lead < 0) return fail(h, BF_EINVAL, "malformed shard");
+    int rc = bf_reset_async(h, hip_stream);  // the rank's node knows nothing about the frames before its slice
+    if (rc != BF_OK || n_feed == 0) return rc;
+    return bf_process_batch_device(h, x_feed_dev, (size_t)n_feed, y_feed_dev, nullptr, hip_stream);
+}
+
+// Per-launch timing of the dominant kernel for launches the CALLER issues (bench.py's timed loop): between begin and end every
+// launch of the fused kernel is bracketed by its own event pair on the stream it is launched on.
+int bf_kernel_timing_begin(bf_handle *h) {
+    if (!h) return BF_EINVAL;
+    if (h->kernel_events) return fail(h, BF_EINVAL, "kernel timing already active");
+    h->own_events.clear();
+    h->kernel_events = &h->own_events;
+    return BF_OK;
+}
+
+int bf_kernel_timing_end(bf_handle *h, float *ms_mean, int *n_launches) {
+    if (!h || !ms_mean) return BF_EINVAL;
+    if (h->kernel_events != &h->own_events) return fail(h, BF_EINVAL, "kernel timing is not active");
+    h->kernel_events = nullptr;
+    float sum = 0.f;
+    int n = 0;
+    hipError_t e = hipSuccess;
+    for (auto &pr : h->own_events) {
+        float t = 0.f;
+        if (e == hipSuccess) e = hipEventSynchronize(pr.second);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, pr.first, pr.second);
+        if (e == hipSuccess) { sum += t; ++n; }
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    h->own_events.clear();
+    if (e != hipSuccess) return fail(h, BF_EIO, "bf_kernel_timing_end", e);
+    *ms_mean = n ? sum / (float)n : 0.f;
+    if (n_launches) *n_launches = n;
     return BF_OK;
 }
 

@@ -126,15 +126,15 @@ class BinPipelineImpl : public BinPipeline {
         return BF_OK;
     }
 
-    int reset() override {
-        PIPE_HIP(hipMemset(d_hist_, 0, (size_t)S_ * M_ * H_ * sizeof(float)));
-        PIPE_HIP(hipMemset(d_tail_[0], 0, (size_t)So_ * H_ * sizeof(float)));
-        PIPE_HIP(hipMemset(d_tail_[1], 0, (size_t)So_ * H_ * sizeof(float)));
+    int reset(hipStream_t st) override {
+        PIPE_HIP(hipMemsetAsync(d_hist_, 0, (size_t)S_ * M_ * H_ * sizeof(float), st));
+        PIPE_HIP(hipMemsetAsync(d_tail_[0], 0, (size_t)So_ * H_ * sizeof(float), st));
+        PIPE_HIP(hipMemsetAsync(d_tail_[1], 0, (size_t)So_ * H_ * sizeof(float), st));
         tail_cur_ = 0;
-        if (d_zhist_) PIPE_HIP(hipMemset(d_zhist_, 0, zhist_bytes()));  // past_ffts setZero (mvdr.cpp:228-232)
-        if (d_mpf_) PIPE_HIP(hipMemset(d_mpf_, 0, mpf_bytes()));          // phasempf.cpp:535-545, current_L=0/first_L
-        if (d_smooth_) PIPE_HIP(hipMemset(d_smooth_, 0, smooth_bytes())); // calloc past_samples (phasempf.cpp:510)
-        if (d_nlms_) PIPE_HIP(hipMemset(d_nlms_, 0, nlms_bytes()));       // calloc block_matrix/filter/last_outputs (gsc.cpp:278-285)
+        if (d_zhist_) PIPE_HIP(hipMemsetAsync(d_zhist_, 0, zhist_bytes(), st));  // past_ffts setZero (mvdr.cpp:228-232); zero bits = z48 zero
+        if (d_mpf_) PIPE_HIP(hipMemsetAsync(d_mpf_, 0, mpf_bytes(), st));          // phasempf.cpp:535-545, current_L=0/first_L
+        if (d_smooth_) PIPE_HIP(hipMemsetAsync(d_smooth_, 0, smooth_bytes(), st)); // calloc past_samples (phasempf.cpp:510)
+        if (d_nlms_) PIPE_HIP(hipMemsetAsync(d_nlms_, 0, nlms_bytes(), st));       // calloc block_matrix/filter/last_outputs (gsc.cpp:278-285)
         gss_reset_mask_ = ~0ull;  // sep_matrix = weights^H (gss.cpp:90-93), done on the stream at next run
         return BF_OK;
     }

@@ -31,7 +31,7 @@ class BinPipeline {
     static BinPipeline *create(const bf_config &cfg, int n_cus);
     virtual ~BinPipeline() {}
     virtual int init() = 0;
-    virtual int reset() = 0;
+    virtual int reset(hipStream_t stream) = 0;  // clears enqueued on `stream`
     virtual int upload_steering(const std::vector<SteeringSet> &dirs, hipStream_t stream) = 0;  // one set per look direction
     virtual void on_theta_changed(int dir = -1) = 0;  // dir < 0: every look direction
     virtual void set_columns(int kp1) = 0;  // interferer added/removed (lcmv.cpp:266-305)

@@ -93,16 +93,71 @@ def run_shard(bf, x_feed_ptr: int, sh: Shard, y_feed_ptr: int, stream: int = 0, 
                 (planar [M][n_feed*hop] or interleaved [n_feed*hop][M], per the handle's layout).
     y_feed_ptr: device buffer of n_feed*hop floats; the owned hops start at element n_drop*hop.
     The handle is put back to the reference's cold start first (the rank's node knows nothing about the frames
-    before its slice).  Enqueued on `stream` without host synchronisation.
+    before its slice): bf_reset_async clears the carried state ON `stream`, so the step orders against whatever the
+    caller has in flight there; nothing synchronises with the host.
     Returns the element offset of the first owned output sample in y_feed.
     """
     if bf.n_streams != 1 or bf.n_dirs != 1:
         raise ValueError("frame-range sharding drives one input stream and one look direction per handle")
     if reset:
-        bf.reset()
+        bf.reset_async(stream)
     if sh.n_feed > 0:
         bf.process_device(x_feed_ptr, sh.n_feed, y_feed_ptr, 0, stream)
     return sh.n_drop * bf.H
+
+
+def pieces(sh: Shard, n_pieces: int):
+    """Cut a rank's fed hops into `n_pieces` consecutive runs: [(f0, f1, own0, n_own)] with f0:f1 the fed-hop range of the piece
+    and own0, n_own the owned hops it completes (indices into the rank's owned range).  Every rank and the receiver use this."""
+    per = -(-sh.n_feed // max(1, n_pieces))
+    out = []
+    for c in range(n_pieces):
+        f0, f1 = c * per, min((c + 1) * per, sh.n_feed)
+        if f1 <= f0:
+            break
+        o0 = max(f0, sh.n_drop)
+        out.append((f0, f1, o0 - sh.n_drop, max(0, f1 - o0)))
+    return out
+
+
+def run_shard_overlapped(bf, x_feed, y_feed, n_frames: int, world: int, rank: int, halo: int, n_pieces: int = 4, dst: int = 0,
+                         out=None, stream: int = 0):
+    """run_shard with the final gather overlapped: the rank's slice is walked in `n_pieces` pieces (state carries from piece
+    to piece), and as soon as a piece is enqueued its owned hops are handed to an ASYNCHRONOUS point-to-point transfer to
+    `dst`, which the backend orders behind the compute stream's work so far and runs on its own stream -- piece c travels
+    while piece c+1 is computed (RCCL: the direct xGMI link of each peer; grouped send / recv is what ncclGather does underneath).
+
+    x_feed [M, n_feed*hop] / y_feed [n_feed*hop]: torch tensors (planar) holding / receiving hops [first_feed_frame, hi).
+    out (dst only): [n_frames*hop] tensor, filled in stream order.  Every rank cuts its slice by the same rule (`pieces`), so
+    the receiver knows each sender's piece sizes without a handshake.
+    Returns the pending work handles: wait on them (or synchronise the device) before reading `out`."""
+    import torch.distributed as dist
+    H = bf.H
+    sh = plan(n_frames, world, rank, halo)
+    bf.reset_async(stream)
+    peers = {r: pieces(plan(n_frames, world, r, halo), n_pieces) for r in range(world)} if rank == dst else None
+    works = []
+    mine_p = pieces(sh, n_pieces)
+    rounds = max(len(ps) for ps in peers.values()) if rank == dst else len(mine_p)  # a peer may cut one piece more than dst
+    for c in range(rounds):
+        n_own = 0
+        if c < len(mine_p):
+            f0, f1, own0, n_own = mine_p[c]
+            bf.process_device_strided(x_feed[:, f0 * H:].data_ptr(), f1 - f0, y_feed[f0 * H:].data_ptr(), sh.n_feed * H, stream)
+            mine = y_feed[(sh.n_drop + own0) * H:(sh.n_drop + own0 + n_own) * H]
+        if rank == dst:
+            if n_own > 0:
+                out[(sh.lo + own0) * H:(sh.lo + own0 + n_own) * H].copy_(mine, non_blocking=True)
+            for r in range(world):
+                if r == rank or c >= len(peers[r]):
+                    continue
+                _, _, o0, n = peers[r][c]
+                if n > 0:
+                    lo_r = plan(n_frames, world, r, halo).lo
+                    works.append(dist.irecv(out[(lo_r + o0) * H:(lo_r + o0 + n) * H], src=r))
+        elif n_own > 0:
+            works.append(dist.isend(mine, dst=dst))
+    return works
 
 
 def run_sharded(bf, x_feed, n_frames: int, world: int, rank: int, halo: int, dst: int = 0, stream: int = 0,

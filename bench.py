@@ -25,7 +25,6 @@ import argparse
 import json
 import math
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -160,13 +159,13 @@ def load_traffic(tag: str):
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as children through torch.distributed.run
     (this parent has not touched the GPU) and hand back their exit code."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    # --standalone: the launcher picks a free rendezvous port itself (no bind-close-reuse race on a shared box)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    if rc != 0:  # the ranks' own output is above; say in one line that no result line follows
+        print(json.dumps({"error": f"torch.distributed.run exited with {rc}: a rank failed, see its traceback above", "n_gpus": n}), flush=True)
+    return rc
 
 
 def main():
@@ -190,7 +189,11 @@ def main():
                     help="--strong: frames of the global stream (default 262144 = BASELINE config 5's batch)")
     ap.add_argument("--independent", action="store_true",
                     help="N > 1: round-1 behaviour, every rank an independent random batch (no shard plan)")
-    ap.add_argument("--gather", default="final", choices=["final", "none"])
+    ap.add_argument("--gather", default="final", choices=["final", "overlap", "none"],
+                    help="final: K steps that each end with one gather of the owned slabs onto rank 0 (serial with the compute);\n"
+                         "overlap: additionally K steps whose slices are walked in --pieces pieces, each piece's owned hops sent to\n"
+                         "rank 0 point-to-point while the next piece computes (shard.run_shard_overlapped)")
+    ap.add_argument("--pieces", type=int, default=4)
     ap.add_argument("--cpu-frames", type=int, default=196608,
                     help="frames in the CPU-baseline sample (0 = skip); the default is ~12 s of single-core work (its oracle, with the FFT plan cached, does ~16 k frames per second)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -327,21 +330,35 @@ def main():
             settle_launches += 8
     for _ in range(args.warmup):
         step()
+    # the K timed steps, with every launch of the dominant kernel bracketed by its own HIP event pair on the launch stream: the
+    # roofline duration comes from the very launches the step time covers (so kernel_ms <= ms_per_step by construction)
+    bf.kernel_timing_begin()
     dt = timed(args.steps)
-    dt_g = None
-    if sharded and args.gather == "final":
+    ms_kernel, n_timed_launches = bf.kernel_timing_end()
+    ms_call = dt / args.steps * 1e3
+    dt_g = dt_o = None
+    if sharded and args.gather in ("final", "overlap"):
         step(True)                                  # first gather also builds the RCCL channels
         dt_g = timed(args.steps, with_gather=True)  # K steps, each ending with the final gather onto rank 0
-
-    # dominant-kernel duration: HIP events on the launch stream, one pair per launch
-    k_iters = max(5, min(args.steps, 50))
-    if sharded:
-        bf.reset()
-    ms_call, ms_kernel = bf.time_device(x.data_ptr(), n_feed, y.data_ptr(), k_iters, sptr)
+    if sharded and args.gather == "overlap" and not one_dev:
+        out_full = torch.empty(F_total * HOP, device=dev, dtype=torch.float32) if rank == 0 else None
+        def step_overlapped():
+            for w in shard.run_shard_overlapped(bf, x, y, F_total, world, rank, halo, n_pieces=args.pieces, out=out_full, stream=sptr):
+                w.wait()                            # stream-level wait: the next step's kernels queue behind it
+        step_overlapped()
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_overlapped()
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        dt_o = all_max([time.perf_counter() - t0])[0]
     torch.cuda.synchronize(dev)
 
     # ---- secondary lines: the other BASELINE configs, rank 0 at N = 1 -------------------------------------------
-    def node_line(algo, M_, F_, S_, interf_=(), das_impl_=BF_DAS_FUSED_F32, iters=5, xin=None, note="", layout_=BF_PLANAR):
+    def node_line(algo, M_, F_, S_, interf_=(), das_impl_=BF_DAS_FUSED_F32, iters=5, xin=None, note="", layout_=BF_PLANAR,
+                  with_traffic=True):
         pm = make_params(algo, n_mics=M_, interf=interf_)
         bm = Beamformer(pm, device=local_rank, n_streams=S_, das_impl=das_impl_, layout=layout_)
         if xin is None:
@@ -364,7 +381,7 @@ def main():
             fl = model_flops_per_frame(algo, M_, len(interf_), pm["past_windows"])
             line["model_flops_per_frame"] = fl
             line["frac_of_fp64_vector_peak"] = fl * fr / (ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TF
-        if layout_ != BF_PLANAR:
+        if layout_ != BF_PLANAR or not with_traffic:  # the committed counter files are for the noise input, planar
             return line
         tag = {"das": "das8_f64", "mvdr": "mvdr8", "phasempf": "phasempf8", "phase": "phase8", "lcmv": "lcmv16"}.get(algo)
         tr = load_traffic(tag) if tag else None
@@ -393,6 +410,23 @@ def main():
             ("lcmv16", lambda: node_line("lcmv", 16, 32768, 1, (-60.0, 90.0, 150.0), iters=3,
                                          note="BASELINE config 5, one GPU's shard of the 262144-frame stream; " + noise)),
         ]
+        def scene_input(M_, F_):
+            # SURVEY 8(d)'s seeded scene (directional band-limited target at 20 deg + 3 interferers + sensor noise, last 10 % silent),
+            # 2048 frames tiled to the batch length: part of the magnitude gates are closed, as in real recordings
+            from beamform_amd.synth import make_scene
+            base = torch.from_numpy(make_scene(M_, 2048, seed=77)).to(dev)
+            return base.repeat(1, F_ // 2048).reshape(1, M_, F_ * HOP).contiguous()
+
+        scene_note = ("input = the seeded synthetic scene of SURVEY 8(d) (beamform_amd.synth.make_scene, 2048 frames tiled): target + 3 "
+                      "interferers + sensor noise, 10 % near-silent frames; gates partly closed")
+        jobs += [
+            ("mvdr_scene", lambda: node_line("mvdr", M, F, 1, xin=scene_input(M, F), with_traffic=False,
+                                             note="BASELINE config 3 on a realistic scene; " + scene_note)),
+            ("phase_scene", lambda: node_line("phase", M, F, 1, xin=scene_input(M, F), with_traffic=False, note=scene_note)),
+            ("lcmv16_scene", lambda: node_line("lcmv", 16, 32768, 1, (-60.0, 90.0, 150.0), iters=3, xin=scene_input(16, 32768), with_traffic=False,
+                                               note="BASELINE config 5 shard on a realistic scene; " + scene_note)),
+        ]
+
         def resample_line():
             # the output stage's sample-rate converter on the batch the headline step just produced (rosjack.cpp:311-338)
             from beamform_amd.capi import Resampler
@@ -476,6 +510,8 @@ def main():
             "dtype": "f32" if (args.algo == "das" and das_impl == BF_DAS_FUSED_F32) else "f64", "data": "synthetic",
             "value_including_final_gather": (frames_total / dt_g) if dt_g else None,
             "ms_per_step_including_final_gather": (dt_g / args.steps * 1e3) if dt_g else None,
+            "value_including_overlapped_gather": (frames_total / dt_o) if dt_o else None,
+            "ms_per_step_including_overlapped_gather": (dt_o / args.steps * 1e3) if dt_o else None,
             "config": {"workload": wl, "frames_per_gpu": n_own, "frames_fed_per_gpu": n_feed,
                        "global_stream_frames": frames_per_step_all_ranks if sharded else None, "mics": M, "fft": NFFT,
                        "hop": HOP, "streams": S, "layout": args.layout,
@@ -491,7 +527,9 @@ def main():
                          "traffic": load_traffic(tag) if (n_feed == 65536 and S == 1 and args.layout == "planar") else None,
                          "kernel": "das_fused_kernel" if (args.algo == "das" and das_impl == BF_DAS_FUSED_F32)
                                    else "bin pipeline (stft + per-bin kernel + istft)",
-                         "kernel_ms": k_ms, "call_ms": ms_call, "algorithmic_bytes_per_frame": bpf,
+                         "kernel_ms": k_ms, "call_ms": ms_call, "kernel_launches_timed": n_timed_launches,
+                         "kernel_ms_source": "one HIP event pair per launch on the launch stream, inside the K timed steps",
+                         "algorithmic_bytes_per_frame": bpf,
                          "frames_per_launch": units_per_launch, "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
         }
         out["cpu_baseline"] = cpu_line  # None at N > 1 (the contract asks for it on rank 0 at N = 1 only)

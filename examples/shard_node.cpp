@@ -1,0 +1,269 @@
+// shard_node.cpp -- one long stream cut into frame ranges across processes (one per GPU), the C way:
+// bf_shard_plan / bf_reset_async / bf_process_batch_device from include/bfcore.h and RCCL called directly for the final gather
+// (north_star: "Host C++ calls a thin C-ABI ... RCCL over xGMI only for the final gather").  The Python counterpart is
+// beamform_amd/shard.py over torch.distributed.
+//
+//   shard_node <das|mvdr|lcmv|phase> <n_mics> <total_frames> <world> <rank> <id_file> [chunks=4] [steps=3]
+//       one process per rank; rank 0 writes the ncclUniqueId into <id_file>, the others wait for it.
+//       Every rank materialises its slice of ONE global counter-noise stream (lead hop + warm-up frames + owned frames),
+//       starts from a cold handle, and walks its slice in `chunks` pieces: while piece c is computed on the compute stream,
+//       piece c-1's owned hops travel to rank 0 on a second stream (grouped ncclSend / ncclRecv = point-to-point over the
+//       direct xGMI link of each peer).  Rank 0 prints the step time with and without the gather and a checksum.
+//   shard_node <algo> <n_mics> <total_frames> <world> logical
+//       no RCCL: one process plays all `world` ranks one after the other on one GPU (device-to-device copies instead of the
+//       gather) and compares the assembled output with the unsharded run of the same stream -- the check that the plan,
+//       the cold start and the chunked walk reproduce the single-node result.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../include/bfcore.h"
+
+#define CK(call)                                                                              \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+#define CKN(call)                                                                              \
+    do {                                                                                       \
+        ncclResult_t r_ = (call);                                                              \
+        if (r_ != ncclSuccess) {                                                               \
+            fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #call, ncclGetErrorString(r_)); \
+            return 1;                                                                          \
+        }                                                                                      \
+    } while (0)
+#define CKB(call)                                                                             \
+    do {                                                                                      \
+        int r_ = (call);                                                                      \
+        if (r_ != BF_OK) {                                                                    \
+            fprintf(stderr, "%s:%d %s: %d %s\n", __FILE__, __LINE__, #call, r_, bf_last_error(nullptr)); \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+// samples [s0, s1) of microphone m of the global stream: the same counter-based hash as beamform_amd.synth.stream_noise, so
+// the halo a rank re-reads is bit-identical to what its neighbour owns (no exchange of input)
+__global__ void stream_noise_kernel(float *out, long long s0, long long n, int m, int seed) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long h = ((unsigned long long)(s0 + i) + (unsigned long long)(m + 1) * 0x632BE5ABull +
+                            (unsigned long long)(seed + 1) * 0x85157AF5ull) & 0xFFFFFFFFull;
+    h = ((h ^ (h >> 16)) * 0x45D9F3Bull) & 0xFFFFFFFFull;
+    h = ((h ^ (h >> 16)) * 0x45D9F3Bull) & 0xFFFFFFFFull;
+    h = h ^ (h >> 16);
+    out[i] = (float)(h >> 8) * (1.0f / 16777216.0f) - 0.5f;
+}
+
+struct Rank {
+    bf_shard sh;
+    float *x = nullptr, *y = nullptr;  // fed hops (planar [M][n_feed * hop]) and their output
+    long long n_feed = 0, n_drop = 0, n_own = 0;
+};
+
+static int make_slice(Rank &r, int M, int H, hipStream_t s) {
+    r.n_feed = bf_shard_n_feed(&r.sh);
+    r.n_drop = bf_shard_n_drop(&r.sh);
+    r.n_own = r.sh.hi - r.sh.lo;
+    CK(hipMalloc((void **)&r.x, (size_t)M * r.n_feed * H * sizeof(float)));
+    CK(hipMalloc((void **)&r.y, (size_t)r.n_feed * H * sizeof(float)));
+    const long long n = r.n_feed * H, s0 = bf_shard_first_feed(&r.sh) * H;
+    for (int m = 0; m < M; ++m)
+        hipLaunchKernelGGL(stream_noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, r.x + (size_t)m * n, s0, n, m, 1234);
+    CK(hipGetLastError());
+    return 0;
+}
+
+// the rank's slice in `chunks` pieces on `cs`; after piece c, `on_piece(c, first owned hop of the piece, its hops)` is called
+// with the compute stream positioned right behind that piece
+template <typename F>
+static int walk(bf_handle *bf, Rank &r, int M, int H, int chunks, hipStream_t cs, F &&on_piece) {
+    CKB(bf_reset_async(bf, cs));  // cold start, ordered on the compute stream
+    const long long per = (r.n_feed + chunks - 1) / chunks;
+    // planar input with n_feed * H samples per microphone: a piece is a column range, described by the handle's mic stride
+    for (int c = 0; c < chunks; ++c) {
+        const long long f0 = c * per, f1 = (f0 + per < r.n_feed) ? f0 + per : r.n_feed;
+        if (f1 <= f0) break;
+        CKB(bf_process_batch_device_strided(bf, r.x + f0 * H, (size_t)(f1 - f0), r.y + f0 * H, cs, (long)(r.n_feed * H)));
+        const long long o0 = f0 > r.n_drop ? f0 : r.n_drop;  // owned part of the piece, in fed-hop indices
+        if (f1 > o0) {
+            int rc = on_piece(c, o0 - r.n_drop, f1 - o0);
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 6) {
+        fprintf(stderr, "usage: %s <das|mvdr|lcmv|phase> <n_mics> <total_frames> <world> <rank|logical> [id_file] [chunks] [steps]\n", argv[0]);
+        return 2;
+    }
+    const char *names[] = {"das", "mvdr", "lcmv", "gss", "phase"};
+    int algo = -1;
+    for (int i = 0; i < 5; ++i)
+        if (!strcmp(argv[1], names[i])) algo = i;
+    const int M = atoi(argv[2]);
+    const long long F = atoll(argv[3]);
+    const int world = atoi(argv[4]);
+    const bool logical = !strcmp(argv[5], "logical");
+    const int rank = logical ? 0 : atoi(argv[5]);
+    const char *id_file = argc > 6 ? argv[6] : "/tmp/bf_shard_node.id";
+    const int chunks = argc > 7 ? atoi(argv[7]) : 4;
+    const int steps = argc > 8 ? atoi(argv[8]) : 3;
+    bf_config cfg;
+    if (algo < 0 || algo == BF_GSS || bf_config_init(&cfg, algo) != BF_OK || M < 1 || M > 16 || world < 1 || F < world) {
+        fprintf(stderr, "bad arguments\n");
+        return 2;
+    }
+    static const double ax[16] = {0.158, 0.158, -0.045, -0.050, -0.195, -0.057, 0.180, 0.158, 0.056, -0.050, -0.128, -0.195, -0.132, -0.057, 0.056, 0.158};
+    static const double ay[16] = {0.115, -0.115, 0.000, -0.188, 0.000, 0.186, 0.000, -0.115, -0.171, -0.188, -0.098, 0.000, 0.098, 0.186, 0.171, 0.115};
+    cfg.n_mics = M;  // beamform_config.yaml:20-35 ("aira16"), first M entries
+    for (int m = 0; m < M; ++m) { cfg.mic_x[m] = ax[m]; cfg.mic_y[m] = ay[m]; }
+    if (algo == BF_LCMV) {
+        cfg.n_interf = 3;
+        cfg.interf_angle[0] = -60.0; cfg.interf_angle[1] = 90.0; cfg.interf_angle[2] = 150.0;
+    }
+    const int halo = bf_shard_halo(&cfg);
+    if (halo < 0) {
+        fprintf(stderr, "this node recurses over frames: it shards by stream only\n");
+        return 2;
+    }
+    int ndev = 0;
+    CK(hipGetDeviceCount(&ndev));
+    cfg.device = logical ? 0 : rank % ndev;
+    CK(hipSetDevice(cfg.device));
+    const int H = cfg.hop;
+    hipStream_t cs, gs;  // compute / gather
+    CK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
+    bf_handle *bf = nullptr;
+    CKB(bf_create(&cfg, &bf));
+
+    if (logical) {
+        // unsharded reference on the same device, then every rank's slice in turn
+        Rank whole;
+        CKB(bf_shard_plan((size_t)F, 1, 0, halo, &whole.sh));
+        if (make_slice(whole, M, H, cs)) return 1;
+        CKB(bf_shard_run(bf, whole.x, &whole.sh, whole.y, cs));
+        float *out = nullptr;
+        CK(hipMalloc((void **)&out, (size_t)F * H * sizeof(float)));
+        for (int r = 0; r < world; ++r) {
+            Rank rk;
+            CKB(bf_shard_plan((size_t)F, world, r, halo, &rk.sh));
+            if (make_slice(rk, M, H, cs)) return 1;
+            int rc = walk(bf, rk, M, H, chunks, cs, [&](int, long long own0, long long n) -> int {
+                CK(hipMemcpyAsync(out + (rk.sh.lo + own0) * H, rk.y + (rk.n_drop + own0) * H, (size_t)n * H * sizeof(float),
+                                  hipMemcpyDeviceToDevice, cs));
+                return 0;
+            });
+            if (rc) return rc;
+            CK(hipStreamSynchronize(cs));
+            CK(hipFree(rk.x));
+            CK(hipFree(rk.y));
+        }
+        std::vector<float> a((size_t)F * H), b((size_t)F * H);
+        CK(hipMemcpy(a.data(), whole.y, a.size() * sizeof(float), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(b.data(), out, b.size() * sizeof(float), hipMemcpyDeviceToHost));
+        double num = 0, den = 0;
+        long long bad = 0, differ = 0;
+        for (size_t i = (size_t)(halo + 1) * H; i < a.size(); ++i) {  // mvdr / lcmv: the first P+1 frames are the reference's NaN frames
+            if (!std::isfinite(a[i]) || !std::isfinite(b[i])) { bad += (std::isfinite(a[i]) != std::isfinite(b[i])); continue; }
+            num += ((double)a[i] - b[i]) * ((double)a[i] - b[i]);
+            den += (double)a[i] * a[i];
+            differ += a[i] != b[i];
+        }
+        const double rel = std::sqrt(num / (den + 1e-300));
+        printf("logical %d ranks x %d pieces, %s %d-mic %lld frames: rel L2 vs unsharded %.3e, %lld samples differ, %lld finite-mask mismatches\n",
+               world, chunks, names[algo], M, F, rel, differ, bad);
+        bf_destroy(bf);
+        return (rel < 1e-5 && bad == 0) ? 0 : 1;
+    }
+
+    // ---- one process per rank, RCCL for the gather -----------------------------------------------------------------------
+    ncclUniqueId id;
+    if (rank == 0) {
+        CKN(ncclGetUniqueId(&id));
+        std::string tmp = std::string(id_file) + ".tmp";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(&id, sizeof(id), 1, f) != 1) return 1;
+        fclose(f);
+        rename(tmp.c_str(), id_file);
+    } else {
+        FILE *f = nullptr;
+        for (int i = 0; i < 600 && !(f = fopen(id_file, "rb")); ++i) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        if (!f || fread(&id, sizeof(id), 1, f) != 1) return 1;
+        fclose(f);
+    }
+    ncclComm_t comm;
+    CKN(ncclCommInitRank(&comm, world, id, rank));
+    Rank me;
+    CKB(bf_shard_plan((size_t)F, world, rank, halo, &me.sh));
+    if (make_slice(me, M, H, cs)) return 1;
+    float *out = nullptr;  // rank 0: the whole output, hops in stream order
+    if (rank == 0) CK(hipMalloc((void **)&out, (size_t)F * H * sizeof(float)));
+    std::vector<bf_shard> plan(world);
+    for (int r = 0; r < world; ++r) CKB(bf_shard_plan((size_t)F, world, r, halo, &plan[r]));
+    hipEvent_t piece_done;
+    CK(hipEventCreateWithFlags(&piece_done, hipEventDisableTiming));
+
+    auto step = [&](bool gather) -> int {
+        return walk(bf, me, M, H, chunks, cs, [&](int c, long long own0, long long n) -> int {
+            if (!gather) return 0;
+            // piece c of every rank moves while piece c+1 is computed: the gather stream waits for this piece only
+            CK(hipEventRecord(piece_done, cs));
+            CK(hipStreamWaitEvent(gs, piece_done, 0));
+            if (rank == 0) CK(hipMemcpyAsync(out + own0 * H, me.y + (me.n_drop + own0) * H, (size_t)n * H * sizeof(float), hipMemcpyDeviceToDevice, gs));
+            CKN(ncclGroupStart());
+            if (rank != 0) {
+                CKN(ncclSend(me.y + (me.n_drop + own0) * H, (size_t)n * H, ncclFloat, 0, comm, gs));
+            } else {
+                for (int r = 1; r < world; ++r) {  // every rank cuts its slice the same way: piece c of rank r is computable here
+                    Rank pr;
+                    pr.sh = plan[r];
+                    const long long nf = bf_shard_n_feed(&pr.sh), nd = bf_shard_n_drop(&pr.sh), per = (nf + chunks - 1) / chunks;
+                    const long long f0 = c * per, f1 = (f0 + per < nf) ? f0 + per : nf, o0 = f0 > nd ? f0 : nd;
+                    if (f1 > o0) CKN(ncclRecv(out + (pr.sh.lo + o0 - nd) * H, (size_t)(f1 - o0) * H, ncclFloat, r, comm, gs));
+                }
+            }
+            CKN(ncclGroupEnd());
+            return 0;
+        });
+    };
+    auto timed = [&](bool gather, double *ms) -> int {
+        if (step(gather)) return 1;  // warm-up (first gather also builds the channels)
+        CK(hipStreamSynchronize(cs));
+        CK(hipStreamSynchronize(gs));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < steps; ++i)
+            if (step(gather)) return 1;
+        CK(hipStreamSynchronize(cs));
+        CK(hipStreamSynchronize(gs));
+        *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / steps;
+        return 0;
+    };
+    double ms_compute = 0, ms_gather = 0;
+    if (timed(false, &ms_compute) || timed(true, &ms_gather)) return 1;
+    if (rank == 0) {
+        std::vector<float> o((size_t)F * H);
+        CK(hipMemcpy(o.data(), out, o.size() * sizeof(float), hipMemcpyDeviceToHost));
+        double cs_ = 0;
+        for (size_t i = (size_t)(halo + 1) * H; i < o.size(); ++i)
+            if (std::isfinite(o[i])) cs_ += std::fabs((double)o[i]);
+        printf("{\"world\": %d, \"algo\": \"%s\", \"mics\": %d, \"total_frames\": %lld, \"pieces\": %d, \"ms_per_step_compute\": %.4f, "
+               "\"ms_per_step_with_overlapped_gather\": %.4f, \"frames_per_s_with_gather\": %.4e, \"checksum\": %.6f}\n",
+               world, names[algo], M, F, chunks, ms_compute, ms_gather, (double)F / (ms_gather * 1e-3), cs_);
+    }
+    ncclCommDestroy(comm);
+    bf_destroy(bf);
+    return 0;
+}

@@ -202,8 +202,40 @@ int bf_get_weights(bf_handle *h, double *w_host);
 size_t bf_state_size(const bf_handle *h);
 int bf_get_state(bf_handle *h, void *blob_host, size_t size);
 int bf_set_state(bf_handle *h, const void *blob_host, size_t size);
-/* Back to the reference's cold start (zeroed rings/tails/history). */
+/* Back to the reference's cold start (zeroed rings/tails/history; prepare_overlap_and_add, util.h:272-286).  Host-synchronous:
+ * waits for the device before and after. */
 int bf_reset(bf_handle *h);
+/* The same, enqueued on `hip_stream` without host synchronisation: ordered against the batches the caller runs on that
+ * stream (what a per-step cold start in a stream-driven loop needs: beamform_amd/shard.py run_shard, bf_shard_run). */
+int bf_reset_async(bf_handle *h, void *hip_stream);
+
+/* ---- frame-range sharding of one long stream across processes (one per GPU) -- SURVEY 8(e) ---------------------------------
+ * The reference runs one node per process on one stream (das.cpp:101-145); frames are independent except for the overlap-add
+ * neighbour (util.h:301-302) and mvdr / lcmv's covariance of the previous P frames (mvdr.cpp:87,100-101), so a rank that owns
+ * the output hops [lo, hi) feeds a COLD node with `lead` hop (seeds the ring buffer, util.h:272-277) + `warm` recomputed frames
+ * (output dropped) + its owned frames and needs no data-path collective; the one collective is the final gather of the
+ * owned hops (RCCL over xGMI: examples/shard_node.cpp calls it directly, beamform_amd/shard.py through torch.distributed). */
+/* bf_process_batch_device on a column range of a longer planar buffer: microphone m starts at x_dev + m * mic_stride
+ * (samples), so one resident slice can be walked in pieces without copies (state carries from piece to piece as always). */
+int bf_process_batch_device_strided(bf_handle *h, const float *x_dev, size_t n_frames, float *y_dev, void *hip_stream,
+                                    long mic_stride);
+typedef struct bf_shard {
+    long long lo, hi; /* output hops this rank owns */
+    int warm;         /* frames recomputed in front of lo (clipped at the stream start) */
+    int lead;         /* hops fed in front of the first recomputed frame (0 at the stream start) */
+} bf_shard;
+/* Frames in front of its first frame a shard must recompute: 1 (das, phase), past_windows + 1 (mvdr, lcmv);
+ * -1 for the nodes that recurse over frames or samples (gss, phasempf, mcra, gsc): those shard by stream only. */
+int bf_shard_halo(const bf_config *cfg);
+/* Contiguous, near-equal frame ranges; rank 0 starts from the true stream state (no warm-up, no lead). */
+int bf_shard_plan(size_t n_frames, int world, int rank, int halo, bf_shard *out);
+static inline long long bf_shard_first_feed(const bf_shard *s) { return s->lo - s->warm - s->lead; }
+static inline long long bf_shard_n_feed(const bf_shard *s) { return s->hi - bf_shard_first_feed(s); }
+static inline long long bf_shard_n_drop(const bf_shard *s) { return (long long)s->warm + s->lead; }
+/* One rank's step: cold start + the fed hops, enqueued on `hip_stream` without host synchronisation.  x_feed_dev holds hops
+ * [first_feed, hi) of the global stream in the handle's layout, y_feed_dev n_feed * hop floats; the owned hops start at
+ * element n_drop * hop of y_feed_dev.  One input stream, one look direction. */
+int bf_shard_run(bf_handle *h, const float *x_feed_dev, const bf_shard *shard, float *y_feed_dev, void *hip_stream);
 
 /* Timing hook for bench.py: runs bf_process_batch_device `iters` times between
  * two hipEvents recorded on `hip_stream` (mean ms per call -> *ms_per_call) and,
@@ -211,6 +243,10 @@ int bf_reset(bf_handle *h);
  * own event pair on the same stream (mean ms per launch -> *ms_kernel). */
 int bf_time_batch_device(bf_handle *h, const float *x_dev, size_t n_frames, float *y_dev, void *hip_stream,
                          int iters, float *ms_per_call, float *ms_kernel);
+/* The same per-launch event pairs around the launches the CALLER issues between begin and end (bench.py takes its
+ * roofline duration from the very launches its step time covers).  end: mean ms per launch, number of launches. */
+int bf_kernel_timing_begin(bf_handle *h);
+int bf_kernel_timing_end(bf_handle *h, float *ms_mean, int *n_launches);
 
 /* ---- rosjack output stage, file half, and the batch front-end ----------------------------------------
  * rosjack.cpp:189-210: sf_open(audio_file_path, SFM_WRITE, {WAV | PCM_16, 1 channel, JACK or resampled rate});

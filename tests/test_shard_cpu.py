@@ -124,3 +124,103 @@ def test_two_rank_direction_sharding():
     x = make_scene(M, F, seed=321)
     for d, t in enumerate(thetas):
         assert np.array_equal(full[d], oracle.OracleNode(make_params("das", n_mics=M, theta=t)).process(x)[0])
+
+
+class _OracleBf:
+    """CPU stand-in with the slice of capi.Beamformer's interface that shard.run_shard_overlapped drives (raw pointers in,
+    state carried from piece to piece): the oracle node is the compute (test infrastructure)."""
+
+    def __init__(self, p):
+        import oracle
+        self._p, self._oracle = p, oracle
+        self.H, self.M, self.n_streams, self.n_dirs = p["hop"], p["n_mics"], 1, 1
+        self.node = oracle.OracleNode(p)
+
+    def reset_async(self, stream=0):
+        self.node = self._oracle.OracleNode(self._p)
+
+    def process_device_strided(self, x_ptr, n_frames, y_ptr, mic_stride, stream=0):
+        import ctypes
+        n = n_frames * self.H
+        x = np.stack([np.ctypeslib.as_array(ctypes.cast(x_ptr + 4 * m * mic_stride, ctypes.POINTER(ctypes.c_float)), (n,))
+                      for m in range(self.M)])
+        y, _ = self.node.process(np.ascontiguousarray(x))
+        np.ctypeslib.as_array(ctypes.cast(y_ptr, ctypes.POINTER(ctypes.c_float)), (n,))[:] = y
+
+
+def _overlap_worker(rank, world, port, algo, M, F, n_pieces, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p = make_params(algo, n_mics=M, theta=20.0)
+    halo = shard.halo_frames(p)
+    sh = shard.plan(F, world, rank, halo)
+    x = torch.from_numpy(np.ascontiguousarray(make_scene(M, F, seed=123)[:, sh.first_feed_frame * 512: sh.hi * 512]))
+    y = torch.zeros(sh.n_feed * 512)
+    out = torch.full((F * 512,), float("nan")) if rank == 0 else None
+    works = shard.run_shard_overlapped(_OracleBf(p), x, y, F, world, rank, halo, n_pieces=n_pieces, out=out)
+    for w in works:
+        w.wait()
+    if rank == 0:
+        ret.put(out.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("algo,M,F,world,n_pieces", [("das", 4, 23, 2, 3), ("mvdr", 4, 41, 3, 4), ("das", 3, 9, 2, 8)])
+def test_overlapped_gather_reproduces_single_stream(algo, M, F, world, n_pieces):
+    """The chunked walk + per-piece point-to-point transfers (shard.run_shard_overlapped) assemble the single-stream output,
+    including pieces that lie entirely inside a rank's warm-up frames and more pieces than frames."""
+    import torch.multiprocessing as mp
+    import oracle
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, algo, M, F, n_pieces, ret)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    full = ret.get(timeout=120)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    y_ref, _ = oracle.OracleNode(make_params(algo, n_mics=M, theta=20.0)).process(make_scene(M, F, seed=123))
+    assert np.array_equal(full, y_ref, equal_nan=True)
+
+
+def test_pieces_cover_the_owned_range():
+    for F, W, halo, K in [(100, 3, 11, 4), (9, 2, 1, 8), (65536, 8, 1, 4), (40, 4, 11, 1)]:
+        for r in range(W):
+            sh = shard.plan(F, W, r, halo)
+            ps = shard.pieces(sh, K)
+            assert ps[0][0] == 0 and ps[-1][1] == sh.n_feed and all(a[1] == b[0] for a, b in zip(ps, ps[1:]))
+            own = [h for _, _, o0, n in ps for h in range(o0, o0 + n)]
+            assert own == list(range(sh.n_own))
+
+
+def test_c_shard_plan_matches_python():
+    """include/bfcore.h bf_shard_plan / bf_shard_halo (what a C++ embedding calls) == beamform_amd.shard.plan / halo_frames."""
+    import ctypes as C
+    from beamform_amd import capi
+
+    class CShard(C.Structure):
+        _fields_ = [("lo", C.c_longlong), ("hi", C.c_longlong), ("warm", C.c_int), ("lead", C.c_int)]
+
+    L = capi.load()
+    L.bf_shard_plan.argtypes = [C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(CShard)]
+    for F, W, halo in [(10, 2, 1), (11, 3, 11), (65536, 8, 1), (262144, 8, 11), (7, 8, 0), (5, 1, 3)]:
+        for r in range(W):
+            cs = CShard()
+            assert L.bf_shard_plan(F, W, r, halo, C.byref(cs)) == 0
+            ps = shard.plan(F, W, r, halo)
+            assert (cs.lo, cs.hi, cs.warm, cs.lead) == (ps.lo, ps.hi, ps.warm, ps.lead)
+    assert L.bf_shard_plan(10, 2, 2, 1, C.byref(CShard())) != 0
+    for algo in ("das", "phase", "mvdr", "lcmv", "gss", "phasempf", "mcra", "gsc"):
+        p = make_params(algo, interf=(10.0,) if algo in ("lcmv", "gss") else ())
+        cfg = capi.config_from_params(p)
+        h = L.bf_shard_halo(C.byref(cfg))
+        assert h == (shard.halo_frames(p) if shard.halo_frames(p) is not None else -1)
