@@ -26,7 +26,7 @@ EXPORTS = (
     "bf_version", "bf_strerror", "bf_last_error", "bf_device_count", "bf_config_init", "bf_config_load_yaml",
     "bf_config_parse_yaml", "bf_create", "bf_destroy", "bf_set_theta", "bf_set_interference", "bf_process_hop",
     "bf_process_batch", "bf_process_batch_device", "bf_get_weights", "bf_state_size", "bf_get_state", "bf_set_state",
-    "bf_reset", "bf_reset_async", "bf_shard_halo", "bf_shard_plan", "bf_shard_run", "bf_process_batch_device_strided", "bf_kernel_timing_begin", "bf_kernel_timing_end", "bf_time_batch_device", "bf_n_interferers", "bf_set_theta_dir", "bf_set_thetas", "bf_stream_rms", "bf_host_alloc", "bf_host_free",
+    "bf_reset", "bf_reset_async", "bf_shard_halo", "bf_shard_plan", "bf_shard_run", "bf_shard_first_feed", "bf_shard_n_feed", "bf_shard_n_drop", "bf_process_batch_device_strided", "bf_kernel_timing_begin", "bf_kernel_timing_end", "bf_time_batch_device", "bf_n_interferers", "bf_set_theta_dir", "bf_set_thetas", "bf_stream_rms", "bf_host_alloc", "bf_host_free",
     "bf_wav_writer_open", "bf_wav_writer_write", "bf_wav_writer_write_pcm16", "bf_wav_writer_close", "bf_float_to_pcm16",
     "bf_float_to_pcm16_device", "bf_wav_read", "bf_planar_f32_read", "bf_wav_free",
     "bf_resampler_create", "bf_resampler_set_table", "bf_resampler_reset", "bf_resampler_out_count", "bf_resampler_latency",

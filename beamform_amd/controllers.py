@@ -222,16 +222,43 @@ class Vad:
         return self.active
 
 
+class JackRef:
+    """beamform/src/jack_ref.cpp:19-30 + util.h:353-379 (do_overlap_bymic): the reference channel of the two-topic controllers
+    -- one microphone "in the same delayed manner as the rest of the frequency-domain beamformers", i.e. through the WOLA
+    framing with NO processing in between: frame t = [hop t-1 | hop t] times the sqrt-Hann window (util.h:235, in double),
+    stored as float, times the window again (jack_ref.cpp:26-29, float x double -> float), overlap-added
+    (util.h:301-302).  sqrt-Hann^2 at 50 % overlap sums to one, so the output is the input delayed by ONE hop (to float
+    rounding): sample-aligned with the beamformer output that energy2theta-diff.py:74 subtracts from it."""
+
+    def __init__(self, hop: int = 512):
+        self.H = int(hop)
+        n = np.arange(2 * self.H, dtype=np.float64)
+        self.win = np.sqrt(0.5 - 0.5 * np.cos(2.0 * np.pi * n / (2 * self.H)))  # util.h:201-211
+        self.prev_hop = np.zeros(self.H, np.float32)   # ring pre-filled with one hop of zeros (util.h:272-277)
+        self.tail = np.zeros(self.H, np.float32)       # out_buff calloc'ed (util.h:285-286)
+
+    def process_hop(self, s) -> np.ndarray:
+        s = np.asarray(s, np.float32)
+        frame = np.concatenate([self.prev_hop, s]).astype(np.float64) * self.win   # overlap_and_add_prepare_input
+        o = frame.astype(np.float32)                                              # out[j] = real(x[j])
+        o = (o.astype(np.float64) * self.win).astype(np.float32)                  # out[j] *= hann_win[j]
+        y = self.tail + o[:self.H]                                                # float + float (util.h:301-302)
+        self.tail, self.prev_hop = o[self.H:].copy(), s.copy()
+        return y
+
+
 def follow(node, x: np.ndarray, controller, ref_channel: int = 0):
     """The closed loop of the reference, one JACK period at a time: node.process_hop -> controller -> node.set_theta.
 
     node: anything with process_hop([M, hop]) -> [hop], set_theta(deg) and an attribute H (beamform_amd.capi.Beamformer;
     the tests also drive the oracle node through it).  x: [M, F*hop] float32.  For the two-topic controllers
-    (-diff / -spec) the reference channel is microphone `ref_channel` of the same period (jack_ref.cpp republishes one input).
+    (-diff / -spec) the reference channel is microphone `ref_channel` through the jackaudio_ref node (JackRef above): the same
+    one-hop WOLA latency as the beamformer output, so the difference the controller forms is sample-aligned.
     Returns (y [F*hop], thetas: list of (hop index, theta) published)."""
     H = node.H
     F = x.shape[1] // H
     ys, published = [], []
+    ref = JackRef(H) if hasattr(controller, "on_windows") else None
     for t in range(F):
         seg = np.ascontiguousarray(x[:, t * H:(t + 1) * H])
         y = node.process_hop(seg)
@@ -239,7 +266,7 @@ def follow(node, x: np.ndarray, controller, ref_channel: int = 0):
             y = y[0]
         ys.append(np.array(y, copy=True))
         if hasattr(controller, "on_windows"):
-            theta = controller.on_windows(y, seg[ref_channel])
+            theta = controller.on_windows(y, ref.process_hop(seg[ref_channel]))
         else:
             theta = controller.on_window(y)
         if theta is not None:

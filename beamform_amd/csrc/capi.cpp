@@ -71,6 +71,8 @@ struct bf_handle {
     // per-launch timing of the dominant kernel (bf_time_batch_device)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> *kernel_events = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> own_events;  // bf_kernel_timing_begin / _end
+    bool row0_written = true;  // reference-mic weight row: written by the cold start's update_weights(true), left zero by a
+                               // structural interferer change (quirk Q3, lcmv.cpp:243-252,281,304)
 };
 
 namespace {
@@ -318,6 +320,7 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
     h->steer.resize(h->n_dirs);
     for (auto &st : h->steer) st.allocate(h->N, h->M, h->S);
     rebuild_steering(h, true);
+    h->row0_written = true;
 
     BF_CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     BF_CREATE_HIP(hipEventCreate(&h->ev0));
@@ -505,6 +508,7 @@ int bf_set_interference(bf_handle *h, unsigned id, double degrees) {
         // free_interf_buffers + allocate_interf_buffers: weights come back zeroed, row 0 is not rewritten (Q3)
         h->S = (int)ia.size() + 1;
         for (auto &st : h->steer) st.allocate(h->N, h->M, h->S);
+        h->row0_written = false;
         if (h->pipe) h->pipe->set_columns(h->S);
     }
     rebuild_steering(h, false);
@@ -683,6 +687,10 @@ int bf_shard_plan(size_t n_frames, int world, int rank, int halo, bf_shard *out)
     return BF_OK;
 }
 
+long long bf_shard_first_feed(const bf_shard *s) { return s ? s->lo - s->warm - s->lead : 0; }
+long long bf_shard_n_feed(const bf_shard *s) { return s ? s->hi - bf_shard_first_feed(s) : 0; }
+long long bf_shard_n_drop(const bf_shard *s) { return s ? (long long)s->warm + s->lead : 0; }
+
 int bf_shard_run(bf_handle *h, const float *x_feed_dev, const bf_shard *sh, float *y_feed_dev, void *hip_stream) {
     if (!h || !sh) return BF_EINVAL;
     if (h->n_streams != 1 || h->n_dirs != 1)
@@ -760,15 +768,36 @@ struct bf_state_header {
     uint32_t magic, algo, n_mics, n_streams, hop, das_impl;
     uint64_t payload;
 };
-static const uint32_t kStateMagic = 0x42465332;  // "BFS2"
+static const uint32_t kStateMagic = 0x42465333;  // "BFS3"
 // control-plane part of a checkpoint: what /theta and /theta_interference have made of the node since start-up
 struct bf_state_control {
     uint32_t kp1;              // constraint columns (1 + interferers)
     uint32_t row0_written;     // reference-mic weight row: 1 after a cold start, 0 after a structural change (quirk Q3)
     uint64_t gss_pending;      // look directions whose demixing matrices restart at the next run (gss.cpp:90-93)
+    uint64_t cfg_hash;         // the bf_config fields that give the state its meaning (geometry, rate, band, history length, ...)
     double theta[BF_MAX_DIRS];
     double interf[BF_MAX_INTERF];
 };
+
+// FNV-1a over the configuration a checkpoint is only valid under: restoring covariance history or demixing matrices next to
+// another geometry, sample rate, band or window count would silently pair them with the wrong steering
+static uint64_t state_cfg_hash(const bf_handle *h) {
+    uint64_t x = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t n) {
+        const unsigned char *b = (const unsigned char *)p;
+        for (size_t i = 0; i < n; ++i) { x ^= b[i]; x *= 1099511628211ull; }
+    };
+    const bf_config &c = h->cfg;
+    mix(c.mic_x, sizeof(double) * h->M);
+    mix(c.mic_y, sizeof(double) * h->M);
+    const double d[] = {c.sample_rate, c.freq_mag_threshold, c.freq_max, c.freq_min, c.mu, c.lambda_, c.min_phase, c.min_mag,
+                        c.mcra_alphaS, c.mcra_alphaD, c.mcra_alphaD2, c.mcra_delta, c.mpf_alphaS, c.mpf_eta, c.mpf_rev_gamma,
+                        c.mpf_rev_delta, c.gsc_mu0, c.gsc_mu_max};
+    mix(d, sizeof(d));
+    const int i[] = {c.past_windows, c.smooth_size, c.mcra_L, c.layout, c.gsc_filter_size, h->n_dirs};
+    mix(i, sizeof(i));
+    return x;
+}
 
 size_t bf_state_size(const bf_handle *h) {
     if (!h) return 0;
@@ -781,7 +810,11 @@ size_t bf_state_size(const bf_handle *h) {
 }
 
 int bf_get_state(bf_handle *h, void *blob, size_t size) {
-    if (!h || !blob || size < bf_state_size(h)) return BF_EINVAL;
+    if (!h || !blob) return BF_EINVAL;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);  // the payload size follows the interferer count, which /theta_interference changes
+        if (size < bf_state_size(h)) return BF_EINVAL;
+    }
     BF_HIP(h, hipSetDevice(h->device));
     BF_HIP(h, hipDeviceSynchronize());
     bf_state_header hd = {kStateMagic, (uint32_t)h->cfg.algo, (uint32_t)h->M, (uint32_t)h->n_streams | ((uint32_t)h->n_dirs << 20),
@@ -792,7 +825,8 @@ int bf_get_state(bf_handle *h, void *blob, size_t size) {
     {
         std::lock_guard<std::mutex> lk(h->mu);
         ct.kp1 = (uint32_t)h->S;
-        ct.row0_written = h->steer[0].at(0, 0, 0) == cplxd(1.0, 0.0) ? 1u : 0u;
+        ct.row0_written = h->row0_written ? 1u : 0u;
+        ct.cfg_hash = state_cfg_hash(h);
         ct.gss_pending = h->pipe ? h->pipe->pending_resets() : 0ull;
         for (int d = 0; d < h->n_dirs; ++d) ct.theta[d] = h->angle[d];
         for (size_t k = 0; k < h->interf.size(); ++k) ct.interf[k] = h->interf[k];
@@ -810,7 +844,11 @@ int bf_get_state(bf_handle *h, void *blob, size_t size) {
 }
 
 int bf_set_state(bf_handle *h, const void *blob, size_t size) {
-    if (!h || !blob || size < bf_state_size(h)) return BF_EINVAL;
+    if (!h || !blob) return BF_EINVAL;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (size < bf_state_size(h)) return BF_EINVAL;
+    }
     bf_state_header hd;
     memcpy(&hd, blob, sizeof(hd));
     if (hd.magic != kStateMagic || hd.algo != (uint32_t)h->cfg.algo || hd.n_mics != (uint32_t)h->M ||
@@ -825,6 +863,13 @@ int bf_set_state(bf_handle *h, const void *blob, size_t size) {
         // was built under: restore the angles, the interferer list and the pending demixing resets with it
         std::lock_guard<std::mutex> lk(h->mu);
         if ((int)ct.kp1 != h->S) return fail(h, BF_EINVAL, "state blob was taken with a different number of interferers");
+        if (ct.cfg_hash != state_cfg_hash(h))
+            return fail(h, BF_EINVAL, "state blob was taken under another configuration (geometry, rate, band, window count or node parameters)");
+        for (int d = 0; d < h->n_dirs; ++d)
+            if (!std::isfinite(ct.theta[d])) return fail(h, BF_EINVAL, "state blob holds a non-finite look angle");
+        for (size_t k = 0; k < h->interf.size(); ++k)
+            if (!std::isfinite(ct.interf[k])) return fail(h, BF_EINVAL, "state blob holds a non-finite interferer angle");
+        h->row0_written = ct.row0_written != 0;
         for (int d = 0; d < h->n_dirs; ++d) h->angle[d] = ct.theta[d];
         for (size_t k = 0; k < h->interf.size(); ++k) h->interf[k] = ct.interf[k];
         for (auto &st : h->steer)

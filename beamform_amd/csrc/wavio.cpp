@@ -11,8 +11,7 @@
 //     NO clipping: a sample beyond +-1.0 wraps modulo 2^16 exactly as the cast to short does there.
 //   * reading (sf_read_float on PCM files, the front-end): PCM16 -> float by x / 32768 (s2f_array, norm 1/0x8000),
 //     24- and 32-bit PCM by x / 2^23 and x / 2^31, IEEE float as is.
-// The resampling half (rosjack.cpp:311-350, libsamplerate SRC_SINC_FASTEST) needs that library's 2464-entry coefficient
-// table, which is in neither the reference nor the image: not built, on purpose.
+// The resampling half (rosjack.cpp:311-350, libsamplerate SRC_SINC_FASTEST) lives in resample.hip (bf_resampler_*).
 //
 // Host code only (file I/O).  The float -> PCM16 conversion of a batch that is resident in HBM has a device entry point
 // (convert.hip) so that the D2H copy moves 2 bytes per sample instead of 4.
@@ -124,6 +123,14 @@ int bf_wav_read(const char *path, float **planar, int *n_channels, size_t *n_sam
     *planar = nullptr;
     FILE *f = fopen(path, "rb");
     if (!f) return BF_ENOENT;
+    // chunk lengths come from the file: never allocate more than the file can hold (a corrupt or streamed header says 4 GiB)
+    long file_bytes = -1;
+    if (fseek(f, 0, SEEK_END) == 0) file_bytes = ftell(f);
+    if (file_bytes < 0 || fseek(f, 0, SEEK_SET) != 0) {
+        fclose(f);
+        return BF_EIO;
+    }
+    try {  // std::bad_alloc must not cross the extern "C" boundary
     unsigned char hd[12];
     int rc = BF_EINVAL;
     unsigned fmt = 0, ch = 0, bits = 0;
@@ -134,7 +141,10 @@ int bf_wav_read(const char *path, float **planar, int *n_channels, size_t *n_sam
         unsigned char ck[8];
         while (!have_data && fread(ck, 1, 8, f) == 8) {
             const uint32_t sz = get_u32(ck + 4);
+            const long here = ftell(f);
+            const uint64_t left = here >= 0 && here <= file_bytes ? (uint64_t)(file_bytes - here) : 0;
             if (memcmp(ck, "fmt ", 4) == 0 && sz >= 16) {
+                if (sz > 4096 || sz > left) break;  // WAVEFORMATEXTENSIBLE is 40 bytes
                 std::vector<unsigned char> b(sz);
                 if (fread(b.data(), 1, sz, f) != sz) break;
                 fmt = get_u16(b.data());
@@ -146,8 +156,9 @@ int bf_wav_read(const char *path, float **planar, int *n_channels, size_t *n_sam
                 if (sz & 1) fseek(f, 1, SEEK_CUR);
             } else if (memcmp(ck, "data", 4) == 0) {
                 if (!have_fmt) break;
-                data.resize(sz);
-                const size_t got = fread(data.data(), 1, sz, f);
+                const size_t want = sz < left ? (size_t)sz : (size_t)left;
+                data.resize(want);
+                const size_t got = want ? fread(data.data(), 1, want, f) : 0;
                 data.resize(got);  // a truncated or still-open file (length fields 0): take what is there
                 if (sz == 0) {
                     unsigned char tmp[65536];
@@ -192,6 +203,10 @@ int bf_wav_read(const char *path, float **planar, int *n_channels, size_t *n_sam
     }
     fclose(f);
     return rc;
+    } catch (...) {
+        fclose(f);
+        return BF_ENOMEM;
+    }
 }
 
 // Raw planar float32 file: [n_channels][n_samples] little-endian floats, nothing else (the layout bf_process_batch takes).

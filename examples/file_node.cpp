@@ -71,6 +71,7 @@ int main(int argc, char **argv) {
                                         : bf_planar_f32_read(argv[3], g_mics, &planar, &g_samples_per_mic);
     if (rc != BF_OK || (ends_with(argv[3], ".wav") && ch < g_mics)) {
         fprintf(stderr, "cannot read %s (%s)\n", argv[3], bf_strerror(rc));
+        bf_wav_free(planar);  // a readable file with too few channels
         return 2;
     }
     if (ends_with(argv[3], ".wav")) cfg.sample_rate = rate;  // rosjack_sample_rate = what the "server" runs at

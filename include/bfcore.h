@@ -229,9 +229,9 @@ typedef struct bf_shard {
 int bf_shard_halo(const bf_config *cfg);
 /* Contiguous, near-equal frame ranges; rank 0 starts from the true stream state (no warm-up, no lead). */
 int bf_shard_plan(size_t n_frames, int world, int rank, int halo, bf_shard *out);
-static inline long long bf_shard_first_feed(const bf_shard *s) { return s->lo - s->warm - s->lead; }
-static inline long long bf_shard_n_feed(const bf_shard *s) { return s->hi - bf_shard_first_feed(s); }
-static inline long long bf_shard_n_drop(const bf_shard *s) { return (long long)s->warm + s->lead; }
+long long bf_shard_first_feed(const bf_shard *s); /* first hop of the global stream fed to the rank's cold node: lo - warm - lead */
+long long bf_shard_n_feed(const bf_shard *s);     /* hops fed: lead + warm + owned */
+long long bf_shard_n_drop(const bf_shard *s);     /* output hops in front of the owned range that are discarded: warm + lead */
 /* One rank's step: cold start + the fed hops, enqueued on `hip_stream` without host synchronisation.  x_feed_dev holds hops
  * [first_feed, hi) of the global stream in the handle's layout, y_feed_dev n_feed * hop floats; the owned hops start at
  * element n_drop * hop of y_feed_dev.  One input stream, one look direction. */

@@ -26,7 +26,16 @@ def emul_lib():
 
 
 def rel_l2(a, b):
+    """||a - b|| / ||b||.  Both operands are scaled by the reference's largest magnitude first, so spectra of order 1e200 (the
+    rounding noise of a numerically singular constraint system) do not overflow the norm into inf / inf; a NaN result -- any
+    non-finite operand -- fails here instead of slipping through a max() (Python's max drops NaN unless it comes first)."""
     import numpy as np
     a = np.asarray(a, dtype=np.complex128 if np.iscomplexobj(a) or np.iscomplexobj(b) else np.float64)
     b = np.asarray(b, dtype=a.dtype)
-    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
+    assert np.isfinite(a).all() and np.isfinite(b).all(), "rel_l2: non-finite operand (mask those frames out explicitly)"
+    s = float(np.abs(b).max()) if b.size else 0.0
+    if s > 0.0:
+        a, b = a / s, b / s
+    r = float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
+    assert not np.isnan(r), "rel_l2 is NaN"
+    return r

@@ -200,3 +200,32 @@ def test_closed_loop_around_the_oracle_node():
     want = ref_energy2theta([tuple(float(v) for v in y[t * 512:(t + 1) * 512]) for t in range(F)], -15.0, num_win=30)
     assert pub == want
     assert np.ptp([t for _, t in pub]) > 0        # the angle really moves
+
+
+def test_jack_ref_is_the_input_delayed_by_one_hop():
+    """jack_ref.cpp:19-30: mic 0 through the sqrt-Hann^2 WOLA with no processing = the input one hop later (float rounding)."""
+    rng = np.random.default_rng(3)
+    s = (rng.standard_normal(20 * 512) * 0.2).astype(np.float32)
+    ref = controllers.JackRef(512)
+    out = np.concatenate([ref.process_hop(s[t * 512:(t + 1) * 512]) for t in range(20)])
+    assert np.array_equal(out[:512], np.zeros(512, np.float32))
+    assert np.abs(out[512:] - s[:-512]).max() < 2e-7
+
+
+def test_diff_controller_sees_an_aligned_reference():
+    """energy2theta-diff.py:74 subtracts the beamformer output from jackaudio_ref window by window.  With identical
+    channels on co-located microphones (every steering delay 0) das returns the input through the same WOLA, so the aligned
+    difference is ~0 -- with the undelayed reference channel it would be the full-scale difference of two hops."""
+    M, F = 4, 40
+    p = make_params("das", n_mics=M, mics=[(0.0, 0.0)] * M)
+    s = (np.random.default_rng(5).standard_normal(F * 512) * 0.2).astype(np.float32)
+    x = np.tile(s, (M, 1))
+    seen = []
+
+    class Spy(controllers.Energy2ThetaDiff):
+        def on_windows(self, win, win_ref):
+            seen.append(float(np.abs(np.asarray(win_ref, np.float64) - np.asarray(win, np.float64)).max()))
+            return super().on_windows(win, win_ref)
+
+    controllers.follow(oracle.OracleNode(p), x, Spy(initial_angle=0.0))
+    assert len(seen) == F and max(seen) < 1e-6, max(seen)

@@ -169,6 +169,32 @@ def test_das_large_batch_properties():
     assert d < 1e-6, d
 
 
+def test_das_large_batch_random_oracle_windows():
+    """BASELINE size against the ORACLE: a frame's output hop depends on three input hops only (util.h:217-242,301-302), so the
+    oracle fed hops [t0 - 2, t0 + n) reproduces hops t0 .. t0 + n - 1 of the 65 536-frame batch exactly as the reference would
+    compute them in the middle of the stream.  Windows at random offsets, at run boundaries of the kernel's frame walk
+    (multiples of 256 and of 16) and at both ends of the batch."""
+    import oracle
+    from beamform_amd.capi import Beamformer
+    torch = _torch()
+    M, F, n = 8, 65536, 24
+    p = make_params("das", n_mics=M, theta=-40.0)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.rand(M, F * 512, device="cuda", generator=g) - 0.5
+    y = torch.empty(F * 512, device="cuda")
+    Beamformer(p).process_device(x.data_ptr(), F, y.data_ptr())
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(5)
+    starts = [0, 2, 254, 256 * 100 - 3, 256 * 255 + 9, 16 * 1234 - 1, F - n] + [int(v) for v in rng.integers(2, F - n, 6)]
+    for t0 in starts:
+        a = max(t0 - 2, 0)
+        seg = x[:, a * 512:(t0 + n) * 512].cpu().numpy()
+        y_ref, _ = oracle.OracleNode(p).process(np.ascontiguousarray(seg))
+        ref = y_ref[(t0 - a) * 512:]
+        got = y[t0 * 512:(t0 + n) * 512].cpu().numpy()
+        assert rel_l2(got, ref) < TOL_TIME, t0
+
+
 def test_das_w64_variant_matches_oracle(monkeypatch):
     """The experimental 64-lane x 16-point FFT factorisation (BF_DAS_W64=1, das_fused_w64.hip) must agree with
     the oracle like the default kernel does (measured slower in round 1, kept as the round-2 base)."""

@@ -84,6 +84,13 @@ def test_mvdr_lcmv_match_oracle(algo, M, interf, F):
     y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
     y, Y = run_gpu(p, x)
     check(y, Y, y_ref, Y_ref)
+    # without the spectrum dump the per-bin kernels hand the fp32 backward transform f32x2 rows holding the in-band problems
+    # only (BinsArgs::yh32): the product's timed path
+    from beamform_amd.capi import Beamformer
+    y2 = Beamformer(p).process(x)
+    ok = np.isfinite(y_ref)
+    assert (np.isfinite(y2) == ok).all()
+    assert rel_l2(y2[ok], y_ref[ok]) < TOL_TIME
 
 
 def test_mvdr_history_carries_across_batches():
@@ -374,3 +381,43 @@ def test_checkpoint_carries_the_control_plane():
     assert np.abs(c.weights() - a.weights()).max() == 0.0
     ya, yc = a.process(np.ascontiguousarray(x[:, : F * 512])), c.process(np.ascontiguousarray(x[:, : F * 512]))
     assert np.array_equal(ya, yc, equal_nan=True)
+
+
+def test_checkpoint_is_refused_under_another_configuration():
+    """bf_set_state: a blob restores covariance history next to the steering it was built under; a handle with another
+    geometry, band, sample rate or window count must refuse it (the header alone -- algo, mics, streams, hop -- matches)."""
+    from beamform_amd.capi import Beamformer, BfError
+    _torch()
+    M, F = 8, 16
+    p = make_params("mvdr", n_mics=M, theta=20.0)
+    a = Beamformer(p)
+    a.process(make_scene(M, F, seed=3))
+    blob = a.get_state()
+    Beamformer(p).set_state(blob)  # same configuration: accepted
+    others = [dict(freq_max=8000.0), dict(sample_rate=44100.0), dict(mics=[(0.01 * i, 0.02 * i) for i in range(M)])]
+    for over in others:
+        with pytest.raises(BfError):
+            Beamformer(make_params("mvdr", n_mics=M, theta=20.0, **over)).set_state(blob)
+    import struct
+    bad = bytearray(blob)
+    # header 6 x u32 + u64 payload = 32 bytes; control block: kp1, row0 (u32), gss_pending, cfg_hash (u64), then theta[0]
+    struct.pack_into("<d", bad, 32 + 8 + 8 + 8, float("nan"))
+    with pytest.raises(BfError):
+        Beamformer(p).set_state(bytes(bad))
+
+
+def test_c_shard_node_example_reproduces_the_unsharded_stream():
+    """examples/shard_node.cpp in its `logical` mode: bf_shard_plan + bf_reset_async + strided pieces from C++, 3 ranks x 4
+    pieces on one GPU, against the unsharded run of the same counter-noise stream (the RCCL gather needs one GPU per rank)."""
+    import os
+    import subprocess
+    _torch()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "shard_node")
+    assert os.path.exists(exe), "examples/shard_node is built by `make all` (__graft_entry__.build)"
+    for algo, M, F in [("das", 8, 4099), ("mvdr", 8, 1500), ("lcmv", 16, 700)]:
+        out = subprocess.run([exe, algo, str(M), str(F), "3", "logical", "/tmp/unused", "4"], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+    # one rank, RCCL initialised for real: communicator of size 1, the overlapped walk, no peer
+    out = subprocess.run([exe, "das", "8", "8192", "1", "0", "/tmp/bf_shard_node_test.id", "4", "2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ms_per_step_with_overlapped_gather" in out.stdout, out.stdout + out.stderr

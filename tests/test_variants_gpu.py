@@ -1,0 +1,74 @@
+"""Every kernel an environment switch can select (DESIGN.md "Run-time switches") runs against the oracle: the switches are read
+once per process, so each case is its own child process.  A variant that stays in libbfcore.so stays tested."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-5
+
+CHILD = r"""
+import sys, json, numpy as np
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r + "/tests")
+import torch, oracle
+from beamform_amd.capi import Beamformer
+from beamform_amd.params import make_params
+from beamform_amd.synth import make_scene
+from conftest import rel_l2
+algo, M, interf, F, dump = %(algo)r, %(M)d, %(interf)r, %(F)d, %(dump)r
+p = make_params(algo, n_mics=M, interf=interf, theta=20.0)
+x = make_scene(M, F, seed=900 + M)
+y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
+bf = Beamformer(p)
+xd = torch.from_numpy(x).cuda()
+yd = torch.empty(F * 512, dtype=torch.float32, device="cuda")
+Yd = torch.empty((F, 1024, 2), dtype=torch.float64, device="cuda")
+bf.process_device(xd.data_ptr(), F, yd.data_ptr(), Yd.data_ptr() if dump else 0)
+torch.cuda.synchronize()
+y = yd.cpu().numpy()
+ok = np.isfinite(y_ref)
+res = {"finite_mask_equal": bool((np.isfinite(y) == ok).all()), "time": rel_l2(y[ok], y_ref[ok])}
+if dump:
+    Y = Yd.cpu().numpy().view(np.complex128)[..., 0]
+    if algo == "das":  # the fused kernel dumps the Hermitian part of y_fft (the part that reaches Re(ifft))
+        Yh = 0.5 * (Y_ref + np.conj(np.roll(Y_ref[:, ::-1], 1, axis=1)))
+        Y_ref = Yh
+    fin = np.isfinite(Y_ref).all(axis=1)
+    res["finite_frames_equal"] = bool((np.isfinite(Y).all(axis=1) == fin).all())
+    res["spectrum"] = max(rel_l2(Y[t], Y_ref[t]) for t in range(F) if fin[t])
+print("RESULT " + json.dumps(res))
+"""
+
+CASES = [
+    # (environment, algo, mics, interferers, frames, spectrum dump)
+    ({"BF_COV2D": "0"}, "lcmv", 16, (-60.0, 90.0, 150.0), 24, True),   # row-per-lane DPP kernel (mvdr_lcmv_row_kernel)
+    ({"BF_COV2D": "0"}, "mvdr", 12, (), 24, True),                     # lanes kernel, 9..16 microphones
+    ({"BF_COV2D": "2"}, "lcmv", 16, (-60.0, 90.0, 150.0), 24, True),   # two-wavefront build of the 2-D cyclic kernel
+    ({"BF_COV2D": "2"}, "mvdr", 16, (), 24, False),
+    ({"BF_MVDR_GROUP": "1"}, "mvdr", 8, (), 30, True),                 # group-per-problem kernel over LDS
+    ({"BF_MVDR_GROUP": "1"}, "lcmv", 8, (-60.0, 90.0), 30, False),
+    ({"BF_MVDR_TILE": "7"}, "mvdr", 8, (), 40, False),                 # mvdr_fast_kernel: lanes straddle tiles, short last tile
+    ({"BF_DAS_VARIANT": "0"}, "das", 8, (), 37, True),                 # round-1 transposes, run-time pair loop
+    ({"BF_DAS_VARIANT": "1"}, "das", 8, (), 37, True),                 # ds_write_addtid transposes, run-time pair loop
+    ({"BF_DAS_VARIANT": "1"}, "das", 5, (), 21, True),
+    ({"BF_ISTFT_F64": "1"}, "mvdr", 8, (), 30, False),                 # fp64 backward transform behind every node
+    ({"BF_ISTFT_F64": "1"}, "phase", 8, (), 24, True),
+]
+
+
+@pytest.mark.parametrize("env,algo,M,interf,F,dump", CASES, ids=[f"{'_'.join(f'{k}={v}' for k, v in c[0].items())}-{c[1]}{c[2]}" for c in CASES])
+def test_env_selected_kernel_matches_oracle(env, algo, M, interf, F, dump):
+    code = CHILD % dict(root=ROOT, algo=algo, M=M, interf=tuple(interf), F=F, dump=dump)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    res = json.loads(line[len("RESULT "):])
+    assert res["finite_mask_equal"], res
+    assert res["time"] < TOL, res
+    if dump:
+        assert res["finite_frames_equal"] and res["spectrum"] < TOL, res
