@@ -746,6 +746,218 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_il_kernel(DasFusedArgs a)
     }
 }
 
+// ---- interleaved input [sample][mic], 8 microphones: one WAVEFRONT per frame -----------------------------------------------
+// A 32-byte sample holds all eight microphones.  Lane l of half-wavefront h loads bytes 16 h .. 16 h + 15 of sample 32 j + l
+// (microphones 4h .. 4h+3 = pairs 2h, 2h+1), so ONE wave-instruction covers 32 whole samples = 1 KiB of contiguous memory:
+// every 128-byte line is requested once, fully used, by a quarter of the load instructions the planar kernel issues (its
+// loads are 4 bytes per lane).  Each half transforms its two pairs and accumulates a partial S over them; the halves exchange
+// their partial sums with v_permlane32_swap (copy + swap + add per register, no LDS) and then BOTH hold S.  The backward
+// transform therefore runs on the whole wavefront for one frame (half of it redundant: 3 wavefront-passes per frame where the
+// planar kernel needs 2.5); the output work is split: half 0 stores the frame's output hop, half 1 parks the tail for the next
+// frame.  The frame's single load phase is issued in front of the previous frame's backward transform and lands behind it.
+// Same tables and tail ring as das_fused_kernel; the accumulation order is (p0 + p1) + (p2 + p3): last-bit differences from the
+// planar kernel, none between batch / run cuts.
+template <int I0>
+__device__ __forceinline__ void halves_sum8(float (&v)[32]) {
+    float c0 = v[I0], c1 = v[I0 + 1], c2 = v[I0 + 2], c3 = v[I0 + 3], c4 = v[I0 + 4], c5 = v[I0 + 5], c6 = v[I0 + 6], c7 = v[I0 + 7];
+    // swap a, b: lanes 32..63 of a <-> lanes 0..31 of b.  With b a copy of a: a = (lo, lo), b = (hi, hi); a + b = lo + hi in both halves.
+    // s_nop 1: the two wait states a VALU write needs before v_permlane*_swap reads it.
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %8\n\tv_permlane32_swap_b32 %1, %9\n\tv_permlane32_swap_b32 %2, %10\n\tv_permlane32_swap_b32 %3, %11\n\t"
+        "v_permlane32_swap_b32 %4, %12\n\tv_permlane32_swap_b32 %5, %13\n\tv_permlane32_swap_b32 %6, %14\n\tv_permlane32_swap_b32 %7, %15"
+        : "+v"(v[I0]), "+v"(v[I0 + 1]), "+v"(v[I0 + 2]), "+v"(v[I0 + 3]), "+v"(v[I0 + 4]), "+v"(v[I0 + 5]), "+v"(v[I0 + 6]), "+v"(v[I0 + 7]),
+          "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7));
+    v[I0] += c0; v[I0 + 1] += c1; v[I0 + 2] += c2; v[I0 + 3] += c3;
+    v[I0 + 4] += c4; v[I0 + 5] += c5; v[I0 + 6] += c6; v[I0 + 7] += c7;
+}
+__device__ __forceinline__ void halves_sum(float (&v)[32]) {
+    halves_sum8<0>(v);
+    halves_sum8<8>(v);
+    halves_sum8<16>(v);
+    halves_sum8<24>(v);
+}
+
+constexpr int kIl8Waves = kBlock / 64;  // frames in flight per block
+__global__ __launch_bounds__(kBlock, 2) void das_fused_il8_kernel(DasFusedArgs a) {
+    constexpr int NPL = 4, M = 8;
+    __shared__ __attribute__((aligned(16))) float lds[kLdsFixed + NPL * 2048 + (kIl8Waves + 1) * kHop + 32];
+    float *s_win = lds + kLdsTw + kHalves * kLdsPlane;
+    float *s_tails = lds + kLdsFixed + NPL * 2048;
+    volatile int *s_flag = reinterpret_cast<volatile int *>(lds + kLdsFixed + NPL * 2048 + (kIl8Waves + 1) * kHop);
+    constexpr int kSlots = kIl8Waves + 1;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 31;
+    const int hw = tid >> 5, half = hw & 1;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: the frame, its addresses and its ring slots live in SGPRs
+    float *wplane = lds + kLdsTw + wv * kWPlane;
+    const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float *)wplane);
+    const float *wrowp = wplane + lane * kWRow + 32 * half;
+
+    const int stream = blockIdx.x / a.chunks_per_stream;
+    const long c_in_s = blockIdx.x - (long)stream * a.chunks_per_stream;
+    const int in_stream = stream / a.n_dirs;
+    const f32x2 *gains = a.gains + (long)(stream - in_stream * a.n_dirs) * NPL * 1024;
+    {
+        const f32x2 *twc = a.twiddle;
+        f32x2 *ltw = reinterpret_cast<f32x2 *>(lds);
+        for (int i = tid; i < kLdsTw / 2; i += kBlock) {  // paired tables, as the unrolled planar kernel
+            const int k1 = i >> 5, l = i & 31;
+            ltw[((k1 & 15) * 32 + l) * 2 + (k1 >> 4)] = twc[i];
+        }
+        for (int i = tid; i < kNfft; i += kBlock) s_win[(i & 31) * kPS + (i >> 5)] = a.window[i];
+        f32x2 *lg = reinterpret_cast<f32x2 *>(lds + kLdsFixed);
+        for (int i = tid; i < NPL * 1024; i += kBlock) {
+            const int l = i & 31, pos = (i >> 5) & 31, pr = i >> 10;
+            lg[((pr * 16 + (pos >> 1)) * 32 + l) * 2 + (pos & 1)] = gains[i];
+        }
+    }
+    const long T0 = c_in_s * a.frames_per_chunk;
+    long T1 = T0 + a.frames_per_chunk;
+    if (T1 > a.n_frames) T1 = a.n_frames;
+    if (T0 == 0) {
+        for (int i = tid; i < kHop; i += kBlock) s_tails[i] = a.tail_in[(long)stream * kHop + i];
+    }
+    if (tid < kSlots) s_flag[tid] = (tid == 0) ? (int)(T0 - 1) : -2;
+    __syncthreads();
+    const float4 *wrow = reinterpret_cast<const float4 *>(s_win + lane * kPS);
+    const float4 *tw2 = reinterpret_cast<const float4 *>(lds);
+
+    const float *xs = a.x + (long)in_stream * a.stream_stride_x;
+    const float *hs = a.hist_in + (long)in_stream * M * kHop;
+    float *ys = a.y + (long)stream * a.n_frames * kHop;
+
+    float ar[32], ai[32], br[32], bi[32], Sr[32], Si[32];
+    const int n_iter = (int)((T1 - T0 + kIl8Waves - 1) / kIl8Waves);
+
+    // this half's two pairs of frame tc: register position j <-> sample 32 j + lane of the frame
+    const unsigned voff = (unsigned)(lane * M + 4 * half);  // this lane's 16 bytes inside a 32-sample row (floats)
+    auto load_frame = [&](long tc) {
+        const float *s1 = (tc >= 1 ? xs + (tc - 1) * (long)kHop * M : hs);  // wave-uniform bases: SGPR base + VGPR offset addressing
+        const float *s2 = xs + tc * (long)kHop * M;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 u = *reinterpret_cast<const float4 *>(s1 + 32 * j * M + voff);
+            const float4 w = *reinterpret_cast<const float4 *>(s2 + 32 * j * M + voff);
+            ar[j] = u.x; ai[j] = u.y; br[j] = u.z; bi[j] = u.w;
+            ar[j + 16] = w.x; ai[j + 16] = w.y; br[j + 16] = w.z; bi[j + 16] = w.w;
+        }
+    };
+    // window -> FFT-1024 -> weight-and-sum of the pair held in (re, im); FIRST: the half's first pair starts its partial sum
+    auto do_pair = [&](float (&re)[32], float (&im)[32], int p, bool first) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 hv = wrow[g];
+            re[4 * g + 0] *= hv.x; im[4 * g + 0] *= hv.x;
+            re[4 * g + 1] *= hv.y; im[4 * g + 1] *= hv.y;
+            re[4 * g + 2] *= hv.z; im[4 * g + 2] *= hv.z;
+            re[4 * g + 3] *= hv.w; im[4 * g + 3] *= hv.w;
+        }
+#ifdef BF_DAS_STAMPS
+        unsigned long long st_acc[16], st_prev = 0;
+#endif
+        wt_fft_fwd_p2(re, im, lane, tw2, wbase, wrowp BF_STAMP_ARGS);
+        const float4 *gp2 = reinterpret_cast<const float4 *>(lds + kLdsFixed) + p * 512 + lane;
+#pragma unroll
+        for (int i = 0; i < 32; i += 2) {
+            const float4 g = gp2[16 * i];  // gains of positions i and i + 1
+            Sr[i] = bf_fma(-g.y, im[i], bf_fma(g.x, re[i], first ? 0.f : Sr[i]));
+            Si[i] = bf_fma(g.y, re[i], bf_fma(g.x, im[i], first ? 0.f : Si[i]));
+            Sr[i + 1] = bf_fma(-g.w, im[i + 1], bf_fma(g.z, re[i + 1], first ? 0.f : Sr[i + 1]));
+            Si[i + 1] = bf_fma(g.w, re[i + 1], bf_fma(g.z, im[i + 1], first ? 0.f : Si[i + 1]));
+        }
+    };
+
+    {
+        const long t0 = T0 + wv;
+        load_frame(t0 < T1 ? t0 : T1 - 1);
+    }
+    for (int it = 0; it < n_iter; ++it) {
+        const long t = T0 + (long)it * kIl8Waves + wv;
+        const bool valid = t < T1;
+        const long tc = valid ? t : T1 - 1;
+        do_pair(ar, ai, 2 * half, true);
+        do_pair(br, bi, 2 * half + 1, false);
+        halves_sum(Sr);
+        halves_sum(Si);
+
+        if (a.sdump != nullptr && valid && half == 0) {
+            f32x2 *sd = a.sdump + ((long)stream * a.n_frames + t) * kNfft + lane;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) sd[32 * brev5(i)] = f32x2{Sr[i], Si[i]};
+        }
+        // the next frame streams in while the backward transform runs on (Sr, Si)
+        if (it + 1 < n_iter) {
+            const long tn = T0 + (long)(it + 1) * kIl8Waves + wv;
+            load_frame(tn < T1 ? tn : T1 - 1);
+        }
+        {
+#ifdef BF_DAS_STAMPS
+            unsigned long long st_acc[16], st_prev = 0;
+#endif
+            wt_fft_inv_p2(Sr, Si, lane, tw2, wbase, wrowp BF_STAMP_ARGS);
+        }
+
+        // position i holds sample n = 32*brev5(i) + lane; even i -> first half of the frame, odd i -> second half.  Half-wavefront 0
+        // finishes the output hop (first half + the previous frame's tail), half-wavefront 1 parks this frame's tail: each needs
+        // 16 of the 32 positions and 16 of the 32 window values (brev5(2q + 1) = brev5(2q) + 16: a contiguous half of the row)
+        float pq[16];
+        {
+            const float4 *wh = wrow + 4 * half;
+            float hq[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 hv = wh[g];
+                hq[4 * g + 0] = hv.x; hq[4 * g + 1] = hv.y; hq[4 * g + 2] = hv.z; hq[4 * g + 3] = hv.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float ev = Sr[2 * q], od = Sr[2 * q + 1];  // select on VALUES (v_cndmask), not on addresses (a scratch array)
+                pq[q] = (half != 0 ? od : ev) * hq[brev5(2 * q)];
+            }
+        }
+        const int r = (int)(tc - T0);
+        const int my = (r + 1) % kSlots, pv = r % kSlots;
+        if (valid && half == 1) {  // second half of this frame -> its ring slot, then publish
+            float *my_slot = s_tails + my * kHop + lane;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) my_slot[32 * brev5(2 * q)] = pq[q];
+            asm volatile("" ::: "memory");
+            if (lane == 0) s_flag[my] = (int)t;
+            if (t == T1 - 1) {
+                if (T1 < a.n_frames) {  // last frame of the run: its second half belongs to the next run's first hop
+                    float *yn = ys + T1 * kHop + lane;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) atomicAdd(yn + 32 * brev5(2 * q), pq[q]);
+                } else {  // end of the batch: carried state for the next call (OLA tail and the last input hop)
+                    float *to = a.tail_out + (long)stream * kHop + lane;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) to[32 * brev5(2 * q)] = pq[q];
+                    float *ho = a.hist_out + (long)in_stream * M * kHop;
+                    for (int j = 0; j < 16 * M; ++j) ho[32 * j + lane] = xs[t * (long)kHop * M + 32 * j + lane];
+                }
+            }
+        }
+        if (valid && half == 0) {
+            float *yo = ys + t * kHop + lane;
+            if (t == T0 && T0 > 0) {  // first hop of the run: the previous run adds its half separately (both into a zeroed hop)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) atomicAdd(yo + 32 * brev5(2 * q), pq[q]);
+            } else {
+                while (s_flag[pv] != (int)(t - 1)) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+                const float *prev = s_tails + pv * kHop + lane;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+#pragma clang fp contract(off)
+                    yo[32 * brev5(2 * q)] = prev[32 * brev5(2 * q)] + pq[q];
+                }
+            }
+        }
+    }
+}
+
 __global__ void das_hermitian_dump_kernel(const f32x2 *s, f64x2 *out, long total) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -764,10 +976,10 @@ void launch_layout(const DasFusedArgs &a, unsigned blocks, hipStream_t stream) {
     // from inside the gain loop (BF_DAS_VARIANT bit 1; same arithmetic, bit-identical output)
     const bool unr = LAYOUT == 0 && WT && (a.variant & 2);
     if (LAYOUT == 1 && WT && (a.variant & 2) && (a.n_mics == 4 || a.n_mics == 8)) {  // 16-byte loads: two pairs per sample access
-        if (a.n_mics == 4)
+        if (a.n_mics == 4)  // one 16-byte load per sample = the whole sample: two frames per wavefront
             hipLaunchKernelGGL((das_fused_il_kernel<2, 1>), dim3(blocks), dim3(kBlock), 0, stream, a);
-        else
-            hipLaunchKernelGGL((das_fused_il_kernel<4, 2>), dim3(blocks), dim3(kBlock), 0, stream, a);
+        else                // 8 microphones: one frame per wavefront, each half-wavefront loads its 16 bytes of the 32-byte sample
+            hipLaunchKernelGGL(das_fused_il8_kernel, dim3(blocks), dim3(kBlock), 0, stream, a);
         return;
     }
 #define BF_DAS_GO(NPL_, UNR_) hipLaunchKernelGGL((das_fused_kernel<LAYOUT, NPL_, WT, UNR_>), dim3(blocks), dim3(kBlock), 0, stream, a)
