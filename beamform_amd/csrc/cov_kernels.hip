@@ -972,9 +972,16 @@ template <int KM, int WPS>
 __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, int tiles_per_stream) {
     constexpr int NB = KM + 1, NS = (NB + 3) / 4;  // right-hand sides, slots per lane
     constexpr int NG = GramIdx<KM>::NG, NE = GramIdx<KM>::NE;
-    __shared__ __attribute__((aligned(16))) f64x2 s_x[4][2][4][16];   // [wave][new / old][problem][mic]
-    __shared__ __attribute__((aligned(16))) f64x2 s_u[4][4][NB][16];  // [wave][problem][column][row]: U = L^-1 [C | x]
-    __shared__ __attribute__((aligned(16))) f64x2 s_g[4][4][16];      // [wave][problem][Gram entry]
+    // Row paddings against bank conflicts (round-3 PMC, profiles/r03_lcmv16_chain_pmc.txt: 53 % of this kernel's LDS cycles were
+    // conflicts, 16 % of its wave cycles waited to issue an LDS instruction).  A ds_read_b128 serves 16 lanes at a time, drawn
+    // from two of the wavefront's four problems; with 256-byte rows per problem both read the same banks:
+    //   s_x: 320-byte rows (problem stride = 64 B mod 256): the four column entries x(4k+q) of two problems land 64 B apart;
+    //   s_u: 272-byte rows: the Gram sums read the SAME row index i of up to five different columns at once (16 B apart now),
+    //        and a problem's block of NB rows is 80 B mod 256 (NB = 5) / 32 B (NB = 2) from its neighbour's;
+    //   s_g: 272-byte rows: every lane of a problem reads the same entry, two problems per access.
+    __shared__ __attribute__((aligned(16))) f64x2 s_x[4][2][4][20];   // [wave][new / old][problem][mic]
+    __shared__ __attribute__((aligned(16))) f64x2 s_u[4][4][NB][17];  // [wave][problem][column][row]: U = L^-1 [C | x]
+    __shared__ __attribute__((aligned(16))) f64x2 s_g[4][4][17];      // [wave][problem][Gram entry]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int l16 = lane & 15, grp = lane >> 4, p = l16 >> 2, q = l16 & 3;
     const int pq = blockIdx.y * 16 + wv * 4 + grp;

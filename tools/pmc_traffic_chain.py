@@ -30,11 +30,17 @@ pick = lambda acc, sub: mean([x for k, v in acc.items() if sub in k for x in v])
 fetch_factor = GiB / (pick(calf, "copy_x4") * 1024.0)      # 16 B / lane, the bin pipeline's access width
 fetch_factor_dword = GiB / (pick(calf, "read_dword") * 1024.0)
 write_factor = GiB / (pick(calw, "copy_x4") * 1024.0)
+try:  # 12-byte accesses (z48 spectra of the mvdr / lcmv chain): reported beside the 16-byte factors, which the totals use
+    x3_bytes = float((1 << 30) // 12 * 12)
+    fetch_factor_x3 = x3_bytes / (pick(calf, "copy_x3") * 1024.0)
+    write_factor_x3 = x3_bytes / (pick(calw, "copy_x3") * 1024.0)
+except Exception:
+    fetch_factor_x3 = write_factor_x3 = None
 F, W = per_kernel(kf, "FETCH_SIZE"), per_kernel(kw, "WRITE_SIZE")
 ours = sorted(k for k in set(F) | set(W) if "bf::" in k or "das_fused" in k)
 steps = max(len(v) for k, v in F.items() if step in k)
 res = {"calibration": {"known_bytes": GiB, "fetch_factor_x4": fetch_factor, "fetch_factor_dword": fetch_factor_dword,
-                       "write_factor_x4": write_factor},
+                       "write_factor_x4": write_factor, "fetch_factor_x3": fetch_factor_x3, "write_factor_x3": write_factor_x3},
        "steps_profiled": steps, "kernels": {}}
 tr = tw = 0.0
 for k in ours:
