@@ -278,7 +278,13 @@ void bf_wav_free(float *planar);
  * libsamplerate (un-vendored; 0.1.9 on the reference's Ubuntu 20.04) is not in this image: csrc/resample.hip restates
  * src_sinc.c's mono converter; the built-in coefficient table is a Kaiser-windowed sinc of SINC_FASTEST's geometry, NOT
  * libsamplerate's fastest_coeffs.h (parity unpinned) -- bf_resampler_set_table installs any table of that form, e.g. the
- * original one. */
+ * original one.
+ * DEVIATION from rosjack's stage when out_rate > in_rate: the reference keeps output_frames = rosjack_window_size and copies a
+ * new period into the converter only when input_frames == 0 (rosjack.cpp:311-338), and it emits at most one data_length block
+ * per callback (:416-436) -- when upsampling src_process leaves input unconsumed, so the reference DROPS periods and never
+ * writes a trailing partial block.  bf_resampler (and examples/file_node) consume every input sample and return every output
+ * sample: for ratio > 1 the stream is the mathematically complete conversion, longer than the reference's file; for
+ * ratio < 1 only the tail (less than one period) differs.  tests/test_resample_gpu.py pins the chosen behaviour. */
 typedef struct bf_resampler bf_resampler;
 int bf_resampler_create(int in_rate, int out_rate, bf_resampler **out);               /* src_new + src_ratio; BF_EINVAL outside 1/256..256 */
 int bf_resampler_set_table(bf_resampler *r, const float *coeffs, int n_coeffs, int index_inc); /* half table incl. 2 guard entries; resets */

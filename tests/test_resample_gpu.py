@@ -161,3 +161,16 @@ def test_handle_is_safe_against_a_second_thread():
     assert not errors
     g.reset()
     assert np.array_equal(g.process(x), capi.Resampler(48000, 16000).process(x))
+
+
+def test_upsampling_keeps_every_sample():
+    """The documented deviation from rosjack's output stage (include/bfcore.h): with out_rate > in_rate the reference drops
+    periods whenever src_process leaves input unconsumed (rosjack.cpp:311-338) and emits at most one block per callback; the
+    converter here consumes every input sample and returns the complete conversion -- n_in * ratio outputs, less the look-ahead."""
+    g = capi.Resampler(16000, 48000)
+    x = (0.2 * np.sin(2 * np.pi * 440.0 * np.arange(20 * 512) / 16000.0)).astype(np.float32)
+    y = np.concatenate([g.process(x[i:i + 512]) for i in range(0, len(x), 512)])
+    assert abs(len(y) - 3 * (len(x) - g.latency)) <= 3
+    # a 440 Hz tone stays a 440 Hz tone at the new rate (first samples: zero history)
+    ref = 0.2 * np.sin(2 * np.pi * 440.0 * np.arange(len(y)) / 48000.0)
+    assert np.max(np.abs(y[600:] - ref[600:len(y)])) < 2e-3
