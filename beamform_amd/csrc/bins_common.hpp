@@ -185,6 +185,41 @@ __device__ __forceinline__ void atan2_fast_n(const double (&y)[N], const double 
         out[i] = copysign(a, y[i]);
     }
 }
+// fp32 atan2 of N independent arguments for the phase-mask PRE-decision (phase_is_close below): octant reduction as atan2_fast
+// (c in {0, 1/2, 1}, |z| <= 1/4), atan(z) = z (1 - s/3 + s^2/5 - s^3/7), s = z^2 (next term z^9/9 < 5e-7), hardware reciprocal.
+// Absolute error < 2e-6 rad over the float range; both components zero gives 0 like atan2f.
+template <int N>
+__device__ __forceinline__ void atan2f_fast_n(const float (&y)[N], const float (&x)[N], float (&out)[N]) {
+    float mx[N], mn[N], ch[N], z[N];
+    bool swap_[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float ax = __builtin_fabsf(x[i]), ay = __builtin_fabsf(y[i]);
+        swap_[i] = ay > ax;
+        mx[i] = __builtin_fmaxf(ax, ay);
+        mn[i] = __builtin_fminf(ax, ay);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const bool b1 = mn[i] > 0.25f * mx[i], b2 = mn[i] > 0.75f * mx[i];
+        const float c = b2 ? 1.0f : (b1 ? 0.5f : 0.0f);
+        ch[i] = b2 ? 0.78539816f : (b1 ? 0.46364761f : 0.0f);
+        const float num = __builtin_fmaf(-c, mx[i], mn[i]), den = __builtin_fmaf(c, mn[i], mx[i]);
+        z[i] = num * __builtin_amdgcn_rcpf(den);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float s = z[i] * z[i];
+        float q = -0.14285714f;
+        q = __builtin_fmaf(q, s, 0.2f);
+        q = __builtin_fmaf(q, s, -0.33333333f);
+        float a = ch[i] + __builtin_fmaf(z[i] * s, q, z[i]);
+        if (mx[i] == 0.0f) a = 0.0f;
+        if (swap_[i]) a = 1.57079633f - a;
+        if (__builtin_signbit(x[i])) a = 3.14159265f - a;
+        out[i] = __builtin_copysignf(a, y[i]);
+    }
+}
 // 1 / g for a pivot of the small Hermitian systems (|g|^2 well inside the double range: Gram entries of whitened spectra):
 // conj(g) / |g|^2 through the reciprocal estimate + two Newton steps, ~13 instructions against ~100 for Smith's algorithm with its
 // three library divisions.  Relative error ~2e-16.

@@ -67,6 +67,48 @@ __device__ __forceinline__ double pair_phase_mean(const double (&ph)[MP], int M)
     return div_rcp(tot, dn, 1.0 / dn);  // 0/0 = NaN when M == 1, as the reference
 }
 
+// The mask decision `mean wrapped phase difference < min_phase` (phase.cpp:110, phasempf.cpp:229) is 8 atan2 + 28 wrapped
+// differences per bin-frame in the reference's double arithmetic -- most of these nodes' per-bin time.  The decision (not
+// the output) is first formed in fp32: arguments rounded to float, atan2f_fast_n (error < 2e-6 rad), the same pairwise mean
+// (fp32 summation error < 1e-5).  Only when that mean lies within 1e-4 rad of the threshold -- or an argument is outside the
+// float range -- does the wavefront redo the test in double (~6e-5 of the bin-frames, 0.4 % of the wavefronts), so every
+// decision equals the double-precision one.
+template <int MP>
+__device__ __forceinline__ float pair_phase_mean_f(const float (&ph)[MP], int M) {
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < MP; ++i)
+#pragma unroll
+        for (int k = i + 1; k < MP; ++k)
+            if (k < M) {
+                float r = __builtin_fabsf(ph[i] - ph[k]);
+                if (r > 3.14159265f) r = 6.28318531f - r;
+                tot += r;
+            }
+    return tot / (float)(M * (M - 1) / 2);  // 0/0 = NaN when M == 1: falls through to the double path
+}
+template <int MP>
+__device__ __forceinline__ bool phase_is_close(const double (&uy)[MP], const double (&ux)[MP], int M, double thr) {
+    float fy[MP], fx[MP], ph[MP];
+    bool odd = false;  // an argument the float range cannot carry (|u| of [-1,1] audio spectra sits around 1e-3 .. 1e3)
+#pragma unroll
+    for (int m = 0; m < MP; ++m) {
+        fy[m] = (float)uy[m];
+        fx[m] = (float)ux[m];
+        const float big = __builtin_fmaxf(__builtin_fabsf(fx[m]), __builtin_fabsf(fy[m]));
+        if (m < M) odd = odd || !(big > 1e-30f && big < 1e30f);
+    }
+    atan2f_fast_n<MP>(fy, fx, ph);
+    const float mean = pair_phase_mean_f<MP>(ph, M), thrf = (float)thr;
+    const bool unsure = odd || !(__builtin_fabsf(mean - thrf) > 1e-4f);
+    if (__builtin_amdgcn_ballot_w64(unsure) != 0) {  // rare: the reference's arithmetic for this wavefront
+        double pd[MP];
+        atan2_fast_n<MP>(uy, ux, pd);
+        return pair_phase_mean<MP>(pd, M) < thr;
+    }
+    return mean < thrf;
+}
+
 // phase.cpp:87-127 on the unpacked spectra X[m] and steering entries w[m] of bin j
 template <int MP>
 __device__ __forceinline__ cd phase_core(const cd (&X)[MP], const cd (&w)[MP], int M, int j, const bf_config &cfg) {
@@ -79,16 +121,14 @@ __device__ __forceinline__ cd phase_core(const cd (&X)[MP], const cd (&w)[MP], i
     mag = div_rcp(mag, (double)M, 1.0 / (double)M);
     bool keep = false;
     if (mag / (double)kN > cfg.mag_threshold) {
-        double ph[MP], uy[MP], ux[MP];
+        double uy[MP], ux[MP];
 #pragma unroll
         for (int m = 0; m < MP; ++m) {
             const cd u = conj(w[m]) * X[m];  // padding channels: w = X = 0 -> their phase is never read
             uy[m] = u.y;
             ux[m] = u.x;
         }
-        atan2_fast_n<MP>(uy, ux, ph);
-        const double mean = pair_phase_mean<MP>(ph, M);
-        keep = mean < cfg.min_phase * M_PI / 180;
+        keep = phase_is_close<MP>(uy, ux, M, cfg.min_phase * M_PI / 180);
     }
     if (!keep) mag *= cfg.mag_mult;
     // mag * (cos, sin)(arg X_0) = mag * X_0 / |X_0|  (phase.cpp:115-122); arg(0) = 0
@@ -110,7 +150,7 @@ __device__ __forceinline__ cd phase_bin(const BinCtx &c, const bf_config &cfg) {
 template <int MP>
 __device__ __forceinline__ void mpf_mask_core(const cd (&X)[MP], const cd (&w)[MP], int M, const bf_config &cfg, cd &soi_out,
                                               double &int2_out) {
-    double ph[MP], uy[MP], ux[MP], ab[MP];
+    double uy[MP], ux[MP], ab[MP];
     double mag = 0.0;
     cabs_n<MP>(X, ab);
 #pragma unroll
@@ -120,10 +160,8 @@ __device__ __forceinline__ void mpf_mask_core(const cd (&X)[MP], const cd (&w)[M
         ux[m] = u.x;
         if (m < M) mag += ab[m];
     }
-    atan2_fast_n<MP>(uy, ux, ph);
-    const double mean = pair_phase_mean<MP>(ph, M);
+    const bool is_soi = phase_is_close<MP>(uy, ux, M, cfg.min_phase * M_PI / 180);
     mag = div_rcp(mag, (double)M, 1.0 / (double)M);
-    const bool is_soi = mean < cfg.min_phase * M_PI / 180;
     const double lo = mag * cfg.min_mag;
     const double msoi = is_soi ? mag : lo, mint = is_soi ? lo : mag;
     // m * (cos, sin)(arg X_0) = m * X_0 / |X_0| for both magnitudes; arg(0) = 0
