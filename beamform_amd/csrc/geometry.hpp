@@ -139,9 +139,10 @@ inline std::vector<V> twiddle_table_32x32() {
 // (derivation in DESIGN.md).  1/N of util.h:249 is folded in.  Odd mic counts
 // get a zero b-channel.  Layout: [pair][pos i][lane l] = D_p[l + 32*brev5(i)],
 // the register/lane order in which fft1024 leaves the spectrum.
-inline std::vector<f32x2> das_pair_gains(const SteeringSet &s, int n_pairs_alloc) {
+template <typename V>
+inline std::vector<V> das_pair_gains_t(const SteeringSet &s, int n_pairs_alloc) {
     const int N = s.n_fft, M = s.n_mics;
-    std::vector<f32x2> D((size_t)n_pairs_alloc * N, f32x2{0.f, 0.f});
+    std::vector<V> D((size_t)n_pairs_alloc * N, V{0, 0});
     auto ce = [&](int m, int k) -> cplxd {
         if (m >= M) return cplxd(0, 0);
         cplxd c1 = std::conj(s.at(k, m, 0)) / (double)M;
@@ -153,10 +154,11 @@ inline std::vector<f32x2> das_pair_gains(const SteeringSet &s, int n_pairs_alloc
             for (int l = 0; l < 32; ++l) {
                 int k = l + 32 * brev5(i);
                 cplxd d = (ce(2 * p, k) - cplxd(0, 1) * ce(2 * p + 1, k)) / (double)N;
-                D[((size_t)p * 32 + i) * 32 + l] = f32x2{(float)d.real(), (float)d.imag()};
+                D[((size_t)p * 32 + i) * 32 + l] = V{(decltype(V{}.x))d.real(), (decltype(V{}.x))d.imag()};
             }
     return D;
 }
+inline std::vector<f32x2> das_pair_gains(const SteeringSet &s, int n_pairs_alloc) { return das_pair_gains_t<f32x2>(s, n_pairs_alloc); }
 
 
 // Same gains in the register/lane order of the 64-lane factorisation (fft1024_w64.hpp):

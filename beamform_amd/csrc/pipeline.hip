@@ -112,6 +112,8 @@ class BinPipelineImpl : public BinPipeline {
         PIPE_HIP(hipMemcpy(d_freq_, freqs_.data(), N_ * sizeof(double), hipMemcpyHostToDevice));
         for (int i = 0; i < 2; ++i)
             PIPE_HIP(hipMalloc((void **)&d_steer_[i], steer_bytes()));
+        if (das_one_launch_shape())
+            for (int i = 0; i < 2; ++i) PIPE_HIP(hipMalloc((void **)&d_dasg_[i], (size_t)4 * 1024 * sizeof(f64x2)));
         PIPE_HIP(hipMalloc((void **)&d_hist_, (size_t)S_ * M_ * H_ * sizeof(float)));
         PIPE_HIP(hipMalloc((void **)&d_tail_[0], (size_t)So_ * H_ * sizeof(float)));
         PIPE_HIP(hipMalloc((void **)&d_tail_[1], (size_t)So_ * H_ * sizeof(float)));
@@ -155,6 +157,11 @@ class BinPipelineImpl : public BinPipeline {
                         t[(((size_t)d * nc + c) * M_ + m) * N_ + j] = f64x2{w.real(), w.imag()};
                     }
         const int nxt = steer_cur_ ^ 1;
+        std::vector<f64x2> dg;  // das fp64 in one launch: the pair gains of the (single) look direction, same double buffering
+        if (das_one_launch_shape()) {
+            dg = das_pair_gains_t<f64x2>(dirs[0], 4);
+            PIPE_HIP(hipMemcpyAsync(d_dasg_[nxt], dg.data(), dg.size() * sizeof(f64x2), hipMemcpyHostToDevice, stream));
+        }
         PIPE_HIP(hipMemcpyAsync(d_steer_[nxt], t.data(), t.size() * sizeof(f64x2), hipMemcpyHostToDevice, stream));
         PIPE_HIP(hipStreamSynchronize(stream));  // `t` is pageable and about to go out of scope
         steer_cur_ = nxt;
@@ -174,6 +181,7 @@ class BinPipelineImpl : public BinPipeline {
         sn.gss_reset_mask = gss_reset_mask_;
         sn.steer = d_steer_[steer_cur_];
         sn.steer_dir_stride = steer_dir_stride_;
+        sn.das_gains = d_dasg_[steer_cur_];
         gss_reset_mask_ = 0;
         return sn;
     }
@@ -194,6 +202,8 @@ class BinPipelineImpl : public BinPipeline {
     int set_state(const void *host) override { return copy_state((char *)host, false); }
 
    private:
+    // das through this pipeline on the tuned shape: eligible for das_f64_fused_kernel (run_one decides per batch)
+    bool das_one_launch_shape() const { return cfg_.algo == BF_DAS && N_ == 1024 && M_ <= 8 && D_ == 1; }
     size_t steer_bytes() const { return (size_t)D_ * N_ * M_ * kMaxCols * sizeof(f64x2); }
     size_t zhist_bytes() const { return Phist_ ? (size_t)S_ * Phist_ * NP_ * N_ * zsz_ : 0; }
     // recursive per-beam state is sized by OUTPUT streams (input streams x look directions)
@@ -233,7 +243,7 @@ class BinPipelineImpl : public BinPipeline {
     }
 
     void free_all() {
-        void *ptrs[] = {d_tw32_, d_tw_, d_win_, d_freq_, d_steer_[0], d_steer_[1], d_hist_, d_tail_[0], d_tail_[1], d_zhist_,
+        void *ptrs[] = {d_dasg_[0], d_dasg_[1], d_tw32_, d_tw_, d_win_, d_freq_, d_steer_[0], d_steer_[1], d_hist_, d_tail_[0], d_tail_[1], d_zhist_,
                         d_gssW_, d_mpf_, d_smooth_, d_nlms_, d_Z_, d_Yh_, d_yraw_, d_frames_};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
@@ -251,6 +261,7 @@ class BinPipelineImpl : public BinPipeline {
     f32x2 *d_tw32_ = nullptr;
     double *d_win_ = nullptr, *d_freq_ = nullptr;
     f64x2 *d_steer_[2] = {nullptr, nullptr};
+    f64x2 *d_dasg_[2] = {nullptr, nullptr};  // das_pair_gains_t<f64x2> of look direction 0 (das_one_launch_shape)
     int steer_cur_ = 0;
     float *d_hist_ = nullptr;
     float *d_tail_[2] = {nullptr, nullptr};
@@ -277,6 +288,24 @@ int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipS
 
 int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, hipStream_t stream, int layout,
                              long mic_stride, const RunSnapshot &snap) {
+    // das at the reference's precision on the tuned shape, planar input, no spectrum dump: ONE launch, spectra never leave the CU
+    // (BF_FUSED_BINS=0 / =2 keep the chains below for A/B runs)
+    static const int fuse_env0 = getenv("BF_FUSED_BINS") ? atoi(getenv("BF_FUSED_BINS")) : 1;
+    if (das_one_launch_shape() && fuse_env0 == 1 && spectrum == nullptr && layout == BF_PLANAR && snap.das_gains != nullptr) {
+        DasF64Args da;
+        da.x = x; da.hist = d_hist_; da.y = y; da.tail_in = d_tail_[tail_cur_]; da.tail_out = d_tail_[tail_cur_ ^ 1];
+        da.gains = snap.das_gains; da.tw = d_tw_; da.win = d_win_; da.n_frames = F; da.mic_stride = mic_stride;
+        da.stream_stride_x = (long)M_ * F * H_; da.n_streams = S_; da.n_mics = M_; da.run_len = 1;
+        const hipError_t de = ks_->das_f64(da, n_cus_, stream);
+        if (de == hipSuccess) {
+            PIPE_HIP(hipMemcpy2DAsync(d_hist_, H_ * sizeof(float), x + (F - 1) * H_, (size_t)mic_stride * sizeof(float),
+                                      H_ * sizeof(float), (size_t)S_ * M_, hipMemcpyDeviceToDevice, stream));  // ring-buffer carry (util.h:305-308)
+            tail_cur_ ^= 1;
+            return BF_OK;
+        }
+        if (de != hipErrorNotSupported) PIPE_HIP(de);
+        (void)hipGetLastError();
+    }
     const long FT = Phist_ + F;  // frames in the Z workspace per stream
     // nodes without a frame history: STFT and per-bin stage in one launch, spectra never leave the CU (launch_stft_bins_fused;
     // BF_FUSED_BINS=0 selects the two-kernel chain) -- then the Z workspace (64 KB per frame at 8 microphones) is not needed at all

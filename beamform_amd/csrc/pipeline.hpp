@@ -23,6 +23,7 @@ struct RunSnapshot {
     unsigned long long gss_reset_mask = 0;
     const f64x2 *steer = nullptr;
     long steer_dir_stride = 0;
+    const f64x2 *das_gains = nullptr;  // das fp64, one launch: pair gains of this batch's look direction (pipeline_kernels.hpp DasF64Args)
 };
 
 class BinPipeline {

@@ -123,6 +123,144 @@ __global__ __launch_bounds__(256) void stft_kernel(StftArgs a) {
 }
 
 // ======================================================================================
+//                     das at the reference's precision, one launch
+// ======================================================================================
+// The fused fp32 kernel's formulation in double: per frame four packed forward transforms, S += D_p Z_p with the pair gains
+// D_p = ce_a - i ce_b (geometry.hpp das_pair_gains_t: the Hermitian part of the reference's own weights, so the non-conjugate
+// quirk-Q1 bins are exact and no mirror access exists), one backward transform, (float)(Re / N) [1/N folded into D: a power of
+// two], float x double window, float overlap-add (das.cpp:47-70, util.h:217-253,301-302).  Spectra never leave the CU: HBM sees
+// the input and the output (the three-kernel chain moved 2.40 GB per 65 536 frames, 1.98 x algorithmic).
+// A half-wavefront owns (stream, run of frames) and walks the run with the overlap-add tail in registers; the first frame of a
+// run is recomputed for its tail (runs start from the carried state at frame 0).  One 256-thread block per CU: 16 KB twiddles
+// + 8 x 8.5 KB transpose planes + 64 KB of pair gains = 148 KB of LDS, one wavefront per SIMD with 512 registers: the raw
+// samples of the next pair are requested before the current pair is transformed.
+__global__ __launch_bounds__(256) void das_f64_fused_kernel(DasF64Args a) {
+    constexpr int kBlock = 256, kHalves = kBlock / 32;
+    __shared__ __attribute__((aligned(16))) double lds[2048 + kHalves * 32 * kPSd + 4 * 2048];
+    const cx<double> *s_tw = reinterpret_cast<const cx<double> *>(lds);
+    const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
+    double *pbuf = lds + 2048 + hw * 32 * kPSd;
+    const f64x2 *s_gain = reinterpret_cast<const f64x2 *>(lds + 2048 + kHalves * 32 * kPSd);
+    const int M = a.n_mics, NP = (M + 1) >> 1;
+    {
+        const double *twf = reinterpret_cast<const double *>(a.tw), *gf = reinterpret_cast<const double *>(a.gains);
+        for (int i = tid; i < 2048; i += kBlock) lds[i] = twf[i];
+        double *lg = lds + 2048 + kHalves * 32 * kPSd;
+        for (int i = tid; i < NP * 2048; i += kBlock) lg[i] = gf[i];
+        __syncthreads();
+    }
+    double win[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) win[j] = a.win[32 * j + lane];
+    const int L = a.run_len;
+    const long runs = (a.n_frames + L - 1) / L;
+    const long total = (long)a.n_streams * runs;
+    const long stride = (long)gridDim.x * kHalves;
+    const long rounds = (total + stride - 1) / stride;
+    for (long r = 0; r < rounds; ++r) {
+        long item = r * stride + (long)blockIdx.x * kHalves + hw;
+        const bool ok = item < total;
+        if (!ok) item = total - 1;
+        const long run = item % runs;
+        const int s = (int)(item / runs);
+        const long t0 = run * L;
+        const float *xs = a.x + (long)s * a.stream_stride_x;
+        const float *hs = a.hist + (long)s * M * kHop;
+        float *ys = a.y + (long)s * a.n_frames * kHop;
+        // raw samples of pair p of frame t (hop t-1 | hop t; hop -1 = the carried hop), lane l <- sample 32 j + l
+        auto load_pair = [&](long t, int p, float (&va)[32], float (&vb)[32]) {
+            const int ma = 2 * p, mb = (2 * p + 1 < M) ? 2 * p + 1 : ma;
+            const float *a1 = (t >= 1 ? xs + (long)ma * a.mic_stride + (t - 1) * kHop : hs + ma * kHop) + lane;
+            const float *b1 = (t >= 1 ? xs + (long)mb * a.mic_stride + (t - 1) * kHop : hs + mb * kHop) + lane;
+            const float *a2 = xs + (long)ma * a.mic_stride + t * kHop + lane;
+            const float *b2 = xs + (long)mb * a.mic_stride + t * kHop + lane;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                va[j] = a1[32 * j];
+                vb[j] = b1[32 * j];
+                va[j + 16] = a2[32 * j];
+                vb[j + 16] = b2[32 * j];
+            }
+        };
+        float tail[16];  // second half of the previous frame, as the reference keeps it: float (out_buff[0], util.h:302)
+        if (t0 == 0) {
+            const float *ti = a.tail_in + (long)s * kHop + lane;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tail[q] = ti[32 * brev5(2 * q)];
+        }
+        const long tb = t0 == 0 ? 0 : t0 - 1;  // t0 - 1: warm-up frame, only its second half is used
+        long te = t0 + L;
+        if (te > a.n_frames) te = a.n_frames;
+        float na[32], nb[32];
+        load_pair(tb, 0, na, nb);
+        for (long t = tb; t < te; ++t) {
+            double Sr[32], Si[32];
+            for (int p = 0; p < NP; ++p) {
+                double re[32], im[32];
+                const double bs = (2 * p + 1 < M) ? 1.0 : 0.0;
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    re[j] = (double)na[j] * win[j];  // buf[j]*hann_win[i]  (util.h:235)
+                    im[j] = (double)nb[j] * (win[j] * bs);
+                }
+                {  // next pair (or the next frame's first one): in flight during this transform
+                    long tn = t;
+                    int pn = p + 1;
+                    if (pn == NP) {
+                        pn = 0;
+                        tn = t + 1 < te ? t + 1 : t;
+                    }
+                    load_pair(tn, pn, na, nb);
+                }
+                fft1024p_fwd_A<double>(re, im, lane, s_tw, pbuf);
+                __builtin_amdgcn_wave_barrier();
+                fft1024p_B<double>(re, lane, pbuf);
+                __builtin_amdgcn_wave_barrier();
+                fft1024p_C<double, false>(im, lane, pbuf);
+                __builtin_amdgcn_wave_barrier();
+                fft1024p_D<double, -1>(re, im, lane, pbuf);
+                __builtin_amdgcn_wave_barrier();
+                const f64x2 *gp = s_gain + p * 1024 + lane;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const f64x2 g = gp[32 * i];
+                    const double sr = p == 0 ? 0.0 : Sr[i], si = p == 0 ? 0.0 : Si[i];
+                    Sr[i] = fma(-g.y, im[i], fma(g.x, re[i], sr));
+                    Si[i] = fma(g.y, re[i], fma(g.x, im[i], si));
+                }
+            }
+            fft1024p_inv_A<double>(Sr, Si, lane, s_tw, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_B<double>(Sr, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_C<double, true>(Si, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_D<double, +1>(Sr, Si, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            // position i: sample n = 32*brev5(i) + lane (even i: first half, odd i: second half); util.h:247-252 with the float stores
+            float o[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const float f = (float)Sr[i];                 // (float)(Re / N): 1/N is inside the gains
+                o[i] = (float)((double)f * win[brev5(i)]);    // o *= hann_win[n]: sample 32*brev5(i) + lane <-> win[brev5(i)]
+            }
+            if (ok && t >= t0) {
+                float *yo = ys + t * kHop + lane;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) yo[32 * brev5(2 * q)] = tail[q] + o[2 * q];
+                if (t == a.n_frames - 1) {
+                    float *to = a.tail_out + (long)s * kHop + lane;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) to[32 * brev5(2 * q)] = o[2 * q + 1];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tail[q] = o[2 * q + 1];
+        }
+    }
+}
+
+// ======================================================================================
 //                                        ISTFT
 // ======================================================================================
 constexpr int kIstftBlock = 256;
@@ -591,6 +729,21 @@ __global__ void smooth_state_kernel(const float *yraw, double *state, long n, in
 }  // namespace
 
 #if BF_NFFT == 1024
+hipError_t launch_das_f64_fused(const DasF64Args &a, int n_cus, hipStream_t s) {
+    if (a.n_mics > 8) return hipErrorNotSupported;  // the four pair-gain tables fill the LDS
+    DasF64Args b = a;
+    const long slots = (long)n_cus * 8 * 2;  // two runs per half-wavefront slot: a run recomputes its first frame
+    long L = ((long)a.n_streams * a.n_frames + slots - 1) / slots;
+    if (L < 1) L = 1;
+    if (L > 512) L = 512;
+    b.run_len = (int)L;
+    const long total = (long)a.n_streams * ((a.n_frames + L - 1) / L);
+    long blocks = (total + 7) / 8;
+    if (blocks > n_cus) blocks = n_cus;
+    hipLaunchKernelGGL(das_f64_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, s, b);
+    return hipGetLastError();
+}
+
 hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
     // 256 threads, twiddles in LDS: a 512-thread block spills (44 VGPRs) and twiddles read from global memory cost 40 % (measured)
     constexpr int nb = 256, halves = nb / 32;
@@ -645,6 +798,8 @@ hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s) {
 }
 
 #else
+hipError_t launch_das_f64_fused(const DasF64Args &, int, hipStream_t) { return hipErrorNotSupported; }
+
 hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
     const long total = (long)a.n_streams * a.n_frames * ((a.n_fft_mics + 1) / 2);
     long blocks = total < (long)n_cus * 8 ? total : (long)n_cus * 8;

@@ -11,6 +11,7 @@ import pytest
 
 from beamform_amd.params import make_params
 from beamform_amd.synth import make_scene
+from conftest import rel_l2
 from test_pipeline_gpu import check, run_gpu
 
 pytestmark = pytest.mark.gpu
@@ -85,13 +86,53 @@ np.savez(sys.argv[1], **out)
 
 
 def test_fused_is_bit_identical_to_the_two_kernel_chain(tmp_path):
+    """BF_FUSED_BINS=2 (stft + per-bin stage in one kernel, spectra in LDS; the default for phase / phasempf, for das only when
+    the one-launch kernel is switched off) against =0 (two kernels, spectra in HBM): the same arithmetic, bit for bit.  The default
+    (=1) differs from both for das only -- das_f64_fused_kernel, checked against the oracle below -- and from neither for the masks."""
     res = {}
-    for mode in ("1", "0"):
+    for mode in ("2", "0", "1"):
         f = str(tmp_path / f"out{mode}.npz")
         subprocess.check_call([sys.executable, "-c", CHILD % ROOT, f], env=dict(os.environ, BF_FUSED_BINS=mode))
         res[mode] = np.load(f)
-    for k in res["1"].files:
-        assert np.array_equal(res["1"][k], res["0"][k]), k
+    for k in res["2"].files:
+        assert np.array_equal(res["2"][k], res["0"][k]), k
+        if not k.startswith("das"):
+            assert np.array_equal(res["1"][k], res["0"][k]), k
+        else:
+            d = np.abs(res["1"][k].astype(np.float64) - res["0"][k]).max()
+            assert d <= 2e-7 * np.abs(res["0"][k]).max(), (k, d)
+
+
+@pytest.mark.parametrize("M,F,S", [(8, 33, 1), (7, 5, 1), (5, 18, 2), (4, 27, 1), (3, 9, 3), (2, 40, 1), (1, 6, 1), (8, 1, 1), (6, 700, 1)])
+def test_das_f64_one_launch_matches_oracle(M, F, S):
+    """das_f64_fused_kernel (BF_DAS_BINS_F64 without a spectrum dump, planar input): the time output against the oracle, odd
+    microphone counts, several streams, runs that recompute their first frame (F = 700 is cut into runs), and batch cuts."""
+    import oracle
+    from beamform_amd.capi import BF_DAS_BINS_F64, Beamformer
+    p = make_params("das", n_mics=M, theta=-50.0)
+    xs = np.stack([make_scene(M, F, seed=1200 + 7 * M + s) for s in range(S)])
+    bf = Beamformer(p, n_streams=S, das_impl=BF_DAS_BINS_F64)
+    y = bf.process(xs if S > 1 else xs[0]).reshape(S, -1)
+    for s in range(S):
+        y_ref, _ = oracle.OracleNode(p).process(xs[s])
+        assert rel_l2(y[s], y_ref) < 1e-6       # double arithmetic up to the float stores: far inside the 1e-5 budget
+    if S == 1 and F >= 9:
+        bf2 = Beamformer(p, das_impl=BF_DAS_BINS_F64)
+        cuts = [0, 1, 4, F // 2, F]
+        parts = [bf2.process(np.ascontiguousarray(xs[0][:, a * 512:b * 512])) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert np.array_equal(np.concatenate(parts), y[0])   # state (ring hop, tail) carries exactly
+
+
+def test_das_f64_one_launch_streaming_callbacks():
+    """bf_process_hop on the fp64 das node: one callback at a time == batch."""
+    from beamform_amd.capi import BF_DAS_BINS_F64, Beamformer
+    M, F = 8, 12
+    p = make_params("das", n_mics=M, theta=15.0)
+    x = make_scene(M, F, seed=31)
+    whole = Beamformer(p, das_impl=BF_DAS_BINS_F64).process(x)
+    bf = Beamformer(p, das_impl=BF_DAS_BINS_F64)
+    hops = [bf.process_hop(np.ascontiguousarray(x[:, t * 512:(t + 1) * 512])) for t in range(F)]
+    assert np.array_equal(np.concatenate([np.asarray(h).reshape(-1) for h in hops]), whole)
 
 
 CHILD_FULL = r"""
@@ -113,11 +154,38 @@ for algo in ("das", "phase"):
 
 
 def test_fused_equals_two_kernel_chain_at_the_baseline_size():
-    """BASELINE batch (8 microphones x 65 536 frames): the fused kernel and the two-kernel chain give the same bytes."""
+    """BASELINE batch (8 microphones x 65 536 frames): the fused STFT + per-bin kernel (BF_FUSED_BINS=2: phase by default, das
+    when the one-launch kernel is off) and the two-kernel chain give the same bytes."""
     outs = []
-    for mode in ("1", "0"):
+    for mode in ("2", "0"):
         r = subprocess.run([sys.executable, "-c", CHILD_FULL % ROOT], env=dict(os.environ, BF_FUSED_BINS=mode),
                            capture_output=True, text=True, check=True)
         outs.append([ln.split() for ln in r.stdout.strip().splitlines()])
     assert len(outs[0]) == 2 and outs[0] == outs[1], outs
     assert all(float(ln[2]) > 1e-3 for ln in outs[0])
+
+
+def test_das_f64_one_launch_at_the_baseline_size():
+    """65 536 frames through das_f64_fused_kernel: oracle windows at random offsets and at the kernel's run boundaries (a frame's
+    output hop depends on three input hops only), and equality with the fused fp32 kernel to float accuracy."""
+    import oracle
+    import torch
+    from beamform_amd.capi import BF_DAS_BINS_F64, Beamformer
+    M, F, n = 8, 65536, 20
+    p = make_params("das", n_mics=M, theta=35.0)
+    g = torch.Generator(device="cuda").manual_seed(21)
+    x = torch.rand(M, F * 512, device="cuda", generator=g) - 0.5
+    y = torch.empty(F * 512, device="cuda")
+    Beamformer(p, das_impl=BF_DAS_BINS_F64).process_device(x.data_ptr(), F, y.data_ptr())
+    y32 = torch.empty(F * 512, device="cuda")
+    Beamformer(p).process_device(x.data_ptr(), F, y32.data_ptr())
+    torch.cuda.synchronize()
+    assert ((y - y32).norm() / y.norm()).item() < 1e-6
+    rng = np.random.default_rng(9)
+    starts = [0, 3, 14, 15, 16, 17, 31, 32, 33, F - n] + [int(v) for v in rng.integers(2, F - n, 8)]  # run length 16 at this size
+    for t0 in starts:
+        a = max(t0 - 2, 0)
+        seg = x[:, a * 512:(t0 + n) * 512].cpu().numpy()
+        y_ref, _ = oracle.OracleNode(p).process(np.ascontiguousarray(seg))
+        got = y[t0 * 512:(t0 + n) * 512].cpu().numpy()
+        assert rel_l2(got, y_ref[(t0 - a) * 512:]) < 1e-6, t0
