@@ -21,7 +21,7 @@ run() {  # name, step kernel, run_das args...
   tail -1 gpurun_out/${tag}_${name}.log
 }
 run das8 das_fused --algo das
-run das8_f64 stft_bins_fused --algo das --das-f64
+run das8_f64 das_f64_fused --algo das --das-f64
 run mvdr8 stft_kernel --algo mvdr
 run phase8 stft_bins_fused --algo phase
 run phasempf8 stft_bins_fused --algo phasempf --streams 256 --frames 256
