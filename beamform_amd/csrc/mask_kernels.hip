@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void pointwise_bins_kernel(BinsArgs a) {
         y = das_bin<MP>(c);
     else
         y = phase_bin<MP>(c, a.cfg);
-    a.Yh[((long)s * a.n_frames + t) * kYhStride + q] = f64x2{y.x, y.y};
+    st_y(a, ((long)s * a.n_frames + t) * kYhStride + q, q, y);
 }
 
 
@@ -523,10 +523,10 @@ __global__ __launch_bounds__(256, 1) void stft_bins_fused_kernel(StftArgs a, Bin
             const long o = ((long)s * b.n_frames + f0 + f) * kYhStride + q;
             if (ALGO == BF_DAS) {
                 const cd y = das_core<MP>(X, st[n], M);
-                b.Yh[o] = f64x2{y.x, y.y};
+                st_y(b, o, q, y);
             } else if (ALGO == BF_PHASE) {
                 const cd y = phase_core<MP>(X, st[n], M, j, b.cfg);
-                b.Yh[o] = f64x2{y.x, y.y};
+                st_y(b, o, q, y);
             } else {  // phasempf mask
                 if (j == 0) {
                     b.Yh[o] = f64x2{X[0].x, X[0].y};
@@ -567,10 +567,10 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(BinsArgs b, const f64x2
     const long o = sf * kYhStride + q;
     if (ALGO == BF_DAS) {
         const cd y = das_core<MP>(X, w, b.n_mics);
-        b.Yh[o] = f64x2{y.x, y.y};
+        st_y(b, o, q, y);
     } else if (ALGO == BF_PHASE) {
         const cd y = phase_core<MP>(X, w, b.n_mics, j, b.cfg);
-        b.Yh[o] = f64x2{y.x, y.y};
+        st_y(b, o, q, y);
     } else {
         cd soi;
         double int2;

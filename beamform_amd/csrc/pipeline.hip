@@ -370,9 +370,11 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     const bool istft32 = !(cfg_.algo == BF_GSC || istft_f64 || N_ != 1024);
     // mvdr / lcmv hand the fp32 transform f32x2 rows holding only problem 0 and the in-band problems (everything else is zero,
     // mvdr.cpp:103); a spectrum dump keeps the f64x2 rows
-    ba.yh32 = (z48_ && istft32 && spectrum == nullptr) ? 1 : 0;
+    // das / phase through the bin pipeline: f32x2 rows too (every problem written), their per-bin stage has no reader but the transform
+    const bool pointwise32 = (cfg_.algo == BF_DAS || cfg_.algo == BF_PHASE) && istft32 && spectrum == nullptr;
+    ba.yh32 = ((z48_ && istft32 && spectrum == nullptr) || pointwise32) ? 1 : 0;
     ba.yh_lo = 0; ba.yh_hi = NQ_ - 1;
-    if (ba.yh32) {
+    if (ba.yh32 && z48_) {
         int klo = N_, khi = 0;
         for (int q = 1; q < NQ_; ++q) {
             const double f = std::fabs(freqs_[q]);  // problem q = bin q for q <= N/2 + 1
