@@ -732,7 +732,7 @@ __global__ void smooth_state_kernel(const float *yraw, double *state, long n, in
 hipError_t launch_das_f64_fused(const DasF64Args &a, int n_cus, hipStream_t s) {
     if (a.n_mics > 8) return hipErrorNotSupported;  // the four pair-gain tables fill the LDS
     DasF64Args b = a;
-    const long slots = (long)n_cus * 8 * 2;  // two runs per half-wavefront slot: a run recomputes its first frame
+    const long slots = (long)n_cus * 8;  // one run per half-wavefront slot: a run recomputes its first frame (1 / 2 / 4 runs: 0.790 / 0.817 / 0.868 ms)
     long L = ((long)a.n_streams * a.n_frames + slots - 1) / slots;
     if (L < 1) L = 1;
     if (L > 512) L = 512;

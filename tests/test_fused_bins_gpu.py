@@ -182,7 +182,7 @@ def test_das_f64_one_launch_at_the_baseline_size():
     torch.cuda.synchronize()
     assert ((y - y32).norm() / y.norm()).item() < 1e-6
     rng = np.random.default_rng(9)
-    starts = [0, 3, 14, 15, 16, 17, 31, 32, 33, F - n] + [int(v) for v in rng.integers(2, F - n, 8)]  # run length 16 at this size
+    starts = [0, 3, 14, 15, 16, 17, 30, 31, 32, 33, 63, 64, F - n] + [int(v) for v in rng.integers(2, F - n, 8)]  # run length 32 at this size
     for t0 in starts:
         a = max(t0 - 2, 0)
         seg = x[:, a * 512:(t0 + n) * 512].cpu().numpy()
