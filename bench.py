@@ -432,6 +432,29 @@ def main():
                                                note="BASELINE config 5 shard on a realistic scene; " + scene_note)),
         ]
 
+        def other_period_line(hop_, algo_="das"):
+            # JACK periods other than 512 frames (rosjack.cpp:131; fft_win = 2 * period): generic LDS radix-2 transforms, fp64 pipeline;
+            # same number of SAMPLES as the headline batch
+            pm = make_params(algo_, n_mics=M, hop=hop_)
+            F_ = F * HOP // hop_
+            bm = Beamformer(pm, device=local_rank)
+            xin = x.reshape(1, M, F * HOP)
+            yo = torch.empty((1, F_ * hop_), device=dev, dtype=torch.float32)
+            ts = time.perf_counter()
+            n_settle = 0
+            while n_settle < 2 or (time.perf_counter() - ts) < 0.12:
+                bm.process_device(xin.data_ptr(), F_, yo.data_ptr(), 0, sptr)
+                torch.cuda.synchronize(dev)
+                n_settle += 1
+            ms, _ = bm.time_device(xin.data_ptr(), F_, yo.data_ptr(), 5, sptr)
+            bm.close()
+            return {"workload": f"{algo_} {M}-mic, JACK period {hop_} (FFT {2 * hop_}), {F_} frames = the headline batch's samples; fp64 bin pipeline "
+                                "with LDS radix-2 transforms (correct, not tuned: not a benchmark shape)",
+                    "ms_per_step": ms, "frames_per_s": F_ / (ms * 1e-3), "samples_per_s": F_ * hop_ / (ms * 1e-3)}
+
+        jobs.append(("das_period256", lambda: other_period_line(256)))
+        jobs.append(("das_period1024", lambda: other_period_line(1024)))
+
         def resample_line():
             # the output stage's sample-rate converter on the batch the headline step just produced (rosjack.cpp:311-338)
             from beamform_amd.capi import Resampler
