@@ -94,11 +94,12 @@ int fail(bf_handle *h, int code, const char *what, hipError_t e = hipSuccess) {
         if (e_ != hipSuccess) return fail((h), BF_EIO, #call, e_);       \
     } while (0)
 
-// the fused fp32 kernel is built for the 512-frame period (32 x 32 in-register FFT-1024); 256- and 1024-frame periods run das
-// through the fp64 bin pipeline
+// fused fp32 das: the 512-frame period has the register-resident kernels (32 x 32 in-register FFT-1024, das_fused.hip); the 256-
+// and 1024-frame periods one fused kernel on LDS-staged transforms (das_fused_gen.hip)
 bool uses_fused_das(const bf_handle *h) {
-    return h->cfg.algo == BF_DAS && h->cfg.das_impl == BF_DAS_FUSED_F32 && h->cfg.hop == 512;
+    return h->cfg.algo == BF_DAS && h->cfg.das_impl == BF_DAS_FUSED_F32 && (h->cfg.hop == 512 || h->cfg.hop == 256 || h->cfg.hop == 1024);
 }
+bool fused_das_gen(const bf_handle *h) { return h->cfg.hop != 512; }
 
 // update_weights(): recompute every steering column from the current angles.
 void rebuild_steering(bf_handle *h, bool first, int only_dir = -1) {
@@ -122,7 +123,7 @@ int sync_tables(bf_handle *h, hipStream_t s, RunSnapshot *snap) {
         const int np = (h->M + 1) / 2;
         std::vector<f32x2> g, g64;  // [dir][pair][1024]
         for (int d = 0; d < h->n_dirs; ++d) {
-            const std::vector<f32x2> gd = das_pair_gains(h->steer[d], np);
+            const std::vector<f32x2> gd = fused_das_gen(h) ? das_pair_gains_natural(h->steer[d], np) : das_pair_gains(h->steer[d], np);
             g.insert(g.end(), gd.begin(), gd.end());
             if (h->use_w64) {
                 const std::vector<f32x2> gw = das_pair_gains_w64(gd, np);
@@ -152,14 +153,16 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     const int S = h->n_out;
     // one block (16 half-wavefronts) per run of consecutive frames; runs are multiples of 16 frames and
     // there are about as many runs as CUs
-    long runs = h->n_cus / S;
+    const bool gen = fused_das_gen(h);
+    // (periods 256 / 1024: several 256-thread blocks share a CU -- 13 / 52 KB of LDS each -- and a run costs one recomputed frame)
+    long runs = (gen ? (long)h->n_cus * (h->N == 512 ? 8 : 3) : (long)h->n_cus) / S;
     if (runs < 1) runs = 1;
     long fpc = (F + runs - 1) / runs;
-    fpc = ((fpc + 15) / 16) * 16;
+    if (!gen) fpc = ((fpc + 15) / 16) * 16;
     const long cps = (F + fpc - 1) / fpc;
 
     if (spectrum_dev) {
-        const size_t need = (size_t)S * F * 1024;
+        const size_t need = (size_t)S * F * h->N;
         if (need > h->sdump_cap) {
             if (h->d_sdump) (void)hipFree(h->d_sdump);
             h->d_sdump = nullptr;
@@ -194,7 +197,7 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     // forms for A/B runs (same arithmetic, bit-identical output)
     static const int das_variant = getenv("BF_DAS_VARIANT") ? atoi(getenv("BF_DAS_VARIANT")) : 3;
     a.variant = das_variant;
-    BF_HIP(h, prepare_das_fused(a, s));
+    if (!gen) BF_HIP(h, prepare_das_fused(a, s));
     hipEvent_t k0 = nullptr, k1 = nullptr;
     if (h->kernel_events) {
         BF_HIP(h, hipEventCreate(&k0));
@@ -202,11 +205,13 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
         h->kernel_events->push_back(std::make_pair(k0, k1));
         BF_HIP(h, hipEventRecord(k0, s));
     }
-    BF_HIP(h, h->use_w64 ? launch_das_fused_w64(a, s) : launch_das_fused(a, s));
+    BF_HIP(h, gen ? launch_das_fused_gen(a, h->N, s) : h->use_w64 ? launch_das_fused_w64(a, s) : launch_das_fused(a, s));
     if (k1) BF_HIP(h, hipEventRecord(k1, s));
     h->tail_cur ^= 1;
 
-    if (spectrum_dev) BF_HIP(h, launch_das_hermitian_dump(h->d_sdump, (f64x2 *)spectrum_dev, (long)S * F, s));
+    if (spectrum_dev)
+        BF_HIP(h, gen ? launch_das_hermitian_dump_gen(h->d_sdump, (f64x2 *)spectrum_dev, (long)S * F, h->N, s)
+                      : launch_das_hermitian_dump(h->d_sdump, (f64x2 *)spectrum_dev, (long)S * F, s));
     return BF_OK;
 }
 
@@ -328,7 +333,7 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
 
     const size_t S = h->n_streams, So = h->n_out;
     if (uses_fused_das(h)) {
-        const size_t gsz = (size_t)((h->M + 1) / 2) * 1024 * h->n_dirs;
+        const size_t gsz = (size_t)((h->M + 1) / 2) * h->N * h->n_dirs;
         BF_CREATE_HIP(hipMalloc((void **)&h->d_gains[0], gsz * sizeof(f32x2)));
         BF_CREATE_HIP(hipMalloc((void **)&h->d_gains[1], gsz * sizeof(f32x2)));
         BF_CREATE_HIP(hipMalloc((void **)&h->d_gains_w64[0], gsz * sizeof(f32x2)));
@@ -338,8 +343,15 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
             BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle_w64, tw64.size() * sizeof(f32x2)));
             BF_CREATE_HIP(hipMemcpy(h->d_twiddle_w64, tw64.data(), tw64.size() * sizeof(f32x2), hipMemcpyHostToDevice));
         }
-        h->use_w64 = getenv("BF_DAS_W64") && atoi(getenv("BF_DAS_W64")) != 0;
+        h->use_w64 = !fused_das_gen(h) && getenv("BF_DAS_W64") && atoi(getenv("BF_DAS_W64")) != 0;
         std::vector<f32x2> tw = twiddle_table_32x32<f32x2>();
+        if (fused_das_gen(h)) {  // exp(-2 pi i m / N), m < N/2 (Stockham passes)
+            tw.resize(h->N / 2);
+            for (int m = 0; m < h->N / 2; ++m) {
+                const double ang = -2.0 * kPi * (double)m / (double)h->N;
+                tw[m] = f32x2{(float)std::cos(ang), (float)std::sin(ang)};
+            }
+        }
         BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle, tw.size() * sizeof(f32x2)));
         BF_CREATE_HIP(hipMemcpy(h->d_twiddle, tw.data(), tw.size() * sizeof(f32x2), hipMemcpyHostToDevice));
         std::vector<double> hd = sqrt_hann(h->N);
@@ -347,8 +359,8 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
         for (int i = 0; i < h->N; ++i) hf[i] = (float)hd[i];
         BF_CREATE_HIP(hipMalloc((void **)&h->d_window, hf.size() * sizeof(float)));
         BF_CREATE_HIP(hipMemcpy(h->d_window, hf.data(), hf.size() * sizeof(float), hipMemcpyHostToDevice));
-        BF_CREATE_HIP(hipMalloc((void **)&h->d_zeros, 1024 * sizeof(float)));
-        BF_CREATE_HIP(hipMemset(h->d_zeros, 0, 1024 * sizeof(float)));
+        BF_CREATE_HIP(hipMalloc((void **)&h->d_zeros, 2048 * sizeof(float)));
+        BF_CREATE_HIP(hipMemset(h->d_zeros, 0, 2048 * sizeof(float)));
         BF_CREATE_HIP(hipMalloc((void **)&h->d_hist[0], S * h->M * h->H * sizeof(float)));
         BF_CREATE_HIP(hipMalloc((void **)&h->d_hist[1], S * h->M * h->H * sizeof(float)));
         BF_CREATE_HIP(hipMalloc((void **)&h->d_tail[0], So * h->H * sizeof(float)));

@@ -1,0 +1,177 @@
+// das_fused_gen.hip -- fused fp32 delay-and-sum for the JACK periods the in-register 32 x 32 transform does not cover:
+// 256 frames (FFT 512) and 1024 frames (FFT 2048); rosjack.cpp:131, fft_win = 2 * period (util.h:261).
+//
+// Same formulation as das_fused.hip -- per frame ceil(M/2) packed forward transforms, S += D_p Z_p with the pair gains of
+// geometry.hpp (natural bin order here), one backward transform, synthesis window, float overlap-add (das.cpp:47-70,
+// util.h:217-253,301-302) -- in ONE launch, spectra never leaving the CU.  The transforms are LDS-staged radix-2 Stockham
+// passes of a 256-thread block (one frame at a time per block): a plain design, 3-4 x the three-kernel fp64 chain these
+// periods ran before, not the register-resident machinery of the 512-frame period.  A block owns a run of consecutive frames
+// and keeps the overlap-add tail in LDS; a run that does not start the stream recomputes its previous frame for that tail.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace bf {
+
+namespace {
+
+constexpr int kGB = 256;
+
+// autosort radix-2 passes in LDS: data starts in b0, result ends in the returned buffer.  tw[m] = exp(-2 pi i m / N), m < N/2.
+template <int N, int DIR>
+__device__ __forceinline__ float2 *stockham32(float2 *b0, float2 *b1, const float2 *tw, int tid) {
+    float2 *in = b0, *out = b1;
+#pragma unroll 1
+    for (int ns = 1; ns < N; ns <<= 1) {
+#pragma unroll
+        for (int j = tid; j < N / 2; j += kGB) {
+            const int k = j & (ns - 1);
+            const float2 w0 = tw[k * (N / (2 * ns))];
+            const float wx = w0.x, wy = DIR < 0 ? w0.y : -w0.y;
+            const float2 u = in[j], v = in[j + N / 2];
+            const float bx = v.x * wx - v.y * wy, by = v.x * wy + v.y * wx;
+            const int j0 = ((j - k) << 1) + k;
+            out[j0] = float2{u.x + bx, u.y + by};
+            out[j0 + ns] = float2{u.x - bx, u.y - by};
+        }
+        __syncthreads();
+        float2 *t = in;
+        in = out;
+        out = t;
+    }
+    return in;
+}
+
+template <int N>
+__global__ __launch_bounds__(kGB) void das_fused_gen_kernel(DasFusedArgs a) {
+    constexpr int H = N / 2, BPT = N / kGB;  // bins (samples) per thread: 2 or 8
+    __shared__ float2 s_a[N], s_b[N], s_tw[N / 2];
+    __shared__ float s_win[N], s_tail[H];
+    const int tid = threadIdx.x;
+    const int M = a.n_mics, n_pairs = (M + 1) >> 1;
+    const int stream = blockIdx.x / a.chunks_per_stream;  // output stream = input stream * n_dirs + look direction
+    const long c_in_s = blockIdx.x - (long)stream * a.chunks_per_stream;
+    const int in_stream = stream / a.n_dirs;
+    const f32x2 *gains = a.gains + (long)(stream - in_stream * a.n_dirs) * n_pairs * N;  // [pair][bin], 1/N folded in
+    for (int i = tid; i < N / 2; i += kGB) s_tw[i] = float2{a.twiddle[i].x, a.twiddle[i].y};
+    for (int i = tid; i < N; i += kGB) s_win[i] = a.window[i];
+    const long T0 = c_in_s * a.frames_per_chunk;
+    long T1 = T0 + a.frames_per_chunk;
+    if (T1 > a.n_frames) T1 = a.n_frames;
+    if (T0 == 0)
+        for (int i = tid; i < H; i += kGB) s_tail[i] = a.tail_in[(long)stream * H + i];
+    __syncthreads();
+    const float *xs = a.x + (long)in_stream * a.stream_stride_x;
+    const float *hs = a.hist_in + (long)in_stream * M * H;
+    float *ys = a.y + (long)stream * a.n_frames * H;
+
+    for (long t = (T0 == 0 ? 0 : T0 - 1); t < T1; ++t) {  // T0 - 1: warm-up frame, only its second half (the tail) is used
+        float2 S[BPT];
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) S[i] = float2{0.f, 0.f};
+        for (int p = 0; p < n_pairs; ++p) {
+            const int ma = 2 * p, mb = 2 * p + 1;
+            const bool b_ok = mb < M;
+#pragma unroll
+            for (int i = 0; i < BPT; ++i) {
+                const int n = tid + kGB * i;
+                const bool first = n < H;  // first half of the frame = the hop before hop t (the carried hop at t = 0)
+                const int k = first ? n : n - H;
+                float va, vb = 0.f;
+                if (a.layout == 0) {
+                    const float *ba = first ? (t >= 1 ? xs + (long)ma * a.mic_stride + (t - 1) * H : hs + ma * H) : xs + (long)ma * a.mic_stride + t * H;
+                    va = ba[k];
+                    if (b_ok) {
+                        const float *bb = first ? (t >= 1 ? xs + (long)mb * a.mic_stride + (t - 1) * H : hs + mb * H) : xs + (long)mb * a.mic_stride + t * H;
+                        vb = bb[k];
+                    }
+                } else {
+                    const float *bs = first ? (t >= 1 ? xs + (t - 1) * (long)H * M : hs) : xs + t * (long)H * M;
+                    va = bs[(long)k * M + ma];
+                    if (b_ok) vb = bs[(long)k * M + mb];
+                }
+                const float w = s_win[n];
+                s_a[n] = float2{va * w, vb * w};  // buf[j]*hann_win[i]  (util.h:235)
+            }
+            __syncthreads();
+            const float2 *Z = stockham32<N, -1>(s_a, s_b, s_tw, tid);
+            const f32x2 *gp = gains + (long)p * N;
+#pragma unroll
+            for (int i = 0; i < BPT; ++i) {
+                const int k = tid + kGB * i;
+                const f32x2 g = gp[k];
+                const float2 z = Z[k];
+                S[i].x = __builtin_fmaf(-g.y, z.y, __builtin_fmaf(g.x, z.x, S[i].x));
+                S[i].y = __builtin_fmaf(g.y, z.x, __builtin_fmaf(g.x, z.y, S[i].y));
+            }
+            __syncthreads();  // Z is rewritten by the next pair's samples
+        }
+        if (a.sdump != nullptr && t >= T0) {
+            f32x2 *sd = a.sdump + ((long)stream * a.n_frames + t) * N;
+#pragma unroll
+            for (int i = 0; i < BPT; ++i) sd[tid + kGB * i] = f32x2{S[i].x, S[i].y};
+        }
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) s_a[tid + kGB * i] = S[i];
+        __syncthreads();
+        const float2 *Y = stockham32<N, +1>(s_a, s_b, s_tw, tid);
+        float o[BPT];
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            const int n = tid + kGB * i;
+            {
+#pragma clang fp contract(off)
+                o[i] = Y[n].x * s_win[n];  // (float)(Re / N) [1/N inside the gains] times the synthesis window (util.h:249-251)
+                if (n < H && t >= T0) ys[t * H + n] = s_tail[n] + o[i];  // out = prev[H + n] + cur[n]  (util.h:301-302)
+            }
+        }
+        __syncthreads();  // every read of the old tail is done
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            const int n = tid + kGB * i;
+            if (n >= H) s_tail[n - H] = o[i];
+        }
+        __syncthreads();
+        if (t == a.n_frames - 1) {  // end of the batch: carried state for the next call (OLA tail and the last input hop)
+            for (int i = tid; i < H; i += kGB) a.tail_out[(long)stream * H + i] = s_tail[i];
+            float *ho = a.hist_out + (long)in_stream * M * H;  // every direction writes the same values
+            if (a.layout == 0) {
+                for (int i = tid; i < M * H; i += kGB) ho[i] = xs[(long)(i / H) * a.mic_stride + t * H + (i % H)];
+            } else {
+                for (int i = tid; i < M * H; i += kGB) ho[i] = xs[t * (long)H * M + i];
+            }
+        }
+    }
+}
+
+__global__ void das_hermitian_dump_gen_kernel(const f32x2 *s, f64x2 *out, long total, int N) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long f = idx / N;
+    const int k = (int)(idx - f * N);
+    const f32x2 u = s[f * N + k];
+    const f32x2 v = s[f * N + ((N - k) & (N - 1))];
+    // undo the folded 1/N; Hermitian part (S[k] + conj(S[N-k]))/2
+    out[idx] = f64x2{0.5 * N * ((double)u.x + (double)v.x), 0.5 * N * ((double)u.y - (double)v.y)};
+}
+
+}  // namespace
+
+hipError_t launch_das_fused_gen(const DasFusedArgs &a, int n_fft, hipStream_t stream) {
+    const unsigned blocks = (unsigned)((long)a.chunks_per_stream * a.n_streams);
+    if (n_fft == 512)
+        hipLaunchKernelGGL(das_fused_gen_kernel<512>, dim3(blocks), dim3(kGB), 0, stream, a);
+    else if (n_fft == 2048)
+        hipLaunchKernelGGL(das_fused_gen_kernel<2048>, dim3(blocks), dim3(kGB), 0, stream, a);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_das_hermitian_dump_gen(const f32x2 *sdump, f64x2 *out, long n_frames_total, int n_fft, hipStream_t stream) {
+    const long total = n_frames_total * n_fft;
+    hipLaunchKernelGGL(das_hermitian_dump_gen_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, sdump, out, total, n_fft);
+    return hipGetLastError();
+}
+
+}  // namespace bf

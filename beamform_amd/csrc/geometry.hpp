@@ -159,6 +159,22 @@ inline std::vector<V> das_pair_gains_t(const SteeringSet &s, int n_pairs_alloc) 
     return D;
 }
 inline std::vector<f32x2> das_pair_gains(const SteeringSet &s, int n_pairs_alloc) { return das_pair_gains_t<f32x2>(s, n_pairs_alloc); }
+// The same gains in natural bin order [pair][k], any FFT size (das_fused_gen.hip: JACK periods 256 and 1024).
+inline std::vector<f32x2> das_pair_gains_natural(const SteeringSet &s, int n_pairs_alloc) {
+    const int N = s.n_fft, M = s.n_mics;
+    std::vector<f32x2> D((size_t)n_pairs_alloc * N, f32x2{0.f, 0.f});
+    auto ce = [&](int m, int k) -> cplxd {
+        if (m >= M) return cplxd(0, 0);
+        const cplxd c1 = std::conj(s.at(k, m, 0)) / (double)M, c2 = std::conj(s.at((N - k) % N, m, 0)) / (double)M;
+        return 0.5 * (c1 + std::conj(c2));
+    };
+    for (int p = 0; p < (M + 1) / 2; ++p)
+        for (int k = 0; k < N; ++k) {
+            const cplxd d = (ce(2 * p, k) - cplxd(0, 1) * ce(2 * p + 1, k)) / (double)N;
+            D[(size_t)p * N + k] = f32x2{(float)d.real(), (float)d.imag()};
+        }
+    return D;
+}
 
 
 // Same gains in the register/lane order of the 64-lane factorisation (fft1024_w64.hpp):

@@ -42,4 +42,10 @@ hipError_t launch_stream_rms(const float *y, long n_samples, int n_streams, doub
 
 hipError_t launch_das_hermitian_dump(const f32x2 *sdump, f64x2 *out, long n_frames_total, hipStream_t stream);
 
+// JACK periods 256 / 1024 (FFT 512 / 2048), das_fused_gen.hip: same argument block; `gains` = das_pair_gains_natural tables [dir][pair][n_fft],
+// `twiddle` = exp(-2 pi i m / n_fft) for m < n_fft / 2, `window` n_fft floats; frames_per_chunk is free (no multiple of 16), no
+// prepare step (a run that does not start the stream recomputes its previous frame); sdump rows are n_fft long, natural order
+hipError_t launch_das_fused_gen(const DasFusedArgs &a, int n_fft, hipStream_t stream);
+hipError_t launch_das_hermitian_dump_gen(const f32x2 *sdump, f64x2 *out, long n_frames_total, int n_fft, hipStream_t stream);
+
 }  // namespace bf

@@ -74,8 +74,8 @@ typedef struct bf_config {
     int n_mics;                    /* number_of_microphones (util.h:122) */
     int hop;                       /* rosjack_window_size = the JACK period (rosjack.cpp:131); fft_win = 2*hop (util.h:261).
                                       256, 512 or 1024.  512 is the tuned shape (in-register 32 x 32 FFT-1024, fused fp32 das);
-                                      256 / 1024 run every node, das included, through the fp64 bin pipeline with LDS-staged
-                                      radix-2 transforms */
+                                      256 / 1024: das (BF_DAS_FUSED_F32) in one fused fp32 kernel on LDS-staged radix-2
+                                      transforms, every other node through the fp64 bin pipeline with the same transforms */
     double sample_rate;            /* rosjack_sample_rate */
     double mic_x[BF_MAX_MICS];     /* RAW mic<i>.x / .y from beamform_config.yaml (util.h:82-92) */
     double mic_y[BF_MAX_MICS];
@@ -282,7 +282,7 @@ void bf_wav_free(float *planar);
  * DEVIATION from rosjack's stage when out_rate > in_rate: the reference keeps output_frames = rosjack_window_size and copies a
  * new period into the converter only when input_frames == 0 (rosjack.cpp:311-338), and it emits at most one data_length block
  * per callback (:416-436) -- when upsampling src_process leaves input unconsumed, so the reference DROPS periods and never
- * writes a trailing partial block.  bf_resampler (and examples/file_node) consume every input sample and return every output
+ * writes a trailing partial block.  The converter here (and examples/file_node) consumes every input sample and returns every output
  * sample: for ratio > 1 the stream is the mathematically complete conversion, longer than the reference's file; for
  * ratio < 1 only the tail (less than one period) differs.  tests/test_resample_gpu.py pins the chosen behaviour. */
 typedef struct bf_resampler bf_resampler;

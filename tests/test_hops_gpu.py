@@ -57,7 +57,13 @@ def test_nodes_at_other_jack_periods(hop, algo, M, interf):
     x = make_scene(M, F, hop=hop, seed=300 + M + hop // 256)
     y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
     _, y, Y = run(p, x)
+    if algo == "das":  # the fused fp32 kernels (das_fused_gen.hip at these periods) dump the Hermitian part of y_fft: the part that reaches Re(ifft)
+        Y_ref = 0.5 * (Y_ref + np.conj(np.roll(Y_ref[:, ::-1], 1, axis=1)))
     check(y[0], Y[0], y_ref, Y_ref)
+    if algo == "das":  # and the same node at the reference's precision keeps the fp64 pipeline with the full y_fft
+        from beamform_amd.capi import BF_DAS_BINS_F64, Beamformer
+        y64 = Beamformer(p, das_impl=BF_DAS_BINS_F64).process(x)
+        assert rel_l2(y64, y_ref) < TOL
 
 
 @pytest.mark.parametrize("hop", [256, 1024])
@@ -168,3 +174,39 @@ def test_more_than_sixteen_microphones(algo, M, interf, radius, band):
     y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
     _, y, Y = run(p, x)
     check(y[0], Y[0], y_ref, Y_ref)
+
+
+@pytest.mark.parametrize("hop", [256, 1024])
+def test_fused_das_at_other_periods_layouts_streams_directions_cuts(hop):
+    """das_fused_gen.hip (fused fp32 das at JACK periods 256 / 1024): interleaved input, several streams, look directions, a
+    long batch cut into runs (every run but the first recomputes its previous frame), uneven batch cuts -- against the oracle."""
+    import oracle
+    from beamform_amd.capi import BF_INTERLEAVED, Beamformer
+    _torch()
+    M, S, F = 5, 2, 40
+    p = make_params("das", n_mics=M, theta=-30.0, hop=hop)
+    xs = np.stack([make_scene(M, F, hop=hop, seed=70 + s) for s in range(S)])
+    refs = [oracle.OracleNode(p).process(xs[s])[0] for s in range(S)]
+    y = Beamformer(p, n_streams=S).process(xs)
+    yi = Beamformer(p, n_streams=S, layout=BF_INTERLEAVED).process(np.ascontiguousarray(xs.transpose(0, 2, 1)))
+    for s in range(S):
+        assert rel_l2(y[s], refs[s]) < TOL and rel_l2(yi[s], refs[s]) < TOL
+        assert np.array_equal(y[s], yi[s])
+    # look directions: every beam equals its own node
+    thetas = [-60.0, 10.0, 75.0]
+    bf = Beamformer(p, n_dirs=3)
+    bf.set_thetas(thetas)
+    yd = bf.process(xs[0])
+    for d, th in enumerate(thetas):
+        ref, _ = oracle.OracleNode(make_params("das", n_mics=M, theta=th, hop=hop)).process(xs[0])
+        assert rel_l2(yd[d], ref) < TOL
+    # a batch long enough to be cut into many runs, and the same stream in uneven batches
+    Fl = 3000 if hop == 256 else 1200
+    xl = make_scene(M, Fl, hop=hop, seed=99)
+    ref, _ = oracle.OracleNode(p).process(xl)
+    whole = Beamformer(p).process(xl)
+    assert rel_l2(whole, ref) < TOL
+    b2 = Beamformer(p)
+    cuts = [0, 1, 7, Fl // 3, Fl]
+    parts = [b2.process(np.ascontiguousarray(xl[:, a * hop:c * hop])) for a, c in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(np.concatenate(parts), whole)

@@ -1,4 +1,2 @@
 cd /root/repo
-export TMPDIR=/tmp
-for m in 1 2 4; do echo -n "x$m: "; BF_DASF64_RUNS=$m python tools/run_das.py --algo das --das-f64 --iters 20 | tail -1 | cut -c28-60; done
-for m in 1 2; do echo -n "x$m: "; BF_DASF64_RUNS=$m python tools/run_das.py --algo das --das-f64 --iters 20 | tail -1 | cut -c28-60; done
+python -m pytest tests/test_hops_gpu.py tests/test_shard_gpu.py tests/test_dirs_gpu.py -x -q -m gpu 2>&1 | tail -5
