@@ -981,7 +981,7 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
     //   s_g: 272-byte rows: every lane of a problem reads the same entry, two problems per access.
     __shared__ __attribute__((aligned(16))) f64x2 s_x[4][2][4][20];   // [wave][new / old][problem][mic]
     __shared__ __attribute__((aligned(16))) f64x2 s_u[4][4][NB][17];  // [wave][problem][column][row]: U = L^-1 [C | x]
-    __shared__ __attribute__((aligned(16))) f64x2 s_g[4][4][17];      // [wave][problem][Gram entry]
+    __shared__ __attribute__((aligned(16))) f64x2 s_g[4][4][4][17];   // [wave][problem][frame slot][Gram entry]: four frames' systems wait here
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int l16 = lane & 15, grp = lane >> 4, p = l16 >> 2, q = l16 & 3;
     const int pq = blockIdx.y * 16 + wv * 4 + grp;
@@ -1056,13 +1056,19 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
 #pragma unroll
             for (int bc = 0; bc <= ar; ++bc) R[LT(ar, bc)] = cfma_conj(R[LT(ar, bc)], xr[ar], xc[bc]);
     }
+    // The (K+1) x (K+1) system G y = g of a frame has no successor in the recursion (only R slides on), and every lane of a
+    // problem's row would solve it redundantly: the Gram entries of four consecutive frames are parked in LDS instead and
+    // lanes 0..3 of the row solve one frame each -- one pass of the small solve per four frames.
+    unsigned open_mask = 0;  // frame slots of this row whose system waits (uniform per row)
     for (long t = tA; t < tB; ++t) {
+        const int slot = (int)(t - tA) & 3;
         const cd xm = load_mic(t);
         cd xr[4], xc[4];
         spread(xm, 0, xr, xc);
         const double mag = row_sum(fast_sqrt(norm2(xm))) / (double)((unsigned)M * (unsigned)kN);
         const cd x0 = rowbc<0>(xm);
-        cd y;
+        cd y{0, 0};
+        bool deferred = false;
         if (mag > a.cfg.freq_mag_threshold) {  // uniform per row
             cd A[10], b[4][NS];
 #pragma unroll
@@ -1130,12 +1136,26 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc = cfma_conj(acc, ld(&s_u[wv][grp][r2][i]), ld(&s_u[wv][grp][r1][i]));
                 }
-                s_g[wv][grp][l16] = f64x2{acc.x, acc.y};
+                s_g[wv][grp][slot][l16] = f64x2{acc.x, acc.y};
             }
+            deferred = true;
+        } else {
+            y = x0 * 0.01;  // in_fft(0,j)*0.01 (mvdr.cpp:96)
+        }
+        if (!inband) {
+            y = (j == 0 && !lcmv) ? x0 : cd{0, 0};
+            deferred = false;
+        }
+        if (deferred)
+            open_mask |= 1u << slot;
+        else if (live && l16 == 0)
+            st_y(a, yidx + t * kYhStride, qq, y);
+        if (slot == 3 || t == tB - 1) {  // uniform: the parked systems, one frame per lane 0..3 of the row
             __builtin_amdgcn_wave_barrier();
+            const int fs = l16 & 3;
             cd ge[NE];
 #pragma unroll
-            for (int e = 0; e < NE; ++e) ge[e] = ld(&s_g[wv][grp][e]);
+            for (int e = 0; e < NE; ++e) ge[e] = ld(&s_g[wv][grp][fs][e]);
             __builtin_amdgcn_wave_barrier();
             // (K+1) x (K+1) system G y = g on the upper triangle (as in mvdr_lcmv_row_kernel)
             cd gv[KM];
@@ -1172,12 +1192,10 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
                 for (int c = k + 1; c < KM; ++c) acc = acc - ge[UI(k, c)] * gv[c];
                 gv[k] = acc * pinvs[k];
             }
-            y = gv[0];
-        } else {
-            y = x0 * 0.01;  // in_fft(0,j)*0.01 (mvdr.cpp:96)
+            // lane fs of the row holds frame (t - slot + fs)
+            if (live && l16 < 4 && fs <= slot && ((open_mask >> fs) & 1u)) st_y(a, yidx + (t - slot + fs) * kYhStride, qq, gv[0]);
+            open_mask = 0;
         }
-        if (!inband) y = (j == 0 && !lcmv) ? x0 : cd{0, 0};
-        if (live && l16 == 0) st_y(a, yidx + t * kYhStride, qq, y);
         // slide the covariance window: + x_t x_t^H - x_{t-P} x_{t-P}^H (mvdr.cpp:100-101).  x_t is read back from its LDS slot
         // (still there) instead of being kept in 32 registers across the factorisation.
         cd xor_[4], xoc[4];
