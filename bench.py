@@ -403,7 +403,7 @@ def main():
         jobs = [
             ("mvdr", lambda: node_line("mvdr", M, F, 1, xin=x, note="BASELINE config 3; fp64 bin pipeline; " + noise)),
             ("das_f64", lambda: node_line("das", M, F, 1, das_impl_=BF_DAS_BINS_F64, xin=x,
-                                          note="same precision as the reference (double spectra): the fp64 bin pipeline")),
+                                          note="same precision as the reference: das_f64_fused_kernel, the fused kernel's formulation in double, one launch")),
             ("das_interleaved", lambda: node_line("das", M, F, 1, xin=x.reshape(1, F * HOP, M), layout_=BF_INTERLEAVED, iters=20,
                                                   note="the headline workload with [sample][mic] input (same bytes read as interleaved samples)")),
             ("phasempf", lambda: node_line("phasempf", 8, 256, 256, note="BASELINE config 4: 256 streams x 256 frames, recursion per stream")),
