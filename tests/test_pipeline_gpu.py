@@ -421,3 +421,27 @@ def test_c_shard_node_example_reproduces_the_unsharded_stream():
     # one rank, RCCL initialised for real: communicator of size 1, the overlapped walk, no peer
     out = subprocess.run([exe, "das", "8", "8192", "1", "0", "/tmp/bf_shard_node_test.id", "4", "2"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ms_per_step_with_overlapped_gather" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("algo,M,interf", [("mvdr", 8, ()), ("mvdr", 5, ()), ("lcmv", 8, (-60.0,)), ("lcmv", 16, (-60.0, 90.0, 150.0)), ("mvdr", 12, ())])
+@pytest.mark.parametrize("band", [(0.0, 24000.0), (0.0, 23960.0), (300.0, 3400.0), (20000.0, 23000.0), (30.0, 40.0), (5.0, 20.0)])
+def test_mvdr_lcmv_other_bands(algo, M, interf, band):
+    """freq_min / freq_max other than the launch file's (mvdr.cpp:166-178): the full band -- which takes in the irregular
+    problems N/2 (f = 0 by quirk Q1) and N/2 + 1 and routes mvdr to the group kernel --, a band ending between them, a telephone
+    band, a high band, a band of one bin (30-40 Hz holds no bin at all: 46.875 Hz spacing -- only problem 0 is non-zero) --
+    spectrum dump (f64 rows) and the product's f32 band-limited rows both."""
+    import oracle
+    from beamform_amd.capi import Beamformer
+    F = 26
+    p = make_params(algo, n_mics=M, interf=interf, theta=20.0, freq_min=band[0], freq_max=band[1])
+    x = make_scene(M, F, seed=700 + M)
+    y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
+    y, Y = run_gpu(p, x)
+    check(y, Y, y_ref, Y_ref)
+    y2 = Beamformer(p).process(x)
+    ok = np.isfinite(y_ref)
+    assert (np.isfinite(y2) == ok).all()
+    if np.abs(y_ref[ok]).max() > 0:
+        assert rel_l2(y2[ok], y_ref[ok]) < TOL_TIME
+    else:
+        assert np.abs(y2[ok]).max() == 0

@@ -1,3 +1,2 @@
 cd /root/repo
-export TMPDIR=/tmp
-for seed in 11 12 13 14; do python tools/fuzz_parity.py $seed 250 2>&1 | tail -3; done
+python -m pytest tests/test_pipeline_gpu.py -x -q -m gpu -k other_bands 2>&1 | tail -12
