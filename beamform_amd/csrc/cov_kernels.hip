@@ -984,9 +984,16 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
     __shared__ __attribute__((aligned(16))) f64x2 s_g[4][4][4][17];   // [wave][problem][frame slot][Gram entry]: four frames' systems wait here
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int l16 = lane & 15, grp = lane >> 4, p = l16 >> 2, q = l16 & 3;
-    const int pq = blockIdx.y * 16 + wv * 4 + grp;
-    const int s = blockIdx.x / tiles_per_stream;
-    const long tA = (long)(blockIdx.x % tiles_per_stream) * tile;
+    // Workgroup b runs on XCD b % 8 (round-robin dispatch), each XCD behind its own L2.  A block's 16 problems are 192 contiguous
+    // bytes of every spectrum row -- one and a half cache lines -- so neighbouring problem groups share lines: XCD x takes the
+    // (stream, tile) units x, x + 8, ... and walks the problem groups of a unit back to back, which puts the blocks that share
+    // lines into the same L2 at the same time (a 2-D grid had them 1.5 residency windows apart: every shared line came twice).
+    const int n_grp = (kNQ + 15) / 16;
+    const int unit = (int)(blockIdx.x >> 3) / n_grp * 8 + (int)(blockIdx.x & 7);
+    if (unit >= tiles_per_stream * a.n_streams) return;
+    const int pq = ((int)(blockIdx.x >> 3) % n_grp) * 16 + wv * 4 + grp;
+    const int s = unit / tiles_per_stream;
+    const long tA = (long)(unit % tiles_per_stream) * tile;
     long tB = tA + tile;
     if (tB > a.n_frames) tB = a.n_frames;
     const int M = a.n_mics, NP = (M + 1) >> 1, KP1 = a.kp1, P = a.cfg.past_windows;
@@ -1045,6 +1052,16 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
         return (col < KP1 && col < KM && i < M) ? ld(steer + ((long)col * M + i) * kN + j) : cd{0, 0};
     };
 
+    // The constraint columns do not change over the tile: the two-wavefront build (195 registers of 256) keeps this lane's four
+    // entries of column p instead of fetching them again every frame; the three-wavefront build has no register to spare.
+    constexpr bool kKeepC = WPS == 2;
+    cd cst[4];
+    {
+        const cd none[4] = {};
+#pragma unroll
+        for (int ar = 0; ar < 4; ++ar) cst[ar] = (kKeepC && p < KM) ? rhs_init(ar, p, none) : cd{0, 0};
+    }
+
     cd R[10];
 #pragma unroll
     for (int e = 0; e < 10; ++e) R[e] = cd{0, 0};
@@ -1083,7 +1100,12 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
                     A[LT(ar, bc)] = v;
                 }
 #pragma unroll
-                for (int sl = 0; sl < NS; ++sl) b[ar][sl] = (p + 4 * sl < NB) ? rhs_init(ar, p + 4 * sl, xc) : cd{0, 0};
+                for (int sl = 0; sl < NS; ++sl) {
+                    if (kKeepC && sl == 0 && KM <= 4)
+                        b[ar][0] = p == KM ? xc[ar] : (p < KM ? cst[ar] : cd{0, 0});
+                    else
+                        b[ar][sl] = (p + 4 * sl < NB) ? rhs_init(ar, p + 4 * sl, xc) : cd{0, 0};
+                }
             }
             RowStep<0, 16>::run([&](auto jc) {
                 constexpr int jj = decltype(jc)::value, bj = jj >> 2, qj = jj & 3;
@@ -1248,7 +1270,11 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
     // 9..16 microphones, up to 3 interferers: 2-D cyclic 4 x 4 lanes per problem (lcmv 16-mic K=3 19.5 -> 15.8 ms per 32 768 frames,
     // lcmv 12-mic 19.0 -> 14.7, mvdr 16-mic 11.0 -> 10.2).  BF_COV2D=0 selects the row / lanes kernels below for A/B runs, =2 the
     // two-wavefronts-per-SIMD build.
-    static const int cov2d = getenv("BF_COV2D") ? atoi(getenv("BF_COV2D")) : 3;
+    static const int cov2d_env = getenv("BF_COV2D") ? atoi(getenv("BF_COV2D")) : -1;
+    // wavefronts per SIMD: with constraint columns (lcmv) the three-wavefront build spills 30 registers per lane and the spill
+    // traffic alone is 6 GB per 32 768 frames of 16 microphones: two wavefronts at 211 registers are 7 % faster; without
+    // constraints (mvdr, > 8 microphones) three wavefronts win by 12 %
+    const int cov2d = cov2d_env >= 0 ? cov2d_env : (km == 1 ? 3 : 2);
     static const int tile2d_env = getenv("BF_COV2D_TILE") ? atoi(getenv("BF_COV2D_TILE")) : 0;
     if (cov2d && !no_fast && M > 8 && M <= 16) {
         if (tile2d_env > 0) {
@@ -1256,7 +1282,7 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
             if (a.n_frames < tile) tile = (int)a.n_frames;
         }
         const int tps = (int)((a.n_frames + tile - 1) / tile);
-        const dim3 grid(tps * a.n_streams, (kNQ + 15) / 16);
+        const dim3 grid((unsigned)(((long)tps * a.n_streams + 7) / 8 * 8 * ((kNQ + 15) / 16)));  // (unit, problem group) -> XCD-aware order in the kernel
         if (km == 1) {
             if (cov2d == 3) hipLaunchKernelGGL((cov2d_kernel<1, 3>), grid, dim3(256), 0, s, a, tile, tps);
             else hipLaunchKernelGGL((cov2d_kernel<1, 2>), grid, dim3(256), 0, s, a, tile, tps);
