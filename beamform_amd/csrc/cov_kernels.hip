@@ -1224,10 +1224,10 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
         spread(load_mic(t - P), 1, xor_, xoc);
 #pragma unroll
         for (int ar = 0; ar < 4; ++ar) {
-            const cd xra = ld(&s_x[wv][0][grp][4 * ar + p]);
+            const cd xra = kKeepC ? xr[ar] : ld(&s_x[wv][0][grp][4 * ar + p]);
 #pragma unroll
             for (int bc = 0; bc <= ar; ++bc) {
-                const cd xcb = ld(&s_x[wv][0][grp][4 * bc + q]);
+                const cd xcb = kKeepC ? xc[bc] : ld(&s_x[wv][0][grp][4 * bc + q]);
                 R[LT(ar, bc)] = cfms_conj(cfma_conj(R[LT(ar, bc)], xra, xcb), xor_[ar], xoc[bc]);
             }
         }
