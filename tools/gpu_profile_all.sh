@@ -7,6 +7,10 @@ P="rocprofv3 --kernel-trace --output-format csv"
 python bench.py > gpurun_out/${tag}_bench_das8.json 2> gpurun_out/${tag}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_trace_bench -- python bench.py --no-cpu > gpurun_out/${tag}_bench_das8_profiled.json 2>> gpurun_out/${tag}_bench.err
 for f in $(find gpurun_out/${tag}_trace_bench -name "*kernel_stats*"); do cp $f gpurun_out/${tag}_bench_kernel_stats.csv; done
+# 1b. the same without the secondary lines: every das_fused_kernel launch in this trace is a full 65 536-frame batch (the streaming-callback
+#     line above launches the same kernel on single hops, which drags its average down)
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_trace_bench_ne -- python bench.py --no-cpu --no-extra > gpurun_out/${tag}_bench_das8_noextra_profiled.json 2>> gpurun_out/${tag}_bench.err
+for f in $(find gpurun_out/${tag}_trace_bench_ne -name "*kernel_stats*"); do cp $f gpurun_out/${tag}_bench_noextra_kernel_stats.csv; done
 # 2. calibration of FETCH_SIZE / WRITE_SIZE
 $P --pmc FETCH_SIZE -d gpurun_out/${tag}_cal_f -- ./tools/ubench/fetch_calib.bin > gpurun_out/${tag}_cal.log 2>&1
 $P --pmc WRITE_SIZE -d gpurun_out/${tag}_cal_w -- ./tools/ubench/fetch_calib.bin >> gpurun_out/${tag}_cal.log 2>&1

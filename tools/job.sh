@@ -1,9 +1,8 @@
 cd /root/repo
 export TMPDIR=/tmp
-for rep in 1 2; do
-for A in "--algo lcmv --mics 16 --frames 32768" "--algo mvdr --mics 16 --frames 32768"; do
-echo -n "base "; BFCORE_LIB=/root/repo/abtmp/libbfcore_base.so python tools/run_das.py $A --iters 20 | tail -1
-echo -n "new  "; python tools/run_das.py $A --iters 20 | tail -1
-done; done
-echo -n "new mvdr16 2-wave "; BF_COV2D=2 python tools/run_das.py --algo mvdr --mics 16 --frames 32768 --iters 20 | tail -1
-python -m pytest tests/test_pipeline_gpu.py tests/test_variants_gpu.py tests/test_shard_gpu.py -x -q -m gpu 2>&1 | tail -3
+mkdir -p gpurun_out
+tag=r03_d
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_trace_bench_ne -- python bench.py --no-cpu --no-extra > gpurun_out/${tag}_bench_das8_noextra_profiled.json 2>> gpurun_out/${tag}_bench.err
+for f in $(find gpurun_out/${tag}_trace_bench_ne -name "*kernel_stats*"); do cp $f gpurun_out/${tag}_bench_noextra_kernel_stats.csv; done
+head -3 gpurun_out/${tag}_bench_noextra_kernel_stats.csv
+cat gpurun_out/${tag}_bench_das8_noextra_profiled.json | cut -c1-600
