@@ -44,7 +44,10 @@ struct FastPlan {
     int tile, tiles, waves_per_stream;
 };
 
-template <int MP>
+// KC = constraint columns: 1 = mvdr (the steering vector); 2..4 = lcmv with up to KC - 1 interferers (lcmv.cpp:102-130): the
+// columns C ride through the factorisation like the steering vector does (U = L^-1 C, v = L^-1 x), then G = U^H U, g = U^H v and
+// y = (G^-1 g)_0 -- the first row of W^H x with W = R^-1 C (C^H R^-1 C)^-1.  Unused columns are padded with the identity.
+template <int MP, int KC>
 __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan fp) {
     constexpr int NT = MP * (MP + 1) / 2;
     const int lane = threadIdx.x;
@@ -159,10 +162,13 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows have been read: the next DMA may overwrite them
         }
         if (it + 1 < n_it) dma_frame(it + 1, true, pb ^ 1);
-        cd ua[MP];  // the steering column: re-read per frame (L2-resident, consecutive lanes = consecutive bins) instead of
-                    // living in 32 registers that the factorisation needs
+        cd U[KC][MP];  // the constraint columns: re-read per frame (L2-resident, consecutive lanes = consecutive bins) instead of
+                       // living in registers that the factorisation needs
 #pragma unroll
-        for (int m = 0; m < MP; ++m) ua[m] = (m < M) ? ld(steer + (long)m * kN) : cd{0, 0};
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+            for (int m = 0; m < MP; ++m) U[c][m] = (m < M && c < a.kp1) ? ld(steer + ((long)c * M + m) * kN) : cd{0, 0};
+        cd(&ua)[MP] = U[0];
         cd X[MP];
         unpack(pb, 0, X);
         // park the unpacked spectra in the slots their packed form came from (a 16-byte slot holds one complex double): the
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
             open = mag > a.cfg.freq_mag_threshold;
         }
         cd y = X[0] * 0.01;  // gate closed: mvdr.cpp:96
-        if (q == 0) y = X[0];  // mvdr.cpp:76
+        if (q == 0) y = a.cfg.algo == BF_LCMV ? cd{0, 0} : X[0];  // mvdr.cpp:76; lcmv has no such rule: problem 0 is out of band on this path
         if (__builtin_amdgcn_ballot_w64(open && q != 0) != 0) {
             cd A[NT];
 #pragma unroll
@@ -196,13 +202,15 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
 #pragma unroll
             for (int jj = 0; jj < MP; ++jj) {
                 const double inv = fast_rsqrt(A[jj * (jj + 1) / 2 + jj].x);  // 1/L_jj; L_jj itself is never needed
-                ua[jj] = ua[jj] * inv;
+#pragma unroll
+                for (int c = 0; c < KC; ++c) U[c][jj] = U[c][jj] * inv;
                 X[jj] = X[jj] * inv;  // X turns into v = L^-1 x in place
 #pragma unroll
                 for (int i = jj + 1; i < MP; ++i) {
                     const cd Lij = A[i * (i + 1) / 2 + jj] * inv;
                     A[i * (i + 1) / 2 + jj] = Lij;
-                    ua[i] = cfms(ua[i], Lij, ua[jj]);
+#pragma unroll
+                    for (int c = 0; c < KC; ++c) U[c][i] = cfms(U[c][i], Lij, U[c][jj]);
                     X[i] = cfms(X[i], Lij, X[jj]);
                 }
 #pragma unroll
@@ -217,15 +225,66 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
                     }
                 }
             }
-            cd num{0, 0};
-            double den = 0.0;
+            if constexpr (KC == 1) {
+                cd num{0, 0};
+                double den = 0.0;
 #pragma unroll
-            for (int i = 0; i < MP; ++i) {
-                num = cfma_conj(num, X[i], ua[i]);
-                den += norm2(ua[i]);
+                for (int i = 0; i < MP; ++i) {
+                    num = cfma_conj(num, X[i], ua[i]);
+                    den += norm2(ua[i]);
+                }
+                const double rden = fast_rcp(den);
+                if (open && q != 0) y = cd{num.x * rden, num.y * rden};
+            } else {
+                // G (Hermitian, upper triangle row-major) and g, then the KC x KC system by elimination (as cov2d_kernel)
+                auto UI = [](int r, int c) { return r * KC - r * (r - 1) / 2 + (c - r); };
+                cd ge[KC * (KC + 1) / 2], gv[KC];
+#pragma unroll
+                for (int r1 = 0; r1 < KC; ++r1) {
+#pragma unroll
+                    for (int r2 = r1; r2 < KC; ++r2) {
+                        cd acc{0, 0};
+#pragma unroll
+                        for (int i = 0; i < MP; ++i) acc = cfma_conj(acc, U[r2][i], U[r1][i]);
+                        ge[UI(r1, r2)] = acc;
+                    }
+                    cd acc{0, 0};
+#pragma unroll
+                    for (int i = 0; i < MP; ++i) acc = cfma_conj(acc, X[i], U[r1][i]);
+                    gv[r1] = acc;
+                }
+#pragma unroll
+                for (int r1 = 0; r1 < KC; ++r1)
+                    if (r1 >= a.kp1) {
+#pragma unroll
+                        for (int r2 = 0; r2 < r1; ++r2) ge[UI(r2, r1)] = cd{0, 0};
+                        ge[UI(r1, r1)] = cd{1.0, 0.0};
+#pragma unroll
+                        for (int c = r1 + 1; c < KC; ++c) ge[UI(r1, c)] = cd{0, 0};
+                        gv[r1] = cd{0, 0};
+                    }
+                cd pinvs[KC];
+#pragma unroll
+                for (int k = 0; k < KC; ++k) {
+                    const cd pinv = crcp(ge[UI(k, k)]);
+                    pinvs[k] = pinv;
+#pragma unroll
+                    for (int r1 = k + 1; r1 < KC; ++r1) {
+                        const cd fct = conj(ge[UI(k, r1)]) * pinv;
+#pragma unroll
+                        for (int c = r1; c < KC; ++c) ge[UI(r1, c)] = ge[UI(r1, c)] - fct * ge[UI(k, c)];
+                        gv[r1] = gv[r1] - fct * gv[k];
+                    }
+                }
+#pragma unroll
+                for (int k = KC - 1; k >= 0; --k) {
+                    cd acc = gv[k];
+#pragma unroll
+                    for (int c = k + 1; c < KC; ++c) acc = acc - ge[UI(k, c)] * gv[c];
+                    gv[k] = acc * pinvs[k];
+                }
+                if (open && q != 0) y = gv[0];
             }
-            const double rden = fast_rcp(den);
-            if (open && q != 0) y = cd{num.x * rden, num.y * rden};
         }
         if (it < cnt) st_y(a, yidx + it * kYhStride, q, y);
         pb ^= 1;
@@ -1245,6 +1304,10 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
     // frequencies of the irregular problems (quirk Q1, util.h:190-199): f[N/2] = 0, f[N/2+1] = -(N/2-1) sr/N
     const double f_qx = (double)(kN / 2 - 1) * a.cfg.sample_rate / (double)kN;
     const bool band_hits_nyquist = (0.0 >= a.cfg.freq_min && 0.0 <= a.cfg.freq_max) || (f_qx >= a.cfg.freq_min && f_qx <= a.cfg.freq_max);
+    // lcmv with up to 8 microphones rides mvdr_fast_kernel while its columns fit the register file beside R and its working copy:
+    // any K <= 3 up to 6 microphones, K <= 2 at 7-8 (BF_LCMV_FAST=0: the lanes kernel, for A/B runs)
+    static const bool lcmv_fast_on = !(getenv("BF_LCMV_FAST") && atoi(getenv("BF_LCMV_FAST")) == 0);
+    const bool lcmv_fast = !no_fast && !band_hits_nyquist && a.cfg.algo == BF_LCMV && lcmv_fast_on && M <= 8 && a.kp1 <= 4;
 #define BF_LAUNCH_ML(MP_, KM_)                                                                                   \
     hipLaunchKernelGGL((mvdr_lcmv_kernel<MP_, KM_>), dim3(tps * a.n_streams, (kNQ + (256 / MP_) - 1) / (256 / MP_)), \
                        dim3(256), 0, s, a, tile, tps)
@@ -1304,7 +1367,7 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
     // lanes kernel: mvdr with 9..16 microphones (12.7 vs 26 ms per 32 768 frames at 16) and lcmv with up to 8
     // (9.4 vs 15.4 ms per 65 536 frames).  lcmv with 9..16 microphones keeps the row-per-lane kernel: 40 complex of
     // working copy + 5 right-hand sides x 4 rows do not fit 512 registers (736 B of scratch, 5x slower).
-    if (!no_fast && ((a.cfg.algo == BF_MVDR && M > 8) || (a.cfg.algo == BF_LCMV && M <= 8))) {
+    if (!no_fast && ((a.cfg.algo == BF_MVDR && M > 8) || (a.cfg.algo == BF_LCMV && M <= 8 && !lcmv_fast))) {
         int lt = 32;
         if (a.n_frames < lt) lt = (int)a.n_frames;
         const int ltps = (int)((a.n_frames + lt - 1) / lt);
@@ -1320,7 +1383,7 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
         }
         return hipGetLastError();
     }
-    if (a.cfg.algo == BF_MVDR && M <= 8 && !no_fast && !band_hits_nyquist) {
+    if ((a.cfg.algo == BF_MVDR || lcmv_fast) && M <= 8 && !no_fast && !band_hits_nyquist) {
         // the problems that need a solve (FastPlan): 0, the in-band run inside 1 .. N/2-1, and N/2 / N/2+1 when in band
         const std::vector<double> fr = frequency_vector(kN, a.cfg.sample_rate);  // the table the other kernels read (a.freqs)
         auto inb = [&](int q) {
@@ -1355,14 +1418,22 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
         if (!a.yh32)  // f64x2 rows (spectrum dump / fp64 backward transform): the rows nobody solves read as zero (mvdr.cpp:103)
             (void)hipMemsetAsync(a.Yh, 0, (size_t)a.n_streams * a.n_frames * kYhStride * sizeof(f64x2), s);
         const dim3 grid((unsigned)((long)fp.waves_per_stream * a.n_streams));
-        if (M <= 2)
-            hipLaunchKernelGGL((mvdr_fast_kernel<2>), grid, dim3(64), 0, s, a, fp);
-        else if (M <= 4)
-            hipLaunchKernelGGL((mvdr_fast_kernel<4>), grid, dim3(64), 0, s, a, fp);
-        else if (M <= 6)
-            hipLaunchKernelGGL((mvdr_fast_kernel<6>), grid, dim3(64), 0, s, a, fp);
-        else
-            hipLaunchKernelGGL((mvdr_fast_kernel<8>), grid, dim3(64), 0, s, a, fp);
+#define BF_FAST_GO(MP_, KC_) hipLaunchKernelGGL((mvdr_fast_kernel<MP_, KC_>), grid, dim3(64), 0, s, a, fp)
+        if (!lcmv_fast || a.kp1 <= 1) {  // lcmv without interferers = mvdr except problem 0
+            if (M <= 2) BF_FAST_GO(2, 1);
+            else if (M <= 4) BF_FAST_GO(4, 1);
+            else if (M <= 6) BF_FAST_GO(6, 1);
+            else BF_FAST_GO(8, 1);
+        } else if (M <= 2) {
+            BF_FAST_GO(2, 2);
+        } else if (M <= 4) {
+            if (a.kp1 <= 2) BF_FAST_GO(4, 2); else BF_FAST_GO(4, 4);
+        } else if (M <= 6) {
+            if (a.kp1 <= 2) BF_FAST_GO(6, 2); else BF_FAST_GO(6, 4);
+        } else {
+            if (a.kp1 <= 2) BF_FAST_GO(8, 2); else if (a.kp1 == 3) BF_FAST_GO(8, 3); else BF_FAST_GO(8, 4);
+        }
+#undef BF_FAST_GO
         return hipGetLastError();
     }
     if (M <= 4) {

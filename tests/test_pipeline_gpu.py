@@ -93,6 +93,26 @@ def test_mvdr_lcmv_match_oracle(algo, M, interf, F):
     assert rel_l2(y2[ok], y_ref[ok]) < TOL_TIME
 
 
+@pytest.mark.parametrize("M,K", [(2, 0), (2, 1), (3, 1), (3, 2), (4, 1), (4, 2), (5, 2), (5, 3), (6, 1), (6, 3), (7, 2), (7, 3), (8, 1), (8, 3)])
+def test_lcmv_up_to_8_microphones_every_column_count(M, K):
+    """lcmv with <= 8 microphones rides mvdr_fast_kernel<MP, KC>: every (padded microphone count, compiled column count) pair,
+    interferer counts below the compiled column count (identity padding of G), against the oracle -- spectrum and time signal."""
+    import oracle
+    interf = (-60.0, 90.0, 150.0)[:K]
+    p = make_params("lcmv", n_mics=M, interf=interf, theta=-35.0)
+    F = 18 + M
+    x = make_scene(M, F, seed=640 + 8 * M + K)
+    y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
+    y, Y = run_gpu(p, x)
+    check(y, Y, y_ref, Y_ref)
+    from beamform_amd.capi import Beamformer
+    bf = Beamformer(p)
+    y2 = np.concatenate([bf.process(np.ascontiguousarray(x[:, a * 512:b * 512])) for a, b in ((0, 5), (5, 6), (6, F))])  # yh32 rows, batch cuts
+    ok = np.isfinite(y_ref)
+    assert (np.isfinite(y2) == ok).all()
+    assert rel_l2(y2[ok], y_ref[ok]) < TOL_TIME
+
+
 def test_mvdr_history_carries_across_batches():
     """Covariance history (previous P frames), ring hop and OLA tail survive a batch boundary."""
     import oracle
@@ -128,7 +148,7 @@ def windows_vs_oracle(p, x, y, n_windows=6, warm=14, span=6, seed=0):
     return worst
 
 
-@pytest.mark.parametrize("algo,M,interf,F", [("mvdr", 8, (), 65536), ("lcmv", 16, (-60.0, 90.0, 150.0), 32768)])
+@pytest.mark.parametrize("algo,M,interf,F", [("mvdr", 8, (), 65536), ("lcmv", 16, (-60.0, 90.0, 150.0), 32768), ("lcmv", 8, (-60.0, 90.0), 32768)])
 def test_mvdr_lcmv_full_size_windows(algo, M, interf, F):
     """BASELINE configs 3 and 5 (per-GPU shard scaled to the test budget): random windows of the big
     batch against the oracle, plus chunk independence."""

@@ -52,6 +52,9 @@ CASES = [
     ({"BF_COV2D": "2"}, "mvdr", 16, (), 24, False),
     ({"BF_MVDR_GROUP": "1"}, "mvdr", 8, (), 30, True),                 # group-per-problem kernel over LDS
     ({"BF_MVDR_GROUP": "1"}, "lcmv", 8, (-60.0, 90.0), 30, False),
+    ({"BF_LCMV_FAST": "0"}, "lcmv", 8, (-60.0, 90.0), 30, True),       # lanes kernel (lcmv <= 8 microphones before mvdr_fast_kernel<MP, KC>)
+    ({"BF_LCMV_FAST": "0"}, "lcmv", 3, (90.0,), 24, False),
+    ({"BF_MVDR_TILE": "7"}, "lcmv", 8, (-60.0, 90.0), 40, True),       # mvdr_fast_kernel<8, 3>: lanes straddle tiles, short last tile
     ({"BF_MVDR_TILE": "7"}, "mvdr", 8, (), 40, False),                 # mvdr_fast_kernel: lanes straddle tiles, short last tile
     ({"BF_DAS_VARIANT": "0"}, "das", 8, (), 37, True),                 # round-1 transposes, run-time pair loop
     ({"BF_DAS_VARIANT": "1"}, "das", 8, (), 37, True),                 # ds_write_addtid transposes, run-time pair loop

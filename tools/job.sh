@@ -1,8 +1,5 @@
 cd /root/repo
 export TMPDIR=/tmp
-mkdir -p gpurun_out
-tag=r03_d
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_trace_bench_ne -- python bench.py --no-cpu --no-extra > gpurun_out/${tag}_bench_das8_noextra_profiled.json 2>> gpurun_out/${tag}_bench.err
-for f in $(find gpurun_out/${tag}_trace_bench_ne -name "*kernel_stats*"); do cp $f gpurun_out/${tag}_bench_noextra_kernel_stats.csv; done
-head -3 gpurun_out/${tag}_bench_noextra_kernel_stats.csv
-cat gpurun_out/${tag}_bench_das8_noextra_profiled.json | cut -c1-600
+python -m pytest tests/test_pipeline_gpu.py tests/test_variants_gpu.py tests/test_hops_gpu.py -x -q -m gpu 2>&1 | tail -4
+echo "== fast"; python tools/time_lcmv.py 2>&1 | grep -v amdgpu.ids
+for sd in 21 22; do python tools/fuzz_parity.py $sd 150 2>&1 | tail -3; done
