@@ -414,6 +414,8 @@ def main():
                                                   note="the same noise 8x louder: every bin passes mag_threshold and runs the 8 atan2 + 28 wrapped differences")),
             ("lcmv16", lambda: node_line("lcmv", 16, 32768, 1, (-60.0, 90.0, 150.0), iters=3,
                                          note="BASELINE config 5, one GPU's shard of the 262144-frame stream; " + noise)),
+            ("lcmv8", lambda: node_line("lcmv", M, F, 1, (-60.0, 90.0), xin=x, with_traffic=False,
+                                        note="lcmv on the headline array (8 microphones, 2 interferers): mvdr_fast_kernel<8, 3>; " + noise)),
         ]
         def scene_input(M_, F_):
             # SURVEY 8(d)'s seeded scene (directional band-limited target at 20 deg + 3 interferers + sensor noise, last 10 % silent),
