@@ -155,7 +155,11 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     // there are about as many runs as CUs
     const bool gen = fused_das_gen(h);
     // (periods 256 / 1024: several 256-thread blocks share a CU -- 13 / 52 KB of LDS each -- and a run costs one recomputed frame)
-    long runs = (gen ? (long)h->n_cus * (h->N == 512 ? 8 : 3) : (long)h->n_cus) / S;
+    // several look directions, planar input, <= 8 microphones, no dump: one set of forward transforms per frame serves up to 16
+    // directions (das_fused_dirs_kernel); BF_DAS_SHARED_DIRS = the smallest direction count that takes it (0: never)
+    static const int shared_min = getenv("BF_DAS_SHARED_DIRS") ? atoi(getenv("BF_DAS_SHARED_DIRS")) : 6;
+    const bool shared = !gen && !h->use_w64 && layout == BF_PLANAR && h->M <= 8 && !spectrum_dev && shared_min > 0 && h->n_dirs >= shared_min;
+    long runs = (gen ? (long)h->n_cus * (h->N == 512 ? 8 : 3) : (long)h->n_cus) / (shared ? h->n_streams : S);
     if (runs < 1) runs = 1;
     long fpc = (F + runs - 1) / runs;
     if (!gen) fpc = ((fpc + 15) / 16) * 16;
@@ -205,7 +209,12 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
         h->kernel_events->push_back(std::make_pair(k0, k1));
         BF_HIP(h, hipEventRecord(k0, s));
     }
-    BF_HIP(h, gen ? launch_das_fused_gen(a, h->N, s) : h->use_w64 ? launch_das_fused_w64(a, s) : launch_das_fused(a, s));
+    if (shared) {
+        for (int d0 = 0; d0 < h->n_dirs; d0 += 16)
+            BF_HIP(h, launch_das_fused_dirs(a, d0, h->n_dirs - d0 < 16 ? h->n_dirs - d0 : 16, s));
+    } else {
+        BF_HIP(h, gen ? launch_das_fused_gen(a, h->N, s) : h->use_w64 ? launch_das_fused_w64(a, s) : launch_das_fused(a, s));
+    }
     if (k1) BF_HIP(h, hipEventRecord(k1, s));
     h->tail_cur ^= 1;
 

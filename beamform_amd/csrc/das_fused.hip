@@ -958,6 +958,239 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_il8_kernel(DasFusedArgs a
     }
 }
 
+// ---- several look directions from ONE set of forward transforms -----------------------------------------------------------
+// The reference transforms a frame once and applies its weights (das.cpp:51-63); a controller that scans D candidate
+// directions (scripts/energy2theta.py:62-101) runs D nodes on the same input.  das_fused_kernel gives every direction its own
+// block, which redoes the forward transforms: D directions cost D launches' worth.  Here a block walks its run two frames at
+// a time:
+//   forward phase   wavefronts 0-3 = eight half-wavefronts = (frame A | B) x (pair 0..3): window, packed forward transform,
+//                   spectrum parked in LDS -- [frame][pair][position pair][lane] float4, 64 KiB;
+//   direction phase wavefront w takes directions 2w and 2w+1 one after the other, its half h the frame A + h: weight-and-sum
+//                   out of the parked spectra (gains straight from global memory: both halves read the SAME direction's table,
+//                   one 256-byte segment per wave-instruction), backward transform, window, overlap-add.
+// Overlap-add partner: frame A's second half goes to half 1 by v_permlane32_swap in the same step; frame B's second half goes
+// the other way and waits in half 0's registers for the next round (16 registers per direction) -- no ring, no flags.  Run
+// boundaries as in das_fused_kernel (two float atomic adds into a pre-zeroed hop).  Same transforms, same separately rounded
+// overlap-add, the weight-and-sum accumulates pairs in the same order: the output equals das_fused_kernel<0, NPL, true, UNR>'s
+// to the last bits (hipcc fuses the analysis window's products into the first butterflies differently in the two kernels)
+// and does not depend on how a stream is cut into batches and runs.
+__device__ __forceinline__ float halves_exchange(float v, int half) {
+    float lo = v, hi = v;  // swap: lanes 32..63 of lo <-> lanes 0..31 of hi  ->  lo = (v.lo, v.lo), hi = (v.hi, v.hi)
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+    return half ? lo : hi;
+}
+
+constexpr int kDirsZ = 2 * 4 * 16 * 32 * 4;  // floats
+__global__ __launch_bounds__(kBlock, 2) void das_fused_dirs_kernel(DasFusedArgs a, int dir0, int n_here) {
+    __shared__ __attribute__((aligned(16))) float lds[kLdsTw + 8 * kWPlane + kLdsWin + kDirsZ];
+    float *s_win = lds + kLdsTw + 8 * kWPlane;
+    float4 *s_z = reinterpret_cast<float4 *>(lds + kLdsTw + 8 * kWPlane + kLdsWin);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 31;
+    const int hw = tid >> 5, half = hw & 1;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *wplane = lds + kLdsTw + wv * kWPlane;
+    const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float *)wplane);
+    const float *wrowp = wplane + lane * kWRow + 32 * half;
+    const int M = a.n_mics, np = (M + 1) >> 1;
+
+    const int in_stream = blockIdx.x / a.chunks_per_stream;
+    const long c_in_s = blockIdx.x - (long)in_stream * a.chunks_per_stream;
+    {
+        const f32x2 *twc = a.twiddle;
+        f32x2 *ltw = reinterpret_cast<f32x2 *>(lds);
+        for (int i = tid; i < kLdsTw / 2; i += kBlock) {  // paired tables, as the unrolled planar kernel
+            const int k1 = i >> 5, l = i & 31;
+            ltw[((k1 & 15) * 32 + l) * 2 + (k1 >> 4)] = twc[i];
+        }
+        for (int i = tid; i < kNfft; i += kBlock) s_win[(i & 31) * kPS + (i >> 5)] = a.window[i];
+    }
+    const long T0 = c_in_s * a.frames_per_chunk;
+    long T1 = T0 + a.frames_per_chunk;
+    if (T1 > a.n_frames) T1 = a.n_frames;
+    __syncthreads();
+    const float4 *wrow = reinterpret_cast<const float4 *>(s_win + lane * kPS);
+    const float4 *tw2 = reinterpret_cast<const float4 *>(lds);
+    const float *xs = a.x + (long)in_stream * a.stream_stride_x;
+    const float *hs = a.hist_in + (long)in_stream * M * kHop;
+
+    float re[32], im[32];
+    float keep[2][16];  // half 0: the second half of the frame before this round's frame A, per direction of this wavefront
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd) {
+        const int dl = dd * 8 + (7 - wv);
+        const long so = (long)in_stream * a.n_dirs + dir0 + (dl < n_here ? dl : 0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) keep[dd][q] = (T0 == 0) ? a.tail_in[so * kHop + 32 * brev5(2 * q) + lane] : 0.f;
+    }
+
+    // raw samples of this half-wavefront's (frame, pair) of the round that starts at frame tA -> (re, im), natural order
+    auto issue_inputs = [&](long tA) {
+        const int p = hw & 3;
+        const int pc = p < np ? p : np - 1;  // a pair that does not exist redoes the last one (no divergence around the transposes)
+        long tc = tA + (hw >> 2);
+        if (tc >= T1) tc = T1 - 1;
+        const int ma = 2 * pc, mb = 2 * pc + 1;
+        const bool b_ok = mb < M;
+        const float *a1 = (tc >= 1 ? xs + (long)ma * a.mic_stride + (tc - 1) * kHop : hs + ma * kHop) + lane;
+        const float *b1 = (!b_ok ? a.zeros : tc >= 1 ? xs + (long)mb * a.mic_stride + (tc - 1) * kHop : hs + mb * kHop) + lane;
+        const float *a2 = xs + (long)ma * a.mic_stride + tc * kHop + lane;
+        const float *b2 = (!b_ok ? a.zeros : xs + (long)mb * a.mic_stride + tc * kHop) + lane;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            re[j] = a1[32 * j];
+            im[j] = b1[32 * j];
+            re[j + 16] = a2[32 * j];
+            im[j + 16] = b2[32 * j];
+        }
+    };
+    const int n_rounds = (int)((T1 - T0 + 1) / 2);
+    if (wv < 4) issue_inputs(T0);
+    for (int r = 0; r < n_rounds; ++r) {
+        const long tA = T0 + 2L * r;
+        if (wv < 4) {  // ---- forward phase: (frame, pair) = (hw >> 2, hw & 3); the samples were requested at the end of the previous round
+            const int p = hw & 3;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float4 hv = wrow[g];
+                re[4 * g + 0] *= hv.x; im[4 * g + 0] *= hv.x;
+                re[4 * g + 1] *= hv.y; im[4 * g + 1] *= hv.y;
+                re[4 * g + 2] *= hv.z; im[4 * g + 2] *= hv.z;
+                re[4 * g + 3] *= hv.w; im[4 * g + 3] *= hv.w;
+            }
+#ifdef BF_DAS_STAMPS
+            unsigned long long st_acc[16], st_prev = 0;
+#endif
+            wt_fft_fwd_p2(re, im, lane, tw2, wbase, wrowp BF_STAMP_ARGS);
+            if (p < np) {
+                float4 *zp = s_z + ((hw >> 2) * 4 + p) * 16 * 32 + lane;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) zp[m * 32] = float4{re[2 * m], im[2 * m], re[2 * m + 1], im[2 * m + 1]};
+            }
+        }
+        // ---- direction phase: wavefront w takes directions 7 - w and 15 - w (the wavefronts without forward work get the second
+        // direction first: 9-12 directions balance forward + one against two).  Gains come straight from global memory, eight
+        // position pairs (16 entries, 32 registers) at a time, the next group requested before the current one is used; a
+        // direction's first group is requested ahead of the barrier / of the previous direction's backward transform.  The table
+        // offset is made opaque per (round, direction): otherwise LICM hoists the loop-invariant per-position addresses out of
+        // the round loop as 64-bit VGPR pairs, they spill, and every gain load waits on a scratch reload (5.8 ms per 16
+        // directions instead of 3.1)
+        f32x2 ga[16], gb[16];
+        auto gptr = [&](int dd) -> const f32x2 * {
+            long goff = (long)(dir0 + dd * 8 + (7 - wv)) * np * 1024;
+            asm volatile("" : "+s"(goff));
+            return a.gains + goff + lane;
+        };
+        auto ldg = [&](const f32x2 *gd, f32x2(&g)[16], int p, int m0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                g[2 * k] = gd[(p * 32 + 2 * (m0 + k)) * 32];
+                g[2 * k + 1] = gd[(p * 32 + 2 * (m0 + k) + 1) * 32];
+            }
+        };
+        if (7 - wv < n_here) ldg(gptr(0), ga, 0, 0);
+        __syncthreads();
+        const long t = tA + half;
+        const bool valid = t < T1;
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd) {
+            const int dl = dd * 8 + (7 - wv);
+            if (dl < n_here) {  // wave-uniform
+                const int d = dir0 + dl;
+                const f32x2 *gd = gptr(dd);
+                const float4 *zf = s_z + half * 4 * 16 * 32 + lane;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) re[i] = im[i] = 0.f;  // fma(g, z, 0) on the first pair, as das_fused_kernel
+                for (int p = 0; p < np; ++p) {
+                    ldg(gd, gb, p, 8);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float4 z = zf[(p * 16 + k) * 32];
+                        const f32x2 g0 = ga[2 * k], g1 = ga[2 * k + 1];
+                        re[2 * k] = bf_fma(-g0.y, z.y, bf_fma(g0.x, z.x, re[2 * k]));
+                        im[2 * k] = bf_fma(g0.y, z.x, bf_fma(g0.x, z.y, im[2 * k]));
+                        re[2 * k + 1] = bf_fma(-g1.y, z.w, bf_fma(g1.x, z.z, re[2 * k + 1]));
+                        im[2 * k + 1] = bf_fma(g1.y, z.z, bf_fma(g1.x, z.w, im[2 * k + 1]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (p + 1 < np) ldg(gd, ga, p + 1, 0);
+                    else if (dd == 0 && 8 + (7 - wv) < n_here) ldg(gptr(1), ga, 0, 0);  // the next direction's first group rides out the backward transform
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float4 z = zf[(p * 16 + 8 + k) * 32];
+                        const f32x2 g0 = gb[2 * k], g1 = gb[2 * k + 1];
+                        re[16 + 2 * k] = bf_fma(-g0.y, z.y, bf_fma(g0.x, z.x, re[16 + 2 * k]));
+                        im[16 + 2 * k] = bf_fma(g0.y, z.x, bf_fma(g0.x, z.y, im[16 + 2 * k]));
+                        re[16 + 2 * k + 1] = bf_fma(-g1.y, z.w, bf_fma(g1.x, z.z, re[16 + 2 * k + 1]));
+                        im[16 + 2 * k + 1] = bf_fma(g1.y, z.z, bf_fma(g1.x, z.w, im[16 + 2 * k + 1]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                {
+#ifdef BF_DAS_STAMPS
+                    unsigned long long st_acc[16], st_prev = 0;
+#endif
+                    wt_fft_inv_p2(re, im, lane, tw2, wbase, wrowp BF_STAMP_ARGS);
+                }
+                // position i holds sample n = 32*brev5(i) + lane; even i -> first half of the frame, odd i -> second half
+                float h[32];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const float4 hv = wrow[g];
+                    h[4 * g + 0] = hv.x; h[4 * g + 1] = hv.y; h[4 * g + 2] = hv.z; h[4 * g + 3] = hv.w;
+                }
+                float first[16], second[16], partner[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    first[q] = re[2 * q] * h[brev5(2 * q)];
+                    second[q] = re[2 * q + 1] * h[brev5(2 * q + 1)];
+                    partner[q] = halves_exchange(second[q], half);
+                }
+                float *ys = a.y + ((long)in_stream * a.n_dirs + d) * a.n_frames * kHop;
+                if (valid) {
+                    float *yo = ys + t * kHop + lane;
+                    if (t == T0 && T0 > 0) {  // first hop of the run: the previous run adds its half separately (both into a zeroed hop)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) atomicAdd(yo + 32 * brev5(2 * q), first[q]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+#pragma clang fp contract(off)
+                            yo[32 * brev5(2 * q)] = (half ? partner[q] : keep[dd][q]) + first[q];
+                        }
+                    }
+                    if (t == T1 - 1) {
+                        if (T1 < a.n_frames) {  // last frame of the run: its second half belongs to the next run's first hop
+                            float *yn = ys + T1 * kHop + lane;
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) atomicAdd(yn + 32 * brev5(2 * q), second[q]);
+                        } else {  // end of the batch: carried state for the next call (OLA tail and the last input hop)
+                            float *to = a.tail_out + ((long)in_stream * a.n_dirs + d) * kHop + lane;
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) to[32 * brev5(2 * q)] = second[q];
+                            if (dl == 0) {
+                                float *ho = a.hist_out + (long)in_stream * M * kHop;
+                                for (int m = 0; m < M; ++m)
+                                    for (int j = 0; j < 16; ++j)
+                                        ho[m * kHop + 32 * j + lane] = xs[(long)m * a.mic_stride + t * kHop + 32 * j + lane];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) keep[dd][q] = partner[q];  // half 0: frame B's second half, for the next round
+            }
+        }
+        // the next round's samples: in flight across the barrier (the wavefronts with one direction less wait there anyway)
+        if (wv < 4 && r + 1 < n_rounds) issue_inputs(tA + 2);
+        __syncthreads();  // the parked spectra are rewritten by the next round
+    }
+}
+
+
 __global__ void das_hermitian_dump_kernel(const f32x2 *s, f64x2 *out, long total) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -1074,6 +1307,15 @@ hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t stream) {
         }
     }
 #endif
+    return hipGetLastError();
+}
+
+// Look directions dir0 .. dir0 + n_here - 1 (n_here <= 16) of every input stream from one set of forward transforms; planar
+// input, <= 8 microphones, no spectrum dump.  chunks_per_stream counts runs per INPUT stream here.
+hipError_t launch_das_fused_dirs(const DasFusedArgs &a, int dir0, int n_here, hipStream_t stream) {
+    if (a.layout != 0 || a.n_mics > 8 || n_here < 1 || n_here > 16 || a.sdump != nullptr) return hipErrorInvalidValue;
+    const unsigned blocks = (unsigned)((long)a.chunks_per_stream * (a.n_streams / a.n_dirs));
+    hipLaunchKernelGGL(das_fused_dirs_kernel, dim3(blocks), dim3(kBlock), 0, stream, a, dir0, n_here);
     return hipGetLastError();
 }
 
