@@ -454,6 +454,26 @@ def main():
                                 "LDS-staged radix-2 transforms (das_fused_gen.hip; not the register-resident machinery of the 512-frame period)",
                     "ms_per_step": ms, "frames_per_s": F_ / (ms * 1e-3), "samples_per_s": F_ * hop_ / (ms * 1e-3)}
 
+        def dirs_line(D_):
+            # D_ look directions of the headline batch in one call (a controller scanning candidate angles, scripts/energy2theta.py:62-101):
+            # one set of forward transforms per frame serves all of them (das_fused_dirs_kernel)
+            pm = make_params("das", n_mics=M)
+            bm = Beamformer(pm, device=local_rank, n_dirs=D_)
+            bm.set_thetas([-180.0 + 360.0 * d / D_ for d in range(D_)])
+            yo = torch.empty((D_, F * HOP), device=dev, dtype=torch.float32)
+            ts = time.perf_counter()
+            n_settle = 0
+            while n_settle < 2 or (time.perf_counter() - ts) < 0.12:
+                bm.process_device(x.data_ptr(), F, yo.data_ptr(), 0, sptr)
+                torch.cuda.synchronize(dev)
+                n_settle += 1
+            ms, _ = bm.time_device(x.data_ptr(), F, yo.data_ptr(), 5, sptr)
+            bm.close()
+            return {"workload": f"das {M}-mic 1024-pt, {F} frames, {D_} look directions from one set of forward transforms (das_fused_dirs_kernel)",
+                    "ms_per_step": ms, "frames_per_s": F / (ms * 1e-3), "beam_frames_per_s": F * D_ / (ms * 1e-3),
+                    "ratio_to_one_direction": ms / (dt / args.steps * 1e3)}
+
+        jobs.append(("das_dirs16", lambda: dirs_line(16)))
         jobs.append(("das_period256", lambda: other_period_line(256)))
         jobs.append(("das_period1024", lambda: other_period_line(1024)))
 

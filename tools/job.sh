@@ -1,3 +1,5 @@
 cd /root/repo
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_dirs_shared_gpu.py  -q -m gpu 2>&1 | grep -v amdgpu | tail -5
+python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+python -c "import __graft_entry__ as g; g.smoke()"
+( time python bench.py --gpus 1 --steps 20 --warmup 5 ) > gpurun_out/bench_now.json 2> gpurun_out/bench_now.err; tail -4 gpurun_out/bench_now.err
