@@ -3,7 +3,7 @@
 //
 // Same formulation as das_fused.hip -- per frame ceil(M/2) packed forward transforms, S += D_p Z_p with the pair gains of
 // geometry.hpp (natural bin order here), one backward transform, synthesis window, float overlap-add (das.cpp:47-70,
-// util.h:217-253,301-302) -- in ONE launch, spectra never leaving the CU.  The transforms are LDS-staged radix-2 Stockham
+// util.h:217-253,301-302) -- in ONE launch, spectra never leaving the CU.  The transforms are LDS-staged radix-4 Stockham
 // passes of a 256-thread block (one frame at a time per block): a plain design, 3-4 x the three-kernel fp64 chain these
 // periods ran before, not the register-resident machinery of the 512-frame period.  A block owns a run of consecutive frames
 // and keeps the overlap-add tail in LDS; a run that does not start the stream recomputes its previous frame for that tail.
@@ -17,22 +17,53 @@ namespace {
 
 constexpr int kGB = 256;
 
-// autosort radix-2 passes in LDS: data starts in b0, result ends in the returned buffer.  tw[m] = exp(-2 pi i m / N), m < N/2.
+// autosort (Stockham) passes in LDS: data starts in b0, result ends in the returned buffer.  tw[m] = exp(-2 pi i m / N), m < N/2.
+// Radix-4 passes (N = 512: four + one radix-2, N = 2048: five + one radix-2; earlier: nine / eleven radix-2 passes:
+// half the barriers, half the LDS traffic), twiddles W^(q k N / (4 ns)) from the half-length table by W^(m + N/2) = -W^m.
 template <int N, int DIR>
 __device__ __forceinline__ float2 *stockham32(float2 *b0, float2 *b1, const float2 *tw, int tid) {
     float2 *in = b0, *out = b1;
+    auto twd = [&](int m) -> float2 {  // W^m (forward) or its conjugate (backward), m < N
+        const float2 w = tw[m & (N / 2 - 1)];
+        const float sg = (m & (N / 2)) ? -1.f : 1.f;
+        return float2{sg * w.x, DIR < 0 ? sg * w.y : -sg * w.y};
+    };
+    auto cmul = [](float2 v, float2 w) { return float2{v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x}; };
+    int ns = 1;
 #pragma unroll 1
-    for (int ns = 1; ns < N; ns <<= 1) {
+    for (; ns * 4 <= N; ns <<= 2) {
+#pragma unroll
+        for (int j = tid; j < N / 4; j += kGB) {
+            const int k = j & (ns - 1);
+            const int st = k * (N / (4 * ns));
+            const float2 a0 = in[j];
+            const float2 a1 = cmul(in[j + N / 4], twd(st));
+            const float2 a2 = cmul(in[j + N / 2], twd(2 * st));
+            const float2 a3 = cmul(in[j + 3 * N / 4], twd(3 * st));
+            const float2 s02 = float2{a0.x + a2.x, a0.y + a2.y}, d02 = float2{a0.x - a2.x, a0.y - a2.y};
+            const float2 s13 = float2{a1.x + a3.x, a1.y + a3.y}, d13 = float2{a1.x - a3.x, a1.y - a3.y};
+            // forward: -i d13 = (d13.y, -d13.x); backward: +i d13 = (-d13.y, d13.x)
+            const float2 r13 = DIR < 0 ? float2{d13.y, -d13.x} : float2{-d13.y, d13.x};
+            const int j0 = ((j - k) << 2) + k;
+            out[j0] = float2{s02.x + s13.x, s02.y + s13.y};
+            out[j0 + ns] = float2{d02.x + r13.x, d02.y + r13.y};
+            out[j0 + 2 * ns] = float2{s02.x - s13.x, s02.y - s13.y};
+            out[j0 + 3 * ns] = float2{d02.x - r13.x, d02.y - r13.y};
+        }
+        __syncthreads();
+        float2 *t = in;
+        in = out;
+        out = t;
+    }
+    if (ns < N) {  // one radix-2 pass left (N = 2 * 4^k)
 #pragma unroll
         for (int j = tid; j < N / 2; j += kGB) {
             const int k = j & (ns - 1);
-            const float2 w0 = tw[k * (N / (2 * ns))];
-            const float wx = w0.x, wy = DIR < 0 ? w0.y : -w0.y;
-            const float2 u = in[j], v = in[j + N / 2];
-            const float bx = v.x * wx - v.y * wy, by = v.x * wy + v.y * wx;
+            const float2 w = twd(k * (N / (2 * ns)));
+            const float2 u = in[j], b = cmul(in[j + N / 2], w);
             const int j0 = ((j - k) << 1) + k;
-            out[j0] = float2{u.x + bx, u.y + by};
-            out[j0 + ns] = float2{u.x - bx, u.y - by};
+            out[j0] = float2{u.x + b.x, u.y + b.y};
+            out[j0 + ns] = float2{u.x - b.x, u.y - b.y};
         }
         __syncthreads();
         float2 *t = in;

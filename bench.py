@@ -435,7 +435,7 @@ def main():
         ]
 
         def other_period_line(hop_, algo_="das"):
-            # JACK periods other than 512 frames (rosjack.cpp:131; fft_win = 2 * period): one fused fp32 kernel on LDS-staged radix-2
+            # JACK periods other than 512 frames (rosjack.cpp:131; fft_win = 2 * period): one fused fp32 kernel on LDS-staged radix-4
             # transforms (das_fused_gen.hip); same number of SAMPLES as the headline batch
             pm = make_params(algo_, n_mics=M, hop=hop_)
             F_ = F * HOP // hop_
@@ -451,7 +451,7 @@ def main():
             ms, _ = bm.time_device(xin.data_ptr(), F_, yo.data_ptr(), 5, sptr)
             bm.close()
             return {"workload": f"{algo_} {M}-mic, JACK period {hop_} (FFT {2 * hop_}), {F_} frames = the headline batch's samples; fused fp32 kernel on "
-                                "LDS-staged radix-2 transforms (das_fused_gen.hip; not the register-resident machinery of the 512-frame period)",
+                                "LDS-staged radix-4 transforms (das_fused_gen.hip; not the register-resident machinery of the 512-frame period)",
                     "ms_per_step": ms, "frames_per_s": F_ / (ms * 1e-3), "samples_per_s": F_ * hop_ / (ms * 1e-3)}
 
         def dirs_line(D_):

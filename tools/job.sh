@@ -1,5 +1,8 @@
 cd /root/repo
 export TMPDIR=/tmp
-python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-python -c "import __graft_entry__ as g; g.smoke()"
-( time python bench.py --gpus 1 --steps 20 --warmup 5 ) > gpurun_out/bench_now.json 2> gpurun_out/bench_now.err; tail -4 gpurun_out/bench_now.err
+timeout 900 python -m pytest tests/test_hops_gpu.py -q -m gpu 2>&1 | grep -v amdgpu | tail -4
+python bench.py --no-cpu --steps 5 --warmup 2 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+for k in ('das_period256','das_period1024'): print(k, d['extra'][k]['ms_per_step'])
+"
