@@ -244,7 +244,9 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
     // frame t+1 picks it up there.  With 16 frames in flight the reader of a slot is always its next writer, so the
     // only hazard is read-after-write: one flag per slot (= the frame whose tail it holds) replaces block barriers.
     float *s_tails = lds + kLdsFixed + NPL * 2048;
-    volatile int *s_flag = reinterpret_cast<volatile int *>(lds + kLdsFixed + NPL * 2048 + 17 * kHop);
+    // LDS address space spelled out: a volatile access through a generic pointer compiles to flat_load / flat_store, whose wait is
+    // vmcnt(0) -- it would drain the next frame's prefetch in front of every flag read
+    volatile __attribute__((address_space(3))) int *s_flag = (volatile __attribute__((address_space(3))) int *)(lds + kLdsFixed + NPL * 2048 + 17 * kHop);
 #ifdef BF_DAS_STAMPS
     const unsigned long long st_k0 = __builtin_readcyclecounter();
 #endif
@@ -581,7 +583,9 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_il_kernel(DasFusedArgs a)
     __shared__ __attribute__((aligned(16))) float lds[kLdsFixed + NPL * 2048 + 17 * kHop + 32];
     float *s_win = lds + kLdsTw + kHalves * kLdsPlane;
     float *s_tails = lds + kLdsFixed + NPL * 2048;
-    volatile int *s_flag = reinterpret_cast<volatile int *>(lds + kLdsFixed + NPL * 2048 + 17 * kHop);
+    // LDS address space spelled out: a volatile access through a generic pointer compiles to flat_load / flat_store, whose wait is
+    // vmcnt(0) -- it would drain the next frame's prefetch in front of every flag read
+    volatile __attribute__((address_space(3))) int *s_flag = (volatile __attribute__((address_space(3))) int *)(lds + kLdsFixed + NPL * 2048 + 17 * kHop);
     constexpr int M = 4 * NG, UNR = 2 * NG;
 
     const int tid = threadIdx.x;
@@ -784,7 +788,9 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_il8_kernel(DasFusedArgs a
     __shared__ __attribute__((aligned(16))) float lds[kLdsFixed + NPL * 2048 + (kIl8Waves + 1) * kHop + 32];
     float *s_win = lds + kLdsTw + kHalves * kLdsPlane;
     float *s_tails = lds + kLdsFixed + NPL * 2048;
-    volatile int *s_flag = reinterpret_cast<volatile int *>(lds + kLdsFixed + NPL * 2048 + (kIl8Waves + 1) * kHop);
+    // LDS address space spelled out: a volatile access through a generic pointer compiles to flat_load / flat_store, whose wait is
+    // vmcnt(0) -- it would drain the next frame's prefetch in front of every flag read
+    volatile __attribute__((address_space(3))) int *s_flag = (volatile __attribute__((address_space(3))) int *)(lds + kLdsFixed + NPL * 2048 + (kIl8Waves + 1) * kHop);
     constexpr int kSlots = kIl8Waves + 1;
 
     const int tid = threadIdx.x;

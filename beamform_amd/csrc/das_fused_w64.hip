@@ -136,7 +136,9 @@ __global__ __launch_bounds__(kBlock) void das_fused_w64_kernel(DasFusedArgs a) {
     const cx<float> *s_gain = reinterpret_cast<const cx<float> *>(lds + kLdsFixed);
     // 17-slot ring of frame tails with one flag per slot: see das_fused.hip
     float *s_tails = lds + kLdsFixed + NPL * 2048;
-    volatile int *s_flag = reinterpret_cast<volatile int *>(lds + kLdsFixed + NPL * 2048 + 17 * kHop);
+    // LDS address space spelled out: a volatile access through a generic pointer compiles to flat_load / flat_store, whose wait is
+    // vmcnt(0) -- it would drain the next frame's prefetch in front of every flag read
+    volatile __attribute__((address_space(3))) int *s_flag = (volatile __attribute__((address_space(3))) int *)(lds + kLdsFixed + NPL * 2048 + 17 * kHop);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;

@@ -1,8 +1,9 @@
 cd /root/repo
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_hops_gpu.py -q -m gpu 2>&1 | grep -v amdgpu | tail -4
-python bench.py --no-cpu --steps 5 --warmup 2 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-for k in ('das_period256','das_period1024'): print(k, d['extra'][k]['ms_per_step'])
-"
+for rep in 1 2 3; do
+echo -n "base "; BFCORE_LIB=/root/repo/abtmp/libbfcore_base.so python tools/run_das.py --algo das --iters 200 | tail -1
+echo -n "as3  "; python tools/run_das.py --algo das --iters 200 | tail -1
+done
+echo -n "base il "; BFCORE_LIB=/root/repo/abtmp/libbfcore_base.so python tools/run_das.py --algo das --layout interleaved --iters 100 | tail -1
+echo -n "as3  il "; python tools/run_das.py --algo das --layout interleaved --iters 100 | tail -1
+python -m pytest tests/test_das_gpu.py tests/test_variants_gpu.py -x -q -m gpu 2>&1 | tail -2
