@@ -51,7 +51,7 @@ def _single(p, x, theta):
     return Beamformer(dict(p, theta=theta)).process(x)
 
 
-@pytest.mark.parametrize("M,F,D", [(8, 200, 16), (8, 37, 7), (3, 50, 6), (5, 66, 9), (8, 48, 20), (4, 1, 8)])
+@pytest.mark.parametrize("M,F,D", [(8, 200, 16), (8, 37, 7), (3, 50, 6), (5, 66, 9), (8, 48, 20), (4, 1, 8), (1, 20, 6), (2, 33, 16), (7, 19, 64)])
 def test_shared_forward_transforms_equal_the_single_direction_node(M, F, D):
     p = make_params("das", n_mics=M, theta=0.0)
     x = make_scene(M, F, seed=1300 + M + D)
