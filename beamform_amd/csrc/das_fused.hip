@@ -783,6 +783,10 @@ __device__ __forceinline__ void halves_sum(float (&v)[32]) {
 }
 
 constexpr int kIl8Waves = kBlock / 64;  // frames in flight per block
+#ifndef BF_IL8_SPLIT
+#define BF_IL8_SPLIT 1
+#endif
+constexpr bool kIl8Split = BF_IL8_SPLIT != 0;
 __global__ __launch_bounds__(kBlock, 2) void das_fused_il8_kernel(DasFusedArgs a) {
     constexpr int NPL = 4, M = 8;
     __shared__ __attribute__((aligned(16))) float lds[kLdsFixed + NPL * 2048 + (kIl8Waves + 1) * kHop + 32];
@@ -842,6 +846,27 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_il8_kernel(DasFusedArgs a
     auto load_frame = [&](long tc) {
         const float *s1 = (tc >= 1 ? xs + (tc - 1) * (long)kHop * M : hs);  // wave-uniform bases: SGPR base + VGPR offset addressing
         const float *s2 = xs + tc * (long)kHop * M;
+        if (kIl8Split) {
+            // the half's first pair in the first 32 requests, its second pair behind them: the first transform starts when half of the
+            // frame has arrived (vmcnt(32)) and the other half gets that transform's time on top
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float2 u = *reinterpret_cast<const float2 *>(s1 + 32 * j * M + voff);
+                const float2 w = *reinterpret_cast<const float2 *>(s2 + 32 * j * M + voff);
+                ar[j] = u.x; ai[j] = u.y;
+                ar[j + 16] = w.x; ai[j + 16] = w.y;
+            }
+            unsigned voff2 = voff + 2;
+            asm volatile("" : "+v"(voff2));  // opaque: the load vectorizer would fuse the two halves of a sample back into one 16-byte load
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float2 u = *reinterpret_cast<const float2 *>(s1 + 32 * j * M + voff2);
+                const float2 w = *reinterpret_cast<const float2 *>(s2 + 32 * j * M + voff2);
+                br[j] = u.x; bi[j] = u.y;
+                br[j + 16] = w.x; bi[j + 16] = w.y;
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const float4 u = *reinterpret_cast<const float4 *>(s1 + 32 * j * M + voff);
