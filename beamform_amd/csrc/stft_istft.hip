@@ -717,6 +717,35 @@ __global__ void smooth_kernel(const float *yraw, float *y, const double *state, 
     }
     y[idx] = (float)(acc / (double)sz);
 }
+// the same for windows of up to 8 samples (the launch files use 3), four consecutive outputs per thread: one 16-byte load brings the
+// four newest samples, the SZ - 1 older ones come singly; every output is still the double sum of its window, oldest first
+template <int SZ>
+__global__ __launch_bounds__(256) void smooth4_kernel(const float *yraw, float *y, const double *state, long n, int n_streams) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;  // quad index; n is a multiple of 4 (whole hops)
+    const long nq = n >> 2;
+    if (q >= nq * n_streams) return;
+    const int s = (int)(q / nq);
+    const long i0 = (q - (long)s * nq) << 2;
+    const float *yr = yraw + (long)s * n;
+    const double *st = state + (long)s * 64;
+    double w[SZ + 3];
+#pragma unroll
+    for (int m = 0; m < SZ - 1; ++m) {
+        const long src = i0 - (SZ - 1) + m;
+        w[m] = src >= 0 ? (double)yr[src] : st[64 + src];
+    }
+    const float4 cur = *reinterpret_cast<const float4 *>(yr + i0);
+    w[SZ - 1] = (double)cur.x; w[SZ] = (double)cur.y; w[SZ + 1] = (double)cur.z; w[SZ + 2] = (double)cur.w;
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < SZ; ++m) acc += w[j + m];
+        o[j] = (float)(acc / (double)SZ);
+    }
+    *reinterpret_cast<float4 *>(y + (long)s * n + i0) = float4{o[0], o[1], o[2], o[3]};
+}
 __global__ void smooth_state_kernel(const float *yraw, double *state, long n, int n_streams) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 64 * n_streams) return;
@@ -830,8 +859,21 @@ hipError_t launch_smooth(const float *yraw, float *y, double *state, long n_fram
                          hipStream_t s) {
     const long n = n_frames * kHop;
     const long total = n * n_streams;
-    hipLaunchKernelGGL(smooth_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, yraw, y, state, n, n_streams,
-                       smooth_size);
+    const bool al = ((reinterpret_cast<size_t>(yraw) | reinterpret_cast<size_t>(y)) & 15) == 0 && (n & 3) == 0;
+    const dim3 g4((unsigned)((total / 4 + 255) / 256));
+#define BF_SM4(SZ_) hipLaunchKernelGGL((smooth4_kernel<SZ_>), g4, dim3(256), 0, s, yraw, y, state, n, n_streams)
+    if (al && smooth_size == 1) BF_SM4(1);
+    else if (al && smooth_size == 2) BF_SM4(2);
+    else if (al && smooth_size == 3) BF_SM4(3);
+    else if (al && smooth_size == 4) BF_SM4(4);
+    else if (al && smooth_size == 5) BF_SM4(5);
+    else if (al && smooth_size == 6) BF_SM4(6);
+    else if (al && smooth_size == 7) BF_SM4(7);
+    else if (al && smooth_size == 8) BF_SM4(8);
+    else
+        hipLaunchKernelGGL(smooth_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, yraw, y, state, n, n_streams,
+                           smooth_size);
+#undef BF_SM4
     hipLaunchKernelGGL(smooth_state_kernel, dim3((unsigned)((64 * n_streams + 255) / 256)), dim3(256), 0, s, yraw, state, n,
                        n_streams);
     return hipGetLastError();
