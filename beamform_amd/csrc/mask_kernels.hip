@@ -292,7 +292,7 @@ __device__ __forceinline__ cd mpf_step(MpfState &st, const bf_config &c, int j, 
 }
 
 // Pass 2, one thread per (stream, problem), sequential over frames.
-__global__ __launch_bounds__(64) void mpf_recursion_kernel(BinsArgs a, const double *aux) {
+__global__ __launch_bounds__(64) void mpf_recursion_kernel(BinsArgs a, double *aux) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.n_streams * kNQ) return;
     const int s = idx / kNQ, q = idx % kNQ;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64) void mpf_recursion_kernel(BinsArgs a, const dou
     int cL = (int)sv[kMpfVecs * kN + 0];
     bool firstL = sv[kMpfVecs * kN + 1] == 0.0;  // stored as "first_L is over" flag so a zeroed state = cold start
     f64x2 *row = a.Yh + ((long)s * a.n_frames) * kYhStride + q;
-    const double *arow = aux + ((long)s * a.n_frames) * kYhStride + q;
+    double *arow = aux + ((long)s * a.n_frames) * kYhStride + q;
     for (long t = 0; t < a.n_frames; ++t) {
         const cd soi = ld(row + t * kYhStride);
         const double int2 = arow[t * kYhStride];
@@ -314,7 +314,12 @@ __global__ __launch_bounds__(64) void mpf_recursion_kernel(BinsArgs a, const dou
             cL++;
         }
         const cd y = mpf_step(st, a.cfg, j, soi, int2, reset, firstL, cL);
-        row[t * kYhStride] = f64x2{y.x, y.y};
+        // mpf32: the fp32 backward transform is the only reader -- its (float) conversion happens here and the row element takes the
+        // 8-byte slot this thread has just read |out_int|^2 from (half the bytes written, half the bytes read back)
+        if (a.mpf32)
+            reinterpret_cast<f32x2 *>(arow)[t * kYhStride] = f32x2{(float)y.x, (float)y.y};
+        else
+            row[t * kYhStride] = f64x2{y.x, y.y};
     }
     sv[0 * kN + j] = st.Sprev; sv[1 * kN + j] = st.Stmp; sv[2 * kN + j] = st.Smin; sv[3 * kN + j] = st.lam;
     sv[4 * kN + j] = st.Z; sv[5 * kN + j] = st.rev0; sv[6 * kN + j] = st.rev1;
@@ -625,7 +630,7 @@ hipError_t launch_stft_bins_fused(const StftArgs &a, const BinsArgs &b, int n_cu
     if (e != hipSuccess) return e;
     if (algo == BF_PHASEMPF) {  // second pass of launch_phasempf: the recursion over frames
         const int nthr = b.n_streams * kNQ;
-        hipLaunchKernelGGL(mpf_recursion_kernel, dim3((nthr + 63) / 64), dim3(64), 0, s, b, (const double *)aux);
+        hipLaunchKernelGGL(mpf_recursion_kernel, dim3((nthr + 63) / 64), dim3(64), 0, s, b, aux);
         e = hipGetLastError();
     }
     if (e == hipSuccess && b.spectrum) e = launch_expand_spectrum(b.Yh, b.spectrum, (long)b.n_streams * b.n_frames, s);
@@ -652,7 +657,7 @@ hipError_t launch_phasempf(const BinsArgs &a, int n_cus, hipStream_t s) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int nthr = a.n_streams * kNQ;
-    hipLaunchKernelGGL(mpf_recursion_kernel, dim3((nthr + 63) / 64), dim3(64), 0, s, a, (const double *)aux);
+    hipLaunchKernelGGL(mpf_recursion_kernel, dim3((nthr + 63) / 64), dim3(64), 0, s, a, aux);
     return hipGetLastError();
 }
 

@@ -383,6 +383,8 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
         if (khi < N_ / 2 - 1 && klo <= khi) { ba.yh_lo = klo; ba.yh_hi = khi; }
         else if (klo > khi) { ba.yh_lo = 1; ba.yh_hi = 0; }  // empty band: only problem 0
     }
+    // phasempf: the recursion's y_fft has no reader but the fp32 backward transform either: f32x2 rows in the |out_int|^2 slots
+    ba.mpf32 = (cfg_.algo == BF_PHASEMPF && istft32 && spectrum == nullptr) ? 1 : 0;
     bool fused = false;
     if (try_fused) {
         const hipError_t fe = ks_->stft_bins(sa, ba, n_cus_, stream);
@@ -422,6 +424,10 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     ia.tail_out = d_tail_[tail_cur_ ^ 1]; ia.tw = d_tw_; ia.win = d_win_; ia.n_frames = F; ia.n_streams = So_;
     ia.tw32 = istft32 ? d_tw32_ : nullptr;
     ia.yh32 = ba.yh32; ia.yh_lo = ba.yh_lo; ia.yh_hi = ba.yh_hi;
+    if (ba.mpf32) {  // rows of 8-byte elements behind the f64x2 rows (where aux lives), every problem written
+        ia.Yh = d_Yh_ + (size_t)So_ * F * YS_;
+        ia.yh32 = 1; ia.yh_lo = 0; ia.yh_hi = NQ_ - 1;
+    }
     ia.frames = d_frames_;
     ia.post_amp = (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS) ? cfg_.out_amp : 1.0;
     ia.use_post_amp = (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS) ? 1 : 0;
