@@ -303,9 +303,29 @@ __global__ __launch_bounds__(64) void mpf_recursion_kernel(BinsArgs a, double *a
     bool firstL = sv[kMpfVecs * kN + 1] == 0.0;  // stored as "first_L is over" flag so a zeroed state = cold start
     f64x2 *row = a.Yh + ((long)s * a.n_frames) * kYhStride + q;
     double *arow = aux + ((long)s * a.n_frames) * kYhStride + q;
-    for (long t = 0; t < a.n_frames; ++t) {
-        const cd soi = ld(row + t * kYhStride);
-        const double int2 = arow[t * kYhStride];
+    // 2 wavefronts per SIMD at config 4's size and a recursion per thread: the next frames' inputs are requested four frames ahead
+    // (a ring of four register sets), otherwise every step waits out its own two loads
+    constexpr int kAhead = 4;
+    cd soi_r[kAhead];
+    double int_r[kAhead];
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) {
+        const long tt = k < a.n_frames ? k : a.n_frames - 1;
+        soi_r[k] = ld(row + tt * kYhStride);
+        int_r[k] = arow[tt * kYhStride];
+    }
+    for (long t0 = 0; t0 < a.n_frames; t0 += kAhead) {
+#pragma unroll
+      for (int k = 0; k < kAhead; ++k) {
+        const long t = t0 + k;
+        if (t >= a.n_frames) break;
+        const cd soi = soi_r[k];
+        const double int2 = int_r[k];
+        {
+            const long tn = t + kAhead < a.n_frames ? t + kAhead : a.n_frames - 1;
+            soi_r[k] = ld(row + tn * kYhStride);
+            int_r[k] = arow[tn * kYhStride];
+        }
         const bool reset = cL > a.cfg.mcra_L;  // phasempf.cpp:161
         if (reset) {
             cL = 1;
@@ -320,6 +340,7 @@ __global__ __launch_bounds__(64) void mpf_recursion_kernel(BinsArgs a, double *a
             reinterpret_cast<f32x2 *>(arow)[t * kYhStride] = f32x2{(float)y.x, (float)y.y};
         else
             row[t * kYhStride] = f64x2{y.x, y.y};
+      }
     }
     sv[0 * kN + j] = st.Sprev; sv[1 * kN + j] = st.Stmp; sv[2 * kN + j] = st.Smin; sv[3 * kN + j] = st.lam;
     sv[4 * kN + j] = st.Z; sv[5 * kN + j] = st.rev0; sv[6 * kN + j] = st.rev1;
