@@ -58,6 +58,13 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     y = fma(y, fma(-hx * y, y, 0.5), y);
     return y;
 }
+// one Newton step: 4.3e-15 relative (v_rsq_f64 alone: 5.2e-8; two steps: 2.6e-16 -- tools/ubench/rsq_test.hip, 4 M values over 24 decades).
+// For the Cholesky pivots only: their error reaches y_fft times the condition number, next to the 7e-12 of the packed spectra and
+// a 1e-5 tolerance; the step is three dependent fp64 operations on the critical path of every elimination step.
+__device__ __forceinline__ double fast_rsqrt1(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    return fma(y, fma(-0.5 * x * y, y, 0.5), y);
+}
 __device__ __forceinline__ double fast_sqrt(double x) { return x == 0.0 ? 0.0 : x * fast_rsqrt(x); }
 __device__ __forceinline__ double fast_rcp(double x) {
     double y = __builtin_amdgcn_rcp(x);

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
             }
 #pragma unroll
             for (int jj = 0; jj < MP; ++jj) {
-                const double inv = fast_rsqrt(A[jj * (jj + 1) / 2 + jj].x);  // 1/L_jj; L_jj itself is never needed
+                const double inv = fast_rsqrt1(A[jj * (jj + 1) / 2 + jj].x);  // 1/L_jj; L_jj itself is never needed
 #pragma unroll
                 for (int c = 0; c < KC; ++c) U[c][jj] = U[c][jj] * inv;
                 X[jj] = X[jj] * inv;  // X turns into v = L^-1 x in place
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
                     for (int r = 0; r < NB; ++r) s_u[grp][r][0] = b[r];
                 }
                 __builtin_amdgcn_wave_barrier();
-                const double inv = fast_rsqrt(s_col[grp][jj].x);  // 1 / L_jj
+                const double inv = fast_rsqrt1(s_col[grp][jj].x);  // 1 / L_jj
                 const cd Lij = A[jj] * inv;
                 if (i > jj) {
 #pragma unroll
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(64, 1) void mvdr_lcmv_lanes_kernel(BinsArgs a, int 
 #pragma unroll
             for (int jj = 0; jj < MP; ++jj) {
                 const int ro = jj / L, qo = jj % L;  // owner slot / lane of row jj
-                const double inv = fast_rsqrt(bcast_from<L>(qo, A[TIX(ro, jj)].x));
+                const double inv = fast_rsqrt1(bcast_from<L>(qo, A[TIX(ro, jj)].x));
                 cd Lc[RPL];  // scaled column jj of the local rows (meaningful where row > jj)
 #pragma unroll
                 for (int r = ro; r < RPL; ++r) Lc[r] = A[TIX(r, jj)] * inv;
@@ -900,7 +900,7 @@ __global__ __launch_bounds__(256, 2) void mvdr_lcmv_row_kernel(BinsArgs a, int t
             b[KM] = x;
             RowStep<0, MP>::run([&](auto jc) {
                 constexpr int jj = decltype(jc)::value;
-                const double inv = fast_rsqrt(rowbc<jj>(A[jj].x));  // 1 / L_jj from the owner's diagonal
+                const double inv = fast_rsqrt1(rowbc<jj>(A[jj].x));  // 1 / L_jj from the owner's diagonal
                 const cd Lij = A[jj] * inv;                   // my row's entry of the scaled column (valid for i > jj)
 #pragma unroll
                 for (int r = 0; r < NB; ++r) {
@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
             }
             RowStep<0, 16>::run([&](auto jc) {
                 constexpr int jj = decltype(jc)::value, bj = jj >> 2, qj = jj & 3;
-                const double inv = fast_rsqrt(rowbc<5 * qj>(A[LT(bj, bj)].x));  // 1 / L_jj from lane (qj, qj)
+                const double inv = fast_rsqrt1(rowbc<5 * qj>(A[LT(bj, bj)].x));  // 1 / L_jj from lane (qj, qj)
                 cd Lrow[4], Lcol[4], u[NS];
 #pragma unroll
                 for (int ar = bj; ar < 4; ++ar) Lrow[ar] = quadbc<qj>(A[LT(ar, bj)] * inv);  // L(4ar+p, jj) from lane (p, qj)
