@@ -1401,7 +1401,12 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
         // tile length: the wavefronts (64 lanes = 64 (tile, problem) pairs) should fill the 4 x CUs slots a whole number of times;
         // cost of a choice = rounds x (frames walked + P warm-up frames)
         static const int ft_env = getenv("BF_MVDR_TILE") ? atoi(getenv("BF_MVDR_TILE")) : 0;
-        const long slots = (long)n_cus * 4, F = a.n_frames;
+        // resident wavefronts per CU: the prefetch buffers (2 x 2 MP rows of 1 KiB in LDS) and the register count of the instantiation
+        // that will run decide -- 8 microphones: one per SIMD (512 registers); fewer microphones: more
+        const int mp_ = M <= 2 ? 2 : M <= 4 ? 4 : M <= 6 ? 6 : 8;
+        const int kc_ = (!lcmv_fast || a.kp1 <= 1) ? 1 : a.kp1;
+        const int wpc = mp_ == 2 ? 16 : mp_ == 4 ? (kc_ <= 2 ? 9 : 8) : mp_ == 6 ? (kc_ == 1 ? 6 : 4) : 4;
+        const long slots = (long)n_cus * wpc, F = a.n_frames;
         long best_t = 1;
         double best_c = 1e300;
         for (long t = 1; t <= 512 && t <= F; ++t) {
