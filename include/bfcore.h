@@ -109,6 +109,8 @@ typedef struct bf_config {
     int n_dirs;                    /* look directions evaluated per input stream from the SAME samples (0/1 = one, the
                                       reference node).  Output stream index = stream * n_dirs + dir.  Every node except mcra
                                       (no look direction) and gsc; gss / phasempf keep their recursive state per beam.
+                                      das (fp32, planar input, <= 8 microphones): from 6 directions on the forward transforms
+                                      of a frame are computed once and shared by the beams (das.cpp:51-63 transforms once).
                                       SURVEY 8(e) "look directions" / 8(f) row 4 */
     /* gsc (gsc.cpp:199-256, launch/gsc.launch:6-11); write_mu is file I/O and not part of the path */
     int gsc_use_vad;
