@@ -16,23 +16,27 @@ namespace {
 // the run: the hop two consecutive frames share (50 % overlap, util.h:217-242) stays in registers as raw float samples, so
 // every input sample is fetched ONCE (the item-per-frame version fetched 1.5x: counters, profiles/traffic_mvdr8.json of
 // round 2), and the next hop is requested before the current frame is transformed -- a wavefront alone on its SIMD has
-// nobody else to hide the load latency behind.  The window lives in registers for the whole run.
+// nobody else to hide the load latency behind.  The window is read from LDS (rows per lane).
 // Z48: the packed pair spectrum leaves as z48 elements (mvdr / lcmv).
 template <int LAYOUT, bool Z48>
 __global__ __launch_bounds__(256) void stft_kernel(StftArgs a) {
     constexpr int kStftBlock = 256, kStftHalves = kStftBlock / 32;
-    __shared__ __attribute__((aligned(16))) double lds[2048 + kStftHalves * 32 * kPSd];
+    // the window sits in LDS as [lane][j] rows of 34 doubles (272 B: the 16 lanes of a ds_read_b128 group land 4 banks apart): in
+    // registers it cost 64 of the 256 VGPRs beside 128 of data and 96 of carried hops, and hipcc moved ~450 values per frame
+    // through the accumulator registers to make room
+    constexpr int kWinRow = 34;
+    __shared__ __attribute__((aligned(16))) double lds[2048 + kStftHalves * 32 * kPSd + 32 * kWinRow];
     const cx<double> *s_tw = reinterpret_cast<const cx<double> *>(lds);
     const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
     double *pbuf = lds + 2048 + hw * 32 * kPSd;
+    double *s_win = lds + 2048 + kStftHalves * 32 * kPSd;
     {
         const double *twf = reinterpret_cast<const double *>(a.tw);
         for (int i = tid; i < 2048; i += kStftBlock) lds[i] = twf[i];
+        for (int i = tid; i < kN; i += kStftBlock) s_win[(i & 31) * kWinRow + (i >> 5)] = a.win[i] * (Z48 ? 0.5 : 1.0);  // z48 spectra are stored halved (exact)
         __syncthreads();
     }
-    double win[32];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) win[j] = a.win[32 * j + lane] * (Z48 ? 0.5 : 1.0);  // z48 spectra are stored halved (exact)
+    const f64x2 *wrow = reinterpret_cast<const f64x2 *>(s_win + lane * kWinRow);
     const int M = a.n_mics, MF = a.n_fft_mics, NP = (MF + 1) >> 1, L = a.run_len;
     const long runs = (a.n_frames + L - 1) / L;
     const long total = (long)a.n_streams * runs * NP;
@@ -85,11 +89,16 @@ __global__ __launch_bounds__(256) void stft_kernel(StftArgs a) {
             }
             double re[32], im[32];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                re[j] = (double)pa[j] * win[j];  // buf[j]*hann_win[i]  (util.h:235)
-                im[j] = (double)pb[j] * (win[j] * bs);
-                re[j + 16] = (double)ca[j] * win[j + 16];
-                im[j + 16] = (double)cb[j] * (win[j + 16] * bs);
+            for (int j = 0; j < 16; j += 2) {
+                const f64x2 w0 = wrow[j >> 1], w1 = wrow[8 + (j >> 1)];  // win[j], win[j+1] / win[j+16], win[j+17]
+                re[j] = (double)pa[j] * w0.x;  // buf[j]*hann_win[i]  (util.h:235)
+                im[j] = (double)pb[j] * (w0.x * bs);
+                re[j + 1] = (double)pa[j + 1] * w0.y;
+                im[j + 1] = (double)pb[j + 1] * (w0.y * bs);
+                re[j + 16] = (double)ca[j] * w1.x;
+                im[j + 16] = (double)cb[j] * (w1.x * bs);
+                re[j + 17] = (double)ca[j + 1] * w1.y;
+                im[j + 17] = (double)cb[j + 1] * (w1.y * bs);
             }
             fft1024p_fwd_A<double>(re, im, lane, s_tw, pbuf);
             __builtin_amdgcn_wave_barrier();

@@ -1,6 +1,7 @@
 cd /root/repo
 export TMPDIR=/tmp
-for rep in 1 2; do
-echo "== block"; BF_HOP_SPIN=0 python tools/hop_latency.py 2>&1 | grep -v amdgpu
-echo "== spin"; python tools/hop_latency.py 2>&1 | grep -v amdgpu
+for rep in 1 2 3; do
+echo -n "base "; BFCORE_LIB=/root/repo/abtmp/libbfcore_base.so python tools/run_das.py --algo mvdr --iters 30 | tail -1
+echo -n "new  "; python tools/run_das.py --algo mvdr --iters 30 | tail -1
 done
+python -m pytest tests/test_pipeline_gpu.py -x -q -m gpu 2>&1 | tail -2
