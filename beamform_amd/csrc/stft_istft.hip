@@ -145,22 +145,23 @@ __global__ __launch_bounds__(256) void stft_kernel(StftArgs a) {
 // samples of the next pair are requested before the current pair is transformed.
 __global__ __launch_bounds__(256) void das_f64_fused_kernel(DasF64Args a) {
     constexpr int kBlock = 256, kHalves = kBlock / 32;
-    __shared__ __attribute__((aligned(16))) double lds[2048 + kHalves * 32 * kPSd + 4 * 2048];
+    constexpr int kWinRow = 34;  // window as [lane][j] rows in LDS (as stft_kernel): 64 registers less beside 128 of data and 128 of accumulator
+    __shared__ __attribute__((aligned(16))) double lds[2048 + kHalves * 32 * kPSd + 4 * 2048 + 32 * kWinRow];
     const cx<double> *s_tw = reinterpret_cast<const cx<double> *>(lds);
     const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
     double *pbuf = lds + 2048 + hw * 32 * kPSd;
     const f64x2 *s_gain = reinterpret_cast<const f64x2 *>(lds + 2048 + kHalves * 32 * kPSd);
+    double *s_win = lds + 2048 + kHalves * 32 * kPSd + 4 * 2048;
     const int M = a.n_mics, NP = (M + 1) >> 1;
     {
         const double *twf = reinterpret_cast<const double *>(a.tw), *gf = reinterpret_cast<const double *>(a.gains);
         for (int i = tid; i < 2048; i += kBlock) lds[i] = twf[i];
         double *lg = lds + 2048 + kHalves * 32 * kPSd;
         for (int i = tid; i < NP * 2048; i += kBlock) lg[i] = gf[i];
+        for (int i = tid; i < kN; i += kBlock) s_win[(i & 31) * kWinRow + (i >> 5)] = a.win[i];
         __syncthreads();
     }
-    double win[32];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) win[j] = a.win[32 * j + lane];
+    const f64x2 *wrow = reinterpret_cast<const f64x2 *>(s_win + lane * kWinRow);
     const int L = a.run_len;
     const long runs = (a.n_frames + L - 1) / L;
     const long total = (long)a.n_streams * runs;
@@ -208,9 +209,12 @@ __global__ __launch_bounds__(256) void das_f64_fused_kernel(DasF64Args a) {
                 double re[32], im[32];
                 const double bs = (2 * p + 1 < M) ? 1.0 : 0.0;
 #pragma unroll
-                for (int j = 0; j < 32; ++j) {
-                    re[j] = (double)na[j] * win[j];  // buf[j]*hann_win[i]  (util.h:235)
-                    im[j] = (double)nb[j] * (win[j] * bs);
+                for (int j = 0; j < 32; j += 2) {
+                    const f64x2 w = wrow[j >> 1];
+                    re[j] = (double)na[j] * w.x;  // buf[j]*hann_win[i]  (util.h:235)
+                    im[j] = (double)nb[j] * (w.x * bs);
+                    re[j + 1] = (double)na[j + 1] * w.y;
+                    im[j + 1] = (double)nb[j + 1] * (w.y * bs);
                 }
                 {  // next pair (or the next frame's first one): in flight during this transform
                     long tn = t;
@@ -248,6 +252,13 @@ __global__ __launch_bounds__(256) void das_f64_fused_kernel(DasF64Args a) {
             __builtin_amdgcn_wave_barrier();
             // position i: sample n = 32*brev5(i) + lane (even i: first half, odd i: second half); util.h:247-252 with the float stores
             float o[32];
+            double win[32];
+#pragma unroll
+            for (int j = 0; j < 32; j += 2) {
+                const f64x2 w = wrow[j >> 1];
+                win[j] = w.x;
+                win[j + 1] = w.y;
+            }
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
                 const float f = (float)Sr[i];                 // (float)(Re / N): 1/N is inside the gains
