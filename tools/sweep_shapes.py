@@ -9,7 +9,7 @@ from beamform_amd.params import make_params
 
 F = int(os.environ.get("SWEEP_FRAMES", "16384"))
 cases = []
-for M in (2, 3, 4, 5, 6, 8, 9, 12, 16, 24, 32):
+for M in (2, 3, 4, 5, 6, 8, 9, 12, 16):  # make_params lays out up to 16 microphones by itself
     cases.append(("das", M, 0))
     cases.append(("mvdr", M, 0))
     cases.append(("phase", M, 0))
