@@ -1,4 +1,3 @@
 cd /root/repo
 export TMPDIR=/tmp
-for i in 1 2 3; do python -m pytest tests -x -q -m gpu 2>&1 | tail -1; done
-python -c "import __graft_entry__ as g; g.smoke()"
+for sd in 61 62 63 64 65 66 67 68; do timeout 600 python tools/fuzz_parity.py $sd 250 2>&1 | tail -1; done
