@@ -368,18 +368,39 @@ __global__ __launch_bounds__(64) void mcra_node_kernel(BinsArgs a) {
     const f64x2 *Zs = a.Z + ((long)s * a.frames_ws + a.frame_off) * kN;
     f64x2 *row = a.Yh + ((long)s * a.n_frames) * kYhStride + q;
     const double aS = a.cfg.mcra_alphaS, aD = a.cfg.mcra_alphaD, aD2 = a.cfg.mcra_alphaD2, delta = a.cfg.mcra_delta;
-    for (long t = 0; t < a.n_frames; ++t) {
-        const f64x2 *Zf = Zs + t * kN;
-        const cd x = ld(Zf + j);
+    // the three spectrum values of a step are requested four frames ahead (as mpf_recursion_kernel): two wavefronts per SIMD at
+    // 256 streams and a recursion per thread, nobody else covers the load latency
+    constexpr int kAhead = 4;
+    const int jl = j - 1 >= 1 ? j - 1 : j;  // bin 1 has no left neighbour inside [1, N): its slot re-reads bin j and is not used
+    cd xr_[kAhead], xl_[kAhead], xc_[kAhead];
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) {
+        const f64x2 *Zf = Zs + (k < a.n_frames ? k : a.n_frames - 1) * kN;
+        xc_[k] = ld(Zf + j);
+        xl_[k] = ld(Zf + jl);
+        xr_[k] = ld(Zf + j + 1);
+    }
+    for (long t0 = 0; t0 < a.n_frames; t0 += kAhead) {
+#pragma unroll
+      for (int k = 0; k < kAhead; ++k) {
+        const long t = t0 + k;
+        if (t >= a.n_frames) break;
+        const cd x = xc_[k], xl = xl_[k], xr = xr_[k];
+        {
+            const f64x2 *Zn = Zs + (t + kAhead < a.n_frames ? t + kAhead : a.n_frames - 1) * kN;
+            xc_[k] = ld(Zn + j);
+            xl_[k] = ld(Zn + jl);
+            xr_[k] = ld(Zn + j + 1);
+        }
         const double x2 = norm2(x);  // in_fft_square (mcra.cpp:77)
         double Sf;
         if (j == 0) {
             Sf = cabs(x);  // magnitude, not power (mcra.cpp:83)
         } else {           // 0.25 / 0.5 / 0.25 over bins j-1, j, j+1 inside [1, N) (mcra.cpp:84-92); j+1 <= 514 < N here
             Sf = 0.0;
-            if (j - 1 >= 1) Sf += 0.25 * norm2(ld(Zf + j - 1));
+            if (j - 1 >= 1) Sf += 0.25 * norm2(xl);
             Sf += 0.5 * x2;
-            Sf += 0.25 * norm2(ld(Zf + j + 1));
+            Sf += 0.25 * norm2(xr);
         }
         const double S = (aS * Sprev) + ((1 - aS) * Sf);
         if (cL > a.cfg.mcra_L) {  // mcra.cpp:100-113
@@ -412,6 +433,7 @@ __global__ __launch_bounds__(64) void mcra_node_kernel(BinsArgs a) {
         }
         row[t * kYhStride] = f64x2{y.x, y.y};
         Sprev = S;
+      }
     }
     sv[0 * kN + j] = Sprev; sv[1 * kN + j] = Stmp; sv[2 * kN + j] = Smin; sv[3 * kN + j] = lam;
     if (q == 0) {
