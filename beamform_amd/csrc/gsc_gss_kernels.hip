@@ -265,11 +265,30 @@ __global__ __launch_bounds__(256) void gss_kernel(BinsArgs a) {
     }
     const double mu = a.cfg.mu, keep = 1 - a.cfg.lambda_ * a.cfg.mu;
     const double c2 = (double)(size_t)(2 * (1 / (size_t)S));  // integer arithmetic, quirk Q13
-    for (long t = 0; t < a.n_frames; ++t) {
+    // this lane's two packed-spectrum values of a step are requested four frames ahead: the recursion leaves a wavefront nothing
+    // else to cover the load latency with (256 x 256: see EXPERIMENTS)
+    constexpr int kAhead = 4;
+    const int mz = m < M ? m : 0;
+    cd zr_[kAhead], zcr_[kAhead];
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) {
+        const f64x2 *Zf = Zs + (k < a.n_frames ? k : a.n_frames - 1) * NP * kN + (mz >> 1) * kN;
+        zr_[k] = ld(Zf + ksrc);
+        zcr_[k] = ld(Zf + kneg);
+    }
+    for (long t0 = 0; t0 < a.n_frames; t0 += kAhead) {
+#pragma unroll
+      for (int kk = 0; kk < kAhead; ++kk) {
+        const long t = t0 + kk;
+        if (t >= a.n_frames) break;  // uniform
         cd x{0, 0};
+        const cd z = zr_[kk], zc = conj(zcr_[kk]);
+        {
+            const f64x2 *Zn = Zs + (t + kAhead < a.n_frames ? t + kAhead : a.n_frames - 1) * NP * kN + (mz >> 1) * kN;
+            zr_[kk] = ld(Zn + ksrc);
+            zcr_[kk] = ld(Zn + kneg);
+        }
         if (m < M) {
-            const f64x2 *Zf = Zs + t * NP * kN + (m >> 1) * kN;
-            const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
             if ((m & 1) == 0) {
                 x = (z + zc) * 0.5;
             } else {
@@ -330,6 +349,7 @@ __global__ __launch_bounds__(256) void gss_kernel(BinsArgs a) {
         }
         if (m == 0) yout[t * kYhStride] = f64x2{y.x, y.y};
         __builtin_amdgcn_wave_barrier();
+      }
     }
 #pragma unroll
     for (int r = 0; r < KM; ++r)
