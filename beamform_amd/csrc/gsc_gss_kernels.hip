@@ -231,8 +231,28 @@ __global__ __launch_bounds__(64) void gsc_nlms_kernel(const float *aligned, floa
 // ======================================================================================
 // One group of MP lanes per (stream, problem), lane m owns column m of the demixing matrix
 // W_j (S x M) and walks the frames in order (the update is recursive, gss.cpp:136).
+// sum over the MP lanes of a group (MP = 4, 8, 16: inside one 16-lane DPP row), every lane gets the total
+template <int CTRL>
+__device__ __forceinline__ double gss_dpp(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <int MP>
+__device__ __forceinline__ double grp_sum(double v) {
+    v += gss_dpp<0xB1>(v);                 // quad_perm [1,0,3,2]
+    v += gss_dpp<0x4E>(v);                 // quad_perm [2,3,0,1]
+    if (MP >= 8) v += gss_dpp<0x141>(v);   // row_half_mirror
+    if (MP >= 16) v += gss_dpp<0x140>(v);  // row_mirror
+    return v;
+}
+template <int MP>
+__device__ __forceinline__ cd grp_sum(cd v) { return cd{grp_sum<MP>(v.x), grp_sum<MP>(v.y)}; }
+
 template <int MP, int KM>
 __global__ __launch_bounds__(256) void gss_kernel(BinsArgs a) {
+    constexpr bool kDpp = MP <= 16;  // sums over the group's lanes by DPP butterflies (pairwise order) instead of serial walks over LDS
     constexpr int GPB = 256 / MP;
     __shared__ cd s_x[GPB][MP + 1];   // padded rows: see mvdr_lcmv_kernel (gss 256x256: 6.5 -> 5.8 ms)
     __shared__ cd s_p[GPB][KM][MP + 1];
@@ -298,14 +318,21 @@ __global__ __launch_bounds__(256) void gss_kernel(BinsArgs a) {
             if (q == kQX) x = conj(x);
         }
         s_x[grp][m] = x;
+        if (!kDpp) {
 #pragma unroll
-        for (int r = 0; r < KM; ++r) s_p[grp][r][m] = W[r] * x;
+            for (int r = 0; r < KM; ++r) s_p[grp][r][m] = W[r] * x;
+        }
         __builtin_amdgcn_wave_barrier();
         double mag = 0.0, alpha = 0.0;
-        for (int k = 0; k < M; ++k) {
-            const cd v = s_x[grp][k];
-            mag += cabs(v);
-            alpha += norm2(v);
+        if (kDpp) {  // lanes m >= M hold x = 0
+            mag = grp_sum<MP>(cabs(x));
+            alpha = grp_sum<MP>(norm2(x));
+        } else {
+            for (int k = 0; k < M; ++k) {
+                const cd v = s_x[grp][k];
+                mag += cabs(v);
+                alpha += norm2(v);
+            }
         }
         mag /= (double)((unsigned)M * (unsigned)kN);
         cd y;
@@ -313,9 +340,13 @@ __global__ __launch_bounds__(256) void gss_kernel(BinsArgs a) {
             cd yf[KM];
 #pragma unroll
             for (int r = 0; r < KM; ++r) {
-                cd acc{0, 0};
-                for (int k = 0; k < M; ++k) acc = acc + s_p[grp][r][k];
-                yf[r] = acc;
+                if (kDpp) {
+                    yf[r] = grp_sum<MP>(W[r] * x);
+                } else {
+                    cd acc{0, 0};
+                    for (int k = 0; k < M; ++k) acc = acc + s_p[grp][r][k];
+                    yf[r] = acc;
+                }
             }
             y = yf[0];
             alpha *= alpha;
@@ -333,11 +364,15 @@ __global__ __launch_bounds__(256) void gss_kernel(BinsArgs a) {
 #pragma unroll
             for (int r = 0; r < KM; ++r) d2[r] = cd{0, 0};
             if (c2 != 0.0) {  // only S == 1: dj2 = 2 (W C - I) C^H
-                __builtin_amdgcn_wave_barrier();
-                s_p[grp][0][m] = W[0] * C[0];
-                __builtin_amdgcn_wave_barrier();
                 cd wc{0, 0};
-                for (int k = 0; k < M; ++k) wc = wc + s_p[grp][0][k];
+                if (kDpp) {
+                    wc = grp_sum<MP>(W[0] * C[0]);
+                } else {
+                    __builtin_amdgcn_wave_barrier();
+                    s_p[grp][0][m] = W[0] * C[0];
+                    __builtin_amdgcn_wave_barrier();
+                    for (int k = 0; k < M; ++k) wc = wc + s_p[grp][0][k];
+                }
                 wc.x -= 1.0;
                 d2[0] = (wc * conj(C[0])) * c2;
             }
