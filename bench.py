@@ -414,6 +414,8 @@ def main():
                                                   note="the same noise 8x louder: every bin passes mag_threshold and runs the 8 atan2 + 28 wrapped differences")),
             ("lcmv16", lambda: node_line("lcmv", 16, 32768, 1, (-60.0, 90.0, 150.0), iters=3,
                                          note="BASELINE config 5, one GPU's shard of the 262144-frame stream; " + noise)),
+            ("gss", lambda: node_line("gss", 8, 256, 256, (-60.0, 90.0), with_traffic=False,
+                                      note="gss 8-mic, 2 interferers, 256 streams x 256 frames (the demixing matrices recurse over the frames of a stream); " + noise)),
             ("lcmv8", lambda: node_line("lcmv", M, F, 1, (-60.0, 90.0), xin=x, with_traffic=False,
                                         note="lcmv on the headline array (8 microphones, 2 interferers): mvdr_fast_kernel<8, 3>; " + noise)),
         ]

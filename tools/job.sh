@@ -1,8 +1,4 @@
 cd /root/repo
 export TMPDIR=/tmp
-for rep in 1 2; do
-echo -n "base "; BFCORE_LIB=/root/repo/abtmp/libbfcore_base.so python tools/run_das.py --algo gss --mics 8 --streams 256 --frames 256 --iters 10 | tail -1
-echo -n "new  "; python tools/run_das.py --algo gss --mics 8 --streams 256 --frames 256 --iters 10 | tail -1
-done
-python -m pytest tests -x -q -m gpu -k "gss or interf or golden or dirs" 2>&1 | tail -2
-python tools/fuzz_parity.py 81 300 2>&1 | tail -1
+( time python bench.py --gpus 1 --steps 20 --warmup 5 ) > gpurun_out/bench_now.json 2> gpurun_out/bench_now.err; tail -3 gpurun_out/bench_now.err
+python -m pytest tests/test_bench_gpu.py -x -q -m gpu 2>&1 | tail -2
