@@ -40,7 +40,10 @@ namespace {
 // identity (its spectrum is the transform's ~1e-16 rounding residue, not an exact zero).
 struct FastPlan {
     int q_lo, n_main;  // problems q_lo .. q_lo + n_main - 1 are in band (a contiguous run inside 1 .. N/2-1)
-    int nb;            // 1 + n_main (a band that reaches the irregular problems N/2, N/2+1 -- quirk Q1 -- takes the group kernel)
+    int n_extra;       // the irregular problems of quirk Q1 that are in band: N/2 (f := 0) when 0 Hz is, N/2+1 (|f| = (N/2-1) sr/N)
+    int extra_q[2];
+    int solve0;        // lcmv with 0 Hz in band: problem 0 is an ordinary problem (mvdr passes X_0 through, mvdr.cpp:76)
+    int nb;            // 1 + n_main + n_extra
     int tile, tiles, waves_per_stream;
 };
 
@@ -58,7 +61,8 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
     if (!live) id = fp.tiles * fp.nb - 1;
     const int tl0 = id0 / fp.nb, tl = id / fp.nb;  // time tile of lane 0 / of this lane
     const int k = id - tl * fp.nb;
-    const int q = k == 0 ? 0 : fp.q_lo + k - 1;
+    const int q = k == 0 ? 0 : k <= fp.n_main ? fp.q_lo + k - 1 : fp.extra_q[k - 1 - fp.n_main];
+    const bool solve_q = q != 0 || fp.solve0 != 0;
     const int j = q_bin(q);
     const long tA0 = (long)tl0 * fp.tile;          // first frame of lane 0's tile: the wavefront's time origin (uniform)
     const int dt = (tl - tl0) * fp.tile;           // this lane's tile starts dt frames later
@@ -111,6 +115,10 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
             const cd c = dec48(s_pf[buf][base + 2 * p + 1][lane].v);  // Z[N-k], conjugated on the fly
             X[2 * p] = cd{z.x + c.x, z.y - c.y};      // (Z[k] + conj Z[N-k]) / 2
             X[2 * p + 1] = cd{z.y + c.y, c.x - z.x};  // (Z[k] - conj Z[N-k]) / (2i)
+        }
+        if (q == kQX) {  // the extra problem: bin N/2+1 holds the conjugate of bin N/2-1's spectrum
+#pragma unroll
+            for (int m = 0; m < MP; ++m) X[m].y = -X[m].y;
         }
     };
 #define BF_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -190,8 +198,8 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
             open = mag > a.cfg.freq_mag_threshold;
         }
         cd y = X[0] * 0.01;  // gate closed: mvdr.cpp:96
-        if (q == 0) y = a.cfg.algo == BF_LCMV ? cd{0, 0} : X[0];  // mvdr.cpp:76; lcmv has no such rule: problem 0 is out of band on this path
-        if (__builtin_amdgcn_ballot_w64(open && q != 0) != 0) {
+        if (q == 0 && !fp.solve0) y = a.cfg.algo == BF_LCMV ? cd{0, 0} : X[0];  // mvdr.cpp:76; lcmv has no such rule: problem 0 out of band reads as zero
+        if (__builtin_amdgcn_ballot_w64(open && solve_q) != 0) {
             cd A[NT];
 #pragma unroll
             for (int i = 0; i < MP; ++i) {
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
                     den += norm2(ua[i]);
                 }
                 const double rden = fast_rcp(den);
-                if (open && q != 0) y = cd{num.x * rden, num.y * rden};
+                if (open && solve_q) y = cd{num.x * rden, num.y * rden};
             } else {
                 // G (Hermitian, upper triangle row-major) and g, then the KC x KC system by elimination (as cov2d_kernel)
                 auto UI = [](int r, int c) { return r * KC - r * (r - 1) / 2 + (c - r); };
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
                     for (int c = k + 1; c < KC; ++c) acc = acc - ge[UI(k, c)] * gv[c];
                     gv[k] = acc * pinvs[k];
                 }
-                if (open && q != 0) y = gv[0];
+                if (open && solve_q) y = gv[0];
             }
         }
         if (it < cnt) st_y(a, yidx + it * kYhStride, q, y);
@@ -1307,7 +1315,8 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
     // lcmv with up to 8 microphones rides mvdr_fast_kernel while its columns fit the register file beside R and its working copy:
     // any K <= 3 up to 6 microphones, K <= 2 at 7-8 (BF_LCMV_FAST=0: the lanes kernel, for A/B runs)
     static const bool lcmv_fast_on = !(getenv("BF_LCMV_FAST") && atoi(getenv("BF_LCMV_FAST")) == 0);
-    const bool lcmv_fast = !no_fast && !band_hits_nyquist && a.cfg.algo == BF_LCMV && lcmv_fast_on && M <= 8 && a.kp1 <= 4;
+    const bool lcmv_fast = !no_fast && a.cfg.algo == BF_LCMV && lcmv_fast_on && M <= 8 && a.kp1 <= 4;
+    (void)band_hits_nyquist;
 #define BF_LAUNCH_ML(MP_, KM_)                                                                                   \
     hipLaunchKernelGGL((mvdr_lcmv_kernel<MP_, KM_>), dim3(tps * a.n_streams, (kNQ + (256 / MP_) - 1) / (256 / MP_)), \
                        dim3(256), 0, s, a, tile, tps)
@@ -1383,7 +1392,7 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
         }
         return hipGetLastError();
     }
-    if ((a.cfg.algo == BF_MVDR || lcmv_fast) && M <= 8 && !no_fast && !band_hits_nyquist) {
+    if ((a.cfg.algo == BF_MVDR || lcmv_fast) && M <= 8 && !no_fast) {
         // the problems that need a solve (FastPlan): 0, the in-band run inside 1 .. N/2-1, and N/2 / N/2+1 when in band
         const std::vector<double> fr = frequency_vector(kN, a.cfg.sample_rate);  // the table the other kernels read (a.freqs)
         auto inb = [&](int q) {
@@ -1397,7 +1406,12 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
         while (fp.q_lo + fp.n_main < kN / 2 && inb(fp.q_lo + fp.n_main)) ++fp.n_main;
         for (int q = fp.q_lo + fp.n_main; q < kN / 2; ++q)
             if (inb(q)) return hipErrorInvalidValue;  // cannot happen: |f| rises with q below N/2
-        fp.nb = 1 + fp.n_main;
+        fp.n_extra = 0;
+        fp.extra_q[0] = fp.extra_q[1] = 0;
+        if (inb(kN / 2)) fp.extra_q[fp.n_extra++] = kN / 2;          // f[N/2] := 0 (quirk Q1): in band when 0 Hz is
+        if (inb(kN / 2 + 1)) fp.extra_q[fp.n_extra++] = kN / 2 + 1;  // the conjugate problem
+        fp.solve0 = (a.cfg.algo == BF_LCMV && inb(0)) ? 1 : 0;
+        fp.nb = 1 + fp.n_main + fp.n_extra;
         // tile length: the wavefronts (64 lanes = 64 (tile, problem) pairs) should fill the 4 x CUs slots a whole number of times;
         // cost of a choice = rounds x (frames walked + P warm-up frames)
         static const int ft_env = getenv("BF_MVDR_TILE") ? atoi(getenv("BF_MVDR_TILE")) : 0;
@@ -1422,6 +1436,8 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
         fp.waves_per_stream = (int)(((long)fp.tiles * fp.nb + 63) / 64);
         if (!a.yh32)  // f64x2 rows (spectrum dump / fp64 backward transform): the rows nobody solves read as zero (mvdr.cpp:103)
             (void)hipMemsetAsync(a.Yh, 0, (size_t)a.n_streams * a.n_frames * kYhStride * sizeof(f64x2), s);
+        else if (a.yh_lo == 0 && fp.nb < kNQ)  // f32x2 rows that the backward transform reads in full (a band up to the Nyquist problems) while part of them is out of band
+            (void)hipMemsetAsync(a.Yh, 0, (size_t)a.n_streams * a.n_frames * kYhStride * sizeof(f32x2), s);
         const dim3 grid((unsigned)((long)fp.waves_per_stream * a.n_streams));
 #define BF_FAST_GO(MP_, KC_) hipLaunchKernelGGL((mvdr_fast_kernel<MP_, KC_>), grid, dim3(64), 0, s, a, fp)
         if (!lcmv_fast || a.kp1 <= 1) {  // lcmv without interferers = mvdr except problem 0

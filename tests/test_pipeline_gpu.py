@@ -443,11 +443,13 @@ def test_c_shard_node_example_reproduces_the_unsharded_stream():
     assert out.returncode == 0 and "ms_per_step_with_overlapped_gather" in out.stdout, out.stdout + out.stderr
 
 
-@pytest.mark.parametrize("algo,M,interf", [("mvdr", 8, ()), ("mvdr", 5, ()), ("lcmv", 8, (-60.0,)), ("lcmv", 16, (-60.0, 90.0, 150.0)), ("mvdr", 12, ())])
-@pytest.mark.parametrize("band", [(0.0, 24000.0), (0.0, 23960.0), (300.0, 3400.0), (20000.0, 23000.0), (30.0, 40.0), (5.0, 20.0)])
+@pytest.mark.parametrize("algo,M,interf", [("mvdr", 8, ()), ("mvdr", 5, ()), ("lcmv", 8, (-60.0,)), ("lcmv", 16, (-60.0, 90.0, 150.0)), ("mvdr", 12, ()),
+                                           ("lcmv", 3, (90.0,)), ("lcmv", 6, (-60.0, 90.0, 150.0)), ("mvdr", 2, ())])
+@pytest.mark.parametrize("band", [(0.0, 24000.0), (0.0, 23960.0), (0.0, 16000.0), (100.0, 24000.0), (300.0, 3400.0), (20000.0, 23000.0), (30.0, 40.0), (5.0, 20.0)])
 def test_mvdr_lcmv_other_bands(algo, M, interf, band):
     """freq_min / freq_max other than the launch file's (mvdr.cpp:166-178): the full band -- which takes in the irregular
-    problems N/2 (f = 0 by quirk Q1) and N/2 + 1 and routes mvdr to the group kernel --, a band ending between them, a telephone
+    problems N/2 (f = 0 by quirk Q1) and N/2 + 1 (up to 8 microphones they ride mvdr_fast_kernel as two extra problems, lcmv then
+    also solves problem 0) --, a band ending between them, one that starts at 0 Hz, one that ends at the Nyquist problems, a telephone
     band, a high band, a band of one bin (30-40 Hz holds no bin at all: 46.875 Hz spacing -- only problem 0 is non-zero) --
     spectrum dump (f64 rows) and the product's f32 band-limited rows both."""
     import oracle
