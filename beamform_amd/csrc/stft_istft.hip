@@ -582,7 +582,7 @@ __global__ __launch_bounds__(kI32Block) void istft32_kernel(IstftArgs a, int fra
 #else
 
 // ======================================================================================
-//          generic sizes (N = 512, 2048): LDS-staged radix-2 Stockham transforms
+//          generic sizes (N = 512, 2048): LDS-staged radix-4 Stockham transforms
 // ======================================================================================
 // JACK periods other than 512 frames (rosjack.cpp:131; fft_win = 2 * period, util.h:261).  One 256-thread block per
 // transform, the whole signal in LDS (two N-point complex double buffers), log2(N) autosort passes with a barrier each,
@@ -591,15 +591,41 @@ __global__ __launch_bounds__(kI32Block) void istft32_kernel(IstftArgs a, int fra
 constexpr int kGenBlock = 256;
 
 // in-place-looking wrapper: data starts in buf0, result ends in the returned buffer.  DIR = -1 forward, +1 backward.
+// Radix-4 autosort passes and one closing radix-2 pass (N = 2 * 4^k: four + one at 512, five + one at 2048; the first version
+// ran nine / eleven radix-2 passes with the twiddles read from global memory), tw = the half-length table in LDS,
+// W^(m + N/2) = -W^m.
 template <int DIR>
 __device__ __forceinline__ cd *stockham(cd *buf0, cd *buf1, const f64x2 *tw, int tid) {
     cd *in = buf0, *out = buf1;
-    for (int ns = 1; ns < kN; ns <<= 1) {
+    auto twd = [&](int m) -> cd {
+        const f64x2 w = tw[m & (kN / 2 - 1)];
+        const double sg = (m & (kN / 2)) ? -1.0 : 1.0;
+        return cd{sg * w.x, DIR < 0 ? sg * w.y : -sg * w.y};
+    };
+    int ns = 1;
+    for (; ns * 4 <= kN; ns <<= 2) {
+        for (int j = tid; j < kN / 4; j += kGenBlock) {
+            const int k = j & (ns - 1);
+            const int st = k * (kN / (4 * ns));
+            const cd a0 = in[j];
+            const cd a1 = in[j + kN / 4] * twd(st);
+            const cd a2 = in[j + kN / 2] * twd(2 * st);
+            const cd a3 = in[j + 3 * kN / 4] * twd(3 * st);
+            const cd s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+            const cd r13 = DIR < 0 ? cd{d13.y, -d13.x} : cd{-d13.y, d13.x};  // -i d13 (forward) / +i d13 (backward)
+            const int j0 = ((j - k) << 2) + k;
+            out[j0] = s02 + s13;
+            out[j0 + ns] = d02 + r13;
+            out[j0 + 2 * ns] = s02 - s13;
+            out[j0 + 3 * ns] = d02 - r13;
+        }
+        __syncthreads();
+        cd *t = in; in = out; out = t;
+    }
+    if (ns < kN) {
         for (int j = tid; j < kN / 2; j += kGenBlock) {
             const int k = j & (ns - 1);
-            const f64x2 w0 = tw[k * (kN / (2 * ns))];          // exp(-2 pi i k / (2 ns))
-            const cd w{w0.x, DIR < 0 ? w0.y : -w0.y};
-            const cd a = in[j], b = in[j + kN / 2] * w;
+            const cd a = in[j], b = in[j + kN / 2] * twd(k * (kN / (2 * ns)));
             const int j0 = ((j - k) << 1) + k;
             out[j0] = a + b;
             out[j0 + ns] = a - b;
@@ -613,7 +639,15 @@ __device__ __forceinline__ cd *stockham(cd *buf0, cd *buf1, const f64x2 *tw, int
 template <int LAYOUT>
 __global__ __launch_bounds__(kGenBlock) void stft_generic_kernel(StftArgs a) {
     __shared__ cd s_a[kN], s_b[kN];
+    // twiddle table in LDS (4 KB at N = 512, 16 KB at N = 2048: measured better than reading it through L1 there too, 5.52 vs 5.68 ms per mvdr batch)
+    constexpr bool kTwLds = true;
+    __shared__ f64x2 s_twl[kTwLds ? kN / 2 : 1];
     const int tid = threadIdx.x;
+    if (kTwLds) {
+        for (int i = tid; i < kN / 2; i += kGenBlock) s_twl[i] = a.tw[i];
+        __syncthreads();
+    }
+    const f64x2 *s_tw = kTwLds ? s_twl : a.tw;
     const int M = a.n_mics, MF = a.n_fft_mics, NP = (MF + 1) >> 1;
     const long total = (long)a.n_streams * a.n_frames * NP;
     for (long item = blockIdx.x; item < total; item += gridDim.x) {
@@ -646,7 +680,7 @@ __global__ __launch_bounds__(kGenBlock) void stft_generic_kernel(StftArgs a) {
             s_a[n] = cd{(double)va * h, b_ok ? (double)vb * h : 0.0};   // buf[j]*hann_win[i]  (util.h:235)
         }
         __syncthreads();
-        const cd *res = stockham<-1>(s_a, s_b, a.tw, tid);
+        const cd *res = stockham<-1>(s_a, s_b, s_tw, tid);
         const long zoff = (((long)s * a.frames_ws + a.frame_off + t) * NP + p) * kN;
         for (int k = tid; k < kN; k += kGenBlock) {
             if (a.z48)
@@ -670,13 +704,21 @@ __device__ __forceinline__ cd herm_gen(const f64x2 *row, int k) {
 // one frame per block: backward transform + synthesis window, windowed frame to a.frames (float, reference rounding)
 __global__ __launch_bounds__(kGenBlock) void istft_generic_kernel(IstftArgs a) {
     __shared__ cd s_a[kN], s_b[kN];
+    // twiddle table in LDS (4 KB at N = 512, 16 KB at N = 2048: measured better than reading it through L1 there too, 5.52 vs 5.68 ms per mvdr batch)
+    constexpr bool kTwLds = true;
+    __shared__ f64x2 s_twl[kTwLds ? kN / 2 : 1];
     const int tid = threadIdx.x;
+    if (kTwLds) {
+        for (int i = tid; i < kN / 2; i += kGenBlock) s_twl[i] = a.tw[i];
+        __syncthreads();
+    }
+    const f64x2 *s_tw = kTwLds ? s_twl : a.tw;
     const long total = (long)a.n_streams * a.n_frames;
     for (long f = blockIdx.x; f < total; f += gridDim.x) {
         const f64x2 *row = a.Yh + f * kYhStride;
         for (int k = tid; k < kN; k += kGenBlock) s_a[k] = herm_gen(row, k);
         __syncthreads();
-        const cd *res = stockham<+1>(s_a, s_b, a.tw, tid);
+        const cd *res = stockham<+1>(s_a, s_b, s_tw, tid);
         float *fo = a.frames + f * kN;
         for (int n = tid; n < kN; n += kGenBlock) {
             float v = (float)(res[n].x / (double)kN);            // util.h:249
