@@ -101,3 +101,40 @@ def test_shared_forward_transforms_at_the_baseline_size():
         b1.process_device(xd.data_ptr(), F, y1.data_ptr())
         torch.cuda.synchronize()
         assert _same(yd[d].cpu().numpy(), y1[0].cpu().numpy(), np.float32(0.5))
+
+
+def test_block_per_direction_path_still_serves_many_directions():
+    """BF_DAS_SHARED_DIRS=0 (read once per process, hence a child): eight directions through das_fused_kernel, one block per
+    direction, against the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, json, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import torch, oracle
+from beamform_amd.capi import Beamformer
+from beamform_amd.params import make_params
+from beamform_amd.synth import make_scene
+from conftest import rel_l2
+M, F, D = 8, 40, 8
+p = make_params("das", n_mics=M, theta=0.0)
+x = make_scene(M, F, seed=1500)
+thetas = [float(v) for v in np.linspace(-160.0, 160.0, D)]
+bf = Beamformer(p, n_dirs=D); bf.set_thetas(thetas)
+xd = torch.from_numpy(x).cuda()
+yd = torch.empty((D, F * 512), dtype=torch.float32, device="cuda")
+bf.process_device(xd.data_ptr(), F, yd.data_ptr()); torch.cuda.synchronize()
+y = yd.cpu().numpy()
+worst = 0.0
+for d in (0, 3, 7):
+    y_ref, _ = oracle.OracleNode(dict(p, theta=thetas[d])).process(x)
+    worst = max(worst, rel_l2(y[d], y_ref))
+print("RESULT " + json.dumps({"worst": worst}))
+""" % (root, root)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BF_DAS_SHARED_DIRS="0"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res["worst"] < TOL_TIME, res
