@@ -1,0 +1,312 @@
+// das_f64_w64.hip -- das at the reference's precision (double arithmetic, das.cpp:47-70 + util.h:217-314), one launch,
+// one full wavefront per frame.
+//
+// Formulation as das_f64_fused_kernel (stft_istft.hip): per frame four packed forward FFT-1024 (two real microphones each),
+// S += D_p Z_p with the Hermitian-part pair gains (geometry.hpp das_pair_gains_t, 1/N folded in), one backward transform,
+// (float)Re, float x double window, float overlap-add.  What differs is the mapping onto the chip:
+//
+//   * 64 lanes x 16 points per lane (fft1024_w64.hpp, 16 x 16 x 4) instead of 32 lanes x 32 points: 64 data + 64 accumulator
+//     registers, so TWO wavefronts share a SIMD (the 32 x 32 kernel needs 256 + 206 registers and runs one wavefront per SIMD
+//     with ~1 000 v_accvgpr moves per frame).  A lone wavefront issues one vector instruction per 4 cycles and has nobody to
+//     hide its LDS round trips behind; two fill each other's gaps and the non-fp64 instructions issue at 2 cycles.
+//   * a 512-thread block per CU walks a run of consecutive frames, 8 per step (wavefront w: frame T0 + 8 it + w).  First-pass
+//     lane = sample, so every global load is one contiguous 256-byte row; the hop two consecutive frames share is fetched by two
+//     wavefronts of the same CU within one step (L1 / L2), so each sample leaves HBM once (the 32 x 32 kernel re-read the shared
+//     hop a frame later and moved 1.96 x the algorithmic bytes).
+//   * overlap-add partner without a block barrier: wavefront w parks the second half of its frame in the head of its OWN
+//     exchange plane (free between its backward transform and the first exchange of its next frame) and raises ready[w];
+//     wavefront w + 1 adds it to its first half and raises cons[w], which w checks before it reuses the plane.  The tail that
+//     crosses a step (7 -> 0) has two slots of its own.  Run boundaries: two float atomic adds into a hop zeroed beforehand
+//     (prepare_das_f64_w64), bit-exact because a + b == b + a.
+//
+// LDS (159 KB): 16 KB twiddles W1024^(k1 lane) + 1 KB tw2' + 8 x 8.1 KB exchange planes (16 rows x 65 doubles, one scalar plane
+// per wavefront: real parts, then imaginary parts) + 64 KB pair gains + 4 KB step-crossing tails + 9 KB window rows.  Exchange layout: see
+// fft1024_w64.hpp w64_col_rot (every ds_read_b64 / ds_write_b64 group lands on distinct bank pairs).
+#include <hip/hip_runtime.h>
+
+#include "fft1024.hpp"
+#include "fft1024_w64.hpp"
+#include "pipeline_kernels.hpp"
+
+namespace bf {
+
+namespace {
+
+constexpr int kBlock = 512;
+constexpr int kWaves = kBlock / 64;
+constexpr int kHop = 512;
+constexpr int kRS = 65;             // doubles per exchange-plane row (odd: rows k1 = 0..15 start on distinct bank pairs)
+constexpr int kPlaneD = 16 * kRS;   // doubles per wavefront
+// LDS map, in doubles
+constexpr int oTw = 0;                          // 1024 + 64 complex
+constexpr int oPlane = 2 * (1024 + 64);
+constexpr int oGain = oPlane + kWaves * kPlaneD;
+constexpr int oCross = oGain + 4 * 2048;        // 2 x 512 floats
+constexpr int oFlag = oCross + 512;             // 2 x 8 ints
+constexpr int kWinRow = 18;                     // window as [lane][j] rows of 16 doubles + 2: the 16 lanes of a ds_read_b128 group start 9 bank quads apart
+constexpr int oWin = oFlag + 8;
+constexpr int kLdsD = oWin + 64 * kWinRow;
+
+typedef volatile __attribute__((address_space(3))) int *lds_flag_t;
+
+// ---- T2: 4 x 4 transpose across the four 16-lane rows, for doubles (two dwords each) --------------------------------------
+// v_permlane32_swap a, b: rows {2,3} of a <-> rows {0,1} of b;  v_permlane16_swap a, b: odd rows of a <-> even rows of b (lane
+// semantics checked on the device by tools/ubench/permswap.hip; inline asm for the reason given in das_fused_w64.hip).  One block
+// moves the low and the high dwords of four doubles: the four independent swaps between a register's two swaps cover the wait
+// states a swap needs behind the instruction that wrote its operand; the leading s_nop covers the VALU in front of the block.
+__device__ __forceinline__ void row_transpose4(double &d0, double &d1, double &d2, double &d3) {
+    unsigned l0 = (unsigned)__double2loint(d0), l1 = (unsigned)__double2loint(d1), l2 = (unsigned)__double2loint(d2), l3 = (unsigned)__double2loint(d3);
+    unsigned h0 = (unsigned)__double2hiint(d0), h1 = (unsigned)__double2hiint(d1), h2 = (unsigned)__double2hiint(d2), h3 = (unsigned)__double2hiint(d3);
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"
+        "v_permlane32_swap_b32 %4, %6\n\tv_permlane32_swap_b32 %5, %7\n\t"
+        "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+        "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7"
+        : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3), "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3));
+    d0 = __hiloint2double((int)h0, (int)l0);
+    d1 = __hiloint2double((int)h1, (int)l1);
+    d2 = __hiloint2double((int)h2, (int)l2);
+    d3 = __hiloint2double((int)h3, (int)l3);
+}
+constexpr int brev2c(int i) { return ((i & 1) << 1) | ((i >> 1) & 1); }
+
+// T2: position brev2(g) + 4*brev2(q) (row b)  <->  register 4*g + b (row q)   (as das_fused_w64.hip)
+template <bool FWD>
+__device__ __forceinline__ void w64_T2(double (&re)[16], double (&im)[16]) {
+    double nr[16], ni[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        double r[4], s[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int src = FWD ? brev2c(g) + 4 * brev2c(c) : 4 * g + c;
+            r[c] = re[src];
+            s[c] = im[src];
+        }
+        row_transpose4(r[0], r[1], r[2], r[3]);
+        row_transpose4(s[0], s[1], s[2], s[3]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int dst = FWD ? 4 * g + c : brev2c(g) + 4 * brev2c(c);
+            nr[dst] = r[c];
+            ni[dst] = s[c];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        re[i] = nr[i];
+        im[i] = ni[i];
+    }
+}
+
+// ---- T1 through one scalar plane (real parts, then imaginary parts) -----------------------------------------------------------
+// forward: position i (k1 = brev4(i)) of lane 4a+b -> register position (a + 4 b) & 15 of lane 16 b + k1.  LDS operations of one
+// wavefront execute in issue order: only compiler barriers separate the phases.
+__device__ __forceinline__ void T1_fwd(double (&re)[16], double (&im)[16], double *wcol, const double *row16) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wcol[brev4(i) * kRS] = re[i];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) re[c] = row16[c];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wcol[brev4(i) * kRS] = im[i];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) im[c] = row16[c];
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void T1_inv(double (&re)[16], double (&im)[16], double *row16, const double *wcol) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) row16[c] = re[c];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) re[i] = wcol[brev4(i) * kRS];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) row16[c] = im[c];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) im[i] = wcol[brev4(i) * kRS];
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(kBlock) void das_f64_w64_kernel(DasF64Args a, int frames_per_chunk, int chunks_per_stream) {
+    __shared__ __attribute__((aligned(16))) double lds[kLdsD];
+    const cx<double> *s_tw1 = reinterpret_cast<const cx<double> *>(lds + oTw);
+    const cx<double> *s_tw2 = s_tw1 + 1024;
+    const cx<double> *s_gain = reinterpret_cast<const cx<double> *>(lds + oGain);
+    float *s_cross = reinterpret_cast<float *>(lds + oCross);
+    lds_flag_t s_ready = (lds_flag_t)(lds + oFlag);
+    lds_flag_t s_cons = s_ready + kWaves;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: frame index, pointers and the flag protocol stay in SGPRs
+    const int M = a.n_mics, NP = (M + 1) >> 1;
+    double *plane = lds + oPlane + w * kPlaneD;
+    double *wcol = plane + w64_col_rot(lane);                       // first-pass lane 4a+b: its column of every row
+    double *row16 = plane + (lane & 15) * kRS + 16 * (lane >> 4);   // second-pass lane (b, k1): its segment of row k1
+
+    const int stream = blockIdx.x / chunks_per_stream;
+    const long c_in_s = blockIdx.x - (long)stream * chunks_per_stream;
+    {
+        const double *twf = reinterpret_cast<const double *>(a.tw);
+        for (int i = tid; i < 2 * (1024 + 64); i += kBlock) lds[oTw + i] = twf[i];
+        const double *gf = reinterpret_cast<const double *>(a.gains);
+        for (int i = tid; i < NP * 2048; i += kBlock) lds[oGain + i] = gf[i];
+        for (int i = tid; i < 1024; i += kBlock) lds[oWin + (i & 63) * kWinRow + (i >> 6)] = a.win[i];
+        if (tid < 2 * kWaves) s_ready[tid] = -2;
+    }
+    __syncthreads();
+    // window[64 j + lane], j = 0..15: both windows of the frame (util.h:235,250) touch the same 16 values of this lane's row
+    const double *wrow = lds + oWin + lane * kWinRow;
+
+    const long T0 = c_in_s * frames_per_chunk;
+    long T1 = T0 + frames_per_chunk;
+    if (T1 > a.n_frames) T1 = a.n_frames;
+    const float *xs = a.x + (long)stream * a.stream_stride_x;
+    const float *hs = a.hist + (long)stream * M * kHop;
+    float *ys = a.y + (long)stream * a.n_frames * kHop;
+
+    // raw samples of pair p of frame tt (hop tt-1 | hop tt; hop -1 = the carried hop): register j <- sample 64 j + lane
+    float na[16], nb[16];
+    auto request = [&](long tt, int p) {
+        const int ma = 2 * p, mb = (2 * p + 1 < M) ? 2 * p + 1 : ma;
+        const float *a1 = tt >= 1 ? xs + (long)ma * a.mic_stride + (tt - 1) * kHop : hs + ma * kHop;
+        const float *b1 = tt >= 1 ? xs + (long)mb * a.mic_stride + (tt - 1) * kHop : hs + mb * kHop;
+        const float *a2 = xs + (long)ma * a.mic_stride + tt * kHop;
+        const float *b2 = xs + (long)mb * a.mic_stride + tt * kHop;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {  // scalar base + this lane's 32-bit offset
+            na[j] = a1[(unsigned)(64 * j + lane)];
+            nb[j] = b1[(unsigned)(64 * j + lane)];
+            na[j + 8] = a2[(unsigned)(64 * j + lane)];
+            nb[j + 8] = b2[(unsigned)(64 * j + lane)];
+        }
+    };
+
+    const int n_iter = (int)((T1 - T0 + kWaves - 1) / kWaves);
+    if (T0 + w < T1) request(T0 + w, 0);
+    for (int it = 0; it < n_iter; ++it) {
+        const long t = T0 + (long)it * kWaves + w;
+        if (t >= T1) break;  // wavefront-uniform; no block barrier below
+
+        double Sr[16], Si[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Sr[r] = Si[r] = 0.0;
+        for (int p = 0; p < NP; ++p) {
+            double re[16], im[16];
+            const bool b_ok = 2 * p + 1 < M;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                re[j] = (double)na[j] * wrow[j];  // buf[j]*hann_win[i]  (util.h:235)
+                im[j] = b_ok ? (double)nb[j] * wrow[j] : 0.0;
+            }
+            if (p + 1 < NP)  // next pair (or the next frame's first one): in flight during this transform
+                request(t, p + 1);
+            else if (t + kWaves < T1)
+                request(t + kWaves, 0);
+            w64_fwd_p1<double>(re, im, lane, s_tw1);
+            if (p == 0 && it > 0 && w < kWaves - 1)  // the plane's head still holds the last frame's tail until w + 1 has taken it
+                while (s_cons[w] < (int)(t - kWaves)) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            T1_fwd(re, im, wcol, row16);
+            w64_fwd_p2<double>(re, im, lane, s_tw2);
+            w64_T2<true>(re, im);
+            w64_fwd_p3<double>(re, im);
+            const cx<double> *gp = s_gain + p * 1024 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const cx<double> g = gp[64 * r];
+                Sr[r] = fma(-g.y, im[r], fma(g.x, re[r], Sr[r]));
+                Si[r] = fma(g.y, re[r], fma(g.x, im[r], Si[r]));
+            }
+        }
+        w64_inv_p3<double>(Sr, Si);
+        w64_T2<false>(Sr, Si);
+        w64_inv_p2<double>(Sr, Si, lane, s_tw2);
+        T1_inv(Sr, Si, row16, wcol);
+        w64_inv_p1<double>(Sr, Si, lane, s_tw1);
+
+        // register j holds sample n = 64 j + lane (j < 8: first half, j >= 8: second half); util.h:247-252 with the float stores
+        float o[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float f = (float)Sr[j];               // (float)(Re / N): 1/N is inside the gains
+            o[j] = (float)((double)f * wrow[j]);        // o *= hann_win[n]
+        }
+        const int pw = (w + kWaves - 1) & (kWaves - 1);
+        if (t + 1 < T1) {  // the next frame of this run takes my second half
+            float *area = (w < kWaves - 1) ? reinterpret_cast<float *>(plane) : s_cross + (it & 1) * kHop;
+            if (w == kWaves - 1 && it >= 2)  // the slot's previous tail (two steps back) must have been taken: it has, long ago
+                while (s_cons[w] < (int)(t - 2 * kWaves)) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 8; ++j) area[64 * j + lane] = o[j + 8];
+            asm volatile("" ::: "memory");
+            if (lane == 0) s_ready[w] = (int)t;  // LDS operations of a wavefront complete in order: the tail is there first
+        }
+        float *yo = ys + t * kHop;
+        if (t == T0) {
+            if (T0 == 0) {  // stream start: the partner is the carried state (out_buff[0] of the previous call)
+                const float *ti = a.tail_in + (long)stream * kHop;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) yo[(unsigned)(64 * j + lane)] = ti[(unsigned)(64 * j + lane)] + o[j];
+            } else {  // first hop of a run: the previous run adds its half separately, both into a zeroed hop
+#pragma unroll
+                for (int j = 0; j < 8; ++j) atomicAdd(yo + (unsigned)(64 * j + lane), o[j]);
+            }
+        } else {
+            const float *parea = (pw < kWaves - 1) ? reinterpret_cast<const float *>(lds + oPlane + pw * kPlaneD) : s_cross + ((it + 1) & 1) * kHop;
+            while (s_ready[pw] < (int)(t - 1)) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            float prev[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) prev[j] = parea[64 * j + lane];
+            asm volatile("" ::: "memory");
+            if (lane == 0) s_cons[pw] = (int)(t - 1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) yo[(unsigned)(64 * j + lane)] = prev[j] + o[j];  // out_buff[0][j] + out_buff[1][j] as floats (util.h:302)
+        }
+        if (t == T1 - 1) {
+            if (T1 < a.n_frames) {  // last frame of the run: its second half belongs to the next run's first hop
+                float *yn = ys + T1 * kHop;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) atomicAdd(yn + (unsigned)(64 * j + lane), o[j + 8]);
+            } else {  // end of the batch: carried state for the next call
+                float *to = a.tail_out + (long)stream * kHop;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) to[(unsigned)(64 * j + lane)] = o[j + 8];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// frames per run: a multiple of 8 (one step of the block), about one run per CU
+static void das_f64_w64_runs(const DasF64Args &a, int n_cus, long *fpc, long *cps) {
+    long runs = (long)n_cus / a.n_streams;
+    if (runs < 1) runs = 1;
+    long f = (a.n_frames + runs - 1) / runs;
+    f = ((f + kWaves - 1) / kWaves) * kWaves;
+    *fpc = f;
+    *cps = (a.n_frames + f - 1) / f;
+}
+
+hipError_t launch_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s) {
+    if (a.n_mics > 8) return hipErrorNotSupported;  // the four pair-gain tables fill the LDS
+    long fpc, cps;
+    das_f64_w64_runs(a, n_cus, &fpc, &cps);
+    if (cps > 1)  // the first hop of every run but the first of a stream is completed by atomic adds: zero beforehand
+        for (int st = 0; st < a.n_streams; ++st) {
+            hipError_t e = hipMemset2DAsync(a.y + ((long)st * a.n_frames + fpc) * kHop, (size_t)fpc * kHop * sizeof(float), 0,
+                                            kHop * sizeof(float), (size_t)cps - 1, s);
+            if (e != hipSuccess) return e;
+        }
+    hipLaunchKernelGGL(das_f64_w64_kernel, dim3((unsigned)(cps * a.n_streams)), dim3(kBlock), 0, s, a, (int)fpc, (int)cps);
+    return hipGetLastError();
+}
+
+}  // namespace bf

@@ -88,6 +88,14 @@ BF_HD void fft4(T &r0, T &i0, T &r1, T &i1, T &r2, T &i2, T &r3, T &i3) {
 // column of the T1 plane that first-pass lane 4a+b exchanges with the second-pass lanes: 16 b + a
 constexpr int w64_col(int lane) { return 16 * (lane & 3) + (lane >> 2); }
 
+// fp64 kernel (das_f64_w64.hip): the same exchange with segment b of every row rotated by 4 b columns, col = 16 b + ((a + 4 b) & 15).
+// With 8-byte elements the plain map puts the 16 lanes of a ds_write_b64 group (a = 4 g .. 4 g + 3, every b) on 4 bank pairs
+// (4-way conflict); rotated, they cover all 16.  The second-pass lane (b, k1) then holds first-pass lane a at register position
+// (a + 4 b) & 15: a circular shift of the input of its 16-point transform, i.e. a factor W16^(4 b k2) on output k2, which the
+// TW2 table absorbs: tw2'[b][k2] = W64^(b k2) conj(W16^(4 b k2)) = exp(2 pi i 15 b k2 / 64) (geometry.hpp twiddle_table_w64_rot).
+// The backward transform multiplies by conj(tw2') and so leaves its output shifted the same way: the same table serves both.
+constexpr int w64_col_rot(int lane) { return 16 * (lane & 3) + (((lane >> 2) + 4 * (lane & 3)) & 15); }
+
 // forward P1 + TW1.  in: reg j = x[64*j + lane].  out: position i holds A[k1 = brev4(i)] * W1024^(lane*k1)
 template <typename T, typename TW>
 BF_HD void w64_fwd_p1(T (&re)[16], T (&im)[16], int lane, const TW *tw1 /* [k1][lane] = W1024^(lane*k1) */) {

@@ -209,4 +209,33 @@ inline std::vector<f32x2> twiddle_table_w64() {
     return t;
 }
 
+// fp64 tables of the 64-lane factorisation with the rotated exchange (fft1024_w64.hpp w64_col_rot; das_f64_w64.hip):
+// [0, 1024) = W1024^(k1*lane) as [k1][lane]; [1024, 1088) = tw2'[b][k2] = exp(2 pi i 15 b k2 / 64)
+inline std::vector<f64x2> twiddle_table_w64_rot() {
+    std::vector<f64x2> t(1024 + 64);
+    for (int k = 0; k < 16; ++k)
+        for (int l = 0; l < 64; ++l) {
+            const double a = -2.0 * kPi * (double)(k * l) / 1024.0;
+            t[k * 64 + l] = f64x2{std::cos(a), std::sin(a)};
+        }
+    for (int b = 0; b < 4; ++b)
+        for (int k = 0; k < 16; ++k) {
+            const double a = 2.0 * kPi * (double)((15 * b * k) % 64) / 64.0;
+            t[1024 + b * 16 + k] = f64x2{std::cos(a), std::sin(a)};
+        }
+    return t;
+}
+// das_pair_gains_t<f64x2> (32 x 32 order) -> [pair][register r][lane] = D_p[w64_bin(lane, r)]
+inline std::vector<f64x2> das_pair_gains_w64_f64(const std::vector<f64x2> &D32, int n_pairs) {
+    std::vector<f64x2> D((size_t)n_pairs * 1024);
+    std::vector<f64x2> nat(1024);
+    for (int p = 0; p < n_pairs; ++p) {
+        for (int i = 0; i < 32; ++i)
+            for (int l = 0; l < 32; ++l) nat[l + 32 * brev5(i)] = D32[((size_t)p * 32 + i) * 32 + l];
+        for (int r = 0; r < 16; ++r)
+            for (int l = 0; l < 64; ++l) D[((size_t)p * 16 + r) * 64 + l] = nat[w64_bin(l, r)];
+    }
+    return D;
+}
+
 }  // namespace bf

@@ -112,8 +112,13 @@ class BinPipelineImpl : public BinPipeline {
         PIPE_HIP(hipMemcpy(d_freq_, freqs_.data(), N_ * sizeof(double), hipMemcpyHostToDevice));
         for (int i = 0; i < 2; ++i)
             PIPE_HIP(hipMalloc((void **)&d_steer_[i], steer_bytes()));
-        if (das_one_launch_shape())
+        if (das_one_launch_shape()) {
             for (int i = 0; i < 2; ++i) PIPE_HIP(hipMalloc((void **)&d_dasg_[i], (size_t)4 * 1024 * sizeof(f64x2)));
+            for (int i = 0; i < 2; ++i) PIPE_HIP(hipMalloc((void **)&d_dasg_w64_[i], (size_t)4 * 1024 * sizeof(f64x2)));
+            const std::vector<f64x2> tw64 = twiddle_table_w64_rot();
+            PIPE_HIP(hipMalloc((void **)&d_tw_w64_, tw64.size() * sizeof(f64x2)));
+            PIPE_HIP(hipMemcpy(d_tw_w64_, tw64.data(), tw64.size() * sizeof(f64x2), hipMemcpyHostToDevice));
+        }
         PIPE_HIP(hipMalloc((void **)&d_hist_, (size_t)S_ * M_ * H_ * sizeof(float)));
         PIPE_HIP(hipMalloc((void **)&d_tail_[0], (size_t)So_ * H_ * sizeof(float)));
         PIPE_HIP(hipMalloc((void **)&d_tail_[1], (size_t)So_ * H_ * sizeof(float)));
@@ -157,10 +162,12 @@ class BinPipelineImpl : public BinPipeline {
                         t[(((size_t)d * nc + c) * M_ + m) * N_ + j] = f64x2{w.real(), w.imag()};
                     }
         const int nxt = steer_cur_ ^ 1;
-        std::vector<f64x2> dg;  // das fp64 in one launch: the pair gains of the (single) look direction, same double buffering
+        std::vector<f64x2> dg, dg64;  // das fp64 in one launch: the pair gains of the (single) look direction, same double buffering
         if (das_one_launch_shape()) {
             dg = das_pair_gains_t<f64x2>(dirs[0], 4);
+            dg64 = das_pair_gains_w64_f64(dg, 4);
             PIPE_HIP(hipMemcpyAsync(d_dasg_[nxt], dg.data(), dg.size() * sizeof(f64x2), hipMemcpyHostToDevice, stream));
+            PIPE_HIP(hipMemcpyAsync(d_dasg_w64_[nxt], dg64.data(), dg64.size() * sizeof(f64x2), hipMemcpyHostToDevice, stream));
         }
         PIPE_HIP(hipMemcpyAsync(d_steer_[nxt], t.data(), t.size() * sizeof(f64x2), hipMemcpyHostToDevice, stream));
         PIPE_HIP(hipStreamSynchronize(stream));  // `t` is pageable and about to go out of scope
@@ -182,6 +189,7 @@ class BinPipelineImpl : public BinPipeline {
         sn.steer = d_steer_[steer_cur_];
         sn.steer_dir_stride = steer_dir_stride_;
         sn.das_gains = d_dasg_[steer_cur_];
+        sn.das_gains_w64 = d_dasg_w64_[steer_cur_];
         gss_reset_mask_ = 0;
         return sn;
     }
@@ -243,7 +251,7 @@ class BinPipelineImpl : public BinPipeline {
     }
 
     void free_all() {
-        void *ptrs[] = {d_dasg_[0], d_dasg_[1], d_tw32_, d_tw_, d_win_, d_freq_, d_steer_[0], d_steer_[1], d_hist_, d_tail_[0], d_tail_[1], d_zhist_,
+        void *ptrs[] = {d_dasg_[0], d_dasg_[1], d_dasg_w64_[0], d_dasg_w64_[1], d_tw_w64_, d_tw32_, d_tw_, d_win_, d_freq_, d_steer_[0], d_steer_[1], d_hist_, d_tail_[0], d_tail_[1], d_zhist_,
                         d_gssW_, d_mpf_, d_smooth_, d_nlms_, d_Z_, d_Yh_, d_yraw_, d_frames_};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
@@ -262,6 +270,8 @@ class BinPipelineImpl : public BinPipeline {
     double *d_win_ = nullptr, *d_freq_ = nullptr;
     f64x2 *d_steer_[2] = {nullptr, nullptr};
     f64x2 *d_dasg_[2] = {nullptr, nullptr};  // das_pair_gains_t<f64x2> of look direction 0 (das_one_launch_shape)
+    f64x2 *d_dasg_w64_[2] = {nullptr, nullptr};  // das_pair_gains_w64_f64 of the same
+    f64x2 *d_tw_w64_ = nullptr;                  // twiddle_table_w64_rot
     int steer_cur_ = 0;
     float *d_hist_ = nullptr;
     float *d_tail_[2] = {nullptr, nullptr};
@@ -296,7 +306,10 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
         da.x = x; da.hist = d_hist_; da.y = y; da.tail_in = d_tail_[tail_cur_]; da.tail_out = d_tail_[tail_cur_ ^ 1];
         da.gains = snap.das_gains; da.tw = d_tw_; da.win = d_win_; da.n_frames = F; da.mic_stride = mic_stride;
         da.stream_stride_x = (long)M_ * F * H_; da.n_streams = S_; da.n_mics = M_; da.run_len = 1;
-        const hipError_t de = ks_->das_f64(da, n_cus_, stream);
+        // BF_DAS_F64_W64=0: the 32 x 32 half-wavefront kernel (das_f64_fused_kernel) instead of the 64-lane one
+        static const int w64 = getenv("BF_DAS_F64_W64") ? atoi(getenv("BF_DAS_F64_W64")) : 1;
+        if (w64 && snap.das_gains_w64 != nullptr) { da.gains = snap.das_gains_w64; da.tw = d_tw_w64_; }
+        const hipError_t de = (w64 && snap.das_gains_w64 != nullptr) ? launch_das_f64_w64(da, n_cus_, stream) : ks_->das_f64(da, n_cus_, stream);
         if (de == hipSuccess) {
             PIPE_HIP(hipMemcpy2DAsync(d_hist_, H_ * sizeof(float), x + (F - 1) * H_, (size_t)mic_stride * sizeof(float),
                                       H_ * sizeof(float), (size_t)S_ * M_, hipMemcpyDeviceToDevice, stream));  // ring-buffer carry (util.h:305-308)

@@ -66,21 +66,30 @@ inline int brev2(int i) { return ((i & 1) << 1) | ((i >> 1) & 1); }
 
 // T1 forward: reg-position i (k1 = brev4(i)), lane 4a+b  ->  reg a, lane 16b+k1.  The writer stores at row k1, column
 // w64_col(lane) = 16 b + a; the reader takes columns 16 b .. 16 b + 15 of row (lane & 15).
-template <typename T>
+// ROT: the fp64 kernel's exchange (w64_col_rot: segment b rotated by 4 b columns; the reader still takes its segment as it lies)
+template <typename T, bool ROT = false>
 void w64_T1_fwd(T (*re)[16], T (*im)[16]) {
     static T br[16 * kRS64], bi[16 * kRS64];
     for (int l = 0; l < 64; ++l)
-        for (int i = 0; i < 16; ++i) { br[brev4(i) * kRS64 + w64_col(l)] = re[l][i]; bi[brev4(i) * kRS64 + w64_col(l)] = im[l][i]; }
+        for (int i = 0; i < 16; ++i) {
+            const int c = ROT ? w64_col_rot(l) : w64_col(l);
+            br[brev4(i) * kRS64 + c] = re[l][i];
+            bi[brev4(i) * kRS64 + c] = im[l][i];
+        }
     for (int l = 0; l < 64; ++l)
         for (int a = 0; a < 16; ++a) { re[l][a] = br[(l & 15) * kRS64 + 16 * (l >> 4) + a]; im[l][a] = bi[(l & 15) * kRS64 + 16 * (l >> 4) + a]; }
 }
-template <typename T>
+template <typename T, bool ROT = false>
 void w64_T1_inv(T (*re)[16], T (*im)[16]) {
     static T br[16 * kRS64], bi[16 * kRS64];
     for (int l = 0; l < 64; ++l)
         for (int a = 0; a < 16; ++a) { br[(l & 15) * kRS64 + 16 * (l >> 4) + a] = re[l][a]; bi[(l & 15) * kRS64 + 16 * (l >> 4) + a] = im[l][a]; }
     for (int l = 0; l < 64; ++l)
-        for (int i = 0; i < 16; ++i) { re[l][i] = br[brev4(i) * kRS64 + w64_col(l)]; im[l][i] = bi[brev4(i) * kRS64 + w64_col(l)]; }
+        for (int i = 0; i < 16; ++i) {
+            const int c = ROT ? w64_col_rot(l) : w64_col(l);
+            re[l][i] = br[brev4(i) * kRS64 + c];
+            im[l][i] = bi[brev4(i) * kRS64 + c];
+        }
 }
 // T2 forward: position g' + 4*brev2(q) at lane (row b, ..)  ->  register 4*g + b at lane (row q, ..); g' = brev2(g)
 template <typename T>
@@ -110,7 +119,7 @@ void w64_T2_inv(T (*re)[16], T (*im)[16]) {
     memcpy(im, ni, sizeof(ni));
 }
 
-template <typename T>
+template <typename T, bool ROT = false>
 void fft1024_w64_emul(const double *in, double *out, int dir) {
     std::vector<cx<T>> tw1(16 * 64), tw2(4 * 16);
     for (int k = 0; k < 16; ++k)
@@ -120,7 +129,7 @@ void fft1024_w64_emul(const double *in, double *out, int dir) {
         }
     for (int b = 0; b < 4; ++b)
         for (int k = 0; k < 16; ++k) {
-            double a = -2.0 * kPi * (b * k) / 64.0;
+            double a = ROT ? 2.0 * kPi * ((15 * b * k) % 64) / 64.0 : -2.0 * kPi * (b * k) / 64.0;  // twiddle_table_w64_rot
             tw2[b * 16 + k] = cx<T>{(T)std::cos(a), (T)std::sin(a)};
         }
     static T re[64][16], im[64][16];
@@ -129,7 +138,7 @@ void fft1024_w64_emul(const double *in, double *out, int dir) {
             for (int j = 0; j < 16; ++j) { re[l][j] = (T)in[2 * (64 * j + l)]; im[l][j] = (T)in[2 * (64 * j + l) + 1]; }
             w64_fwd_p1<T>(re[l], im[l], l, tw1.data());
         }
-        w64_T1_fwd<T>(re, im);
+        w64_T1_fwd<T, ROT>(re, im);
         for (int l = 0; l < 64; ++l) w64_fwd_p2<T>(re[l], im[l], l, tw2.data());
         w64_T2_fwd<T>(re, im);
         for (int l = 0; l < 64; ++l) {
@@ -143,7 +152,7 @@ void fft1024_w64_emul(const double *in, double *out, int dir) {
         }
         w64_T2_inv<T>(re, im);
         for (int l = 0; l < 64; ++l) w64_inv_p2<T>(re[l], im[l], l, tw2.data());
-        w64_T1_inv<T>(re, im);
+        w64_T1_inv<T, ROT>(re, im);
         for (int l = 0; l < 64; ++l) {
             w64_inv_p1<T>(re[l], im[l], l, tw1.data());
             for (int j = 0; j < 16; ++j) { out[2 * (64 * j + l)] = re[l][j]; out[2 * (64 * j + l) + 1] = im[l][j]; }
@@ -155,6 +164,8 @@ void fft1024_w64_emul(const double *in, double *out, int dir) {
 extern "C" void emul_fft1024_w64(const double *in, double *out, int dir, int use_float) {
     if (use_float) fft1024_w64_emul<float>(in, out, dir); else fft1024_w64_emul<double>(in, out, dir);
 }
+// the fp64 kernel's variant: rotated exchange + tw2' table (das_f64_w64.hip)
+extern "C" void emul_fft1024_w64_rot(const double *in, double *out, int dir) { fft1024_w64_emul<double, true>(in, out, dir); }
 
 extern "C" {
 

@@ -46,6 +46,12 @@ def test_emulated_fft1024_w64(emul_lib):
             emul_lib.emul_fft1024_w64(_ptr(x), _ptr(o), d, use_float)
             ref = np.fft.fft(x) if d < 0 else np.fft.ifft(x) * 1024
             assert rel_l2(o, ref) < tol
+    for d in (-1, 1):  # the fp64 kernel's exchange: segments rotated by 4 b columns, the shift absorbed by the tw2' table
+        x = rng.standard_normal(1024) + 1j * rng.standard_normal(1024)
+        o = np.empty(1024, np.complex128)
+        emul_lib.emul_fft1024_w64_rot(_ptr(x), _ptr(o), d)
+        ref = np.fft.fft(x) if d < 0 else np.fft.ifft(x) * 1024
+        assert rel_l2(o, ref) < 1e-14
 
 
 @pytest.mark.parametrize("M,theta", [(8, 20.0), (4, 0.0), (3, -75.0), (16, 135.0), (1, 0.0)])
