@@ -38,8 +38,9 @@ constexpr int kHop = 512;
 constexpr int kRS = 65;             // doubles per exchange-plane row (odd: rows k1 = 0..15 start on distinct bank pairs)
 constexpr int kPlaneD = 16 * kRS;   // doubles per wavefront
 // LDS map, in doubles
-constexpr int oTw = 0;                          // 1024 + 64 complex
-constexpr int oPlane = 2 * (1024 + 64);
+constexpr int kTwD = 2 * (1024 + 4 * kTw2RowW64Rot);  // 1024 + 4 x 17 complex (geometry.hpp twiddle_table_w64_rot)
+constexpr int oTw = 0;
+constexpr int oPlane = kTwD;
 constexpr int oGain = oPlane + kWaves * kPlaneD;
 constexpr int oCross = oGain + 4 * 2048;        // 2 x 512 floats
 constexpr int oFlag = oCross + 512;             // 2 x 8 ints
@@ -54,6 +55,28 @@ typedef volatile __attribute__((address_space(3))) int *lds_flag_t;
 // semantics checked on the device by tools/ubench/permswap.hip; inline asm for the reason given in das_fused_w64.hip).  One block
 // moves the low and the high dwords of four doubles: the four independent swaps between a register's two swaps cover the wait
 // states a swap needs behind the instruction that wrote its operand; the leading s_nop covers the VALU in front of the block.
+#ifndef BF_W64_SWAP_ASM
+__device__ __forceinline__ void swap32(unsigned &a, unsigned &b) {
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+__device__ __forceinline__ void swap16(unsigned &a, unsigned &b) {
+    auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+__device__ __forceinline__ void row_transpose4(double &d0, double &d1, double &d2, double &d3) {
+    unsigned l0 = (unsigned)__double2loint(d0), l1 = (unsigned)__double2loint(d1), l2 = (unsigned)__double2loint(d2), l3 = (unsigned)__double2loint(d3);
+    unsigned h0 = (unsigned)__double2hiint(d0), h1 = (unsigned)__double2hiint(d1), h2 = (unsigned)__double2hiint(d2), h3 = (unsigned)__double2hiint(d3);
+    swap32(l0, l2); swap32(l1, l3); swap32(h0, h2); swap32(h1, h3);
+    swap16(l0, l1); swap16(l2, l3); swap16(h0, h1); swap16(h2, h3);
+    d0 = __hiloint2double((int)h0, (int)l0);
+    d1 = __hiloint2double((int)h1, (int)l1);
+    d2 = __hiloint2double((int)h2, (int)l2);
+    d3 = __hiloint2double((int)h3, (int)l3);
+}
+#else
 __device__ __forceinline__ void row_transpose4(double &d0, double &d1, double &d2, double &d3) {
     unsigned l0 = (unsigned)__double2loint(d0), l1 = (unsigned)__double2loint(d1), l2 = (unsigned)__double2loint(d2), l3 = (unsigned)__double2loint(d3);
     unsigned h0 = (unsigned)__double2hiint(d0), h1 = (unsigned)__double2hiint(d1), h2 = (unsigned)__double2hiint(d2), h3 = (unsigned)__double2hiint(d3);
@@ -69,6 +92,7 @@ __device__ __forceinline__ void row_transpose4(double &d0, double &d1, double &d
     d2 = __hiloint2double((int)h2, (int)l2);
     d3 = __hiloint2double((int)h3, (int)l3);
 }
+#endif
 constexpr int brev2c(int i) { return ((i & 1) << 1) | ((i >> 1) & 1); }
 
 // T2: position brev2(g) + 4*brev2(q) (row b)  <->  register 4*g + b (row q)   (as das_fused_w64.hip)
@@ -103,18 +127,24 @@ __device__ __forceinline__ void w64_T2(double (&re)[16], double (&im)[16]) {
 // ---- T1 through one scalar plane (real parts, then imaginary parts) -----------------------------------------------------------
 // forward: position i (k1 = brev4(i)) of lane 4a+b -> register position (a + 4 b) & 15 of lane 16 b + k1.  LDS operations of one
 // wavefront execute in issue order: only compiler barriers separate the phases.
+// exchange reads as single ds_read_b64 (2 LDS cycles per 512 B): merged into ds_read2_b64 by the compiler they take 8 cycles per 1 KB
+#ifdef BF_T1_MERGED_READS
+#define BF_T1_RD(p) (*(p))
+#else
+#define BF_T1_RD(p) (*(const volatile __attribute__((address_space(3))) double *)(p))
+#endif
 __device__ __forceinline__ void T1_fwd(double (&re)[16], double (&im)[16], double *wcol, const double *row16) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) wcol[brev4(i) * kRS] = re[i];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int c = 0; c < 16; ++c) re[c] = row16[c];
+    for (int c = 0; c < 16; ++c) re[c] = BF_T1_RD(row16 + c);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < 16; ++i) wcol[brev4(i) * kRS] = im[i];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int c = 0; c < 16; ++c) im[c] = row16[c];
+    for (int c = 0; c < 16; ++c) im[c] = BF_T1_RD(row16 + c);
     __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ void T1_inv(double (&re)[16], double (&im)[16], double *row16, const double *wcol) {
@@ -122,14 +152,49 @@ __device__ __forceinline__ void T1_inv(double (&re)[16], double (&im)[16], doubl
     for (int c = 0; c < 16; ++c) row16[c] = re[c];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) re[i] = wcol[brev4(i) * kRS];
+    for (int i = 0; i < 16; ++i) re[i] = BF_T1_RD(wcol + brev4(i) * kRS);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int c = 0; c < 16; ++c) row16[c] = im[c];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) im[i] = wcol[brev4(i) * kRS];
+    for (int i = 0; i < 16; ++i) im[i] = BF_T1_RD(wcol + brev4(i) * kRS);
     __builtin_amdgcn_wave_barrier();
+}
+
+// ---- staged twiddle / gain access ------------------------------------------------------------------------------------------
+// The per-lane passes of fft1024_w64.hpp fetch each twiddle right where it is multiplied in; at 256 registers hipcc then keeps one or
+// two ds_read_b128 in flight and every fourth instruction waits a full LDS round trip (36 % of the wave cycles in s_waitcnt,
+// profiles/r04_a_das8_f64_w64_pmc.txt).  Here a pass's 15 twiddles (60 registers) are requested as a block BEFORE the 16-point
+// transform that precedes their use and are all there when it ends; sched_barrier keeps hipcc from sinking them back.
+#define BF_STAGE() __builtin_amdgcn_sched_barrier(0)
+
+// (two batches: 8 twiddles ahead of the transform, the other 7 requested when the multiplication starts and consumed last)
+template <int LO, int HI>
+__device__ __forceinline__ void load_tw1(cx<double> (&tw)[15], const cx<double> *s_tw1, int lane) {
+#pragma unroll
+    for (int i = LO; i < HI; ++i) tw[i - 1] = s_tw1[brev4(i) * 64 + lane];  // W1024^(lane * k1), k1 = brev4(i)
+}
+template <int LO, int HI>
+__device__ __forceinline__ void load_tw2(cx<double> (&tw)[15], const cx<double> *s_tw2, int lane) {
+    const cx<double> *row = s_tw2 + (lane >> 4) * kTw2RowW64Rot;
+#pragma unroll
+    for (int i = LO; i < HI; ++i) tw[i - 1] = row[brev4(i)];
+}
+template <bool CONJ, int LO, int HI>
+__device__ __forceinline__ void mul_tw(double (&re)[16], double (&im)[16], const cx<double> (&tw)[15]) {
+#pragma unroll
+    for (int i = LO; i < HI; ++i) {
+        const cx<double> w = tw[i - 1];
+        const double xr = re[i], xi = im[i];
+        if (!CONJ) {
+            re[i] = xr * w.x - xi * w.y;
+            im[i] = xr * w.y + xi * w.x;
+        } else {
+            re[i] = xr * w.x + xi * w.y;
+            im[i] = xi * w.x - xr * w.y;
+        }
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void das_f64_w64_kernel(DasF64Args a, int frames_per_chunk, int chunks_per_stream) {
@@ -152,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void das_f64_w64_kernel(DasF64Args a, int f
     const long c_in_s = blockIdx.x - (long)stream * chunks_per_stream;
     {
         const double *twf = reinterpret_cast<const double *>(a.tw);
-        for (int i = tid; i < 2 * (1024 + 64); i += kBlock) lds[oTw + i] = twf[i];
+        for (int i = tid; i < kTwD; i += kBlock) lds[oTw + i] = twf[i];
         const double *gf = reinterpret_cast<const double *>(a.gains);
         for (int i = tid; i < NP * 2048; i += kBlock) lds[oGain + i] = gf[i];
         for (int i = tid; i < 1024; i += kBlock) lds[oWin + (i & 63) * kWinRow + (i >> 6)] = a.win[i];
@@ -199,35 +264,85 @@ __global__ __launch_bounds__(kBlock) void das_f64_w64_kernel(DasF64Args a, int f
             double re[16], im[16];
             const bool b_ok = 2 * p + 1 < M;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                re[j] = (double)na[j] * wrow[j];  // buf[j]*hann_win[i]  (util.h:235)
-                im[j] = b_ok ? (double)nb[j] * wrow[j] : 0.0;
+            for (int j = 0; j < 16; ++j) re[j] = (double)na[j] * wrow[j];  // buf[j]*hann_win[i]  (util.h:235)
+            if (b_ok) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) im[j] = (double)nb[j] * wrow[j];
+            } else {  // odd microphone count: the last pair's second channel is silence
+#pragma unroll
+                for (int j = 0; j < 16; ++j) im[j] = 0.0;
             }
-            if (p + 1 < NP)  // next pair (or the next frame's first one): in flight during this transform
-                request(t, p + 1);
-            else if (t + kWaves < T1)
-                request(t + kWaves, 0);
-            w64_fwd_p1<double>(re, im, lane, s_tw1);
+            {  // next pair (or the next frame's first one; past the run's end: this frame's again, unused): in flight during this transform
+                long tn = t;
+                int pn = p + 1;
+                if (pn == NP) {
+                    pn = 0;
+                    if (t + kWaves < T1) tn = t + kWaves;
+                }
+                request(tn, pn);
+            }
+            cx<double> tw[15];
+            BF_STAGE();
+            load_tw1<1, 9>(tw, s_tw1, lane);  // lands during the first 16-point transform
+            BF_STAGE();
+            fft16_core<double, -1, true>(re, im);
+            BF_STAGE();
+            load_tw1<9, 16>(tw, s_tw1, lane);
+            BF_STAGE();
+            mul_tw<false, 1, 9>(re, im, tw);
+            BF_STAGE();
+            mul_tw<false, 9, 16>(re, im, tw);
             if (p == 0 && it > 0 && w < kWaves - 1)  // the plane's head still holds the last frame's tail until w + 1 has taken it
                 while (s_cons[w] < (int)(t - kWaves)) __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
+            BF_STAGE();
             T1_fwd(re, im, wcol, row16);
-            w64_fwd_p2<double>(re, im, lane, s_tw2);
+            load_tw2<1, 9>(tw, s_tw2, lane);  // queued behind the exchange's reads: there when the second transform ends
+            BF_STAGE();
+            fft16_core<double, -1, true>(re, im);
+            BF_STAGE();
+            load_tw2<9, 16>(tw, s_tw2, lane);
+            BF_STAGE();
+            mul_tw<false, 1, 9>(re, im, tw);
+            BF_STAGE();
+            mul_tw<false, 9, 16>(re, im, tw);
+            BF_STAGE();
             w64_T2<true>(re, im);
-            w64_fwd_p3<double>(re, im);
+            cx<double> g[16];
             const cx<double> *gp = s_gain + p * 1024 + lane;
+            BF_STAGE();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) g[r] = gp[64 * r];  // lands during the 4-point transforms
+            BF_STAGE();
+            w64_fwd_p3<double>(re, im);
+            BF_STAGE();
+#pragma unroll
+            for (int r = 8; r < 16; ++r) g[r] = gp[64 * r];
+            BF_STAGE();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const cx<double> g = gp[64 * r];
-                Sr[r] = fma(-g.y, im[r], fma(g.x, re[r], Sr[r]));
-                Si[r] = fma(g.y, re[r], fma(g.x, im[r], Si[r]));
+                if (r == 8) BF_STAGE();
+                Sr[r] = fma(-g[r].y, im[r], fma(g[r].x, re[r], Sr[r]));
+                Si[r] = fma(g[r].y, re[r], fma(g[r].x, im[r], Si[r]));
             }
         }
+        cx<double> tw[15];
+        BF_STAGE();
+        load_tw2<1, 16>(tw, s_tw2, lane);  // the backward half has registers to spare: re / im are dead
+        BF_STAGE();
         w64_inv_p3<double>(Sr, Si);
         w64_T2<false>(Sr, Si);
-        w64_inv_p2<double>(Sr, Si, lane, s_tw2);
+        BF_STAGE();
+        mul_tw<true, 1, 16>(Sr, Si, tw);
+        BF_STAGE();
+        load_tw1<1, 16>(tw, s_tw1, lane);
+        BF_STAGE();
+        fft16_core<double, +1, false>(Sr, Si);
+        BF_STAGE();
         T1_inv(Sr, Si, row16, wcol);
-        w64_inv_p1<double>(Sr, Si, lane, s_tw1);
+        BF_STAGE();
+        mul_tw<true, 1, 16>(Sr, Si, tw);
+        fft16_core<double, +1, false>(Sr, Si);
 
         // register j holds sample n = 64 j + lane (j < 8: first half, j >= 8: second half); util.h:247-252 with the float stores
         float o[16];

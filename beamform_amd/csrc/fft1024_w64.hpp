@@ -110,14 +110,15 @@ BF_HD void w64_fwd_p1(T (&re)[16], T (&im)[16], int lane, const TW *tw1 /* [k1][
     }
 }
 // after T1 (reg a natural): forward P2 + TW2.  out: position i holds C[k2 = brev4(i)] * W64^(b*k2), b = lane >> 4
-template <typename T, typename TW>
-BF_HD void w64_fwd_p2(T (&re)[16], T (&im)[16], int lane, const TW *tw2 /* [b][16] = W64^(b*k2) */) {
+// TW2S = row stride of the tw2 table in elements (16, or 17 where the four rows must start on different LDS banks)
+template <typename T, typename TW, int TW2S = 16>
+BF_HD void w64_fwd_p2(T (&re)[16], T (&im)[16], int lane, const TW *tw2 /* [b][TW2S] = W64^(b*k2) */) {
     fft16_core<T, -1, true>(re, im);
     const int b = lane >> 4;
 #pragma unroll
     for (int i = 1; i < 16; ++i) {
         const int k2 = brev4(i);
-        const TW w = tw2[b * 16 + k2];
+        const TW w = tw2[b * TW2S + k2];
         const T xr = re[i], xi = im[i];
         re[i] = xr * w.x - xi * w.y;
         im[i] = xr * w.y + xi * w.x;
@@ -140,13 +141,13 @@ BF_HD void w64_inv_p3(T (&re)[16], T (&im)[16]) {
 }
 // after T2 (back): position i holds element k2 = brev4(i) (same register map the forward P2 left), b = lane >> 4.
 // conj TW2 then inverse 16-point over k2 (bit-reversed in, natural out): reg a natural.
-template <typename T, typename TW>
+template <typename T, typename TW, int TW2S = 16>
 BF_HD void w64_inv_p2(T (&re)[16], T (&im)[16], int lane, const TW *tw2) {
     const int b = lane >> 4;
 #pragma unroll
     for (int i = 1; i < 16; ++i) {
         const int k2 = brev4(i);
-        const TW w = tw2[b * 16 + k2];
+        const TW w = tw2[b * TW2S + k2];
         const T xr = re[i], xi = im[i];
         re[i] = xr * w.x + xi * w.y;
         im[i] = xi * w.x - xr * w.y;

@@ -210,9 +210,11 @@ inline std::vector<f32x2> twiddle_table_w64() {
 }
 
 // fp64 tables of the 64-lane factorisation with the rotated exchange (fft1024_w64.hpp w64_col_rot; das_f64_w64.hip):
-// [0, 1024) = W1024^(k1*lane) as [k1][lane]; [1024, 1088) = tw2'[b][k2] = exp(2 pi i 15 b k2 / 64)
+// [0, 1024) = W1024^(k1*lane) as [k1][lane]; [1024, 1092) = tw2'[b][k2] = exp(2 pi i 15 b k2 / 64) in rows of 17 (one element of
+// padding: the four rows a wavefront reads at once then start 4 LDS banks apart instead of on the same one)
+constexpr int kTw2RowW64Rot = 17;
 inline std::vector<f64x2> twiddle_table_w64_rot() {
-    std::vector<f64x2> t(1024 + 64);
+    std::vector<f64x2> t(1024 + 4 * kTw2RowW64Rot, f64x2{0.0, 0.0});
     for (int k = 0; k < 16; ++k)
         for (int l = 0; l < 64; ++l) {
             const double a = -2.0 * kPi * (double)(k * l) / 1024.0;
@@ -221,7 +223,7 @@ inline std::vector<f64x2> twiddle_table_w64_rot() {
     for (int b = 0; b < 4; ++b)
         for (int k = 0; k < 16; ++k) {
             const double a = 2.0 * kPi * (double)((15 * b * k) % 64) / 64.0;
-            t[1024 + b * 16 + k] = f64x2{std::cos(a), std::sin(a)};
+            t[1024 + b * kTw2RowW64Rot + k] = f64x2{std::cos(a), std::sin(a)};
         }
     return t;
 }
