@@ -68,9 +68,11 @@ struct bf_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
-    // per-launch timing of the dominant kernel (bf_time_batch_device)
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> *kernel_events = nullptr;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> own_events;  // bf_kernel_timing_begin / _end
+    // per-launch timing of the dominant kernel: a pool of event pairs, created on demand (bf_kernel_timing_begin reserves a batch so
+    // that the caller's timed loop only records), reused by every session and destroyed with the handle
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    int timing = 0;  // 0: off; 1: bf_kernel_timing_begin .. _end; 2: inside bf_time_batch_device
     bool row0_written = true;  // reference-mic weight row: written by the cold start's update_weights(true), left zero by a
                                // structural interferer change (quirk Q3, lcmv.cpp:243-252,281,304)
 };
@@ -147,6 +149,49 @@ int sync_tables(bf_handle *h, hipStream_t s, RunSnapshot *snap) {
     return BF_OK;
 }
 
+// Event pair for the next launch of the dominant kernel (both null when no timing session is active).
+int timing_reserve(bf_handle *h, size_t n) {
+    while (h->ev_pool.size() < n) {
+        hipEvent_t k0 = nullptr, k1 = nullptr;
+        BF_HIP(h, hipEventCreate(&k0));
+        hipError_t e = hipEventCreate(&k1);
+        if (e != hipSuccess) {
+            (void)hipEventDestroy(k0);
+            return fail(h, BF_EIO, "hipEventCreate", e);
+        }
+        h->ev_pool.push_back(std::make_pair(k0, k1));
+    }
+    return BF_OK;
+}
+int timing_acquire(bf_handle *h, hipEvent_t *k0, hipEvent_t *k1) {
+    *k0 = *k1 = nullptr;
+    if (!h->timing) return BF_OK;
+    int rc = timing_reserve(h, h->ev_used + 1);
+    if (rc != BF_OK) return rc;
+    *k0 = h->ev_pool[h->ev_used].first;
+    *k1 = h->ev_pool[h->ev_used].second;
+    ++h->ev_used;
+    return BF_OK;
+}
+// mean duration of the pairs recorded since the session began; ends the session
+int timing_collect(bf_handle *h, float *ms_mean, int *n_launches) {
+    float sum = 0.f;
+    int n = 0;
+    hipError_t e = hipSuccess;
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        float t = 0.f;
+        if (e == hipSuccess) e = hipEventSynchronize(h->ev_pool[i].second);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, h->ev_pool[i].first, h->ev_pool[i].second);
+        if (e == hipSuccess) { sum += t; ++n; }
+    }
+    h->ev_used = 0;
+    h->timing = 0;
+    if (e != hipSuccess) return fail(h, BF_EIO, "kernel timing", e);
+    *ms_mean = n ? sum / (float)n : 0.f;
+    if (n_launches) *n_launches = n;
+    return BF_OK;
+}
+
 int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_dev, void *spectrum_dev, hipStream_t s,
                   int layout, long mic_stride) {
     const long F = (long)n_frames;
@@ -203,12 +248,11 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     a.variant = das_variant;
     if (!gen) BF_HIP(h, prepare_das_fused(a, s));
     hipEvent_t k0 = nullptr, k1 = nullptr;
-    if (h->kernel_events) {
-        BF_HIP(h, hipEventCreate(&k0));
-        BF_HIP(h, hipEventCreate(&k1));
-        h->kernel_events->push_back(std::make_pair(k0, k1));
-        BF_HIP(h, hipEventRecord(k0, s));
+    {
+        int trc = timing_acquire(h, &k0, &k1);
+        if (trc != BF_OK) return trc;
     }
+    if (k0) BF_HIP(h, hipEventRecord(k0, s));
     if (shared) {
         for (int d0 = 0; d0 < h->n_dirs; d0 += 16)
             BF_HIP(h, launch_das_fused_dirs(a, d0, h->n_dirs - d0 < 16 ? h->n_dirs - d0 : 16, s));
@@ -231,7 +275,17 @@ int run_batch_device(bf_handle *h, const float *x_dev, size_t n_frames, float *y
     int rc = sync_tables(h, s, &snap);
     if (rc != BF_OK) return rc;
     if (uses_fused_das(h)) return run_das_fused(h, x_dev, n_frames, y_dev, spectrum_dev, s, layout, mic_stride);
+    // the pipeline brackets its dominant kernel with this pair when it has one (das fp64 in one launch); otherwise the pair stays
+    // unrecorded and the session's mean is taken over nothing (callers fall back to the call time)
+    hipEvent_t k0 = nullptr, k1 = nullptr;
+    rc = timing_acquire(h, &k0, &k1);
+    if (rc != BF_OK) return rc;
+    h->pipe->kev0 = k0;
+    h->pipe->kev1 = k1;
+    h->pipe->kev_recorded = false;
     rc = h->pipe->run(x_dev, (long)n_frames, y_dev, (f64x2 *)spectrum_dev, s, layout, mic_stride, snap);
+    h->pipe->kev0 = h->pipe->kev1 = nullptr;
+    if (k0 && !h->pipe->kev_recorded) --h->ev_used;  // nothing was bracketed: hand the pair back
     if (rc != BF_OK) return fail(h, rc, h->pipe->error().c_str());
     return BF_OK;
 }
@@ -417,6 +471,10 @@ void bf_destroy(bf_handle *h) {
     if (h->d_x) (void)hipFree(h->d_x);
     if (h->d_y) (void)hipFree(h->d_y);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
+    for (auto &pr : h->ev_pool) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
     for (hipEvent_t e : h->ev_in) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_out) (void)hipEventDestroy(e);
     if (h->s_h2d) (void)hipStreamDestroy(h->s_h2d);
@@ -727,60 +785,52 @@ int bf_shard_run(bf_handle *h, const float *x_feed_dev, const bf_shard *sh, floa
 // launch of the fused kernel is bracketed by its own event pair on the stream it is launched on.
 int bf_kernel_timing_begin(bf_handle *h) {
     if (!h) return BF_EINVAL;
-    if (h->kernel_events) return fail(h, BF_EINVAL, "kernel timing already active");
-    h->own_events.clear();
-    h->kernel_events = &h->own_events;
+    if (h->timing) return fail(h, BF_EINVAL, "kernel timing already active");
+    BF_HIP(h, hipSetDevice(h->device));
+    int rc = timing_reserve(h, 256);  // the caller's timed loop then only records
+    if (rc != BF_OK) return rc;
+    h->ev_used = 0;
+    h->timing = 1;
     return BF_OK;
 }
 
 int bf_kernel_timing_end(bf_handle *h, float *ms_mean, int *n_launches) {
     if (!h || !ms_mean) return BF_EINVAL;
-    if (h->kernel_events != &h->own_events) return fail(h, BF_EINVAL, "kernel timing is not active");
-    h->kernel_events = nullptr;
-    float sum = 0.f;
-    int n = 0;
-    hipError_t e = hipSuccess;
-    for (auto &pr : h->own_events) {
-        float t = 0.f;
-        if (e == hipSuccess) e = hipEventSynchronize(pr.second);
-        if (e == hipSuccess) e = hipEventElapsedTime(&t, pr.first, pr.second);
-        if (e == hipSuccess) { sum += t; ++n; }
-        (void)hipEventDestroy(pr.first);
-        (void)hipEventDestroy(pr.second);
-    }
-    h->own_events.clear();
-    if (e != hipSuccess) return fail(h, BF_EIO, "bf_kernel_timing_end", e);
-    *ms_mean = n ? sum / (float)n : 0.f;
-    if (n_launches) *n_launches = n;
-    return BF_OK;
+    if (h->timing != 1) return fail(h, BF_EINVAL, "kernel timing is not active");
+    return timing_collect(h, ms_mean, n_launches);
 }
 
 int bf_time_batch_device(bf_handle *h, const float *x_dev, size_t n_frames, float *y_dev, void *hip_stream, int iters,
                          float *ms_per_call, float *ms_kernel) {
     if (!h || !x_dev || !y_dev || iters < 1 || !ms_per_call) return BF_EINVAL;
+    if (h->timing) return fail(h, BF_EINVAL, "bf_time_batch_device inside a bf_kernel_timing_begin session");
     BF_HIP(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)hip_stream;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
-    h->kernel_events = ms_kernel ? &kev : nullptr;
+    if (ms_kernel) {
+        int rc0 = timing_reserve(h, (size_t)iters);
+        if (rc0 != BF_OK) return rc0;
+        h->ev_used = 0;
+        h->timing = 2;
+    }
     int rc = BF_OK;
     hipError_t e = hipEventRecord(h->ev0, s);
     for (int i = 0; i < iters && rc == BF_OK && e == hipSuccess; ++i)
         rc = run_batch_device(h, x_dev, n_frames, y_dev, nullptr, s, h->cfg.layout, (long)n_frames * h->H);
-    h->kernel_events = nullptr;
     if (e == hipSuccess) e = hipEventRecord(h->ev1, s);
     if (e == hipSuccess) e = hipEventSynchronize(h->ev1);
     float ms = 0.f, msk = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, h->ev0, h->ev1);
-    for (auto &pr : kev) {
-        float t = 0.f;
-        if (e == hipSuccess && rc == BF_OK && hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) msk += t;
-        (void)hipEventDestroy(pr.first);
-        (void)hipEventDestroy(pr.second);
+    int nk = 0;
+    if (h->timing == 2) {
+        int trc = (e == hipSuccess && rc == BF_OK) ? timing_collect(h, &msk, &nk) : BF_OK;
+        h->timing = 0;
+        h->ev_used = 0;
+        if (rc == BF_OK) rc = trc;
     }
     if (rc != BF_OK) return rc;
     if (e != hipSuccess) return fail(h, BF_EIO, "bf_time_batch_device", e);
     *ms_per_call = ms / (float)iters;
-    if (ms_kernel) *ms_kernel = kev.empty() ? 0.f : msk / (float)kev.size();
+    if (ms_kernel) *ms_kernel = nk ? msk : 0.f;
     return BF_OK;
 }
 

@@ -410,16 +410,24 @@ static void das_f64_w64_runs(const DasF64Args &a, int n_cus, long *fpc, long *cp
     *cps = (a.n_frames + f - 1) / f;
 }
 
-hipError_t launch_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s) {
+// the first hop of every run but the first of a stream is completed by atomic adds: zero them on `s` beforehand
+hipError_t prepare_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s) {
     if (a.n_mics > 8) return hipErrorNotSupported;  // the four pair-gain tables fill the LDS
     long fpc, cps;
     das_f64_w64_runs(a, n_cus, &fpc, &cps);
-    if (cps > 1)  // the first hop of every run but the first of a stream is completed by atomic adds: zero beforehand
+    if (cps > 1)
         for (int st = 0; st < a.n_streams; ++st) {
             hipError_t e = hipMemset2DAsync(a.y + ((long)st * a.n_frames + fpc) * kHop, (size_t)fpc * kHop * sizeof(float), 0,
                                             kHop * sizeof(float), (size_t)cps - 1, s);
             if (e != hipSuccess) return e;
         }
+    return hipSuccess;
+}
+
+hipError_t launch_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s) {
+    if (a.n_mics > 8) return hipErrorNotSupported;
+    long fpc, cps;
+    das_f64_w64_runs(a, n_cus, &fpc, &cps);
     hipLaunchKernelGGL(das_f64_w64_kernel, dim3((unsigned)(cps * a.n_streams)), dim3(kBlock), 0, s, a, (int)fpc, (int)cps);
     return hipGetLastError();
 }

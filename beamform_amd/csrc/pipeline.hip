@@ -309,7 +309,16 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
         // BF_DAS_F64_W64=0: the 32 x 32 half-wavefront kernel (das_f64_fused_kernel) instead of the 64-lane one
         static const int w64 = getenv("BF_DAS_F64_W64") ? atoi(getenv("BF_DAS_F64_W64")) : 1;
         if (w64 && snap.das_gains_w64 != nullptr) { da.gains = snap.das_gains_w64; da.tw = d_tw_w64_; }
-        const hipError_t de = (w64 && snap.das_gains_w64 != nullptr) ? launch_das_f64_w64(da, n_cus_, stream) : ks_->das_f64(da, n_cus_, stream);
+        const bool use_w64 = w64 && snap.das_gains_w64 != nullptr;
+        hipError_t de = use_w64 ? prepare_das_f64_w64(da, n_cus_, stream) : hipSuccess;
+        if (de == hipSuccess) {
+            if (kev0) PIPE_HIP(hipEventRecord(kev0, stream));
+            de = use_w64 ? launch_das_f64_w64(da, n_cus_, stream) : ks_->das_f64(da, n_cus_, stream);
+            if (kev1 && de == hipSuccess) {
+                PIPE_HIP(hipEventRecord(kev1, stream));
+                kev_recorded = true;
+            }
+        }
         if (de == hipSuccess) {
             PIPE_HIP(hipMemcpy2DAsync(d_hist_, H_ * sizeof(float), x + (F - 1) * H_, (size_t)mic_stride * sizeof(float),
                                       H_ * sizeof(float), (size_t)S_ * M_, hipMemcpyDeviceToDevice, stream));  // ring-buffer carry (util.h:305-308)

@@ -49,6 +49,10 @@ class BinPipeline {
     virtual int get_state(void *host) = 0;
     virtual int set_state(const void *host) = 0;
     const std::string &error() const { return err_; }
+    // set by the caller around run(): when non-null and the run has ONE dominant kernel (das fp64 in one launch), the two events are
+    // recorded on the run's stream right before and after that launch and kev_recorded is raised (bf_kernel_timing_begin / _end)
+    hipEvent_t kev0 = nullptr, kev1 = nullptr;
+    bool kev_recorded = false;
 
    protected:
     std::string err_;

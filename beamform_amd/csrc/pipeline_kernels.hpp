@@ -112,7 +112,9 @@ struct DasF64Args {
 };
 
 // the same node on one full wavefront per frame (das_f64_w64.hip; N = 1024 only): `gains` = das_pair_gains_w64_f64, `tw` =
-// twiddle_table_w64_rot; zeroes the run-boundary hops of y on `s` before the launch.  hipErrorNotSupported above 8 microphones.
+// twiddle_table_w64_rot.  prepare_ zeroes the run-boundary hops of y on `s` (they are completed by atomic adds) and must precede the
+// launch.  hipErrorNotSupported above 8 microphones.
+hipError_t prepare_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s);
 hipError_t launch_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s);
 
 #ifdef BF_NFFT

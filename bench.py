@@ -6,8 +6,10 @@ A "step" is one pass of the hot path (window -> FFTs -> per-bin weight-and-sum
 already resident in HBM.
 
 N = 1 (default): BASELINE.json configs[1] -- das, 8 mics, 1024-pt FFT / hop 512, one
-65 536-frame batch.  `extra` carries one line per other BASELINE config (mvdr 8-mic,
-phasempf 256 x 256, lcmv 16-mic K = 3 per-GPU shard) and the double-precision das.
+65 536-frame batch, computed in DOUBLE like the reference (das.cpp:16-24: std::complex<double>, FFTW double plans):
+das_f64_w64_kernel.  `extra` carries the fused fp32 kernel on the same batch (`das_f32`, with its own roofline
+block; --das-f32 makes it the headline) and one line per other BASELINE config (mvdr 8-mic, phasempf 256 x 256,
+lcmv 16-mic K = 3 per-GPU shard).
 
 N > 1 (`--gpus N`, one rank per GPU over torch.distributed / RCCL): ONE global stream is cut into
 contiguous frame ranges by beamform_amd.shard.plan; every rank holds only its slice (its owned hops
@@ -182,7 +184,8 @@ def main():
     ap.add_argument("--frames", type=int, default=65536, help="frames per GPU per step (per stream)")
     ap.add_argument("--streams", type=int, default=1)
     ap.add_argument("--layout", default="planar", choices=["planar", "interleaved"])
-    ap.add_argument("--das-f64", action="store_true", help="das through the fp64 bin pipeline (BF_DAS_BINS_F64)")
+    ap.add_argument("--das-f64", action="store_true", help="das in double, the reference's arithmetic (BF_DAS_BINS_F64): the default")
+    ap.add_argument("--das-f32", action="store_true", help="das through the fused fp32 kernel (BF_DAS_FUSED_F32) as the headline")
     ap.add_argument("--strong", action="store_true",
                     help="N > 1: keep the global stream at --total-frames for every N (strong scaling)")
     ap.add_argument("--total-frames", type=int, default=0,
@@ -255,7 +258,7 @@ def main():
     interf = (-60.0, 90.0, 150.0) if args.algo in ("lcmv", "gss") else ()
     p = make_params(args.algo, n_mics=M, interf=interf)
     layout = BF_PLANAR if args.layout == "planar" else BF_INTERLEAVED
-    das_impl = BF_DAS_BINS_F64 if (args.das_f64 and args.algo == "das") else BF_DAS_FUSED_F32
+    das_impl = BF_DAS_FUSED_F32 if (args.das_f32 and not args.das_f64) else BF_DAS_BINS_F64   # only das looks at it
     bf = Beamformer(p, device=local_rank, n_streams=S, layout=layout, das_impl=das_impl)
     stream = torch.cuda.current_stream(dev)
     sptr = stream.cuda_stream
@@ -358,7 +361,7 @@ def main():
 
     # ---- secondary lines: the other BASELINE configs, rank 0 at N = 1 -------------------------------------------
     def node_line(algo, M_, F_, S_, interf_=(), das_impl_=BF_DAS_FUSED_F32, iters=5, xin=None, note="", layout_=BF_PLANAR,
-                  with_traffic=True):
+                  with_traffic=True, roofline_kernel=None, traffic_tag=None):
         pm = make_params(algo, n_mics=M_, interf=interf_)
         bm = Beamformer(pm, device=local_rank, n_streams=S_, das_impl=das_impl_, layout=layout_)
         if xin is None:
@@ -373,7 +376,7 @@ def main():
             bm.process_device(xin.data_ptr(), F_, yo.data_ptr(), 0, sptr)
             torch.cuda.synchronize(dev)
             n_settle += 1
-        ms, _ = bm.time_device(xin.data_ptr(), F_, yo.data_ptr(), iters, sptr)
+        ms, ms_k = bm.time_device(xin.data_ptr(), F_, yo.data_ptr(), iters, sptr)
         bm.close()
         fr = S_ * F_
         bpf = algorithmic_bytes_per_frame(M_)
@@ -386,24 +389,35 @@ def main():
             fl = model_flops_per_frame(algo, M_, len(interf_), pm["past_windows"])
             line["model_flops_per_frame"] = fl
             line["frac_of_fp64_vector_peak"] = fl * fr / (ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TF
+        if roofline_kernel and ms_k > 0:  # a one-kernel node: the same block the headline carries (event pair per launch, on the launch stream)
+            ach = bpf * fr / (ms_k * 1e-3) / 1e9
+            line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                "traffic": load_traffic(traffic_tag) if traffic_tag else None, "kernel": roofline_kernel,
+                                "kernel_ms": ms_k, "call_ms": ms, "kernel_launches_timed": iters,
+                                "algorithmic_bytes_per_frame": bpf, "frames_per_launch": fr,
+                                "frac_of_measured_copy_ceiling_6290": ach / 6290.0}
         if layout_ != BF_PLANAR or not with_traffic:  # the committed counter files are for the noise input, planar
             return line
-        tag = {"das": "das8_f64", "mvdr": "mvdr8", "phasempf": "phasempf8", "phase": "phase8", "lcmv": "lcmv16"}.get(algo)
+        tag = traffic_tag or {"das": "das8_f64", "mvdr": "mvdr8", "phasempf": "phasempf8", "phase": "phase8", "lcmv": "lcmv16"}.get(algo)
         tr = load_traffic(tag) if tag else None
         if tr is not None:
             line["traffic"] = tr
         return line
 
     extra = None
-    if rank == 0 and world == 1 and args.algo == "das" and das_impl == BF_DAS_FUSED_F32 and not args.no_extra and S == 1 \
-            and layout == BF_PLANAR:
+    if rank == 0 and world == 1 and args.algo == "das" and not args.no_extra and S == 1 and layout == BF_PLANAR:
         extra = {}
         noise = ("input = uniform noise in [-0.5, 0.5): every in-band bin passes the magnitude gate, so every bin-frame "
                  "takes the covariance solve (the worst case; real scenes close part of the gates)")
         jobs = [
             ("mvdr", lambda: node_line("mvdr", M, F, 1, xin=x, note="BASELINE config 3; fp64 bin pipeline; " + noise)),
-            ("das_f64", lambda: node_line("das", M, F, 1, das_impl_=BF_DAS_BINS_F64, xin=x,
-                                          note="same precision as the reference: das_f64_fused_kernel, the fused kernel's formulation in double, one launch")),
+            ("das_f32" if das_impl == BF_DAS_BINS_F64 else "das_f64",
+             (lambda: node_line("das", M, F, 1, das_impl_=BF_DAS_FUSED_F32, xin=x, iters=20, roofline_kernel="das_fused_kernel", traffic_tag="das8",
+                                note="the headline batch through the fused fp32 kernel (das_fused_kernel): meets north_star's 1e-5 (1.5e-7 observed) but "
+                                     "computes in single precision where the reference computes in double"))
+             if das_impl == BF_DAS_BINS_F64 else
+             (lambda: node_line("das", M, F, 1, das_impl_=BF_DAS_BINS_F64, xin=x, iters=20, roofline_kernel="das_f64_w64_kernel", traffic_tag="das8_f64",
+                                note="same precision as the reference: das_f64_w64_kernel, one launch"))),
             ("das_interleaved", lambda: node_line("das", M, F, 1, xin=x.reshape(1, F * HOP, M), layout_=BF_INTERLEAVED, iters=20,
                                                   note="the headline workload with [sample][mic] input (same bytes read as interleaved samples)")),
             ("phasempf", lambda: node_line("phasempf", 8, 256, 256, note="BASELINE config 4: 256 streams x 256 frames, recursion per stream")),
@@ -473,7 +487,12 @@ def main():
             bm.close()
             return {"workload": f"das {M}-mic 1024-pt, {F} frames, {D_} look directions from one set of forward transforms (das_fused_dirs_kernel)",
                     "ms_per_step": ms, "frames_per_s": F / (ms * 1e-3), "beam_frames_per_s": F * D_ / (ms * 1e-3),
-                    "ratio_to_one_direction": ms / (dt / args.steps * 1e3)}
+                    "ratio_to_one_direction_fp32": (ms / one_dir_f32_ms()) if one_dir_f32_ms() else None}
+
+        def one_dir_f32_ms():  # the fused fp32 kernel on one direction of the same batch: this run's own figure
+            if das_impl == BF_DAS_FUSED_F32:
+                return dt / args.steps * 1e3
+            return extra.get("das_f32", {}).get("ms_per_step")
 
         jobs.append(("das_dirs16", lambda: dirs_line(16)))
         jobs.append(("das_period256", lambda: other_period_line(256)))
@@ -577,7 +596,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          # PMC traffic exists for the profiled workloads only (profiles/traffic_<tag>.json)
                          "traffic": load_traffic(tag) if (n_feed == 65536 and S == 1 and args.layout == "planar") else None,
-                         "kernel": "das_fused_kernel" if (args.algo == "das" and das_impl == BF_DAS_FUSED_F32)
+                         "kernel": ("das_fused_kernel" if das_impl == BF_DAS_FUSED_F32 else "das_f64_w64_kernel") if args.algo == "das"
                                    else "bin pipeline (stft + per-bin kernel + istft)",
                          "kernel_ms": k_ms, "call_ms": ms_call, "kernel_launches_timed": n_timed_launches,
                          "kernel_ms_source": "one HIP event pair per launch on the launch stream, inside the K timed steps",

@@ -20,17 +20,20 @@ def _last_json(out: str) -> dict:
     return json.loads(lines[0])
 
 
-def _check_line(d, n):
+def _check_line(d, n, dtype="f64"):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["metric"] == "stft_frames_per_sec" and d["unit"] == "frames/s" and d["n_gpus"] == n
     assert d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
-    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    # the headline computes in double, as the reference does (das.cpp:16-24); --das-f32 selects the fused fp32 kernel
+    assert d["vs_baseline"] is None and d["dtype"] == dtype and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
+    assert r["kernel"] == ("das_f64_w64_kernel" if dtype == "f64" else "das_fused_kernel")
+    assert 0 < r["kernel_ms"] <= d["ms_per_step"] and r["kernel_launches_timed"] == 3   # event pairs inside the timed steps
     assert abs(d["value"] - n * 4096 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
 
 
@@ -45,6 +48,13 @@ def test_bench_single_gpu_line():
     usable = c["all_cores"]["host"]["usable"]
     assert c["all_cores"]["cores"] == usable <= len(os.sched_getaffinity(0))
     assert usable == 1 or c["all_cores"]["value"] > c["value"]
+
+
+def test_bench_fp32_headline_on_request():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--no-cpu", "--das-f32"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    _check_line(_last_json(out.stdout), 1, dtype="f32")
 
 
 def test_bench_two_ranks_through_the_launcher():
