@@ -96,11 +96,9 @@ int fail(bf_handle *h, int code, const char *what, hipError_t e = hipSuccess) {
         if (e_ != hipSuccess) return fail((h), BF_EIO, #call, e_);       \
     } while (0)
 
-// fused fp32 das: the 512-frame period has the register-resident kernels (32 x 32 in-register FFT-1024, das_fused.hip); the 256-
-// and 1024-frame periods one fused kernel on LDS-staged transforms (das_fused_gen.hip)
-bool uses_fused_das(const bf_handle *h) {
-    return h->cfg.algo == BF_DAS && h->cfg.das_impl == BF_DAS_FUSED_F32 && (h->cfg.hop == 512 || h->cfg.hop == 256 || h->cfg.hop == 1024);
-}
+// fused fp32 das: the 512-frame period has the register-resident kernels (32 x 32 in-register FFT-1024, das_fused.hip); every
+// other period (64 ... 4096 frames) one fused kernel on LDS-staged transforms (das_fused_gen.hip)
+bool uses_fused_das(const bf_handle *h) { return h->cfg.algo == BF_DAS && h->cfg.das_impl == BF_DAS_FUSED_F32; }
 bool fused_das_gen(const bf_handle *h) { return h->cfg.hop != 512; }
 
 // update_weights(): recompute every steering column from the current angles.
@@ -204,7 +202,9 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     // directions (das_fused_dirs_kernel); BF_DAS_SHARED_DIRS = the smallest direction count that takes it (0: never)
     static const int shared_min = getenv("BF_DAS_SHARED_DIRS") ? atoi(getenv("BF_DAS_SHARED_DIRS")) : 6;
     const bool shared = !gen && !h->use_w64 && layout == BF_PLANAR && h->M <= 8 && !spectrum_dev && shared_min > 0 && h->n_dirs >= shared_min;
-    long runs = (gen ? (long)h->n_cus * (h->N == 512 ? 8 : 3) : (long)h->n_cus) / (shared ? h->n_streams : S);
+    // (generic periods: blocks of 13 N bytes of LDS -- 26 N at N = 8192 -- share a CU: 8 at N <= 512, 3 at 2048, 1 from 4096 on)
+    const int gen_per_cu = h->N <= 512 ? 8 : h->N <= 1024 ? 6 : h->N <= 2048 ? 3 : 1;
+    long runs = (gen ? (long)h->n_cus * gen_per_cu : (long)h->n_cus) / (shared ? h->n_streams : S);
     if (runs < 1) runs = 1;
     long fpc = (F + runs - 1) / runs;
     if (!gen) fpc = ((fpc + 15) / 16) * 16;
@@ -340,8 +340,8 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
     *out = nullptr;
     if (cfg->algo < BF_DAS || cfg->algo > BF_GSC) return fail(nullptr, BF_EINVAL, "algo out of range");
     if (cfg->n_mics < 1 || cfg->n_mics > BF_MAX_MICS) return fail(nullptr, BF_EINVAL, "n_mics out of range");
-    if (cfg->hop != 256 && cfg->hop != 512 && cfg->hop != 1024)
-        return fail(nullptr, BF_ENOSYS, "hop (JACK period) must be 256, 512 or 1024 frames: fft_win 512 / 1024 / 2048");
+    if (cfg->hop < 64 || cfg->hop > 4096 || (cfg->hop & (cfg->hop - 1)) != 0)  // jackd -p takes powers of two; rosjack.cpp:131-134 whatever it reports
+        return fail(nullptr, BF_ENOSYS, "hop (JACK period) must be a power of two from 64 to 4096 frames (fft_win 128 ... 8192)");
     if (cfg->n_streams < 1) return fail(nullptr, BF_EINVAL, "n_streams < 1");
     if (cfg->n_dirs < 0 || cfg->n_dirs > BF_MAX_DIRS) return fail(nullptr, BF_EINVAL, "n_dirs out of range");
     if (cfg->n_dirs > 1 && (cfg->algo == BF_MCRA || cfg->algo == BF_GSC))
@@ -740,7 +740,9 @@ int bf_process_hop(bf_handle *h, const float *const *in, float *out, uint32_t nf
 int bf_process_batch_device_strided(bf_handle *h, const float *x_dev, size_t n_frames, float *y_dev, void *hip_stream,
                                     long mic_stride) {
     if (!h || !x_dev || !y_dev || mic_stride < (long)(n_frames * (size_t)h->H)) return BF_EINVAL;
-    if (h->cfg.layout != BF_PLANAR || h->n_streams != 1) return fail(h, BF_EINVAL, "strided batches: planar layout, one input stream");
+    // (several look directions write [dir][n_frames * hop] rows: a piece of a longer output buffer would need its own row stride)
+    if (h->cfg.layout != BF_PLANAR || h->n_streams != 1 || h->n_dirs != 1)
+        return fail(h, BF_EINVAL, "strided batches: planar layout, one input stream, one look direction");
     BF_HIP(h, hipSetDevice(h->device));
     return run_batch_device(h, x_dev, n_frames, y_dev, nullptr, (hipStream_t)hip_stream, h->cfg.layout, mic_stride);
 }

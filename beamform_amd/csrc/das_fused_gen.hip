@@ -1,12 +1,14 @@
 // das_fused_gen.hip -- fused fp32 delay-and-sum for the JACK periods the in-register 32 x 32 transform does not cover:
-// 256 frames (FFT 512) and 1024 frames (FFT 2048); rosjack.cpp:131, fft_win = 2 * period (util.h:261).
+// every power of two from 64 to 4096 frames except 512 (FFT 128 ... 8192); the reference takes whatever period the server
+// reports (rosjack.cpp:131-134) and sets fft_win = 2 * period (util.h:261).
 //
 // Same formulation as das_fused.hip -- per frame ceil(M/2) packed forward transforms, S += D_p Z_p with the pair gains of
 // geometry.hpp (natural bin order here), one backward transform, synthesis window, float overlap-add (das.cpp:47-70,
 // util.h:217-253,301-302) -- in ONE launch, spectra never leaving the CU.  The transforms are LDS-staged radix-4 Stockham
-// passes of a 256-thread block (one frame at a time per block): a plain design, 3-4 x the three-kernel fp64 chain these
-// periods ran before, not the register-resident machinery of the 512-frame period.  A block owns a run of consecutive frames
-// and keeps the overlap-add tail in LDS; a run that does not start the stream recomputes its previous frame for that tail.
+// passes of one block (256 threads; N / 2 threads below N = 512; one frame at a time per block): a plain design, 3-4 x the
+// three-kernel fp64 chain these periods ran before, not the register-resident machinery of the 512-frame period.  A block owns
+// a run of consecutive frames and keeps the overlap-add tail in LDS; a run that does not start the stream recomputes its
+// previous frame for that tail.  N = 8192 reads twiddles and window through L1 (its two transform buffers fill the LDS).
 #include <hip/hip_runtime.h>
 
 #include "kernels.hpp"
@@ -15,13 +17,14 @@ namespace bf {
 
 namespace {
 
-constexpr int kGB = 256;
+constexpr int gen_block(int n) { return n >= 512 ? 256 : n / 2; }  // threads per block: at least two points per thread
 
 // autosort (Stockham) passes in LDS: data starts in b0, result ends in the returned buffer.  tw[m] = exp(-2 pi i m / N), m < N/2.
 // Radix-4 passes (N = 512: four + one radix-2, N = 2048: five + one radix-2; earlier: nine / eleven radix-2 passes:
 // half the barriers, half the LDS traffic), twiddles W^(q k N / (4 ns)) from the half-length table by W^(m + N/2) = -W^m.
 template <int N, int DIR>
 __device__ __forceinline__ float2 *stockham32(float2 *b0, float2 *b1, const float2 *tw, int tid) {
+    constexpr int kGB = gen_block(N);
     float2 *in = b0, *out = b1;
     auto twd = [&](int m) -> float2 {  // W^m (forward) or its conjugate (backward), m < N
         const float2 w = tw[m & (N / 2 - 1)];
@@ -74,18 +77,24 @@ __device__ __forceinline__ float2 *stockham32(float2 *b0, float2 *b1, const floa
 }
 
 template <int N>
-__global__ __launch_bounds__(kGB) void das_fused_gen_kernel(DasFusedArgs a) {
-    constexpr int H = N / 2, BPT = N / kGB;  // bins (samples) per thread: 2 or 8
-    __shared__ float2 s_a[N], s_b[N], s_tw[N / 2];
-    __shared__ float s_win[N], s_tail[H];
+__global__ __launch_bounds__(gen_block(N)) void das_fused_gen_kernel(DasFusedArgs a) {
+    constexpr int kGB = gen_block(N);
+    constexpr int H = N / 2, BPT = N / kGB;  // bins (samples) per thread: 2 .. 32
+    constexpr bool kTabLds = N <= 4096;      // N = 8192: 2 x 64 KB of transform buffers + 16 KB of tail leave no room for the tables
+    __shared__ float2 s_a[N], s_b[N], s_twl[kTabLds ? N / 2 : 1];
+    __shared__ float s_winl[kTabLds ? N : 1], s_tail[H];
+    const float2 *s_tw = kTabLds ? s_twl : reinterpret_cast<const float2 *>(a.twiddle);
+    const float *s_win = kTabLds ? s_winl : a.window;
     const int tid = threadIdx.x;
     const int M = a.n_mics, n_pairs = (M + 1) >> 1;
     const int stream = blockIdx.x / a.chunks_per_stream;  // output stream = input stream * n_dirs + look direction
     const long c_in_s = blockIdx.x - (long)stream * a.chunks_per_stream;
     const int in_stream = stream / a.n_dirs;
     const f32x2 *gains = a.gains + (long)(stream - in_stream * a.n_dirs) * n_pairs * N;  // [pair][bin], 1/N folded in
-    for (int i = tid; i < N / 2; i += kGB) s_tw[i] = float2{a.twiddle[i].x, a.twiddle[i].y};
-    for (int i = tid; i < N; i += kGB) s_win[i] = a.window[i];
+    if (kTabLds) {
+        for (int i = tid; i < N / 2; i += kGB) s_twl[i] = float2{a.twiddle[i].x, a.twiddle[i].y};
+        for (int i = tid; i < N; i += kGB) s_winl[i] = a.window[i];
+    }
     const long T0 = c_in_s * a.frames_per_chunk;
     long T1 = T0 + a.frames_per_chunk;
     if (T1 > a.n_frames) T1 = a.n_frames;
@@ -190,12 +199,12 @@ __global__ void das_hermitian_dump_gen_kernel(const f32x2 *s, f64x2 *out, long t
 
 hipError_t launch_das_fused_gen(const DasFusedArgs &a, int n_fft, hipStream_t stream) {
     const unsigned blocks = (unsigned)((long)a.chunks_per_stream * a.n_streams);
-    if (n_fft == 512)
-        hipLaunchKernelGGL(das_fused_gen_kernel<512>, dim3(blocks), dim3(kGB), 0, stream, a);
-    else if (n_fft == 2048)
-        hipLaunchKernelGGL(das_fused_gen_kernel<2048>, dim3(blocks), dim3(kGB), 0, stream, a);
-    else
-        return hipErrorInvalidValue;
+#define BF_GEN(N_) case N_: hipLaunchKernelGGL(das_fused_gen_kernel<N_>, dim3(blocks), dim3(gen_block(N_)), 0, stream, a); break
+    switch (n_fft) {
+        BF_GEN(128); BF_GEN(256); BF_GEN(512); BF_GEN(2048); BF_GEN(4096); BF_GEN(8192);
+        default: return hipErrorInvalidValue;
+    }
+#undef BF_GEN
     return hipGetLastError();
 }
 

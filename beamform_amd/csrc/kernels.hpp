@@ -36,7 +36,8 @@ hipError_t launch_das_fused_w64(const DasFusedArgs &a, hipStream_t stream);
 hipError_t prepare_das_fused(const DasFusedArgs &a, hipStream_t stream);  // zero the atomically-completed hops
 hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t stream);
 // look directions dir0 .. dir0 + n_here - 1 (n_here <= 16) from ONE set of forward transforms per frame (planar, <= 8 microphones, no
-// spectrum dump); a.chunks_per_stream / frames_per_chunk describe the runs of an INPUT stream; output equal to launch_das_fused's to the last bits
+// spectrum dump); a.chunks_per_stream / frames_per_chunk describe the runs of an INPUT stream; output equal to launch_das_fused's within float rounding, not bit for bit
+// (the window products are fused differently: a beam's low-order bits may change when n_dirs crosses BF_DAS_SHARED_DIRS)
 hipError_t launch_das_fused_dirs(const DasFusedArgs &a, int dir0, int n_here, hipStream_t stream);
 
 // S dump -> Hermitian part of the reference's y_fft as double2 [frames][1024]

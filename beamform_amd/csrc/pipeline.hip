@@ -67,7 +67,7 @@ class BinPipelineImpl : public BinPipeline {
 
     int init() override {
         if (ks_ == nullptr) {
-            err_ = "hop must be 256, 512 or 1024 (FFT 512 / 1024 / 2048)";
+            err_ = "hop (JACK period) must be a power of two from 64 to 4096 frames";
             return BF_ENOSYS;
         }
         if (M_ > 32 && (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS)) {

@@ -9,8 +9,8 @@
 namespace bf {
 
 // FFT size of a translation unit.  The kernel files (stft_istft / mask / cov / gsc_gss / pipeline_kernels .hip) are compiled
-// once per supported hop -- -DBF_NFFT=512 | 1024 | 2048, i.e. JACK periods of 256 / 512 / 1024 frames (rosjack.cpp:131,
-// util.h:261 fft_win = 2 * window) -- into namespaces bf::n512 / bf::n1024 / bf::n2048; the host side (pipeline.hip) is
+// once per supported hop -- -DBF_NFFT=128 ... 8192, i.e. JACK periods of 64 ... 4096 frames (rosjack.cpp:131,
+// util.h:261 fft_win = 2 * window) -- into namespaces bf::n128 ... bf::n8192; the host side (pipeline.hip) is
 // compiled once and picks a KernelSet by the configured hop.
 #ifdef BF_NFFT
 #define BF_CAT2_(a, b) a##b
@@ -156,11 +156,24 @@ struct KernelSet {
     hipError_t (*gsc_nlms)(const float *, float *, float *, long, int, int, const bf_config &, hipStream_t);
     hipError_t (*das_f64)(const DasF64Args &, int, hipStream_t);
 };
+const KernelSet *kernel_set_n128();
+const KernelSet *kernel_set_n256();
 const KernelSet *kernel_set_n512();
 const KernelSet *kernel_set_n1024();
 const KernelSet *kernel_set_n2048();
+const KernelSet *kernel_set_n4096();
+const KernelSet *kernel_set_n8192();
 inline const KernelSet *kernel_set(int nfft) {
-    return nfft == 512 ? kernel_set_n512() : nfft == 1024 ? kernel_set_n1024() : nfft == 2048 ? kernel_set_n2048() : nullptr;
+    switch (nfft) {
+        case 128: return kernel_set_n128();
+        case 256: return kernel_set_n256();
+        case 512: return kernel_set_n512();
+        case 1024: return kernel_set_n1024();
+        case 2048: return kernel_set_n2048();
+        case 4096: return kernel_set_n4096();
+        case 8192: return kernel_set_n8192();
+        default: return nullptr;
+    }
 }
 
 }  // namespace bf

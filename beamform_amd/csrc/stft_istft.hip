@@ -582,13 +582,35 @@ __global__ __launch_bounds__(kI32Block) void istft32_kernel(IstftArgs a, int fra
 #else
 
 // ======================================================================================
-//          generic sizes (N = 512, 2048): LDS-staged radix-4 Stockham transforms
+//          generic sizes (N = 128 ... 8192 except 1024): LDS-staged transforms
 // ======================================================================================
-// JACK periods other than 512 frames (rosjack.cpp:131; fft_win = 2 * period, util.h:261).  One 256-thread block per
-// transform, the whole signal in LDS (two N-point complex double buffers), log2(N) autosort passes with a barrier each,
-// twiddles exp(-2 pi i m / N) from a double-precision table built on the host.  Correctness first: these sizes are not the
-// benchmark shape; the 1024-point path keeps its in-register 32 x 32 kernels.
+// JACK periods other than 512 frames (rosjack.cpp:131-134 takes whatever the server reports; fft_win = 2 * period, util.h:261).
+// One 256-thread block per transform, the whole signal in LDS: two N-point complex double buffers and radix-4 autosort (Stockham)
+// passes with a barrier each up to N = 4096; at N = 8192 one buffer fills the LDS (128 KB), so that size runs radix-2 passes
+// in place on bit-reversed input.  Twiddles exp(-2 pi i m / N) from a double-precision table built on the host (in LDS up to
+// N = 2048, through L1 above).  Correctness first: these sizes are not the benchmark shape; the 1024-point path keeps its
+// in-register kernels.
 constexpr int kGenBlock = 256;
+constexpr bool kGenInPlace = kN >= 8192;
+constexpr bool kGenTwLds = kN <= 2048;  // 4 KB at N = 512, 16 KB at N = 2048: measured better than L1 there (5.52 vs 5.68 ms per mvdr batch)
+constexpr int gen_log2(int n) { return n <= 1 ? 0 : 1 + gen_log2(n >> 1); }
+// where sample / bin n goes before the transform: its own slot (autosort) or the bit-reversed one (in-place passes)
+__device__ __forceinline__ int gen_slot(int n) { return kGenInPlace ? (int)(__brev((unsigned)n) >> (32 - gen_log2(kN))) : n; }
+// radix-2 decimation-in-time passes in place: input at its bit-reversed slot, result in natural order
+template <int DIR>
+__device__ __forceinline__ void fft_inplace(cd *buf, const f64x2 *tw, int tid) {
+    for (int half = 1; half < kN; half <<= 1) {
+        for (int b = tid; b < kN / 2; b += kGenBlock) {
+            const int k = b & (half - 1);
+            const int j = ((b - k) << 1) + k;
+            const f64x2 w = tw[k * (kN / (2 * half))];  // W^(k N / (2 half)): index < N / 2
+            const cd u = buf[j], v = buf[j + half] * cd{w.x, DIR < 0 ? w.y : -w.y};
+            buf[j] = u + v;
+            buf[j + half] = u - v;
+        }
+        __syncthreads();
+    }
+}
 
 // in-place-looking wrapper: data starts in buf0, result ends in the returned buffer.  DIR = -1 forward, +1 backward.
 // Radix-4 autosort passes and one closing radix-2 pass (N = 2 * 4^k: four + one at 512, five + one at 2048; the first version
@@ -638,9 +660,8 @@ __device__ __forceinline__ cd *stockham(cd *buf0, cd *buf1, const f64x2 *tw, int
 
 template <int LAYOUT>
 __global__ __launch_bounds__(kGenBlock) void stft_generic_kernel(StftArgs a) {
-    __shared__ cd s_a[kN], s_b[kN];
-    // twiddle table in LDS (4 KB at N = 512, 16 KB at N = 2048: measured better than reading it through L1 there too, 5.52 vs 5.68 ms per mvdr batch)
-    constexpr bool kTwLds = true;
+    __shared__ cd s_a[kN], s_b[kGenInPlace ? 1 : kN];
+    constexpr bool kTwLds = kGenTwLds;
     __shared__ f64x2 s_twl[kTwLds ? kN / 2 : 1];
     const int tid = threadIdx.x;
     if (kTwLds) {
@@ -677,10 +698,14 @@ __global__ __launch_bounds__(kGenBlock) void stft_generic_kernel(StftArgs a) {
                 vb = bs[(long)i * M + mb];
             }
             const double h = a.win[n] * (a.z48 ? 0.5 : 1.0);  // z48 spectra are stored halved (exact)
-            s_a[n] = cd{(double)va * h, b_ok ? (double)vb * h : 0.0};   // buf[j]*hann_win[i]  (util.h:235)
+            s_a[gen_slot(n)] = cd{(double)va * h, b_ok ? (double)vb * h : 0.0};   // buf[j]*hann_win[i]  (util.h:235)
         }
         __syncthreads();
-        const cd *res = stockham<-1>(s_a, s_b, s_tw, tid);
+        const cd *res = s_a;
+        if (kGenInPlace)
+            fft_inplace<-1>(s_a, s_tw, tid);
+        else
+            res = stockham<-1>(s_a, s_b, s_tw, tid);
         const long zoff = (((long)s * a.frames_ws + a.frame_off + t) * NP + p) * kN;
         for (int k = tid; k < kN; k += kGenBlock) {
             if (a.z48)
@@ -703,9 +728,8 @@ __device__ __forceinline__ cd herm_gen(const f64x2 *row, int k) {
 
 // one frame per block: backward transform + synthesis window, windowed frame to a.frames (float, reference rounding)
 __global__ __launch_bounds__(kGenBlock) void istft_generic_kernel(IstftArgs a) {
-    __shared__ cd s_a[kN], s_b[kN];
-    // twiddle table in LDS (4 KB at N = 512, 16 KB at N = 2048: measured better than reading it through L1 there too, 5.52 vs 5.68 ms per mvdr batch)
-    constexpr bool kTwLds = true;
+    __shared__ cd s_a[kN], s_b[kGenInPlace ? 1 : kN];
+    constexpr bool kTwLds = kGenTwLds;
     __shared__ f64x2 s_twl[kTwLds ? kN / 2 : 1];
     const int tid = threadIdx.x;
     if (kTwLds) {
@@ -716,9 +740,13 @@ __global__ __launch_bounds__(kGenBlock) void istft_generic_kernel(IstftArgs a) {
     const long total = (long)a.n_streams * a.n_frames;
     for (long f = blockIdx.x; f < total; f += gridDim.x) {
         const f64x2 *row = a.Yh + f * kYhStride;
-        for (int k = tid; k < kN; k += kGenBlock) s_a[k] = herm_gen(row, k);
+        for (int k = tid; k < kN; k += kGenBlock) s_a[gen_slot(k)] = herm_gen(row, k);
         __syncthreads();
-        const cd *res = stockham<+1>(s_a, s_b, s_tw, tid);
+        const cd *res = s_a;
+        if (kGenInPlace)
+            fft_inplace<+1>(s_a, s_tw, tid);
+        else
+            res = stockham<+1>(s_a, s_b, s_tw, tid);
         float *fo = a.frames + f * kN;
         for (int n = tid; n < kN; n += kGenBlock) {
             float v = (float)(res[n].x / (double)kN);            // util.h:249

@@ -131,9 +131,22 @@ def run_shard_overlapped(bf, x_feed, y_feed, n_frames: int, world: int, rank: in
     out (dst only): [n_frames*hop] tensor, filled in stream order.  Every rank cuts its slice by the same rule (`pieces`), so
     the receiver knows each sender's piece sizes without a handshake.
     Returns the pending work handles: wait on them (or synchronise the device) before reading `out`."""
+    import contextlib
+    import torch
     import torch.distributed as dist
+    if bf.n_streams != 1 or bf.n_dirs != 1:  # a piece writes [piece_frames * hop] at y_feed[f0 * hop:]: one output row only
+        raise ValueError("frame-range sharding drives one input stream and one look direction per handle")
     H = bf.H
     sh = plan(n_frames, world, rank, halo)
+    # the transfers and the copies below order against torch's CURRENT stream, the kernels against `stream`: make them the same
+    ctx = contextlib.nullcontext()
+    if x_feed.is_cuda and stream != torch.cuda.current_stream(x_feed.device).cuda_stream:
+        ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream, device=x_feed.device))
+    with ctx:
+        return _run_shard_overlapped(bf, x_feed, y_feed, n_frames, world, rank, halo, n_pieces, dst, out, stream, sh, H, dist)
+
+
+def _run_shard_overlapped(bf, x_feed, y_feed, n_frames, world, rank, halo, n_pieces, dst, out, stream, sh, H, dist):
     bf.reset_async(stream)
     peers = {r: pieces(plan(n_frames, world, r, halo), n_pieces) for r in range(world)} if rank == dst else None
     works = []

@@ -83,8 +83,20 @@ static int make_slice(Rank &r, int M, int H, hipStream_t s) {
     return 0;
 }
 
-// the rank's slice in `chunks` pieces on `cs`; after piece c, `on_piece(c, first owned hop of the piece, its hops)` is called
-// with the compute stream positioned right behind that piece
+// owned hops of piece c when a slice of n_feed fed hops (the first n_drop of them warm-up) is cut into `chunks` pieces:
+// [*own0, *own0 + return value) in owned-hop indices.  Every rank evaluates this for every rank, so that both ends of a transfer
+// agree on its size (the pieces of two ranks differ: rank 0 feeds no halo, and a short slice has fewer pieces than `chunks`).
+static long long piece_owned(long long n_feed, long long n_drop, int chunks, int c, long long *own0) {
+    const long long per = (n_feed + chunks - 1) / chunks;
+    const long long f0 = c * per, f1 = (f0 + per < n_feed) ? f0 + per : n_feed;
+    const long long o0 = f0 > n_drop ? f0 : n_drop;
+    *own0 = o0 - n_drop;
+    return f1 > o0 ? f1 - o0 : 0;
+}
+
+// the rank's slice in `chunks` pieces on `cs`; in EVERY round c = 0 .. chunks-1, `on_piece(c, first owned hop of the piece, its hops)`
+// is called with the compute stream positioned right behind that piece -- with 0 hops when this rank's piece c is empty or
+// all warm-up: the gather's receiving side has to post the peers' piece c in that round all the same
 template <typename F>
 static int walk(bf_handle *bf, Rank &r, int M, int H, int chunks, hipStream_t cs, F &&on_piece) {
     CKB(bf_reset_async(bf, cs));  // cold start, ordered on the compute stream
@@ -92,13 +104,12 @@ static int walk(bf_handle *bf, Rank &r, int M, int H, int chunks, hipStream_t cs
     // planar input with n_feed * H samples per microphone: a piece is a column range, described by the handle's mic stride
     for (int c = 0; c < chunks; ++c) {
         const long long f0 = c * per, f1 = (f0 + per < r.n_feed) ? f0 + per : r.n_feed;
-        if (f1 <= f0) break;
-        CKB(bf_process_batch_device_strided(bf, r.x + f0 * H, (size_t)(f1 - f0), r.y + f0 * H, cs, (long)(r.n_feed * H)));
-        const long long o0 = f0 > r.n_drop ? f0 : r.n_drop;  // owned part of the piece, in fed-hop indices
-        if (f1 > o0) {
-            int rc = on_piece(c, o0 - r.n_drop, f1 - o0);
-            if (rc) return rc;
-        }
+        if (f1 > f0)
+            CKB(bf_process_batch_device_strided(bf, r.x + f0 * H, (size_t)(f1 - f0), r.y + f0 * H, cs, (long)(r.n_feed * H)));
+        long long own0 = 0;
+        const long long n = piece_owned(r.n_feed, r.n_drop, chunks, c, &own0);
+        int rc = on_piece(c, own0, n);
+        if (rc) return rc;
     }
     return 0;
 }
@@ -162,6 +173,7 @@ int main(int argc, char **argv) {
             CKB(bf_shard_plan((size_t)F, world, r, halo, &rk.sh));
             if (make_slice(rk, M, H, cs)) return 1;
             int rc = walk(bf, rk, M, H, chunks, cs, [&](int, long long own0, long long n) -> int {
+                if (n == 0) return 0;
                 CK(hipMemcpyAsync(out + (rk.sh.lo + own0) * H, rk.y + (rk.n_drop + own0) * H, (size_t)n * H * sizeof(float),
                                   hipMemcpyDeviceToDevice, cs));
                 return 0;
@@ -213,31 +225,37 @@ int main(int argc, char **argv) {
     if (rank == 0) CK(hipMalloc((void **)&out, (size_t)F * H * sizeof(float)));
     std::vector<bf_shard> plan(world);
     for (int r = 0; r < world; ++r) CKB(bf_shard_plan((size_t)F, world, r, halo, &plan[r]));
-    hipEvent_t piece_done;
+    hipEvent_t piece_done, gather_done;
     CK(hipEventCreateWithFlags(&piece_done, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&gather_done, hipEventDisableTiming));
+    CK(hipEventRecord(gather_done, gs));
 
     auto step = [&](bool gather) -> int {
-        return walk(bf, me, M, H, chunks, cs, [&](int c, long long own0, long long n) -> int {
+        // the walk below rewrites me.y on the compute stream: not before the previous step's last transfer has read it
+        if (gather) CK(hipStreamWaitEvent(cs, gather_done, 0));
+        int rc = walk(bf, me, M, H, chunks, cs, [&](int c, long long own0, long long n) -> int {
             if (!gather) return 0;
             // piece c of every rank moves while piece c+1 is computed: the gather stream waits for this piece only
             CK(hipEventRecord(piece_done, cs));
             CK(hipStreamWaitEvent(gs, piece_done, 0));
-            if (rank == 0) CK(hipMemcpyAsync(out + own0 * H, me.y + (me.n_drop + own0) * H, (size_t)n * H * sizeof(float), hipMemcpyDeviceToDevice, gs));
+            if (rank == 0 && n > 0)
+                CK(hipMemcpyAsync(out + own0 * H, me.y + (me.n_drop + own0) * H, (size_t)n * H * sizeof(float), hipMemcpyDeviceToDevice, gs));
             CKN(ncclGroupStart());
             if (rank != 0) {
-                CKN(ncclSend(me.y + (me.n_drop + own0) * H, (size_t)n * H, ncclFloat, 0, comm, gs));
+                if (n > 0) CKN(ncclSend(me.y + (me.n_drop + own0) * H, (size_t)n * H, ncclFloat, 0, comm, gs));
             } else {
-                for (int r = 1; r < world; ++r) {  // every rank cuts its slice the same way: piece c of rank r is computable here
-                    Rank pr;
-                    pr.sh = plan[r];
-                    const long long nf = bf_shard_n_feed(&pr.sh), nd = bf_shard_n_drop(&pr.sh), per = (nf + chunks - 1) / chunks;
-                    const long long f0 = c * per, f1 = (f0 + per < nf) ? f0 + per : nf, o0 = f0 > nd ? f0 : nd;
-                    if (f1 > o0) CKN(ncclRecv(out + (pr.sh.lo + o0 - nd) * H, (size_t)(f1 - o0) * H, ncclFloat, r, comm, gs));
+                for (int r = 1; r < world; ++r) {  // piece c of rank r, cut by rank r's own feed length (piece_owned): posted in round c
+                    long long po0 = 0;               // whether or not rank 0 has a piece of its own in this round
+                    const long long pn = piece_owned(bf_shard_n_feed(&plan[r]), bf_shard_n_drop(&plan[r]), chunks, c, &po0);
+                    if (pn > 0) CKN(ncclRecv(out + (plan[r].lo + po0) * H, (size_t)pn * H, ncclFloat, r, comm, gs));
                 }
             }
             CKN(ncclGroupEnd());
             return 0;
         });
+        if (rc) return rc;
+        if (gather) CK(hipEventRecord(gather_done, gs));
+        return 0;
     };
     auto timed = [&](bool gather, double *ms) -> int {
         if (step(gather)) return 1;  // warm-up (first gather also builds the channels)

@@ -73,9 +73,10 @@ typedef struct bf_config {
     int algo;                      /* enum bf_algo */
     int n_mics;                    /* number_of_microphones (util.h:122) */
     int hop;                       /* rosjack_window_size = the JACK period (rosjack.cpp:131); fft_win = 2*hop (util.h:261).
-                                      256, 512 or 1024.  512 is the tuned shape (in-register 32 x 32 FFT-1024, fused fp32 das);
-                                      256 / 1024: das (BF_DAS_FUSED_F32) in one fused fp32 kernel on LDS-staged radix-2
-                                      transforms, every other node through the fp64 bin pipeline with the same transforms */
+                                      Any power of two from 64 to 4096 (what jackd -p accepts in that range).  512 is the tuned
+                                      shape (in-register FFT-1024 kernels); the other periods run das (BF_DAS_FUSED_F32) in one
+                                      fused fp32 kernel on LDS-staged radix-4 transforms and every other node through the fp64
+                                      bin pipeline on LDS-staged transforms (radix-4 autosort; radix-2 in place at 4096) */
     double sample_rate;            /* rosjack_sample_rate */
     double mic_x[BF_MAX_MICS];     /* RAW mic<i>.x / .y from beamform_config.yaml (util.h:82-92) */
     double mic_y[BF_MAX_MICS];

@@ -64,7 +64,7 @@ def test_bad_arguments_are_rejected_not_fatal():
     with pytest.raises(BfError):
         bf.set_theta_dir(1, 0.0)                                        # single-direction handle
     with pytest.raises(BfError):
-        Beamformer(make_params("das", n_mics=4, hop=300))               # JACK periods 256 / 512 / 1024 are built
+        Beamformer(make_params("das", n_mics=4, hop=300))               # JACK periods are powers of two, 64 ... 4096
     # the handle still works afterwards
     y = bf.process(make_scene(4, 3, seed=1))
     assert np.isfinite(y).all()

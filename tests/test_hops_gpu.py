@@ -1,4 +1,5 @@
-"""Boundary generality on the GPU: JACK periods of 256 and 1024 frames (rosjack.cpp:131; fft_win = 2 * period, util.h:261),
+"""Boundary generality on the GPU: every power-of-two JACK period from 64 to 4096 frames (rosjack.cpp:131-134 takes what the
+server reports; fft_win = 2 * period, util.h:261),
 more than three interferers (lcmv.cpp:258-309 appends without a cap; beamform_config.yaml:43-57 lists 15) and more than
 16 microphones -- every case against the oracle through the C ABI."""
 import numpy as np
@@ -46,14 +47,20 @@ def check(y, Y, y_ref, Y_ref, skip=0, hop=512):
     assert rel_l2(y[ok], y_ref[ok]) < TOL
 
 
-@pytest.mark.parametrize("hop", [256, 1024])
-@pytest.mark.parametrize("algo,M,interf", [("das", 8, ()), ("das", 3, ()), ("mvdr", 8, ()), ("mvdr", 4, ()), ("lcmv", 8, (-60.0, 90.0)),
-                                           ("lcmv", 16, (-60.0, 90.0, 150.0)), ("gss", 8, (-60.0,)), ("phase", 8, ()),
-                                           ("phasempf", 8, ()), ("mcra", 2, ())])
+ALL_NODES = [("das", 8, ()), ("das", 3, ()), ("mvdr", 8, ()), ("mvdr", 4, ()), ("lcmv", 8, (-60.0, 90.0)),
+             ("lcmv", 16, (-60.0, 90.0, 150.0)), ("gss", 8, (-60.0,)), ("phase", 8, ()), ("phasempf", 8, ()), ("mcra", 2, ())]
+# the periods jackd is usually started with besides 512 get every node; the far ends of the range the nodes of the metric, the
+# recursive mask node and one 16-microphone lcmv (N = 8192 runs the in-place transforms, N = 128 / 256 blocks with idle threads)
+FEW_NODES = [("das", 8, ()), ("das", 3, ()), ("mvdr", 8, ()), ("lcmv", 16, (-60.0, 90.0, 150.0)), ("phase", 8, ()), ("phasempf", 8, ()),
+             ("gss", 8, (-60.0,))]
+CASES = [(hop,) + n for hop in (256, 1024) for n in ALL_NODES] + [(hop,) + n for hop in (64, 128, 2048, 4096) for n in FEW_NODES]
+
+
+@pytest.mark.parametrize("hop,algo,M,interf", CASES)
 def test_nodes_at_other_jack_periods(hop, algo, M, interf):
     import oracle
     p = make_params(algo, n_mics=M, interf=interf, theta=20.0, hop=hop)
-    F = 48 if hop == 256 else 30
+    F = {64: 96, 128: 64, 256: 48, 1024: 30, 2048: 24, 4096: 20}[hop]   # enough frames behind the covariance window / MCRA start-up
     x = make_scene(M, F, hop=hop, seed=300 + M + hop // 256)
     y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
     _, y, Y = run(p, x)
@@ -66,7 +73,7 @@ def test_nodes_at_other_jack_periods(hop, algo, M, interf):
         assert rel_l2(y64, y_ref) < TOL
 
 
-@pytest.mark.parametrize("hop", [256, 1024])
+@pytest.mark.parametrize("hop", [64, 128, 256, 1024, 2048, 4096])
 @pytest.mark.parametrize("algo", ["das", "mvdr", "phasempf"])
 def test_streaming_callbacks_at_other_jack_periods(hop, algo):
     """bf_process_hop with nframes = the configured period, one callback at a time == batch == oracle; theta in between."""
@@ -97,7 +104,10 @@ def test_unsupported_period_is_refused():
     from beamform_amd.capi import Beamformer, BfError
     _torch()
     with pytest.raises(BfError):
-        Beamformer(make_params("das", n_mics=4, hop=384))
+        Beamformer(make_params("das", n_mics=4, hop=384))      # not a power of two
+    for hop in (32, 8192):                                       # outside 64 ... 4096
+        with pytest.raises(BfError):
+            Beamformer(make_params("mvdr", n_mics=4, hop=hop))
 
 
 @pytest.mark.parametrize("algo,M,interf", [
@@ -176,9 +186,9 @@ def test_more_than_sixteen_microphones(algo, M, interf, radius, band):
     check(y[0], Y[0], y_ref, Y_ref)
 
 
-@pytest.mark.parametrize("hop", [256, 1024])
+@pytest.mark.parametrize("hop", [64, 256, 1024, 4096])
 def test_fused_das_at_other_periods_layouts_streams_directions_cuts(hop):
-    """das_fused_gen.hip (fused fp32 das at JACK periods 256 / 1024): interleaved input, several streams, look directions, a
+    """das_fused_gen.hip (fused fp32 das at the JACK periods other than 512): interleaved input, several streams, look directions, a
     long batch cut into runs (every run but the first recomputes its previous frame), uneven batch cuts -- against the oracle."""
     import oracle
     from beamform_amd.capi import BF_INTERLEAVED, Beamformer
@@ -201,7 +211,7 @@ def test_fused_das_at_other_periods_layouts_streams_directions_cuts(hop):
         ref, _ = oracle.OracleNode(make_params("das", n_mics=M, theta=th, hop=hop)).process(xs[0])
         assert rel_l2(yd[d], ref) < TOL
     # a batch long enough to be cut into many runs, and the same stream in uneven batches
-    Fl = 3000 if hop == 256 else 1200
+    Fl = {64: 6000, 256: 3000, 1024: 1200, 4096: 300}[hop]
     xl = make_scene(M, Fl, hop=hop, seed=99)
     ref, _ = oracle.OracleNode(p).process(xl)
     whole = Beamformer(p).process(xl)
