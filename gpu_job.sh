@@ -1,3 +1,3 @@
 cd /root/repo
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_hops_gpu.py -x -q 2>&1 | tail -15
+timeout 600 python -m pytest tests/test_controllers_gpu.py -x -q 2>&1 | tail -8

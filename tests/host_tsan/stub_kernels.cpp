@@ -40,9 +40,15 @@ static hipError_t launch_stft_bins(const StftArgs &, const BinsArgs &, int, hipS
 
 // the harness runs at hop 512; the other sizes share the same host code
 static const KernelSet g_stub_set = {1024, &launch_stft, &launch_bins, &launch_stft_bins, &launch_istft, &launch_smooth, &launch_gsc_nlms};
+const KernelSet *kernel_set_n128() { return &g_stub_set; }
+const KernelSet *kernel_set_n256() { return &g_stub_set; }
 const KernelSet *kernel_set_n512() { return &g_stub_set; }
 const KernelSet *kernel_set_n1024() { return &g_stub_set; }
 const KernelSet *kernel_set_n2048() { return &g_stub_set; }
+const KernelSet *kernel_set_n4096() { return &g_stub_set; }
+const KernelSet *kernel_set_n8192() { return &g_stub_set; }
+hipError_t prepare_das_f64_w64(const DasF64Args &, int, hipStream_t) { return hipSuccess; }
+hipError_t launch_das_f64_w64(const DasF64Args &, int, hipStream_t) { return hipSuccess; }
 
 hipError_t prepare_das_fused(const DasFusedArgs &, hipStream_t) { return hipSuccess; }
 hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t) {

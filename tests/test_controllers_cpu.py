@@ -1,179 +1,90 @@
-"""Theta controllers against a numpy transcription of the reference scripts' callbacks.
-
-The transcriptions below restate scripts/energy2theta.py:62-101 (+ :23-60), energy2theta-diff.py:72-103 (+ :60),
-energy2theta-spec.py:105-150 (+ :39-103, 'history' method) and SIR2theta.py:9-26 with their module-level globals as a dict
-(test infrastructure, like the oracle).  Both sides are driven by the same oracle output windows; the published angles
-must be identical.  The closed loop (`controllers.follow`) is then run around the oracle node."""
+"""Theta controllers: beamform_amd/controllers.py against the committed fixture
+tests/golden/controllers_loop.npz (window stream in, published theta sequences out; tests/golden/make_controllers_golden.py) and
+against oracle/controllers_oracle.py, the restatement of the reference scripts' callbacks that produced it.  The published
+angles must be identical, value for value.  The closed loop (`controllers.follow`) is then run around the oracle node."""
+import json
 import math
-from collections import deque
+import os
 
 import numpy as np
 import pytest
 
 import oracle
+from oracle import controllers_oracle as co
 from beamform_amd import controllers
 from beamform_amd.params import make_params
 from beamform_amd.synth import make_scene
 
-
-# ---- transcriptions ---------------------------------------------------------------------------------------------------
-def ref_energy_from_list(data_list):                              # energy2theta.py:23-27
-    sq = [i ** 2 for i in data_list]
-    return math.sqrt(sum(sq) / len(sq))
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "controllers_loop.npz")
 
 
-def ref_energy2theta(windows_in, initial_angle, num_win=50, vad_threshold=0.001, mu=25):
-    g = dict(num_win_i=0, past_energy=-100.0, past_theta=initial_angle, windows=deque([]), hist_bins=[])
-    out = []
-
-    def energy_from_deque(dq):                                    # energy2theta.py:29-60
-        data_list = [item for sub in list(dq) for item in sub]
-        data_np = np.abs(np.array(data_list))
-        if len(g["hist_bins"]) > 0:
-            vals, bins = np.histogram(data_np, g["hist_bins"])
-        else:
-            vals, bins = np.histogram(data_np, "fd")
-            g["hist_bins"] = bins
-        p = vals.astype(float) / len(data_list)
-        return np.sum(bins[0:-1] * p)
-
-    for k, data in enumerate(windows_in):                         # energy2theta.py:62-101
-        this_win = list(data)
-        if ref_energy_from_list(this_win) >= vad_threshold:
-            if g["num_win_i"] < num_win:
-                g["windows"].append(this_win)
-                g["num_win_i"] += 1
-            else:
-                g["windows"].popleft()
-                g["windows"].append(this_win)
-                if g["past_energy"] == -100.0:
-                    g["past_energy"] = energy_from_deque(g["windows"])
-                energy = energy_from_deque(g["windows"])
-                theta = g["past_theta"] + mu * (energy - g["past_energy"])
-                if theta > 180:
-                    theta = theta - 360
-                elif theta < -180:
-                    theta = theta + 360
-                out.append((k, theta))
-                g["past_energy"], g["past_theta"] = energy, theta
-    return out
-
-
-def ref_energy2theta_diff(pairs, initial_angle, num_win=50, vad_threshold=0.001, mu=25):
-    g = dict(num_win_i=0, past_energy=-100.0, past_theta=initial_angle, windows=deque([]))
-    out = []
-    for k, (a, r) in enumerate(pairs):                            # energy2theta-diff.py:72-103
-        this_win = (np.array(list(r)) - np.array(list(a))).tolist()
-        if g["num_win_i"] < num_win:
-            g["windows"].append(this_win)
-            g["num_win_i"] += 1
-        else:
-            g["windows"].popleft()
-            g["windows"].append(this_win)
-        if ref_energy_from_list(this_win) >= vad_threshold:
-            def e():                                              # :31-62: RMS of the deque
-                d = np.abs(np.array([item for sub in list(g["windows"]) for item in sub]))
-                return math.sqrt(np.mean(d ** 2))
-            if g["past_energy"] == -100.0:
-                g["past_energy"] = e()
-            energy = e()
-            theta = g["past_theta"] - mu * (energy - g["past_energy"])
-            if theta > 180:
-                theta = theta - 360
-            elif theta < -180:
-                theta = theta + 360
-            out.append((k, theta))
-            g["past_energy"], g["past_theta"] = energy, theta
-    return out
-
-
-def ref_energy2theta_spec_history(pairs, initial_angle, num_win=100, vad_threshold=0.001):
-    g = dict(num_win_i=0, past_energy=-100.0, past_theta=initial_angle, windows=deque([]), mu=5000)
-    out = []
-
-    def e():                                                      # energy2theta-spec.py:39-103, 'history'
-        g["mu"] = 10
-        alpha = 1000
-        past_values = np.array([np.sqrt(np.mean(np.array(w) ** 2)) for w in list(g["windows"])])
-        delta = past_values[-1] - np.mean(past_values)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            energy = past_values[-1] / (delta * alpha)
-        return -100.0 if math.isnan(energy) else energy
-
-    for k, (a, r) in enumerate(pairs):                            # :105-150
-        this_win = (np.array(list(r)) - np.array(list(a))).tolist()
-        if g["num_win_i"] < num_win:
-            g["windows"].append(this_win)
-            g["num_win_i"] += 1
-        else:
-            if g["num_win_i"] == num_win:
-                g["num_win_i"] += 1
-            g["windows"].popleft()
-            g["windows"].append(this_win)
-            if ref_energy_from_list(this_win) >= vad_threshold:
-                if g["past_energy"] == -100.0:
-                    g["past_energy"] = e()
-                energy = e()
-                if energy > -100.0:
-                    theta = g["past_theta"] + g["mu"] * (energy - g["past_energy"])
-                    if theta > 180:
-                        theta = theta - 360
-                    elif theta < -180:
-                        theta = theta + 360
-                    out.append((k, theta))
-                    g["past_energy"], g["past_theta"] = energy, theta
-    return out
-
-
-# ---- data -------------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
-def windows():
-    """Output windows of an oracle das node looking 35 degrees off the source, plus the reference channel."""
-    M, F = 4, 170
-    p = make_params("das", n_mics=M, theta=-15.0)
-    x = make_scene(M, F, seed=41, theta_s=20.0, silent_frac=0.12)
+def golden():
+    g = np.load(GOLDEN)
+    sc = json.loads(str(g["scene"]))
+    as_msg = lambda a: tuple(float(v) for v in a)   # rospy hands the callbacks float32[] fields as tuples of Python floats
+    ys, refs = [as_msg(w) for w in g["win"]], [as_msg(r) for r in g["ref"]]
+    seq = {n: list(zip(g["k_" + n].tolist(), g["theta_" + n].tolist())) for n in ("energy", "diff", "spec_history", "spec_spectrogram")}
+    return sc, ys, refs, seq
+
+
+def test_fixture_windows_are_the_oracle_nodes_output(golden):
+    """The stored window stream is what the CPU oracle's das node emits for the stored scene parameters (drift check)."""
+    sc, ys, refs, _ = golden
+    p = make_params("das", n_mics=sc["n_mics"], theta=sc["node_theta"])
+    x = make_scene(sc["n_mics"], sc["n_frames"], seed=sc["seed"], theta_s=sc["theta_s"], silent_frac=sc["silent_frac"])
     y, _ = oracle.OracleNode(p).process(x)
-    # rospy hands the callbacks float32[] fields as tuples of Python floats: the transcriptions get exactly that
-    as_msg = lambda a: tuple(float(v) for v in a)
-    return [as_msg(y[t * 512:(t + 1) * 512]) for t in range(F)], [as_msg(x[0, t * 512:(t + 1) * 512]) for t in range(F)]
+    assert np.array_equal(y.reshape(-1, 512).astype(np.float32), np.array(ys, np.float32))
+    assert np.array_equal(x[0].reshape(-1, 512), np.array(refs, np.float32))
 
 
-def test_energy2theta_matches_the_script(windows):
-    ys, _ = windows
-    ctl = controllers.Energy2Theta(initial_angle=-15.0)
+def test_oracle_restatement_reproduces_the_fixture(golden):
+    sc, ys, refs, seq = golden
+    pairs = list(zip(ys, refs))
+    assert co.ref_energy2theta(ys, sc["node_theta"]) == seq["energy"]
+    assert co.ref_energy2theta_diff(pairs, sc["node_theta"]) == seq["diff"]
+    assert co.ref_energy2theta_spec(pairs, sc["node_theta"], method="history") == seq["spec_history"]
+    assert co.ref_energy2theta_spec(pairs, sc["node_theta"], method="spectrogram", num_win=30) == seq["spec_spectrogram"]
+
+
+def test_energy2theta_matches_the_fixture(golden):
+    sc, ys, _, seq = golden
+    ctl = controllers.Energy2Theta(initial_angle=sc["node_theta"])
     got = [(k, th) for k, w in enumerate(ys) if (th := ctl.on_window(w)) is not None]
-    want = ref_energy2theta(ys, -15.0)
-    assert len(want) > 60 and len(got) == len(want)
-    assert [k for k, _ in got] == [k for k, _ in want]
-    assert np.array_equal([t for _, t in got], [t for _, t in want])
+    want = seq["energy"]
+    assert len(want) > 60 and got == want
     assert want[0][0] == 50                       # fifty active windows fill the deque before the first step
     assert all(k <= 151 for k, _ in want)         # the silent tail (from hop 150, one hop of latency) is gated out by the VAD threshold
 
 
-def test_energy2theta_diff_and_spec_match_the_scripts(windows):
-    ys, refs = windows
+def test_energy2theta_diff_and_spec_match_the_fixture(golden):
+    sc, ys, refs, seq = golden
     pairs = list(zip(ys, refs))
-    ctl = controllers.Energy2ThetaDiff(initial_angle=-15.0)
+    ctl = controllers.Energy2ThetaDiff(initial_angle=sc["node_theta"])
     got = [(k, th) for k, (a, r) in enumerate(pairs) if (th := ctl.on_windows(a, r)) is not None]
-    want = ref_energy2theta_diff(pairs, -15.0)
-    assert len(want) > 100 and got == want
-    ctl = controllers.Energy2ThetaSpec(initial_angle=-15.0, num_win=100, method="history")
+    assert len(seq["diff"]) > 100 and got == seq["diff"]
+    ctl = controllers.Energy2ThetaSpec(initial_angle=sc["node_theta"], num_win=100, method="history")
     got = [(k, th) for k, (a, r) in enumerate(pairs) if (th := ctl.on_windows(a, r)) is not None]
-    want = ref_energy2theta_spec_history(pairs, -15.0)
-    assert len(want) > 30 and got == want
-    spec = controllers.Energy2ThetaSpec(initial_angle=0.0, num_win=20, method="spectrogram")
-    th = [spec.on_windows(a, r) for a, r in pairs[:60]]
-    assert all(t is None for t in th[:20]) and any(t is not None and math.isfinite(t) for t in th[20:])
+    assert len(seq["spec_history"]) > 30 and got == seq["spec_history"]
+    # energy_calc_method = 'spectrogram' (energy2theta-spec.py:55-75): sqrt of the mean thresholded spectrogram bin of the deque, mu = 5000
+    ctl = controllers.Energy2ThetaSpec(initial_angle=sc["node_theta"], num_win=30, method="spectrogram")
+    got = [(k, th) for k, (a, r) in enumerate(pairs) if (th := ctl.on_windows(a, r)) is not None]
+    assert len(seq["spec_spectrogram"]) > 100 and got == seq["spec_spectrogram"]
+    assert np.ptp([t for _, t in got]) > 0.5      # mu = 5000 really moves the angle
+
+
+def test_spectrogram_energy_below_the_threshold_is_invalid():
+    """An empty thresholded spectrogram gives np.mean([]) = nan -> -100 ('invalid', energy2theta-spec.py:100-101): no step."""
+    ctl = controllers.Energy2ThetaSpec(initial_angle=5.0, num_win=4, method="spectrogram", vad_threshold=0.0)
+    quiet = np.full(512, 1e-6)
+    assert [ctl.on_windows(np.zeros(512), quiet) for _ in range(8)] == [None] * 8
+    assert co.ref_energy2theta_spec([(tuple(np.zeros(512)), tuple(quiet))] * 8, 5.0, method="spectrogram", num_win=4, vad_threshold=0.0) == []
 
 
 def test_wrap_and_sir2theta():
     assert controllers.wrap180(190.0) == -170.0 and controllers.wrap180(-181.0) == 179.0 and controllers.wrap180(30.0) == 30.0
     c = controllers.SIR2Theta()
-    past_sir, past_theta, want = -100.0, 1.0, []
-    for sir in (3.0, 4.5, 2.0):                   # SIR2theta.py:9-26
-        theta = past_theta - 0.01 * (sir - past_sir)
-        want.append(theta)
-        past_sir, past_theta = sir, theta
+    want = [t for _, t in co.ref_sir2theta((3.0, 4.5, 2.0))]   # SIR2theta.py:9-26
     assert c.initial() == 1.0 and [c.on_sir(s) for s in (3.0, 4.5, 2.0)] == want
     big = controllers.Energy2Theta(initial_angle=170.0, num_win=1, mu=1e6)
     w = np.full(512, 0.1)
@@ -197,7 +108,7 @@ def test_closed_loop_around_the_oracle_node():
     node = oracle.OracleNode(p)
     y, pub = controllers.follow(node, x, controllers.Energy2Theta(initial_angle=-15.0, num_win=30, mu=25.0))
     assert len(pub) == F - 30
-    want = ref_energy2theta([tuple(float(v) for v in y[t * 512:(t + 1) * 512]) for t in range(F)], -15.0, num_win=30)
+    want = co.ref_energy2theta([tuple(float(v) for v in y[t * 512:(t + 1) * 512]) for t in range(F)], -15.0, num_win=30)
     assert pub == want
     assert np.ptp([t for _, t in pub]) > 0        # the angle really moves
 

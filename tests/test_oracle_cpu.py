@@ -17,7 +17,7 @@ from beamform_amd.synth import make_scene
 from conftest import rel_l2
 
 GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
-              if not os.path.basename(p).startswith("wav_"))   # wav_pcm16.npz belongs to tests/test_wavio_*.py
+              if not os.path.basename(p).startswith(("wav_", "controllers_", "resample_")))   # those belong to test_wavio_*, test_controllers_*, test_resample_*
 
 
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
