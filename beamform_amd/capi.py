@@ -31,6 +31,7 @@ EXPORTS = (
     "bf_float_to_pcm16_device", "bf_wav_read", "bf_planar_f32_read", "bf_wav_free",
     "bf_resampler_create", "bf_resampler_set_table", "bf_resampler_reset", "bf_resampler_out_count", "bf_resampler_latency",
     "bf_resampler_process_device", "bf_resampler_process", "bf_resampler_destroy", "bf_resampler_default_table",
+    "bf_resampler_set_mode", "bf_resampler_callback", "bf_resampler_callback_device",
 )
 
 
@@ -136,6 +137,9 @@ def load():
     L.bf_resampler_destroy.argtypes = [C.c_void_p]
     L.bf_resampler_destroy.restype = None
     L.bf_resampler_default_table.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.bf_resampler_set_mode.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.bf_resampler_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.bf_resampler_callback_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
     _lib = L
     return L
 
@@ -258,6 +262,29 @@ class Resampler:
         self._check(self._L.bf_resampler_process_device(self._r, in_ptr, n_in, out_ptr, out_cap, C.byref(n), stream or None),
                     "bf_resampler_process_device")
         return n.value
+
+    def set_mode_rosjack(self, period: int):
+        """BF_RS_ROSJACK: the stage as rosjack drives it (period drops on upsampling, one block per callback); see bfcore.h."""
+        self._period = int(period)
+        self._check(self._L.bf_resampler_set_mode(self._r, 1, int(period)), "bf_resampler_set_mode")
+
+    def set_mode_stream(self):
+        self._check(self._L.bf_resampler_set_mode(self._r, 0, 0), "bf_resampler_set_mode")
+
+    def callback(self, period: np.ndarray):
+        """One output_to_rosjack: returns (published block or None, accepted flag)."""
+        a = np.ascontiguousarray(period, np.float32)
+        assert a.size == self._period
+        out = np.empty(self._period, np.float32)
+        em, acc = C.c_int(), C.c_int()
+        self._check(self._L.bf_resampler_callback(self._r, a.ctypes.data, out.ctypes.data, C.byref(em), C.byref(acc)), "bf_resampler_callback")
+        return (out if em.value else None), bool(acc.value)
+
+    def callback_device(self, in_ptr: int, out_ptr: int, stream: int = 0):
+        em, acc = C.c_int(), C.c_int()
+        self._check(self._L.bf_resampler_callback_device(self._r, in_ptr, out_ptr, C.byref(em), C.byref(acc), stream or None),
+                    "bf_resampler_callback_device")
+        return bool(em.value), bool(acc.value)
 
     def close(self):
         if self._r:

@@ -289,6 +289,16 @@ struct bf_resampler {
     long poly_g = 1;
     float *d_in = nullptr, *d_out = nullptr;  // staging for the host entry point
     size_t cap_in = 0, cap_out = 0;
+    // BF_RS_ROSJACK (bf_resampler_set_mode): the stage as rosjack drives it, one call per JACK period
+    int mode = BF_RS_STREAM;
+    long period = 0;                 // rosjack_window_size: the input block, the cap on one src_process' output, the published block
+    long b_len = 0, b_current = 0, b_end = 0;  // libsamplerate's buffer bookkeeping: decides input_frames_used (prepare_data)
+    float *d_pend = nullptr;         // samplerate_buff_in: the last accepted period
+    long pend_off = 0, pend_n = 0;   // its part not yet pulled into the converter (data_in / input_frames)
+    float *d_fifo[2] = {nullptr, nullptr};  // every output computed so far and not yet published (samplerate_circbuff and what the
+    int fifo_cur = 0;                       // converter would still hold back), linear; compacted into the other buffer when full
+    long fifo_cap = 0, fifo_base = 0;       // global output index of d_fifo[fifo_cur][0]
+    long released = 0, emitted = 0;         // outputs src_process has handed over / rosjack has published
 
     double ratio() const { return (double)out_rate / (double)in_rate; }
     long half_taps() const {
@@ -424,6 +434,8 @@ extern "C" int bf_resampler_set_table(bf_resampler *r, const float *coeffs, int 
     return upload_table(r, coeffs, n_coeffs, index_inc);
 }
 
+static int rj_reset_locked(bf_resampler *r);
+
 extern "C" int bf_resampler_reset(bf_resampler *r) {
     if (!r) return BF_EINVAL;
     std::lock_guard<std::mutex> lk(r->mu);
@@ -431,7 +443,7 @@ extern "C" int bf_resampler_reset(bf_resampler *r) {
         if (hipMemset(r->d_hist[b], 0, sizeof(float) * (size_t)r->hist_len) != hipSuccess) return BF_EIO;
     r->hist_cur = 0;
     r->consumed = r->generated = 0;
-    return BF_OK;
+    return rj_reset_locked(r);
 }
 
 extern "C" size_t bf_resampler_out_count(bf_resampler *r, size_t n_in) {
@@ -509,12 +521,14 @@ extern "C" int bf_resampler_process_device(bf_resampler *r, const float *in_dev,
                                            void *hip_stream) {
     if (!r || (n_in && !in_dev)) return BF_EINVAL;
     std::lock_guard<std::mutex> lk(r->mu);
+    if (r->mode != BF_RS_STREAM) return BF_EINVAL;  // BF_RS_ROSJACK: one bf_resampler_callback* per JACK period
     return process_locked(r, in_dev, n_in, out_dev, out_cap, n_out, (hipStream_t)hip_stream);
 }
 
 extern "C" int bf_resampler_process(bf_resampler *r, const float *in, size_t n_in, float *out, size_t out_cap, size_t *n_out) {
     if (!r || (n_in && !in)) return BF_EINVAL;
     std::lock_guard<std::mutex> lk(r->mu);
+    if (r->mode != BF_RS_STREAM) return BF_EINVAL;
     const size_t want = (size_t)(r->outputs_for(r->consumed + (long)n_in) - r->generated);
     if (n_out) *n_out = want;
     if (want > out_cap || (want && !out)) return BF_EINVAL;
@@ -540,8 +554,167 @@ extern "C" int bf_resampler_process(bf_resampler *r, const float *in, size_t n_i
     return BF_OK;
 }
 
+// ---- BF_RS_ROSJACK: rosjack.cpp:311-349,416-436 around libsamplerate 0.1.9's src_process -----------------------------------------
+// What the reference's stage does that a stream converter does not: (1) samplerate_data.output_frames = rosjack_window_size
+// (rosjack.cpp:176-183), so one src_process returns at most one period of output; (2) the callback's period is copied into the
+// converter's input only when input_frames == 0 (:314-320), otherwise it is DROPPED; (3) src_process pulls input into its buffer
+// only when fewer than half_filter_chan_len + 1 samples are in hand and then as much as fits (src_sinc.c prepare_data), so that
+// when the output rate is the higher one input_frames_used is often 0 and whole periods never reach the converter
+// (16 -> 48 kHz keeps about every third period); (4) a block is published only when a full period of output is queued, at most
+// one per callback (:340-349, :416-436).  The sample VALUES are the stream converter's: the output at position K of the stream of
+// ACCEPTED periods does not depend on when it is computed, so the outputs are computed when their input is pulled in and parked
+// in a device FIFO; the bookkeeping below only decides which periods enter and when blocks leave.
+static long rj_prepare_len(bf_resampler *r) {  // prepare_data (libsamplerate 0.1.9), one channel
+    const long half = r->half_taps();
+    long len;
+    if (r->b_current == 0) {  // initial state: zeros in front, then data
+        len = r->b_len - 2 * half;
+        r->b_current = r->b_end = half;
+    } else if (r->b_end + half + 1 < r->b_len) {
+        len = r->b_len - r->b_current - half;
+    } else {  // what is left moves to the start of the buffer
+        const long keep = r->b_end - r->b_current;
+        r->b_current = half;
+        r->b_end = half + keep;
+        len = r->b_len - r->b_current - half;
+    }
+    return len > 0 ? len : 0;
+}
+
+static int rj_reset_locked(bf_resampler *r) {
+    r->b_current = r->b_end = 0;
+    r->pend_off = r->pend_n = 0;
+    r->fifo_cur = 0;
+    r->fifo_base = 0;
+    r->released = r->emitted = 0;
+    return BF_OK;
+}
+
+extern "C" int bf_resampler_set_mode(bf_resampler *r, int mode, int period) {
+    if (!r || (mode != BF_RS_STREAM && mode != BF_RS_ROSJACK) || (mode == BF_RS_ROSJACK && (period < 1 || period > 65536))) return BF_EINVAL;
+    {
+        std::lock_guard<std::mutex> lk(r->mu);
+        if (r->d_pend) (void)hipFree(r->d_pend);
+        for (int b = 0; b < 2; ++b) {
+            if (r->d_fifo[b]) (void)hipFree(r->d_fifo[b]);
+            r->d_fifo[b] = nullptr;
+        }
+        r->d_pend = nullptr;
+        r->mode = mode;
+        r->period = period;
+        if (mode == BF_RS_ROSJACK) {
+            // sinc_set_converter (0.1.9): b_len = max(lrint(2.5 * coeff_half_len / index_inc * SRC_MAX_RATIO), 4096) * channels
+            const long bl = lrint(2.5 * (double)(r->table_len - 2) / (double)r->index_inc * 256.0);
+            r->b_len = bl > 4096 ? bl : 4096;
+            const double up = r->ratio() > 1.0 ? r->ratio() : 1.0;
+            r->fifo_cap = 2 * ((long)std::ceil((double)(r->b_len + period) * up) + 2 * (long)period);
+            if (hipMalloc(&r->d_pend, sizeof(float) * (size_t)period) != hipSuccess) return BF_ENOMEM;
+            for (int b = 0; b < 2; ++b)
+                if (hipMalloc(&r->d_fifo[b], sizeof(float) * (size_t)r->fifo_cap) != hipSuccess) return BF_ENOMEM;
+        }
+    }
+    return bf_resampler_reset(r);
+}
+
+// one output_to_rosjack(data_out, data_length = period) on device buffers
+static int rj_callback_locked(bf_resampler *r, const float *d_period, float *d_block, int *emitted, int *accepted, hipStream_t s) {
+    if (r->mode != BF_RS_ROSJACK || !r->d_pend || !r->d_fifo[0] || !r->d_fifo[1]) return BF_EINVAL;
+    const long P = r->period, half = r->half_taps();
+    int acc = 0;
+    if (r->pend_n == 0) {  // rosjack.cpp:314-320
+        if (hipMemcpyAsync(r->d_pend, d_period, sizeof(float) * (size_t)P, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EIO;
+        r->pend_off = 0;
+        r->pend_n = P;
+        acc = 1;
+    }
+    // src_process with output_frames = P (sinc_mono_vari_process' loop; positions in the exact arithmetic of this converter)
+    long out_gen = 0;
+    while (out_gen < P) {
+        if (r->b_end - r->b_current <= half) {  // samples_in_hand <= half_filter_chan_len: reload
+            long n = rj_prepare_len(r);
+            if (n > r->pend_n) n = r->pend_n;
+            if (n > 0) {
+                // pull n samples in: every output they complete is computed now and parked behind the ones already there
+                const long total = r->outputs_for(r->consumed + n), want = total - r->generated;
+                long used = r->generated - r->fifo_base;  // floats in the FIFO
+                if (used + want > r->fifo_cap) {          // compact: drop what has been published
+                    const long live0 = r->emitted - r->fifo_base, live = used - live0;
+                    if (live + want > r->fifo_cap) return BF_ENOMEM;  // cannot happen: fifo_cap covers a full converter buffer
+                    if (live > 0 && hipMemcpyAsync(r->d_fifo[r->fifo_cur ^ 1], r->d_fifo[r->fifo_cur] + live0, sizeof(float) * (size_t)live,
+                                                   hipMemcpyDeviceToDevice, s) != hipSuccess)
+                        return BF_EIO;
+                    r->fifo_cur ^= 1;
+                    r->fifo_base = r->emitted;
+                    used = live;
+                }
+                const int rc = process_locked(r, r->d_pend + r->pend_off, (size_t)n, r->d_fifo[r->fifo_cur] + used, (size_t)(r->fifo_cap - used),
+                                              nullptr, s);
+                if (rc != BF_OK) return rc;
+                r->pend_off += n;
+                r->pend_n -= n;
+                r->b_end += n;
+            }
+            if (r->b_end - r->b_current <= half) break;
+        }
+        // one output sample; b_current advances by the integer step of the input position: cur(K + 1) - cur(K)
+        const unsigned long long K = (unsigned long long)r->released;
+        const long step = (long)(((K + 1) * (unsigned long long)r->in_rate) / (unsigned long long)r->out_rate -
+                                 (K * (unsigned long long)r->in_rate) / (unsigned long long)r->out_rate);
+        r->b_current += step;
+        ++r->released;
+        ++out_gen;
+    }
+    int em = 0;
+    if (r->released - r->emitted >= P) {  // convert_to_sample_rate_ready (:340-349): one block per callback (:416-436)
+        if (d_block && hipMemcpyAsync(d_block, r->d_fifo[r->fifo_cur] + (r->emitted - r->fifo_base), sizeof(float) * (size_t)P,
+                                      hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return BF_EIO;
+        r->emitted += P;
+        em = 1;
+    }
+    if (emitted) *emitted = em;
+    if (accepted) *accepted = acc;
+    return BF_OK;
+}
+
+extern "C" int bf_resampler_callback_device(bf_resampler *r, const float *period_dev, float *block_dev, int *emitted, int *accepted,
+                                            void *hip_stream) {
+    if (!r || !period_dev || !block_dev) return BF_EINVAL;
+    std::lock_guard<std::mutex> lk(r->mu);
+    return rj_callback_locked(r, period_dev, block_dev, emitted, accepted, (hipStream_t)hip_stream);
+}
+
+extern "C" int bf_resampler_callback(bf_resampler *r, const float *period, float *block, int *emitted, int *accepted) {
+    if (!r || !period || !block) return BF_EINVAL;
+    std::lock_guard<std::mutex> lk(r->mu);
+    if (r->mode != BF_RS_ROSJACK) return BF_EINVAL;
+    const size_t P = (size_t)r->period;
+    for (int k = 0; k < 2; ++k) {  // staging: d_in holds the period, d_out the block
+        float **buf = k ? &r->d_out : &r->d_in;
+        size_t *cap = k ? &r->cap_out : &r->cap_in;
+        if (P > *cap) {
+            if (*buf) (void)hipFree(*buf);
+            *buf = nullptr;
+            *cap = 0;
+            if (hipMalloc(buf, sizeof(float) * P) != hipSuccess) return BF_ENOMEM;
+            *cap = P;
+        }
+    }
+    if (hipMemcpy(r->d_in, period, sizeof(float) * P, hipMemcpyHostToDevice) != hipSuccess) return BF_EIO;
+    int em = 0;
+    const int rc = rj_callback_locked(r, r->d_in, r->d_out, &em, accepted, nullptr);
+    if (rc != BF_OK) return rc;
+    if (hipDeviceSynchronize() != hipSuccess) return BF_EIO;
+    if (em && hipMemcpy(block, r->d_out, sizeof(float) * P, hipMemcpyDeviceToHost) != hipSuccess) return BF_EIO;
+    if (emitted) *emitted = em;
+    return BF_OK;
+}
+
 extern "C" void bf_resampler_destroy(bf_resampler *r) {
     if (!r) return;
+    if (r->d_pend) (void)hipFree(r->d_pend);
+    for (int b = 0; b < 2; ++b)
+        if (r->d_fifo[b]) (void)hipFree(r->d_fifo[b]);
     if (r->d_table) (void)hipFree(r->d_table);
     for (int b = 0; b < 2; ++b)
         if (r->d_hist[b]) (void)hipFree(r->d_hist[b]);

@@ -26,6 +26,7 @@ static FILE *g_out = nullptr;
 static bf_wav_writer *g_wav = nullptr;
 static bf_resampler *g_rs = nullptr;
 static std::vector<float> g_rs_buf;
+static bool g_rosjack_stage = false;  // argv[7] = "rosjack": BF_RS_ROSJACK (bfcore.h) instead of the complete stream conversion
 
 static float **input_from_files(int n) {            // stands in for rosjack.cpp:538-547
     for (int m = 0; m < g_mics; ++m) g_ptrs[m] = g_in.data() + (size_t)m * g_samples_per_mic + g_pos;
@@ -33,7 +34,12 @@ static float **input_from_files(int n) {            // stands in for rosjack.cpp
     return g_ptrs.data();
 }
 static void output_to_file(float *data, int n, int) {  // rosjack.cpp:356 output_to_rosjack, write_file branch :404-409
-    if (g_rs) {  // convert_to_sample_rate (rosjack.cpp:311-338): whatever the converter releases for this period
+    if (g_rs && g_rosjack_stage) {  // the stage as rosjack runs it: a period may be dropped, at most one block leaves per callback
+        int emitted = 0;
+        g_rs_buf.resize((size_t)n);
+        if (bf_resampler_callback(g_rs, data, g_rs_buf.data(), &emitted, nullptr) != BF_OK || !emitted) return;
+        data = g_rs_buf.data();
+    } else if (g_rs) {  // convert_to_sample_rate (rosjack.cpp:311-338) as a complete stream conversion: whatever the converter releases
         size_t got = 0;
         g_rs_buf.resize(bf_resampler_out_count(g_rs, (size_t)n) + 1);
         if (bf_resampler_process(g_rs, data, (size_t)n, g_rs_buf.data(), g_rs_buf.size(), &got) != BF_OK) return;
@@ -52,7 +58,7 @@ static bool ends_with(const char *s, const char *suf) {
 
 int main(int argc, char **argv) {
     if (argc < 5) {
-        fprintf(stderr, "usage: %s <algo> <config.yaml> <in.f32> <out.f32> [theta_script]\n", argv[0]);
+        fprintf(stderr, "usage: %s <algo> <config.yaml> <in.f32|.wav> <out.f32|.wav> [theta_script|-] [out_rate] [rosjack]\n", argv[0]);
         return 2;
     }
     const char *names[] = {"das", "mvdr", "lcmv", "gss", "phase", "phasempf", "mcra", "gsc"};
@@ -82,6 +88,8 @@ int main(int argc, char **argv) {
         fprintf(stderr, "invalid output sample rate %d: keeping %d\n", out_rate, (int)cfg.sample_rate);  // rosjack.cpp:170-172
         out_rate = (int)cfg.sample_rate;
     }
+    g_rosjack_stage = g_rs && argc > 7 && !strcmp(argv[7], "rosjack");
+    if (g_rosjack_stage && bf_resampler_set_mode(g_rs, BF_RS_ROSJACK, cfg.hop) != BF_OK) return 2;
     if (ends_with(argv[4], ".wav")) {
         if (bf_wav_writer_open(argv[4], out_rate, &g_wav) != BF_OK) return 2;
     } else {

@@ -282,15 +282,26 @@ void bf_wav_free(float *planar);
  * src_sinc.c's mono converter; the built-in coefficient table is a Kaiser-windowed sinc of SINC_FASTEST's geometry, NOT
  * libsamplerate's fastest_coeffs.h (parity unpinned) -- bf_resampler_set_table installs any table of that form, e.g. the
  * original one.
- * DEVIATION from rosjack's stage when out_rate > in_rate: the reference keeps output_frames = rosjack_window_size and copies a
- * new period into the converter only when input_frames == 0 (rosjack.cpp:311-338), and it emits at most one data_length block
- * per callback (:416-436) -- when upsampling src_process leaves input unconsumed, so the reference DROPS periods and never
- * writes a trailing partial block.  The converter here (and examples/file_node) consumes every input sample and returns every output
- * sample: for ratio > 1 the stream is the mathematically complete conversion, longer than the reference's file; for
- * ratio < 1 only the tail (less than one period) differs.  tests/test_resample_gpu.py pins the chosen behaviour. */
+ * Two ways of driving it (bf_resampler_set_mode):
+ *   BF_RS_STREAM (default)  every input sample is consumed and every output sample returned (bf_resampler_process*): the
+ *                           mathematically complete conversion of the stream, independent of how it is cut into calls;
+ *   BF_RS_ROSJACK           the stage exactly as rosjack runs it, one bf_resampler_callback* per JACK period: src_process may
+ *                           return at most one period of output (output_frames = rosjack_window_size, rosjack.cpp:176-183), a
+ *                           period is copied into the converter only when input_frames == 0 and DROPPED otherwise (:311-338),
+ *                           libsamplerate pulls input in lazily (src_sinc.c prepare_data), and a block is published only when a
+ *                           full period of output is queued, at most one per callback, the tail never (:340-349, :416-436).
+ *                           With out_rate > in_rate the reference therefore loses whole periods (16 -> 48 kHz keeps about every
+ *                           third one); with out_rate <= in_rate the two modes differ only in the blocking of the output.
+ *                           examples/file_node: trailing argument "rosjack". */
 typedef struct bf_resampler bf_resampler;
 int bf_resampler_create(int in_rate, int out_rate, bf_resampler **out);               /* src_new + src_ratio; BF_EINVAL outside 1/256..256 */
 int bf_resampler_set_table(bf_resampler *r, const float *coeffs, int n_coeffs, int index_inc); /* half table incl. 2 guard entries; resets */
+enum bf_resampler_mode { BF_RS_STREAM = 0, BF_RS_ROSJACK = 1 };
+int bf_resampler_set_mode(bf_resampler *r, int mode, int period);                     /* period = rosjack_window_size (BF_RS_ROSJACK); resets */
+/* BF_RS_ROSJACK: one output_to_rosjack(data_out, period).  *emitted = 1 when a block of `period` samples was published into
+ * `block`, *accepted = 0 when the reference would have dropped this period.  Device or host buffers of `period` floats. */
+int bf_resampler_callback_device(bf_resampler *r, const float *period_dev, float *block_dev, int *emitted, int *accepted, void *hip_stream);
+int bf_resampler_callback(bf_resampler *r, const float *period, float *block, int *emitted, int *accepted);
 int bf_resampler_reset(bf_resampler *r);                                              /* src_reset */
 size_t bf_resampler_out_count(bf_resampler *r, size_t n_in);                          /* outputs the next call with n_in samples yields */
 int bf_resampler_latency(bf_resampler *r);                                            /* look-ahead in input samples */

@@ -56,3 +56,24 @@ def test_table_geometry():
     assert len(t) == 2464 and DEFAULT_INC == 128 and t[-1] == 0.0
     assert abs(float(t[0]) - 0.8314723730) < 1e-7      # libsamplerate's published first SINC_FASTEST coefficient
     assert abs(float(t[1]) - 0.8314140055) < 1e-7      # ... and the second
+
+
+def test_rosjack_stage_restatement_drops_periods_when_upsampling():
+    """oracle/rosjack_stage_oracle.py (rosjack.cpp:311-349,416-436 around libsamplerate's lazy prepare_data): what it publishes is
+    the stream conversion of the periods it accepted, one block per callback; 16 -> 48 kHz keeps roughly every third period."""
+    from oracle.rosjack_stage_oracle import RosjackStage
+    from oracle.resample_oracle import SincResampler
+    rng = np.random.default_rng(3)
+    P, F = 256, 24
+    y = (0.1 * rng.standard_normal(F * P)).astype(np.float32)
+    for rates, frac in (((16000, 48000), (0.3, 0.5)), ((44100, 48000), (0.85, 0.99)), ((48000, 16000), (1.0, 1.0))):
+        st = RosjackStage(*rates, P)
+        out, acc = st.run(y)
+        assert frac[0] <= acc.mean() <= frac[1], (rates, acc.mean())
+        kept = np.concatenate([y[t * P:(t + 1) * P] for t in range(F) if acc[t]])
+        ref = SincResampler(*rates).process(kept)
+        assert len(out) % P == 0 and len(out) > 0 and np.array_equal(out, ref[:len(out)])
+        assert all(u in (0, P) for u in st.used)          # libsamplerate's buffer (12 310 samples) always has room for a whole period
+    st = RosjackStage(16000, 48000, P)
+    st.run(y)
+    assert st.accepted[:9] == [True, True, False, True, False, False, True, False, False]

@@ -174,3 +174,74 @@ def test_upsampling_keeps_every_sample():
     # a 440 Hz tone stays a 440 Hz tone at the new rate (first samples: zero history)
     ref = 0.2 * np.sin(2 * np.pi * 440.0 * np.arange(len(y)) / 48000.0)
     assert np.max(np.abs(y[600:] - ref[600:len(y)])) < 2e-3
+
+
+@pytest.mark.parametrize("rates", [(16000, 48000), (44100, 48000), (48000, 16000), (48000, 44100)])
+@pytest.mark.parametrize("period", [512, 1024])
+def test_rosjack_stage_mode_matches_the_restatement_of_rosjack(rates, period):
+    """BF_RS_ROSJACK against oracle/rosjack_stage_oracle.py (rosjack.cpp:311-349,416-436 around libsamplerate's lazy prepare_data):
+    the same periods accepted / dropped, a block published in the same callbacks, the same samples (1e-6 of the scale: the two
+    sides differ only by the oracle's accumulated input position); and the complete stream conversion (BF_RS_STREAM) of the SAME
+    input beside it -- longer when upsampling, where the reference loses whole periods."""
+    from oracle.rosjack_stage_oracle import RosjackStage
+    rng = np.random.default_rng(21)
+    F = 60
+    y = (0.2 * rng.standard_normal(F * period)).astype(np.float32)
+    st = RosjackStage(*rates, period)
+    g = capi.Resampler(*rates)
+    g.set_mode_rosjack(period)
+    blocks_o, blocks_g, acc_g, when_o, when_g = [], [], [], [], []
+    for t in range(F):
+        seg = y[t * period:(t + 1) * period]
+        bo = st.callback(seg)
+        bg, ag = g.callback(seg)
+        acc_g.append(ag)
+        if bo is not None:
+            blocks_o.append(bo)
+            when_o.append(t)
+        if bg is not None:
+            blocks_g.append(bg)
+            when_g.append(t)
+    assert acc_g == st.accepted and when_g == when_o and len(blocks_g) > 10
+    yo, yg = np.concatenate(blocks_o), np.concatenate(blocks_g)
+    assert np.max(np.abs(yo - yg)) <= 1e-6 * np.max(np.abs(yo))
+    if rates[1] > rates[0]:
+        assert not all(acc_g)                       # the reference drops periods when upsampling ...
+        if rates == (16000, 48000):
+            assert 0.3 < np.mean(acc_g) < 0.45      # ... about two of three at a ratio of 3
+    else:
+        assert all(acc_g)
+    with pytest.raises(capi.BfError):
+        g.process(y[:period])                       # the stream entry refuses a converter that is in rosjack mode
+    # the same input through the default mode: every sample converted
+    s = capi.Resampler(*rates)
+    whole = s.process(y)
+    assert abs(len(whole) - int(len(y) * rates[1] / rates[0])) <= 2 * s.latency * max(1, rates[1] // rates[0]) + 2
+    if all(acc_g):                                  # nothing dropped: the stage's blocks are a prefix of the stream conversion
+        assert np.array_equal(yg, whole[:len(yg)])
+    else:
+        assert len(whole) > len(yg)
+    # back to stream mode on the same object
+    g.set_mode_stream()
+    assert np.array_equal(g.process(y), whole)
+
+
+def test_rosjack_stage_on_device_buffers():
+    import torch
+    period, F = 512, 40
+    rng = np.random.default_rng(22)
+    y = (0.2 * rng.standard_normal(F * period)).astype(np.float32)
+    h = capi.Resampler(16000, 48000)
+    h.set_mode_rosjack(period)
+    d = capi.Resampler(16000, 48000)
+    d.set_mode_rosjack(period)
+    yd = torch.from_numpy(y).cuda()
+    od = torch.empty(period, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    for t in range(F):
+        bh, ah = h.callback(y[t * period:(t + 1) * period])
+        em, ad = d.callback_device(yd[t * period:].data_ptr(), od.data_ptr(), s)
+        assert ad == ah and em == (bh is not None)
+        if em:
+            torch.cuda.synchronize()
+            assert np.array_equal(od.cpu().numpy(), bh)
