@@ -120,8 +120,27 @@ def pieces(sh: Shard, n_pieces: int):
     return out
 
 
+class _StagedRecv:
+    """irecv into a host buffer + the copy into its device slice once it has arrived (host_staged transfers)."""
+
+    def __init__(self, work, host, dev_slice):
+        self.work, self.host, self.dev_slice = work, host, dev_slice
+
+    def wait(self):
+        self.work.wait()
+        self.dev_slice.copy_(self.host)
+
+
+class _StagedSend:
+    def __init__(self, work, host):
+        self.work, self.host = work, host   # the host buffer lives as long as the transfer
+
+    def wait(self):
+        self.work.wait()
+
+
 def run_shard_overlapped(bf, x_feed, y_feed, n_frames: int, world: int, rank: int, halo: int, n_pieces: int = 4, dst: int = 0,
-                         out=None, stream: int = 0):
+                         out=None, stream: int = 0, host_staged: bool = False):
     """run_shard with the final gather overlapped: the rank's slice is walked in `n_pieces` pieces (state carries from piece
     to piece), and as soon as a piece is enqueued its owned hops are handed to an ASYNCHRONOUS point-to-point transfer to
     `dst`, which the backend orders behind the compute stream's work so far and runs on its own stream -- piece c travels
@@ -130,6 +149,8 @@ def run_shard_overlapped(bf, x_feed, y_feed, n_frames: int, world: int, rank: in
     x_feed [M, n_feed*hop] / y_feed [n_feed*hop]: torch tensors (planar) holding / receiving hops [first_feed_frame, hi).
     out (dst only): [n_frames*hop] tensor, filled in stream order.  Every rank cuts its slice by the same rule (`pieces`), so
     the receiver knows each sender's piece sizes without a handshake.
+    host_staged: carry the pieces through host buffers (a backend without device-tensor point-to-point, e.g. gloo: the one-GPU
+    test hook); the schedule -- who sends what in which round -- is the same.
     Returns the pending work handles: wait on them (or synchronise the device) before reading `out`."""
     import contextlib
     import torch
@@ -143,10 +164,11 @@ def run_shard_overlapped(bf, x_feed, y_feed, n_frames: int, world: int, rank: in
     if x_feed.is_cuda and stream != torch.cuda.current_stream(x_feed.device).cuda_stream:
         ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream, device=x_feed.device))
     with ctx:
-        return _run_shard_overlapped(bf, x_feed, y_feed, n_frames, world, rank, halo, n_pieces, dst, out, stream, sh, H, dist)
+        return _run_shard_overlapped(bf, x_feed, y_feed, n_frames, world, rank, halo, n_pieces, dst, out, stream, sh, H, dist, host_staged)
 
 
-def _run_shard_overlapped(bf, x_feed, y_feed, n_frames, world, rank, halo, n_pieces, dst, out, stream, sh, H, dist):
+def _run_shard_overlapped(bf, x_feed, y_feed, n_frames, world, rank, halo, n_pieces, dst, out, stream, sh, H, dist, host_staged):
+    import torch
     bf.reset_async(stream)
     peers = {r: pieces(plan(n_frames, world, r, halo), n_pieces) for r in range(world)} if rank == dst else None
     works = []
@@ -167,9 +189,18 @@ def _run_shard_overlapped(bf, x_feed, y_feed, n_frames, world, rank, halo, n_pie
                 _, _, o0, n = peers[r][c]
                 if n > 0:
                     lo_r = plan(n_frames, world, r, halo).lo
-                    works.append(dist.irecv(out[(lo_r + o0) * H:(lo_r + o0 + n) * H], src=r))
+                    sl = out[(lo_r + o0) * H:(lo_r + o0 + n) * H]
+                    if host_staged:
+                        hb = torch.empty(n * H, dtype=out.dtype)
+                        works.append(_StagedRecv(dist.irecv(hb, src=r), hb, sl))
+                    else:
+                        works.append(dist.irecv(sl, src=r))
         elif n_own > 0:
-            works.append(dist.isend(mine, dst=dst))
+            if host_staged:
+                hb = mine.cpu()   # synchronises with the piece just enqueued
+                works.append(_StagedSend(dist.isend(hb, dst=dst), hb))
+            else:
+                works.append(dist.isend(mine, dst=dst))
     return works
 
 

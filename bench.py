@@ -192,10 +192,14 @@ def main():
                     help="--strong: frames of the global stream (default 262144 = BASELINE config 5's batch)")
     ap.add_argument("--independent", action="store_true",
                     help="N > 1: round-1 behaviour, every rank an independent random batch (no shard plan)")
-    ap.add_argument("--gather", default="final", choices=["final", "overlap", "none"],
+    ap.add_argument("--gather", default="overlap", choices=["final", "overlap", "none"],
                     help="final: K steps that each end with one gather of the owned slabs onto rank 0 (serial with the compute);\n"
-                         "overlap: additionally K steps whose slices are walked in --pieces pieces, each piece's owned hops sent to\n"
-                         "rank 0 point-to-point while the next piece computes (shard.run_shard_overlapped)")
+                         "overlap (default): additionally K steps whose slices are walked in --pieces pieces, each piece's owned hops sent\n"
+                         "to rank 0 point-to-point while the next piece computes (shard.run_shard_overlapped)")
+    ap.add_argument("--gather-timeout-s", type=float, default=180.0,
+                    help="N > 1: if the gather timings (which follow the compute timing) have not finished after this long, rank 0 prints\n"
+                         "the line with the compute figures and gather_error set, and every rank exits: a collective that hangs on\n"
+                         "hardware this build never saw must not cost the run its result")
     ap.add_argument("--pieces", type=int, default=4)
     ap.add_argument("--cpu-frames", type=int, default=196608,
                     help="frames in the CPU-baseline sample (0 = skip); the default is ~12 s of single-core work (its oracle, with the FFT plan cached, does ~16 k frames per second)")
@@ -236,8 +240,12 @@ def main():
     # test hook for single-GPU boxes: BF_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and uses gloo for the
     # (host-staged) gather, so the launcher / barrier / shard-plan / gather code path can be exercised without 2 GPUs
     one_dev = os.environ.get("BF_BENCH_ONE_DEVICE", "0") == "1"
+    narrowed = any(k in os.environ for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"))
     if one_dev:
         local_rank = 0
+    elif world > torch.cuda.device_count() and not narrowed:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} device(s) visible: two ranks on one GPU would halve each "
+                         "other's numbers silently (BF_BENCH_ONE_DEVICE=1 is the test hook for that)")
     elif local_rank >= torch.cuda.device_count():  # launcher narrowed the visible devices per rank (HIP_VISIBLE_DEVICES)
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
@@ -248,6 +256,14 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+
+    n_ranks_seen = 1
+    if world > 1:  # every rank really joined the group: a sum of ones
+        ones = torch.ones(1, device="cpu" if one_dev else dev, dtype=torch.float64)
+        dist.all_reduce(ones)
+        n_ranks_seen = int(ones.item())
+        if n_ranks_seen != world:
+            raise SystemExit(f"all_reduce of ones over the group gives {n_ranks_seen}, WORLD_SIZE is {world}")
 
     def all_max(vals):
         t = torch.tensor(vals, device="cpu" if one_dev else dev, dtype=torch.float64)
@@ -339,14 +355,90 @@ def main():
     dt = timed(args.steps)
     ms_kernel, n_timed_launches = bf.kernel_timing_end()
     ms_call = dt / args.steps * 1e3
+    def make_line(dt_g, dt_o, gather_error, extra):
+        """The one JSON line (rank 0).  Called at the end -- or by the gather watchdog with what has been measured so far."""
+        frames_total = frames_per_step_all_ranks * args.steps
+        value = frames_total / dt
+        bpf = algorithmic_bytes_per_frame(M)
+        units_per_launch = S * n_feed
+        # fused das: its one kernel; the other nodes run a chain of kernels (stft -> per-bin -> istft): the chain's duration
+        k_ms = ms_kernel if ms_kernel > 0 else ms_call
+        achieved = bpf * units_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        tag = f"{args.algo}{M}" + ("_f64" if das_impl == BF_DAS_BINS_F64 else "")
+        if sharded:
+            shl = shard.plan(F_total, world, world - 1, halo)
+            wl = (f"{args.algo} {M}-mic 1024-pt (hop 512), ONE {F_total}-frame stream frame-sharded x{world} by shard.plan "
+                  f"(last rank: {shl.n_own} owned + {shl.warm} warm-up frames + {shl.lead} lead hop), cold handle per step, "
+                  f"planar slices resident in HBM")
+        else:
+            wl = (f"{args.algo} {M}-mic 1024-pt (hop 512), {F}-frame batch per GPU, {S} stream(s), {args.layout} input resident in HBM")
+        out = {
+            "metric": "stft_frames_per_sec", "value": value, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong" if (sharded and args.strong) else "weak", "vs_baseline": None,
+            "dtype": "f32" if (args.algo == "das" and das_impl == BF_DAS_FUSED_F32) else "f64", "data": "synthetic",
+            "value_including_final_gather": (frames_total / dt_g) if dt_g else None,
+            "ms_per_step_including_final_gather": (dt_g / args.steps * 1e3) if dt_g else None,
+            "value_including_overlapped_gather": (frames_total / dt_o) if dt_o else None,
+            "ms_per_step_including_overlapped_gather": (dt_o / args.steps * 1e3) if dt_o else None,
+            "config": {"workload": wl, "frames_per_gpu": n_own, "frames_fed_per_gpu": n_feed,
+                       "global_stream_frames": frames_per_step_all_ranks if sharded else None, "mics": M, "fft": NFFT,
+                       "hop": HOP, "streams": S, "layout": args.layout,
+                       "gather": (args.gather if sharded else "n/a"),
+                       "final_gather_bytes_into_rank0": ((world - 1) * own_max * HOP * 4) if sharded else None,
+                       "parallelism": (f"frame-sharded x{world} (shard.plan: halo recomputed locally, no data-path collective)"
+                                       if sharded else f"independent batches x{world}"),
+                       "input": "uniform noise in [-0.5, 0.5) (counter-based global stream)" if sharded else "uniform noise in [-0.5, 0.5)",
+                       "settle_launches_before_warmup": settle_launches},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # PMC traffic exists for the profiled workloads only (profiles/traffic_<tag>.json)
+                         "traffic": load_traffic(tag) if (n_feed == 65536 and S == 1 and args.layout == "planar") else None,
+                         "kernel": ("das_fused_kernel" if das_impl == BF_DAS_FUSED_F32 else "das_f64_w64_kernel") if args.algo == "das"
+                                   else "bin pipeline (stft + per-bin kernel + istft)",
+                         "kernel_ms": k_ms, "call_ms": ms_call, "kernel_launches_timed": n_timed_launches,
+                         "kernel_ms_source": "one HIP event pair per launch on the launch stream, inside the K timed steps",
+                         "algorithmic_bytes_per_frame": bpf,
+                         "frames_per_launch": units_per_launch, "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
+        }
+        out["n_ranks_seen"] = n_ranks_seen
+        if gather_error:
+            out["gather_error"] = gather_error
+        out["cpu_baseline"] = cpu_line  # None at N > 1 (the contract asks for it on rank 0 at N = 1 only)
+        if extra:
+            out["extra"] = extra
+        return out
+
     dt_g = dt_o = None
+    gather_state = {"dt_g": None, "dt_o": None, "error": None, "phase": "idle", "armed": False}
+    watchdog = None
+    if sharded and args.gather in ("final", "overlap") and args.gather_timeout_s > 0:
+        import threading
+
+        def on_gather_timeout():
+            if not gather_state["armed"]:
+                return
+            gather_state["error"] = (f"gather phase '{gather_state['phase']}' did not finish within {args.gather_timeout_s:.0f} s: "
+                                     "compute figures only")
+            if rank == 0:
+                print(json.dumps(make_line(gather_state["dt_g"], gather_state["dt_o"], gather_state["error"], None)), flush=True)
+            os._exit(0)  # the hung collective cannot be cancelled from here; every rank's own watchdog does the same
+
+        watchdog = threading.Timer(args.gather_timeout_s, on_gather_timeout)
+        watchdog.daemon = True
     if sharded and args.gather in ("final", "overlap"):
+        if watchdog is not None:
+            gather_state["armed"], gather_state["phase"] = True, "final"
+            watchdog.start()
         step(True)                                  # first gather also builds the RCCL channels
         dt_g = timed(args.steps, with_gather=True)  # K steps, each ending with the final gather onto rank 0
-    if sharded and args.gather == "overlap" and not one_dev:
+        gather_state["dt_g"] = dt_g
+    if sharded and args.gather == "overlap":
+        gather_state["phase"] = "overlap"
         out_full = torch.empty(F_total * HOP, device=dev, dtype=torch.float32) if rank == 0 else None
         def step_overlapped():
-            for w in shard.run_shard_overlapped(bf, x, y, F_total, world, rank, halo, n_pieces=args.pieces, out=out_full, stream=sptr):
+            for w in shard.run_shard_overlapped(bf, x, y, F_total, world, rank, halo, n_pieces=args.pieces, out=out_full, stream=sptr,
+                                                host_staged=one_dev):
                 w.wait()                            # stream-level wait: the next step's kernels queue behind it
         step_overlapped()
         torch.cuda.synchronize(dev)
@@ -357,6 +449,10 @@ def main():
         torch.cuda.synchronize(dev)
         dist.barrier()
         dt_o = all_max([time.perf_counter() - t0])[0]
+        gather_state["dt_o"] = dt_o
+    gather_state["armed"] = False
+    if watchdog is not None:
+        watchdog.cancel()
     torch.cuda.synchronize(dev)
 
     # ---- secondary lines: the other BASELINE configs, rank 0 at N = 1 -------------------------------------------
@@ -559,54 +655,7 @@ def main():
             extra["mvdr_frac_of_fp64_vector_peak"] = extra["mvdr"]["frac_of_fp64_vector_peak"]
 
     if rank == 0:
-        frames_total = frames_per_step_all_ranks * args.steps
-        value = frames_total / dt
-        bpf = algorithmic_bytes_per_frame(M)
-        units_per_launch = S * n_feed
-        # fused das: its one kernel; the other nodes run a chain of kernels (stft -> per-bin -> istft): the chain's duration
-        k_ms = ms_kernel if ms_kernel > 0 else ms_call
-        achieved = bpf * units_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        tag = f"{args.algo}{M}" + ("_f64" if das_impl == BF_DAS_BINS_F64 else "")
-        if sharded:
-            shl = shard.plan(F_total, world, world - 1, halo)
-            wl = (f"{args.algo} {M}-mic 1024-pt (hop 512), ONE {F_total}-frame stream frame-sharded x{world} by shard.plan "
-                  f"(last rank: {shl.n_own} owned + {shl.warm} warm-up frames + {shl.lead} lead hop), cold handle per step, "
-                  f"planar slices resident in HBM")
-        else:
-            wl = (f"{args.algo} {M}-mic 1024-pt (hop 512), {F}-frame batch per GPU, {S} stream(s), {args.layout} input resident in HBM")
-        out = {
-            "metric": "stft_frames_per_sec", "value": value, "unit": "frames/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if (sharded and args.strong) else "weak", "vs_baseline": None,
-            "dtype": "f32" if (args.algo == "das" and das_impl == BF_DAS_FUSED_F32) else "f64", "data": "synthetic",
-            "value_including_final_gather": (frames_total / dt_g) if dt_g else None,
-            "ms_per_step_including_final_gather": (dt_g / args.steps * 1e3) if dt_g else None,
-            "value_including_overlapped_gather": (frames_total / dt_o) if dt_o else None,
-            "ms_per_step_including_overlapped_gather": (dt_o / args.steps * 1e3) if dt_o else None,
-            "config": {"workload": wl, "frames_per_gpu": n_own, "frames_fed_per_gpu": n_feed,
-                       "global_stream_frames": frames_per_step_all_ranks if sharded else None, "mics": M, "fft": NFFT,
-                       "hop": HOP, "streams": S, "layout": args.layout,
-                       "gather": (args.gather if sharded else "n/a"),
-                       "final_gather_bytes_into_rank0": ((world - 1) * own_max * HOP * 4) if sharded else None,
-                       "parallelism": (f"frame-sharded x{world} (shard.plan: halo recomputed locally, no data-path collective)"
-                                       if sharded else f"independent batches x{world}"),
-                       "input": "uniform noise in [-0.5, 0.5) (counter-based global stream)" if sharded else "uniform noise in [-0.5, 0.5)",
-                       "settle_launches_before_warmup": settle_launches},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         # PMC traffic exists for the profiled workloads only (profiles/traffic_<tag>.json)
-                         "traffic": load_traffic(tag) if (n_feed == 65536 and S == 1 and args.layout == "planar") else None,
-                         "kernel": ("das_fused_kernel" if das_impl == BF_DAS_FUSED_F32 else "das_f64_w64_kernel") if args.algo == "das"
-                                   else "bin pipeline (stft + per-bin kernel + istft)",
-                         "kernel_ms": k_ms, "call_ms": ms_call, "kernel_launches_timed": n_timed_launches,
-                         "kernel_ms_source": "one HIP event pair per launch on the launch stream, inside the K timed steps",
-                         "algorithmic_bytes_per_frame": bpf,
-                         "frames_per_launch": units_per_launch, "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
-        }
-        out["cpu_baseline"] = cpu_line  # None at N > 1 (the contract asks for it on rank 0 at N = 1 only)
-        if extra:
-            out["extra"] = extra
-        print(json.dumps(out), flush=True)
+        print(json.dumps(make_line(dt_g, dt_o, gather_state["error"], extra)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -9,6 +9,9 @@
 //       starts from a cold handle, and walks its slice in `chunks` pieces: while piece c is computed on the compute stream,
 //       piece c-1's owned hops travel to rank 0 on a second stream (grouped ncclSend / ncclRecv = point-to-point over the
 //       direct xGMI link of each peer).  Rank 0 prints the step time with and without the gather and a checksum.
+//       BF_SHARD_STUB=1: the same schedule with the transfers carried by named pipes through host memory instead of RCCL (which
+//       refuses two ranks on one device): every ncclSend / ncclRecv of the real run has its counterpart, sizes are checked at the
+//       receiving end and an unmatched transfer blocks -- the way to run all ranks of the gather on a one-GPU box.
 //   shard_node <algo> <n_mics> <total_frames> <world> logical
 //       no RCCL: one process plays all `world` ranks one after the other on one GPU (device-to-device copies instead of the
 //       gather) and compares the assembled output with the unsharded run of the same stream -- the check that the plan,
@@ -16,11 +19,17 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cerrno>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -114,6 +123,86 @@ static int walk(bf_handle *bf, Rank &r, int M, int H, int chunks, hipStream_t cs
     return 0;
 }
 
+// ---- the gather's transport: RCCL point-to-point, or (BF_SHARD_STUB=1) named pipes through host memory --------------------------
+struct Transport {
+    bool stub = false;
+    ncclComm_t comm = nullptr;
+    int rank = 0;
+    std::string base;  // stub: pipes <base>.<src>.<dst>
+    std::vector<float> host;
+
+    int init(int world, int rank_, const char *id_file, bool stub_) {
+        stub = stub_;
+        rank = rank_;
+        base = id_file;
+        if (stub) {
+            for (int r = 1; r < world; ++r) {  // every rank may create them; EEXIST is fine
+                const std::string p = base + "." + std::to_string(r) + ".0";
+                if (mkfifo(p.c_str(), 0600) != 0 && errno != EEXIST) return 1;
+            }
+            return 0;
+        }
+        ncclUniqueId id;
+        if (rank == 0) {
+            CKN(ncclGetUniqueId(&id));
+            const std::string tmp = base + ".tmp";
+            FILE *f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(&id, sizeof(id), 1, f) != 1) return 1;
+            fclose(f);
+            rename(tmp.c_str(), base.c_str());
+        } else {
+            FILE *f = nullptr;
+            for (int i = 0; i < 600 && !(f = fopen(base.c_str(), "rb")); ++i) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            if (!f || fread(&id, sizeof(id), 1, f) != 1) return 1;
+            fclose(f);
+        }
+        CKN(ncclCommInitRank(&comm, world, id, rank));
+        return 0;
+    }
+    int group_start() { if (!stub) CKN(ncclGroupStart()); return 0; }
+    int group_end() { if (!stub) CKN(ncclGroupEnd()); return 0; }
+    int send(const float *dev, size_t n, int peer, hipStream_t s) {
+        if (!stub) { CKN(ncclSend(dev, n, ncclFloat, peer, comm, s)); return 0; }
+        host.resize(n);
+        CK(hipStreamSynchronize(s));
+        CK(hipMemcpy(host.data(), dev, n * sizeof(float), hipMemcpyDeviceToHost));
+        const std::string p = base + "." + std::to_string(rank) + "." + std::to_string(peer);
+        const int fd = open(p.c_str(), O_WRONLY);  // blocks until the receiver opens its end
+        if (fd < 0) return 1;
+        unsigned long long hdr = n;
+        bool ok = write(fd, &hdr, sizeof(hdr)) == (ssize_t)sizeof(hdr);
+        for (size_t off = 0; ok && off < n * sizeof(float);) {
+            const ssize_t w = write(fd, (const char *)host.data() + off, n * sizeof(float) - off);
+            if (w <= 0) ok = false; else off += (size_t)w;
+        }
+        close(fd);
+        return ok ? 0 : 1;
+    }
+    int recv(float *dev, size_t n, int peer, hipStream_t s) {
+        if (!stub) { CKN(ncclRecv(dev, n, ncclFloat, peer, comm, s)); return 0; }
+        const std::string p = base + "." + std::to_string(peer) + "." + std::to_string(rank);
+        const int fd = open(p.c_str(), O_RDONLY);
+        if (fd < 0) return 1;
+        unsigned long long hdr = 0;
+        bool ok = read(fd, &hdr, sizeof(hdr)) == (ssize_t)sizeof(hdr);
+        if (ok && hdr != n) {
+            fprintf(stderr, "stub transport: rank %d expects %zu floats from rank %d, which sends %llu\n", rank, n, peer, hdr);
+            ok = false;
+        }
+        host.resize(n);
+        for (size_t off = 0; ok && off < n * sizeof(float);) {
+            const ssize_t r = read(fd, (char *)host.data() + off, n * sizeof(float) - off);
+            if (r <= 0) ok = false; else off += (size_t)r;
+        }
+        close(fd);
+        if (!ok) return 1;
+        CK(hipStreamSynchronize(s));
+        CK(hipMemcpy(dev, host.data(), n * sizeof(float), hipMemcpyHostToDevice));
+        return 0;
+    }
+    void destroy() { if (comm) ncclCommDestroy(comm); }
+};
+
 int main(int argc, char **argv) {
     if (argc < 6) {
         fprintf(stderr, "usage: %s <das|mvdr|lcmv|phase> <n_mics> <total_frames> <world> <rank|logical> [id_file] [chunks] [steps]\n", argv[0]);
@@ -151,7 +240,7 @@ int main(int argc, char **argv) {
     }
     int ndev = 0;
     CK(hipGetDeviceCount(&ndev));
-    cfg.device = logical ? 0 : rank % ndev;
+    cfg.device = logical ? 0 : rank % ndev;  // (a one-GPU box puts every rank on device 0: RCCL refuses that, BF_SHARD_STUB=1 does not)
     CK(hipSetDevice(cfg.device));
     const int H = cfg.hop;
     hipStream_t cs, gs;  // compute / gather
@@ -202,22 +291,12 @@ int main(int argc, char **argv) {
     }
 
     // ---- one process per rank, RCCL for the gather -----------------------------------------------------------------------
-    ncclUniqueId id;
-    if (rank == 0) {
-        CKN(ncclGetUniqueId(&id));
-        std::string tmp = std::string(id_file) + ".tmp";
-        FILE *f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(&id, sizeof(id), 1, f) != 1) return 1;
-        fclose(f);
-        rename(tmp.c_str(), id_file);
-    } else {
-        FILE *f = nullptr;
-        for (int i = 0; i < 600 && !(f = fopen(id_file, "rb")); ++i) std::this_thread::sleep_for(std::chrono::milliseconds(100));
-        if (!f || fread(&id, sizeof(id), 1, f) != 1) return 1;
-        fclose(f);
+    const bool stub = getenv("BF_SHARD_STUB") && atoi(getenv("BF_SHARD_STUB")) != 0;
+    Transport tr;
+    if (tr.init(world, rank, id_file, stub)) {
+        fprintf(stderr, "rank %d: transport set-up failed\n", rank);
+        return 1;
     }
-    ncclComm_t comm;
-    CKN(ncclCommInitRank(&comm, world, id, rank));
     Rank me;
     CKB(bf_shard_plan((size_t)F, world, rank, halo, &me.sh));
     if (make_slice(me, M, H, cs)) return 1;
@@ -240,17 +319,17 @@ int main(int argc, char **argv) {
             CK(hipStreamWaitEvent(gs, piece_done, 0));
             if (rank == 0 && n > 0)
                 CK(hipMemcpyAsync(out + own0 * H, me.y + (me.n_drop + own0) * H, (size_t)n * H * sizeof(float), hipMemcpyDeviceToDevice, gs));
-            CKN(ncclGroupStart());
+            if (tr.group_start()) return 1;
             if (rank != 0) {
-                if (n > 0) CKN(ncclSend(me.y + (me.n_drop + own0) * H, (size_t)n * H, ncclFloat, 0, comm, gs));
+                if (n > 0 && tr.send(me.y + (me.n_drop + own0) * H, (size_t)n * H, 0, gs)) return 1;
             } else {
                 for (int r = 1; r < world; ++r) {  // piece c of rank r, cut by rank r's own feed length (piece_owned): posted in round c
                     long long po0 = 0;               // whether or not rank 0 has a piece of its own in this round
                     const long long pn = piece_owned(bf_shard_n_feed(&plan[r]), bf_shard_n_drop(&plan[r]), chunks, c, &po0);
-                    if (pn > 0) CKN(ncclRecv(out + (plan[r].lo + po0) * H, (size_t)pn * H, ncclFloat, r, comm, gs));
+                    if (pn > 0 && tr.recv(out + (plan[r].lo + po0) * H, (size_t)pn * H, r, gs)) return 1;
                 }
             }
-            CKN(ncclGroupEnd());
+            if (tr.group_end()) return 1;
             return 0;
         });
         if (rc) return rc;
@@ -281,7 +360,7 @@ int main(int argc, char **argv) {
                "\"ms_per_step_with_overlapped_gather\": %.4f, \"frames_per_s_with_gather\": %.4e, \"checksum\": %.6f}\n",
                world, names[algo], M, F, chunks, ms_compute, ms_gather, (double)F / (ms_gather * 1e-3), cs_);
     }
-    ncclCommDestroy(comm);
+    tr.destroy();
     bf_destroy(bf);
     return 0;
 }

@@ -1,3 +1,3 @@
 cd /root/repo
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_resample_gpu.py tests/test_node_shim_gpu.py -x -q 2>&1 | tail -8
+timeout 1500 python -m pytest tests/test_bench_gpu.py tests/test_shard_gpu.py -x -q 2>&1 | tail -12

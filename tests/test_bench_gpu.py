@@ -68,6 +68,10 @@ def test_bench_two_ranks_through_the_launcher():
     # the two ranks ran ONE 8192-frame stream through shard.plan (halo 1 + lead hop on rank 1), gather inside the second timing
     assert d["config"]["global_stream_frames"] == 8192 and d["config"]["frames_per_gpu"] == 4096
     assert d["value_including_final_gather"] is not None and 0 < d["value_including_final_gather"] <= d["value"] * 1.5
+    # the default is --gather overlap: pieces sent to rank 0 while the next piece computes (host-staged over gloo on this one-GPU box)
+    assert d["config"]["gather"] == "overlap" and d["value_including_overlapped_gather"] is not None
+    assert 0 < d["value_including_overlapped_gather"] <= d["value"] * 1.5
+    assert d["n_ranks_seen"] == 2 and "gather_error" not in d
     assert d["cpu_baseline"] is None  # rank 0 at N = 1 only
 
 
@@ -81,3 +85,16 @@ def test_bench_spawns_its_own_ranks_when_no_launcher_is_present():
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_stream_frames"] == 6000
     assert abs(d["value"] - 6000 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_gather_watchdog_prints_the_compute_line():
+    """A gather that does not finish (here: a time-out far below what two ranks need to build their channels) must not cost the
+    run its result: rank 0 prints the line with the compute figures and gather_error, every rank exits 0."""
+    env = dict(os.environ, BF_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29655", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "65536", "--steps", "40", "--warmup", "1",
+           "--settle-ms", "0", "--no-extra", "--no-cpu", "--gather-timeout-s", "0.05"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "did not finish" in d["gather_error"]
+    assert d["value_including_overlapped_gather"] is None

@@ -443,6 +443,40 @@ def test_c_shard_node_example_reproduces_the_unsharded_stream():
     assert out.returncode == 0 and "ms_per_step_with_overlapped_gather" in out.stdout, out.stdout + out.stderr
 
 
+@pytest.mark.parametrize("algo,M,F,world,chunks", [("das", 8, 10, 2, 4), ("das", 8, 4099, 3, 4), ("mvdr", 8, 1500, 2, 3), ("das", 4, 37, 4, 5)])
+def test_c_shard_node_gather_schedule_with_every_rank_on_one_gpu(algo, M, F, world, chunks, tmp_path):
+    """examples/shard_node.cpp, one PROCESS per rank, BF_SHARD_STUB=1: the overlapped gather's send / receive schedule with named
+    pipes through host memory in place of RCCL (which refuses two ranks on one device).  Every ncclSend / ncclRecv of the real
+    run has its counterpart, the receiver checks each size, an unmatched transfer blocks until the time-out.  F = 10 on two
+    ranks in four pieces is the case where rank 1 (halo + lead hop: 7 fed hops) cuts one piece more than rank 0 (5): rank 0 has
+    to post that piece's receive in a round where it computes nothing.  The assembled stream must be the single-rank one."""
+    import json
+    import os
+    import subprocess
+    _torch()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "shard_node")
+    env = dict(os.environ, BF_SHARD_STUB="1")
+    one = subprocess.run([exe, algo, str(M), str(F), "1", "0", str(tmp_path / "one"), str(chunks), "1"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert one.returncode == 0, one.stdout + one.stderr
+    want = json.loads(one.stdout.strip().splitlines()[-1])["checksum"]
+    base = str(tmp_path / "pipes")
+    procs = [subprocess.Popen([exe, algo, str(M), str(F), str(world), str(r), base, str(chunks), "1"], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+    outs = []
+    try:
+        for pr in procs:
+            outs.append(pr.communicate(timeout=240))
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    assert all(pr.returncode == 0 for pr in procs), outs
+    got = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert got["world"] == world and got["checksum"] == want and want > 0
+
+
 @pytest.mark.parametrize("algo,M,interf", [("mvdr", 8, ()), ("mvdr", 5, ()), ("lcmv", 8, (-60.0,)), ("lcmv", 16, (-60.0, 90.0, 150.0)), ("mvdr", 12, ()),
                                            ("lcmv", 3, (90.0,)), ("lcmv", 6, (-60.0, 90.0, 150.0)), ("mvdr", 2, ())])
 @pytest.mark.parametrize("band", [(0.0, 24000.0), (0.0, 23960.0), (0.0, 16000.0), (100.0, 24000.0), (300.0, 3400.0), (20000.0, 23000.0), (30.0, 40.0), (5.0, 20.0)])
