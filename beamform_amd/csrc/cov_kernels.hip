@@ -332,15 +332,17 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
     const int j = q_bin(q);
     const bool lcmv = a.cfg.algo == BF_LCMV;
     const long yidx = ((long)s * a.n_frames) * kYhStride + q;
-    const z48 *Zs = reinterpret_cast<const z48 *>(a.Z) + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;  // frame 0 of this batch
+    const long z0 = ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;  // element index of frame 0 of this batch
     const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
 
-    // one microphone's spectrum at this problem's bin, frame t (may be negative: history)
+    // one microphone's spectrum at this problem's bin, frame t (may be negative: history); z48 elements (stored halved) or,
+    // with BF_Z48=0, full doubles (halved here)
     const int ksrc = q_src_bin(q), kneg = (kN - ksrc) & (kN - 1);
+    auto ldz = [&](long e) -> cd { return a.z48 ? ld(reinterpret_cast<const z48 *>(a.Z) + e) : ld(a.Z + e) * 0.5; };
     auto load_xi = [&](long t) -> cd {
         if (i >= M) return cd{0, 0};
-        const z48 *Zf = Zs + t * NP * kN + (i >> 1) * kN;
-        const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
+        const long ef = z0 + t * NP * kN + (long)(i >> 1) * kN;
+        const cd z = ldz(ef + ksrc), zc = conj(ldz(ef + kneg));
         cd x;
         if ((i & 1) == 0) {
             x = z + zc;  // z48 spectra are stored halved
@@ -1308,7 +1310,8 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
     if (a.n_frames < tile) tile = (int)a.n_frames;
     const int tps = (int)((a.n_frames + tile - 1) / tile);
     const int M = a.n_mics, km = a.kp1 <= 1 ? 1 : 4;
-    static const bool no_fast = getenv("BF_MVDR_GROUP") && atoi(getenv("BF_MVDR_GROUP")) != 0;
+    static const bool no_fast_env = getenv("BF_MVDR_GROUP") && atoi(getenv("BF_MVDR_GROUP")) != 0;
+    const bool no_fast = no_fast_env || !a.z48;  // full-double spectra (BF_Z48=0): the group-per-problem kernel reads them
     // frequencies of the irregular problems (quirk Q1, util.h:190-199): f[N/2] = 0, f[N/2+1] = -(N/2-1) sr/N
     const double f_qx = (double)(kN / 2 - 1) * a.cfg.sample_rate / (double)kN;
     const bool band_hits_nyquist = (0.0 >= a.cfg.freq_min && 0.0 <= a.cfg.freq_max) || (f_qx >= a.cfg.freq_min && f_qx <= a.cfg.freq_max);

@@ -60,7 +60,10 @@ class BinPipelineImpl : public BinPipeline {
         const bool multi = (c.algo == BF_LCMV || c.algo == BF_GSS);
         KP1_ = multi ? c.n_interf + 1 : 1;
         Phist_ = (c.algo == BF_MVDR || c.algo == BF_LCMV) ? c.past_windows : 0;
-        z48_ = (c.algo == BF_MVDR || c.algo == BF_LCMV);  // packed spectra as 12-byte z48 elements (pipeline_kernels.hpp)
+        // packed spectra as 12-byte z48 elements (pipeline_kernels.hpp); BF_Z48=0 keeps full doubles and the group-per-problem kernel:
+        // the switch for comparing against the reference on ill-conditioned scenes (36 mantissa bits x cond(R))
+        static const bool z48_off = getenv("BF_Z48") && atoi(getenv("BF_Z48")) == 0;
+        z48_ = (c.algo == BF_MVDR || c.algo == BF_LCMV) && !z48_off;
         zsz_ = z48_ ? sizeof(z48) : sizeof(f64x2);
     }
     ~BinPipelineImpl() override { free_all(); }
@@ -385,6 +388,7 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     ba.Z = d_Z_; ba.Yh = d_Yh_; ba.spectrum = spectrum; ba.steer = snap.steer; ba.freqs = d_freq_;
     ba.n_frames = F; ba.frames_ws = FT; ba.frame_off = Phist_; ba.n_streams = So_; ba.n_mics = MF_; ba.kp1 = snap.kp1;
     ba.n_dirs = D_; ba.steer_dir_stride = snap.steer_dir_stride;
+    ba.z48 = z48_ ? 1 : 0;
     ba.cfg = cfg_; ba.gssW = d_gssW_; ba.mpf = d_mpf_; ba.gss_reset_mask = snap.gss_reset_mask;
     // backward transform in fp32 (no error amplification behind the per-bin stage; output is float32), except for gsc, whose
     // sample-serial NLMS branches on the aligned signals

@@ -77,6 +77,8 @@ struct BinsArgs {
     f64x2 *gssW;         // [stream][N][kp1][n_mics]
     double *mpf;         // [stream][kMpfVecs*N + 8] (the mcra node uses vectors 0..3 and the two scalars)
     unsigned long long gss_reset_mask;  // bit d: look direction d re-initialises W = C^H (gss.cpp:90-93) in this batch
+    int z48;             // mvdr / lcmv: Z holds z48 elements (the default); 0 = full f64x2 spectra (BF_Z48=0: parity debugging on
+                         // ill-conditioned scenes; only the group-per-problem kernel reads them)
     int mpf32;           // phasempf in front of the fp32 backward transform: the recursion leaves y_fft as f32x2 rows in the slots of its
                          // |out_int|^2 input (8 bytes each, same [stream][frame][kYhStride] layout, behind the f64x2 rows)
 };

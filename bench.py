@@ -204,8 +204,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=196608,
                     help="frames in the CPU-baseline sample (0 = skip); the default is ~12 s of single-core work (its oracle, with the FFT plan cached, does ~16 k frames per second)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-all-cores-frames", type=int, default=2048,
-                    help="frames per host core in the all-cores CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-all-cores-frames", type=int, default=40960,
+                    help="frames per host core in the all-cores CPU baseline (0 = skip): ~2.5 s per worker at the oracle's ~16 k frames/s")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary lines (other BASELINE configs)")
     args = ap.parse_args()
 

@@ -61,6 +61,9 @@ CASES = [
     ({"BF_DAS_VARIANT": "1"}, "das", 5, (), 21, True),
     ({"BF_ISTFT_F64": "1"}, "mvdr", 8, (), 30, False),                 # fp64 backward transform behind every node
     ({"BF_ISTFT_F64": "1"}, "phase", 8, (), 24, True),
+    ({"BF_Z48": "0"}, "mvdr", 8, (), 30, True),                        # full-double spectra in HBM (no z48 packing), group kernel
+    ({"BF_Z48": "0"}, "lcmv", 16, (-60.0, 90.0, 150.0), 24, True),
+    ({"BF_DAS_F64_W64": "0"}, "das", 8, (), 37, False),                # (only the fp64 das node reads it; the fp32 node must not care)
 ]
 
 
@@ -75,3 +78,51 @@ def test_env_selected_kernel_matches_oracle(env, algo, M, interf, F, dump):
     assert res["time"] < TOL, res
     if dump:
         assert res["finite_frames_equal"] and res["spectrum"] < TOL, res
+
+
+CHILD_COND = r"""
+import sys, json, numpy as np
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r + "/tests")
+import torch, oracle
+from beamform_amd.capi import Beamformer
+from beamform_amd.params import make_params
+from beamform_amd.synth import make_scene
+from conftest import rel_l2
+M, F = 8, 60
+p = make_params("mvdr", n_mics=M, theta=20.0)
+# one loud directional source, interferers and sensor noise 60 dB below it: the 10-frame covariance is numerically rank one and only the
+# 1.001 diagonal loading (mvdr.cpp:239-243) keeps it invertible -- cond(R o whiteR) ~ 1e4 at every in-band bin
+x = make_scene(M, F, seed=4242, sigma_s=0.3, sigma_i=3e-4, sigma_n=3e-4, silent_frac=0.0)
+y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
+bf = Beamformer(p)
+xd = torch.from_numpy(x).cuda()
+yd = torch.empty(F * 512, dtype=torch.float32, device="cuda")
+Yd = torch.empty((F, 1024, 2), dtype=torch.float64, device="cuda")
+bf.process_device(xd.data_ptr(), F, yd.data_ptr(), Yd.data_ptr())
+torch.cuda.synchronize()
+Y = Yd.cpu().numpy().view(np.complex128)[..., 0]
+fin = np.isfinite(Y_ref).all(axis=1)
+np.save(sys.argv[1], Y)
+print("RESULT " + json.dumps({"spectrum": max(rel_l2(Y[t], Y_ref[t]) for t in range(F) if fin[t]), "frames": int(fin.sum())}))
+"""
+
+
+def test_z48_against_full_double_spectra_on_an_ill_conditioned_scene(tmp_path):
+    """The packed 12-byte spectra (36 mantissa bits) against BF_Z48=0 (full doubles in HBM) where it matters: a covariance that is
+    rank one up to its diagonal loading.  Both stay inside the 1e-5 budget against the oracle; the figure that the packing itself
+    costs is their mutual distance."""
+    import numpy as np
+    res, Ys = {}, {}
+    for mode in ("1", "0"):
+        f = str(tmp_path / f"Y{mode}.npy")
+        out = subprocess.run([sys.executable, "-c", CHILD_COND % dict(root=ROOT), f], env=dict(os.environ, BF_Z48=mode),
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[mode] = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
+        Ys[mode] = np.load(f)
+    assert res["1"]["frames"] == res["0"]["frames"] > 40
+    assert res["0"]["spectrum"] < TOL and res["1"]["spectrum"] < TOL, res
+    fin = np.isfinite(Ys["0"]).all(axis=1)
+    d = max(np.linalg.norm(Ys["1"][t] - Ys["0"][t]) / np.linalg.norm(Ys["0"][t]) for t in range(len(fin)) if fin[t] and np.abs(Ys["0"][t]).max() > 0)
+    assert d < 1e-6, d          # 2^-37 on X times the condition number
