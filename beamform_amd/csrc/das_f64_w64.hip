@@ -197,6 +197,9 @@ __device__ __forceinline__ void mul_tw(double (&re)[16], double (&im)[16], const
     }
 }
 
+// LAYOUT 0: planar [mic][sample]; 1: interleaved [sample][mic] (bf_layout) -- a pair's two microphones are then one 8-byte load per
+// sample, the four pairs of a frame read the same 128-byte lines one after the other (from L2: each sample still leaves HBM once)
+template <int LAYOUT>
 __global__ __launch_bounds__(kBlock) void das_f64_w64_kernel(DasF64Args a, int frames_per_chunk, int chunks_per_stream) {
     __shared__ __attribute__((aligned(16))) double lds[kLdsD];
     const cx<double> *s_tw1 = reinterpret_cast<const cx<double> *>(lds + oTw);
@@ -238,16 +241,40 @@ __global__ __launch_bounds__(kBlock) void das_f64_w64_kernel(DasF64Args a, int f
     float na[16], nb[16];
     auto request = [&](long tt, int p) {
         const int ma = 2 * p, mb = (2 * p + 1 < M) ? 2 * p + 1 : ma;
-        const float *a1 = tt >= 1 ? xs + (long)ma * a.mic_stride + (tt - 1) * kHop : hs + ma * kHop;
-        const float *b1 = tt >= 1 ? xs + (long)mb * a.mic_stride + (tt - 1) * kHop : hs + mb * kHop;
-        const float *a2 = xs + (long)ma * a.mic_stride + tt * kHop;
-        const float *b2 = xs + (long)mb * a.mic_stride + tt * kHop;
+        if (LAYOUT == 0) {
+            const float *a1 = tt >= 1 ? xs + (long)ma * a.mic_stride + (tt - 1) * kHop : hs + ma * kHop;
+            const float *b1 = tt >= 1 ? xs + (long)mb * a.mic_stride + (tt - 1) * kHop : hs + mb * kHop;
+            const float *a2 = xs + (long)ma * a.mic_stride + tt * kHop;
+            const float *b2 = xs + (long)mb * a.mic_stride + tt * kHop;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {  // scalar base + this lane's 32-bit offset
-            na[j] = a1[(unsigned)(64 * j + lane)];
-            nb[j] = b1[(unsigned)(64 * j + lane)];
-            na[j + 8] = a2[(unsigned)(64 * j + lane)];
-            nb[j + 8] = b2[(unsigned)(64 * j + lane)];
+            for (int j = 0; j < 8; ++j) {  // scalar base + this lane's 32-bit offset
+                na[j] = a1[(unsigned)(64 * j + lane)];
+                nb[j] = b1[(unsigned)(64 * j + lane)];
+                na[j + 8] = a2[(unsigned)(64 * j + lane)];
+                nb[j + 8] = b2[(unsigned)(64 * j + lane)];
+            }
+        } else {
+            const float *s1 = tt >= 1 ? xs + (tt - 1) * (long)kHop * M : hs;  // the carried hop is kept in the same layout
+            const float *s2 = xs + tt * (long)kHop * M;
+            if ((M & 1) == 0) {  // even microphone count: the pair is 8 bytes, 8-byte aligned
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float2 v1 = *reinterpret_cast<const float2 *>(s1 + (unsigned)((64 * j + lane) * M + ma));
+                    const float2 v2 = *reinterpret_cast<const float2 *>(s2 + (unsigned)((64 * j + lane) * M + ma));
+                    na[j] = v1.x;
+                    nb[j] = v1.y;
+                    na[j + 8] = v2.x;
+                    nb[j + 8] = v2.y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    na[j] = s1[(unsigned)((64 * j + lane) * M + ma)];
+                    nb[j] = s1[(unsigned)((64 * j + lane) * M + mb)];
+                    na[j + 8] = s2[(unsigned)((64 * j + lane) * M + ma)];
+                    nb[j + 8] = s2[(unsigned)((64 * j + lane) * M + mb)];
+                }
+            }
         }
     };
 
@@ -428,7 +455,10 @@ hipError_t launch_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s) {
     if (a.n_mics > 8) return hipErrorNotSupported;
     long fpc, cps;
     das_f64_w64_runs(a, n_cus, &fpc, &cps);
-    hipLaunchKernelGGL(das_f64_w64_kernel, dim3((unsigned)(cps * a.n_streams)), dim3(kBlock), 0, s, a, (int)fpc, (int)cps);
+    if (a.layout == 0)
+        hipLaunchKernelGGL(das_f64_w64_kernel<0>, dim3((unsigned)(cps * a.n_streams)), dim3(kBlock), 0, s, a, (int)fpc, (int)cps);
+    else
+        hipLaunchKernelGGL(das_f64_w64_kernel<1>, dim3((unsigned)(cps * a.n_streams)), dim3(kBlock), 0, s, a, (int)fpc, (int)cps);
     return hipGetLastError();
 }
 

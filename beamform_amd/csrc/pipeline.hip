@@ -304,13 +304,16 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     // das at the reference's precision on the tuned shape, planar input, no spectrum dump: ONE launch, spectra never leave the CU
     // (BF_FUSED_BINS=0 / =2 keep the chains below for A/B runs)
     static const int fuse_env0 = getenv("BF_FUSED_BINS") ? atoi(getenv("BF_FUSED_BINS")) : 1;
-    if (das_one_launch_shape() && fuse_env0 == 1 && spectrum == nullptr && layout == BF_PLANAR && snap.das_gains != nullptr) {
+    static const int w64 = getenv("BF_DAS_F64_W64") ? atoi(getenv("BF_DAS_F64_W64")) : 1;
+    // (interleaved input: the 64-lane kernel only)
+    if (das_one_launch_shape() && fuse_env0 == 1 && spectrum == nullptr && snap.das_gains != nullptr &&
+        (layout == BF_PLANAR || (w64 && snap.das_gains_w64 != nullptr))) {
         DasF64Args da;
         da.x = x; da.hist = d_hist_; da.y = y; da.tail_in = d_tail_[tail_cur_]; da.tail_out = d_tail_[tail_cur_ ^ 1];
         da.gains = snap.das_gains; da.tw = d_tw_; da.win = d_win_; da.n_frames = F; da.mic_stride = mic_stride;
         da.stream_stride_x = (long)M_ * F * H_; da.n_streams = S_; da.n_mics = M_; da.run_len = 1;
         // BF_DAS_F64_W64=0: the 32 x 32 half-wavefront kernel (das_f64_fused_kernel) instead of the 64-lane one
-        static const int w64 = getenv("BF_DAS_F64_W64") ? atoi(getenv("BF_DAS_F64_W64")) : 1;
+        da.layout = layout;
         if (w64 && snap.das_gains_w64 != nullptr) { da.gains = snap.das_gains_w64; da.tw = d_tw_w64_; }
         const bool use_w64 = w64 && snap.das_gains_w64 != nullptr;
         hipError_t de = use_w64 ? prepare_das_f64_w64(da, n_cus_, stream) : hipSuccess;
@@ -322,9 +325,14 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
                 kev_recorded = true;
             }
         }
-        if (de == hipSuccess) {
-            PIPE_HIP(hipMemcpy2DAsync(d_hist_, H_ * sizeof(float), x + (F - 1) * H_, (size_t)mic_stride * sizeof(float),
-                                      H_ * sizeof(float), (size_t)S_ * M_, hipMemcpyDeviceToDevice, stream));  // ring-buffer carry (util.h:305-308)
+        if (de == hipSuccess) {  // ring-buffer carry (util.h:305-308)
+            if (layout == BF_PLANAR)
+                PIPE_HIP(hipMemcpy2DAsync(d_hist_, H_ * sizeof(float), x + (F - 1) * H_, (size_t)mic_stride * sizeof(float),
+                                          H_ * sizeof(float), (size_t)S_ * M_, hipMemcpyDeviceToDevice, stream));
+            else
+                PIPE_HIP(hipMemcpy2DAsync(d_hist_, (size_t)H_ * M_ * sizeof(float), x + (F - 1) * (long)H_ * M_,
+                                          (size_t)F * H_ * M_ * sizeof(float), (size_t)H_ * M_ * sizeof(float), (size_t)S_,
+                                          hipMemcpyDeviceToDevice, stream));
             tail_cur_ ^= 1;
             return BF_OK;
         }

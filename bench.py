@@ -515,7 +515,11 @@ def main():
              (lambda: node_line("das", M, F, 1, das_impl_=BF_DAS_BINS_F64, xin=x, iters=20, roofline_kernel="das_f64_w64_kernel", traffic_tag="das8_f64",
                                 note="same precision as the reference: das_f64_w64_kernel, one launch"))),
             ("das_interleaved", lambda: node_line("das", M, F, 1, xin=x.reshape(1, F * HOP, M), layout_=BF_INTERLEAVED, iters=20,
-                                                  note="the headline workload with [sample][mic] input (same bytes read as interleaved samples)")),
+                                                  note="the headline workload with [sample][mic] input (same bytes read as interleaved samples), fused fp32 kernel")),
+            ("das_f64_interleaved", lambda: node_line("das", M, F, 1, das_impl_=BF_DAS_BINS_F64, xin=x.reshape(1, F * HOP, M), layout_=BF_INTERLEAVED,
+                                                      iters=20, roofline_kernel="das_f64_w64_kernel<1>",
+                                                      note="the headline kernel (double) on [sample][mic] input: a pair's two microphones are one 8-byte "
+                                                           "load per sample, the four pairs of a frame re-read the same lines from L2")),
             ("phasempf", lambda: node_line("phasempf", 8, 256, 256, note="BASELINE config 4: 256 streams x 256 frames, recursion per stream")),
             ("phase", lambda: node_line("phase", M, F, 1, xin=x,
                                         note="uniform noise of this level stays below the node's mag_threshold (0.05): every bin takes the cheap branch "

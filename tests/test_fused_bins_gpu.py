@@ -116,6 +116,16 @@ def test_das_f64_one_launch_matches_oracle(M, F, S):
     for s in range(S):
         y_ref, _ = oracle.OracleNode(p).process(xs[s])
         assert rel_l2(y[s], y_ref) < 1e-6       # double arithmetic up to the float stores: far inside the 1e-5 budget
+    # [sample][mic] input (the layout north_star names): the same arithmetic on the same samples, bit for bit
+    from beamform_amd.capi import BF_INTERLEAVED
+    xi = np.ascontiguousarray(xs.transpose(0, 2, 1))
+    yi = Beamformer(p, n_streams=S, das_impl=BF_DAS_BINS_F64, layout=BF_INTERLEAVED).process(xi if S > 1 else xi[0]).reshape(S, -1)
+    assert np.array_equal(yi, y)
+    if S == 1 and F >= 9:
+        bi = Beamformer(p, das_impl=BF_DAS_BINS_F64, layout=BF_INTERLEAVED)   # carried hop in the interleaved layout across batch cuts
+        cuts = [0, 2, F // 2, F]
+        parts = [bi.process(np.ascontiguousarray(xi[0][a * 512:b * 512])) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert np.array_equal(np.concatenate(parts), y[0])
     if S == 1 and F >= 9:
         bf2 = Beamformer(p, das_impl=BF_DAS_BINS_F64)
         cuts = [0, 1, 4, F // 2, F]
