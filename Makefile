@@ -49,7 +49,7 @@ oracle:
 	$(MAKE) -C oracle -s
 
 ubench:
-	for f in valu_rate fetch_calib w64_test rowbc vmem_issue rsq_test; do $(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fno-slp-vectorize -Wno-unused-result tools/ubench/$$f.hip -o tools/ubench/$$f.bin; done
+	for f in valu_rate fetch_calib w64_test rowbc vmem_issue rsq_test f64_rate launch_lds realtime_cal; do $(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fno-slp-vectorize -Wno-unused-result tools/ubench/$$f.hip -o tools/ubench/$$f.bin; done
 
 emul:
 	g++ -O2 -std=c++17 -fPIC -shared -o tests/host_emul/libemul.so tests/host_emul/emul.cpp

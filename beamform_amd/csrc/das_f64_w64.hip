@@ -218,15 +218,6 @@ __global__ __launch_bounds__(kBlock) void das_f64_w64_kernel(DasF64Args a, int f
 
     const int stream = blockIdx.x / chunks_per_stream;
     const long c_in_s = blockIdx.x - (long)stream * chunks_per_stream;
-    {
-        const double *twf = reinterpret_cast<const double *>(a.tw);
-        for (int i = tid; i < kTwD; i += kBlock) lds[oTw + i] = twf[i];
-        const double *gf = reinterpret_cast<const double *>(a.gains);
-        for (int i = tid; i < NP * 2048; i += kBlock) lds[oGain + i] = gf[i];
-        for (int i = tid; i < 1024; i += kBlock) lds[oWin + (i & 63) * kWinRow + (i >> 6)] = a.win[i];
-        if (tid < 2 * kWaves) s_ready[tid] = -2;
-    }
-    __syncthreads();
     // window[64 j + lane], j = 0..15: both windows of the frame (util.h:235,250) touch the same 16 values of this lane's row
     const double *wrow = lds + oWin + lane * kWinRow;
 
@@ -279,22 +270,44 @@ __global__ __launch_bounds__(kBlock) void das_f64_w64_kernel(DasF64Args a, int f
     };
 
     const int n_iter = (int)((T1 - T0 + kWaves - 1) / kWaves);
-    if (T0 + w < T1) request(T0 + w, 0);
+    if (T0 + w < T1) request(T0 + w, 0);  // the first frame's samples travel while the tables are copied into LDS
+    {
+        const f64x2 *tw2 = a.tw, *g2 = a.gains;  // 16-byte copies (kTwD, oGain are even)
+        f64x2 *ltw = reinterpret_cast<f64x2 *>(lds + oTw), *lg = reinterpret_cast<f64x2 *>(lds + oGain);
+#pragma unroll 4
+        for (int i = tid; i < kTwD / 2; i += kBlock) ltw[i] = tw2[i];
+#pragma unroll 8
+        for (int i = tid; i < NP * 1024; i += kBlock) lg[i] = g2[i];
+#pragma unroll 2
+        for (int i = tid; i < 1024; i += kBlock) lds[oWin + (i & 63) * kWinRow + (i >> 6)] = a.win[i];
+        if (tid < 2 * kWaves) s_ready[tid] = -2;
+    }
+    __syncthreads();
     for (int it = 0; it < n_iter; ++it) {
         const long t = T0 + (long)it * kWaves + w;
         if (t >= T1) break;  // wavefront-uniform; no block barrier below
 
         double Sr[16], Si[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Sr[r] = Si[r] = 0.0;
         for (int p = 0; p < NP; ++p) {
             double re[16], im[16];
             const bool b_ok = 2 * p + 1 < M;
+            // buf[j]*hann_win[i] (util.h:235) and the first butterfly stage of the transform in one: x_p w_p +- x_(p+8) w_(p+8) as one product
+            // and two FMAs (the second product is not rounded on its own: <= 1 ulp from the separate form)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) re[j] = (double)na[j] * wrow[j];  // buf[j]*hann_win[i]  (util.h:235)
+            for (int j = 0; j < 8; ++j) {
+                const double w0 = wrow[j], w1 = wrow[j + 8];
+                const double t = (double)na[j] * w0, u = (double)na[j + 8];
+                re[j] = fma(u, w1, t);
+                re[j + 8] = fma(-u, w1, t);
+            }
             if (b_ok) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) im[j] = (double)nb[j] * wrow[j];
+                for (int j = 0; j < 8; ++j) {
+                    const double w0 = wrow[j], w1 = wrow[j + 8];
+                    const double t = (double)nb[j] * w0, u = (double)nb[j + 8];
+                    im[j] = fma(u, w1, t);
+                    im[j + 8] = fma(-u, w1, t);
+                }
             } else {  // odd microphone count: the last pair's second channel is silence
 #pragma unroll
                 for (int j = 0; j < 16; ++j) im[j] = 0.0;
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(kBlock) void das_f64_w64_kernel(DasF64Args a, int f
             BF_STAGE();
             load_tw1<1, 9>(tw, s_tw1, lane);  // lands during the first 16-point transform
             BF_STAGE();
-            fft16_core<double, -1, true>(re, im);
+            fft16_core<double, -1, true, 1>(re, im);  // stage 0 is done
             BF_STAGE();
             load_tw1<9, 16>(tw, s_tw1, lane);
             BF_STAGE();
@@ -346,11 +359,20 @@ __global__ __launch_bounds__(kBlock) void das_f64_w64_kernel(DasF64Args a, int f
 #pragma unroll
             for (int r = 8; r < 16; ++r) g[r] = gp[64 * r];
             BF_STAGE();
+            if (p == 0) {  // the first pair starts the sum (no zero fill, a multiplication instead of the inner FMA)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (r == 8) BF_STAGE();
-                Sr[r] = fma(-g[r].y, im[r], fma(g[r].x, re[r], Sr[r]));
-                Si[r] = fma(g[r].y, re[r], fma(g[r].x, im[r], Si[r]));
+                for (int r = 0; r < 16; ++r) {
+                    if (r == 8) BF_STAGE();
+                    Sr[r] = fma(-g[r].y, im[r], g[r].x * re[r]);
+                    Si[r] = fma(g[r].y, re[r], g[r].x * im[r]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (r == 8) BF_STAGE();
+                    Sr[r] = fma(-g[r].y, im[r], fma(g[r].x, re[r], Sr[r]));
+                    Si[r] = fma(g[r].y, re[r], fma(g[r].x, im[r], Si[r]));
+                }
             }
         }
         cx<double> tw[15];

@@ -40,10 +40,12 @@ constexpr int brev4(int i) { return ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >
 // 16-point in-place radix-2 DIT with fused twiddles; PERM_BREV as in fft32_core:
 //   false: physical in = bit-reversed (x[brev4(i)] at i), out natural
 //   true : physical in = natural, out X[brev4(i)] at i
-template <typename T, int DIR, bool PERM_BREV>
+// S0 = first stage to run: 1 when the caller has done stage 0 itself (with PERM_BREV that stage is the plain butterfly of the
+// physical positions p and p + 8, p < 8 -- das_f64_w64.hip folds the analysis window into it)
+template <typename T, int DIR, bool PERM_BREV, int S0 = 0>
 BF_HD void fft16_core(T (&re)[16], T (&im)[16]) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = S0; s < 4; ++s) {
         const int half = 1 << s;
         const int tstep = 16 >> s;  // in units of the 32-point twiddle table: W16^j = W32^(2j)
 #pragma unroll

@@ -16,7 +16,9 @@ s = torch.cuda.current_stream().cuda_stream
 for _ in range(30):
     bf.process_device(x.data_ptr(), F, y.data_ptr(), 0, s)
 torch.cuda.synchronize()
-ts = [bf.time_device(x.data_ptr(), F, y.data_ptr(), 10, s)[0] for _ in range(5)]
+tk = [bf.time_device(x.data_ptr(), F, y.data_ptr(), 10, s) for _ in range(5)]
+ts = [t[0] for t in tk]
 yy = y.cpu().numpy()
+print(f"kernel-only (event pair around the launch): best {min(t[1] for t in tk):.4f} ms")
 print(f"das f64 (BF_DAS_F64_W64={os.environ.get('BF_DAS_F64_W64', '1')}) {M}-mic {F} frames: best {min(ts):.4f} ms, median {sorted(ts)[2]:.4f} ms; "
       f"{18432 * F / (min(ts) * 1e-3) / 8e12 * (M * 2048 + 2048) / 18432:.4f} of 8 TB/s; checksum {float(np.abs(yy).sum()):.6f}", flush=True)
