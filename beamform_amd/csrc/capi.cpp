@@ -408,13 +408,7 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
         }
         h->use_w64 = !fused_das_gen(h) && getenv("BF_DAS_W64") && atoi(getenv("BF_DAS_W64")) != 0;
         std::vector<f32x2> tw = twiddle_table_32x32<f32x2>();
-        if (fused_das_gen(h)) {  // exp(-2 pi i m / N), m < N/2 (Stockham passes)
-            tw.resize(h->N / 2);
-            for (int m = 0; m < h->N / 2; ++m) {
-                const double ang = -2.0 * kPi * (double)m / (double)h->N;
-                tw[m] = f32x2{(float)std::cos(ang), (float)std::sin(ang)};
-            }
-        }
+        if (fused_das_gen(h)) tw = stockham_twiddles<f32x2>(h->N);  // W^m, m < N/2, + the per-pass radix-4 blocks (geometry.hpp)
         BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle, tw.size() * sizeof(f32x2)));
         BF_CREATE_HIP(hipMemcpy(h->d_twiddle, tw.data(), tw.size() * sizeof(f32x2), hipMemcpyHostToDevice));
         std::vector<double> hd = sqrt_hann(h->N);

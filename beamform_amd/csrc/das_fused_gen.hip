@@ -19,30 +19,27 @@ namespace {
 
 constexpr int gen_block(int n) { return n >= 512 ? 256 : n / 2; }  // threads per block: at least two points per thread
 
-// autosort (Stockham) passes in LDS: data starts in b0, result ends in the returned buffer.  tw[m] = exp(-2 pi i m / N), m < N/2.
-// Radix-4 passes (N = 512: four + one radix-2, N = 2048: five + one radix-2; earlier: nine / eleven radix-2 passes:
-// half the barriers, half the LDS traffic), twiddles W^(q k N / (4 ns)) from the half-length table by W^(m + N/2) = -W^m.
+// autosort (Stockham) passes in LDS: data starts in b0, result ends in the returned buffer.  Radix-4 passes (N = 512: four + one
+// radix-2, N = 2048: five + one radix-2; earlier: nine / eleven radix-2 passes: half the barriers, half the LDS traffic).  Twiddles:
+// c4 = the per-pass blocks of geometry.hpp stockham_twiddles (the three factors of butterfly k contiguous in k: conflict-free reads),
+// tw = W^m, m < N/2, read in order by the closing radix-2 pass.
 template <int N, int DIR>
-__device__ __forceinline__ float2 *stockham32(float2 *b0, float2 *b1, const float2 *tw, int tid) {
+__device__ __forceinline__ float2 *stockham32(float2 *b0, float2 *b1, const float2 *c4, const float2 *tw, int tid) {
     constexpr int kGB = gen_block(N);
     float2 *in = b0, *out = b1;
-    auto twd = [&](int m) -> float2 {  // W^m (forward) or its conjugate (backward), m < N
-        const float2 w = tw[m & (N / 2 - 1)];
-        const float sg = (m & (N / 2)) ? -1.f : 1.f;
-        return float2{sg * w.x, DIR < 0 ? sg * w.y : -sg * w.y};
-    };
+    auto dirw = [](float2 w) { return float2{w.x, DIR < 0 ? w.y : -w.y}; };  // W (forward) or its conjugate (backward)
     auto cmul = [](float2 v, float2 w) { return float2{v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x}; };
     int ns = 1;
 #pragma unroll 1
     for (; ns * 4 <= N; ns <<= 2) {
+        const float2 *cp = c4 + (ns - 1);
 #pragma unroll
         for (int j = tid; j < N / 4; j += kGB) {
             const int k = j & (ns - 1);
-            const int st = k * (N / (4 * ns));
             const float2 a0 = in[j];
-            const float2 a1 = cmul(in[j + N / 4], twd(st));
-            const float2 a2 = cmul(in[j + N / 2], twd(2 * st));
-            const float2 a3 = cmul(in[j + 3 * N / 4], twd(3 * st));
+            const float2 a1 = cmul(in[j + N / 4], dirw(cp[k]));
+            const float2 a2 = cmul(in[j + N / 2], dirw(cp[ns + k]));
+            const float2 a3 = cmul(in[j + 3 * N / 4], dirw(cp[2 * ns + k]));
             const float2 s02 = float2{a0.x + a2.x, a0.y + a2.y}, d02 = float2{a0.x - a2.x, a0.y - a2.y};
             const float2 s13 = float2{a1.x + a3.x, a1.y + a3.y}, d13 = float2{a1.x - a3.x, a1.y - a3.y};
             // forward: -i d13 = (d13.y, -d13.x); backward: +i d13 = (-d13.y, d13.x)
@@ -58,15 +55,12 @@ __device__ __forceinline__ float2 *stockham32(float2 *b0, float2 *b1, const floa
         in = out;
         out = t;
     }
-    if (ns < N) {  // one radix-2 pass left (N = 2 * 4^k)
+    if (ns < N) {  // one radix-2 pass left (N = 2 * 4^k): ns = N / 2, twiddle W^k
 #pragma unroll
         for (int j = tid; j < N / 2; j += kGB) {
-            const int k = j & (ns - 1);
-            const float2 w = twd(k * (N / (2 * ns)));
-            const float2 u = in[j], b = cmul(in[j + N / 2], w);
-            const int j0 = ((j - k) << 1) + k;
-            out[j0] = float2{u.x + b.x, u.y + b.y};
-            out[j0 + ns] = float2{u.x - b.x, u.y - b.y};
+            const float2 u = in[j], b = cmul(in[j + N / 2], dirw(tw[j]));
+            out[j] = float2{u.x + b.x, u.y + b.y};
+            out[j + N / 2] = float2{u.x - b.x, u.y - b.y};
         }
         __syncthreads();
         float2 *t = in;
@@ -81,9 +75,12 @@ __global__ __launch_bounds__(gen_block(N)) void das_fused_gen_kernel(DasFusedArg
     constexpr int kGB = gen_block(N);
     constexpr int H = N / 2, BPT = N / kGB;  // bins (samples) per thread: 2 .. 32
     constexpr bool kTabLds = N <= 4096;      // N = 8192: 2 x 64 KB of transform buffers + 16 KB of tail leave no room for the tables
-    __shared__ float2 s_a[N], s_b[N], s_twl[kTabLds ? N / 2 : 1];
+    constexpr int kR4 = stockham_r4_entries(N);
+    constexpr bool kTw2Lds = kTabLds && N <= 1024;  // the radix-2 pass' table: in order, L1 serves it as well (N = 2048: keeps three blocks per CU)
+    __shared__ float2 s_a[N], s_b[N], s_c4l[kTabLds ? kR4 : 1], s_twl[kTw2Lds ? N / 2 : 1];
     __shared__ float s_winl[kTabLds ? N : 1], s_tail[H];
-    const float2 *s_tw = kTabLds ? s_twl : reinterpret_cast<const float2 *>(a.twiddle);
+    const float2 *s_c4 = kTabLds ? s_c4l : reinterpret_cast<const float2 *>(a.twiddle) + N / 2;
+    const float2 *s_tw = kTw2Lds ? s_twl : reinterpret_cast<const float2 *>(a.twiddle);
     const float *s_win = kTabLds ? s_winl : a.window;
     const int tid = threadIdx.x;
     const int M = a.n_mics, n_pairs = (M + 1) >> 1;
@@ -92,7 +89,9 @@ __global__ __launch_bounds__(gen_block(N)) void das_fused_gen_kernel(DasFusedArg
     const int in_stream = stream / a.n_dirs;
     const f32x2 *gains = a.gains + (long)(stream - in_stream * a.n_dirs) * n_pairs * N;  // [pair][bin], 1/N folded in
     if (kTabLds) {
-        for (int i = tid; i < N / 2; i += kGB) s_twl[i] = float2{a.twiddle[i].x, a.twiddle[i].y};
+        for (int i = tid; i < kR4; i += kGB) s_c4l[i] = float2{a.twiddle[N / 2 + i].x, a.twiddle[N / 2 + i].y};
+        if (kTw2Lds)
+            for (int i = tid; i < N / 2; i += kGB) s_twl[i] = float2{a.twiddle[i].x, a.twiddle[i].y};
         for (int i = tid; i < N; i += kGB) s_winl[i] = a.window[i];
     }
     const long T0 = c_in_s * a.frames_per_chunk;
@@ -134,7 +133,7 @@ __global__ __launch_bounds__(gen_block(N)) void das_fused_gen_kernel(DasFusedArg
                 s_a[n] = float2{va * w, vb * w};  // buf[j]*hann_win[i]  (util.h:235)
             }
             __syncthreads();
-            const float2 *Z = stockham32<N, -1>(s_a, s_b, s_tw, tid);
+            const float2 *Z = stockham32<N, -1>(s_a, s_b, s_c4, s_tw, tid);
             const f32x2 *gp = gains + (long)p * N;
 #pragma unroll
             for (int i = 0; i < BPT; ++i) {
@@ -154,7 +153,7 @@ __global__ __launch_bounds__(gen_block(N)) void das_fused_gen_kernel(DasFusedArg
 #pragma unroll
         for (int i = 0; i < BPT; ++i) s_a[tid + kGB * i] = S[i];
         __syncthreads();
-        const float2 *Y = stockham32<N, +1>(s_a, s_b, s_tw, tid);
+        const float2 *Y = stockham32<N, +1>(s_a, s_b, s_c4, s_tw, tid);
         float o[BPT];
 #pragma unroll
         for (int i = 0; i < BPT; ++i) {

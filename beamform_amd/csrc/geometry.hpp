@@ -209,6 +209,35 @@ inline std::vector<f32x2> twiddle_table_w64() {
     return t;
 }
 
+// Twiddles of the LDS-staged autosort (Stockham) transforms of the generic FFT sizes (das_fused_gen.hip, stft_istft.hip):
+//   [0, N/2)            W^m = exp(-2 pi i m / N): the closing radix-2 pass of N = 2 * 4^k reads it in order (and the in-place
+//                       transform of N = 8192 with its own strides);
+//   [N/2, N/2 + R4)     one block per radix-4 pass ns = 1, 4, 16, ... (4 ns <= N), at offset N/2 + (ns - 1): [q][k] = W^((q + 1) k N / (4 ns)),
+//                       q = 0..2, k < ns -- the three twiddles of butterfly k CONTIGUOUS in k.  Read out of the plain W^m table the lanes of
+//                       a wavefront (consecutive k) are N / (4 ns) entries apart: up to 16 of them on one LDS bank (measured: half of the
+//                       LDS cycles of das_fused_gen_kernel<2048> were bank conflicts).
+constexpr int stockham_r4_entries(int n) {
+    int ns = 1, tot = 0;
+    for (; ns * 4 <= n; ns <<= 2) tot += 3 * ns;
+    return tot;
+}
+template <typename V>
+inline std::vector<V> stockham_twiddles(int N) {
+    std::vector<V> t((size_t)N / 2 + stockham_r4_entries(N));
+    typedef decltype(V{}.x) T;
+    for (int m = 0; m < N / 2; ++m) {
+        const double a = -2.0 * kPi * (double)m / (double)N;
+        t[m] = V{(T)std::cos(a), (T)std::sin(a)};
+    }
+    for (int ns = 1; ns * 4 <= N; ns <<= 2)
+        for (int q = 0; q < 3; ++q)
+            for (int k = 0; k < ns; ++k) {
+                const double a = -2.0 * kPi * (double)((long)(q + 1) * k * (N / (4 * ns))) / (double)N;
+                t[(size_t)N / 2 + (ns - 1) + (size_t)q * ns + k] = V{(T)std::cos(a), (T)std::sin(a)};
+            }
+    return t;
+}
+
 // fp64 tables of the 64-lane factorisation with the rotated exchange (fft1024_w64.hpp w64_col_rot; das_f64_w64.hip):
 // [0, 1024) = W1024^(k1*lane) as [k1][lane]; [1024, 1092) = tw2'[b][k2] = exp(2 pi i 15 b k2 / 64) in rows of 17 (one element of
 // padding: the four rows a wavefront reads at once then start 4 LDS banks apart instead of on the same one)

@@ -95,13 +95,7 @@ class BinPipelineImpl : public BinPipeline {
         }
         // N = 1024: inter-pass twiddles of the 32 x 32 factorisation; other sizes: exp(-2 pi i m / N), m < N/2 (Stockham passes)
         std::vector<f64x2> tw = twiddle_table_32x32<f64x2>();
-        if (N_ != 1024) {
-            tw.resize(N_ / 2);
-            for (int m = 0; m < N_ / 2; ++m) {
-                const double a = -2.0 * kPi * (double)m / (double)N_;
-                tw[m] = f64x2{std::cos(a), std::sin(a)};
-            }
-        }
+        if (N_ != 1024) tw = stockham_twiddles<f64x2>(N_);
         PIPE_HIP(hipMalloc((void **)&d_tw_, tw.size() * sizeof(f64x2)));
         PIPE_HIP(hipMemcpy(d_tw_, tw.data(), tw.size() * sizeof(f64x2), hipMemcpyHostToDevice));
         std::vector<f32x2> tw32 = twiddle_table_32x32<f32x2>();

@@ -617,22 +617,18 @@ __device__ __forceinline__ void fft_inplace(cd *buf, const f64x2 *tw, int tid) {
 // ran nine / eleven radix-2 passes with the twiddles read from global memory), tw = the half-length table in LDS,
 // W^(m + N/2) = -W^m.
 template <int DIR>
-__device__ __forceinline__ cd *stockham(cd *buf0, cd *buf1, const f64x2 *tw, int tid) {
+__device__ __forceinline__ cd *stockham(cd *buf0, cd *buf1, const f64x2 *c4, const f64x2 *tw, int tid) {
     cd *in = buf0, *out = buf1;
-    auto twd = [&](int m) -> cd {
-        const f64x2 w = tw[m & (kN / 2 - 1)];
-        const double sg = (m & (kN / 2)) ? -1.0 : 1.0;
-        return cd{sg * w.x, DIR < 0 ? sg * w.y : -sg * w.y};
-    };
+    auto dirw = [](f64x2 w) { return cd{w.x, DIR < 0 ? w.y : -w.y}; };  // W (forward) or its conjugate (backward)
     int ns = 1;
     for (; ns * 4 <= kN; ns <<= 2) {
+        const f64x2 *cp = c4 + (ns - 1);  // this pass' block: the three twiddles of butterfly k contiguous in k (geometry.hpp stockham_twiddles)
         for (int j = tid; j < kN / 4; j += kGenBlock) {
             const int k = j & (ns - 1);
-            const int st = k * (kN / (4 * ns));
             const cd a0 = in[j];
-            const cd a1 = in[j + kN / 4] * twd(st);
-            const cd a2 = in[j + kN / 2] * twd(2 * st);
-            const cd a3 = in[j + 3 * kN / 4] * twd(3 * st);
+            const cd a1 = in[j + kN / 4] * dirw(cp[k]);
+            const cd a2 = in[j + kN / 2] * dirw(cp[ns + k]);
+            const cd a3 = in[j + 3 * kN / 4] * dirw(cp[2 * ns + k]);
             const cd s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
             const cd r13 = DIR < 0 ? cd{d13.y, -d13.x} : cd{-d13.y, d13.x};  // -i d13 (forward) / +i d13 (backward)
             const int j0 = ((j - k) << 2) + k;
@@ -644,13 +640,11 @@ __device__ __forceinline__ cd *stockham(cd *buf0, cd *buf1, const f64x2 *tw, int
         __syncthreads();
         cd *t = in; in = out; out = t;
     }
-    if (ns < kN) {
+    if (ns < kN) {  // closing radix-2 pass (N = 2 * 4^k): ns = N / 2, twiddle W^k in order
         for (int j = tid; j < kN / 2; j += kGenBlock) {
-            const int k = j & (ns - 1);
-            const cd a = in[j], b = in[j + kN / 2] * twd(k * (kN / (2 * ns)));
-            const int j0 = ((j - k) << 1) + k;
-            out[j0] = a + b;
-            out[j0 + ns] = a - b;
+            const cd a = in[j], b = in[j + kN / 2] * dirw(tw[j]);
+            out[j] = a + b;
+            out[j + kN / 2] = a - b;
         }
         __syncthreads();
         cd *t = in; in = out; out = t;
@@ -662,13 +656,14 @@ template <int LAYOUT>
 __global__ __launch_bounds__(kGenBlock) void stft_generic_kernel(StftArgs a) {
     __shared__ cd s_a[kN], s_b[kGenInPlace ? 1 : kN];
     constexpr bool kTwLds = kGenTwLds;
-    __shared__ f64x2 s_twl[kTwLds ? kN / 2 : 1];
+    constexpr int kR4 = stockham_r4_entries(kN);
+    __shared__ f64x2 s_twl[kTwLds ? kR4 : 1];  // the radix-4 passes' blocks; the closing radix-2 pass reads W^m in order through L1
     const int tid = threadIdx.x;
     if (kTwLds) {
-        for (int i = tid; i < kN / 2; i += kGenBlock) s_twl[i] = a.tw[i];
+        for (int i = tid; i < kR4; i += kGenBlock) s_twl[i] = a.tw[kN / 2 + i];
         __syncthreads();
     }
-    const f64x2 *s_tw = kTwLds ? s_twl : a.tw;
+    const f64x2 *s_c4 = kTwLds ? s_twl : a.tw + kN / 2, *s_tw = a.tw;
     const int M = a.n_mics, MF = a.n_fft_mics, NP = (MF + 1) >> 1;
     const long total = (long)a.n_streams * a.n_frames * NP;
     for (long item = blockIdx.x; item < total; item += gridDim.x) {
@@ -705,7 +700,7 @@ __global__ __launch_bounds__(kGenBlock) void stft_generic_kernel(StftArgs a) {
         if (kGenInPlace)
             fft_inplace<-1>(s_a, s_tw, tid);
         else
-            res = stockham<-1>(s_a, s_b, s_tw, tid);
+            res = stockham<-1>(s_a, s_b, s_c4, s_tw, tid);
         const long zoff = (((long)s * a.frames_ws + a.frame_off + t) * NP + p) * kN;
         for (int k = tid; k < kN; k += kGenBlock) {
             if (a.z48)
@@ -730,13 +725,14 @@ __device__ __forceinline__ cd herm_gen(const f64x2 *row, int k) {
 __global__ __launch_bounds__(kGenBlock) void istft_generic_kernel(IstftArgs a) {
     __shared__ cd s_a[kN], s_b[kGenInPlace ? 1 : kN];
     constexpr bool kTwLds = kGenTwLds;
-    __shared__ f64x2 s_twl[kTwLds ? kN / 2 : 1];
+    constexpr int kR4 = stockham_r4_entries(kN);
+    __shared__ f64x2 s_twl[kTwLds ? kR4 : 1];  // the radix-4 passes' blocks; the closing radix-2 pass reads W^m in order through L1
     const int tid = threadIdx.x;
     if (kTwLds) {
-        for (int i = tid; i < kN / 2; i += kGenBlock) s_twl[i] = a.tw[i];
+        for (int i = tid; i < kR4; i += kGenBlock) s_twl[i] = a.tw[kN / 2 + i];
         __syncthreads();
     }
-    const f64x2 *s_tw = kTwLds ? s_twl : a.tw;
+    const f64x2 *s_c4 = kTwLds ? s_twl : a.tw + kN / 2, *s_tw = a.tw;
     const long total = (long)a.n_streams * a.n_frames;
     for (long f = blockIdx.x; f < total; f += gridDim.x) {
         const f64x2 *row = a.Yh + f * kYhStride;
@@ -746,7 +742,7 @@ __global__ __launch_bounds__(kGenBlock) void istft_generic_kernel(IstftArgs a) {
         if (kGenInPlace)
             fft_inplace<+1>(s_a, s_tw, tid);
         else
-            res = stockham<+1>(s_a, s_b, s_tw, tid);
+            res = stockham<+1>(s_a, s_b, s_c4, s_tw, tid);
         float *fo = a.frames + f * kN;
         for (int n = tid; n < kN; n += kGenBlock) {
             float v = (float)(res[n].x / (double)kN);            // util.h:249

@@ -17,16 +17,17 @@ ap.add_argument("--warmup", type=int, default=10)
 ap.add_argument("--settle-ms", type=float, default=80.0)
 ap.add_argument("--dirs", type=int, default=1, help="look directions per input stream (same input, n_dirs outputs)")
 ap.add_argument("--das-f64", action="store_true", help="das through the fp64 bin pipeline")
+ap.add_argument("--hop", type=int, default=512, help="JACK period (frames are 2 * hop samples); --frames counts frames of that period")
 a = ap.parse_args()
 interf = (-60.0, 90.0, 150.0) if a.algo in ("lcmv", "gss") else ()
-p = make_params(a.algo, n_mics=a.mics, interf=interf)
+p = make_params(a.algo, n_mics=a.mics, interf=interf, hop=a.hop)
 lay = BF_PLANAR if a.layout == "planar" else BF_INTERLEAVED
 bf = Beamformer(p, n_streams=a.streams, layout=lay, n_dirs=a.dirs, das_impl=1 if a.das_f64 else 0)
 if a.dirs > 1:
     bf.set_thetas([-90.0 + 180.0 * d / (a.dirs - 1) for d in range(a.dirs)])
-shape = (a.streams, a.mics, a.frames * 512) if lay == BF_PLANAR else (a.streams, a.frames * 512, a.mics)
+shape = (a.streams, a.mics, a.frames * a.hop) if lay == BF_PLANAR else (a.streams, a.frames * a.hop, a.mics)
 x = torch.rand(shape, device="cuda") - 0.5
-y = torch.empty((a.streams * a.dirs, a.frames * 512), device="cuda")
+y = torch.empty((a.streams * a.dirs, a.frames * a.hop), device="cuda")
 import time
 t0 = time.perf_counter()
 n_warm = 0
