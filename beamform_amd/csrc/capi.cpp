@@ -44,6 +44,7 @@ struct bf_handle {
     int gains_cur = 0;
     f32x2 *d_twiddle = nullptr;
     f32x2 *d_twiddle_w64 = nullptr;
+    f32x2 *d_twiddle_split = nullptr;  // hop 1024: twiddle_table_split2048() (das_fused_2048.hip)
     f32x2 *d_gains_w64[2] = {nullptr, nullptr};
     bool use_w64 = false;
     float *d_window = nullptr;
@@ -204,7 +205,11 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     const bool shared = !gen && !h->use_w64 && layout == BF_PLANAR && h->M <= 8 && !spectrum_dev && shared_min > 0 && h->n_dirs >= shared_min;
     // (generic periods: blocks of 13 N bytes of LDS -- 26 N at N = 8192 -- share a CU: 8 at N <= 512, 3 at 2048, 1 from 4096 on)
     const int gen_per_cu = h->N <= 512 ? 8 : h->N <= 1024 ? 6 : h->N <= 2048 ? 3 : 1;
-    long runs = (gen ? (long)h->n_cus * gen_per_cu : (long)h->n_cus) / (shared ? h->n_streams : S);
+    // period 1024 without a dump: two FFT-1024 passes per frame on the in-register machinery, a half-wavefront per run, 16 runs per CU
+    // (BF_DAS_SPLIT2048=0: the generic kernel, for A/B runs)
+    static const bool split_on = !(getenv("BF_DAS_SPLIT2048") && atoi(getenv("BF_DAS_SPLIT2048")) == 0);
+    const bool split2048 = gen && h->N == 2048 && !spectrum_dev && split_on && h->d_twiddle_split != nullptr;
+    long runs = (split2048 ? (long)h->n_cus * 8 : gen ? (long)h->n_cus * gen_per_cu : (long)h->n_cus) / (shared ? h->n_streams : S);
     if (runs < 1) runs = 1;
     long fpc = (F + runs - 1) / runs;
     if (!gen) fpc = ((fpc + 15) / 16) * 16;
@@ -257,7 +262,9 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
         for (int d0 = 0; d0 < h->n_dirs; d0 += 16)
             BF_HIP(h, launch_das_fused_dirs(a, d0, h->n_dirs - d0 < 16 ? h->n_dirs - d0 : 16, s));
     } else {
-        BF_HIP(h, gen ? launch_das_fused_gen(a, h->N, s) : h->use_w64 ? launch_das_fused_w64(a, s) : launch_das_fused(a, s));
+        BF_HIP(h, split2048 ? launch_das_fused_2048(a, h->d_twiddle_split, s)
+                  : gen     ? launch_das_fused_gen(a, h->N, s)
+                  : h->use_w64 ? launch_das_fused_w64(a, s) : launch_das_fused(a, s));
     }
     if (k1) BF_HIP(h, hipEventRecord(k1, s));
     h->tail_cur ^= 1;
@@ -409,6 +416,11 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
         h->use_w64 = !fused_das_gen(h) && getenv("BF_DAS_W64") && atoi(getenv("BF_DAS_W64")) != 0;
         std::vector<f32x2> tw = twiddle_table_32x32<f32x2>();
         if (fused_das_gen(h)) tw = stockham_twiddles<f32x2>(h->N);  // W^m, m < N/2, + the per-pass radix-4 blocks (geometry.hpp)
+        if (h->N == 2048) {
+            const std::vector<f32x2> ts = twiddle_table_split2048();
+            BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle_split, ts.size() * sizeof(f32x2)));
+            BF_CREATE_HIP(hipMemcpy(h->d_twiddle_split, ts.data(), ts.size() * sizeof(f32x2), hipMemcpyHostToDevice));
+        }
         BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle, tw.size() * sizeof(f32x2)));
         BF_CREATE_HIP(hipMemcpy(h->d_twiddle, tw.data(), tw.size() * sizeof(f32x2), hipMemcpyHostToDevice));
         std::vector<double> hd = sqrt_hann(h->N);
@@ -458,6 +470,7 @@ void bf_destroy(bf_handle *h) {
     }
     if (h->d_twiddle) (void)hipFree(h->d_twiddle);
     if (h->d_twiddle_w64) (void)hipFree(h->d_twiddle_w64);
+    if (h->d_twiddle_split) (void)hipFree(h->d_twiddle_split);
     if (h->d_window) (void)hipFree(h->d_window);
     if (h->d_zeros) (void)hipFree(h->d_zeros);
     if (h->d_sdump) (void)hipFree(h->d_sdump);

@@ -50,6 +50,10 @@ hipError_t launch_das_hermitian_dump(const f32x2 *sdump, f64x2 *out, long n_fram
 // `twiddle` = exp(-2 pi i m / n_fft) for m < n_fft / 2, `window` n_fft floats; frames_per_chunk is free (no multiple of 16), no
 // prepare step (a run that does not start the stream recomputes its previous frame); sdump rows are n_fft long, natural order
 hipError_t launch_das_fused_gen(const DasFusedArgs &a, int n_fft, hipStream_t stream);
+// JACK period 1024 (FFT 2048) on the in-register FFT-1024 machinery, two passes per frame (das_fused_2048.hip): `gains` as for
+// launch_das_fused_gen, tw_split = twiddle_table_split2048(); a.frames_per_chunk / a.chunks_per_stream = frames per run / runs per OUTPUT
+// stream (a half-wavefront per run).  hipErrorNotSupported with a spectrum dump (launch_das_fused_gen serves that).
+hipError_t launch_das_fused_2048(const DasFusedArgs &a, const f32x2 *tw_split, hipStream_t stream);
 hipError_t launch_das_hermitian_dump_gen(const f32x2 *sdump, f64x2 *out, long n_frames_total, int n_fft, hipStream_t stream);
 
 }  // namespace bf

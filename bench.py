@@ -552,7 +552,7 @@ def main():
 
         def other_period_line(hop_, algo_="das"):
             # JACK periods other than 512 frames (rosjack.cpp:131; fft_win = 2 * period): one fused fp32 kernel on LDS-staged radix-4
-            # transforms (das_fused_gen.hip); same number of SAMPLES as the headline batch
+            # transforms (das_fused_gen.hip; period 1024: das_fused_2048.hip); same number of SAMPLES as the headline batch
             pm = make_params(algo_, n_mics=M, hop=hop_)
             F_ = F * HOP // hop_
             bm = Beamformer(pm, device=local_rank)
@@ -566,8 +566,9 @@ def main():
                 n_settle += 1
             ms, _ = bm.time_device(xin.data_ptr(), F_, yo.data_ptr(), 5, sptr)
             bm.close()
-            return {"workload": f"{algo_} {M}-mic, JACK period {hop_} (FFT {2 * hop_}), {F_} frames = the headline batch's samples; fused fp32 kernel on "
-                                "LDS-staged radix-4 transforms (das_fused_gen.hip; not the register-resident machinery of the 512-frame period)",
+            how = ("two register-resident FFT-1024 passes per frame (das_fused_2048.hip)" if hop_ == 1024 else
+                   "LDS-staged radix-4 transforms (das_fused_gen.hip; not the register-resident machinery of the 512-frame period)")
+            return {"workload": f"{algo_} {M}-mic, JACK period {hop_} (FFT {2 * hop_}), {F_} frames = the headline batch's samples; fused fp32 kernel on " + how,
                     "ms_per_step": ms, "frames_per_s": F_ / (ms * 1e-3), "samples_per_s": F_ * hop_ / (ms * 1e-3)}
 
         def dirs_line(D_):

@@ -220,3 +220,36 @@ def test_fused_das_at_other_periods_layouts_streams_directions_cuts(hop):
     cuts = [0, 1, 7, Fl // 3, Fl]
     parts = [b2.process(np.ascontiguousarray(xl[:, a * hop:c * hop])) for a, c in zip(cuts[:-1], cuts[1:])]
     assert np.array_equal(np.concatenate(parts), whole)
+
+
+CHILD_1024 = r"""
+import sys, json, numpy as np
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r + "/tests")
+import oracle
+from beamform_amd.capi import Beamformer
+from beamform_amd.params import make_params
+from beamform_amd.synth import make_scene
+from conftest import rel_l2
+res = {}
+for M, F in ((8, 300), (7, 41), (12, 33)):   # gains in LDS (<= 8 microphones, one direction) and from L2 (12)
+    p = make_params("das", n_mics=M, theta=35.0, hop=1024)
+    x = make_scene(M, F, hop=1024, seed=1024 + M)
+    ref, _ = oracle.OracleNode(p).process(x)
+    y = Beamformer(p).process(x)
+    res[str(M)] = rel_l2(y, ref)
+print("RESULT " + json.dumps(res))
+"""
+
+
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_period_1024_split_kernel_and_its_switch(split):
+    """das_fused_2048.hip (two FFT-1024 passes per frame, the default at the 1024-frame period without a spectrum dump) and
+    BF_DAS_SPLIT2048=0 (das_fused_gen_kernel<2048>) against the oracle; the switch is read once per process."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", CHILD_1024 % dict(root=root)], env=dict(os.environ, BF_DAS_SPLIT2048=split),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
+    assert set(res) == {"8", "7", "12"} and max(res.values()) < TOL, res
