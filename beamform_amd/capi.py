@@ -69,6 +69,29 @@ class BfError(RuntimeError):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  A PyTorch-ROCm wheel ships its own libamdhip64.so (same soname as /opt/rocm's); if libbfcore.so
+    is loaded first it brings in /opt/rocm's copy, torch then loads its own beside it, and the second runtime to initialise reports
+    "no ROCm-capable device".  When torch is installed but not imported yet, load ITS runtime first (without importing torch) so that
+    libbfcore.so's DT_NEEDED resolves to the copy torch will use.  BF_NO_TORCH_HIP=1 skips this (a process that never imports torch)."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("BF_NO_TORCH_HIP") == "1":
+        return
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # not loadable on its own: libbfcore.so falls back to its RUNPATH copy
+
+
 def load():
     """dlopen libbfcore.so; raises if it has not been built (no fallback)."""
     global _lib
@@ -77,6 +100,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run `make` (or __graft_entry__.build()); "
                           "beamform_amd has no CPU fallback")
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     L.bf_version.restype = C.c_char_p
     L.bf_strerror.restype = C.c_char_p

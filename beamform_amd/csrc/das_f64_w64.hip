@@ -1,28 +1,31 @@
 // das_f64_w64.hip -- das at the reference's precision (double arithmetic, das.cpp:47-70 + util.h:217-314), one launch,
-// one full wavefront per frame.
+// one full wavefront per transform (fft1024_w64.hpp: 64 lanes x 16 points, 16 x 16 x 4).
 //
-// Formulation as das_f64_fused_kernel (stft_istft.hip): per frame four packed forward FFT-1024 (two real microphones each),
-// S += D_p Z_p with the Hermitian-part pair gains (geometry.hpp das_pair_gains_t, 1/N folded in), one backward transform,
-// (float)Re, float x double window, float overlap-add.  What differs is the mapping onto the chip:
+// Two kernels share the transform machinery:
+//   das_f64_pair_kernel  planar input (the bench headline).  A complex transform carries frames t and t + 1 of ONE microphone;
+//                        U = sum_m ce_m Z_m with the per-microphone Hermitian gains, one backward transform returns both frames
+//                        (real / imaginary part): 4.5 transforms per frame.  Frame pairs are handed out to the eight wavefronts of
+//                        a block through an LDS counter, the overlap-add between pairs is first come first served (below).
+//   das_f64_w64_kernel   [sample][mic] input (and BF_DAS_F64_PAIR=0).  A transform carries two microphones of one frame (one 8-byte
+//                        load per sample), S += D_p Z_p with the Hermitian-part pair gains (das_pair_gains_t), Re of the backward
+//                        transform: 5 transforms per frame; wavefront w of a block takes frame T0 + 8 it + w.
+// Both: (float)Re, float x double window, float overlap-add (util.h:247-252,301-302), 1/N inside the gains.
 //
-//   * 64 lanes x 16 points per lane (fft1024_w64.hpp, 16 x 16 x 4) instead of 32 lanes x 32 points: 64 data + 64 accumulator
-//     registers, so TWO wavefronts share a SIMD (the 32 x 32 kernel needs 256 + 206 registers and runs one wavefront per SIMD
-//     with ~1 000 v_accvgpr moves per frame).  A lone wavefront issues one vector instruction per 4 cycles and has nobody to
-//     hide its LDS round trips behind; two fill each other's gaps and the non-fp64 instructions issue at 2 cycles.
-//   * a 512-thread block per CU walks a run of consecutive frames, 8 per step (wavefront w: frame T0 + 8 it + w).  First-pass
-//     lane = sample, so every global load is one contiguous 256-byte row; the hop two consecutive frames share is fetched by two
-//     wavefronts of the same CU within one step (L1 / L2), so each sample leaves HBM once (the 32 x 32 kernel re-read the shared
-//     hop a frame later and moved 1.96 x the algorithmic bytes).
-//   * overlap-add partner without a block barrier: wavefront w parks the second half of its frame in the head of its OWN
-//     exchange plane (free between its backward transform and the first exchange of its next frame) and raises ready[w];
-//     wavefront w + 1 adds it to its first half and raises cons[w], which w checks before it reuses the plane.  The tail that
-//     crosses a step (7 -> 0) has two slots of its own.  Run boundaries: two float atomic adds into a hop zeroed beforehand
+// Mapping onto the chip (what differs from the 32 x 32 das_f64_fused_kernel of stft_istft.hip):
+//   * 64 lanes x 16 points per lane: 64 data + 64 accumulator registers, so TWO wavefronts share a SIMD (the 32 x 32 kernel needs
+//     256 + 206 registers, one wavefront per SIMD, ~1 000 v_accvgpr moves per frame).
+//   * a 512-thread block per CU walks a run of consecutive frames.  First-pass lane = sample, so every global load is one
+//     contiguous 256-byte row; the hop two consecutive frames (pairs) share is fetched by two wavefronts of the same CU within
+//     microseconds (L1 / L2): each sample leaves HBM once.
+//   * no block barrier after the table copy.  Run boundaries: two float atomic adds into a hop zeroed beforehand
 //     (prepare_das_f64_w64), bit-exact because a + b == b + a.
 //
-// LDS (159 KB): 16 KB twiddles W1024^(k1 lane) + 1 KB tw2' + 8 x 8.1 KB exchange planes (16 rows x 65 doubles, one scalar plane
-// per wavefront: real parts, then imaginary parts) + 64 KB pair gains + 4 KB step-crossing tails + 9 KB window rows.  Exchange layout: see
-// fft1024_w64.hpp w64_col_rot (every ds_read_b64 / ds_write_b64 group lands on distinct bank pairs).
+// LDS (155-159 KB): twiddles W1024^(k1 lane) + tw2' (16 KB), 8 x 8.1 KB exchange planes (16 rows x 65 doubles, one scalar plane per
+// wavefront: real parts, then imaginary parts), 64-65 KB gains, 9 KB window rows, flags.  Exchange layout: fft1024_w64.hpp
+// w64_col_rot (every ds_read_b64 / ds_write_b64 group lands on distinct bank pairs).
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "fft1024.hpp"
 #include "fft1024_w64.hpp"
@@ -447,21 +450,398 @@ __global__ __launch_bounds__(kBlock) void das_f64_w64_kernel(DasF64Args a, int f
     }
 }
 
+
+// =====================================================================================================================================
+//                 frame-pair kernel: two consecutive frames of ONE microphone per complex transform (planar input)
+// =====================================================================================================================================
+// The kernel above packs two microphones of one frame into a transform and takes Re of the backward transform: half of that
+// transform's output is thrown away.  Packing the SAME microphone's frames t and t + 1 instead (z = x_t + i x_(t+1)) keeps every
+// spectrum Hermitian-separable:  U = sum_m ce_m (X_m(t) + i X_m(t+1)) = H_t + i H_(t+1)  with ce_m the Hermitian part of conj(w_m) / M
+// (geometry.hpp das_mic_gains_w64_f64; ce_m[N - k] = conj ce_m[k]) and H real-output spectra, so ONE backward transform returns y_t in
+// its real and y_(t+1) in its imaginary part: 4.5 transforms per frame instead of 5, three hops loaded per microphone and frame pair
+// instead of four, one overlap-add across wavefronts per two frames (the inner one is a register add: samples n and n + 512 share a lane).
+//
+// Scheduling.  The two wavefronts of a SIMD do not share it evenly: the older one issues whenever it can (it runs at the lone-wavefront
+// rate), the younger one gets what is left (tools/stats_w64.py: with a fixed frame -> wavefront map and a ring of hand-offs, wavefronts
+// 0-3 slept a third of the kernel waiting for 4-7, i.e. a third of the time each SIMD ran ONE wavefront).  So (i) frame pairs are taken
+// from an LDS counter -- the fast wavefronts end up with ~72 % of them and all eight finish together -- and (ii) the overlap-add
+// between pairs never waits for the other side's arithmetic (claim_boundary below).
+// Gains: ce_m is Hermitian, so only bins 0 .. 512 are kept: [mic][row 2 g + k3, k3 < 2][65] = ce_m[64 g + 256 k3 + c], c = 0 .. 64.
+// Register 4 g + k3 of lane l is bin l + 64 g + 256 k3: k3 < 2 reads row (g, k3) column l; k3 >= 2 reads row (3 - g, 3 - k3) column
+// 64 - l (N - k = (64 - l) + 64 (3 - g) + 256 (3 - k3)) and conjugates through the FMA signs.  The 65th column is the bin behind the row.
+constexpr int kGRow = 65;                                  // complex entries per gain row
+constexpr int kGMic = 8 * kGRow;                           // per microphone
+constexpr int kStepP = 2 * kWaves;                         // frames of one round of the block's wavefronts (run lengths are multiples)
+constexpr int kSlots = 64;                                 // boundary states in flight (<= 2 pairs per wavefront are): a ring
+constexpr int kTwP = 2 * (960 + 4 * kTw2RowW64Rot);        // tw1 rows k1 = 1 .. 15 (row 0 is all ones and never read) + tw2'
+constexpr int pTw = 0;
+constexpr int pPlane = kTwP;
+constexpr int pGain = pPlane + kWaves * kPlaneD;
+constexpr int pFlag = pGain + 8 * kGMic * 2;
+constexpr int pWin = pFlag + (kSlots + 4) / 2;           // kSlots + 1 ints, padded to 16 bytes
+constexpr int kLdsP = pWin + 64 * kWinRow;
+static_assert(kLdsP * 8 <= 160 * 1024, "LDS");
+static_assert((pGain & 1) == 0 && (pWin & 1) == 0, "16-byte alignment");
+
+
+typedef volatile __attribute__((address_space(3))) int *lds_int_t;
+__device__ __forceinline__ int lds_fetch_add(lds_int_t p, int v, int lane) {
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add((__attribute__((address_space(3))) int *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __builtin_amdgcn_readfirstlane(old);
+}
+// the next frame pair of the run (wavefront-uniform)
+__device__ __forceinline__ int take_pair(lds_int_t counter, int lane) { return lds_fetch_add(counter, 1, lane); }
+// Boundary b lives in slot b mod kSlots; over its life the slot gains 4 (two claims of 1, one publication of 2), so generation b / kSlots
+// starts at 4 (b / kSlots).  claim: 0 = first to arrive; otherwise the other side has claimed (1) or already published (3).
+__device__ __forceinline__ int claim_boundary(lds_int_t st, int b, int lane) { return lds_fetch_add(st + (b & (kSlots - 1)), 1, lane) - 4 * (b / kSlots); }
+__device__ __forceinline__ void publish_boundary(lds_int_t st, int b, int lane) { (void)lds_fetch_add(st + (b & (kSlots - 1)), 2, lane); }
+__device__ __forceinline__ void await_boundary(lds_int_t st, int b) {
+    while (st[b & (kSlots - 1)] - 4 * (b / kSlots) < 3) __builtin_amdgcn_s_sleep(1);
+}
+
+#ifdef BF_W64_STATS  // debug build (tools/ab_w64.sh stats -DBF_W64_STATS): how the hand-offs of das_f64_pair_kernel went, per wavefront
+// [block][wavefront][partner there before the backward transform / at the epilogue / had to wait / 10 ns ticks waited / ticks in the kernel]
+__device__ unsigned long long g_stats[256 * 8 * 5];
+#define BF_STATS_DECL unsigned long long st_[5] = {0, 0, 0, 0, 0}; const unsigned long long st_t0_ = __builtin_amdgcn_s_memrealtime()
+#define BF_STAT(i) (++st_[i])
+#define BF_STAT_WAIT_BEGIN const unsigned long long st_w0_ = __builtin_amdgcn_s_memrealtime()
+#define BF_STAT_WAIT_END st_[3] += __builtin_amdgcn_s_memrealtime() - st_w0_
+#define BF_STATS_FLUSH do { st_[4] = __builtin_amdgcn_s_memrealtime() - st_t0_; if (lane == 0 && blockIdx.x < 256) for (int i_ = 0; i_ < 5; ++i_) g_stats[(blockIdx.x * 8 + w) * 5 + i_] = st_[i_]; } while (0)
+#else
+#define BF_STATS_DECL
+#define BF_STAT(i) ((void)0)
+#define BF_STAT_WAIT_BEGIN
+#define BF_STAT_WAIT_END
+#define BF_STATS_FLUSH
+#endif
+#ifdef BF_W64_STAMPS  // debug build (tools/ab_w64.sh stamps -DBF_W64_STAMPS [-DBF_W64_FINE]): s_memrealtime (100 MHz) per wavefront
+__device__ unsigned long long g_stamps[256 * 8 * 64];
+#define BF_STAMP_RAW(slot) do { if (lane == 0 && blockIdx.x < 256 && (slot) < 64) g_stamps[(blockIdx.x * 8 + w) * 64 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#ifdef BF_W64_FINE  // the phases inside step 8 instead of the steps of the run
+#define BF_STAMP(slot) do { } while (0)
+#define BF_FSTAMP(k) do { if (it == 8) BF_STAMP_RAW(6 * m + (k)); } while (0)
+#define BF_BSTAMP(k) do { if (it == 8) BF_STAMP_RAW(48 + (k)); } while (0)
+#else
+#define BF_STAMP(slot) BF_STAMP_RAW(slot)
+#define BF_FSTAMP(k) do { } while (0)
+#define BF_BSTAMP(k) do { } while (0)
+#endif
+#else
+#define BF_STAMP(slot) do { } while (0)
+#define BF_FSTAMP(k) do { } while (0)
+#define BF_BSTAMP(k) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int frames_per_chunk, int chunks_per_stream) {
+    __shared__ __attribute__((aligned(16))) double lds[kLdsP];
+    const cx<double> *s_tw1 = reinterpret_cast<const cx<double> *>(lds + pTw) - 64;  // row k1 starts at 64 (k1 - 1)
+    const cx<double> *s_tw2 = reinterpret_cast<const cx<double> *>(lds + pTw) + 960;
+    const cx<double> *s_gain = reinterpret_cast<const cx<double> *>(lds + pGain);
+    lds_int_t s_state = (lds_int_t)(lds + pFlag);  // kSlots boundary states, then the next frame pair to hand out
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = a.n_mics;
+    double *plane = lds + pPlane + w * kPlaneD;
+    double *wcol = plane + w64_col_rot(lane);
+    double *row16 = plane + (lane & 15) * kRS + 16 * (lane >> 4);
+
+    const int stream = blockIdx.x / chunks_per_stream;
+    const long c_in_s = blockIdx.x - (long)stream * chunks_per_stream;
+    const double *wrow = lds + pWin + lane * kWinRow;
+
+    const long T0 = c_in_s * frames_per_chunk;
+    long T1 = T0 + frames_per_chunk;
+    if (T1 > a.n_frames) T1 = a.n_frames;
+    const float *xs = a.x + (long)stream * a.stream_stride_x;
+    const float *hs = a.hist + (long)stream * M * kHop;
+    float *ys = a.y + (long)stream * a.n_frames * kHop;
+
+    // hops tA - 1 (hop -1 = the carried hop), tA, tA + 1 of microphone m: register j <- sample 64 j + lane of the hop
+    float n0[8], n1[8], n2[8];
+    auto request = [&](long tA, int m) {
+        const float *xm = xs + (long)m * a.mic_stride;
+        const float *h0 = tA >= 1 ? xm + (tA - 1) * kHop : hs + m * kHop;
+        const float *h1 = xm + tA * kHop;
+        const float *h2 = xm + (tA + 1 < a.n_frames ? tA + 1 : tA) * kHop;  // a lone last frame: any readable hop, unused
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            n0[j] = h0[(unsigned)(64 * j + lane)];
+            n1[j] = h1[(unsigned)(64 * j + lane)];
+            n2[j] = h2[(unsigned)(64 * j + lane)];
+        }
+    };
+
+    BF_STAMP(0);
+    const int n_pairs = (int)((T1 - T0 + 1) >> 1);  // frame pairs of this run (the last one may be a lone frame)
+    if (w < n_pairs) request(T0 + 2 * w, 0);       // the first kWaves pairs are handed out statically: their samples travel during the table copy
+    {
+        const f64x2 *tw2 = a.tw + 64, *g2 = a.gains_mic;
+        f64x2 *ltw = reinterpret_cast<f64x2 *>(lds + pTw), *lg = reinterpret_cast<f64x2 *>(lds + pGain);
+#pragma unroll 4
+        for (int i = tid; i < kTwP / 2; i += kBlock) ltw[i] = tw2[i];
+#pragma unroll 8
+        for (int i = tid; i < M * kGMic; i += kBlock) lg[i] = g2[i];
+#pragma unroll 2
+        for (int i = tid; i < 1024; i += kBlock) lds[pWin + (i & 63) * kWinRow + (i >> 6)] = a.win[i];
+        if (tid <= kSlots) s_state[tid] = tid == kSlots ? kWaves : 0;
+    }
+    __syncthreads();
+    BF_STAMP(1);
+    BF_STATS_DECL;
+    int P = w, it = 0;  // this wavefront's frame pair; `it`: how many it has done (debug stamps)
+    while (P < n_pairs) {  // wavefront-uniform; no block barrier below
+        const long tA = T0 + 2L * P;
+        const bool pair = tA + 1 < T1;       // false: the odd last frame of the batch on its own (imaginary input zero)
+        const long tL = pair ? tA + 1 : tA;  // the frame whose second half leaves this wavefront
+        int Pn = n_pairs;                    // the pair after this one: taken when the last microphone starts
+
+        double Sr[16], Si[16];
+        for (int m = 0; m < M; ++m) {
+            double re[16], im[16];
+            BF_FSTAMP(0);
+            // buf[j]*hann_win[i] (util.h:235) and the first butterfly stage in one (see the kernel above); hop tA is the second half of
+            // frame tA and the first half of frame tA + 1
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double w0 = wrow[j], w1 = wrow[j + 8];
+                const double c = (double)n1[j];
+                const double t = (double)n0[j] * w0;
+                re[j] = fma(c, w1, t);
+                re[j + 8] = fma(-c, w1, t);
+                const double t2 = c * w0, u = (double)n2[j];
+                im[j] = fma(u, w1, t2);
+                im[j + 8] = fma(-u, w1, t2);
+            }
+            if (!pair) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) im[j] = 0.0;
+            }
+            {  // the next microphone, or the first one of this wavefront's next pair (none left: this pair's again, unused)
+                long tn = tA;
+                int mn = m + 1;
+                if (mn == M) {
+                    mn = 0;
+                    Pn = take_pair(s_state + kSlots, lane);
+                    if (Pn < n_pairs) tn = T0 + 2L * Pn;
+                }
+                request(tn, mn);
+            }
+            BF_FSTAMP(1);
+            cx<double> tw[15];
+            BF_STAGE();
+            load_tw1<1, 9>(tw, s_tw1, lane);
+            BF_STAGE();
+            fft16_core<double, -1, true, 1>(re, im);
+            BF_STAGE();
+            load_tw1<9, 16>(tw, s_tw1, lane);
+            BF_STAGE();
+            mul_tw<false, 1, 9>(re, im, tw);
+            BF_STAGE();
+            mul_tw<false, 9, 16>(re, im, tw);
+            BF_STAGE();
+            BF_FSTAMP(2);
+            T1_fwd(re, im, wcol, row16);
+            BF_FSTAMP(3);
+            load_tw2<1, 9>(tw, s_tw2, lane);
+            BF_STAGE();
+            fft16_core<double, -1, true>(re, im);
+            BF_STAGE();
+            load_tw2<9, 16>(tw, s_tw2, lane);
+            BF_STAGE();
+            mul_tw<false, 1, 9>(re, im, tw);
+            BF_STAGE();
+            mul_tw<false, 9, 16>(re, im, tw);
+            BF_STAGE();
+            BF_FSTAMP(4);
+            w64_T2<true>(re, im);
+            BF_FSTAMP(5);
+            cx<double> g[16];
+            const cx<double> *gd = s_gain + m * kGMic + lane;         // k3 < 2: row (g, k3), column lane
+            const cx<double> *gm = s_gain + m * kGMic + (64 - lane);  // k3 >= 2: row (3 - g, 3 - k3), column 64 - lane, conjugated
+            BF_STAGE();
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                g[r] = (r & 3) < 2 ? gd[(2 * (r >> 2) + (r & 3)) * kGRow] : gm[(2 * (3 - (r >> 2)) + 3 - (r & 3)) * kGRow];
+            BF_STAGE();
+            w64_fwd_p3<double>(re, im);
+            BF_STAGE();
+#pragma unroll
+            for (int r = 8; r < 16; ++r)
+                g[r] = (r & 3) < 2 ? gd[(2 * (r >> 2) + (r & 3)) * kGRow] : gm[(2 * (3 - (r >> 2)) + 3 - (r & 3)) * kGRow];
+            BF_STAGE();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (r == 8) BF_STAGE();
+                const double gx = g[r].x, gy = (r & 3) < 2 ? g[r].y : -g[r].y;
+                if (m == 0) {  // the first microphone starts the sum
+                    Sr[r] = fma(-gy, im[r], gx * re[r]);
+                    Si[r] = fma(gy, re[r], gx * im[r]);
+                } else {
+                    Sr[r] = fma(-gy, im[r], fma(gx, re[r], Sr[r]));
+                    Si[r] = fma(gy, re[r], fma(gx, im[r], Si[r]));
+                }
+            }
+        }
+        BF_STAMP(2 + 3 * it);
+        BF_BSTAMP(0);
+        float *yo = ys + tA * kHop;
+        cx<double> tw[15];
+        BF_STAGE();
+        load_tw2<1, 16>(tw, s_tw2, lane);
+        BF_STAGE();
+        w64_inv_p3<double>(Sr, Si);
+        w64_T2<false>(Sr, Si);
+        BF_BSTAMP(1);
+        BF_STAGE();
+        mul_tw<true, 1, 16>(Sr, Si, tw);
+        BF_STAGE();
+        load_tw1<1, 16>(tw, s_tw1, lane);
+        BF_STAGE();
+        fft16_core<double, +1, false>(Sr, Si);
+        BF_STAGE();
+        BF_BSTAMP(2);
+        T1_inv(Sr, Si, row16, wcol);
+        BF_BSTAMP(3);
+        BF_STAGE();
+        mul_tw<true, 1, 16>(Sr, Si, tw);
+        fft16_core<double, +1, false>(Sr, Si);
+
+        // register j: sample n = 64 j + lane of frame tA (real part) and of frame tA + 1 (imaginary part); util.h:247-252, float stores
+        BF_STAMP(3 + 3 * it);
+        BF_BSTAMP(4);
+        // Overlap-add across wavefronts, first come first served: the hop between two frame pairs is the float sum of the second half of
+        // the earlier pair's last frame and the first half of the later pair's first frame (util.h:302; a + b == b + a bit for bit).
+        // Whichever side gets there first claims the boundary (LDS atomic), parks its half in the output hop itself and publishes it
+        // once the stores are acknowledged; the other side finds the claim, reads the hop back, adds its half and stores the hop for
+        // good.  Nobody waits for anybody's arithmetic -- at most for a store acknowledgement when both arrive within a microsecond.
+        float oA[16], tl[8];
+        if (pair) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f1 = (float)Si[j + 8];
+                tl[j] = (float)((double)f1 * wrow[j + 8]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f1 = (float)Sr[j + 8];
+                tl[j] = (float)((double)f1 * wrow[j + 8]);
+            }
+        }
+        const bool has_t = tL + 1 < T1, has_h = P > 0;  // boundaries P (behind this pair) and P - 1 (in front of it) inside the run
+        float *yn = ys + (tL + 1) * kHop;
+        int oT = -1, oH = -1;                            // what the claim found: 0 = nobody yet
+        if (has_t) {
+            oT = claim_boundary(s_state, P, lane);
+            if (oT == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) yn[(unsigned)(64 * j + lane)] = tl[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float f = (float)Sr[j];               // (float)(Re / N): 1/N is inside the gains
+            oA[j] = (float)((double)f * wrow[j]);       // o *= hann_win[n]
+        }
+        if (pair) {
+            float *y1 = ys + (tA + 1) * kHop;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f0 = (float)Si[j];
+                const float b0 = (float)((double)f0 * wrow[j]);
+                y1[(unsigned)(64 * j + lane)] = oA[j + 8] + b0;  // out_buff[0][j] + out_buff[1][j] as floats (util.h:302), both halves in this lane
+            }
+        }
+        if (has_h) {
+            oH = claim_boundary(s_state, P - 1, lane);
+            if (oH == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) yo[(unsigned)(64 * j + lane)] = oA[j];
+            }
+        } else if (T0 == 0) {  // stream start: the partner is the carried state (out_buff[0] of the previous call)
+            const float *ti = a.tail_in + (long)stream * kHop;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) yo[(unsigned)(64 * j + lane)] = ti[(unsigned)(64 * j + lane)] + oA[j];
+        } else {               // first hop of a run: the previous run adds its half separately, both into a hop zeroed beforehand
+#pragma unroll
+            for (int j = 0; j < 8; ++j) atomicAdd(yo + (unsigned)(64 * j + lane), oA[j]);
+        }
+        if (oT == 0 || oH == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the parked halves have reached L2 (one CU: one L1) before anyone is told
+            if (oT == 0) publish_boundary(s_state, P, lane);
+            if (oH == 0) publish_boundary(s_state, P - 1, lane);
+        }
+        if (oT > 0) {
+            BF_STAT(2);
+            BF_STAT_WAIT_BEGIN;
+            await_boundary(s_state, P);
+            BF_STAT_WAIT_END;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = __builtin_nontemporal_load(yn + (unsigned)(64 * j + lane));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) yn[(unsigned)(64 * j + lane)] = tl[j] + o[j];
+        } else {
+            BF_STAT(0);
+        }
+        if (oH > 0) {
+            BF_STAT(2);
+            BF_STAT_WAIT_BEGIN;
+            await_boundary(s_state, P - 1);
+            BF_STAT_WAIT_END;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = __builtin_nontemporal_load(yo + (unsigned)(64 * j + lane));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) yo[(unsigned)(64 * j + lane)] = o[j] + oA[j];
+        } else {
+            BF_STAT(1);
+        }
+        if (tL == T1 - 1) {
+            if (T1 < a.n_frames) {
+                float *yn = ys + T1 * kHop;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) atomicAdd(yn + (unsigned)(64 * j + lane), tl[j]);
+            } else {
+                float *to = a.tail_out + (long)stream * kHop;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) to[(unsigned)(64 * j + lane)] = tl[j];
+            }
+        }
+        BF_STAMP(4 + 3 * it);
+        BF_BSTAMP(5);
+        P = Pn;
+        ++it;
+    }
+    BF_STATS_FLUSH;
+}
+
 }  // namespace
 
-// frames per run: a multiple of 8 (one step of the block), about one run per CU
+// BF_DAS_F64_PAIR=0: the microphone-pair kernel for planar input too (A/B runs)
+static bool use_pair_kernel(const DasF64Args &a) {
+    static const bool on = !(getenv("BF_DAS_F64_PAIR") && atoi(getenv("BF_DAS_F64_PAIR")) == 0);
+    return on && a.layout == 0 && a.gains_mic != nullptr;
+}
+
+// frames per run: a multiple of one step of the block (8 frames, 16 in the frame-pair kernel), about one run per CU
 static void das_f64_w64_runs(const DasF64Args &a, int n_cus, long *fpc, long *cps) {
+    const long step = use_pair_kernel(a) ? kStepP : kWaves;
     long runs = (long)n_cus / a.n_streams;
     if (runs < 1) runs = 1;
     long f = (a.n_frames + runs - 1) / runs;
-    f = ((f + kWaves - 1) / kWaves) * kWaves;
+    f = ((f + step - 1) / step) * step;
     *fpc = f;
     *cps = (a.n_frames + f - 1) / f;
 }
 
 // the first hop of every run but the first of a stream is completed by atomic adds: zero them on `s` beforehand
 hipError_t prepare_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s) {
-    if (a.n_mics > 8) return hipErrorNotSupported;  // the four pair-gain tables fill the LDS
+    if (a.n_mics > 8) return hipErrorNotSupported;  // the gain tables fill the LDS
     long fpc, cps;
     das_f64_w64_runs(a, n_cus, &fpc, &cps);
     if (cps > 1)
@@ -477,7 +857,9 @@ hipError_t launch_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s) {
     if (a.n_mics > 8) return hipErrorNotSupported;
     long fpc, cps;
     das_f64_w64_runs(a, n_cus, &fpc, &cps);
-    if (a.layout == 0)
+    if (use_pair_kernel(a))
+        hipLaunchKernelGGL(das_f64_pair_kernel, dim3((unsigned)(cps * a.n_streams)), dim3(kBlock), 0, s, a, (int)fpc, (int)cps);
+    else if (a.layout == 0)
         hipLaunchKernelGGL(das_f64_w64_kernel<0>, dim3((unsigned)(cps * a.n_streams)), dim3(kBlock), 0, s, a, (int)fpc, (int)cps);
     else
         hipLaunchKernelGGL(das_f64_w64_kernel<1>, dim3((unsigned)(cps * a.n_streams)), dim3(kBlock), 0, s, a, (int)fpc, (int)cps);
@@ -485,3 +867,14 @@ hipError_t launch_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s) {
 }
 
 }  // namespace bf
+
+#ifdef BF_W64_STATS
+extern "C" int bf_dbg_stats(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bf::g_stats), sizeof(unsigned long long) * 256 * 8 * 5);
+}
+#endif
+#ifdef BF_W64_STAMPS
+extern "C" int bf_dbg_stamps(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bf::g_stamps), sizeof(unsigned long long) * 256 * 8 * 64);
+}
+#endif

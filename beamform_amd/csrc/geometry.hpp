@@ -280,4 +280,22 @@ inline std::vector<f64x2> das_pair_gains_w64_f64(const std::vector<f64x2> &D32, 
     return D;
 }
 
+// Per-microphone Hermitian-part gains of the frame-pair kernel (das_f64_w64.hip das_f64_pair_kernel): ce_m[k] / N for the bins 0 .. 512
+// only (ce_m[N - k] = conj ce_m[k]), [mic][row 2 g + k3, k3 < 2][65]: entry c of row (g, k3) = bin 64 g + 256 k3 + c, c = 0 .. 64.
+constexpr int kDasMicGainRow = 65, kDasMicGainRows = 8;
+inline std::vector<f64x2> das_mic_gains_w64_f64(const SteeringSet &s, int n_mics_alloc) {
+    const int N = s.n_fft, M = s.n_mics;
+    std::vector<f64x2> T((size_t)n_mics_alloc * kDasMicGainRows * kDasMicGainRow, f64x2{0, 0});
+    for (int m = 0; m < M && m < n_mics_alloc; ++m)
+        for (int g = 0; g < 4; ++g)
+            for (int k3 = 0; k3 < 2; ++k3)
+                for (int c = 0; c <= 64; ++c) {
+                    const int k = 64 * g + 256 * k3 + c;
+                    const cplxd c1 = std::conj(s.at(k, m, 0)) / (double)M, c2 = std::conj(s.at((N - k) % N, m, 0)) / (double)M;
+                    const cplxd ce = 0.5 * (c1 + std::conj(c2)) / (double)N;
+                    T[((size_t)m * kDasMicGainRows + 2 * g + k3) * kDasMicGainRow + c] = f64x2{ce.real(), ce.imag()};
+                }
+    return T;
+}
+
 }  // namespace bf

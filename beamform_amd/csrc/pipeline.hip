@@ -112,6 +112,7 @@ class BinPipelineImpl : public BinPipeline {
         if (das_one_launch_shape()) {
             for (int i = 0; i < 2; ++i) PIPE_HIP(hipMalloc((void **)&d_dasg_[i], (size_t)4 * 1024 * sizeof(f64x2)));
             for (int i = 0; i < 2; ++i) PIPE_HIP(hipMalloc((void **)&d_dasg_w64_[i], (size_t)4 * 1024 * sizeof(f64x2)));
+            for (int i = 0; i < 2; ++i) PIPE_HIP(hipMalloc((void **)&d_dasg_mic_[i], (size_t)8 * kDasMicGainRows * kDasMicGainRow * sizeof(f64x2)));
             const std::vector<f64x2> tw64 = twiddle_table_w64_rot();
             PIPE_HIP(hipMalloc((void **)&d_tw_w64_, tw64.size() * sizeof(f64x2)));
             PIPE_HIP(hipMemcpy(d_tw_w64_, tw64.data(), tw64.size() * sizeof(f64x2), hipMemcpyHostToDevice));
@@ -159,12 +160,14 @@ class BinPipelineImpl : public BinPipeline {
                         t[(((size_t)d * nc + c) * M_ + m) * N_ + j] = f64x2{w.real(), w.imag()};
                     }
         const int nxt = steer_cur_ ^ 1;
-        std::vector<f64x2> dg, dg64;  // das fp64 in one launch: the pair gains of the (single) look direction, same double buffering
+        std::vector<f64x2> dg, dg64, dgm;  // das fp64 in one launch: the pair gains of the (single) look direction, same double buffering
         if (das_one_launch_shape()) {
             dg = das_pair_gains_t<f64x2>(dirs[0], 4);
             dg64 = das_pair_gains_w64_f64(dg, 4);
             PIPE_HIP(hipMemcpyAsync(d_dasg_[nxt], dg.data(), dg.size() * sizeof(f64x2), hipMemcpyHostToDevice, stream));
             PIPE_HIP(hipMemcpyAsync(d_dasg_w64_[nxt], dg64.data(), dg64.size() * sizeof(f64x2), hipMemcpyHostToDevice, stream));
+            dgm = das_mic_gains_w64_f64(dirs[0], 8);
+            PIPE_HIP(hipMemcpyAsync(d_dasg_mic_[nxt], dgm.data(), dgm.size() * sizeof(f64x2), hipMemcpyHostToDevice, stream));
         }
         PIPE_HIP(hipMemcpyAsync(d_steer_[nxt], t.data(), t.size() * sizeof(f64x2), hipMemcpyHostToDevice, stream));
         PIPE_HIP(hipStreamSynchronize(stream));  // `t` is pageable and about to go out of scope
@@ -187,6 +190,7 @@ class BinPipelineImpl : public BinPipeline {
         sn.steer_dir_stride = steer_dir_stride_;
         sn.das_gains = d_dasg_[steer_cur_];
         sn.das_gains_w64 = d_dasg_w64_[steer_cur_];
+        sn.das_gains_mic = d_dasg_mic_[steer_cur_];
         gss_reset_mask_ = 0;
         return sn;
     }
@@ -248,7 +252,7 @@ class BinPipelineImpl : public BinPipeline {
     }
 
     void free_all() {
-        void *ptrs[] = {d_dasg_[0], d_dasg_[1], d_dasg_w64_[0], d_dasg_w64_[1], d_tw_w64_, d_tw32_, d_tw_, d_win_, d_freq_, d_steer_[0], d_steer_[1], d_hist_, d_tail_[0], d_tail_[1], d_zhist_,
+        void *ptrs[] = {d_dasg_[0], d_dasg_[1], d_dasg_w64_[0], d_dasg_w64_[1], d_dasg_mic_[0], d_dasg_mic_[1], d_tw_w64_, d_tw32_, d_tw_, d_win_, d_freq_, d_steer_[0], d_steer_[1], d_hist_, d_tail_[0], d_tail_[1], d_zhist_,
                         d_gssW_, d_mpf_, d_smooth_, d_nlms_, d_Z_, d_Yh_, d_yraw_, d_frames_};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
@@ -269,6 +273,7 @@ class BinPipelineImpl : public BinPipeline {
     f64x2 *d_dasg_[2] = {nullptr, nullptr};  // das_pair_gains_t<f64x2> of look direction 0 (das_one_launch_shape)
     f64x2 *d_dasg_w64_[2] = {nullptr, nullptr};  // das_pair_gains_w64_f64 of the same
     f64x2 *d_tw_w64_ = nullptr;                  // twiddle_table_w64_rot
+    f64x2 *d_dasg_mic_[2] = {nullptr, nullptr};  // das_mic_gains_w64_f64 (frame-pair kernel)
     int steer_cur_ = 0;
     float *d_hist_ = nullptr;
     float *d_tail_[2] = {nullptr, nullptr};
@@ -308,7 +313,7 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
         da.stream_stride_x = (long)M_ * F * H_; da.n_streams = S_; da.n_mics = M_; da.run_len = 1;
         // BF_DAS_F64_W64=0: the 32 x 32 half-wavefront kernel (das_f64_fused_kernel) instead of the 64-lane one
         da.layout = layout;
-        if (w64 && snap.das_gains_w64 != nullptr) { da.gains = snap.das_gains_w64; da.tw = d_tw_w64_; }
+        if (w64 && snap.das_gains_w64 != nullptr) { da.gains = snap.das_gains_w64; da.gains_mic = snap.das_gains_mic; da.tw = d_tw_w64_; }
         const bool use_w64 = w64 && snap.das_gains_w64 != nullptr;
         hipError_t de = use_w64 ? prepare_das_f64_w64(da, n_cus_, stream) : hipSuccess;
         if (de == hipSuccess) {

@@ -112,6 +112,7 @@ struct DasF64Args {
     long n_frames, mic_stride, stream_stride_x;
     int n_streams, n_mics, run_len;
     int layout = 0;        // bf_layout of x and hist; 1 (interleaved) only with launch_das_f64_w64
+    const f64x2 *gains_mic = nullptr;  // das_mic_gains_w64_f64: per-microphone Hermitian gains of the frame-pair kernel (planar input)
 };
 
 // the same node on one full wavefront per frame (das_f64_w64.hip; N = 1024 only): `gains` = das_pair_gains_w64_f64, `tw` =

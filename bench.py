@@ -7,7 +7,7 @@ already resident in HBM.
 
 N = 1 (default): BASELINE.json configs[1] -- das, 8 mics, 1024-pt FFT / hop 512, one
 65 536-frame batch, computed in DOUBLE like the reference (das.cpp:16-24: std::complex<double>, FFTW double plans):
-das_f64_w64_kernel.  `extra` carries the fused fp32 kernel on the same batch (`das_f32`, with its own roofline
+das_f64_pair_kernel (das_f64_w64.hip).  `extra` carries the fused fp32 kernel on the same batch (`das_f32`, with its own roofline
 block; --das-f32 makes it the headline) and one line per other BASELINE config (mvdr 8-mic, phasempf 256 x 256,
 lcmv 16-mic K = 3 per-GPU shard).
 
@@ -394,7 +394,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          # PMC traffic exists for the profiled workloads only (profiles/traffic_<tag>.json)
                          "traffic": load_traffic(tag) if (n_feed == 65536 and S == 1 and args.layout == "planar") else None,
-                         "kernel": ("das_fused_kernel" if das_impl == BF_DAS_FUSED_F32 else "das_f64_w64_kernel") if args.algo == "das"
+                         "kernel": ("das_fused_kernel" if das_impl == BF_DAS_FUSED_F32 else ("das_f64_pair_kernel" if args.layout == "planar" else "das_f64_w64_kernel<1>")) if args.algo == "das"
                                    else "bin pipeline (stft + per-bin kernel + istft)",
                          "kernel_ms": k_ms, "call_ms": ms_call, "kernel_launches_timed": n_timed_launches,
                          "kernel_ms_source": "one HIP event pair per launch on the launch stream, inside the K timed steps",
@@ -512,8 +512,8 @@ def main():
                                 note="the headline batch through the fused fp32 kernel (das_fused_kernel): meets north_star's 1e-5 (1.5e-7 observed) but "
                                      "computes in single precision where the reference computes in double"))
              if das_impl == BF_DAS_BINS_F64 else
-             (lambda: node_line("das", M, F, 1, das_impl_=BF_DAS_BINS_F64, xin=x, iters=20, roofline_kernel="das_f64_w64_kernel", traffic_tag="das8_f64",
-                                note="same precision as the reference: das_f64_w64_kernel, one launch"))),
+             (lambda: node_line("das", M, F, 1, das_impl_=BF_DAS_BINS_F64, xin=x, iters=20, roofline_kernel="das_f64_pair_kernel", traffic_tag="das8_f64",
+                                note="same precision as the reference: das_f64_pair_kernel, one launch"))),
             ("das_interleaved", lambda: node_line("das", M, F, 1, xin=x.reshape(1, F * HOP, M), layout_=BF_INTERLEAVED, iters=20,
                                                   note="the headline workload with [sample][mic] input (same bytes read as interleaved samples), fused fp32 kernel")),
             ("das_f64_interleaved", lambda: node_line("das", M, F, 1, das_impl_=BF_DAS_BINS_F64, xin=x.reshape(1, F * HOP, M), layout_=BF_INTERLEAVED,

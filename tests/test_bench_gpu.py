@@ -32,7 +32,7 @@ def _check_line(d, n, dtype="f64"):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
-    assert r["kernel"] == ("das_f64_w64_kernel" if dtype == "f64" else "das_fused_kernel")
+    assert r["kernel"] == ("das_f64_pair_kernel" if dtype == "f64" else "das_fused_kernel")
     assert 0 < r["kernel_ms"] <= d["ms_per_step"] and r["kernel_launches_timed"] == 3   # event pairs inside the timed steps
     assert abs(d["value"] - n * 4096 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
 

@@ -103,6 +103,12 @@ def test_fused_is_bit_identical_to_the_two_kernel_chain(tmp_path):
             assert d <= 2e-7 * np.abs(res["0"][k]).max(), (k, d)
 
 
+def same_floats(a, b):
+    """Equal up to the rounding of the float stores (a few ulp of the signal's scale): two evaluation orders of the same double sums."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return a.shape == b.shape and np.abs(a - b).max() <= 4e-7 * max(np.abs(b).max(), 1e-30)
+
+
 @pytest.mark.parametrize("M,F,S", [(8, 33, 1), (7, 5, 1), (5, 18, 2), (4, 27, 1), (3, 9, 3), (2, 40, 1), (1, 6, 1), (8, 1, 1), (6, 700, 1)])
 def test_das_f64_one_launch_matches_oracle(M, F, S):
     """das_f64_fused_kernel (BF_DAS_BINS_F64 without a spectrum dump, planar input): the time output against the oracle, odd
@@ -116,21 +122,23 @@ def test_das_f64_one_launch_matches_oracle(M, F, S):
     for s in range(S):
         y_ref, _ = oracle.OracleNode(p).process(xs[s])
         assert rel_l2(y[s], y_ref) < 1e-6       # double arithmetic up to the float stores: far inside the 1e-5 budget
-    # [sample][mic] input (the layout north_star names): the same arithmetic on the same samples, bit for bit
+    # [sample][mic] input (the layout north_star names).  The planar kernel (das_f64_pair_kernel) transforms two consecutive frames of a
+    # microphone per complex FFT, the interleaved one (das_f64_w64_kernel<1>) two microphones of a frame: the same sums in double, rounded
+    # differently at 1e-16 -- equal up to the last bit of the float stores, not bit for bit
     from beamform_amd.capi import BF_INTERLEAVED
     xi = np.ascontiguousarray(xs.transpose(0, 2, 1))
     yi = Beamformer(p, n_streams=S, das_impl=BF_DAS_BINS_F64, layout=BF_INTERLEAVED).process(xi if S > 1 else xi[0]).reshape(S, -1)
-    assert np.array_equal(yi, y)
+    assert same_floats(yi, y)
     if S == 1 and F >= 9:
         bi = Beamformer(p, das_impl=BF_DAS_BINS_F64, layout=BF_INTERLEAVED)   # carried hop in the interleaved layout across batch cuts
         cuts = [0, 2, F // 2, F]
         parts = [bi.process(np.ascontiguousarray(xi[0][a * 512:b * 512])) for a, b in zip(cuts[:-1], cuts[1:])]
-        assert np.array_equal(np.concatenate(parts), y[0])
+        assert np.array_equal(np.concatenate(parts), yi[0])   # one frame per transform there: bit for bit whatever the cuts
     if S == 1 and F >= 9:
         bf2 = Beamformer(p, das_impl=BF_DAS_BINS_F64)
         cuts = [0, 1, 4, F // 2, F]
         parts = [bf2.process(np.ascontiguousarray(xs[0][:, a * 512:b * 512])) for a, b in zip(cuts[:-1], cuts[1:])]
-        assert np.array_equal(np.concatenate(parts), y[0])   # state (ring hop, tail) carries exactly
+        assert same_floats(np.concatenate(parts), y[0])   # state (ring hop, tail) carries; which frames share a transform depends on the cuts
 
 
 def test_das_f64_one_launch_streaming_callbacks():
@@ -142,7 +150,7 @@ def test_das_f64_one_launch_streaming_callbacks():
     whole = Beamformer(p, das_impl=BF_DAS_BINS_F64).process(x)
     bf = Beamformer(p, das_impl=BF_DAS_BINS_F64)
     hops = [bf.process_hop(np.ascontiguousarray(x[:, t * 512:(t + 1) * 512])) for t in range(F)]
-    assert np.array_equal(np.concatenate([np.asarray(h).reshape(-1) for h in hops]), whole)
+    assert same_floats(np.concatenate([np.asarray(h).reshape(-1) for h in hops]), whole)   # a callback is a lone frame, the batch pairs them
 
 
 CHILD_FULL = r"""

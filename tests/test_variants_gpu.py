@@ -126,3 +126,55 @@ def test_z48_against_full_double_spectra_on_an_ill_conditioned_scene(tmp_path):
     fin = np.isfinite(Ys["0"]).all(axis=1)
     d = max(np.linalg.norm(Ys["1"][t] - Ys["0"][t]) / np.linalg.norm(Ys["0"][t]) for t in range(len(fin)) if fin[t] and np.abs(Ys["0"][t]).max() > 0)
     assert d < 1e-6, d          # 2^-37 on X times the condition number
+
+
+CHILD_F64 = r"""
+import sys, json, numpy as np
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r + "/tests")
+import oracle
+from beamform_amd.capi import BF_DAS_BINS_F64, BF_INTERLEAVED, Beamformer
+from beamform_amd.params import make_params
+from beamform_amd.synth import make_scene
+from conftest import rel_l2
+res = {}
+for M, F in ((8, 700), (5, 37), (8, 1)):
+    p = make_params("das", n_mics=M, theta=-25.0)
+    x = make_scene(M, F, seed=640 + M)
+    ref, _ = oracle.OracleNode(p).process(x)
+    res[f"planar{M}x{F}"] = rel_l2(Beamformer(p, das_impl=BF_DAS_BINS_F64).process(x), ref)
+    res[f"interleaved{M}x{F}"] = rel_l2(Beamformer(p, das_impl=BF_DAS_BINS_F64, layout=BF_INTERLEAVED).process(np.ascontiguousarray(x.T)), ref)
+print("RESULT " + json.dumps(res))
+"""
+
+
+@pytest.mark.parametrize("env", [{}, {"BF_DAS_F64_PAIR": "0"}, {"BF_DAS_F64_W64": "0"}], ids=["default", "BF_DAS_F64_PAIR=0", "BF_DAS_F64_W64=0"])
+def test_das_in_double_every_one_launch_kernel(env):
+    """das at the reference's precision without a spectrum dump: das_f64_pair_kernel (planar, the default), das_f64_w64_kernel
+    (BF_DAS_F64_PAIR=0; the interleaved layout always) and das_f64_fused_kernel (BF_DAS_F64_W64=0) against the oracle -- a batch that
+    is cut into runs, an odd microphone count with an odd number of frames, one lone frame."""
+    out = subprocess.run([sys.executable, "-c", CHILD_F64 % dict(root=ROOT)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
+    assert len(res) == 6 and max(res.values()) < 1e-6, res
+
+
+def test_bfcore_before_torch_shares_one_hip_runtime():
+    """libbfcore.so loaded and used BEFORE torch is imported: capi.load() brings in torch's libamdhip64 first, so the later
+    `import torch` finds the device (two HIP runtimes in one process: the second reports hipErrorNoDevice)."""
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from beamform_amd.capi import Beamformer
+from beamform_amd.params import make_params
+from beamform_amd.synth import make_scene
+assert "torch" not in sys.modules
+y = Beamformer(make_params("das", n_mics=4)).process(make_scene(4, 8, seed=1))
+import torch
+g = torch.Generator(device="cuda").manual_seed(1)
+x = torch.rand(16, device="cuda", generator=g)
+print("OK", y.shape, float(x.sum()) > 0)
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]

@@ -25,7 +25,7 @@ run() {  # name, step kernel, run_das args...
   for f in $(find gpurun_out/${tag}_${name}_trace -name "*kernel_stats*"); do cp $f gpurun_out/${tag}_${name}_kernel_stats.csv; done
   tail -1 gpurun_out/${tag}_${name}.log
 }
-run das8_f64 das_f64_w64 --algo das --das-f64
+run das8_f64 das_f64_pair --algo das --das-f64
 run das8 das_fused --algo das
 run mvdr8 stft_kernel --algo mvdr
 run phase8 stft_bins_fused --algo phase
