@@ -2,6 +2,9 @@
 #include <cstdlib>
 
 #include "bins_common.hpp"
+#if BF_NFFT == 1024
+#include "w64_f64_dev.hpp"
+#endif
 
 namespace bf {
 namespace BF_NTAG {
@@ -600,6 +603,215 @@ __global__ __launch_bounds__(256, 1) void stft_bins_fused_kernel(StftArgs a, Bin
     }
 }
 
+// The same node on the 64-lane x 16-point transform (fft1024_w64.hpp, w64_f64_dev.hpp) with no block barrier in the loop: a 512-thread
+// block is 8 / NPc TEAMS of NPc wavefronts; a team owns one frame at a time -- one full wavefront per microphone pair transforms it into
+// the team's LDS slots (64 data registers per lane instead of 128: two wavefronts per SIMD), a team barrier (LDS counter), the team's
+// threads run the per-bin stage of that frame out of LDS (the code above, bit-identical per bin; the transform's rounding differs from
+// the 32 x 32 one at 1e-16), another team barrier.  Teams take frames from an LDS counter and drift apart, so one team's global loads and
+// LDS round trips are covered by the others' arithmetic, and the wavefronts that win the issue arbitration of their SIMD (the older
+// ones: das_f64_w64.hip) simply take more frames.  The exchange plane of a transform (16 x 65 doubles) lies inside the 16 KB slot that
+// receives its spectrum; spectra are stored in natural bin order.  LDS: 17 KB twiddles + 128 KB slots + 9 KB window rows + counters.
+typedef volatile __attribute__((address_space(3))) int *lds_cnt_t;
+__device__ __forceinline__ int lds_cnt_add(lds_cnt_t p, int lane) {
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add((__attribute__((address_space(3))) int *)p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __builtin_amdgcn_readfirstlane(old);
+}
+// all NPc wavefronts of a team arrive; LDS operations of a wavefront complete in issue order, so what it wrote before arriving is there
+__device__ __forceinline__ void team_barrier(lds_cnt_t cnt, int target, int lane) {
+    asm volatile("" ::: "memory");
+    (void)lds_cnt_add(cnt, lane);
+    while (*cnt < target) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+
+template <int LAYOUT, int MP, int ALGO>
+__global__ __launch_bounds__(512) void stft_bins_w64_kernel(StftArgs a, BinsArgs b, long frames_per_block, long total_frames, double *aux,
+                                                            f64x2 *xtail) {
+    constexpr int NPc = MP / 2;            // wavefronts per team = pair slots per frame
+    constexpr int NT = 8 / NPc;            // teams per block
+    constexpr int TT = 64 * NPc;           // threads per team
+    constexpr int kQMain = kN / 2;
+    constexpr int NIT = kQMain / TT;       // (frame, bin) items per thread
+    constexpr int kTwD = 2 * (1024 + 4 * kTw2RowW64Rot);
+    constexpr int kWinRow = 18;            // [lane][j] rows of 16 doubles + 2 (das_f64_w64.hip)
+    constexpr int oWin = kTwD + 8 * 2048, oCnt = oWin + 64 * kWinRow;
+    __shared__ __attribute__((aligned(16))) double lds[oCnt + 10];  // 1 + 2 NT <= 17 counters
+    const cx<double> *s_tw1 = reinterpret_cast<const cx<double> *>(lds);
+    const cx<double> *s_tw2 = s_tw1 + 1024;
+    lds_cnt_t s_next = (lds_cnt_t)(lds + oCnt);  // next frame of the block; then one arrival counter per team
+    lds_cnt_t s_arr = s_next + 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int team = w / NPc, p = w % NPc, tt = tid - team * TT;  // thread index inside the team
+    double *slot = lds + kTwD + w * 2048;  // this wavefront's spectrum [1024] c128; its head is the exchange plane while it transforms
+    double *wcol = slot + w64_col_rot(lane);
+    double *row16 = slot + (lane & 15) * kRS + 16 * (lane >> 4);
+    const double *wrow = lds + oWin + lane * kWinRow;  // window[64 j + lane], j = 0..15
+    {
+        const f64x2 *tw2 = a.tw_w64;
+        f64x2 *ltw = reinterpret_cast<f64x2 *>(lds);
+        for (int i = tid; i < kTwD / 2; i += 512) ltw[i] = tw2[i];
+        for (int i = tid; i < kN; i += 512) lds[oWin + (i & 63) * kWinRow + (i >> 6)] = a.win[i];
+        if (tid <= NT) s_next[tid] = tid == 0 ? NT : 0;  // the first NT frames are handed out statically
+    }
+    const int M = a.n_mics, NP = (M + 1) >> 1;
+    const bool has_pair = p < NP;
+    const long gf0 = (long)blockIdx.x * frames_per_block;  // frames are numbered stream * n_frames + frame
+    long gf1 = gf0 + frames_per_block;
+    if (gf1 > total_frames) gf1 = total_frames;
+    const int n_local = (int)(gf1 - gf0);
+
+    float na[16], nb[16];  // raw samples of this wavefront's pair of the team's next frame: register j <- sample 64 j + lane of (hop t - 1 | hop t)
+    auto request = [&](int lf) {
+        const long gf = gf0 + lf;
+        const int s = (int)(gf / a.n_frames);
+        const long t = gf - (long)s * a.n_frames;
+        if (!has_pair) return;
+        const float *xs = a.x + (long)s * a.stream_stride_x;
+        const float *hs = a.hist + (long)s * M * kHop;
+        const int ma = 2 * p;
+        const int mb = (2 * p + 1 < M) ? 2 * p + 1 : ma;
+        if (LAYOUT == 0) {
+            const float *a1 = t >= 1 ? xs + (long)ma * a.mic_stride + (t - 1) * kHop : hs + ma * kHop;
+            const float *b1 = t >= 1 ? xs + (long)mb * a.mic_stride + (t - 1) * kHop : hs + mb * kHop;
+            const float *a2 = xs + (long)ma * a.mic_stride + t * kHop;
+            const float *b2 = xs + (long)mb * a.mic_stride + t * kHop;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                na[j] = a1[(unsigned)(64 * j + lane)];
+                nb[j] = b1[(unsigned)(64 * j + lane)];
+                na[j + 8] = a2[(unsigned)(64 * j + lane)];
+                nb[j + 8] = b2[(unsigned)(64 * j + lane)];
+            }
+        } else {
+            const float *s1 = t >= 1 ? xs + (t - 1) * (long)kHop * M : hs;
+            const float *s2 = xs + t * (long)kHop * M;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                na[j] = s1[(unsigned)((64 * j + lane) * M + ma)];
+                nb[j] = s1[(unsigned)((64 * j + lane) * M + mb)];
+                na[j + 8] = s2[(unsigned)((64 * j + lane) * M + ma)];
+                nb[j + 8] = s2[(unsigned)((64 * j + lane) * M + mb)];
+            }
+        }
+    };
+    int lf = team;  // the team's frame (local index); every wavefront of the team follows the same sequence
+    if (lf < n_local) request(lf);
+    __syncthreads();  // twiddles, window, counters
+    int arrivals = 0;
+    lds_cnt_t my_arr = s_arr + team;
+    lds_cnt_t my_nxt = s_arr + NT + team;  // the team's next frame, published by its first wavefront
+    while (lf < n_local) {
+        const long gf = gf0 + lf;
+        const int s = (int)(gf / a.n_frames);
+        const long t = gf - (long)s * a.n_frames;
+        // ---- pass 1: window + forward FFT of (frame, pair p) into this wavefront's slot -------------------------------------------
+        if (has_pair) {
+            double re[16], im[16];
+            const bool b_ok = 2 * p + 1 < M;
+            // buf[j]*hann_win[i] (util.h:235) and the first butterfly stage of the transform in one (das_f64_w64.hip)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double w0 = wrow[j], w1 = wrow[j + 8];
+                const double t0 = (double)na[j] * w0, u = (double)na[j + 8];
+                re[j] = fma(u, w1, t0);
+                re[j + 8] = fma(-u, w1, t0);
+            }
+            if (b_ok) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double w0 = wrow[j], w1 = wrow[j + 8];
+                    const double t0 = (double)nb[j] * w0, u = (double)nb[j + 8];
+                    im[j] = fma(u, w1, t0);
+                    im[j + 8] = fma(-u, w1, t0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) im[j] = 0.0;
+            }
+            cx<double> tw[15];
+            BF_STAGE();
+            load_tw1<1, 9>(tw, s_tw1, lane);
+            BF_STAGE();
+            fft16_core<double, -1, true, 1>(re, im);  // stage 0 is done
+            BF_STAGE();
+            load_tw1<9, 16>(tw, s_tw1, lane);
+            BF_STAGE();
+            mul_tw<false, 1, 9>(re, im, tw);
+            BF_STAGE();
+            mul_tw<false, 9, 16>(re, im, tw);
+            BF_STAGE();
+            T1_fwd(re, im, wcol, row16);
+            load_tw2<1, 9>(tw, s_tw2, lane);
+            BF_STAGE();
+            fft16_core<double, -1, true>(re, im);
+            BF_STAGE();
+            load_tw2<9, 16>(tw, s_tw2, lane);
+            BF_STAGE();
+            mul_tw<false, 1, 9>(re, im, tw);
+            BF_STAGE();
+            mul_tw<false, 9, 16>(re, im, tw);
+            BF_STAGE();
+            w64_T2<true>(re, im);
+            w64_fwd_p3<double>(re, im);
+            // register 4 g + k3 of lane l holds bin l + 64 g + 256 k3: natural order in the slot, one contiguous 1 KB row per store
+            f64x2 *zo = reinterpret_cast<f64x2 *>(slot) + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zo[64 * (r >> 2) + 256 * (r & 3)] = f64x2{re[r], im[r]};
+        }
+        // the team's next frame: taken by its first wavefront, read by the others behind the barrier
+        if (p == 0) {
+            const int nx = lds_cnt_add(s_next, lane);
+            if (lane == 0) *my_nxt = nx;
+        }
+        arrivals += NPc;
+        team_barrier(my_arr, arrivals, lane);
+        const int lf_next = __builtin_amdgcn_readfirstlane(*my_nxt);
+        if (lf_next < n_local) request(lf_next);  // lands while the per-bin pass runs
+        // ---- pass 2: the per-bin stage of the frame, spectra read back from LDS -------------------------------------------------
+        const f64x2 *zs = reinterpret_cast<const f64x2 *>(lds + kTwD) + (long)team * NPc * kN;
+#pragma nounroll  // one item's registers at a time (two interleaved items spill 28 registers in the phasempf build)
+        for (int n = 0; n < NIT; ++n) {
+            const int q = tt + TT * n, j = q_bin(q);
+            cd wst[MP];
+            load_steer<MP>(b.steer, j, M, wst);  // from L1 / L2, in flight while the spectra come out of LDS
+            cd X[MP];
+            load_X<MP>(zs, q, M, X);
+            const long o = ((long)s * b.n_frames + t) * kYhStride + q;
+            if (ALGO == BF_DAS) {
+                const cd y = das_core<MP>(X, wst, M);
+                st_y(b, o, q, y);
+            } else if (ALGO == BF_PHASE) {
+                const cd y = phase_core<MP>(X, wst, M, j, b.cfg);
+                st_y(b, o, q, y);
+            } else {  // phasempf mask
+                if (j == 0) {
+                    b.Yh[o] = f64x2{X[0].x, X[0].y};
+                    aux[o] = 0.0;
+                } else {
+                    cd soi;
+                    double int2;
+                    mpf_mask_core<MP>(X, wst, M, b.cfg, soi, int2);
+                    b.Yh[o] = f64x2{soi.x, soi.y};
+                    aux[o] = int2;
+                }
+            }
+        }
+        if (tt < 2) {  // bins N/2 and N/2+1 of the frame: X only (fused_tail_kernel finishes them)
+            const int q = kQMain + tt;
+            cd X[MP];
+            load_X<MP>(zs, q, M, X);
+            f64x2 *xt = xtail + (((long)s * b.n_frames + t) * 2 + tt) * MP;
+#pragma unroll
+            for (int m = 0; m < MP; ++m) xt[m] = f64x2{X[m].x, X[m].y};
+        }
+        arrivals += NPc;
+        team_barrier(my_arr, arrivals, lane);  // the slots are rewritten by the next frame
+        lf = lf_next;
+    }
+}
+
 // the two deferred problems per frame of stft_bins_fused_kernel: one thread per (stream, frame, q in {N/2, N/2+1})
 template <int MP, int ALGO>
 __global__ __launch_bounds__(256) void fused_tail_kernel(BinsArgs b, const f64x2 *xtail, double *aux) {
@@ -650,10 +862,22 @@ hipError_t launch_stft_bins_fused(const StftArgs &a, const BinsArgs &b, int n_cu
     if (!xtail) return hipErrorInvalidValue;
     const long tail_items = (long)b.n_streams * b.n_frames * 2;
     const unsigned tail_blocks = (unsigned)((tail_items + 255) / 256);
+    // BF_BINS_W64=0: the half-wavefront (32 x 32) version, one wavefront per SIMD
+    static const bool w64_on = !(getenv("BF_BINS_W64") && atoi(getenv("BF_BINS_W64")) == 0);
+    const bool w64 = w64_on && a.tw_w64 != nullptr;
+    const long wtotal = a.n_frames * a.n_streams;  // frames, numbered stream * n_frames + frame; one contiguous range per block
+    long wblocks = wtotal < n_cus ? wtotal : n_cus;
+    if (wblocks < 1) wblocks = 1;
+    const long wfpb = (wtotal + wblocks - 1) / wblocks;
+    wblocks = (wtotal + wfpb - 1) / wfpb;
 #define BF_FUSED_GO(L_, MP_, A_)                                                                                             \
     do {                                                                                                                      \
-        hipLaunchKernelGGL((stft_bins_fused_kernel<L_, MP_, A_>), dim3((unsigned)blocks), dim3(256), 0, s, a, b, gps, total, gpb, \
-                           aux, xtail);                                                                                       \
+        if (w64)                                                                                                              \
+            hipLaunchKernelGGL((stft_bins_w64_kernel<L_, MP_, A_>), dim3((unsigned)wblocks), dim3(512), 0, s, a, b, wfpb, wtotal, aux, \
+                               xtail);                                                                                        \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((stft_bins_fused_kernel<L_, MP_, A_>), dim3((unsigned)blocks), dim3(256), 0, s, a, b, gps, total, gpb, \
+                               aux, xtail);                                                                                   \
         hipLaunchKernelGGL((fused_tail_kernel<MP_, A_>), dim3(tail_blocks), dim3(256), 0, s, b, (const f64x2 *)xtail, aux);   \
     } while (0)
 #define BF_FUSED_ALGO(L_, MP_)                                   \

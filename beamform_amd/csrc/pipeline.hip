@@ -113,6 +113,8 @@ class BinPipelineImpl : public BinPipeline {
             for (int i = 0; i < 2; ++i) PIPE_HIP(hipMalloc((void **)&d_dasg_[i], (size_t)4 * 1024 * sizeof(f64x2)));
             for (int i = 0; i < 2; ++i) PIPE_HIP(hipMalloc((void **)&d_dasg_w64_[i], (size_t)4 * 1024 * sizeof(f64x2)));
             for (int i = 0; i < 2; ++i) PIPE_HIP(hipMalloc((void **)&d_dasg_mic_[i], (size_t)8 * kDasMicGainRows * kDasMicGainRow * sizeof(f64x2)));
+        }
+        if (N_ == 1024) {
             const std::vector<f64x2> tw64 = twiddle_table_w64_rot();
             PIPE_HIP(hipMalloc((void **)&d_tw_w64_, tw64.size() * sizeof(f64x2)));
             PIPE_HIP(hipMemcpy(d_tw_w64_, tw64.data(), tw64.size() * sizeof(f64x2), hipMemcpyHostToDevice));
@@ -376,7 +378,7 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     sa.n_frames = F; sa.frames_ws = FT; sa.frame_off = Phist_; sa.mic_stride = mic_stride;
     sa.stream_stride_x = (long)M_ * F * H_; sa.n_streams = S_; sa.n_mics = M_; sa.n_fft_mics = MF_; sa.layout = layout;
     sa.skip_lo = N_; sa.skip_hi = 0;  // store everything ...
-    sa.z48 = z48_ ? 1 : 0; sa.run_len = 1;
+    sa.z48 = z48_ ? 1 : 0; sa.run_len = 1; sa.tw_w64 = d_tw_w64_;
     if (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS) {
         // ... except, for the band-limited nodes, the bins between the highest in-band bin k and its mirror N-k
         // (quirk Q1 makes bins 511..513 irregular: only skip when the band ends below them)

@@ -58,6 +58,7 @@ struct StftArgs {
     int skip_lo, skip_hi;  // packed-spectrum bins in (skip_lo, skip_hi) are never read by the per-bin kernel: not stored
     int z48;               // store z48 elements (mvdr / lcmv)
     int run_len;           // consecutive frames one half-wavefront walks (N = 1024): the shared hop stays in registers
+    const f64x2 *tw_w64 = nullptr;  // twiddle_table_w64_rot (N = 1024): stft_bins_w64_kernel
 };
 
 struct BinsArgs {

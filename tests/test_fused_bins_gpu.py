@@ -87,20 +87,26 @@ np.savez(sys.argv[1], **out)
 
 def test_fused_is_bit_identical_to_the_two_kernel_chain(tmp_path):
     """BF_FUSED_BINS=2 (stft + per-bin stage in one kernel, spectra in LDS; the default for phase / phasempf, for das only when
-    the one-launch kernel is switched off) against =0 (two kernels, spectra in HBM): the same arithmetic, bit for bit.  The default
-    (=1) differs from both for das only -- das_f64_fused_kernel, checked against the oracle below -- and from neither for the masks."""
+    the one-launch kernel is switched off) against =0 (two kernels, spectra in HBM).  With BF_BINS_W64=0 both run the 32 x 32
+    transform: the same arithmetic, bit for bit.  The default fused kernel (stft_bins_w64_kernel) runs the 64-lane transform, whose
+    rounding differs at 1e-16: equal up to the last bit of the float output.  BF_FUSED_BINS=1 differs for das only (the one-launch
+    kernels, checked against the oracle below)."""
     res = {}
-    for mode in ("2", "0", "1"):
-        f = str(tmp_path / f"out{mode}.npz")
-        subprocess.check_call([sys.executable, "-c", CHILD % ROOT, f], env=dict(os.environ, BF_FUSED_BINS=mode))
-        res[mode] = np.load(f)
+    for tag, env in (("2", dict(BF_FUSED_BINS="2", BF_BINS_W64="0")), ("0", dict(BF_FUSED_BINS="0")), ("1", dict(BF_FUSED_BINS="1", BF_BINS_W64="0")),
+                     ("w2", dict(BF_FUSED_BINS="2")), ("w1", dict(BF_FUSED_BINS="1"))):
+        f = str(tmp_path / f"out{tag}.npz")
+        subprocess.check_call([sys.executable, "-c", CHILD % ROOT, f], env=dict(os.environ, **env))
+        res[tag] = np.load(f)
     for k in res["2"].files:
         assert np.array_equal(res["2"][k], res["0"][k]), k
+        assert same_floats(res["w2"][k], res["0"][k]), k
         if not k.startswith("das"):
             assert np.array_equal(res["1"][k], res["0"][k]), k
+            assert np.array_equal(res["w1"][k], res["w2"][k]), k
         else:
-            d = np.abs(res["1"][k].astype(np.float64) - res["0"][k]).max()
-            assert d <= 2e-7 * np.abs(res["0"][k]).max(), (k, d)
+            for tag in ("1", "w1"):
+                d = np.abs(res[tag][k].astype(np.float64) - res["0"][k]).max()
+                assert d <= 2e-7 * np.abs(res["0"][k]).max(), (k, d)
 
 
 def same_floats(a, b):
@@ -168,19 +174,26 @@ for algo in ("das", "phase"):
     bf.process_device(x.data_ptr(), F, y.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     print(algo, hashlib.sha1(y.cpu().numpy().tobytes()).hexdigest(), float(y.abs().mean()))
+    if len(sys.argv) > 1:
+        np.save(sys.argv[1] + algo + ".npy", y.cpu().numpy())
 """
 
 
-def test_fused_equals_two_kernel_chain_at_the_baseline_size():
+def test_fused_equals_two_kernel_chain_at_the_baseline_size(tmp_path):
     """BASELINE batch (8 microphones x 65 536 frames): the fused STFT + per-bin kernel (BF_FUSED_BINS=2: phase by default, das
-    when the one-launch kernel is off) and the two-kernel chain give the same bytes."""
-    outs = []
-    for mode in ("2", "0"):
-        r = subprocess.run([sys.executable, "-c", CHILD_FULL % ROOT], env=dict(os.environ, BF_FUSED_BINS=mode),
-                           capture_output=True, text=True, check=True)
-        outs.append([ln.split() for ln in r.stdout.strip().splitlines()])
-    assert len(outs[0]) == 2 and outs[0] == outs[1], outs
-    assert all(float(ln[2]) > 1e-3 for ln in outs[0])
+    when the one-launch kernel is off) against the two-kernel chain: the same bytes on the 32 x 32 transform (BF_BINS_W64=0), equal
+    up to the last bit of the float output with the default 64-lane transform (stft_bins_w64_kernel)."""
+    outs = {}
+    for tag, env, save in (("fused32", dict(BF_FUSED_BINS="2", BF_BINS_W64="0"), False), ("chain", dict(BF_FUSED_BINS="0"), True),
+                           ("fused64", dict(BF_FUSED_BINS="2"), True)):
+        args = [sys.executable, "-c", CHILD_FULL % ROOT] + ([str(tmp_path / tag)] if save else [])
+        r = subprocess.run(args, env=dict(os.environ, **env), capture_output=True, text=True, check=True)
+        outs[tag] = [ln.split() for ln in r.stdout.strip().splitlines()]
+    assert len(outs["chain"]) == 2 and outs["fused32"] == outs["chain"], outs
+    assert all(float(ln[2]) > 1e-3 for ln in outs["chain"])
+    for algo in ("das", "phase"):
+        a, c = np.load(str(tmp_path / "fused64") + algo + ".npy"), np.load(str(tmp_path / "chain") + algo + ".npy")
+        assert same_floats(a, c), algo
 
 
 def test_das_f64_one_launch_at_the_baseline_size():
