@@ -1,6 +1,11 @@
 // stft_istft.hip -- the two ends of the fp64 bin pipeline: STFT (window + forward FFTs, packed pair spectra to HBM), ISTFT
 // (Hermitian extension, backward FFT, synthesis window, overlap-add), the full-spectrum dump and phasempf's output smoothing.
+#include <cstdlib>
+
 #include "bins_common.hpp"
+#if BF_NFFT == 1024
+#include "w64_f64_dev.hpp"
+#endif
 
 namespace bf {
 namespace BF_NTAG {
@@ -128,6 +133,155 @@ __global__ __launch_bounds__(256) void stft_kernel(StftArgs a) {
                 cb[j] = nb[j];
             }
         }
+    }
+}
+
+// The same transform on the 64-lane x 16-point factorisation (fft1024_w64.hpp, w64_f64_dev.hpp): one full wavefront per (stream,
+// microphone pair, run), 64 data registers per lane, so a 512-thread block runs TWO wavefronts per SIMD and covers its own load and
+// LDS latencies.  Runs are short (32 frames) and the eight wavefronts of a block take them from an LDS counter: the two wavefronts of
+// a SIMD do not share it evenly (das_f64_w64.hip), the faster one simply takes more runs.  First-pass lane = sample: every load is one
+// contiguous 256-byte row; register 4 g + k3 of lane l is bin l + 64 g + 256 k3: every store is one contiguous row of 64 bins.
+// LDS: 17 KB twiddles + 8 x 8.1 KB exchange planes + 9 KB window rows.
+template <int LAYOUT, bool Z48>
+__global__ __launch_bounds__(512) void stft_w64_kernel(StftArgs a, long items_per_block) {
+    constexpr int kTwD = 2 * (1024 + 4 * kTw2RowW64Rot);
+    constexpr int kWinRow = 18;
+    constexpr int oPlane = kTwD, oWin = oPlane + 8 * kPlaneD, oCnt = oWin + 64 * kWinRow;
+    __shared__ __attribute__((aligned(16))) double lds[oCnt + 2];
+    const cx<double> *s_tw1 = reinterpret_cast<const cx<double> *>(lds);
+    const cx<double> *s_tw2 = s_tw1 + 1024;
+    typedef volatile __attribute__((address_space(3))) int *lds_cnt_t;
+    lds_cnt_t s_next = (lds_cnt_t)(lds + oCnt);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *plane = lds + oPlane + w * kPlaneD;
+    double *wcol = plane + w64_col_rot(lane);
+    double *row16 = plane + (lane & 15) * kRS + 16 * (lane >> 4);
+    const double *wrow = lds + oWin + lane * kWinRow;  // window[64 j + lane], j = 0..15 (halved for z48: the spectra are stored halved, exact)
+    {
+        const f64x2 *tw2 = a.tw_w64;
+        f64x2 *ltw = reinterpret_cast<f64x2 *>(lds);
+        for (int i = tid; i < kTwD / 2; i += 512) ltw[i] = tw2[i];
+        for (int i = tid; i < kN; i += 512) lds[oWin + (i & 63) * kWinRow + (i >> 6)] = a.win[i] * (Z48 ? 0.5 : 1.0);
+        if (tid == 0) *s_next = 8;  // the first eight runs are handed out statically
+    }
+    __syncthreads();
+    const int M = a.n_mics, MF = a.n_fft_mics, NP = (MF + 1) >> 1, L = a.run_len;
+    const long runs = (a.n_frames + L - 1) / L;
+    const long total = (long)a.n_streams * runs * NP;
+    const long i0 = (long)blockIdx.x * items_per_block;
+    long i1 = i0 + items_per_block;
+    if (i1 > total) i1 = total;
+    const int n_local = (int)(i1 - i0);
+    for (int li = w; li < n_local;) {  // wavefront-uniform; no block barrier below
+        const long item = i0 + li;
+        const int p = (int)(item % NP);
+        const long sr = item / NP;
+        const long run = sr % runs;
+        const int s = (int)(sr / runs);
+        const long t0 = run * L;
+        const float *xs = a.x + (long)s * a.stream_stride_x;
+        const float *hs = a.hist + (long)s * M * kHop;
+        const int ma = 2 * p;
+        const bool b_ok = 2 * p + 1 < MF;
+        const int mb = b_ok ? 2 * p + 1 : ma;
+        // hop h of this pair (h = -1: the carried hop in front of the batch) as raw samples: register j <- sample 64 j + lane
+        auto load_hop = [&](long h, float (&va)[8], float (&vb)[8]) {
+            if (LAYOUT == 0) {
+                const float *pa = h >= 0 ? xs + (long)ma * a.mic_stride + h * kHop : hs + ma * kHop;
+                const float *pb = h >= 0 ? xs + (long)mb * a.mic_stride + h * kHop : hs + mb * kHop;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    va[j] = pa[(unsigned)(64 * j + lane)];
+                    vb[j] = pb[(unsigned)(64 * j + lane)];
+                }
+            } else {
+                const float *ps = h >= 0 ? xs + h * (long)kHop * M : hs;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    va[j] = ps[(unsigned)((64 * j + lane) * M + ma)];
+                    vb[j] = ps[(unsigned)((64 * j + lane) * M + mb)];
+                }
+            }
+        };
+        float pa[8], pb[8], ca[8], cb[8], na[8], nb[8];
+        load_hop(t0 - 1, pa, pb);
+        load_hop(t0, ca, cb);
+        long te = t0 + L;
+        if (te > a.n_frames) te = a.n_frames;
+        for (long t = t0; t < te; ++t) {
+            {  // next hop: in flight during this frame's transform
+                long tn = t + 1;
+                if (tn >= a.n_frames) tn = a.n_frames - 1;
+                load_hop(tn, na, nb);
+            }
+            double re[16], im[16];
+            // buf[j]*hann_win[i] (util.h:235) and the first butterfly stage of the transform in one (das_f64_w64.hip)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double w0 = wrow[j], w1 = wrow[j + 8];
+                const double t0w = (double)pa[j] * w0, u = (double)ca[j];
+                re[j] = fma(u, w1, t0w);
+                re[j + 8] = fma(-u, w1, t0w);
+            }
+            if (b_ok) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double w0 = wrow[j], w1 = wrow[j + 8];
+                    const double t0w = (double)pb[j] * w0, u = (double)cb[j];
+                    im[j] = fma(u, w1, t0w);
+                    im[j + 8] = fma(-u, w1, t0w);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) im[j] = 0.0;
+            }
+            cx<double> tw[15];
+            BF_STAGE();
+            load_tw1<1, 9>(tw, s_tw1, lane);
+            BF_STAGE();
+            fft16_core<double, -1, true, 1>(re, im);  // stage 0 is done
+            BF_STAGE();
+            load_tw1<9, 16>(tw, s_tw1, lane);
+            BF_STAGE();
+            mul_tw<false, 1, 9>(re, im, tw);
+            BF_STAGE();
+            mul_tw<false, 9, 16>(re, im, tw);
+            BF_STAGE();
+            T1_fwd(re, im, wcol, row16);
+            load_tw2<1, 9>(tw, s_tw2, lane);
+            BF_STAGE();
+            fft16_core<double, -1, true>(re, im);
+            BF_STAGE();
+            load_tw2<9, 16>(tw, s_tw2, lane);
+            BF_STAGE();
+            mul_tw<false, 1, 9>(re, im, tw);
+            BF_STAGE();
+            mul_tw<false, 9, 16>(re, im, tw);
+            BF_STAGE();
+            w64_T2<true>(re, im);
+            w64_fwd_p3<double>(re, im);
+            const long zoff = (((long)s * a.frames_ws + a.frame_off + t) * NP + p) * kN + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 64 * (r >> 2) + 256 * (r & 3);  // bins row .. row + 63 of this store
+                if (row > a.skip_lo && row + 63 < a.skip_hi) continue;  // band-limited nodes never read these bins
+                if (Z48)
+                    reinterpret_cast<z48 *>(a.Z)[zoff + row] = enc48(re[r], im[r]);
+                else
+                    a.Z[zoff + row] = f64x2{re[r], im[r]};
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                pa[j] = ca[j];
+                pb[j] = cb[j];
+                ca[j] = na[j];
+                cb[j] = nb[j];
+            }
+        }
+        int nx = 0;
+        if (lane == 0) nx = __hip_atomic_fetch_add((__attribute__((address_space(3))) int *)s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        li = __builtin_amdgcn_readfirstlane(nx);
     }
 }
 
@@ -860,9 +1014,33 @@ hipError_t launch_das_f64_fused(const DasF64Args &a, int n_cus, hipStream_t s) {
 }
 
 hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
+    const long np = (a.n_fft_mics + 1) / 2;
+#if BF_NFFT == 1024
+    // BF_STFT_W64=1: the 64-lane kernel (two wavefronts per SIMD, runs handed out dynamically).  Off by default: the STFT in front of
+    // mvdr / lcmv / gss moves 3.3 GB at 5 TB/s either way (0.62-0.74 ms against 0.67 for the half-wavefront kernel, box to box)
+    static const bool w64_on = getenv("BF_STFT_W64") && atoi(getenv("BF_STFT_W64")) == 1;
+    if (w64_on && a.tw_w64 != nullptr) {
+        StftArgs b = a;
+        static const long L_env = getenv("BF_STFT_W64_L") ? atol(getenv("BF_STFT_W64_L")) : 32;
+        long L = L_env;  // a run re-reads its leading hop: 3 % of the input; short runs level the eight wavefronts of a block
+        if (L > a.n_frames) L = a.n_frames;
+        b.run_len = (int)L;
+        const long total = (long)a.n_streams * ((a.n_frames + L - 1) / L) * np;
+        long blocks = total < n_cus ? total : n_cus;
+        const long ipb = (total + blocks - 1) / blocks;
+        blocks = (total + ipb - 1) / ipb;
+        if (a.layout == 0) {
+            if (a.z48) hipLaunchKernelGGL((stft_w64_kernel<0, true>), dim3((unsigned)blocks), dim3(512), 0, s, b, ipb);
+            else hipLaunchKernelGGL((stft_w64_kernel<0, false>), dim3((unsigned)blocks), dim3(512), 0, s, b, ipb);
+        } else {
+            if (a.z48) hipLaunchKernelGGL((stft_w64_kernel<1, true>), dim3((unsigned)blocks), dim3(512), 0, s, b, ipb);
+            else hipLaunchKernelGGL((stft_w64_kernel<1, false>), dim3((unsigned)blocks), dim3(512), 0, s, b, ipb);
+        }
+        return hipGetLastError();
+    }
+#endif
     // 256 threads, twiddles in LDS: a 512-thread block spills (44 VGPRs) and twiddles read from global memory cost 40 % (measured)
     constexpr int nb = 256, halves = nb / 32;
-    const long np = (a.n_fft_mics + 1) / 2;
     // frames per run: one run per half-wavefront slot (one block per CU) when the batch is long enough -- the first frame of a
     // run fetches its leading hop a second time (1/run_len of the input)
     StftArgs b = a;

@@ -63,6 +63,8 @@ CASES = [
     ({"BF_ISTFT_F64": "1"}, "phase", 8, (), 24, True),
     ({"BF_Z48": "0"}, "mvdr", 8, (), 30, True),                        # full-double spectra in HBM (no z48 packing), group kernel
     ({"BF_Z48": "0"}, "lcmv", 16, (-60.0, 90.0, 150.0), 24, True),
+    ({"BF_STFT_W64": "1"}, "mvdr", 8, (), 30, True),                   # stft_w64_kernel in front of the covariance nodes (z48 rows)
+    ({"BF_STFT_W64": "1"}, "gss", 5, (-60.0,), 30, True),              # ... and full-double rows, odd microphone count
     ({"BF_BINS_W64": "0"}, "phase", 8, (), 24, True),                  # stft_bins_fused_kernel: the 32 x 32 half-wavefront version of the fused STFT + per-bin kernel
     ({"BF_BINS_W64": "0"}, "phasempf", 5, (), 30, True),
     ({"BF_DAS_F64_W64": "0"}, "das", 8, (), 37, False),                # (only the fp64 das node reads it; the fp32 node must not care)
