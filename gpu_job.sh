@@ -1,8 +1,8 @@
 cd /root/repo
 export TMPDIR=/tmp
-for i in 1 2; do
-for alg in "mvdr" ; do
-  timeout 200 python tools/run_das.py --algo $alg --iters 10 > gpurun_out/t.log 2>&1; tail -1 gpurun_out/t.log
-  BF_STFT_W64=0 timeout 200 python tools/run_das.py --algo $alg --iters 10 > gpurun_out/t.log 2>&1; tail -1 gpurun_out/t.log
+for rep in 1 2; do
+for v in "" _fsl9 _fsl11; do
+  if [ -z "$v" ]; then lib=/root/repo/beamform_amd/lib/libbfcore.so; else lib=/root/repo/beamform_amd/lib/libbfcore$v.so; fi
+  BFCORE_LIB=$lib timeout 120 python tools/run_das.py --algo das --iters 20 > gpurun_out/t.log 2>&1; echo "planar '$v' $(tail -1 gpurun_out/t.log | cut -c1-70)"
+  BFCORE_LIB=$lib timeout 120 python tools/run_das.py --algo das --layout interleaved --iters 20 > gpurun_out/t.log 2>&1; echo "interl '$v' $(tail -1 gpurun_out/t.log | cut -c1-70)"
 done; done
-timeout 1500 python -m pytest tests/test_pipeline_gpu.py tests/test_shard_gpu.py tests/test_golden_gpu.py tests/test_hops_gpu.py -q > gpurun_out/t1.log 2>&1; tail -3 gpurun_out/t1.log
