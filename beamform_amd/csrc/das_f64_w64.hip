@@ -319,6 +319,12 @@ __global__ __launch_bounds__(kBlock) void das_f64_w64_kernel(DasF64Args a, int f
 // Gains: ce_m is Hermitian, so only bins 0 .. 512 are kept: [mic][row 2 g + k3, k3 < 2][65] = ce_m[64 g + 256 k3 + c], c = 0 .. 64.
 // Register 4 g + k3 of lane l is bin l + 64 g + 256 k3: k3 < 2 reads row (g, k3) column l; k3 >= 2 reads row (3 - g, 3 - k3) column
 // 64 - l (N - k = (64 - l) + 64 (3 - g) + 256 (3 - k3)) and conjugates through the FMA signs.  The 65th column is the bin behind the row.
+// read-back of a parked half: non-temporal (used once); a plain load moved 4 % more bytes across the fabric (-DBF_PARK_PLAIN for A/B runs)
+#ifdef BF_PARK_PLAIN
+#define BF_PARK_LD(p) (*(const volatile float *)(p))
+#else
+#define BF_PARK_LD(p) __builtin_nontemporal_load(p)
+#endif
 constexpr int kGRow = 65;                                  // complex entries per gain row
 constexpr int kGMic = 8 * kGRow;                           // per microphone
 constexpr int kStepP = 2 * kWaves;                         // frames of one round of the block's wavefronts (run lengths are multiples)
@@ -631,7 +637,7 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             float o[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = __builtin_nontemporal_load(yn + (unsigned)(64 * j + lane));
+            for (int j = 0; j < 8; ++j) o[j] = BF_PARK_LD(yn + (unsigned)(64 * j + lane));
 #pragma unroll
             for (int j = 0; j < 8; ++j) yn[(unsigned)(64 * j + lane)] = tl[j] + o[j];
         } else {
@@ -645,7 +651,7 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             float o[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = __builtin_nontemporal_load(yo + (unsigned)(64 * j + lane));
+            for (int j = 0; j < 8; ++j) o[j] = BF_PARK_LD(yo + (unsigned)(64 * j + lane));
 #pragma unroll
             for (int j = 0; j < 8; ++j) yo[(unsigned)(64 * j + lane)] = o[j] + oA[j];
         } else {

@@ -40,5 +40,5 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
   i=$((i+1))
   $P --pmc $set -d gpurun_out/${tag}_f64pmc$i -- python tools/run_das.py --das-f64 --iters 3 --warmup 2 > gpurun_out/${tag}_f64pmc$i.log 2>&1
 done
-python tools/pmc_summary.py gpurun_out/${tag}_f64pmc1 gpurun_out/${tag}_f64pmc2 gpurun_out/${tag}_f64pmc3 gpurun_out/${tag}_f64pmc4 | cut -c40- > gpurun_out/${tag}_das8_f64_w64_pmc.txt
-cat gpurun_out/${tag}_das8_f64_w64_pmc.txt
+python tools/pmc_summary.py gpurun_out/${tag}_f64pmc1 gpurun_out/${tag}_f64pmc2 gpurun_out/${tag}_f64pmc3 gpurun_out/${tag}_f64pmc4 | cut -c40- > gpurun_out/${tag}_das8_f64_pair_pmc.txt
+cat gpurun_out/${tag}_das8_f64_pair_pmc.txt
