@@ -511,7 +511,7 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
             mul_tw<false, 9, 16>(re, im, tw);
             BF_STAGE();
             BF_FSTAMP(4);
-            w64_T2<true>(re, im);
+            w64_T2_any<true>(re, im, row16 - 16 * (lane >> 4), lane >> 4);
             BF_FSTAMP(5);
             cx<double> g[16];
             const cx<double> *gd = s_gain + m * kGMic + lane;         // k3 < 2: row (g, k3), column lane
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
         load_tw2<1, 16>(tw, s_tw2, lane);
         BF_STAGE();
         w64_inv_p3<double>(Sr, Si);
-        w64_T2<false>(Sr, Si);
+        w64_T2_any<false>(Sr, Si, row16 - 16 * (lane >> 4), lane >> 4);
         BF_BSTAMP(1);
         BF_STAGE();
         mul_tw<true, 1, 16>(Sr, Si, tw);

@@ -89,15 +89,71 @@ __device__ __forceinline__ void w64_T2(double (&re)[16], double (&im)[16]) {
     }
 }
 
-// ---- T1 through one scalar plane (real parts, then imaginary parts) -----------------------------------------------------------
-// forward: position i (k1 = brev4(i)) of lane 4a+b -> register position (a + 4 b) & 15 of lane 16 b + k1.  LDS operations of one
-// wavefront execute in issue order: only compiler barriers separate the phases.
-// exchange reads as single ds_read_b64 (2 LDS cycles per 512 B): merged into ds_read2_b64 by the compiler they take 8 cycles per 1 KB
 #ifdef BF_T1_MERGED_READS
 #define BF_T1_RD(p) (*(p))
 #else
 #define BF_T1_RD(p) (*(const volatile __attribute__((address_space(3))) double *)(p))
 #endif
+
+// ---- T2 through the exchange plane ---------------------------------------------------------------------------------------------
+// The same 4 x 4 transpose as w64_T2 without the permlane swaps (128 swaps of a transform = 1 000 of its ~3 500 vector cycles): lane
+// (b, k1) writes its 16 values into row k1 of the plane, lane (q, k1) reads its 16 back (and the reverse for the backward transform).
+// Element (q, g, b) of row k1 sits at column  f = 32 (b & 1) + 16 ((q ^ b) & 1) + 4 g + 2 (q >> 1) + (b >> 1):  rows are kRS = 65
+// doubles apart, so the 16 lanes of a ds_write_b64 group (one b or q, k1 = 0..15) cover 16 bank pairs, and the two 16-lane groups
+// of a ds_read_b64 pass (q or b = 0, 1 / 2, 3) sit 16 bank pairs apart: no conflicts in either direction.
+// prow = plane + (lane & 15) * kRS, hi = lane >> 4.
+// Measured (das_f64_pair_kernel, one box): 0.575 ms against 0.545 with the swaps -- the two more LDS round trips per transform cost more than
+// the 1 000 vector cycles they free.  Kept for A/B runs: -DBF_T2_LDS.
+template <bool FWD>
+__device__ __forceinline__ void w64_T2_lds(double (&re)[16], double (&im)[16], double *prow, int hi) {
+    // this lane as the "b side" (forward writer / backward reader): q, g compile-time
+    double *bE = prow + 48 * (hi & 1) + (hi >> 1);        // q even: f = 48 (b&1) + (b>>1) + 4 g + 2 (q>>1)
+    double *bO = prow + 16 + 16 * (hi & 1) + (hi >> 1);   // q odd : f = 16 + 16 (b&1) + (b>>1) + 4 g + 2 (q>>1)
+    // this lane as the "q side" (forward reader / backward writer): g, b compile-time
+    double *qE = prow + 16 * (hi & 1) + 2 * (hi >> 1);        // b even: f = 16 (q&1) + 2 (q>>1) + 4 g + (b>>1)
+    double *qO = prow + 48 - 16 * (hi & 1) + 2 * (hi >> 1);   // b odd : f = 48 - 16 (q&1) + 2 (q>>1) + 4 g + (b>>1)
+    auto pass = [&](double (&v)[16]) {
+        if (FWD) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ((q & 1) ? bO : bE)[4 * g + 2 * (q >> 1)] = v[brev2c(g) + 4 * brev2c(q)];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) v[4 * g + b] = BF_T1_RD(((b & 1) ? qO : qE) + 4 * g + (b >> 1));
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) ((b & 1) ? qO : qE)[4 * g + (b >> 1)] = v[4 * g + b];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[brev2c(g) + 4 * brev2c(q)] = BF_T1_RD(((q & 1) ? bO : bE) + 4 * g + 2 * (q >> 1));
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    pass(re);
+    pass(im);
+}
+// the second transpose of a transform: by permlane swaps (default) or through LDS (-DBF_T2_LDS)
+template <bool FWD>
+__device__ __forceinline__ void w64_T2_any(double (&re)[16], double (&im)[16], double *prow, int hi) {
+#ifdef BF_T2_LDS
+    w64_T2_lds<FWD>(re, im, prow, hi);
+#else
+    (void)prow; (void)hi;
+    w64_T2<FWD>(re, im);
+#endif
+}
+
+// ---- T1 through one scalar plane (real parts, then imaginary parts) -----------------------------------------------------------
+// forward: position i (k1 = brev4(i)) of lane 4a+b -> register position (a + 4 b) & 15 of lane 16 b + k1.  LDS operations of one
+// wavefront execute in issue order: only compiler barriers separate the phases.
+// exchange reads as single ds_read_b64 (2 LDS cycles per 512 B): merged into ds_read2_b64 by the compiler they take 8 cycles per 1 KB
 __device__ __forceinline__ void T1_fwd(double (&re)[16], double (&im)[16], double *wcol, const double *row16) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) wcol[brev4(i) * kRS] = re[i];
