@@ -45,6 +45,7 @@ struct bf_handle {
     f32x2 *d_twiddle = nullptr;
     f32x2 *d_twiddle_w64 = nullptr;
     f32x2 *d_twiddle_split = nullptr;  // hop 1024: twiddle_table_split2048() (das_fused_2048.hip)
+    f32x2 *d_twiddle_split_w64 = nullptr;  // hop 1024: twiddle_table_split2048_w64() (das_fused_w64.hip das_fused_2048_w64_kernel)
     f32x2 *d_gains_w64[2] = {nullptr, nullptr};
     bool use_w64 = false;
     float *d_window = nullptr;
@@ -206,10 +207,12 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     // (generic periods: blocks of 13 N bytes of LDS -- 26 N at N = 8192 -- share a CU: 8 at N <= 512, 3 at 2048, 1 from 4096 on)
     const int gen_per_cu = h->N <= 512 ? 8 : h->N <= 1024 ? 6 : h->N <= 2048 ? 3 : 1;
     // period 1024 without a dump: two FFT-1024 passes per frame on the in-register machinery, a half-wavefront per run, 16 runs per CU
-    // (BF_DAS_SPLIT2048=0: the generic kernel, for A/B runs)
-    static const bool split_on = !(getenv("BF_DAS_SPLIT2048") && atoi(getenv("BF_DAS_SPLIT2048")) == 0);
-    const bool split2048 = gen && h->N == 2048 && !spectrum_dev && split_on && h->d_twiddle_split != nullptr;
-    long runs = (split2048 ? (long)h->n_cus * 8 : gen ? (long)h->n_cus * gen_per_cu : (long)h->n_cus) / (shared ? h->n_streams : S);
+    // -- or, the default, a full wavefront per run on the 64-lane transform, 12 runs per CU (BF_DAS_SPLIT2048=1: the half-wavefront
+    // version, =0: the generic kernel; for A/B runs)
+    static const int split_env = getenv("BF_DAS_SPLIT2048") ? atoi(getenv("BF_DAS_SPLIT2048")) : 2;
+    const bool split2048 = gen && h->N == 2048 && !spectrum_dev && split_env != 0 && h->d_twiddle_split != nullptr;
+    const bool split_w64 = split2048 && split_env == 2 && h->d_twiddle_split_w64 != nullptr;
+    long runs = (split_w64 ? (long)h->n_cus * 12 : split2048 ? (long)h->n_cus * 8 : gen ? (long)h->n_cus * gen_per_cu : (long)h->n_cus) / (shared ? h->n_streams : S);
     if (runs < 1) runs = 1;
     long fpc = (F + runs - 1) / runs;
     if (!gen) fpc = ((fpc + 15) / 16) * 16;
@@ -262,7 +265,8 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
         for (int d0 = 0; d0 < h->n_dirs; d0 += 16)
             BF_HIP(h, launch_das_fused_dirs(a, d0, h->n_dirs - d0 < 16 ? h->n_dirs - d0 : 16, s));
     } else {
-        BF_HIP(h, split2048 ? launch_das_fused_2048(a, h->d_twiddle_split, s)
+        BF_HIP(h, split_w64 ? launch_das_fused_2048_w64(a, h->d_twiddle_split_w64, s)
+                  : split2048 ? launch_das_fused_2048(a, h->d_twiddle_split, s)
                   : gen     ? launch_das_fused_gen(a, h->N, s)
                   : h->use_w64 ? launch_das_fused_w64(a, s) : launch_das_fused(a, s));
     }
@@ -420,6 +424,9 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
             const std::vector<f32x2> ts = twiddle_table_split2048();
             BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle_split, ts.size() * sizeof(f32x2)));
             BF_CREATE_HIP(hipMemcpy(h->d_twiddle_split, ts.data(), ts.size() * sizeof(f32x2), hipMemcpyHostToDevice));
+            const std::vector<f32x2> tsw = twiddle_table_split2048_w64();
+            BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle_split_w64, tsw.size() * sizeof(f32x2)));
+            BF_CREATE_HIP(hipMemcpy(h->d_twiddle_split_w64, tsw.data(), tsw.size() * sizeof(f32x2), hipMemcpyHostToDevice));
         }
         BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle, tw.size() * sizeof(f32x2)));
         BF_CREATE_HIP(hipMemcpy(h->d_twiddle, tw.data(), tw.size() * sizeof(f32x2), hipMemcpyHostToDevice));
@@ -471,6 +478,7 @@ void bf_destroy(bf_handle *h) {
     if (h->d_twiddle) (void)hipFree(h->d_twiddle);
     if (h->d_twiddle_w64) (void)hipFree(h->d_twiddle_w64);
     if (h->d_twiddle_split) (void)hipFree(h->d_twiddle_split);
+    if (h->d_twiddle_split_w64) (void)hipFree(h->d_twiddle_split_w64);
     if (h->d_window) (void)hipFree(h->d_window);
     if (h->d_zeros) (void)hipFree(h->d_zeros);
     if (h->d_sdump) (void)hipFree(h->d_sdump);

@@ -315,6 +315,178 @@ __global__ __launch_bounds__(kBlock) void das_fused_w64_kernel(DasFusedArgs a) {
     }
 }
 
+// =====================================================================================================================================
+//        JACK period 1024 (FFT 2048) on the 64-lane transform: das_fused_2048.hip's radix-2 split, one full wavefront per frame
+// =====================================================================================================================================
+// e[n] = w[n] x[n] + w[n + 1024] x[n + 1024] gives the even bins, (w[n] x[n] - w[n + 1024] x[n + 1024]) W2048^n the odd ones; per pass
+// ceil(M/2) packed forward FFT-1024, S += D_p Z_p with the pair gains of the even (odd) bins, one backward transform; y[n] = Re A[n] +
+// Re(conj(W^n) B[n]), y[n + 1024] = Re A[n] - ... (das_fused_2048.hip).  16 points per lane instead of 32: ~130 registers, THREE
+// wavefronts per SIMD (the half-wavefront version needs 350 and runs one).  A wavefront owns (output stream, run of consecutive frames)
+// and walks it; the overlap-add tail waits in the output buffer (same lane, same addresses, program order); a run that does not
+// start the stream recomputes its previous frame.  LDS: 8.5 KB twiddles + 12 x 4.3 KB exchange planes + 8 KB W^n + 8 KB window +
+// 64 KB pair gains in the order the passes read them (one look direction, <= 8 microphones; otherwise from L2 in natural order).
+constexpr int kBlk2 = 768, kWaves2 = kBlk2 / 64;
+constexpr int kH2 = 1024;  // hop = JACK period
+constexpr int o2Pl = kLdsTw, o2W = o2Pl + kWaves2 * kPlane, o2Win = o2W + 2048, o2G = o2Win + 2048, kLds2 = o2G + 2 * 4 * 16 * 64 * 2;
+
+template <int LAYOUT>
+__global__ __launch_bounds__(kBlk2) void das_fused_2048_w64_kernel(DasFusedArgs a, const f32x2 *tw_split) {
+    __shared__ __attribute__((aligned(16))) float lds[kLds2];
+    const cx<float> *s_tw1 = reinterpret_cast<const cx<float> *>(lds);
+    const cx<float> *s_tw2 = s_tw1 + 1024;
+    const f32x2 *s_w = reinterpret_cast<const f32x2 *>(lds + o2W);
+    const float *s_win = lds + o2Win;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *pl = lds + o2Pl + w * kPlane;
+    float *row16 = pl + (lane & 15) * kRS + 16 * (lane >> 4);
+    float *wcol = pl + w64_col(lane);
+    const int M = a.n_mics, NP = (M + 1) >> 1;
+    const bool g_lds = NP <= 4 && a.n_dirs == 1;
+    {
+        const float *tf = reinterpret_cast<const float *>(tw_split);  // [w64 twiddles (1088 complex) | W2048^n, n < 1024]
+        for (int i = tid; i < kLdsTw; i += kBlk2) lds[i] = tf[i];
+        for (int i = tid; i < 2048; i += kBlk2) lds[o2W + i] = tf[kLdsTw + i];
+        for (int i = tid; i < 2048; i += kBlk2) lds[o2Win + i] = a.window[i];
+        if (g_lds) {
+            f32x2 *lg = reinterpret_cast<f32x2 *>(lds + o2G);
+            for (int e = tid; e < NP * 2048; e += kBlk2) {  // e = ((pass * NP + p) * 16 + r) * 64 + lane  <-  bin 2 w64_bin(lane, r) + pass of pair p
+                const int l = e & 63, r = (e >> 6) & 15, pp = e >> 10, p = pp % NP, pass = pp / NP;
+                lg[e] = a.gains[(long)p * 2048 + 2 * w64_bin(l, r) + pass];
+            }
+        }
+    }
+    __syncthreads();
+    const long L = a.frames_per_chunk, runs = a.chunks_per_stream;
+    const long item = (long)blockIdx.x * kWaves2 + w;
+    if (item >= (long)a.n_streams * runs) return;  // no block barrier below
+    const int s = (int)(item / runs);              // output stream = input stream * n_dirs + look direction
+    const long t0 = (item - (long)s * runs) * L;
+    long te = t0 + L;
+    if (te > a.n_frames) te = a.n_frames;
+    const int in_stream = s / a.n_dirs;
+    const f32x2 *gains = a.gains + (long)(s - in_stream * a.n_dirs) * NP * 2048;  // [pair][bin], 1/N folded in
+    const float *xs = a.x + (long)in_stream * a.stream_stride_x;
+    const float *hs = a.hist_in + (long)in_stream * M * kH2;
+    float *ys = a.y + (long)s * a.n_frames * kH2;
+
+    // sample 64 j + lane of hop h (h = -1: the carried hop) of microphone m; jstep = elements between a lane's consecutive registers
+    auto hop_ptr = [&](long h, int m) -> const float * {
+        if (LAYOUT == 0) return (h >= 0 ? xs + (long)m * a.mic_stride + h * kH2 : hs + (long)m * kH2) + lane;
+        return (h >= 0 ? xs + h * (long)kH2 * M : hs) + (long)lane * M + m;
+    };
+    const long jstep = LAYOUT == 0 ? 64 : (long)64 * M;
+
+    const long tb = t0 == 0 ? 0 : t0 - 1;
+    for (long t = tb; t < te; ++t) {  // t0 - 1: warm-up frame, only its second half (the tail) is used
+        float v[16];  // Re(conj(W^n) B[n]) of the odd pass
+        float Sr[16], Si[16];
+        for (int pass = 1; pass >= 0; --pass) {  // odd bins first
+            const float sg = pass ? -1.f : 1.f;  // the sign of the second half's term
+            for (int p = 0; p < NP; ++p) {
+                float re[16], im[16];
+                const int ma = 2 * p, mb = 2 * p + 1;
+                {   // channel a, then channel b: one channel's two hops in flight at a time
+                    float x2[16];
+                    const float *q1 = hop_ptr(t - 1, ma), *q2 = hop_ptr(t, ma);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) re[j] = q1[j * jstep];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) x2[j] = q2[j * jstep];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)  // buf[j]*hann_win[i] (util.h:235), both halves of the frame
+                        re[j] = bf_fma(x2[j], s_win[kH2 + 64 * j + lane] * sg, re[j] * s_win[64 * j + lane]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (mb < M) {
+                        const float *r1 = hop_ptr(t - 1, mb), *r2 = hop_ptr(t, mb);
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) im[j] = r1[j * jstep];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) x2[j] = r2[j * jstep];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j)
+                            im[j] = bf_fma(x2[j], s_win[kH2 + 64 * j + lane] * sg, im[j] * s_win[64 * j + lane]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) im[j] = 0.f;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (pass) {  // o[n] *= W^n
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const f32x2 ww = s_w[64 * j + lane];
+                        const float xr = re[j], xi = im[j];
+                        re[j] = xr * ww.x - xi * ww.y;
+                        im[j] = xr * ww.y + xi * ww.x;
+                    }
+                }
+                w64_fwd_p1<float>(re, im, lane, s_tw1);
+                w64_T1_fwd(re, im, wcol, row16);
+                w64_fwd_p2<float>(re, im, lane, s_tw2);
+                w64_T2<true>(re, im);
+                w64_fwd_p3<float>(re, im);
+                // register r of lane l holds bin k = w64_bin(l, r) of this pass' transform = bin 2 k + pass of the frame
+                if (g_lds) {
+                    const f32x2 *gp = reinterpret_cast<const f32x2 *>(lds + o2G) + (pass * NP + p) * 1024 + lane;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const f32x2 g = gp[64 * r];
+                        Sr[r] = bf_fma(-g.y, im[r], bf_fma(g.x, re[r], p == 0 ? 0.f : Sr[r]));
+                        Si[r] = bf_fma(g.y, re[r], bf_fma(g.x, im[r], p == 0 ? 0.f : Si[r]));
+                    }
+                } else {
+                    const f32x2 *gp = gains + (long)p * 2048 + pass;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const f32x2 g = gp[2 * w64_bin(lane, r)];
+                        Sr[r] = bf_fma(-g.y, im[r], bf_fma(g.x, re[r], p == 0 ? 0.f : Sr[r]));
+                        Si[r] = bf_fma(g.y, re[r], bf_fma(g.x, im[r], p == 0 ? 0.f : Si[r]));
+                    }
+                }
+            }
+            w64_inv_p3<float>(Sr, Si);
+            w64_T2<false>(Sr, Si);
+            w64_inv_p2<float>(Sr, Si, lane, s_tw2);
+            w64_T1_inv(Sr, Si, row16, wcol);
+            w64_inv_p1<float>(Sr, Si, lane, s_tw1);
+            if (pass) {  // register j <-> n = 64 j + lane: Re(conj(W^n) B[n])
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const f32x2 ww = s_w[64 * j + lane];
+                    v[j] = Sr[j] * ww.x + Si[j] * ww.y;
+                }
+            }
+        }
+        // Sr = Re A.  First half: sample n, second half: sample n + 1024; synthesis window and overlap-add with the float stores
+        float *yo = ys + t * kH2 + lane;
+        const float *prev = (t == 0) ? a.tail_in + (long)s * kH2 + lane : yo;  // the tail parked by frame t - 1 (the carried state at t = 0)
+        const bool store = t >= t0, park = t + 1 < te;
+        float *yn = yo + kH2;
+        float o2[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+#pragma clang fp contract(off)
+            const float o1 = (Sr[j] + v[j]) * s_win[64 * j + lane];     // (float)(Re / N) [1/N inside the gains] times hann (util.h:249-251)
+            o2[j] = (Sr[j] - v[j]) * s_win[kH2 + 64 * j + lane];
+            if (store) yo[64 * j] = prev[64 * j] + o1;                  // out = prev[H + n] + cur[n]  (util.h:301-302)
+            if (park) yn[64 * j] = o2[j];                               // completed by the run's next frame
+        }
+        if (t == a.n_frames - 1) {  // end of the batch: carried state for the next call (OLA tail and the last input hop)
+            float *to = a.tail_out + (long)s * kH2 + lane;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) to[64 * j] = o2[j];
+            float *ho = a.hist_out + (long)in_stream * M * kH2;  // every look direction writes the same values
+            if (LAYOUT == 0) {
+                for (int m = 0; m < M; ++m)
+                    for (int j = 0; j < 16; ++j) ho[m * kH2 + 64 * j + lane] = xs[(long)m * a.mic_stride + t * kH2 + 64 * j + lane];
+            } else {
+                for (int j = 0; j < 16 * M; ++j) ho[64 * j + lane] = xs[t * (long)kH2 * M + 64 * j + lane];
+            }
+        }
+    }
+}
+
 template <int LAYOUT>
 void launch_layout(const DasFusedArgs &a, unsigned blocks, hipStream_t stream) {
     const int np = (a.n_mics + 1) / 2;
@@ -332,6 +504,19 @@ hipError_t launch_das_fused_w64(const DasFusedArgs &a, hipStream_t stream) {
         launch_layout<0>(a, blocks, stream);
     else
         launch_layout<1>(a, blocks, stream);
+    return hipGetLastError();
+}
+
+// a.frames_per_chunk / a.chunks_per_stream: frames per run and runs per OUTPUT stream (one wavefront per run); tw_split =
+// twiddle_table_split2048_w64() (geometry.hpp); a.gains = das_pair_gains_natural tables; no spectrum dump
+hipError_t launch_das_fused_2048_w64(const DasFusedArgs &a, const f32x2 *tw_split, hipStream_t stream) {
+    if (a.sdump != nullptr) return hipErrorNotSupported;
+    const long items = (long)a.chunks_per_stream * a.n_streams;
+    const unsigned blocks = (unsigned)((items + kWaves2 - 1) / kWaves2);
+    if (a.layout == 0)
+        hipLaunchKernelGGL(das_fused_2048_w64_kernel<0>, dim3(blocks), dim3(kBlk2), 0, stream, a, tw_split);
+    else
+        hipLaunchKernelGGL(das_fused_2048_w64_kernel<1>, dim3(blocks), dim3(kBlk2), 0, stream, a, tw_split);
     return hipGetLastError();
 }
 

@@ -249,6 +249,17 @@ inline std::vector<f32x2> twiddle_table_split2048() {
     return t;
 }
 
+// the same for das_fused_w64.hip das_fused_2048_w64_kernel: [twiddle_table_w64() (1088 entries) | W2048^n, n < 1024]
+inline std::vector<f32x2> twiddle_table_split2048_w64() {
+    std::vector<f32x2> t = twiddle_table_w64();
+    t.resize(1088 + 1024);
+    for (int n = 0; n < 1024; ++n) {
+        const double a = -2.0 * kPi * (double)n / 2048.0;
+        t[1088 + n] = f32x2{(float)std::cos(a), (float)std::sin(a)};
+    }
+    return t;
+}
+
 // fp64 tables of the 64-lane factorisation with the rotated exchange (fft1024_w64.hpp w64_col_rot; das_f64_w64.hip):
 // [0, 1024) = W1024^(k1*lane) as [k1][lane]; [1024, 1092) = tw2'[b][k2] = exp(2 pi i 15 b k2 / 64) in rows of 17 (one element of
 // padding: the four rows a wavefront reads at once then start 4 LDS banks apart instead of on the same one)

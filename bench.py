@@ -566,7 +566,7 @@ def main():
                 n_settle += 1
             ms, _ = bm.time_device(xin.data_ptr(), F_, yo.data_ptr(), 5, sptr)
             bm.close()
-            how = ("two register-resident FFT-1024 passes per frame (das_fused_2048.hip)" if hop_ == 1024 else
+            how = ("two register-resident FFT-1024 passes per frame on the 64-lane transform (das_fused_w64.hip das_fused_2048_w64_kernel)" if hop_ == 1024 else
                    "LDS-staged radix-4 transforms (das_fused_gen.hip; not the register-resident machinery of the 512-frame period)")
             return {"workload": f"{algo_} {M}-mic, JACK period {hop_} (FFT {2 * hop_}), {F_} frames = the headline batch's samples; fused fp32 kernel on " + how,
                     "ms_per_step": ms, "frames_per_s": F_ / (ms * 1e-3), "samples_per_s": F_ * hop_ / (ms * 1e-3)}

@@ -1,3 +1,3 @@
 cd /root/repo
 export TMPDIR=/tmp
-for seed in 11 12 13; do timeout 1500 python tools/fuzz_parity.py $seed 500 > gpurun_out/fuzz_$seed.log 2>&1; tail -4 gpurun_out/fuzz_$seed.log; done
+timeout 1500 python -m pytest tests/test_hops_gpu.py -q > gpurun_out/t1.log 2>&1; tail -3 gpurun_out/t1.log

@@ -242,10 +242,11 @@ print("RESULT " + json.dumps(res))
 """
 
 
-@pytest.mark.parametrize("split", ["1", "0"])
+@pytest.mark.parametrize("split", ["2", "1", "0"])
 def test_period_1024_split_kernel_and_its_switch(split):
-    """das_fused_2048.hip (two FFT-1024 passes per frame, the default at the 1024-frame period without a spectrum dump) and
-    BF_DAS_SPLIT2048=0 (das_fused_gen_kernel<2048>) against the oracle; the switch is read once per process."""
+    """The 1024-frame period without a spectrum dump: das_fused_2048_w64_kernel (two FFT-1024 passes per frame on the 64-lane transform, the
+    default = BF_DAS_SPLIT2048=2), das_fused_2048_kernel (=1: the half-wavefront version) and das_fused_gen_kernel<2048> (=0) against the
+    oracle; the switch is read once per process."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", CHILD_1024 % dict(root=root)], env=dict(os.environ, BF_DAS_SPLIT2048=split),
