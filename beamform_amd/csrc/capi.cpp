@@ -45,6 +45,8 @@ struct bf_handle {
     f32x2 *d_twiddle = nullptr;
     f32x2 *d_twiddle_w64 = nullptr;
     f32x2 *d_twiddle_split = nullptr;  // hop 1024: twiddle_table_split2048() (das_fused_2048.hip)
+    f32x2 *d_gains_il[2] = {nullptr, nullptr};  // hop < 512: das_pair_gains_interleaved tables (das_fused_small.hip), double-buffered with d_gains
+    f32x2 *d_twiddle_1024 = nullptr;            // hop < 512: twiddle_table_32x32 (the frame-interleaving kernel runs the 1024-point machinery)
     f32x2 *d_twiddle_split_w64 = nullptr;  // hop 1024: twiddle_table_split2048_w64() (das_fused_w64.hip das_fused_2048_w64_kernel)
     f32x2 *d_gains_w64[2] = {nullptr, nullptr};
     bool use_w64 = false;
@@ -123,8 +125,12 @@ int sync_tables(bf_handle *h, hipStream_t s, RunSnapshot *snap) {
     }
     if (uses_fused_das(h)) {
         const int np = (h->M + 1) / 2;
-        std::vector<f32x2> g, g64;  // [dir][pair][1024]
+        std::vector<f32x2> g, g64, gil;  // [dir][pair][1024]
         for (int d = 0; d < h->n_dirs; ++d) {
+            if (h->d_gains_il[0]) {
+                const std::vector<f32x2> gi = das_pair_gains_interleaved(h->steer[d], np);
+                gil.insert(gil.end(), gi.begin(), gi.end());
+            }
             const std::vector<f32x2> gd = fused_das_gen(h) ? das_pair_gains_natural(h->steer[d], np) : das_pair_gains(h->steer[d], np);
             g.insert(g.end(), gd.begin(), gd.end());
             if (h->use_w64) {
@@ -136,6 +142,8 @@ int sync_tables(bf_handle *h, hipStream_t s, RunSnapshot *snap) {
         BF_HIP(h, hipMemcpyAsync(h->d_gains[nxt], g.data(), g.size() * sizeof(f32x2), hipMemcpyHostToDevice, s));
         if (h->use_w64)
             BF_HIP(h, hipMemcpyAsync(h->d_gains_w64[nxt], g64.data(), g64.size() * sizeof(f32x2), hipMemcpyHostToDevice, s));
+        if (h->d_gains_il[0])
+            BF_HIP(h, hipMemcpyAsync(h->d_gains_il[nxt], gil.data(), gil.size() * sizeof(f32x2), hipMemcpyHostToDevice, s));
         BF_HIP(h, hipStreamSynchronize(s));  // pageable staging vectors go out of scope
         h->gains_cur = nxt;
     }
@@ -212,10 +220,18 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     static const int split_env = getenv("BF_DAS_SPLIT2048") ? atoi(getenv("BF_DAS_SPLIT2048")) : 2;
     const bool split2048 = gen && h->N == 2048 && !spectrum_dev && split_env != 0 && h->d_twiddle_split != nullptr;
     const bool split_w64 = split2048 && split_env == 2 && h->d_twiddle_split_w64 != nullptr;
-    long runs = (split_w64 ? (long)h->n_cus * 12 : split2048 ? (long)h->n_cus * 8 : gen ? (long)h->n_cus * gen_per_cu : (long)h->n_cus) / (shared ? h->n_streams : S);
+    // periods below 512 without a dump: 1024 / N frames interleaved into one pass of the 1024-point machinery, a half-wavefront per
+    // run, 16 runs per CU (das_fused_small.hip; BF_DAS_INTERLEAVE=0: the generic kernel, for A/B runs)
+    static const bool il_on = !(getenv("BF_DAS_INTERLEAVE") && atoi(getenv("BF_DAS_INTERLEAVE")) == 0);
+    const bool small = gen && h->N < 1024 && !spectrum_dev && il_on && h->d_gains_il[0] != nullptr && h->d_twiddle_1024 != nullptr;
+    long runs = (small ? (long)h->n_cus * 16 : split_w64 ? (long)h->n_cus * 12 : split2048 ? (long)h->n_cus * 8 : gen ? (long)h->n_cus * gen_per_cu : (long)h->n_cus) / (shared ? h->n_streams : S);
     if (runs < 1) runs = 1;
     long fpc = (F + runs - 1) / runs;
     if (!gen) fpc = ((fpc + 15) / 16) * 16;
+    if (small) {  // whole groups of interleaved frames
+        const long R = 1024 / h->N;
+        fpc = ((fpc + R - 1) / R) * R;
+    }
     const long cps = (F + fpc - 1) / fpc;
 
     if (spectrum_dev) {
@@ -236,7 +252,7 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     a.y = y_dev;
     a.tail_in = h->d_tail[h->tail_cur];
     a.tail_out = h->d_tail[h->tail_cur ^ 1];
-    a.gains = h->use_w64 ? h->d_gains_w64[h->gains_cur] : h->d_gains[h->gains_cur];
+    a.gains = small ? h->d_gains_il[h->gains_cur] : h->use_w64 ? h->d_gains_w64[h->gains_cur] : h->d_gains[h->gains_cur];
     a.twiddle = h->use_w64 ? h->d_twiddle_w64 : h->d_twiddle;
     a.window = h->d_window;
     a.zeros = h->d_zeros;
@@ -265,7 +281,8 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
         for (int d0 = 0; d0 < h->n_dirs; d0 += 16)
             BF_HIP(h, launch_das_fused_dirs(a, d0, h->n_dirs - d0 < 16 ? h->n_dirs - d0 : 16, s));
     } else {
-        BF_HIP(h, split_w64 ? launch_das_fused_2048_w64(a, h->d_twiddle_split_w64, s)
+        BF_HIP(h, small ? launch_das_fused_small(a, h->N, h->d_twiddle_1024, s)
+                  : split_w64 ? launch_das_fused_2048_w64(a, h->d_twiddle_split_w64, s)
                   : split2048 ? launch_das_fused_2048(a, h->d_twiddle_split, s)
                   : gen     ? launch_das_fused_gen(a, h->N, s)
                   : h->use_w64 ? launch_das_fused_w64(a, s) : launch_das_fused(a, s));
@@ -420,6 +437,13 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
         h->use_w64 = !fused_das_gen(h) && getenv("BF_DAS_W64") && atoi(getenv("BF_DAS_W64")) != 0;
         std::vector<f32x2> tw = twiddle_table_32x32<f32x2>();
         if (fused_das_gen(h)) tw = stockham_twiddles<f32x2>(h->N);  // W^m, m < N/2, + the per-pass radix-4 blocks (geometry.hpp)
+        if (h->N < 1024) {
+            const std::vector<f32x2> t32 = twiddle_table_32x32<f32x2>();
+            BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle_1024, t32.size() * sizeof(f32x2)));
+            BF_CREATE_HIP(hipMemcpy(h->d_twiddle_1024, t32.data(), t32.size() * sizeof(f32x2), hipMemcpyHostToDevice));
+            const size_t gil = (size_t)((h->M + 1) / 2) * 1024 * h->n_dirs;
+            for (int i = 0; i < 2; ++i) BF_CREATE_HIP(hipMalloc((void **)&h->d_gains_il[i], gil * sizeof(f32x2)));
+        }
         if (h->N == 2048) {
             const std::vector<f32x2> ts = twiddle_table_split2048();
             BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle_split, ts.size() * sizeof(f32x2)));
@@ -479,6 +503,9 @@ void bf_destroy(bf_handle *h) {
     if (h->d_twiddle_w64) (void)hipFree(h->d_twiddle_w64);
     if (h->d_twiddle_split) (void)hipFree(h->d_twiddle_split);
     if (h->d_twiddle_split_w64) (void)hipFree(h->d_twiddle_split_w64);
+    if (h->d_twiddle_1024) (void)hipFree(h->d_twiddle_1024);
+    for (int i = 0; i < 2; ++i)
+        if (h->d_gains_il[i]) (void)hipFree(h->d_gains_il[i]);
     if (h->d_window) (void)hipFree(h->d_window);
     if (h->d_zeros) (void)hipFree(h->d_zeros);
     if (h->d_sdump) (void)hipFree(h->d_sdump);

@@ -672,6 +672,7 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
         BF_BSTAMP(5);
         P = Pn;
         ++it;
+        (void)it;
     }
     BF_STATS_FLUSH;
 }

@@ -177,6 +177,26 @@ inline std::vector<f32x2> das_pair_gains_natural(const SteeringSet &s, int n_pai
 }
 
 
+// Frame-interleaving kernel (das_fused_small.hip; N = 512 / 256 / 128): the N-point pair gains repeated 1024 / N times over the bins of
+// the 1024-point transform, 1/1024 folded in, in the register / lane order of fft1024: [pair][position i][lane l] = D_p[(l + 32 brev5(i)) mod N]
+inline std::vector<f32x2> das_pair_gains_interleaved(const SteeringSet &s, int n_pairs_alloc) {
+    const int N = s.n_fft, M = s.n_mics;
+    std::vector<f32x2> D((size_t)n_pairs_alloc * 1024, f32x2{0.f, 0.f});
+    auto ce = [&](int m, int k) -> cplxd {
+        if (m >= M) return cplxd(0, 0);
+        const cplxd c1 = std::conj(s.at(k, m, 0)) / (double)M, c2 = std::conj(s.at((N - k) % N, m, 0)) / (double)M;
+        return 0.5 * (c1 + std::conj(c2));
+    };
+    for (int p = 0; p < (M + 1) / 2; ++p)
+        for (int i = 0; i < 32; ++i)
+            for (int l = 0; l < 32; ++l) {
+                const int k = (l + 32 * brev5(i)) % N;
+                const cplxd d = (ce(2 * p, k) - cplxd(0, 1) * ce(2 * p + 1, k)) / 1024.0;
+                D[((size_t)p * 32 + i) * 32 + l] = f32x2{(float)d.real(), (float)d.imag()};
+            }
+    return D;
+}
+
 // Same gains in the register/lane order of the 64-lane factorisation (fft1024_w64.hpp):
 // [pair][register r][lane] = D_p[w64_bin(lane, r)].
 inline std::vector<f32x2> das_pair_gains_w64(const std::vector<f32x2> &D32, int n_pairs) {

@@ -54,6 +54,10 @@ hipError_t launch_das_fused_gen(const DasFusedArgs &a, int n_fft, hipStream_t st
 // launch_das_fused_gen, tw_split = twiddle_table_split2048(); a.frames_per_chunk / a.chunks_per_stream = frames per run / runs per OUTPUT
 // stream (a half-wavefront per run).  hipErrorNotSupported with a spectrum dump (launch_das_fused_gen serves that).
 hipError_t launch_das_fused_2048(const DasFusedArgs &a, const f32x2 *tw_split, hipStream_t stream);
+// JACK periods 256 / 128 / 64 (n_fft = 512 / 256 / 128; das_fused_small.hip): 1024 / n_fft frames interleaved into one pass of the 1024-point
+// machinery.  a.gains = das_pair_gains_interleaved tables [dir][pair][1024], a.window = the n_fft-point window, tw1024 = twiddle_table_32x32;
+// a.frames_per_chunk (a multiple of 1024 / n_fft) / a.chunks_per_stream = frames per run / runs per OUTPUT stream; no spectrum dump
+hipError_t launch_das_fused_small(const DasFusedArgs &a, int n_fft, const f32x2 *tw1024, hipStream_t stream);
 // the same on the 64-lane transform, one full wavefront per run (das_fused_w64.hip); tw_split = twiddle_table_split2048_w64()
 hipError_t launch_das_fused_2048_w64(const DasFusedArgs &a, const f32x2 *tw_split, hipStream_t stream);
 hipError_t launch_das_hermitian_dump_gen(const f32x2 *sdump, f64x2 *out, long n_frames_total, int n_fft, hipStream_t stream);
