@@ -185,7 +185,10 @@ int bf_process_hop(bf_handle *h, const float *const *in, float *out, uint32_t nf
 /* n_frames consecutive callbacks per stream in one call, host buffers.
  * x: layout per cfg.layout with n_frames*hop samples per mic;
  * y: [n_streams][n_frames*hop].  State carries over to the next call exactly
- * as consecutive callbacks would. */
+ * as consecutive callbacks would.  Rounding: the das kernels that pack several frames of a batch into one transform (das in double on
+ * planar input: two; fp32 das at periods below 512 frames: 1024 / (2 hop)) choose the frames by their position in the batch, so the same
+ * stream cut differently agrees to the last bits of the float output (<= 1e-6 of its scale), not bit for bit; every cut is within the
+ * stated tolerance of the reference arithmetic. */
 int bf_process_batch(bf_handle *h, const float *x_host, size_t n_frames, float *y_host);
 
 /* Same, buffers already resident in HBM; enqueued on `hip_stream`
