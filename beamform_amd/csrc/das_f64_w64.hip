@@ -666,6 +666,16 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
                 float *to = a.tail_out + (long)stream * kHop;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) to[(unsigned)(64 * j + lane)] = tl[j];
+                // ... and the ring-buffer carry (util.h:305-308): the last input hop, into the OTHER hist buffer (frame 0 of this launch may
+                // still be reading the current one)
+                if (a.hist_out != nullptr) {
+                    float *ho = a.hist_out + (long)stream * M * kHop;
+                    for (int m = 0; m < M; ++m) {
+                        const float *xl = xs + (long)m * a.mic_stride + tL * kHop;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ho[m * kHop + 64 * j + lane] = xl[(unsigned)(64 * j + lane)];
+                    }
+                }
             }
         }
         BF_STAMP(4 + 3 * it);
@@ -684,6 +694,8 @@ static bool use_pair_kernel(const DasF64Args &a) {
     static const bool on = !(getenv("BF_DAS_F64_PAIR") && atoi(getenv("BF_DAS_F64_PAIR")) == 0);
     return on && a.layout == 0 && a.gains_mic != nullptr;
 }
+
+bool das_f64_writes_hist(const DasF64Args &a) { return use_pair_kernel(a) && a.hist_out != nullptr; }
 
 // frames per run: a multiple of one step of the block (8 frames, 16 in the frame-pair kernel), about one run per CU
 static void das_f64_w64_runs(const DasF64Args &a, int n_cus, long *fpc, long *cps) {

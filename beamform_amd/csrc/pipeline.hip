@@ -119,7 +119,7 @@ class BinPipelineImpl : public BinPipeline {
             PIPE_HIP(hipMalloc((void **)&d_tw_w64_, tw64.size() * sizeof(f64x2)));
             PIPE_HIP(hipMemcpy(d_tw_w64_, tw64.data(), tw64.size() * sizeof(f64x2), hipMemcpyHostToDevice));
         }
-        PIPE_HIP(hipMalloc((void **)&d_hist_, (size_t)S_ * M_ * H_ * sizeof(float)));
+        for (int i = 0; i < 2; ++i) PIPE_HIP(hipMalloc((void **)&d_hist2_[i], (size_t)S_ * M_ * H_ * sizeof(float)));
         PIPE_HIP(hipMalloc((void **)&d_tail_[0], (size_t)So_ * H_ * sizeof(float)));
         PIPE_HIP(hipMalloc((void **)&d_tail_[1], (size_t)So_ * H_ * sizeof(float)));
         if (Phist_ > 0) PIPE_HIP(hipMalloc((void **)&d_zhist_, zhist_bytes()));
@@ -134,7 +134,8 @@ class BinPipelineImpl : public BinPipeline {
     }
 
     int reset(hipStream_t st) override {
-        PIPE_HIP(hipMemsetAsync(d_hist_, 0, (size_t)S_ * M_ * H_ * sizeof(float), st));
+        PIPE_HIP(hipMemsetAsync(d_hist2_[0], 0, (size_t)S_ * M_ * H_ * sizeof(float), st));
+        hist_cur_ = 0;
         PIPE_HIP(hipMemsetAsync(d_tail_[0], 0, (size_t)So_ * H_ * sizeof(float), st));
         PIPE_HIP(hipMemsetAsync(d_tail_[1], 0, (size_t)So_ * H_ * sizeof(float), st));
         tail_cur_ = 0;
@@ -230,7 +231,7 @@ class BinPipelineImpl : public BinPipeline {
     int copy_state(char *p, bool to_host) {
         PIPE_HIP(hipDeviceSynchronize());
         struct Seg { void *d; size_t n; } segs[] = {
-            {d_hist_, (size_t)S_ * M_ * H_ * 4}, {d_tail_[tail_cur_], (size_t)So_ * H_ * 4}, {d_zhist_, zhist_bytes()},
+            {d_hist2_[hist_cur_], (size_t)S_ * M_ * H_ * 4}, {d_tail_[tail_cur_], (size_t)So_ * H_ * 4}, {d_zhist_, zhist_bytes()},
             {d_gssW_, gss_bytes()}, {d_mpf_, mpf_bytes()}, {d_smooth_, smooth_bytes()}, {d_nlms_, nlms_bytes()}};
         for (auto &s : segs) {
             if (!s.n) continue;
@@ -254,7 +255,7 @@ class BinPipelineImpl : public BinPipeline {
     }
 
     void free_all() {
-        void *ptrs[] = {d_dasg_[0], d_dasg_[1], d_dasg_w64_[0], d_dasg_w64_[1], d_dasg_mic_[0], d_dasg_mic_[1], d_tw_w64_, d_tw32_, d_tw_, d_win_, d_freq_, d_steer_[0], d_steer_[1], d_hist_, d_tail_[0], d_tail_[1], d_zhist_,
+        void *ptrs[] = {d_dasg_[0], d_dasg_[1], d_dasg_w64_[0], d_dasg_w64_[1], d_dasg_mic_[0], d_dasg_mic_[1], d_tw_w64_, d_tw32_, d_tw_, d_win_, d_freq_, d_steer_[0], d_steer_[1], d_hist2_[0], d_hist2_[1], d_tail_[0], d_tail_[1], d_zhist_,
                         d_gssW_, d_mpf_, d_smooth_, d_nlms_, d_Z_, d_Yh_, d_yraw_, d_frames_};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
@@ -277,7 +278,8 @@ class BinPipelineImpl : public BinPipeline {
     f64x2 *d_tw_w64_ = nullptr;                  // twiddle_table_w64_rot
     f64x2 *d_dasg_mic_[2] = {nullptr, nullptr};  // das_mic_gains_w64_f64 (frame-pair kernel)
     int steer_cur_ = 0;
-    float *d_hist_ = nullptr;
+    float *d_hist2_[2] = {nullptr, nullptr};  // ring hop in front of the next batch; two buffers: das_f64_pair_kernel writes the carry itself
+    int hist_cur_ = 0;
     float *d_tail_[2] = {nullptr, nullptr};
     int tail_cur_ = 0;
     f64x2 *d_zhist_ = nullptr;   // [stream][Phist][NP][1024] elements of zsz_ bytes: packed spectra of the previous Phist frames
@@ -310,7 +312,7 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     if (das_one_launch_shape() && fuse_env0 == 1 && spectrum == nullptr && snap.das_gains != nullptr &&
         (layout == BF_PLANAR || (w64 && snap.das_gains_w64 != nullptr))) {
         DasF64Args da;
-        da.x = x; da.hist = d_hist_; da.y = y; da.tail_in = d_tail_[tail_cur_]; da.tail_out = d_tail_[tail_cur_ ^ 1];
+        da.x = x; da.hist = d_hist2_[hist_cur_]; da.hist_out = d_hist2_[hist_cur_ ^ 1]; da.y = y; da.tail_in = d_tail_[tail_cur_]; da.tail_out = d_tail_[tail_cur_ ^ 1];
         da.gains = snap.das_gains; da.tw = d_tw_; da.win = d_win_; da.n_frames = F; da.mic_stride = mic_stride;
         da.stream_stride_x = (long)M_ * F * H_; da.n_streams = S_; da.n_mics = M_; da.run_len = 1;
         // BF_DAS_F64_W64=0: the 32 x 32 half-wavefront kernel (das_f64_fused_kernel) instead of the 64-lane one
@@ -327,11 +329,13 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
             }
         }
         if (de == hipSuccess) {  // ring-buffer carry (util.h:305-308)
-            if (layout == BF_PLANAR)
-                PIPE_HIP(hipMemcpy2DAsync(d_hist_, H_ * sizeof(float), x + (F - 1) * H_, (size_t)mic_stride * sizeof(float),
+            if (use_w64 && das_f64_writes_hist(da)) {
+                hist_cur_ ^= 1;  // das_f64_pair_kernel stored the last hop into the other buffer
+            } else if (layout == BF_PLANAR)
+                PIPE_HIP(hipMemcpy2DAsync(d_hist2_[hist_cur_], H_ * sizeof(float), x + (F - 1) * H_, (size_t)mic_stride * sizeof(float),
                                           H_ * sizeof(float), (size_t)S_ * M_, hipMemcpyDeviceToDevice, stream));
             else
-                PIPE_HIP(hipMemcpy2DAsync(d_hist_, (size_t)H_ * M_ * sizeof(float), x + (F - 1) * (long)H_ * M_,
+                PIPE_HIP(hipMemcpy2DAsync(d_hist2_[hist_cur_], (size_t)H_ * M_ * sizeof(float), x + (F - 1) * (long)H_ * M_,
                                           (size_t)F * H_ * M_ * sizeof(float), (size_t)H_ * M_ * sizeof(float), (size_t)S_,
                                           hipMemcpyDeviceToDevice, stream));
             tail_cur_ ^= 1;
@@ -374,7 +378,7 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
                                   (size_t)Phist_ * frame_elems * zsz_, (size_t)S_, hipMemcpyDeviceToDevice, stream));
 
     StftArgs sa;
-    sa.x = x; sa.hist = d_hist_; sa.Z = d_Z_; sa.tw = d_tw_; sa.win = d_win_;
+    sa.x = x; sa.hist = d_hist2_[hist_cur_]; sa.Z = d_Z_; sa.tw = d_tw_; sa.win = d_win_;
     sa.n_frames = F; sa.frames_ws = FT; sa.frame_off = Phist_; sa.mic_stride = mic_stride;
     sa.stream_stride_x = (long)M_ * F * H_; sa.n_streams = S_; sa.n_mics = M_; sa.n_fft_mics = MF_; sa.layout = layout;
     sa.skip_lo = N_; sa.skip_hi = 0;  // store everything ...
@@ -439,10 +443,10 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
 
     // ring-buffer carry (util.h:305-308)
     if (layout == BF_PLANAR) {
-        PIPE_HIP(hipMemcpy2DAsync(d_hist_, H_ * sizeof(float), x + (F - 1) * H_, (size_t)mic_stride * sizeof(float),
+        PIPE_HIP(hipMemcpy2DAsync(d_hist2_[hist_cur_], H_ * sizeof(float), x + (F - 1) * H_, (size_t)mic_stride * sizeof(float),
                                   H_ * sizeof(float), (size_t)S_ * M_, hipMemcpyDeviceToDevice, stream));
     } else {
-        PIPE_HIP(hipMemcpy2DAsync(d_hist_, (size_t)H_ * M_ * sizeof(float), x + (F - 1) * (long)H_ * M_,
+        PIPE_HIP(hipMemcpy2DAsync(d_hist2_[hist_cur_], (size_t)H_ * M_ * sizeof(float), x + (F - 1) * (long)H_ * M_,
                                   (size_t)F * H_ * M_ * sizeof(float), (size_t)H_ * M_ * sizeof(float), (size_t)S_,
                                   hipMemcpyDeviceToDevice, stream));
     }

@@ -113,6 +113,7 @@ struct DasF64Args {
     long n_frames, mic_stride, stream_stride_x;
     int n_streams, n_mics, run_len;
     int layout = 0;        // bf_layout of x and hist; 1 (interleaved) only with launch_das_f64_w64
+    float *hist_out = nullptr;         // das_f64_pair_kernel: receives the last hop of the batch (the ring-buffer carry), layout as hist
     const f64x2 *gains_mic = nullptr;  // das_mic_gains_w64_f64: per-microphone Hermitian gains of the frame-pair kernel (planar input)
 };
 
@@ -121,6 +122,7 @@ struct DasF64Args {
 // launch.  hipErrorNotSupported above 8 microphones.
 hipError_t prepare_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s);
 hipError_t launch_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s);
+bool das_f64_writes_hist(const DasF64Args &a);  // the kernel launch_das_f64_w64 picks stores a.hist_out itself (no copy behind it)
 
 #ifdef BF_NFFT
 namespace BF_NTAG {

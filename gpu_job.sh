@@ -1,10 +1,6 @@
 cd /root/repo
 export TMPDIR=/tmp
-timeout 2400 python -m pytest tests/ -q -m gpu > gpurun_out/full_gpu.log 2>&1; tail -6 gpurun_out/full_gpu.log
-timeout 900 python bench.py > gpurun_out/r04_c_bench_das8.json 2> gpurun_out/r04_c_bench.err; python - <<'PY'
+timeout 1200 python -m pytest tests/test_fused_bins_gpu.py tests/test_variants_gpu.py tests/test_das_gpu.py tests/test_pipeline_gpu.py tests/test_edges_gpu.py -q > gpurun_out/t1.log 2>&1; tail -4 gpurun_out/t1.log
+timeout 300 python bench.py --no-cpu --no-extra > gpurun_out/t.json 2>/dev/null; python -c "
 import json
-d=json.loads([l for l in open('gpurun_out/r04_c_bench_das8.json') if l.startswith('{')][0])
-print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['kernel_ms'])
-for k,v in d['extra'].items():
-    if isinstance(v,dict): print(k, v.get('ms_per_step'))
-PY
+d=json.loads([l for l in open('gpurun_out/t.json') if l.startswith('{')][0]); print(d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'])"

@@ -49,6 +49,7 @@ const KernelSet *kernel_set_n4096() { return &g_stub_set; }
 const KernelSet *kernel_set_n8192() { return &g_stub_set; }
 hipError_t prepare_das_f64_w64(const DasF64Args &, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_das_f64_w64(const DasF64Args &, int, hipStream_t) { return hipSuccess; }
+bool das_f64_writes_hist(const DasF64Args &) { return false; }
 
 hipError_t prepare_das_fused(const DasFusedArgs &, hipStream_t) { return hipSuccess; }
 hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t) {
