@@ -1,5 +1,7 @@
 // gsc_gss_kernels.hip -- the two adaptive nodes: gss (per-bin demixing-matrix recursion) and gsc (per-microphone alignment
 // + sample-serial float32 NLMS).
+#include <cstdlib>
+
 #include "bins_common.hpp"
 
 namespace bf {
@@ -226,6 +228,191 @@ __global__ __launch_bounds__(64) void gsc_nlms_kernel(const float *aligned, floa
     for (int k = lane; k < fs; k += 64) sv[2 * nb * fs + k] = s_lo[h + k];
 }
 
+// Pass 2, taps over the lanes (the default; BF_GSC_SERIAL=1 selects the kernel above).  The sample loop stays serial -- the filter that
+// produces sample n was updated with sample n - 1 -- but inside a sample the filter_size-tap dot products of the nb blocking branches, their
+// window powers and the output window's power are spread over the 64 lanes (tap k = lane + 64 c) and summed by DPP butterflies inside the
+// 16-lane rows plus four v_readlane: ~200 vector instructions per sample instead of a dependent chain of filter_size additions per lane
+// with an LDS round trip every eight taps (3 us per sample: 99 ms per 256 streams x 64 frames).  Every product and partial sum still
+// rounds on its own (no FMA contraction); what changes against the reference is the ORDER of the float additions inside a sum
+// (pairwise instead of tap 0, 1, 2, ...): results agree to float rounding of the sums (1e-7 relative per sample, observed <= 1e-6 on
+// the output against the oracle), not bit for bit; the comparisons the reference branches on see the same quantities.
+template <int CTRL>
+__device__ __forceinline__ float gsc_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 64 lanes, the same value in every lane (separately rounded float additions, pairwise order): butterflies inside the
+// 16-lane rows, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3, and lane 63 holds the total
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float gsc_dpp_rows(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float gsc_wave_sum(float v) {
+#pragma clang fp contract(off)
+    v = v + gsc_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = v + gsc_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = v + gsc_dpp<0x141>(v);  // row_half_mirror
+    v = v + gsc_dpp<0x140>(v);  // row_mirror: every lane of a 16-lane row holds the row's sum
+    v = v + gsc_dpp_rows<0x142, 0xA>(v);  // rows 1, 3 += lane 15 of rows 0, 2
+    v = v + gsc_dpp_rows<0x143, 0xC>(v);  // rows 2, 3 += lane 31
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+template <int NBM, int KPL>  // NBM >= blocking branches (M - 1), KPL >= ceil(filter_size / 64)
+__global__ __launch_bounds__(64) void gsc_nlms_par_kernel(const float *aligned, float *y, float *state, long n, int M, int fs,
+                                                          int use_vad, double vad_threshold, double mu0, double mu_max) {
+#pragma clang fp contract(off)
+    extern __shared__ float gl[];
+    const int lane = threadIdx.x;
+    const int nb = M - 1;                 // blocking branches
+    const int nbr = nb > 0 ? nb : 1;
+    const int bstride = (fs + 64 * KPL + 8) | 1;  // mirrored ring: a window starts at h1 < fs; reads past it land in the row padding
+    float *s_bm = gl;                     // [nb][bstride]
+    float *s_lo = s_bm + nbr * bstride;   // [2*fs + 64*KPL]
+    float *s_d = s_lo + 2 * fs + 64 * KPL + 16;  // [nb][64] neighbour differences of the current tile
+    float *s_das = s_d + nbr * 64;        // [64] upper beamformer of the current tile
+    float *s_out = s_das + 64;            // [64]
+    const int s = blockIdx.x;
+    const float *as = aligned + (long)s * M * n;
+    float *ys = y + (long)s * n;
+    float *sv = state + (long)s * (2 * nb + 1) * fs;
+    float freg[NBM][KPL];  // filter taps k = lane + 64 c of every branch
+    bool tap_ok[KPL];
+#pragma unroll
+    for (int c = 0; c < KPL; ++c) tap_ok[c] = lane + 64 * c < fs;
+#pragma unroll
+    for (int i = 0; i < NBM; ++i)
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) {
+            const int k = lane + 64 * c;
+            float v = 0.f;
+            if (i < nb && k < fs) {
+                const float b = sv[i * fs + k];
+                s_bm[i * bstride + k] = b;
+                s_bm[i * bstride + k + fs] = b;
+                v = sv[nb * fs + i * fs + k];
+            }
+            freg[i][c] = v;
+        }
+    for (int k = lane; k < fs; k += 64) {
+        const float v = sv[2 * nb * fs + k];
+        s_lo[k] = v;
+        s_lo[k + fs] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    int h = 0;  // ring position of the oldest element (same for every window: all advance once per sample)
+    const float fsz = (float)fs;
+    for (long n0 = 0; n0 < n; n0 += 64) {
+        {   // tile prologue, lane = sample: das_out (gsc.cpp:122-127) and the blocking-matrix inputs (gsc.cpp:131)
+            const bool ok = n0 + lane < n;
+            float prev = ok ? as[n0 + lane] : 0.f, das = 0.f;
+            das = (das + prev);
+            for (int m = 1; m < M; ++m) {
+                const float cur = ok ? as[(long)m * n + n0 + lane] : 0.f;
+                das = (das + cur);
+                s_d[(m - 1) * 64 + lane] = (cur - prev);
+                prev = cur;
+            }
+            s_das[lane] = __fdiv_rn(das, (float)M);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int cnt = (n - n0) < 64 ? (int)(n - n0) : 64;
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float das = s_das[jj];
+            if (lane < nb) {
+                const float d = s_d[lane * 64 + jj];
+                s_bm[lane * bstride + h] = d;
+                s_bm[lane * bstride + h + fs] = d;
+            }
+            const int h1 = (h + 1 == fs) ? 0 : h + 1;  // window = [h1, h1 + fs)
+            __builtin_amdgcn_wave_barrier();
+            // block_out_i = sum_k filter_i[k] u_i[k] and the power sum_k u_i[k]^2 of every branch: this lane's taps, then the wave sums
+            // (unconditional loads -- rows are padded to 64 KPL taps -- and a select: a load inside the condition compiles to a branch per tap)
+            float bmv[NBM][KPL];
+#pragma unroll
+            for (int i = 0; i < NBM; ++i)
+#pragma unroll
+                for (int c = 0; c < KPL; ++c) bmv[i][c] = s_bm[(i < nb ? i : 0) * bstride + h1 + lane + 64 * c];
+            // the output window WITHOUT its newest element (known only below): taps 0 .. fs - 2
+            float lov[KPL];
+#pragma unroll
+            for (int c = 0; c < KPL; ++c) lov[c] = s_lo[h1 + lane + 64 * c];
+#pragma unroll
+            for (int c = 0; c < KPL; ++c) {
+#pragma unroll
+                for (int i = 0; i < NBM; ++i) bmv[i][c] = tap_ok[c] ? bmv[i][c] : 0.f;
+                lov[c] = (lane + 64 * c < fs - 1) ? lov[c] : 0.f;
+            }
+            float out = das, pws[NBM];
+#pragma unroll
+            for (int i = 0; i < NBM; ++i) {
+                float pb = 0.f, pp = 0.f;
+#pragma unroll
+                for (int c = 0; c < KPL; ++c) {
+                    pb = (pb + (freg[i][c] * bmv[i][c]));
+                    pp = (pp + (bmv[i][c] * bmv[i][c]));
+                }
+                pws[i] = 0.f;
+                if (i < nb) {  // uniform
+                    out = out - gsc_wave_sum(pb);
+                    pws[i] = gsc_wave_sum(pp);
+                }
+            }
+            float pl = 0.f;
+#pragma unroll
+            for (int c = 0; c < KPL; ++c) pl = (pl + (lov[c] * lov[c]));
+            const float pwl = gsc_wave_sum(pl);
+            const float lop = __fsqrt_rn(__fdiv_rn((pwl + (out * out)), fsz));  // calculate_power(last_outputs)
+            if (lane == 0) {
+                s_lo[h] = out;
+                s_lo[h + fs] = out;
+                s_out[jj] = out;
+            }
+            const bool adapt = ((double)lop < vad_threshold) || !use_vad;  // gsc.cpp:147
+            if (adapt && nb > 0) {
+                // filter[i][k] += this_mu*out[j]*block_matrix[i][k] (gsc.cpp:163-170).  Lane i works out branch i's step size (two double
+                // divisions: once per branch, not once per lane and branch), the products mu_i * out travel by v_readlane
+                float mypw = 0.f;
+#pragma unroll
+                for (int i = 0; i < NBM; ++i) mypw = lane == i ? pws[i] : mypw;
+                const float bp = __fsqrt_rn(__fdiv_rn(mypw, fsz));
+                float mu;
+                if (mu0 * (double)bp / (double)lop < mu_max)  // gsc.cpp:153-157 (double arithmetic: mu0 is a double)
+                    mu = (float)(mu0 / (double)lop);
+                else
+                    mu = (float)(mu0 / (double)bp);
+                if (isnan(mu) || isinf(mu)) mu = 0.f;
+                const float cvl = (mu * out);
+#pragma unroll
+                for (int i = 0; i < NBM; ++i)
+                    if (i < nb) {  // uniform
+                        const float cv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cvl), i));
+#pragma unroll
+                        for (int c = 0; c < KPL; ++c) {
+                            float fv = (freg[i][c] + (cv * bmv[i][c]));
+                            if (isnan(fv)) fv = 0.f;
+                            freg[i][c] = tap_ok[c] ? fv : 0.f;
+                        }
+                    }
+            }
+            __builtin_amdgcn_wave_barrier();
+            h = h1;
+        }
+        if (lane < cnt) ys[n0 + lane] = s_out[lane];
+        __builtin_amdgcn_wave_barrier();
+    }
+    // carried state in the reference's (shifted, oldest-first) order
+    for (int e = lane; e < nb * fs; e += 64) {
+        const int i = e / fs, k = e - i * fs;
+        sv[e] = s_bm[i * bstride + h + k];
+    }
+#pragma unroll
+    for (int i = 0; i < NBM; ++i)
+#pragma unroll
+        for (int c = 0; c < KPL; ++c)
+            if (i < nb && tap_ok[c]) sv[nb * fs + i * fs + lane + 64 * c] = freg[i][c];
+    for (int k = lane; k < fs; k += 64) sv[2 * nb * fs + k] = s_lo[h + k];
+}
+
 // ======================================================================================
 //                              gss: geometric source separation
 // ======================================================================================
@@ -419,11 +606,21 @@ hipError_t launch_gsc_nlms(const float *aligned, float *y, float *state, long n_
                            const bf_config &cfg, hipStream_t s) {
     const int fs = cfg.gsc_filter_size, nb = n_mics - 1, nbr = nb > 0 ? nb : 1;
     const int kpl = (fs + 63) / 64, kp = kpl <= 1 ? 1 : kpl <= 2 ? 2 : 4;
-    const size_t lds = sizeof(float) * ((size_t)nbr * ((fs + 64 * kp + 8) | 1) + (size_t)nbr * ((64 * kp + 8) | 1) + 2 * fs + 16 +
-                                        (size_t)nbr * 64 + 64 + 16 + 64);
-#define BF_NLMS(NBM_, KPL_)                                                                                              \
-    hipLaunchKernelGGL((gsc_nlms_kernel<NBM_, KPL_>), dim3((unsigned)n_streams), dim3(64), lds, s, aligned, y, state,    \
-                       n_samples, n_mics, fs, cfg.gsc_use_vad, cfg.gsc_vad_threshold, cfg.gsc_mu0, cfg.gsc_mu_max)
+    // BF_GSC_SERIAL=1: the sums in the reference's tap order, one branch per lane (gsc_nlms_kernel); default: taps over the lanes
+    static const bool serial = getenv("BF_GSC_SERIAL") && atoi(getenv("BF_GSC_SERIAL")) == 1;
+    const size_t lds_serial = sizeof(float) * ((size_t)nbr * ((fs + 64 * kp + 8) | 1) + (size_t)nbr * ((64 * kp + 8) | 1) + 2 * fs + 16 +
+                                               (size_t)nbr * 64 + 64 + 16 + 64);
+    const size_t lds_par = sizeof(float) * ((size_t)nbr * ((fs + 64 * kp + 8) | 1) + 2 * fs + 64 * kp + 16 + (size_t)nbr * 64 + 64 + 64);
+    const size_t lds = serial ? lds_serial : lds_par;
+#define BF_NLMS(NBM_, KPL_)                                                                                                        \
+    do {                                                                                                                            \
+        if (serial)                                                                                                                 \
+            hipLaunchKernelGGL((gsc_nlms_kernel<NBM_, KPL_>), dim3((unsigned)n_streams), dim3(64), lds, s, aligned, y, state,       \
+                               n_samples, n_mics, fs, cfg.gsc_use_vad, cfg.gsc_vad_threshold, cfg.gsc_mu0, cfg.gsc_mu_max);         \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((gsc_nlms_par_kernel<NBM_, KPL_>), dim3((unsigned)n_streams), dim3(64), lds, s, aligned, y, state,   \
+                               n_samples, n_mics, fs, cfg.gsc_use_vad, cfg.gsc_vad_threshold, cfg.gsc_mu0, cfg.gsc_mu_max);         \
+    } while (0)
 #define BF_NLMS_K(NBM_)                     \
     do {                                    \
         if (kpl <= 1) BF_NLMS(NBM_, 1);     \

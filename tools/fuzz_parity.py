@@ -15,7 +15,8 @@ worst = {}
 for case in range(n_cases):
     algo = rng.choice(["das", "mvdr", "lcmv", "gss", "phase", "phasempf", "mcra", "gsc"])
     M = int(rng.integers(1 if algo in ("das", "mcra", "gsc", "phase") else 2, 17))
-    K = int(rng.integers(0, min(3, M - 1) + 1)) if algo in ("lcmv", "gss") else 0
+    # lcmv with as many constraints as microphones (K + 1 = M) is the documented no-parity-claim case (include/bfcore.h, bf_set_interference): K + 1 < M
+    K = int(rng.integers(0, max(min(3, M - (2 if algo == "lcmv" else 1)), 0) + 1)) if algo in ("lcmv", "gss") else 0
     interf = tuple(float(a) for a in rng.choice([-150.0, -100.0, -60.0, -20.0, 45.0, 90.0, 150.0], size=K, replace=False))
     theta = float(rng.uniform(-180, 180))
     F = int(rng.integers(3, 40 if algo != "gsc" else 10))
