@@ -530,6 +530,9 @@ def main():
                                          note="BASELINE config 5, one GPU's shard of the 262144-frame stream; " + noise)),
             ("gss", lambda: node_line("gss", 8, 256, 256, (-60.0, 90.0), with_traffic=False,
                                       note="gss 8-mic, 2 interferers, 256 streams x 256 frames (the demixing matrices recurse over the frames of a stream); " + noise)),
+            ("gsc", lambda: node_line("gsc", 8, 64, 256, iters=3, with_traffic=False,
+                                      note="gsc 8-mic (SURVEY 8(f) row 1), 256 streams x 64 frames: STFT + per-microphone alignment + fp64 ISTFT, then the "
+                                           "sample-serial float NLMS with the 128 taps of the 7 blocking branches over a wavefront's lanes; " + noise)),
             ("lcmv8", lambda: node_line("lcmv", M, F, 1, (-60.0, 90.0), xin=x, with_traffic=False,
                                         note="lcmv on the headline array (8 microphones, 2 interferers): mvdr_fast_kernel<8, 3>; " + noise)),
         ]
