@@ -139,6 +139,38 @@ __device__ __forceinline__ cd phase_core(const cd (&X)[MP], const cd (&w)[MP], i
     const double sc = mag * fast_rcp(ab[0]);
     return cd{sc * X[0].x, sc * X[0].y};
 }
+// phase_core with the steering entries fetched only where the magnitude gate is open (stft_bins_w64_kernel re-reads them per item from
+// L1 / L2: on a frame below the gate that is 128 bytes per bin for nothing); the same arithmetic, bit for bit
+template <int MP>
+__device__ __forceinline__ cd phase_core_lazy(const cd (&X)[MP], const f64x2 *steer, int M, int j, const bf_config &cfg) {
+    if (j == 0) return X[0];
+    double ab[MP], mag = 0.0;
+    cabs_n<MP>(X, ab);
+#pragma unroll
+    for (int m = 0; m < MP; ++m)
+        if (m < M) mag += ab[m];
+    mag = div_rcp(mag, (double)M, 1.0 / (double)M);
+    bool keep = false;
+    const bool open = mag / (double)kN > cfg.mag_threshold;
+    if (__builtin_amdgcn_ballot_w64(open) != 0) {  // wavefront-uniform: nobody loads when every lane is below the gate
+        cd w[MP];
+        load_steer<MP>(steer, j, M, w);
+        if (open) {
+            double uy[MP], ux[MP];
+#pragma unroll
+            for (int m = 0; m < MP; ++m) {
+                const cd u = conj(w[m]) * X[m];
+                uy[m] = u.y;
+                ux[m] = u.x;
+            }
+            keep = phase_is_close<MP>(uy, ux, M, cfg.min_phase * M_PI / 180);
+        }
+    }
+    if (!keep) mag *= cfg.mag_mult;
+    if (ab[0] == 0.0) return cd{mag, 0.0};
+    const double sc = mag * fast_rcp(ab[0]);
+    return cd{sc * X[0].x, sc * X[0].y};
+}
 template <int MP>
 __device__ __forceinline__ cd phase_bin(const BinCtx &c, const bf_config &cfg) {
     cd X[MP], w[MP];
@@ -775,7 +807,7 @@ __global__ __launch_bounds__(512) void stft_bins_w64_kernel(StftArgs a, BinsArgs
         for (int n = 0; n < NIT; ++n) {
             const int q = tt + TT * n, j = q_bin(q);
             cd wst[MP];
-            load_steer<MP>(b.steer, j, M, wst);  // from L1 / L2, in flight while the spectra come out of LDS
+            if (ALGO != BF_PHASE) load_steer<MP>(b.steer, j, M, wst);  // from L1 / L2, in flight while the spectra come out of LDS
             cd X[MP];
             load_X<MP>(zs, q, M, X);
             const long o = ((long)s * b.n_frames + t) * kYhStride + q;
@@ -783,7 +815,7 @@ __global__ __launch_bounds__(512) void stft_bins_w64_kernel(StftArgs a, BinsArgs
                 const cd y = das_core<MP>(X, wst, M);
                 st_y(b, o, q, y);
             } else if (ALGO == BF_PHASE) {
-                const cd y = phase_core<MP>(X, wst, M, j, b.cfg);
+                const cd y = phase_core_lazy<MP>(X, b.steer, M, j, b.cfg);  // steering only where the magnitude gate is open
                 st_y(b, o, q, y);
             } else {  // phasempf mask
                 if (j == 0) {
