@@ -29,6 +29,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <csignal>
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -130,12 +132,24 @@ struct Transport {
     int rank = 0;
     std::string base;  // stub: pipes <base>.<src>.<dst>
     std::vector<float> host;
+    // stub: every pipe is opened once and stays open for the whole run.  (Opening and closing one per message loses data: a sender that
+    // reopens while the receiver still holds the previous message's descriptor writes into a pipe whose last reader then closes --
+    // EPIPE / SIGPIPE on the sender, and the other ranks wait for ever.)
+    std::map<int, int> wfd, rfd;
+    int pipe_fd(std::map<int, int> &m, int peer, const std::string &path, int flags) {
+        auto it = m.find(peer);
+        if (it != m.end()) return it->second;
+        const int fd = open(path.c_str(), flags);  // O_WRONLY blocks until the receiver opens its end, and the reverse
+        if (fd >= 0) m[peer] = fd;
+        return fd;
+    }
 
     int init(int world, int rank_, const char *id_file, bool stub_) {
         stub = stub_;
         rank = rank_;
         base = id_file;
         if (stub) {
+            signal(SIGPIPE, SIG_IGN);  // a vanished peer is a write error here, not a silent death
             for (int r = 1; r < world; ++r) {  // every rank may create them; EEXIST is fine
                 const std::string p = base + "." + std::to_string(r) + ".0";
                 if (mkfifo(p.c_str(), 0600) != 0 && errno != EEXIST) return 1;
@@ -167,7 +181,7 @@ struct Transport {
         CK(hipStreamSynchronize(s));
         CK(hipMemcpy(host.data(), dev, n * sizeof(float), hipMemcpyDeviceToHost));
         const std::string p = base + "." + std::to_string(rank) + "." + std::to_string(peer);
-        const int fd = open(p.c_str(), O_WRONLY);  // blocks until the receiver opens its end
+        const int fd = pipe_fd(wfd, peer, p, O_WRONLY);
         if (fd < 0) return 1;
         unsigned long long hdr = n;
         bool ok = write(fd, &hdr, sizeof(hdr)) == (ssize_t)sizeof(hdr);
@@ -175,16 +189,19 @@ struct Transport {
             const ssize_t w = write(fd, (const char *)host.data() + off, n * sizeof(float) - off);
             if (w <= 0) ok = false; else off += (size_t)w;
         }
-        close(fd);
         return ok ? 0 : 1;
     }
     int recv(float *dev, size_t n, int peer, hipStream_t s) {
         if (!stub) { CKN(ncclRecv(dev, n, ncclFloat, peer, comm, s)); return 0; }
         const std::string p = base + "." + std::to_string(peer) + "." + std::to_string(rank);
-        const int fd = open(p.c_str(), O_RDONLY);
+        const int fd = pipe_fd(rfd, peer, p, O_RDONLY);
         if (fd < 0) return 1;
         unsigned long long hdr = 0;
-        bool ok = read(fd, &hdr, sizeof(hdr)) == (ssize_t)sizeof(hdr);
+        bool ok = true;
+        for (size_t off = 0; ok && off < sizeof(hdr);) {  // (a read on a pipe may return less than asked)
+            const ssize_t r = read(fd, (char *)&hdr + off, sizeof(hdr) - off);
+            if (r <= 0) ok = false; else off += (size_t)r;
+        }
         if (ok && hdr != n) {
             fprintf(stderr, "stub transport: rank %d expects %zu floats from rank %d, which sends %llu\n", rank, n, peer, hdr);
             ok = false;
@@ -194,13 +211,16 @@ struct Transport {
             const ssize_t r = read(fd, (char *)host.data() + off, n * sizeof(float) - off);
             if (r <= 0) ok = false; else off += (size_t)r;
         }
-        close(fd);
         if (!ok) return 1;
         CK(hipStreamSynchronize(s));
         CK(hipMemcpy(dev, host.data(), n * sizeof(float), hipMemcpyHostToDevice));
         return 0;
     }
-    void destroy() { if (comm) ncclCommDestroy(comm); }
+    void destroy() {
+        if (comm) ncclCommDestroy(comm);
+        for (auto &kv : wfd) close(kv.second);
+        for (auto &kv : rfd) close(kv.second);
+    }
 };
 
 int main(int argc, char **argv) {
