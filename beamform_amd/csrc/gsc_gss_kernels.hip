@@ -413,6 +413,187 @@ __global__ __launch_bounds__(64) void gsc_nlms_par_kernel(const float *aligned, 
     for (int k = lane; k < fs; k += 64) sv[2 * nb * fs + k] = s_lo[h + k];
 }
 
+// The same with the blocking branches dealt out to NW wavefronts of one block (branch i belongs to wavefront i mod NW): 256 streams
+// of 8 microphones keep 1 024 wavefronts busy instead of 256.  Per sample two block barriers: behind the branch sums (every wavefront
+// then forms `out`, the output power and the adapt decision from the same numbers, in the same order) and behind the ring updates.
+// Arithmetic and summation order are gsc_nlms_par_kernel's: the results are the same bit for bit.
+template <int NW, int NBL, int KPL>  // NBL >= ceil((M - 1) / NW) branches per wavefront, KPL >= ceil(filter_size / 64)
+__global__ __launch_bounds__(64 * NW) void gsc_nlms_mw_kernel(const float *aligned, float *y, float *state, long n, int M, int fs,
+                                                              int use_vad, double vad_threshold, double mu0, double mu_max) {
+#pragma clang fp contract(off)
+    extern __shared__ float gl[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = M - 1;
+    const int nbr = nb > 0 ? nb : 1;
+    const int bstride = (fs + 64 * KPL + 8) | 1;
+    float *s_bm = gl;                                // [nb][bstride] mirrored rings of the blocking-matrix inputs
+    float *s_lo = s_bm + nbr * bstride;              // [2*fs + 64*KPL + 16] mirrored ring of the outputs
+    float *s_d = s_lo + 2 * fs + 64 * KPL + 16;      // [nb][64] neighbour differences of the current tile
+    float *s_das = s_d + nbr * 64;                   // [64] upper beamformer of the current tile
+    float *s_out = s_das + 64;                       // [64]
+    float *s_bo = s_out + 64;                        // [16] block_out_i of the current sample
+    float *s_pw = s_bo + 16;                         // [16] window power of branch i; [15]: of the output window
+    const int s = blockIdx.x;
+    const float *as = aligned + (long)s * M * n;
+    float *ys = y + (long)s * n;
+    float *sv = state + (long)s * (2 * nb + 1) * fs;
+    float freg[NBL][KPL];  // filter taps k = lane + 64 c of this wavefront's branches wv, wv + NW, ...
+    bool tap_ok[KPL];
+#pragma unroll
+    for (int c = 0; c < KPL; ++c) tap_ok[c] = lane + 64 * c < fs;
+#pragma unroll
+    for (int l = 0; l < NBL; ++l) {
+        const int i = wv + NW * l;
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) {
+            const int k = lane + 64 * c;
+            freg[l][c] = (i < nb && k < fs) ? sv[nb * fs + i * fs + k] : 0.f;
+        }
+    }
+    for (int e = tid; e < nb * fs; e += 64 * NW) {
+        const int i = e / fs, k = e - i * fs;
+        const float b = sv[e];
+        s_bm[i * bstride + k] = b;
+        s_bm[i * bstride + k + fs] = b;
+    }
+    for (int k = tid; k < fs; k += 64 * NW) {
+        const float v = sv[2 * nb * fs + k];
+        s_lo[k] = v;
+        s_lo[k + fs] = v;
+    }
+    int h = 0;
+    const float fsz = (float)fs;
+    for (long n0 = 0; n0 < n; n0 += 64) {
+        __syncthreads();  // the previous tile's s_out has been stored; rings initialised
+        if (wv == 0) {    // tile prologue, lane = sample: das_out (gsc.cpp:122-127) and the blocking-matrix inputs (gsc.cpp:131)
+            const bool ok = n0 + lane < n;
+            float prev = ok ? as[n0 + lane] : 0.f, das = 0.f;
+            das = (das + prev);
+            for (int m = 1; m < M; ++m) {
+                const float cur = ok ? as[(long)m * n + n0 + lane] : 0.f;
+                das = (das + cur);
+                s_d[(m - 1) * 64 + lane] = (cur - prev);
+                prev = cur;
+            }
+            s_das[lane] = __fdiv_rn(das, (float)M);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < nb) {  // the tile's first sample enters the rings
+                const float d = s_d[lane * 64];
+                s_bm[lane * bstride + h] = d;
+                s_bm[lane * bstride + h + fs] = d;
+            }
+        }
+        __syncthreads();
+        const int cnt = (n - n0) < 64 ? (int)(n - n0) : 64;
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float das = s_das[jj];
+            const int h1 = (h + 1 == fs) ? 0 : h + 1;  // window = [h1, h1 + fs)
+            // ---- this wavefront's branches: block_out_i and the window power --------------------------------------------------------
+            float bmv[NBL][KPL];
+#pragma unroll
+            for (int l = 0; l < NBL; ++l) {
+                const int i = wv + NW * l, ir = i < nb ? i : 0;
+#pragma unroll
+                for (int c = 0; c < KPL; ++c) bmv[l][c] = s_bm[ir * bstride + h1 + lane + 64 * c];
+            }
+            float lov[KPL];
+            if (wv == 0) {
+#pragma unroll
+                for (int c = 0; c < KPL; ++c) lov[c] = s_lo[h1 + lane + 64 * c];
+            }
+#pragma unroll
+            for (int l = 0; l < NBL; ++l) {
+                const int i = wv + NW * l;
+                float pb = 0.f, pp = 0.f;
+#pragma unroll
+                for (int c = 0; c < KPL; ++c) {
+                    bmv[l][c] = tap_ok[c] ? bmv[l][c] : 0.f;
+                    pb = (pb + (freg[l][c] * bmv[l][c]));
+                    pp = (pp + (bmv[l][c] * bmv[l][c]));
+                }
+                if (i < nb) {  // uniform
+                    const float sb = gsc_wave_sum(pb), sp = gsc_wave_sum(pp);
+                    if (lane == 0) {
+                        s_bo[i] = sb;
+                        s_pw[i] = sp;
+                    }
+                }
+            }
+            if (wv == 0) {  // the output window WITHOUT its newest element (known only below): taps 0 .. fs - 2
+                float pl = 0.f;
+#pragma unroll
+                for (int c = 0; c < KPL; ++c) {
+                    const float v = (lane + 64 * c < fs - 1) ? lov[c] : 0.f;
+                    pl = (pl + (v * v));
+                }
+                const float sl = gsc_wave_sum(pl);
+                if (lane == 0) s_pw[15] = sl;
+            }
+            __syncthreads();
+            // ---- every wavefront: out, the output power, the adapt decision (same numbers, same order) ---------------------------------
+            float out = das;
+            for (int i = 0; i < nb; ++i) out = out - s_bo[i];
+            const float lop = __fsqrt_rn(__fdiv_rn((s_pw[15] + (out * out)), fsz));  // calculate_power(last_outputs)
+            const bool adapt = ((double)lop < vad_threshold) || !use_vad;          // gsc.cpp:147
+            if (adapt && nb > 0) {
+                // lane i works out branch i's step size (gsc.cpp:153-157, double arithmetic); this wavefront's branches take theirs by v_readlane
+                const float mypw = lane < nb ? s_pw[lane] : 0.f;
+                const float bp = __fsqrt_rn(__fdiv_rn(mypw, fsz));
+                float mu;
+                if (mu0 * (double)bp / (double)lop < mu_max)
+                    mu = (float)(mu0 / (double)lop);
+                else
+                    mu = (float)(mu0 / (double)bp);
+                if (isnan(mu) || isinf(mu)) mu = 0.f;
+                const float cvl = (mu * out);
+#pragma unroll
+                for (int l = 0; l < NBL; ++l) {
+                    const int i = wv + NW * l;
+                    if (i < nb) {  // uniform
+                        const float cv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cvl), i));
+#pragma unroll
+                        for (int c = 0; c < KPL; ++c) {  // filter[i][k] += this_mu*out[j]*block_matrix[i][k]  (gsc.cpp:163-170)
+                            float fv = (freg[l][c] + (cv * bmv[l][c]));
+                            if (isnan(fv)) fv = 0.f;
+                            freg[l][c] = tap_ok[c] ? fv : 0.f;
+                        }
+                    }
+                }
+            }
+            if (wv == 0) {  // the rings move on: this sample's output, the next sample's blocking-matrix inputs
+                if (lane == 0) {
+                    s_lo[h] = out;
+                    s_lo[h + fs] = out;
+                    s_out[jj] = out;
+                }
+                if (jj + 1 < cnt && lane < nb) {
+                    const float d = s_d[lane * 64 + jj + 1];
+                    s_bm[lane * bstride + h1] = d;
+                    s_bm[lane * bstride + h1 + fs] = d;
+                }
+            }
+            __syncthreads();
+            h = h1;
+        }
+        if (wv == 0 && lane < cnt) ys[n0 + lane] = s_out[lane];
+    }
+    __syncthreads();
+    // carried state in the reference's (shifted, oldest-first) order
+    for (int e = tid; e < nb * fs; e += 64 * NW) {
+        const int i = e / fs, k = e - i * fs;
+        sv[e] = s_bm[i * bstride + h + k];
+    }
+#pragma unroll
+    for (int l = 0; l < NBL; ++l) {
+        const int i = wv + NW * l;
+#pragma unroll
+        for (int c = 0; c < KPL; ++c)
+            if (i < nb && tap_ok[c]) sv[nb * fs + i * fs + lane + 64 * c] = freg[l][c];
+    }
+    for (int k = tid; k < fs; k += 64 * NW) sv[2 * nb * fs + k] = s_lo[h + k];
+}
+
 // ======================================================================================
 //                              gss: geometric source separation
 // ======================================================================================
@@ -606,12 +787,38 @@ hipError_t launch_gsc_nlms(const float *aligned, float *y, float *state, long n_
                            const bf_config &cfg, hipStream_t s) {
     const int fs = cfg.gsc_filter_size, nb = n_mics - 1, nbr = nb > 0 ? nb : 1;
     const int kpl = (fs + 63) / 64, kp = kpl <= 1 ? 1 : kpl <= 2 ? 2 : 4;
-    // BF_GSC_SERIAL=1: the sums in the reference's tap order, one branch per lane (gsc_nlms_kernel); default: taps over the lanes
+    // BF_GSC_SERIAL=1: the sums in the reference's tap order, one branch per lane (gsc_nlms_kernel); default: taps over the lanes, the
+    // branches dealt out to BF_GSC_WAVES wavefronts per stream (default 8 from five branches on, 4 from three, 2 at two; 1: gsc_nlms_par_kernel;
+    // 8 microphones, 256 streams x 64 frames: 52.6 / 54.2 / 43.1 / 36.8 ms at 1 / 2 / 4 / 8)
     static const bool serial = getenv("BF_GSC_SERIAL") && atoi(getenv("BF_GSC_SERIAL")) == 1;
+    static const int waves_env = getenv("BF_GSC_WAVES") ? atoi(getenv("BF_GSC_WAVES")) : 0;
+    const int nw = serial ? 1 : waves_env > 0 ? (waves_env >= 8 ? 8 : waves_env >= 4 ? 4 : waves_env >= 2 ? 2 : 1) : (nb >= 5 ? 8 : nb >= 3 ? 4 : nb >= 2 ? 2 : 1);
     const size_t lds_serial = sizeof(float) * ((size_t)nbr * ((fs + 64 * kp + 8) | 1) + (size_t)nbr * ((64 * kp + 8) | 1) + 2 * fs + 16 +
                                                (size_t)nbr * 64 + 64 + 16 + 64);
-    const size_t lds_par = sizeof(float) * ((size_t)nbr * ((fs + 64 * kp + 8) | 1) + 2 * fs + 64 * kp + 16 + (size_t)nbr * 64 + 64 + 64);
+    const size_t lds_par = sizeof(float) * ((size_t)nbr * ((fs + 64 * kp + 8) | 1) + 2 * fs + 64 * kp + 16 + (size_t)nbr * 64 + 64 + 64 + 32);
     const size_t lds = serial ? lds_serial : lds_par;
+    if (nw > 1 && nb <= 15) {
+        const int nbl = (nb + nw - 1) / nw;  // <= 4 at nw = 4, <= 8 at nw = 2
+#define BF_MW(NW_, NBL_, KPL_)                                                                                                     \
+    hipLaunchKernelGGL((gsc_nlms_mw_kernel<NW_, NBL_, KPL_>), dim3((unsigned)n_streams), dim3(64 * NW_), lds, s, aligned, y, state, \
+                       n_samples, n_mics, fs, cfg.gsc_use_vad, cfg.gsc_vad_threshold, cfg.gsc_mu0, cfg.gsc_mu_max)
+#define BF_MW_K(NW_, NBL_)                     \
+    do {                                       \
+        if (kpl <= 1) BF_MW(NW_, NBL_, 1);     \
+        else if (kpl <= 2) BF_MW(NW_, NBL_, 2);\
+        else BF_MW(NW_, NBL_, 4);              \
+    } while (0)
+        if (nw == 8) {
+            if (nbl <= 1) BF_MW_K(8, 1); else BF_MW_K(8, 2);
+        } else if (nw == 4) {
+            if (nbl <= 1) BF_MW_K(4, 1); else if (nbl <= 2) BF_MW_K(4, 2); else BF_MW_K(4, 4);
+        } else {
+            if (nbl <= 1) BF_MW_K(2, 1); else if (nbl <= 2) BF_MW_K(2, 2); else if (nbl <= 4) BF_MW_K(2, 4); else BF_MW_K(2, 8);
+        }
+#undef BF_MW_K
+#undef BF_MW
+        return hipGetLastError();
+    }
 #define BF_NLMS(NBM_, KPL_)                                                                                                        \
     do {                                                                                                                            \
         if (serial)                                                                                                                 \

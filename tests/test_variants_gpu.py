@@ -65,6 +65,8 @@ CASES = [
     ({"BF_Z48": "0"}, "lcmv", 16, (-60.0, 90.0, 150.0), 24, True),
     ({"BF_GSC_SERIAL": "1"}, "gsc", 4, (), 10, False),                  # gsc_nlms_kernel: the sums in the reference's tap order, one branch per lane
     ({"BF_GSC_SERIAL": "1"}, "gsc", 8, (), 8, False),
+    ({"BF_GSC_WAVES": "1"}, "gsc", 8, (), 8, False),                    # gsc_nlms_par_kernel: one wavefront per stream
+    ({"BF_GSC_WAVES": "2"}, "gsc", 6, (), 8, False),                    # gsc_nlms_mw_kernel<2, ...>
     ({"BF_STFT_W64": "1"}, "mvdr", 8, (), 30, True),                   # stft_w64_kernel in front of the covariance nodes (z48 rows)
     ({"BF_STFT_W64": "1"}, "gss", 5, (-60.0,), 30, True),              # ... and full-double rows, odd microphone count
     ({"BF_BINS_W64": "0"}, "phase", 8, (), 24, True),                  # stft_bins_fused_kernel: the 32 x 32 half-wavefront version of the fused STFT + per-bin kernel
