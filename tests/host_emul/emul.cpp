@@ -256,6 +256,107 @@ void emul_das_fused(int M, int H, double sr, const double *mx, const double *my,
     }
 }
 
+// das_f64_pair_kernel's formulation in double with the kernel's own gain table (geometry.hpp das_mic_gains_w64_f64: bins 0 .. 512 in rows
+// of 65) and its addressing: frames t, t + 1 of one microphone per transform, register 4 g + k3 of lane l = bin l + 64 g + 256 k3; k3 < 2
+// reads row (g, k3) column l, k3 >= 2 row (3 - g, 3 - k3) column 64 - l, conjugated.  Real part of the backward transform = frame t,
+// imaginary part = frame t + 1.  x planar [M][F*512], y [F*512].
+void emul_das_pair_f64(int M, double sr, const double *mx, const double *my, double theta, const float *x, long F, float *y) {
+    const int N = 1024, H = 512;
+    ArrayGeometry g;
+    g.set(mx, my, M);
+    std::vector<double> freqs = frequency_vector(N, sr);
+    SteeringSet st;
+    st.allocate(N, M, 1);
+    st.update_column(g, freqs, 0, theta, true);
+    const std::vector<f64x2> T = das_mic_gains_w64_f64(st, 8);
+    const std::vector<double> h = sqrt_hann(N);
+    std::vector<float> tail(H, 0.f);
+    std::vector<double> z(2 * N), Z(2 * N), U(2 * N), u(2 * N);
+    auto sample = [&](int m, long s) -> double { return s < 0 ? 0.0 : (double)x[(size_t)m * F * H + s]; };
+    for (long t = 0; t < F; t += 2) {
+        const bool two = t + 1 < F;
+        std::fill(U.begin(), U.end(), 0.0);
+        for (int m = 0; m < M; ++m) {
+            for (int n = 0; n < N; ++n) {
+                z[2 * n] = h[n] * sample(m, (t - 1) * (long)H + n);
+                z[2 * n + 1] = two ? h[n] * sample(m, t * (long)H + n) : 0.0;
+            }
+            fft1024_emul<double>(z.data(), Z.data(), -1);
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 16; ++r) {
+                    const int k = w64_bin(lane, r), gg = r >> 2, k3 = r & 3;
+                    f64x2 G;
+                    if (k3 < 2) {
+                        G = T[((size_t)m * kDasMicGainRows + 2 * gg + k3) * kDasMicGainRow + lane];
+                    } else {
+                        G = T[((size_t)m * kDasMicGainRows + 2 * (3 - gg) + (3 - k3)) * kDasMicGainRow + (64 - lane)];
+                        G.y = -G.y;
+                    }
+                    U[2 * k] += G.x * Z[2 * k] - G.y * Z[2 * k + 1];
+                    U[2 * k + 1] += G.x * Z[2 * k + 1] + G.y * Z[2 * k];
+                }
+        }
+        fft1024_emul<double>(U.data(), u.data(), +1);  // unnormalised: 1/N is inside the gains
+        for (int f = 0; f < (two ? 2 : 1); ++f)
+            for (int n = 0; n < H; ++n) {
+                const float o1 = (float)((double)(float)u[2 * n + f] * h[n]);
+                const float o2 = (float)((double)(float)u[2 * (n + H) + f] * h[n + H]);
+                y[(size_t)(t + f) * H + n] = tail[n] + o1;
+                tail[n] = o2;
+            }
+    }
+}
+
+// das_fused_small_kernel's formulation (periods below 512 frames): R = 1024 / N consecutive frames interleaved sample by sample into one
+// 1024-point sequence, the N-point pair gains repeated R times (das_pair_gains_interleaved, fp32 table in the 32 x 32 order), one
+// 1024-point transform pair per microphone pair and GROUP of frames.  Arithmetic in double (the kernel: float).  x planar [M][F*H].
+void emul_das_small(int M, int H, double sr, const double *mx, const double *my, double theta, const float *x, long F, float *y) {
+    const int N = 2 * H, R = 1024 / N;
+    ArrayGeometry g;
+    g.set(mx, my, M);
+    std::vector<double> freqs = frequency_vector(N, sr);
+    SteeringSet st;
+    st.allocate(N, M, 1);
+    st.update_column(g, freqs, 0, theta, true);
+    const int NP = (M + 1) / 2;
+    const std::vector<f32x2> D = das_pair_gains_interleaved(st, NP);
+    const std::vector<double> hd = sqrt_hann(N);
+    std::vector<float> h(N);
+    for (int i = 0; i < N; ++i) h[i] = (float)hd[i];
+    std::vector<std::vector<float>> tails(1, std::vector<float>(H, 0.f));
+    std::vector<float> tail(H, 0.f);
+    std::vector<double> z(2 * 1024), Z(2 * 1024), S(2 * 1024), u(2 * 1024);
+    auto sample = [&](int m, long s) -> double { return (m >= M || s < 0 || s >= F * (long)H) ? 0.0 : (double)x[(size_t)m * F * H + s]; };
+    for (long tg = 0; tg < F; tg += R) {
+        std::fill(S.begin(), S.end(), 0.0);
+        for (int p = 0; p < NP; ++p) {
+            for (int n = 0; n < 1024; ++n) {  // interleaved index n = R m + i: sample m of frame tg + i
+                const int i = n % R, m = n / R;
+                const long s0 = (tg + i - 1) * (long)H + m;
+                const bool ok = tg + i < F;
+                z[2 * n] = ok ? (double)h[m] * sample(2 * p, s0) : 0.0;
+                z[2 * n + 1] = ok ? (double)h[m] * sample(2 * p + 1, s0) : 0.0;
+            }
+            fft1024_emul<double>(z.data(), Z.data(), -1);
+            for (int i = 0; i < 32; ++i)
+                for (int l = 0; l < 32; ++l) {
+                    const int k = l + 32 * brev5(i);
+                    const f32x2 d = D[((size_t)p * 32 + i) * 32 + l];
+                    S[2 * k] += (double)d.x * Z[2 * k] - (double)d.y * Z[2 * k + 1];
+                    S[2 * k + 1] += (double)d.x * Z[2 * k + 1] + (double)d.y * Z[2 * k];
+                }
+        }
+        fft1024_emul<double>(S.data(), u.data(), +1);
+        for (int i = 0; i < R && tg + i < F; ++i)
+            for (int m = 0; m < H; ++m) {
+                const float o1 = (float)u[2 * (R * m + i)] * h[m];
+                const float o2 = (float)u[2 * (R * (m + H) + i)] * h[m + H];
+                y[(size_t)(tg + i) * H + m] = tail[m] + o1;
+                tail[m] = o2;
+            }
+    }
+}
+
 // Host geometry accessors for known-answer tests.
 void emul_freqs(int N, double sr, double *f) {
     std::vector<double> v = frequency_vector(N, sr);

@@ -69,6 +69,38 @@ def test_emulated_fused_das_matches_oracle(emul_lib, M, theta):
     assert rel_l2(y, y_ref) < 1e-6
 
 
+@pytest.mark.parametrize("M,theta,F", [(8, 20.0, 9), (5, -110.0, 6), (1, 0.0, 3)])
+def test_emulated_frame_pair_das_matches_oracle(emul_lib, M, theta, F):
+    """das_f64_pair_kernel's formulation on the CPU with the kernel's own gain table and addressing (geometry.hpp das_mic_gains_w64_f64:
+    bins 0 .. 512 in rows of 65, mirror bins read from row (3 - g, 3 - k3) column 64 - lane and conjugated): two frames of a microphone per
+    transform, real / imaginary part of ONE backward transform = the two frames.  Odd frame counts end on a lone frame."""
+    import oracle
+    p = make_params("das", n_mics=M, theta=theta)
+    x = make_scene(M, F, seed=77 + M)
+    y_ref, _ = oracle.OracleNode(p).process(x)
+    y = np.empty(F * 512, np.float32)
+    mx = np.array([m[0] for m in p["mics"]])
+    my = np.array([m[1] for m in p["mics"]])
+    emul_lib.emul_das_pair_f64(M, C.c_double(48000.0), _ptr(mx), _ptr(my), C.c_double(theta), _ptr(x), C.c_long(F), _ptr(y))
+    assert rel_l2(y, y_ref) < 2e-7   # double arithmetic up to the float stores
+
+
+@pytest.mark.parametrize("hop,M,F", [(256, 8, 11), (128, 3, 14), (64, 6, 21)])
+def test_emulated_frame_interleaving_das_matches_oracle(emul_lib, hop, M, F):
+    """das_fused_small_kernel's formulation on the CPU: 1024 / N consecutive frames interleaved into one 1024-point sequence, the N-point
+    pair gains repeated (geometry.hpp das_pair_gains_interleaved) -- the N-point chain of every frame is the 1024-point chain of the
+    interleaved sequence.  Frame counts that are not multiples of the group size end on a partial group."""
+    import oracle
+    p = make_params("das", n_mics=M, theta=40.0, hop=hop)
+    x = make_scene(M, F, hop=hop, seed=5 + hop)
+    y_ref, _ = oracle.OracleNode(p).process(x)
+    y = np.empty(F * hop, np.float32)
+    mx = np.array([m[0] for m in p["mics"]])
+    my = np.array([m[1] for m in p["mics"]])
+    emul_lib.emul_das_small(M, hop, C.c_double(48000.0), _ptr(mx), _ptr(my), C.c_double(40.0), _ptr(x), C.c_long(F), _ptr(y))
+    assert rel_l2(y, y_ref) < 1e-6   # fp32 gain table
+
+
 def test_host_geometry_matches_oracle(emul_lib):
     import oracle
     p = make_params("das", n_mics=8, theta=57.0)
