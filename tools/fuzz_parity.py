@@ -25,8 +25,12 @@ for case in range(n_cases):
         over["mcra_L"] = int(rng.integers(3, 15))
     if algo == "gsc":
         over["gsc_filter_size"] = int(rng.choice([16, 50, 64, 128, 200]))
+    # das also at the other JACK periods (the frame-interleaving and split kernels); the other nodes at a reduced rate (generic transforms)
+    hop = int(rng.choice([64, 128, 256, 512, 512, 1024])) if (algo == "das" or rng.random() < 0.15) and algo != "gsc" else 512
+    if hop != 512:
+        over["hop"] = hop
     p = make_params(algo, n_mics=M, theta=theta, interf=interf, **over)
-    x = make_scene(M, F, seed=int(rng.integers(1 << 30)), theta_s=float(rng.uniform(-180, 180)))
+    x = make_scene(M, F, hop=hop, seed=int(rng.integers(1 << 30)), theta_s=float(rng.uniform(-180, 180)))
     layout = BF_INTERLEAVED if rng.random() < 0.3 else BF_PLANAR
     node = oracle.OracleNode(p)
     impl = BF_DAS_BINS_F64 if (algo == "das" and rng.random() < 0.6) else BF_DAS_FUSED_F32   # das: in double (one-launch kernels) or fused fp32
@@ -37,7 +41,7 @@ for case in range(n_cases):
         if rng.random() < 0.3:
             t2 = float(rng.uniform(-180, 180))
             node.set_theta(t2); bf.set_theta(t2)
-        seg = np.ascontiguousarray(x[:, a * 512:b * 512])
+        seg = np.ascontiguousarray(x[:, a * hop:b * hop])
         refs.append(node.process(seg)[0])
         ys.append(bf.process(seg if layout == BF_PLANAR else np.ascontiguousarray(seg.T)))
     y, r = np.concatenate(ys), np.concatenate(refs)
