@@ -222,16 +222,23 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     const bool split_w64 = split2048 && split_env == 2 && h->d_twiddle_split_w64 != nullptr;
     // periods below 512 without a dump: 1024 / N frames interleaved into one pass of the 1024-point machinery, a half-wavefront per
     // run, 16 runs per CU (das_fused_small.hip; BF_DAS_INTERLEAVE=0: the generic kernel, for A/B runs)
-    static const bool il_on = !(getenv("BF_DAS_INTERLEAVE") && atoi(getenv("BF_DAS_INTERLEAVE")) == 0);
-    const bool small = gen && h->N < 1024 && !spectrum_dev && il_on && h->d_gains_il[0] != nullptr && h->d_twiddle_1024 != nullptr;
-    long runs = (small ? (long)h->n_cus * 16 : split_w64 ? (long)h->n_cus * 12 : split2048 ? (long)h->n_cus * 8 : gen ? (long)h->n_cus * gen_per_cu : (long)h->n_cus) / (shared ? h->n_streams : S);
+    // (=3: a full wavefront per run on the 64-lane transform, 12 runs per CU; =2: the half-wavefront version, 16 runs per CU; =1, the
+    // default: the period-512 kernel itself in group mode -- one block per run, tails through its LDS ring, HBM sees every hop once --
+    // for planar input with up to 8 microphones, =3 otherwise)
+    static const int il_env = getenv("BF_DAS_INTERLEAVE") ? atoi(getenv("BF_DAS_INTERLEAVE")) : 1;
+    // BF_DAS_VARIANT bit 0: ds_write_addtid transposes, bit 1: unrolled pair loop with in-loop prefetch; 0 / 1 select the older
+    // forms for A/B runs (same arithmetic, bit-identical output)
+    static const int das_variant = getenv("BF_DAS_VARIANT") ? atoi(getenv("BF_DAS_VARIANT")) : 3;
+    const bool small = gen && h->N < 1024 && !spectrum_dev && il_env != 0 && h->d_gains_il[0] != nullptr && h->d_twiddle_1024 != nullptr;
+    const long Rg = small ? 1024 / h->N : 1;
+    const bool small_ring = small && il_env == 1 && layout == BF_PLANAR && h->M <= 8 && das_variant == 3;
+    const bool small_w64 = small && !small_ring && il_env != 2 && h->d_twiddle_w64 != nullptr;
+    long runs = (small_ring ? (long)h->n_cus : small_w64 ? (long)h->n_cus * 12 : small ? (long)h->n_cus * 16 : split_w64 ? (long)h->n_cus * 12 : split2048 ? (long)h->n_cus * 8 : gen ? (long)h->n_cus * gen_per_cu : (long)h->n_cus) / (shared ? h->n_streams : S);
     if (runs < 1) runs = 1;
     long fpc = (F + runs - 1) / runs;
     if (!gen) fpc = ((fpc + 15) / 16) * 16;
-    if (small) {  // whole groups of interleaved frames
-        const long R = 1024 / h->N;
-        fpc = ((fpc + R - 1) / R) * R;
-    }
+    if (small_ring) fpc = ((fpc + 16 * Rg - 1) / (16 * Rg)) * (16 * Rg);  // sixteen groups per pass of a block
+    else if (small) fpc = ((fpc + Rg - 1) / Rg) * Rg;                     // whole groups of interleaved frames
     const long cps = (F + fpc - 1) / fpc;
 
     if (spectrum_dev) {
@@ -253,7 +260,7 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     a.tail_in = h->d_tail[h->tail_cur];
     a.tail_out = h->d_tail[h->tail_cur ^ 1];
     a.gains = small ? h->d_gains_il[h->gains_cur] : h->use_w64 ? h->d_gains_w64[h->gains_cur] : h->d_gains[h->gains_cur];
-    a.twiddle = h->use_w64 ? h->d_twiddle_w64 : h->d_twiddle;
+    a.twiddle = small_ring ? h->d_twiddle_1024 : h->use_w64 ? h->d_twiddle_w64 : h->d_twiddle;
     a.window = h->d_window;
     a.zeros = h->d_zeros;
     a.sdump = spectrum_dev ? h->d_sdump : nullptr;
@@ -266,11 +273,9 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     a.frames_per_chunk = (int)fpc;
     a.chunks_per_stream = (int)cps;
     a.layout = layout;
-    // BF_DAS_VARIANT bit 0: ds_write_addtid transposes, bit 1: unrolled pair loop with in-loop prefetch; 0 / 1 select the older
-    // forms for A/B runs (same arithmetic, bit-identical output)
-    static const int das_variant = getenv("BF_DAS_VARIANT") ? atoi(getenv("BF_DAS_VARIANT")) : 3;
     a.variant = das_variant;
-    if (!gen) BF_HIP(h, prepare_das_fused(a, s));
+    a.group = small_ring ? (int)Rg : 1;
+    if (!gen || small_ring) BF_HIP(h, prepare_das_fused(a, s));
     hipEvent_t k0 = nullptr, k1 = nullptr;
     {
         int trc = timing_acquire(h, &k0, &k1);
@@ -281,7 +286,9 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
         for (int d0 = 0; d0 < h->n_dirs; d0 += 16)
             BF_HIP(h, launch_das_fused_dirs(a, d0, h->n_dirs - d0 < 16 ? h->n_dirs - d0 : 16, s));
     } else {
-        BF_HIP(h, small ? launch_das_fused_small(a, h->N, h->d_twiddle_1024, s)
+        BF_HIP(h, small_ring ? launch_das_fused(a, s)
+                  : small_w64 ? launch_das_fused_small_w64(a, h->N, h->d_twiddle_w64, s)
+                  : small ? launch_das_fused_small(a, h->N, h->d_twiddle_1024, s)
                   : split_w64 ? launch_das_fused_2048_w64(a, h->d_twiddle_split_w64, s)
                   : split2048 ? launch_das_fused_2048(a, h->d_twiddle_split, s)
                   : gen     ? launch_das_fused_gen(a, h->N, s)

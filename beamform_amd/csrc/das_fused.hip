@@ -166,7 +166,25 @@ __device__ __forceinline__ void wt_fft_inv(float (&re)[32], float (&im)[32], int
 //   gains:    [pair][m < 16][lane][2] = { D[2m][lane], D[2m + 1][lane] }
 // SPLIT: the second 32-point pass stops after its stages 0..2 (fft32_dif_head); the caller finishes it four positions at a time
 // with fft32_dif_tail and takes every finished group straight into the weight-and-sum
-template <bool SPLIT = false>
+//
+// R > 1 (frame groups, see das_fused_kernel): the lanes of a half-wavefront carry the 32 residues n mod 32 in the order perm_lane<R> --
+// physical lane p holds logical lane (p mod (32 / R)) R + p / (32 / R), so that the 32 / R lanes of one frame sit side by side and a load
+// instruction touches one run of consecutive samples per frame.  The transform does not care which physical lane holds a residue: the
+// first pass is per lane (its twiddles are looked up under the logical lane, `lane` below), and the plane transpose turns the physical
+// lane into the register index -- a renaming of registers at compile time, no instruction.
+template <int R>
+__device__ constexpr int perm_lane(int p) { return (p % (32 / R)) * R + p / (32 / R); }
+template <int R>
+__device__ __forceinline__ void perm_regs_fwd(float (&v)[32]) {  // v[p] (column p of the plane: physical lane p) -> position perm_lane(p)
+    if constexpr (R > 1) {
+        float t[32];
+#pragma unroll
+        for (int p = 0; p < 32; ++p) t[perm_lane<R>(p)] = v[p];
+#pragma unroll
+        for (int p = 0; p < 32; ++p) v[p] = t[p];
+    }
+}
+template <bool SPLIT = false, int R = 1>
 __device__ __forceinline__ void wt_fft_fwd_p2(float (&re)[32], float (&im)[32], int lane, const float4 *tw2, unsigned base,
                                               const float *rp BF_STAMP_PARAMS) {
     fft32_dif<float, -1>(re, im);
@@ -189,6 +207,8 @@ __device__ __forceinline__ void wt_fft_fwd_p2(float (&re)[32], float (&im)[32], 
     wt_load_row(re, rp);
     wt_store_plane<false>(im, base);
     wt_load_row(im, rp);
+    perm_regs_fwd<R>(re);
+    perm_regs_fwd<R>(im);
     BF_STAMP(3);
     if (SPLIT) {
 #pragma unroll
@@ -198,6 +218,9 @@ __device__ __forceinline__ void wt_fft_fwd_p2(float (&re)[32], float (&im)[32], 
     }
     BF_STAMP(4);
 }
+// R > 1: row i of the plane (the lane that reads it: physical lane i) receives register perm_lane(i) -- the output lanes carry the residues
+// in the same order as the forward transform's input lanes
+template <int R = 1>
 __device__ __forceinline__ void wt_fft_inv_p2(float (&re)[32], float (&im)[32], int lane, const float4 *tw2, unsigned base,
                                               const float *rp BF_STAMP_PARAMS) {
     fft32_dit<float, +1>(re, im);
@@ -215,10 +238,22 @@ __device__ __forceinline__ void wt_fft_inv_p2(float (&re)[32], float (&im)[32], 
         im[k + 16] = yi * w.z - yr * w.w;
     }
     BF_STAMP(7);
-    wt_store_plane<true>(re, base);
-    wt_load_row(re, rp);
-    wt_store_plane<true>(im, base);
-    wt_load_row(im, rp);
+    if constexpr (R > 1) {
+        float t[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t[i] = re[perm_lane<R>(i)];
+        wt_store_plane<true>(t, base);
+        wt_load_row(re, rp);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t[i] = im[perm_lane<R>(i)];
+        wt_store_plane<true>(t, base);
+        wt_load_row(im, rp);
+    } else {
+        wt_store_plane<true>(re, base);
+        wt_load_row(re, rp);
+        wt_store_plane<true>(im, base);
+        wt_load_row(im, rp);
+    }
     BF_STAMP(8);
     fft32_dif<float, +1>(re, im);
     BF_STAMP(9);
@@ -234,8 +269,19 @@ __device__ __forceinline__ void wt_fft_inv_p2(float (&re)[32], float (&im)[32], 
 // partner (second half of frame t-1) comes from the neighbour through a 17-slot LDS ring; only the
 // first hop of a run needs the previous run's last frame, and that one hop is completed by two
 // float atomic adds into a pre-zeroed hop (sum of two terms: order-independent, bit-exact).
-template <int LAYOUT, int NPL, bool WT, int UNR = 0>
+//
+// R > 1 (JACK periods 256 / 128 / 64, frames of N = 1024 / R samples): the unit of work is a GROUP of R consecutive frames
+// interleaved into one 1024-point sequence (z[R m + i] = frame_{R g + i}[m]; the N-point pair gains repeated R times act on every
+// frame separately -- das_fused_small.hip has the identity).  Lane p holds frame p / (32 / R), samples (32 / R) j + p mod (32 / R): the
+// lanes of a frame side by side (perm_lane above; with the frames alternating from lane to lane the texture addresser served 4x the
+// cache accesses of R = 1 and was 75 % busy -- profiles/r04_e_pmc_small.txt).  A group yields 512 output samples like a frame does at
+// R = 1, parks the same 512-float second half in the ring, and differs only in where the overlap-add partner sits: in the group's own
+// slot, 32 / R lanes to the left, for the frames inside a group; in the previous group's slot, (R - 1) 32 / R lanes to the right, for
+// its first frame; the run boundaries' atomics touch the hop of that one frame.  a.gains = das_pair_gains_interleaved
+// tables, a.window = the N-point window, a.frames_per_chunk a multiple of 16 R; T0 / T1 / t below count groups.
+template <int LAYOUT, int NPL, bool WT, int UNR = 0, int R = 1>
 __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
+    constexpr int H = kHop / R, JS = 32 / R;  // hop of a frame; samples between a lane's consecutive registers
     __shared__ __attribute__((aligned(16))) float lds[kLdsFixed + NPL * 2048 + 17 * kHop + 32];
     const cx<float> *s_tw = reinterpret_cast<const cx<float> *>(lds);
     float *s_win = lds + kLdsTw + kHalves * kLdsPlane;
@@ -254,6 +300,8 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 31;
     const int hw = tid >> 5;
+    const int fi = lane / JS, c = lane % JS;  // frame inside the group and sample offset (R = 1: 0 and the lane)
+    const int llane = perm_lane<R>(lane);     // the residue n mod 32 this lane carries (R = 1: the lane)
     float *pbuf = lds + kLdsTw + hw * kLdsPlane;
     // WT: the two halves of a wavefront share one interleaved plane (8 x 8.5 KiB inside the same 72 KiB region)
     float *wplane = lds + kLdsTw + (hw >> 1) * kWPlane;
@@ -274,7 +322,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             const int k1 = i >> 5, l = i & 31;
             ltw[kP2 ? (((k1 & 15) * 32 + l) * 2 + (k1 >> 4)) : i] = twc[i];
         }
-        for (int i = tid; i < kNfft; i += kBlock) s_win[(i & 31) * kPS + (i >> 5)] = a.window[i];  // [lane][j]
+        for (int i = tid; i < kNfft; i += kBlock) s_win[(i & 31) * kPS + (i >> 5)] = a.window[i / R];  // [lane][j]; interleaved index i <-> sample i / R
         if (NPL > 0) {
             f32x2 *lg = reinterpret_cast<f32x2 *>(lds + kLdsFixed);
             for (int i = tid; i < n_pairs * 1024; i += kBlock) {  // i = (pair * 32 + pos) * 32 + lane
@@ -283,19 +331,25 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             }
         }
     }
-    const long T0 = c_in_s * a.frames_per_chunk;
-    long T1 = T0 + a.frames_per_chunk;
-    if (T1 > a.n_frames) T1 = a.n_frames;
-    if (T0 == 0) {  // stream start: the overlap partner of frame 0 is the carried state (out_buff[0], util.h:302)
-        for (int i = tid; i < kHop; i += kBlock) s_tails[i] = a.tail_in[(long)stream * kHop + i];
+    const long n_units = (a.n_frames + R - 1) / R;  // groups per stream (the last one may be partial)
+    const long T0 = c_in_s * (a.frames_per_chunk / R);
+    long T1 = T0 + a.frames_per_chunk / R;
+    if (T1 > n_units) T1 = n_units;
+    if (T0 == 0) {  // stream start: the overlap partner of frame 0 is the carried state (out_buff[0], util.h:302), parked as frame R - 1 of "group -1"
+        for (int i = tid; i < H; i += kBlock) s_tails[32 * (i / JS) + (R - 1) * JS + (i % JS)] = a.tail_in[(long)stream * H + i];
     }
     if (tid < 17) s_flag[tid] = (tid == 0) ? (int)(T0 - 1) : -2;  // slot 0 holds "frame T0-1" (state, or unused when T0 > 0)
     __syncthreads();
-    const float4 *wrow = reinterpret_cast<const float4 *>(s_win + lane * kPS);
+    const float4 *wrow = reinterpret_cast<const float4 *>(s_win + llane * kPS);
 
     const float *xs = a.x + (long)in_stream * a.stream_stride_x;
-    const float *hs = a.hist_in + (long)in_stream * M * kHop;
-    float *ys = a.y + (long)stream * a.n_frames * kHop;
+    const float *hs = a.hist_in + (long)in_stream * M * H;
+    float *ys = a.y + (long)stream * a.n_frames * H;
+    // the frame this lane holds of unit tc (R = 1: the unit itself); past the end of the stream: the last frame again, never stored
+    auto lane_frame = [&](long tc) -> long {
+        const long f = tc * R + fi;
+        return (R > 1 && f >= a.n_frames) ? a.n_frames - 1 : f;
+    };
 
     float re[32], im[32], Sr[32], Si[32];
     const int n_iter = (int)((T1 - T0 + kHalves - 1) / kHalves);
@@ -316,16 +370,17 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
         const int ma = 2 * p, mb = 2 * p + 1;
         const bool b_ok = mb < M;  // odd microphone count: the last pair's partner channel reads the zero buffer
         {
-            const float *a1 = (tc >= 1 ? xs + (long)ma * a.mic_stride + (tc - 1) * kHop : hs + ma * kHop) + lane;
-            const float *b1 = (!b_ok ? a.zeros : tc >= 1 ? xs + (long)mb * a.mic_stride + (tc - 1) * kHop : hs + mb * kHop) + lane;
-            const float *a2 = xs + (long)ma * a.mic_stride + tc * kHop + lane;
-            const float *b2 = (!b_ok ? a.zeros : xs + (long)mb * a.mic_stride + tc * kHop) + lane;
+            const long f = lane_frame(tc);
+            const float *a1 = (f >= 1 ? xs + (long)ma * a.mic_stride + (f - 1) * H : hs + ma * H) + c;
+            const float *b1 = (!b_ok ? a.zeros : f >= 1 ? xs + (long)mb * a.mic_stride + (f - 1) * H : hs + mb * H) + c;
+            const float *a2 = xs + (long)ma * a.mic_stride + f * H + c;
+            const float *b2 = (!b_ok ? a.zeros : xs + (long)mb * a.mic_stride + f * H) + c;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                re[j] = a1[32 * j];
-                im[j] = b1[32 * j];
-                re[j + 16] = a2[32 * j];
-                im[j + 16] = b2[32 * j];
+                re[j] = a1[JS * j];
+                im[j] = b1[JS * j];
+                re[j + 16] = a2[JS * j];
+                im[j + 16] = b2[JS * j];
             }
         }
     };
@@ -345,14 +400,15 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             auto rows = [&](int p, int i0, int n) {
                 const int ma = 2 * p, mb = 2 * p + 1;
                 const bool b_ok = mb < M;  // odd microphone count: the last pair's partner channel reads the zero buffer
-                const float *a1 = (tc >= 1 ? xs + (long)ma * a.mic_stride + (tc - 1) * kHop : hs + ma * kHop) + lane;
-                const float *b1 = (!b_ok ? a.zeros : tc >= 1 ? xs + (long)mb * a.mic_stride + (tc - 1) * kHop : hs + mb * kHop) + lane;
-                const float *a2 = xs + (long)ma * a.mic_stride + tc * kHop + lane;
-                const float *b2 = (!b_ok ? a.zeros : xs + (long)mb * a.mic_stride + tc * kHop) + lane;
+                const long f = lane_frame(tc);
+                const float *a1 = (f >= 1 ? xs + (long)ma * a.mic_stride + (f - 1) * H : hs + ma * H) + c;
+                const float *b1 = (!b_ok ? a.zeros : f >= 1 ? xs + (long)mb * a.mic_stride + (f - 1) * H : hs + mb * H) + c;
+                const float *a2 = xs + (long)ma * a.mic_stride + f * H + c;
+                const float *b2 = (!b_ok ? a.zeros : xs + (long)mb * a.mic_stride + f * H) + c;
 #pragma unroll
                 for (int jx = i0; jx < i0 + n; ++jx) {
-                    re[jx] = jx < 16 ? a1[32 * jx] : a2[32 * (jx - 16)];
-                    im[jx] = jx < 16 ? b1[32 * jx] : b2[32 * (jx - 16)];
+                    re[jx] = jx < 16 ? a1[JS * jx] : a2[JS * (jx - 16)];
+                    im[jx] = jx < 16 ? b1[JS * jx] : b2[JS * (jx - 16)];
                 }
             };
 #pragma unroll
@@ -366,7 +422,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                     re[4 * g + 3] *= hv.w; im[4 * g + 3] *= hv.w;
                 }
                 BF_STAMP(0);
-                wt_fft_fwd_p2<true>(re, im, lane, reinterpret_cast<const float4 *>(lds), wbase, wrowp BF_STAMP_ARGS);
+                wt_fft_fwd_p2<true, R>(re, im, llane, reinterpret_cast<const float4 *>(lds), wbase, wrowp BF_STAMP_ARGS);
                 const float4 *gp2 = reinterpret_cast<const float4 *>(lds + kLdsFixed) + p * 512 + lane;
                 // the last two stages of the second pass run four register positions at a time; every finished group goes straight
                 // into the weight-and-sum and its registers to the next pair's loads, so those are spread over stages 3-4 AND the
@@ -400,13 +456,14 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                 // interleaved [sample][mic]: the two mics of a pair are adjacent -> one 8-byte load per sample
                 const int ma = 2 * p;
                 const int mb = b_ok ? 2 * p + 1 : ma;
-                const float *s1 = (tc >= 1 ? xs + (tc - 1) * (long)kHop * M : hs) + (long)lane * M;
-                const float *s2 = xs + tc * (long)kHop * M + (long)lane * M;
+                const long f = lane_frame(tc);
+                const float *s1 = (f >= 1 ? xs + (f - 1) * (long)H * M : hs) + (long)c * M;
+                const float *s2 = xs + f * (long)H * M + (long)c * M;
                 if (b_ok && (M & 1) == 0) {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
-                        const float2 u = *reinterpret_cast<const float2 *>(s1 + (long)32 * j * M + ma);
-                        const float2 w = *reinterpret_cast<const float2 *>(s2 + (long)32 * j * M + ma);
+                        const float2 u = *reinterpret_cast<const float2 *>(s1 + (long)JS * j * M + ma);
+                        const float2 w = *reinterpret_cast<const float2 *>(s2 + (long)JS * j * M + ma);
                         re[j] = u.x;
                         im[j] = u.y;
                         re[j + 16] = w.x;
@@ -415,10 +472,10 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                 } else {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
-                        re[j] = s1[(long)32 * j * M + ma];
-                        im[j] = b_ok ? s1[(long)32 * j * M + mb] : 0.f;
-                        re[j + 16] = s2[(long)32 * j * M + ma];
-                        im[j + 16] = b_ok ? s2[(long)32 * j * M + mb] : 0.f;
+                        re[j] = s1[(long)JS * j * M + ma];
+                        im[j] = b_ok ? s1[(long)JS * j * M + mb] : 0.f;
+                        re[j + 16] = s2[(long)JS * j * M + ma];
+                        im[j + 16] = b_ok ? s2[(long)JS * j * M + mb] : 0.f;
                     }
                 }
             } else if (p > 0) {
@@ -464,6 +521,8 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             }
         }
 
+        // (R > 1 never gets a dump -- launch_das_fused refuses it -- but the branch stays in those instantiations: without this block boundary
+        // the scheduler pulls the next unit's 64 prefetch registers up into the pair loop and the kernel spills 1.6 KB per lane)
         if (a.sdump != nullptr && valid) {
             f32x2 *sd = a.sdump + ((long)stream * a.n_frames + t) * kNfft + lane;
 #pragma unroll
@@ -475,7 +534,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
         BF_STAMP(13);
 
         if (kP2) {
-            wt_fft_inv_p2(Sr, Si, lane, reinterpret_cast<const float4 *>(lds), wbase, wrowp BF_STAMP_ARGS);
+            wt_fft_inv_p2<R>(Sr, Si, lane, reinterpret_cast<const float4 *>(lds), wbase, wrowp BF_STAMP_ARGS);
         } else if (WT) {
             wt_fft_inv(Sr, Si, lane, s_tw, wbase, wrowp);
         } else {
@@ -508,7 +567,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             if (lane == 0) s_flag[my] = (int)t;
         }
         BF_STAMP(10);
-        if (valid) {
+        if (R == 1 && valid) {
             float *yo = ys + t * kHop + lane;
             if (t == T0 && T0 > 0) {
                 // first hop of the run: the previous run adds its half separately (both into a zeroed hop)
@@ -529,7 +588,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                 }
             }
             if (t == T1 - 1) {
-                if (T1 < a.n_frames) {  // last frame of the run: its second half belongs to the next run's first hop
+                if (T1 < n_units) {  // last frame of the run: its second half belongs to the next run's first hop
                     float *yn = ys + T1 * kHop + lane;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) atomicAdd(yn + 32 * brev5(2 * q), Sr[2 * q + 1] * h[brev5(2 * q + 1)]);
@@ -545,6 +604,53 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                                 ho[m * kHop + 32 * j + lane] = xs[(long)m * a.mic_stride + t * kHop + 32 * j + lane];
                     } else {
                         for (int j = 0; j < 16 * M; ++j) ho[32 * j + lane] = xs[t * (long)kHop * M + 32 * j + lane];
+                    }
+                }
+            }
+        }
+        if (R > 1 && valid) {
+            // groups of R frames: the partner of a frame inside the group is the second half of the frame 32 / R lanes to the left, parked
+            // in this group's own slot a moment ago; the partner of the group's first frame is the last frame of the previous group's slot
+            const long f = t * R + fi;           // this lane's frame
+            const bool f_ok = f < a.n_frames;    // the last group of a stream may be partial
+            float *yo = ys + f * H + c;
+            const bool run_head = t == T0 && T0 > 0;
+            if (!run_head) {
+                while (s_flag[pv] != (int)(t - 1)) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+            }
+            const float *src = fi == 0 ? s_tails + pv * kHop + lane + (R - 1) * JS : s_tails + my * kHop + lane - JS;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+#pragma clang fp contract(off)
+                const float o1 = Sr[2 * q] * h[brev5(2 * q)];
+                if (run_head && fi == 0) {
+                    // first hop of the run: the previous run adds its half separately (both into a zeroed hop)
+                    if (f_ok) atomicAdd(yo + JS * brev5(2 * q), o1);
+                } else {
+                    const float partner = src[32 * brev5(2 * q)];
+                    if (f_ok) yo[JS * brev5(2 * q)] = partner + o1;
+                }
+            }
+            if (t == T1 - 1) {
+                if (T1 < n_units) {  // last group of the run: its last frame's second half belongs to the next run's first hop
+                    if (fi == R - 1) {
+                        float *yn = ys + T1 * (long)R * H + c;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) atomicAdd(yn + JS * brev5(2 * q), Sr[2 * q + 1] * h[brev5(2 * q + 1)]);
+                    }
+                } else if (f == a.n_frames - 1) {
+                    // end of the batch: carried state for the next call (OLA tail and the last input hop)
+                    float *to = a.tail_out + (long)stream * H + c;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) to[JS * brev5(2 * q)] = Sr[2 * q + 1] * h[brev5(2 * q + 1)];
+                    float *ho = a.hist_out + (long)in_stream * M * H;  // every direction writes the same values
+                    if (LAYOUT == 0) {
+                        for (int m = 0; m < M; ++m)
+                            for (int j = 0; j < 16; ++j) ho[m * H + JS * j + c] = xs[(long)m * a.mic_stride + f * H + JS * j + c];
+                    } else {
+                        for (int m = 0; m < M; ++m)
+                            for (int j = 0; j < 16; ++j) ho[(JS * j + c) * M + m] = xs[(f * (long)H + JS * j + c) * M + m];
                     }
                 }
             }
@@ -1246,6 +1352,19 @@ void launch_layout(const DasFusedArgs &a, unsigned blocks, hipStream_t stream) {
             hipLaunchKernelGGL(das_fused_il8_kernel, dim3(blocks), dim3(kBlock), 0, stream, a);
         return;
     }
+    if (a.group > 1) {  // frame groups (periods below 512): launch_das_fused checked the shape
+        if constexpr (LAYOUT == 0 && WT) {
+#define BF_DAS_GRP(NPL_, UNR_)                                                                                                                    \
+    do {                                                                                                                                          \
+        if (a.group == 2) hipLaunchKernelGGL((das_fused_kernel<0, NPL_, true, UNR_, 2>), dim3(blocks), dim3(kBlock), 0, stream, a);               \
+        else if (a.group == 4) hipLaunchKernelGGL((das_fused_kernel<0, NPL_, true, UNR_, 4>), dim3(blocks), dim3(kBlock), 0, stream, a);          \
+        else hipLaunchKernelGGL((das_fused_kernel<0, NPL_, true, UNR_, 8>), dim3(blocks), dim3(kBlock), 0, stream, a);                            \
+    } while (0)
+            if (np == 1) BF_DAS_GRP(1, 1); else if (np == 2) BF_DAS_GRP(2, 2); else if (np == 3) BF_DAS_GRP(4, 3); else BF_DAS_GRP(4, 4);
+#undef BF_DAS_GRP
+        }
+        return;
+    }
 #define BF_DAS_GO(NPL_, UNR_) hipLaunchKernelGGL((das_fused_kernel<LAYOUT, NPL_, WT, UNR_>), dim3(blocks), dim3(kBlock), 0, stream, a)
     if (np <= 1) {
         if (unr) BF_DAS_GO(1, 1); else BF_DAS_GO(1, 0);
@@ -1283,9 +1402,10 @@ __global__ __launch_bounds__(256) void stream_sumsq_kernel(const float *y, long 
 // atomic adds and must be zero beforehand (prepare_das_fused).
 hipError_t prepare_das_fused(const DasFusedArgs &a, hipStream_t stream) {
     if (a.chunks_per_stream > 1) {
+        const int H = a.group > 1 ? kHop / a.group : kHop;  // frame groups: the hop of one frame of the period
         for (int s = 0; s < a.n_streams; ++s) {
-            hipError_t e = hipMemset2DAsync(a.y + ((long)s * a.n_frames + a.frames_per_chunk) * kHop,
-                                            (size_t)a.frames_per_chunk * kHop * sizeof(float), 0, kHop * sizeof(float),
+            hipError_t e = hipMemset2DAsync(a.y + ((long)s * a.n_frames + a.frames_per_chunk) * H,
+                                            (size_t)a.frames_per_chunk * H * sizeof(float), 0, H * sizeof(float),
                                             (size_t)a.chunks_per_stream - 1, stream);
             if (e != hipSuccess) return e;
         }
@@ -1293,7 +1413,14 @@ hipError_t prepare_das_fused(const DasFusedArgs &a, hipStream_t stream) {
     return hipSuccess;
 }
 
+// a.group = 2 / 4 / 8 (periods 256 / 128 / 64 as groups of interleaved frames): planar input, up to 8 microphones, the default
+// variant, no spectrum dump; a.frames_per_chunk a multiple of 16 * group
+bool das_fused_takes_groups(const DasFusedArgs &a) {
+    return a.layout == 0 && (a.variant & 3) == 3 && a.n_mics <= 8 && a.sdump == nullptr && (a.group == 2 || a.group == 4 || a.group == 8);
+}
+
 hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t stream) {
+    if (a.group > 1 && !(das_fused_takes_groups(a) && a.frames_per_chunk % (16 * a.group) == 0)) return hipErrorInvalidValue;
     const unsigned blocks = (unsigned)((long)a.chunks_per_stream * a.n_streams);
     if (a.layout == 0)
         { if (a.variant & 1) launch_layout<0, true>(a, blocks, stream); else launch_layout<0, false>(a, blocks, stream); }

@@ -30,8 +30,8 @@ constexpr int kPSf = plane_stride<float>::value;  // 36
 // LDS map (floats)
 constexpr int oTw = 0;                           // 1024 complex: inter-pass twiddles of the 32 x 32 factorisation
 constexpr int oPl = 2048;                        // 16 planes of 32 x 36
-constexpr int oWin = oPl + kHalves * 32 * kPSf;  // window expanded to the interleaved index: w_N[n / R], n < 1024
-constexpr int oG = oWin + 1024;                  // pair gains [pair][position][lane] complex, 4 pairs
+constexpr int oWin = oPl + kHalves * 32 * kPSf;  // window expanded to the interleaved index, w_N[n / R], as [lane][j] rows of 36 floats (ds_read_b128)
+constexpr int oG = oWin + 32 * kPSf;              // pair gains [pair][position][lane] complex, 4 pairs
 constexpr int kLds = oG + 4 * 2048;
 
 template <int CTRL>
@@ -45,7 +45,6 @@ __global__ __launch_bounds__(kBlk) void das_fused_small_kernel(DasFusedArgs a, c
     constexpr int JS = 32 / R;              // samples between a lane's consecutive registers
     __shared__ __attribute__((aligned(16))) float lds[kLds];
     const cx<float> *s_tw = reinterpret_cast<const cx<float> *>(lds + oTw);
-    const float *s_win = lds + oWin;
     const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
     float *pbuf = lds + oPl + hw * 32 * kPSf;
     const int M = a.n_mics, NP = (M + 1) >> 1;
@@ -53,7 +52,7 @@ __global__ __launch_bounds__(kBlk) void das_fused_small_kernel(DasFusedArgs a, c
     {
         const float *tf = reinterpret_cast<const float *>(tw1024);
         for (int i = tid; i < 2048; i += kBlk) lds[oTw + i] = tf[i];
-        for (int i = tid; i < 1024; i += kBlk) lds[oWin + i] = a.window[i / R];
+        for (int i = tid; i < 1024; i += kBlk) lds[oWin + (i & 31) * kPSf + (i >> 5)] = a.window[i / R];  // [lane][j]
         if (g_lds) {
             const float *gf = reinterpret_cast<const float *>(a.gains);
             for (int i = tid; i < NP * 2048; i += kBlk) lds[oG + i] = gf[i];
@@ -73,6 +72,7 @@ __global__ __launch_bounds__(kBlk) void das_fused_small_kernel(DasFusedArgs a, c
     const float *hs = a.hist_in + (long)in_stream * M * H;
     float *ys = a.y + (long)s * a.n_frames * H;
     const int fi = lane % R, c = lane / R;  // this lane's frame inside a group and its sample offset
+    const float4 *wrow = reinterpret_cast<const float4 *>(lds + oWin + lane * kPSf);  // window of this lane's interleaved indices 32 j + lane
 
     // sample c of hop h (h = -1: the carried hop) of microphone m; consecutive registers are JS samples apart
     auto hop_ptr = [&](long h, int m) -> const float * {
@@ -115,10 +115,12 @@ __global__ __launch_bounds__(kBlk) void das_fused_small_kernel(DasFusedArgs a, c
                 for (int j = 0; j < 32; ++j) im[j] = 0.f;
             }
 #pragma unroll
-            for (int j = 0; j < 32; ++j) {  // buf[j]*hann_win[i]  (util.h:235); register j <-> interleaved index 32 j + lane
-                const float w = s_win[32 * j + lane];
-                re[j] *= w;
-                im[j] *= w;
+            for (int g = 0; g < 8; ++g) {  // buf[j]*hann_win[i]  (util.h:235); register j <-> interleaved index 32 j + lane
+                const float4 hv = wrow[g];
+                re[4 * g + 0] *= hv.x; im[4 * g + 0] *= hv.x;
+                re[4 * g + 1] *= hv.y; im[4 * g + 1] *= hv.y;
+                re[4 * g + 2] *= hv.z; im[4 * g + 2] *= hv.z;
+                re[4 * g + 3] *= hv.w; im[4 * g + 3] *= hv.w;
             }
             fft1024p_fwd_A<float>(re, im, lane, s_tw, pbuf);
             __builtin_amdgcn_wave_barrier();
@@ -147,13 +149,17 @@ __global__ __launch_bounds__(kBlk) void das_fused_small_kernel(DasFusedArgs a, c
         // position i <-> interleaved index n = 32 brev5(i) + lane; even i: first half of this lane's frame, odd i: n + 512, its second half
         const bool store = f_ok && tg >= t0;
         float *yo = ys + f * H + c;
-        float tcur[16];
+        float tcur[16], h[32];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 hv = wrow[g];
+            h[4 * g + 0] = hv.x; h[4 * g + 1] = hv.y; h[4 * g + 2] = hv.z; h[4 * g + 3] = hv.w;
+        }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
 #pragma clang fp contract(off)
-            const int n = 32 * brev5(2 * q);
-            const float o1 = Sr[2 * q] * s_win[n + lane];             // (float)(Re / N) [inside the gains] times hann (util.h:249-251)
-            tcur[q] = Sr[2 * q + 1] * s_win[512 + n + lane];
+            const float o1 = Sr[2 * q] * h[brev5(2 * q)];             // (float)(Re / N) [inside the gains] times hann (util.h:249-251)
+            tcur[q] = Sr[2 * q + 1] * h[brev5(2 * q + 1)];
             // partner: the second half of the frame before this lane's -- one lane to the left in this group, or (frame 0 of the group) the
             // last frame of the previous group, R - 1 lanes to the right in the previous iteration's values; never across a 16-lane row
             const float pl = dpp_mov<0x111>(tcur[q]);                 // row_shr:1

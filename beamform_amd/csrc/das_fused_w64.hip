@@ -487,6 +487,182 @@ __global__ __launch_bounds__(kBlk2) void das_fused_2048_w64_kernel(DasFusedArgs 
     }
 }
 
+// =====================================================================================================================================
+//     JACK periods below 512 frames on the 64-lane transform: das_fused_small.hip's frame interleaving, one full wavefront per run
+// =====================================================================================================================================
+// R = 1024 / N consecutive frames interleaved into one 1024-point sequence, the N-point pair gains repeated R times (an LTI identity:
+// das_fused_small.hip).  Lane l of the wavefront holds frame l mod R, samples m = (64 / R) j + l / R; first halves are registers j < 8,
+// the overlap-add partner of (frame i, m) is one lane to the left, for i = 0 the previous group's last frame R - 1 lanes to the right in the
+// previous iteration's values (both inside a 16-lane row: DPP).  16 points per lane: ~130 registers, three wavefronts per SIMD -- the
+// half-wavefront version (32 points per lane, 229 registers, two) runs at 0.54 ms for the headline batch's samples at period 256, this
+// one at the rate of the 1024-frame-period kernel above.  a.gains = das_pair_gains_interleaved tables (32 x 32 order; re-ordered here).
+constexpr int kBlk3 = 768, kWaves3 = kBlk3 / 64;
+constexpr int o3Pl = kLdsTw, o3Win = o3Pl + kWaves3 * kPlane, o3G = o3Win + 1024, kLds3 = o3G + 4 * 2048;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+template <int LAYOUT, int R>
+__global__ __launch_bounds__(kBlk3) void das_fused_small_w64_kernel(DasFusedArgs a, const f32x2 *tw_w64) {
+    constexpr int N = 1024 / R, H = N / 2;  // frame length and hop
+    constexpr int JS = 64 / R;              // samples between a lane's consecutive registers
+    __shared__ __attribute__((aligned(16))) float lds[kLds3];
+    const cx<float> *s_tw1 = reinterpret_cast<const cx<float> *>(lds);
+    const cx<float> *s_tw2 = s_tw1 + 1024;
+    const float *s_win = lds + o3Win;  // window expanded to the interleaved index: w_N[n / R], n < 1024
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *pl = lds + o3Pl + w * kPlane;
+    float *row16 = pl + (lane & 15) * kRS + 16 * (lane >> 4);
+    float *wcol = pl + w64_col(lane);
+    const int M = a.n_mics, NP = (M + 1) >> 1;
+    const bool g_lds = NP <= 4 && a.n_dirs == 1;
+    {
+        const float *tf = reinterpret_cast<const float *>(tw_w64);
+        for (int i = tid; i < kLdsTw; i += kBlk3) lds[i] = tf[i];
+        for (int i = tid; i < 1024; i += kBlk3) lds[o3Win + i] = a.window[i / R];
+        if (g_lds) {
+            f32x2 *lg = reinterpret_cast<f32x2 *>(lds + o3G);
+            for (int e = tid; e < NP * 1024; e += kBlk3) {  // e = (p * 16 + r) * 64 + lane  <-  bin k = w64_bin(lane, r): position brev5(k >> 5), lane k & 31 of the 32 x 32 table
+                const int l = e & 63, r = (e >> 6) & 15, p = e >> 10, k = w64_bin(l, r);
+                lg[e] = a.gains[((long)p * 32 + brev5(k >> 5)) * 32 + (k & 31)];
+            }
+        }
+    }
+    __syncthreads();
+    const long L = a.frames_per_chunk, runs = a.chunks_per_stream;  // L: frames per run, a multiple of R
+    const long item = (long)blockIdx.x * kWaves3 + w;
+    if (item >= (long)a.n_streams * runs) return;  // no block barrier below
+    const int s = (int)(item / runs);              // output stream = input stream * n_dirs + look direction
+    const long t0 = (item - (long)s * runs) * L;
+    long te = t0 + L;
+    if (te > a.n_frames) te = a.n_frames;
+    const int in_stream = s / a.n_dirs;
+    const f32x2 *gains = a.gains + (long)(s - in_stream * a.n_dirs) * NP * 1024;  // [pair][position][lane] of the 32 x 32 order
+    const float *xs = a.x + (long)in_stream * a.stream_stride_x;
+    const float *hs = a.hist_in + (long)in_stream * M * H;
+    float *ys = a.y + (long)s * a.n_frames * H;
+    const int fi = lane % R, c = lane / R;  // this lane's frame inside a group and its sample offset
+
+    auto hop_ptr = [&](long h, int m) -> const float * {  // sample c of hop h (h = -1: the carried hop) of microphone m
+        if (LAYOUT == 0) return (h >= 0 ? xs + (long)m * a.mic_stride + h * H : hs + (long)m * H) + c;
+        return (h >= 0 ? xs + h * (long)H * M : hs) + (long)c * M + m;
+    };
+    const long jstep = LAYOUT == 0 ? JS : (long)JS * M;
+
+    float tprev[8];  // second halves of the previous group, windowed; lanes == R - 1 (mod R) feed the next group
+    if (t0 == 0) {   // stream start: the carried state (out_buff[0] of the previous call)
+        const float *ti = a.tail_in + (long)s * H + c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tprev[j] = ti[JS * j];
+    }
+    for (long tg = (t0 == 0 ? 0 : t0 - R); tg < te; tg += R) {  // t0 - R: warm-up group, only its last second half is used
+        long f = tg + fi;                                         // this lane's frame; past the end: the last frame again, never stored
+        const bool f_ok = f < a.n_frames;
+        if (!f_ok) f = a.n_frames - 1;
+        float Sr[16], Si[16];
+        for (int p = 0; p < NP; ++p) {
+            float re[16], im[16];
+            const int ma = 2 * p, mb = 2 * p + 1;
+            {
+                const float *q1 = hop_ptr(f - 1, ma), *q2 = hop_ptr(f, ma);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    re[j] = q1[j * jstep];
+                    re[j + 8] = q2[j * jstep];
+                }
+            }
+            if (mb < M) {
+                const float *r1 = hop_ptr(f - 1, mb), *r2 = hop_ptr(f, mb);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    im[j] = r1[j * jstep];
+                    im[j + 8] = r2[j * jstep];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) im[j] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {  // buf[j]*hann_win[i]  (util.h:235); register j <-> interleaved index 64 j + lane
+                const float wv = s_win[64 * j + lane];
+                re[j] *= wv;
+                im[j] *= wv;
+            }
+            w64_fwd_p1<float>(re, im, lane, s_tw1);
+            w64_T1_fwd(re, im, wcol, row16);
+            w64_fwd_p2<float>(re, im, lane, s_tw2);
+            w64_T2<true>(re, im);
+            w64_fwd_p3<float>(re, im);
+            if (g_lds) {
+                const f32x2 *gp = reinterpret_cast<const f32x2 *>(lds + o3G) + p * 1024 + lane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f32x2 g = gp[64 * r];
+                    Sr[r] = bf_fma(-g.y, im[r], bf_fma(g.x, re[r], p == 0 ? 0.f : Sr[r]));
+                    Si[r] = bf_fma(g.y, re[r], bf_fma(g.x, im[r], p == 0 ? 0.f : Si[r]));
+                }
+            } else {
+                const f32x2 *gp = gains + (long)p * 1024;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k = w64_bin(lane, r);
+                    const f32x2 g = gp[brev5(k >> 5) * 32 + (k & 31)];
+                    Sr[r] = bf_fma(-g.y, im[r], bf_fma(g.x, re[r], p == 0 ? 0.f : Sr[r]));
+                    Si[r] = bf_fma(g.y, re[r], bf_fma(g.x, im[r], p == 0 ? 0.f : Si[r]));
+                }
+            }
+        }
+        w64_inv_p3<float>(Sr, Si);
+        w64_T2<false>(Sr, Si);
+        w64_inv_p2<float>(Sr, Si, lane, s_tw2);
+        w64_T1_inv(Sr, Si, row16, wcol);
+        w64_inv_p1<float>(Sr, Si, lane, s_tw1);
+        // register j <-> interleaved index n = 64 j + lane: j < 8 the first half of this lane's frame, j >= 8 its second half
+        const bool store = f_ok && tg >= t0;
+        float *yo = ys + f * H + c;
+        float tcur[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma clang fp contract(off)
+            const float o1 = Sr[j] * s_win[64 * j + lane];              // (float)(Re / N) [inside the gains] times hann (util.h:249-251)
+            tcur[j] = Sr[j + 8] * s_win[512 + 64 * j + lane];
+            // partner: the second half of the frame before this lane's -- one lane to the left in this group, or (frame 0 of the group) the
+            // last frame of the previous group, R - 1 lanes to the right in the previous iteration's values; never across a 16-lane row
+            const float pleft = dpp_mov_f<0x111>(tcur[j]);               // row_shr:1
+            const float pright = dpp_mov_f<0x100 + (R - 1)>(tprev[j]);   // row_shl:R-1
+            const float partner = fi == 0 ? pright : pleft;
+            if (store) yo[JS * j] = partner + o1;                        // out = prev[H + n] + cur[n]  (util.h:301-302)
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tprev[j] = tcur[j];
+        if (f_ok && f == a.n_frames - 1 && tg + R >= te) {  // end of the batch: carried state for the next call (OLA tail and the last input hop)
+            float *to = a.tail_out + (long)s * H + c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) to[JS * j] = tcur[j];
+            float *ho = a.hist_out + (long)in_stream * M * H;  // every look direction writes the same values
+            if (LAYOUT == 0) {
+                for (int m = 0; m < M; ++m)
+                    for (int j = 0; j < 8; ++j) ho[m * H + JS * j + c] = xs[(long)m * a.mic_stride + f * H + JS * j + c];
+            } else {
+                for (int m = 0; m < M; ++m)
+                    for (int j = 0; j < 8; ++j) ho[(JS * j + c) * M + m] = xs[(f * (long)H + JS * j + c) * M + m];
+            }
+        }
+    }
+}
+
+template <int LAYOUT>
+hipError_t launch_small_r(const DasFusedArgs &a, int R, const f32x2 *tw_w64, unsigned blocks, hipStream_t stream) {
+    if (R == 2) hipLaunchKernelGGL((das_fused_small_w64_kernel<LAYOUT, 2>), dim3(blocks), dim3(kBlk3), 0, stream, a, tw_w64);
+    else if (R == 4) hipLaunchKernelGGL((das_fused_small_w64_kernel<LAYOUT, 4>), dim3(blocks), dim3(kBlk3), 0, stream, a, tw_w64);
+    else if (R == 8) hipLaunchKernelGGL((das_fused_small_w64_kernel<LAYOUT, 8>), dim3(blocks), dim3(kBlk3), 0, stream, a, tw_w64);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 template <int LAYOUT>
 void launch_layout(const DasFusedArgs &a, unsigned blocks, hipStream_t stream) {
     const int np = (a.n_mics + 1) / 2;
@@ -505,6 +681,17 @@ hipError_t launch_das_fused_w64(const DasFusedArgs &a, hipStream_t stream) {
     else
         launch_layout<1>(a, blocks, stream);
     return hipGetLastError();
+}
+
+// n_fft = 512 / 256 / 128 on the 64-lane transform: a.frames_per_chunk (a multiple of 1024 / n_fft) / a.chunks_per_stream = frames per run / runs
+// per OUTPUT stream (one wavefront per run); tw_w64 = twiddle_table_w64(); a.gains = das_pair_gains_interleaved tables; a.window = the n_fft-point
+// window; no spectrum dump
+hipError_t launch_das_fused_small_w64(const DasFusedArgs &a, int n_fft, const f32x2 *tw_w64, hipStream_t stream) {
+    if (a.sdump != nullptr) return hipErrorNotSupported;
+    const int R = 1024 / n_fft;
+    const long items = (long)a.chunks_per_stream * a.n_streams;
+    const unsigned blocks = (unsigned)((items + kWaves3 - 1) / kWaves3);
+    return a.layout == 0 ? launch_small_r<0>(a, R, tw_w64, blocks, stream) : launch_small_r<1>(a, R, tw_w64, blocks, stream);
 }
 
 // a.frames_per_chunk / a.chunks_per_stream: frames per run and runs per OUTPUT stream (one wavefront per run); tw_split =

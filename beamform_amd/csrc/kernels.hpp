@@ -30,11 +30,13 @@ struct DasFusedArgs {
     int chunks_per_stream;
     int layout;            // bf_layout
     int variant;           // bit 0: wave-interleaved transposes stored with ds_write_addtid_b32 (default on)
+    int group = 1;         // launch_das_fused only: R = 1024 / n_fft frames of a period below 512 interleaved per unit of work (1: period 512)
 };
 // 64-lane variant (das_fused_w64.hip): `gains` / `twiddle` must be the *_w64 tables
 hipError_t launch_das_fused_w64(const DasFusedArgs &a, hipStream_t stream);
 hipError_t prepare_das_fused(const DasFusedArgs &a, hipStream_t stream);  // zero the atomically-completed hops
 hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t stream);
+bool das_fused_takes_groups(const DasFusedArgs &a);  // whether launch_das_fused runs this shape with a.group > 1
 // look directions dir0 .. dir0 + n_here - 1 (n_here <= 16) from ONE set of forward transforms per frame (planar, <= 8 microphones, no
 // spectrum dump); a.chunks_per_stream / frames_per_chunk describe the runs of an INPUT stream; output equal to launch_das_fused's within float rounding, not bit for bit
 // (the window products are fused differently: a beam's low-order bits may change when n_dirs crosses BF_DAS_SHARED_DIRS)
@@ -58,6 +60,8 @@ hipError_t launch_das_fused_2048(const DasFusedArgs &a, const f32x2 *tw_split, h
 // machinery.  a.gains = das_pair_gains_interleaved tables [dir][pair][1024], a.window = the n_fft-point window, tw1024 = twiddle_table_32x32;
 // a.frames_per_chunk (a multiple of 1024 / n_fft) / a.chunks_per_stream = frames per run / runs per OUTPUT stream; no spectrum dump
 hipError_t launch_das_fused_small(const DasFusedArgs &a, int n_fft, const f32x2 *tw1024, hipStream_t stream);
+// the same on the 64-lane transform, one full wavefront per run (das_fused_w64.hip); tw_w64 = twiddle_table_w64()
+hipError_t launch_das_fused_small_w64(const DasFusedArgs &a, int n_fft, const f32x2 *tw_w64, hipStream_t stream);
 // the same on the 64-lane transform, one full wavefront per run (das_fused_w64.hip); tw_split = twiddle_table_split2048_w64()
 hipError_t launch_das_fused_2048_w64(const DasFusedArgs &a, const f32x2 *tw_split, hipStream_t stream);
 hipError_t launch_das_hermitian_dump_gen(const f32x2 *sdump, f64x2 *out, long n_frames_total, int n_fft, hipStream_t stream);

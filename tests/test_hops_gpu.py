@@ -268,17 +268,27 @@ import sys, json, numpy as np
 sys.path.insert(0, %(root)r)
 sys.path.insert(0, %(root)r + "/tests")
 import oracle
-from beamform_amd.capi import Beamformer
+from beamform_amd.capi import Beamformer, BF_INTERLEAVED
 from beamform_amd.params import make_params
 from beamform_amd.synth import make_scene
 from conftest import rel_l2
 res = {}
-for hop, M, F in ((256, 8, 301), (128, 7, 203), (64, 12, 95), (256, 1, 9), (64, 8, 1)):   # odd frame counts: partial last groups; 12 microphones: gains from L2
+# odd frame counts: partial last groups; 12 microphones: gains from L2; the long ones: many runs per stream (run boundaries completed by atomics in
+# the group mode of das_fused_kernel, warm-up groups in the per-run kernels); two calls in a row: the carried hop and tail across batches
+for hop, M, F in ((256, 8, 301), (128, 7, 203), (64, 12, 95), (256, 1, 9), (64, 8, 1), (256, 8, 9001), (128, 4, 9003), (64, 3, 20001)):
     p = make_params("das", n_mics=M, theta=-65.0, hop=hop)
     x = make_scene(M, F, hop=hop, seed=hop + M)
     ref, _ = oracle.OracleNode(p).process(x)
     bf = Beamformer(p)
     res[f"{hop}/{M}/{F}"] = rel_l2(bf.process(x), ref)
+    if F > 1000:
+        cut = (F // 3) * hop
+        bfc = Beamformer(p)
+        yc = np.concatenate([bfc.process(np.ascontiguousarray(x[:, :cut])), bfc.process(np.ascontiguousarray(x[:, cut:]))])
+        res[f"{hop}/{M}/{F}/cut"] = rel_l2(yc, ref)
+        bfi = Beamformer(p, layout=BF_INTERLEAVED)
+        res[f"{hop}/{M}/{F}/interleaved"] = rel_l2(bfi.process(np.ascontiguousarray(x.T)), ref)
+        continue
     # the same stream one callback at a time: every group is a lone frame plus padding lanes
     bf2, node = Beamformer(p), oracle.OracleNode(p)
     ys = [bf2.process_hop(np.ascontiguousarray(x[:, t * hop:(t + 1) * hop])) for t in range(min(F, 12))]
@@ -287,14 +297,16 @@ print("RESULT " + json.dumps(res))
 """
 
 
-@pytest.mark.parametrize("il", ["1", "0"])
+@pytest.mark.parametrize("il", ["1", "3", "2", "0"])
 def test_small_periods_interleaving_kernel_and_its_switch(il):
-    """Periods 256 / 128 / 64 without a spectrum dump: das_fused_small_kernel<R> (1024 / N frames interleaved into one 1024-point pass, the
-    default) and BF_DAS_INTERLEAVE=0 (das_fused_gen_kernel<N>) against the oracle: odd frame counts, one callback at a time, 12 microphones."""
+    """Periods 256 / 128 / 64 without a spectrum dump, 1024 / N frames interleaved into one 1024-point pass: das_fused_kernel in group mode
+    (BF_DAS_INTERLEAVE=1, the default; planar input with up to 8 microphones), das_fused_small_w64_kernel<R> (=3 and every other shape),
+    das_fused_small_kernel<R> (=2), and das_fused_gen_kernel<N> (=0) against the oracle: odd frame counts, one callback at a time,
+    12 microphones, many runs per stream, a cut stream, interleaved input."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", CHILD_SMALL % dict(root=root)], env=dict(os.environ, BF_DAS_INTERLEAVE=il),
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
-    assert len(res) == 10 and max(res.values()) < TOL, res
+    assert len(res) == 19 and max(res.values()) < TOL, res
