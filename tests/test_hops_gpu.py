@@ -202,7 +202,10 @@ def test_fused_das_at_other_periods_layouts_streams_directions_cuts(hop):
     yi = Beamformer(p, n_streams=S, layout=BF_INTERLEAVED).process(np.ascontiguousarray(xs.transpose(0, 2, 1)))
     for s in range(S):
         assert rel_l2(y[s], refs[s]) < TOL and rel_l2(yi[s], refs[s]) < TOL
-        assert np.array_equal(y[s], yi[s])
+        if hop >= 512:
+            assert np.array_equal(y[s], yi[s])
+        else:  # below 512 the two layouts run different transforms (planar: the period-512 kernel in group mode; interleaved: the 64-lane one)
+            assert np.abs(y[s].astype(np.float64) - yi[s]).max() <= 2e-6 * np.abs(refs[s]).max()
     # look directions: every beam equals its own node
     thetas = [-60.0, 10.0, 75.0]
     bf = Beamformer(p, n_dirs=3)
