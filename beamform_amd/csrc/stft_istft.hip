@@ -866,6 +866,153 @@ __global__ __launch_bounds__(kGenBlock) void stft_generic_kernel(StftArgs a) {
     }
 }
 
+#if BF_NFFT == 128 || BF_NFFT == 256 || BF_NFFT == 512
+// ---- N = 512 / 256 / 128 in registers: 32 points per lane x N / 32 lanes, 1024 / N frames per half-wavefront ---------------------------
+// The generic kernel above costs 2.1 ms per 131 072 frames of 8 microphones at N = 512 (the N = 1024 kernel: 0.69 ms for the same samples).
+// N = 32 x NL: lane (g, n2) of a half-wavefront -- g = lane / NL the frame, n2 = lane mod NL -- holds x_g[NL j + n2] in register j.  The first
+// pass is fft1024.hpp's (32-point DIF over j, twiddle W_N^(n2 k1), plane transpose: the G = 32 / NL frames of the half-wavefront travel through
+// the same 32 x 32 plane side by side); after it lane k1 holds, for every frame g, the NL values n2 = 0..NL-1 in registers g NL .. g NL + NL - 1,
+// and the second pass is one NL-point DIF per frame: position i' of frame g = bin k1 + 32 brev(i').  A store instruction writes 32 consecutive
+// bins of one frame.  The lanes of a frame sit side by side, so a load instruction touches G runs of NL consecutive samples.
+constexpr int kNL = kN / 32, kG = 32 / kNL, kLogNL = gen_log2(kNL);
+constexpr int brevn(int i, int logn) { return logn == 0 ? 0 : ((i & 1) << (logn - 1)) | brevn(i >> 1, logn - 1); }
+
+// NL-point DIF on registers OFF .. OFF + NL - 1: natural order in, X[brev(i)] at position OFF + i (fft32_core's butterflies on a shorter block)
+template <int DIR, int OFF>
+__device__ __forceinline__ void fft_nl_dif(double (&re)[32], double (&im)[32]) {
+#pragma unroll
+    for (int st = 0; st < kLogNL; ++st) {
+        const int half = 1 << st, tstep = 16 >> st;
+#pragma unroll
+        for (int blk = 0; blk < kNL; blk += 2 * half) {
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+                const int la = blk + j, lb = la + half;
+                const int pa = OFF + brevn(la, kLogNL), pb = OFF + brevn(lb, kLogNL);
+                bfly_dit<double, DIR>(j * tstep, re[pa], im[pa], re[pb], im[pb]);
+            }
+        }
+    }
+}
+template <int DIR, int G0 = 0>
+__device__ __forceinline__ void fft_nl_dif_all(double (&re)[32], double (&im)[32]) {
+    if constexpr (G0 < kG) {
+        fft_nl_dif<DIR, G0 * kNL>(re, im);
+        fft_nl_dif_all<DIR, G0 + 1>(re, im);
+    }
+}
+
+template <int LAYOUT, bool Z48>
+__global__ __launch_bounds__(256) void stft_small_kernel(StftArgs a) {
+    constexpr int kBlock = 256, kHalves = kBlock / 32, kWinRow = 34;
+    __shared__ __attribute__((aligned(16))) double lds[2 * 32 * kNL + kHalves * 32 * kPSd + kNL * kWinRow];
+    cx<double> *s_tw = reinterpret_cast<cx<double> *>(lds);  // [k1][n2] = W_N^(k1 n2)
+    const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
+    double *pbuf = lds + 2 * 32 * kNL + hw * 32 * kPSd;
+    double *s_win = lds + 2 * 32 * kNL + kHalves * 32 * kPSd;  // [n2][j] = win[NL j + n2]
+    {
+        for (int i = tid; i < 32 * kNL; i += kBlock) {
+            const int m = ((i / kNL) * (i % kNL)) % kN;  // a.tw[m] = exp(-2 pi i m / N) for m < N / 2; W^(m + N/2) = -W^m
+            const f64x2 w = a.tw[m % (kN / 2)];
+            s_tw[i] = m < kN / 2 ? cx<double>{w.x, w.y} : cx<double>{-w.x, -w.y};
+        }
+        for (int i = tid; i < kN; i += kBlock) s_win[(i % kNL) * kWinRow + i / kNL] = a.win[i] * (Z48 ? 0.5 : 1.0);  // z48 spectra are stored halved (exact)
+        __syncthreads();
+    }
+    const int g = lane / kNL, n2 = lane % kNL;
+    const f64x2 *wrow = reinterpret_cast<const f64x2 *>(s_win + n2 * kWinRow);
+    const int M = a.n_mics, MF = a.n_fft_mics, NP = (MF + 1) >> 1, L = a.run_len;  // L: a multiple of G
+    const long runs = (a.n_frames + L - 1) / L;
+    const long total = (long)a.n_streams * runs * NP;
+    const long stride = (long)gridDim.x * kHalves;
+    for (long item = (long)blockIdx.x * kHalves + hw; item < total; item += stride) {  // no block barrier below
+        const int p = (int)(item % NP);
+        const long sr = item / NP;
+        const long run = sr % runs;
+        const int s = (int)(sr / runs);
+        const float *xs = a.x + (long)s * a.stream_stride_x;
+        const float *hs = a.hist + (long)s * M * kHop;
+        const int ma = 2 * p;
+        const bool b_ok = 2 * p + 1 < MF;
+        const int mb = b_ok ? 2 * p + 1 : ma;
+        const double bs = b_ok ? 1.0 : 0.0;
+        long te = (run + 1) * L;
+        if (te > a.n_frames) te = a.n_frames;
+        for (long t = run * L; t < te; t += kG) {
+            long f = t + g;  // this lane's frame; past the end: the last frame again, never stored
+            if (f >= a.n_frames) f = a.n_frames - 1;
+            double re[32], im[32];
+            {
+                float va[32], vb[32];  // hop f - 1 (f = 0: the carried hop) and hop f as raw samples, register j <- sample NL j + n2
+                if (LAYOUT == 0) {
+                    const float *pa = (f >= 1 ? xs + (long)ma * a.mic_stride + (f - 1) * kHop : hs + ma * kHop) + n2;
+                    const float *pb = (f >= 1 ? xs + (long)mb * a.mic_stride + (f - 1) * kHop : hs + mb * kHop) + n2;
+                    const float *ca = xs + (long)ma * a.mic_stride + f * kHop + n2, *cb = xs + (long)mb * a.mic_stride + f * kHop + n2;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        va[j] = pa[kNL * j];
+                        vb[j] = pb[kNL * j];
+                        va[j + 16] = ca[kNL * j];
+                        vb[j + 16] = cb[kNL * j];
+                    }
+                } else {
+                    const float *ps = (f >= 1 ? xs + (f - 1) * (long)kHop * M : hs) + (long)n2 * M, *cs = xs + f * (long)kHop * M + (long)n2 * M;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        va[j] = ps[(long)kNL * j * M + ma];
+                        vb[j] = ps[(long)kNL * j * M + mb];
+                        va[j + 16] = cs[(long)kNL * j * M + ma];
+                        vb[j + 16] = cs[(long)kNL * j * M + mb];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 32; j += 2) {
+                    const f64x2 w = wrow[j >> 1];  // win[NL j + n2], win[NL (j + 1) + n2]
+                    re[j] = (double)va[j] * w.x;   // buf[j]*hann_win[i]  (util.h:235)
+                    im[j] = (double)vb[j] * (w.x * bs);
+                    re[j + 1] = (double)va[j + 1] * w.y;
+                    im[j + 1] = (double)vb[j + 1] * (w.y * bs);
+                }
+            }
+            fft32_dif<double, -1>(re, im);
+#pragma unroll
+            for (int i = 1; i < 32; ++i) {
+                const cx<double> w = s_tw[brev5(i) * kNL + n2];
+                const double xr = re[i], xi = im[i];
+                re[i] = xr * w.x - xi * w.y;
+                im[i] = xr * w.y + xi * w.x;
+            }
+#pragma unroll
+            for (int i = 0; i < 32; ++i) pbuf[brev5(i) * kPSd + lane] = re[i];
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_B<double>(re, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_C<double, false>(im, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int cc = 0; cc < 32; ++cc) im[cc] = pbuf[lane * kPSd + cc];
+            __builtin_amdgcn_wave_barrier();
+            fft_nl_dif_all<-1>(re, im);
+            // lane = k1; register g' NL + i' = bin k1 + 32 brev(i') of frame t + g'
+#pragma unroll
+            for (int gg = 0; gg < kG; ++gg) {
+                if (t + gg >= te) continue;
+                const long zoff = (((long)s * a.frames_ws + a.frame_off + t + gg) * NP + p) * kN + lane;
+#pragma unroll
+                for (int i = 0; i < kNL; ++i) {
+                    const int row = 32 * brevn(i, kLogNL);  // bins row .. row + 31 of this store
+                    if (row > a.skip_lo && row + 31 < a.skip_hi) continue;  // band-limited nodes never read these bins
+                    if (Z48)
+                        reinterpret_cast<z48 *>(a.Z)[zoff + row] = enc48(re[gg * kNL + i], im[gg * kNL + i]);
+                    else
+                        a.Z[zoff + row] = f64x2{re[gg * kNL + i], im[gg * kNL + i]};
+                }
+            }
+        }
+    }
+}
+#endif
+
 // Hermitian part of y_fft at bin k (0..N-1) from the per-bin kernels' output row.
 __device__ __forceinline__ cd herm_gen(const f64x2 *row, int k) {
     if (k == 0 || k == kN / 2) return cd{row[k].x, 0.0};
@@ -1096,6 +1243,32 @@ hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s) {
 hipError_t launch_das_f64_fused(const DasF64Args &, int, hipStream_t) { return hipErrorNotSupported; }
 
 hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
+#if BF_NFFT == 128 || BF_NFFT == 256 || BF_NFFT == 512
+    // the in-register kernel (BF_STFT_SMALL=0: the generic one, for A/B runs)
+    static const bool small_on = !(getenv("BF_STFT_SMALL") && atoi(getenv("BF_STFT_SMALL")) == 0);
+    if (small_on) {
+        constexpr int halves = 8;
+        const long np = (a.n_fft_mics + 1) / 2;
+        StftArgs b = a;
+        const long slots = (long)n_cus * halves * 2;  // two rounds of runs per half-wavefront slot
+        long L = ((long)a.n_streams * a.n_frames * np + slots - 1) / slots;
+        L = ((L + kG - 1) / kG) * kG;  // whole groups of frames
+        if (L > 256) L = 256;
+        if (L < kG) L = kG;
+        b.run_len = (int)L;
+        const long items = (long)a.n_streams * ((a.n_frames + L - 1) / L) * np;
+        long blocks = (items + halves - 1) / halves;
+        if (blocks > (long)n_cus * 4) blocks = (long)n_cus * 4;
+        if (a.layout == 0) {
+            if (a.z48) hipLaunchKernelGGL((stft_small_kernel<0, true>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+            else hipLaunchKernelGGL((stft_small_kernel<0, false>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+        } else {
+            if (a.z48) hipLaunchKernelGGL((stft_small_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+            else hipLaunchKernelGGL((stft_small_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+        }
+        return hipGetLastError();
+    }
+#endif
     const long total = (long)a.n_streams * a.n_frames * ((a.n_fft_mics + 1) / 2);
     long blocks = total < (long)n_cus * 8 ? total : (long)n_cus * 8;
     if (blocks < 1) blocks = 1;

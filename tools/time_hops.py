@@ -7,7 +7,7 @@ from beamform_amd.capi import Beamformer, BF_PLANAR
 from beamform_amd.params import make_params
 NS = 65536 * 512
 for algo in ("mvdr", "phase", "lcmv"):
-    for hop in (256, 512, 1024):
+    for hop in (64, 256, 512, 1024):
         interf = (-60.0, 90.0) if algo == "lcmv" else ()
         p = make_params(algo, n_mics=8, hop=hop, interf=interf)
         F = NS // hop
