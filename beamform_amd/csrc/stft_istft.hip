@@ -1174,6 +1174,138 @@ __global__ __launch_bounds__(kGenBlock) void istft_generic_kernel(IstftArgs a) {
     }
 }
 
+#if BF_NFFT == 128 || BF_NFFT == 256 || BF_NFFT == 512
+// ---- backward side of stft_small_kernel: Hermitian extension, N-point backward transform, window, overlap-add in ONE kernel -----------------
+// y[NL n1 + n2] = sum_k1 W32^(-n1 k1) [ W_N^(-n2 k1) sum_k2 Y[k1 + 32 k2] W_NL^(-n2 k2) ]: an NL-point DIT per frame in the registers of lane k1
+// (positions g NL + brev(k2) in, g NL + n2 out), the conjugate twiddle, the plane transpose, and fft32_dif<+1> over k1 in lane (g, n2).  Position i
+// of lane (g, n2) then holds sample NL brev5(i) + n2 of frame g: even positions the first half, odd positions the second.  The overlap-add partner
+// (second half of the frame before) sits NL lanes to the left -- or, for g = 0, in the last NL lanes of the previous iteration: both through a
+// small LDS buffer.  A run that does not start the stream recomputes the group in front of it.  Same float roundings as istft_generic_kernel +
+// ola_generic_kernel (util.h:249-250, 301-302), which wrote every windowed frame to HBM and added the halves in a second kernel: 0.46 ms per
+// 131 072 frames at N = 512.
+template <int DIR, int OFF>
+__device__ __forceinline__ void fft_nl_dit(double (&re)[32], double (&im)[32]) {  // X[brev(i)]-ordered in, natural out (fft32_core's butterflies)
+#pragma unroll
+    for (int st = 0; st < kLogNL; ++st) {
+        const int half = 1 << st, tstep = 16 >> st;
+#pragma unroll
+        for (int blk = 0; blk < kNL; blk += 2 * half) {
+#pragma unroll
+            for (int j = 0; j < half; ++j) bfly_dit<double, DIR>(j * tstep, re[OFF + blk + j], im[OFF + blk + j], re[OFF + blk + j + half], im[OFF + blk + j + half]);
+        }
+    }
+}
+template <int DIR, int G0 = 0>
+__device__ __forceinline__ void fft_nl_dit_all(double (&re)[32], double (&im)[32]) {
+    if constexpr (G0 < kG) {
+        fft_nl_dit<DIR, G0 * kNL>(re, im);
+        fft_nl_dit_all<DIR, G0 + 1>(re, im);
+    }
+}
+
+__global__ __launch_bounds__(256) void istft_small_kernel(IstftArgs a, int L) {
+    constexpr int kBlock = 256, kHalves = kBlock / 32, kWinRow = 34, kTS = 17;
+    __shared__ __attribute__((aligned(16))) double lds[2 * 32 * kNL + kHalves * 32 * kPSd + kNL * kWinRow + kHalves * 32 * kTS / 2 + 8];
+    cx<double> *s_tw = reinterpret_cast<cx<double> *>(lds);  // [n2][k1] = W_N^(k1 n2)
+    const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
+    double *pbuf = lds + 2 * 32 * kNL + hw * 32 * kPSd;
+    double *s_win = lds + 2 * 32 * kNL + kHalves * 32 * kPSd;  // [n2][j] = win[NL j + n2]
+    float *tb = reinterpret_cast<float *>(lds + 2 * 32 * kNL + kHalves * 32 * kPSd + kNL * kWinRow) + hw * 32 * kTS;  // second halves: [lane][q]
+    {
+        for (int i = tid; i < 32 * kNL; i += kBlock) {
+            const int m = ((i / 32) * (i % 32)) % kN;  // a.tw[m] = exp(-2 pi i m / N) for m < N / 2; W^(m + N/2) = -W^m
+            const f64x2 w = a.tw[m % (kN / 2)];
+            s_tw[i] = m < kN / 2 ? cx<double>{w.x, w.y} : cx<double>{-w.x, -w.y};
+        }
+        for (int i = tid; i < kN; i += kBlock) s_win[(i % kNL) * kWinRow + i / kNL] = a.win[i];
+        __syncthreads();
+    }
+    const int g = lane / kNL, n2 = lane % kNL;
+    const long runs = (a.n_frames + L - 1) / L;
+    const long total = (long)a.n_streams * runs;
+    const long stride = (long)gridDim.x * kHalves;
+    for (long item = (long)blockIdx.x * kHalves + hw; item < total; item += stride) {  // no block barrier below
+        const int s = (int)(item / runs);
+        const long t0 = (item - (long)s * runs) * L;
+        long te = t0 + L;
+        if (te > a.n_frames) te = a.n_frames;
+        float *ys = a.y + (long)s * a.n_frames * kHop;
+        if (t0 == 0) {  // stream start: the carried second half (out_buff[0], util.h:302) stands in for "the last frame of the group before"
+            if (g == kG - 1) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) tb[lane * kTS + q] = a.tail_in[(long)s * kHop + kNL * brev5(2 * q) + n2];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (long t = (t0 == 0 ? 0 : t0 - kG); t < te; t += kG) {  // t0 - G: warm-up group, only its last frame's second half is used
+            double re[32], im[32];
+            // lane = k1: position gg NL + i' <- bin k1 + 32 brev(i') of frame t + gg (past the end: the last frame again, never stored)
+#pragma unroll
+            for (int gg = 0; gg < kG; ++gg) {
+                long fr = t + gg;
+                if (fr >= a.n_frames) fr = a.n_frames - 1;
+                const f64x2 *row = a.Yh + ((long)s * a.n_frames + fr) * kYhStride;
+#pragma unroll
+                for (int i = 0; i < kNL; ++i) {
+                    const cd v = herm_gen(row, lane + 32 * brevn(i, kLogNL));
+                    re[gg * kNL + i] = v.x;
+                    im[gg * kNL + i] = v.y;
+                }
+            }
+            fft_nl_dit_all<+1>(re, im);
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                if (r % kNL == 0) continue;  // n2 = 0: no twiddle
+                const cx<double> w = s_tw[(r % kNL) * 32 + lane];  // conj applied
+                const double xr = re[r], xi = im[r];
+                re[r] = xr * w.x + xi * w.y;
+                im[r] = xi * w.x - xr * w.y;
+            }
+#pragma unroll
+            for (int r = 0; r < 32; ++r) pbuf[r * kPSd + lane] = re[r];
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_B<double>(re, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_C<double, true>(im, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_D<double, +1>(re, im, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            // lane = (g, n2): position i = sample NL brev5(i) + n2 of frame t + g
+            const double *wr = s_win + n2 * kWinRow;
+            float first[16], tail[16];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                float v = (float)(re[i] / (double)kN);                        // util.h:249
+                v = (float)((double)v * wr[brev5(i)]);                        // util.h:250
+                if (a.use_post_amp) v = (float)((double)v * a.post_amp);      // mvdr.cpp:112-114
+                if (i & 1) tail[i >> 1] = v; else first[i >> 1] = v;
+            }
+            float prev0[16];  // g = 0: the last frame of the group before, parked by the previous iteration
+#pragma unroll
+            for (int q = 0; q < 16; ++q) prev0[q] = tb[((lane + 32 - kNL) & 31) * kTS + q];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tb[lane * kTS + q] = tail[q];
+            __builtin_amdgcn_wave_barrier();
+            const long f = t + g;
+            const bool st_ok = t >= t0 && f < te;
+            float *yo = ys + f * kHop + n2;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float left = tb[((lane + 32 - kNL) & 31) * kTS + q];  // g >= 1: the frame before, NL lanes to the left
+                const float partner = g == 0 ? prev0[q] : left;
+                if (st_ok) yo[kNL * brev5(2 * q)] = partner + first[q];  // out = prev[H + n] + cur[n]  (util.h:301-302)
+            }
+            if (f == a.n_frames - 1 && t >= t0) {  // carried state for the next call
+#pragma unroll
+                for (int q = 0; q < 16; ++q) a.tail_out[(long)s * kHop + kNL * brev5(2 * q) + n2] = tail[q];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+#endif
+
 // do_overlap's overlap-add (util.h:301-302): out hop t = second half of frame t-1 + first half of frame t
 __global__ void ola_generic_kernel(IstftArgs a) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1424,6 +1556,21 @@ hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
 }
 
 hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s) {
+#if BF_NFFT == 128 || BF_NFFT == 256 || BF_NFFT == 512
+    // backward transform, window and overlap-add in registers (BF_STFT_SMALL=0: the generic pair of kernels, for A/B runs)
+    static const bool small_on = !(getenv("BF_STFT_SMALL") && atoi(getenv("BF_STFT_SMALL")) == 0);
+    if (small_on && !a.yh32) {
+        constexpr int halves = 8;
+        const long slots = (long)n_cus * halves;
+        long L = ((long)a.n_streams * a.n_frames + slots - 1) / slots;
+        L = ((L + kG - 1) / kG) * kG;  // whole groups of frames
+        if (L < 4 * kG) L = 4 * kG;    // a run recomputes one group
+        const long items = (long)a.n_streams * ((a.n_frames + L - 1) / L);
+        long blocks = (items + halves - 1) / halves;
+        hipLaunchKernelGGL(istft_small_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, (int)L);
+        return hipGetLastError();
+    }
+#endif
     if (a.frames == nullptr) return hipErrorInvalidValue;
     const long total = (long)a.n_streams * a.n_frames;
     long blocks = total < (long)n_cus * 8 ? total : (long)n_cus * 8;
