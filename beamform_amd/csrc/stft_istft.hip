@@ -1306,6 +1306,105 @@ __global__ __launch_bounds__(256) void istft_small_kernel(IstftArgs a, int L) {
 }
 #endif
 
+#if BF_NFFT == 2048
+// ---- backward side of stft_split_kernel: ONE FFT-1024 per frame ------------------------------------------------------------------------------
+// y real: its even samples have the spectrum A[k] = Y[k] + Y[k + 1024], its odd samples B[k] = (Y[k] - Y[k + 1024]) conj(W2048^k) (one radix-2
+// decimation-in-frequency step of the backward transform), both Hermitian over 1024 bins -- so IFFT1024(A + i B) = y_even + i y_odd: one complex
+// transform on fft1024.hpp's machinery returns the whole frame, sample pair (2 m, 2 m + 1) in (re, im) of one register.  Window, the reference's
+// float roundings (util.h:249-250), overlap-add against the previous frame's second half carried in registers, 8-byte stores.  A half-wavefront
+// per (stream, run of frames); a run that does not start the stream recomputes the frame in front of it.  istft_generic_kernel + ola_generic_kernel:
+// 0.77 ms per 32 768 frames.
+__global__ __launch_bounds__(256) void istft_split_kernel(IstftArgs a, int L) {
+    constexpr int kBlock = 256, kHalves = kBlock / 32, kWinRow = 66;
+    __shared__ __attribute__((aligned(16))) double lds[2048 + 2048 + kHalves * 32 * kPSd + 32 * kWinRow];
+    cx<double> *s_tw = reinterpret_cast<cx<double> *>(lds);         // [n2][k1] = W1024^(k1 n2) (symmetric)
+    cx<double> *s_w2 = reinterpret_cast<cx<double> *>(lds + 2048);  // [k] = W2048^k, k < 1024
+    const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
+    double *pbuf = lds + 4096 + hw * 32 * kPSd;
+    double *s_win = lds + 4096 + kHalves * 32 * kPSd;  // [lane][2 j + q] = win[2 (32 j + lane) + q], j < 32
+    {
+        for (int i = tid; i < 1024; i += kBlock) {
+            const int m = (2 * (i >> 5) * (i & 31)) % kN;
+            const f64x2 w = a.tw[m % 1024];
+            s_tw[i] = m < 1024 ? cx<double>{w.x, w.y} : cx<double>{-w.x, -w.y};
+            const f64x2 v = a.tw[i];
+            s_w2[i] = cx<double>{v.x, v.y};
+        }
+        for (int i = tid; i < kN; i += kBlock) {
+            const int m = i >> 1;
+            s_win[(m & 31) * kWinRow + 2 * (m >> 5) + (i & 1)] = a.win[i];
+        }
+        __syncthreads();
+    }
+    const f64x2 *wrow = reinterpret_cast<const f64x2 *>(s_win + lane * kWinRow);
+    const long runs = (a.n_frames + L - 1) / L;
+    const long total = (long)a.n_streams * runs;
+    const long stride = (long)gridDim.x * kHalves;
+    for (long item = (long)blockIdx.x * kHalves + hw; item < total; item += stride) {  // no block barrier below
+        const int s = (int)(item / runs);
+        const long t0 = (item - (long)s * runs) * L;
+        long te = t0 + L;
+        if (te > a.n_frames) te = a.n_frames;
+        float2 *ys = reinterpret_cast<float2 *>(a.y + (long)s * a.n_frames * kHop);
+        float2 tail[16];  // second half of the frame before: sample pair 2 (32 brev5(2 q) + lane) + {0, 1} of its last 1024 samples
+        if (t0 == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tail[q] = reinterpret_cast<const float2 *>(a.tail_in + (long)s * kHop)[32 * brev5(2 * q) + lane];
+        }
+        for (long t = (t0 == 0 ? 0 : t0 - 1); t < te; ++t) {  // t0 - 1: warm-up frame, only its second half is used
+            const f64x2 *row = a.Yh + ((long)s * a.n_frames + t) * kYhStride;
+            double re[32], im[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {  // lane = k1: position i <- k = k1 + 32 brev5(i)
+                const int k = lane + 32 * brev5(i);
+                const cd y0 = herm_gen(row, k), y1 = herm_gen(row, k + 1024);
+                const cx<double> w = s_w2[k];
+                const double dr = y0.x - y1.x, di = y0.y - y1.y;
+                const double br = dr * w.x + di * w.y, bi = di * w.x - dr * w.y;  // (Y[k] - Y[k + 1024]) conj(W2048^k)
+                re[i] = (y0.x + y1.x) - bi;  // A + i B
+                im[i] = (y0.y + y1.y) + br;
+            }
+            fft1024p_inv_A<double>(re, im, lane, s_tw, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_B<double>(re, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_C<double, true>(im, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_D<double, +1>(re, im, lane, pbuf);
+            __builtin_amdgcn_wave_barrier();
+            // lane = n2: position i holds samples 2 m, 2 m + 1 of the frame, m = 32 brev5(i) + n2
+            const bool st_ok = t >= t0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float2 fh, sh;
+                {
+                    const f64x2 w = wrow[brev5(2 * q)];
+                    float v0 = (float)(re[2 * q] / (double)kN), v1 = (float)(im[2 * q] / (double)kN);  // util.h:249
+                    v0 = (float)((double)v0 * w.x);                                                     // util.h:250
+                    v1 = (float)((double)v1 * w.y);
+                    if (a.use_post_amp) { v0 = (float)((double)v0 * a.post_amp); v1 = (float)((double)v1 * a.post_amp); }  // mvdr.cpp:112-114
+                    fh = float2{v0, v1};
+                }
+                {
+                    const f64x2 w = wrow[brev5(2 * q + 1)];
+                    float v0 = (float)(re[2 * q + 1] / (double)kN), v1 = (float)(im[2 * q + 1] / (double)kN);
+                    v0 = (float)((double)v0 * w.x);
+                    v1 = (float)((double)v1 * w.y);
+                    if (a.use_post_amp) { v0 = (float)((double)v0 * a.post_amp); v1 = (float)((double)v1 * a.post_amp); }
+                    sh = float2{v0, v1};
+                }
+                if (st_ok) ys[t * (kHop / 2) + 32 * brev5(2 * q) + lane] = float2{tail[q].x + fh.x, tail[q].y + fh.y};  // out = prev[H + n] + cur[n]  (util.h:301-302)
+                tail[q] = sh;
+            }
+            if (t == a.n_frames - 1) {  // carried state for the next call
+#pragma unroll
+                for (int q = 0; q < 16; ++q) reinterpret_cast<float2 *>(a.tail_out + (long)s * kHop)[32 * brev5(2 * q) + lane] = tail[q];
+            }
+        }
+    }
+}
+#endif
+
 // do_overlap's overlap-add (util.h:301-302): out hop t = second half of frame t-1 + first half of frame t
 __global__ void ola_generic_kernel(IstftArgs a) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1568,6 +1667,19 @@ hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s) {
         const long items = (long)a.n_streams * ((a.n_frames + L - 1) / L);
         long blocks = (items + halves - 1) / halves;
         hipLaunchKernelGGL(istft_small_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, (int)L);
+        return hipGetLastError();
+    }
+#endif
+#if BF_NFFT == 2048
+    // one FFT-1024 per frame, window and overlap-add in registers (BF_STFT_SPLIT=0: the generic pair of kernels, for A/B runs)
+    static const bool split_on = !(getenv("BF_STFT_SPLIT") && atoi(getenv("BF_STFT_SPLIT")) == 0);
+    if (split_on && !a.yh32) {
+        constexpr int halves = 8;
+        const long slots = (long)n_cus * halves;
+        long L = ((long)a.n_streams * a.n_frames + slots - 1) / slots;
+        if (L < 8) L = 8;  // a run recomputes one frame
+        const long items = (long)a.n_streams * ((a.n_frames + L - 1) / L);
+        hipLaunchKernelGGL(istft_split_kernel, dim3((unsigned)((items + halves - 1) / halves)), dim3(256), 0, s, a, (int)L);
         return hipGetLastError();
     }
 #endif
