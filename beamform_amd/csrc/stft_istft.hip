@@ -3,6 +3,7 @@
 #include <cstdlib>
 
 #include "bins_common.hpp"
+#include "fft_small.hpp"
 #if BF_NFFT == 1024
 #include "w64_f64_dev.hpp"
 #endif
@@ -875,33 +876,6 @@ __global__ __launch_bounds__(kGenBlock) void stft_generic_kernel(StftArgs a) {
 // and the second pass is one NL-point DIF per frame: position i' of frame g = bin k1 + 32 brev(i').  A store instruction writes 32 consecutive
 // bins of one frame.  The lanes of a frame sit side by side, so a load instruction touches G runs of NL consecutive samples.
 constexpr int kNL = kN / 32, kG = 32 / kNL, kLogNL = gen_log2(kNL);
-constexpr int brevn(int i, int logn) { return logn == 0 ? 0 : ((i & 1) << (logn - 1)) | brevn(i >> 1, logn - 1); }
-
-// NL-point DIF on registers OFF .. OFF + NL - 1: natural order in, X[brev(i)] at position OFF + i (fft32_core's butterflies on a shorter block)
-template <int DIR, int OFF>
-__device__ __forceinline__ void fft_nl_dif(double (&re)[32], double (&im)[32]) {
-#pragma unroll
-    for (int st = 0; st < kLogNL; ++st) {
-        const int half = 1 << st, tstep = 16 >> st;
-#pragma unroll
-        for (int blk = 0; blk < kNL; blk += 2 * half) {
-#pragma unroll
-            for (int j = 0; j < half; ++j) {
-                const int la = blk + j, lb = la + half;
-                const int pa = OFF + brevn(la, kLogNL), pb = OFF + brevn(lb, kLogNL);
-                bfly_dit<double, DIR>(j * tstep, re[pa], im[pa], re[pb], im[pb]);
-            }
-        }
-    }
-}
-template <int DIR, int G0 = 0>
-__device__ __forceinline__ void fft_nl_dif_all(double (&re)[32], double (&im)[32]) {
-    if constexpr (G0 < kG) {
-        fft_nl_dif<DIR, G0 * kNL>(re, im);
-        fft_nl_dif_all<DIR, G0 + 1>(re, im);
-    }
-}
-
 template <int LAYOUT, bool Z48>
 __global__ __launch_bounds__(256) void stft_small_kernel(StftArgs a) {
     constexpr int kBlock = 256, kHalves = kBlock / 32, kWinRow = 34;
@@ -992,7 +966,7 @@ __global__ __launch_bounds__(256) void stft_small_kernel(StftArgs a) {
 #pragma unroll
             for (int cc = 0; cc < 32; ++cc) im[cc] = pbuf[lane * kPSd + cc];
             __builtin_amdgcn_wave_barrier();
-            fft_nl_dif_all<-1>(re, im);
+            fftn_dif_all<double, -1, kLogNL>(re, im);
             // lane = k1; register g' NL + i' = bin k1 + 32 brev(i') of frame t + g'
 #pragma unroll
             for (int gg = 0; gg < kG; ++gg) {
@@ -1183,26 +1157,6 @@ __global__ __launch_bounds__(kGenBlock) void istft_generic_kernel(IstftArgs a) {
 // small LDS buffer.  A run that does not start the stream recomputes the group in front of it.  Same float roundings as istft_generic_kernel +
 // ola_generic_kernel (util.h:249-250, 301-302), which wrote every windowed frame to HBM and added the halves in a second kernel: 0.46 ms per
 // 131 072 frames at N = 512.
-template <int DIR, int OFF>
-__device__ __forceinline__ void fft_nl_dit(double (&re)[32], double (&im)[32]) {  // X[brev(i)]-ordered in, natural out (fft32_core's butterflies)
-#pragma unroll
-    for (int st = 0; st < kLogNL; ++st) {
-        const int half = 1 << st, tstep = 16 >> st;
-#pragma unroll
-        for (int blk = 0; blk < kNL; blk += 2 * half) {
-#pragma unroll
-            for (int j = 0; j < half; ++j) bfly_dit<double, DIR>(j * tstep, re[OFF + blk + j], im[OFF + blk + j], re[OFF + blk + j + half], im[OFF + blk + j + half]);
-        }
-    }
-}
-template <int DIR, int G0 = 0>
-__device__ __forceinline__ void fft_nl_dit_all(double (&re)[32], double (&im)[32]) {
-    if constexpr (G0 < kG) {
-        fft_nl_dit<DIR, G0 * kNL>(re, im);
-        fft_nl_dit_all<DIR, G0 + 1>(re, im);
-    }
-}
-
 __global__ __launch_bounds__(256) void istft_small_kernel(IstftArgs a, int L) {
     constexpr int kBlock = 256, kHalves = kBlock / 32, kWinRow = 34, kTS = 17;
     __shared__ __attribute__((aligned(16))) double lds[2 * 32 * kNL + kHalves * 32 * kPSd + kNL * kWinRow + kHalves * 32 * kTS / 2 + 8];
@@ -1252,7 +1206,7 @@ __global__ __launch_bounds__(256) void istft_small_kernel(IstftArgs a, int L) {
                     im[gg * kNL + i] = v.y;
                 }
             }
-            fft_nl_dit_all<+1>(re, im);
+            fftn_dit_all<double, +1, kLogNL>(re, im);
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
                 if (r % kNL == 0) continue;  // n2 = 0: no twiddle

@@ -8,6 +8,7 @@
 
 #include "../../beamform_amd/csrc/fft1024.hpp"
 #include "../../beamform_amd/csrc/fft1024_w64.hpp"
+#include "../../beamform_amd/csrc/fft_small.hpp"
 #include "../../beamform_amd/csrc/geometry.hpp"
 
 using namespace bf;
@@ -160,6 +161,124 @@ void fft1024_w64_emul(const double *in, double *out, int dir) {
     }
 }
 }  // namespace
+
+// N = 32 x NL (fft_small.hpp): G = 32 / NL transforms side by side through one 32 x 32 plane, as stft_small_kernel / istft_small_kernel run
+// them.  in / out: [G][N] complex doubles.
+template <int LOGNL>
+static void fft_small_emul(const double *in, double *out, int dir) {
+    constexpr int NL = 1 << LOGNL, G = 32 / NL, N = 32 * NL, PS = plane_stride<double>::value;
+    std::vector<double> plane(32 * PS);
+    static double re[32][32], im[32][32];
+    auto tw = [&](int k1, int n2) {
+        const double a = -2.0 * kPi * (k1 * n2) / (double)N;
+        return cx<double>{std::cos(a), std::sin(a)};
+    };
+    auto transpose = [&](double (*v)[32], bool natural_rows) {  // register r of lane l -> row (natural_rows ? r : brev5(r)), column l; lane q reads row q
+        for (int l = 0; l < 32; ++l)
+            for (int r = 0; r < 32; ++r) plane[(natural_rows ? r : brev5(r)) * PS + l] = v[l][r];
+        for (int q = 0; q < 32; ++q)
+            for (int c = 0; c < 32; ++c) v[q][c] = plane[q * PS + c];
+    };
+    if (dir < 0) {
+        for (int l = 0; l < 32; ++l) {  // lane (g, n2): register j <- x_g[NL j + n2]
+            const int g = l / NL, n2 = l % NL;
+            for (int j = 0; j < 32; ++j) {
+                re[l][j] = in[2 * (g * N + NL * j + n2)];
+                im[l][j] = in[2 * (g * N + NL * j + n2) + 1];
+            }
+            fft32_dif<double, -1>(re[l], im[l]);
+            for (int i = 1; i < 32; ++i) {
+                const cx<double> w = tw(brev5(i), n2);
+                const double xr = re[l][i], xi = im[l][i];
+                re[l][i] = xr * w.x - xi * w.y;
+                im[l][i] = xr * w.y + xi * w.x;
+            }
+        }
+        transpose(re, false);
+        transpose(im, false);
+        for (int k1 = 0; k1 < 32; ++k1) {
+            fftn_dif_all<double, -1, LOGNL>(re[k1], im[k1]);
+            for (int g = 0; g < G; ++g)
+                for (int i = 0; i < NL; ++i) {
+                    const int k = k1 + 32 * brevn(i, LOGNL);
+                    out[2 * (g * N + k)] = re[k1][g * NL + i];
+                    out[2 * (g * N + k) + 1] = im[k1][g * NL + i];
+                }
+        }
+    } else {
+        for (int k1 = 0; k1 < 32; ++k1) {  // lane k1: position g NL + i' <- Y_g[k1 + 32 brev(i')]
+            for (int g = 0; g < G; ++g)
+                for (int i = 0; i < NL; ++i) {
+                    const int k = k1 + 32 * brevn(i, LOGNL);
+                    re[k1][g * NL + i] = in[2 * (g * N + k)];
+                    im[k1][g * NL + i] = in[2 * (g * N + k) + 1];
+                }
+            fftn_dit_all<double, +1, LOGNL>(re[k1], im[k1]);
+            for (int r = 0; r < 32; ++r) {
+                const cx<double> w = tw(k1, r % NL);  // conj applied
+                const double xr = re[k1][r], xi = im[k1][r];
+                re[k1][r] = xr * w.x + xi * w.y;
+                im[k1][r] = xi * w.x - xr * w.y;
+            }
+        }
+        transpose(re, true);
+        transpose(im, true);
+        for (int l = 0; l < 32; ++l) {
+            const int g = l / NL, n2 = l % NL;
+            fft32_dif<double, +1>(re[l], im[l]);
+            for (int i = 0; i < 32; ++i) {
+                out[2 * (g * N + NL * brev5(i) + n2)] = re[l][i];
+                out[2 * (g * N + NL * brev5(i) + n2) + 1] = im[l][i];
+            }
+        }
+    }
+}
+extern "C" int emul_fft_small(int n, const double *in, double *out, int dir) {
+    if (n == 512) fft_small_emul<4>(in, out, dir);
+    else if (n == 256) fft_small_emul<3>(in, out, dir);
+    else if (n == 128) fft_small_emul<2>(in, out, dir);
+    else return -1;
+    return 0;
+}
+
+// N = 2048 around FFT-1024 (stft_split_kernel / istft_split_kernel).  Forward: in = 2048 complex samples, E / O = FFT-1024 of the even / odd ones,
+// X[k] = E[k] + W^k O[k], X[k + 1024] = E[k] - W^k O[k].  Backward (the spectrum of a REAL frame, 2048 complex bins in): A = Y[k] + Y[k + 1024],
+// B = (Y[k] - Y[k + 1024]) conj(W^k), one backward FFT-1024 of A + i B returns sample 2 m in its real and 2 m + 1 in its imaginary part; out = 2048 reals.
+extern "C" void emul_fft2048_split(const double *in, double *out, int dir) {
+    std::vector<double> a(2048), b(2048), fa(2048), fb(2048);
+    if (dir < 0) {
+        for (int m = 0; m < 1024; ++m) {
+            a[2 * m] = in[2 * (2 * m)];
+            a[2 * m + 1] = in[2 * (2 * m) + 1];
+            b[2 * m] = in[2 * (2 * m + 1)];
+            b[2 * m + 1] = in[2 * (2 * m + 1) + 1];
+        }
+        fft1024_emul<double>(a.data(), fa.data(), -1);
+        fft1024_emul<double>(b.data(), fb.data(), -1);
+        for (int k = 0; k < 1024; ++k) {
+            const double ang = -2.0 * kPi * k / 2048.0, wx = std::cos(ang), wy = std::sin(ang);
+            const double tr = fb[2 * k] * wx - fb[2 * k + 1] * wy, ti = fb[2 * k] * wy + fb[2 * k + 1] * wx;
+            out[2 * k] = fa[2 * k] + tr;
+            out[2 * k + 1] = fa[2 * k + 1] + ti;
+            out[2 * (k + 1024)] = fa[2 * k] - tr;
+            out[2 * (k + 1024) + 1] = fa[2 * k + 1] - ti;
+        }
+    } else {
+        for (int k = 0; k < 1024; ++k) {
+            const double ang = -2.0 * kPi * k / 2048.0, wx = std::cos(ang), wy = std::sin(ang);
+            const double y0r = in[2 * k], y0i = in[2 * k + 1], y1r = in[2 * (k + 1024)], y1i = in[2 * (k + 1024) + 1];
+            const double dr = y0r - y1r, di = y0i - y1i;
+            const double br = dr * wx + di * wy, bi = di * wx - dr * wy;
+            a[2 * k] = (y0r + y1r) - bi;
+            a[2 * k + 1] = (y0i + y1i) + br;
+        }
+        fft1024_emul<double>(a.data(), fa.data(), +1);
+        for (int m = 0; m < 1024; ++m) {
+            out[2 * m] = fa[2 * m];
+            out[2 * m + 1] = fa[2 * m + 1];
+        }
+    }
+}
 
 extern "C" void emul_fft1024_w64(const double *in, double *out, int dir, int use_float) {
     if (use_float) fft1024_w64_emul<float>(in, out, dir); else fft1024_w64_emul<double>(in, out, dir);

@@ -36,6 +36,30 @@ def test_emulated_fft32_and_fft1024(emul_lib):
             assert rel_l2(o, ref) < tol
 
 
+def test_emulated_small_and_split_transforms(emul_lib):
+    """fft_small.hpp (N = 32 x NL: 1024 / N frames side by side through one transpose plane, an NL-point second pass per frame -- the transforms of
+    stft_small_kernel / istft_small_kernel) and the radix-2 steps around FFT-1024 that stft_split_kernel / istft_split_kernel use at N = 2048,
+    instantiated on the CPU against numpy: index maps, twiddles, the one-transform backward path of a real frame."""
+    rng = np.random.default_rng(7)
+    for n in (512, 256, 128):
+        g = 1024 // n
+        for d in (-1, 1):
+            x = rng.standard_normal((g, n)) + 1j * rng.standard_normal((g, n))
+            o = np.empty((g, n), np.complex128)
+            assert emul_lib.emul_fft_small(n, _ptr(x), _ptr(o), d) == 0
+            ref = np.fft.fft(x, axis=1) if d < 0 else np.fft.ifft(x, axis=1) * n
+            assert rel_l2(o, ref) < 1e-14
+    x = rng.standard_normal(2048) + 1j * rng.standard_normal(2048)
+    o = np.empty(2048, np.complex128)
+    emul_lib.emul_fft2048_split(_ptr(x), _ptr(o), -1)
+    assert rel_l2(o, np.fft.fft(x)) < 1e-14
+    yr = rng.standard_normal(2048)           # backward: the spectrum of a real frame comes back from ONE complex FFT-1024
+    Y = np.fft.fft(yr)
+    back = np.empty(2048)
+    emul_lib.emul_fft2048_split(_ptr(Y), _ptr(back), 1)
+    assert rel_l2(back, yr * 2048) < 1e-14
+
+
 def test_emulated_fft1024_w64(emul_lib):
     """64-lane x 16-point three-pass factorisation (fft1024_w64.hpp): index maps and twiddles."""
     rng = np.random.default_rng(1)
