@@ -2,6 +2,7 @@
 #include <cstdlib>
 
 #include "bins_common.hpp"
+#include "fft_small.hpp"
 #if BF_NFFT == 1024
 #include "w64_f64_dev.hpp"
 #endif
@@ -844,6 +845,8 @@ __global__ __launch_bounds__(512) void stft_bins_w64_kernel(StftArgs a, BinsArgs
     }
 }
 
+#endif
+
 // the two deferred problems per frame of stft_bins_fused_kernel: one thread per (stream, frame, q in {N/2, N/2+1})
 template <int MP, int ALGO>
 __global__ __launch_bounds__(256) void fused_tail_kernel(BinsArgs b, const f64x2 *xtail, double *aux) {
@@ -869,6 +872,199 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(BinsArgs b, const f64x2
         mpf_mask_core<MP>(X, w, b.n_mics, b.cfg, soi, int2);
         b.Yh[o] = f64x2{soi.x, soi.y};
         aux[o] = int2;
+    }
+}
+
+#if BF_NFFT == 128 || BF_NFFT == 256 || BF_NFFT == 512
+// ---- the same fusion at the JACK periods 64 / 128 / 256: stft_small_kernel's transform in front of the per-bin arithmetic ----------------------
+// A half-wavefront transforms the G = 1024 / N frames of one group for one microphone pair (fft_small.hpp: N = 32 x NL, the frames side by side
+// through one transpose plane) into its 16 KB LDS slot -- [g][N] packed pair spectra, the plane inside the slot while it transforms -- and the
+// block then runs the per-bin stage of the 8 / NPc groups = FPR = (8 / NPc) G frames of the round out of LDS with the functions of the unfused
+// kernels (bit-identical per bin).  HBM sees the samples, the per-bin rows and the two deferred bins per frame; the c128 spectra (1 ms of
+// traffic each way per headline batch of samples at 8 microphones) stay on the CU.
+template <int MP, typename ZT>
+__device__ __forceinline__ void load_X_stride(const ZT *Zf, long pair_stride, int q, int M, cd (&X)[MP]) {  // bins_common.hpp load_X with the pairs `pair_stride` apart
+    const int k = q_src_bin(q);
+    const int kn = (kN - k) & (kN - 1);
+#pragma unroll
+    for (int p = 0; p < MP / 2; ++p) {
+        if (2 * p < M) {
+            const cd z = ld(Zf + p * pair_stride + k);
+            const cd zc = conj(ld(Zf + p * pair_stride + kn));
+            cd xa = (z + zc) * 0.5;
+            const cd d = z - zc;
+            cd xb = cd{0.5 * d.y, -0.5 * d.x};
+            if (q == kQX) {
+                xa = conj(xa);
+                xb = conj(xb);
+            }
+            X[2 * p] = xa;
+            X[2 * p + 1] = xb;
+        } else {
+            X[2 * p] = cd{0, 0};
+            X[2 * p + 1] = cd{0, 0};
+        }
+    }
+}
+
+template <int LAYOUT, int MP, int ALGO>
+__global__ __launch_bounds__(256, 1) void stft_bins_small_kernel(StftArgs a, BinsArgs b, long rounds_per_stream, long total_rounds,
+                                                                 long rounds_per_block, double *aux, f64x2 *xtail) {
+    constexpr int kNL = kN / 32, kG = 32 / kNL, kLogNL = kNL == 16 ? 4 : kNL == 8 ? 3 : 2;
+    constexpr int NPc = MP / 2;        // pair slots per group of frames
+    constexpr int FS = 8 / NPc;        // groups per round
+    constexpr int FPR = FS * kG;       // frames per round
+    constexpr int kQMain = kN / 2;     // problems 0 .. N/2-1 in the main passes; N/2 and N/2+1 go to fused_tail_kernel
+    constexpr int NIT = FPR * kQMain / 256;
+    __shared__ __attribute__((aligned(16))) double lds[2 * 32 * kNL + 8 * 2048 + kNL * 33];
+    cx<double> *s_tw = reinterpret_cast<cx<double> *>(lds);  // [k1][n2] = W_N^(k1 n2)
+    const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
+    double *slot = lds + 2 * 32 * kNL + hw * 2048;  // this half-wavefront's spectra [g][N] c128; transpose plane while it transforms
+    double *s_win = lds + 2 * 32 * kNL + 8 * 2048;  // [n2][j] = win[NL j + n2], rows of 33
+    {
+        for (int i = tid; i < 32 * kNL; i += 256) {
+            const int m = ((i / kNL) * (i % kNL)) % kN;  // a.tw[m] = exp(-2 pi i m / N) for m < N / 2; W^(m + N/2) = -W^m
+            const f64x2 w = a.tw[m % (kN / 2)];
+            s_tw[i] = m < kN / 2 ? cx<double>{w.x, w.y} : cx<double>{-w.x, -w.y};
+        }
+        for (int i = tid; i < kN; i += 256) s_win[(i % kNL) * 33 + i / kNL] = a.win[i];
+    }
+    const int M = a.n_mics, NP = (M + 1) >> 1;
+    const int fs = hw / NPc, p = hw % NPc;
+    const bool has_pair = p < NP;
+    const int gl = lane / kNL, n2 = lane % kNL;  // first pass: this lane's frame inside the group and its sample offset
+    const double *hwin = s_win + n2 * 33;
+
+    int it_f[NIT], it_q[NIT];  // the (frame of the round, problem) items of this thread and their steering entries: the same in every round
+    cd st[NIT][MP];
+#pragma unroll
+    for (int n = 0; n < NIT; ++n) {
+        const int idx = tid + 256 * n;
+        it_f[n] = idx / kQMain;
+        it_q[n] = idx % kQMain;
+        load_steer<MP>(b.steer, q_bin(it_q[n]), M, st[n]);
+    }
+
+    const long r0 = (long)blockIdx.x * rounds_per_block;
+    long r1 = r0 + rounds_per_block;
+    if (r1 > total_rounds) r1 = total_rounds;
+
+    float fr[32], fi[32];  // raw samples of this half-wavefront's next (group, pair): register j <- sample NL j + n2 of frame gl
+    auto request = [&](long r) {
+        const int s = (int)(r / rounds_per_stream);
+        const long tg = (r % rounds_per_stream) * FPR + fs * kG;  // first frame of this half-wavefront's group
+        if (!has_pair || tg >= a.n_frames) return;
+        long t = tg + gl;
+        if (t >= a.n_frames) t = a.n_frames - 1;  // past the end: the last frame again, never used
+        const float *xs = a.x + (long)s * a.stream_stride_x;
+        const float *hs = a.hist + (long)s * M * kHop;
+        const int ma = 2 * p;
+        const int mb = (2 * p + 1 < M) ? 2 * p + 1 : ma;
+        if (LAYOUT == 0) {
+            const float *a1 = (t >= 1 ? xs + (long)ma * a.mic_stride + (t - 1) * kHop : hs + ma * kHop) + n2;
+            const float *b1 = (t >= 1 ? xs + (long)mb * a.mic_stride + (t - 1) * kHop : hs + mb * kHop) + n2;
+            const float *a2 = xs + (long)ma * a.mic_stride + t * kHop + n2;
+            const float *b2 = xs + (long)mb * a.mic_stride + t * kHop + n2;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                fr[j] = a1[kNL * j];
+                fi[j] = b1[kNL * j];
+                fr[j + 16] = a2[kNL * j];
+                fi[j + 16] = b2[kNL * j];
+            }
+        } else {
+            const float *s1 = (t >= 1 ? xs + (t - 1) * (long)kHop * M : hs) + (long)n2 * M;
+            const float *s2 = xs + t * (long)kHop * M + (long)n2 * M;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                fr[j] = s1[(long)kNL * j * M + ma];
+                fi[j] = s1[(long)kNL * j * M + mb];
+                fr[j + 16] = s2[(long)kNL * j * M + ma];
+                fi[j + 16] = s2[(long)kNL * j * M + mb];
+            }
+        }
+    };
+    if (r0 < r1) request(r0);
+    __syncthreads();  // twiddles, window
+
+    for (long r = r0; r < r1; ++r) {
+        const int s = (int)(r / rounds_per_stream);
+        const long f0 = (r % rounds_per_stream) * FPR;
+        // ---- pass 1: window + forward transforms of (group fs, pair p) into this half-wavefront's slot -------------------------------------
+        if (has_pair && f0 + fs * kG < a.n_frames) {
+            double re[32], im[32];
+            const double bs = (2 * p + 1 < M) ? 1.0 : 0.0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                re[j] = (double)fr[j] * hwin[j];          // buf[j]*hann_win[i]  (util.h:235)
+                im[j] = (double)fi[j] * (hwin[j] * bs);
+            }
+            fft32_dif<double, -1>(re, im);
+#pragma unroll
+            for (int i = 1; i < 32; ++i) {
+                const cx<double> w = s_tw[brev5(i) * kNL + n2];
+                const double xr = re[i], xi = im[i];
+                re[i] = xr * w.x - xi * w.y;
+                im[i] = xr * w.y + xi * w.x;
+            }
+#pragma unroll
+            for (int i = 0; i < 32; ++i) slot[brev5(i) * kPSd + lane] = re[i];
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_B<double>(re, lane, slot);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_C<double, false>(im, lane, slot);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int cc = 0; cc < 32; ++cc) im[cc] = slot[lane * kPSd + cc];
+            __builtin_amdgcn_wave_barrier();
+            fftn_dif_all<double, -1, kLogNL>(re, im);
+            f64x2 *zo = reinterpret_cast<f64x2 *>(slot) + lane;  // lane = k1: position g NL + i' = bin k1 + 32 brev(i') of frame g
+#pragma unroll
+            for (int gg = 0; gg < kG; ++gg)
+#pragma unroll
+                for (int i = 0; i < kNL; ++i) zo[gg * kN + 32 * brevn(i, kLogNL)] = f64x2{re[gg * kNL + i], im[gg * kNL + i]};
+        }
+        __syncthreads();
+        if (r + 1 < r1) request(r + 1);  // lands while the per-bin pass runs
+        // ---- pass 2: the per-bin stage of the FPR frames, spectra read back from LDS ----------------------------------------------------------
+        const f64x2 *zs = reinterpret_cast<const f64x2 *>(lds + 2 * 32 * kNL);
+        auto frame_spectra = [&](int f) { return zs + (long)(f / kG) * NPc * 1024 + (f % kG) * kN; };  // pair p of that frame: + p * 1024
+#pragma unroll
+        for (int n = 0; n < NIT; ++n) {
+            const int f = it_f[n];
+            if (f0 + f >= a.n_frames) continue;
+            const int q = it_q[n], j = q_bin(q);
+            cd X[MP];
+            load_X_stride<MP>(frame_spectra(f), 1024, q, M, X);
+            const long o = ((long)s * b.n_frames + f0 + f) * kYhStride + q;
+            if (ALGO == BF_DAS) {
+                const cd y = das_core<MP>(X, st[n], M);
+                st_y(b, o, q, y);
+            } else if (ALGO == BF_PHASE) {
+                const cd y = phase_core<MP>(X, st[n], M, j, b.cfg);
+                st_y(b, o, q, y);
+            } else {  // phasempf mask
+                if (j == 0) {
+                    b.Yh[o] = f64x2{X[0].x, X[0].y};
+                    aux[o] = 0.0;
+                } else {
+                    cd soi;
+                    double int2;
+                    mpf_mask_core<MP>(X, st[n], M, b.cfg, soi, int2);
+                    b.Yh[o] = f64x2{soi.x, soi.y};
+                    aux[o] = int2;
+                }
+            }
+        }
+        if (tid < 2 * FPR && f0 + (tid >> 1) < a.n_frames) {  // bins N/2 and N/2+1 of every frame of the round: X only
+            const int f = tid >> 1, q = kQMain + (tid & 1);
+            cd X[MP];
+            load_X_stride<MP>(frame_spectra(f), 1024, q, M, X);
+            f64x2 *xt = xtail + (((long)s * b.n_frames + f0 + f) * 2 + (tid & 1)) * MP;
+#pragma unroll
+            for (int m = 0; m < MP; ++m) xt[m] = f64x2{X[m].x, X[m].y};
+        }
+        __syncthreads();  // the slots are rewritten by the next round
     }
 }
 #endif
@@ -911,6 +1107,50 @@ hipError_t launch_stft_bins_fused(const StftArgs &a, const BinsArgs &b, int n_cu
             hipLaunchKernelGGL((stft_bins_fused_kernel<L_, MP_, A_>), dim3((unsigned)blocks), dim3(256), 0, s, a, b, gps, total, gpb, \
                                aux, xtail);                                                                                   \
         hipLaunchKernelGGL((fused_tail_kernel<MP_, A_>), dim3(tail_blocks), dim3(256), 0, s, b, (const f64x2 *)xtail, aux);   \
+    } while (0)
+#define BF_FUSED_ALGO(L_, MP_)                                   \
+    do {                                                          \
+        if (algo == BF_DAS) BF_FUSED_GO(L_, MP_, BF_DAS);         \
+        else if (algo == BF_PHASE) BF_FUSED_GO(L_, MP_, BF_PHASE); \
+        else BF_FUSED_GO(L_, MP_, BF_PHASEMPF);                   \
+    } while (0)
+    if (a.layout == 0) {
+        if (a.n_mics <= 4) BF_FUSED_ALGO(0, 4); else BF_FUSED_ALGO(0, 8);
+    } else {
+        if (a.n_mics <= 4) BF_FUSED_ALGO(1, 4); else BF_FUSED_ALGO(1, 8);
+    }
+#undef BF_FUSED_ALGO
+#undef BF_FUSED_GO
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (algo == BF_PHASEMPF) {  // second pass of launch_phasempf: the recursion over frames
+        const int nthr = b.n_streams * kNQ;
+        hipLaunchKernelGGL(mpf_recursion_kernel, dim3((nthr + 63) / 64), dim3(64), 0, s, b, aux);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && b.spectrum) e = launch_expand_spectrum(b.Yh, b.spectrum, (long)b.n_streams * b.n_frames, s);
+    return e;
+#elif BF_NFFT == 128 || BF_NFFT == 256 || BF_NFFT == 512
+    const int algo = b.cfg.algo;
+    if (!(algo == BF_DAS || algo == BF_PHASE || algo == BF_PHASEMPF)) return hipErrorNotSupported;
+    if (a.n_mics > 8 || a.n_fft_mics != a.n_mics || b.n_dirs != 1 || a.frame_off != 0 || b.n_streams != a.n_streams)
+        return hipErrorNotSupported;
+    const int fpr = (a.n_mics <= 4 ? 4 : 2) * (1024 / kN);  // frames per round
+    const long rps = (a.n_frames + fpr - 1) / fpr;
+    const long total = rps * a.n_streams;
+    long blocks = total < n_cus ? total : n_cus;
+    if (blocks < 1) blocks = 1;
+    const long rpb = (total + blocks - 1) / blocks;
+    blocks = (total + rpb - 1) / rpb;
+    double *aux = reinterpret_cast<double *>(b.Yh + (long)b.n_streams * b.n_frames * kYhStride);
+    f64x2 *xtail = a.Z;  // [stream][frame][2][MP]: the caller sizes the Z workspace for it
+    if (!xtail) return hipErrorInvalidValue;
+    const long tail_items = (long)b.n_streams * b.n_frames * 2;
+    const unsigned tail_blocks = (unsigned)((tail_items + 255) / 256);
+#define BF_FUSED_GO(L_, MP_, A_)                                                                                                                  \
+    do {                                                                                                                                          \
+        hipLaunchKernelGGL((stft_bins_small_kernel<L_, MP_, A_>), dim3((unsigned)blocks), dim3(256), 0, s, a, b, rps, total, rpb, aux, xtail);    \
+        hipLaunchKernelGGL((fused_tail_kernel<MP_, A_>), dim3(tail_blocks), dim3(256), 0, s, b, (const f64x2 *)xtail, aux);                       \
     } while (0)
 #define BF_FUSED_ALGO(L_, MP_)                                   \
     do {                                                          \
