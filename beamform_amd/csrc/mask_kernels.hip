@@ -1069,6 +1069,180 @@ __global__ __launch_bounds__(256, 1) void stft_bins_small_kernel(StftArgs a, Bin
 }
 #endif
 
+#if BF_NFFT == 2048
+// ---- the same fusion at the 1024-frame JACK period ------------------------------------------------------------------------------------------------
+// X[k] = E[k] + W^k O[k], X[k + 1024] = E[k] - W^k O[k] with E, O = FFT-1024 of the even / odd samples (stft_split_kernel).  Here the two transforms
+// of a (frame, microphone pair) run on TWO half-wavefronts side by side, each into its own 16 KB LDS slot, and the radix-2 step is folded into
+// the per-bin stage's spectrum read: eight half-wavefronts = the eight transforms of one frame at 8 microphones (two frames up to 4), 128 KB of
+// slots + 16 KB of inter-pass twiddles; the window and W2048^k come through L1 (the LDS is full).  The c128 spectra (4.3 GB each way per headline
+// batch of samples at 8 microphones) stay on the CU.
+template <int MP, typename ZT>
+__device__ __forceinline__ void load_X_split(const ZT *Zf, const f64x2 *w2048, int q, int M, cd (&X)[MP]) {  // Zf = [pair][E | O][1024]
+    const int k = q_src_bin(q);
+    const int kn = (kN - k) & (kN - 1);
+    const int k1 = k & 1023, kn1 = kn & 1023;
+    const cd wk = ld(w2048 + k1), wn = ld(w2048 + kn1);
+    const double sk = k < 1024 ? 1.0 : -1.0, sn = kn < 1024 ? 1.0 : -1.0;
+#pragma unroll
+    for (int p = 0; p < MP / 2; ++p) {
+        if (2 * p < M) {
+            const cd z = ld(Zf + p * 2048 + k1) + (ld(Zf + p * 2048 + 1024 + k1) * wk) * sk;
+            const cd zc = conj(ld(Zf + p * 2048 + kn1) + (ld(Zf + p * 2048 + 1024 + kn1) * wn) * sn);
+            cd xa = (z + zc) * 0.5;                 // (Z[k] + conj Z[N-k]) / 2
+            const cd d = z - zc;                    // (Z[k] - conj Z[N-k]) / (2i) = -i/2 * d
+            cd xb = cd{0.5 * d.y, -0.5 * d.x};
+            if (q == kQX) {
+                xa = conj(xa);
+                xb = conj(xb);
+            }
+            X[2 * p] = xa;
+            X[2 * p + 1] = xb;
+        } else {
+            X[2 * p] = cd{0, 0};
+            X[2 * p + 1] = cd{0, 0};
+        }
+    }
+}
+
+template <int LAYOUT, int MP, int ALGO>
+__global__ __launch_bounds__(256, 1) void stft_bins_split_kernel(StftArgs a, BinsArgs b, long rounds_per_stream, long total_rounds,
+                                                                 long rounds_per_block, double *aux, f64x2 *xtail) {
+    constexpr int NPc = MP / 2;           // pair slots per frame; two half-wavefronts (even / odd samples) per pair
+    constexpr int FPR = 8 / (2 * NPc);    // frames per round
+    constexpr int kQMain = kN / 2;        // problems 0 .. N/2-1 in the main passes; N/2 and N/2+1 go to fused_tail_kernel
+    constexpr int NIT = FPR * kQMain / 256;
+    __shared__ __attribute__((aligned(16))) double lds[2048 + 8 * 2048];
+    cx<double> *s_tw = reinterpret_cast<cx<double> *>(lds);  // [k1][n2] = W1024^(k1 n2)
+    const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
+    double *slot = lds + 2048 + hw * 2048;  // this half-wavefront's E or O spectrum [1024] c128; transpose plane while it transforms
+    for (int i = tid; i < 1024; i += 256) {
+        const int m = (2 * (i >> 5) * (i & 31)) % kN;  // W1024^(k1 n2) = W2048^(2 k1 n2); a.tw[m] = W2048^m for m < 1024, W^(m + 1024) = -W^m
+        const f64x2 w = a.tw[m % 1024];
+        s_tw[i] = m < 1024 ? cx<double>{w.x, w.y} : cx<double>{-w.x, -w.y};
+    }
+    const int M = a.n_mics, NP = (M + 1) >> 1;
+    const int fs = hw / (2 * NPc), p = (hw % (2 * NPc)) >> 1, eo = hw & 1;
+    const bool has_pair = p < NP;
+
+    int it_f[NIT], it_q[NIT];  // the (frame of the round, problem) items of this thread and their steering entries: the same in every round
+    cd st[NIT][MP];
+#pragma unroll
+    for (int n = 0; n < NIT; ++n) {
+        const int idx = tid + 256 * n;
+        it_f[n] = idx / kQMain;
+        it_q[n] = idx % kQMain;
+        load_steer<MP>(b.steer, q_bin(it_q[n]), M, st[n]);
+    }
+
+    const long r0 = (long)blockIdx.x * rounds_per_block;
+    long r1 = r0 + rounds_per_block;
+    if (r1 > total_rounds) r1 = total_rounds;
+
+    float fr[32], fi[32];  // raw samples of this half-wavefront's next (frame, pair): register j <- sample 2 (32 j + lane) + eo
+    auto request = [&](long r) {
+        const int s = (int)(r / rounds_per_stream);
+        const long t = (r % rounds_per_stream) * FPR + fs;
+        if (!has_pair || t >= a.n_frames) return;
+        const float *xs = a.x + (long)s * a.stream_stride_x;
+        const float *hs = a.hist + (long)s * M * kHop;
+        const int ma = 2 * p;
+        const int mb = (2 * p + 1 < M) ? 2 * p + 1 : ma;
+        if (LAYOUT == 0) {
+            const float *a1 = (t >= 1 ? xs + (long)ma * a.mic_stride + (t - 1) * kHop : hs + ma * kHop) + 2 * lane + eo;
+            const float *b1 = (t >= 1 ? xs + (long)mb * a.mic_stride + (t - 1) * kHop : hs + mb * kHop) + 2 * lane + eo;
+            const float *a2 = xs + (long)ma * a.mic_stride + t * kHop + 2 * lane + eo;
+            const float *b2 = xs + (long)mb * a.mic_stride + t * kHop + 2 * lane + eo;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                fr[j] = a1[64 * j];
+                fi[j] = b1[64 * j];
+                fr[j + 16] = a2[64 * j];
+                fi[j + 16] = b2[64 * j];
+            }
+        } else {
+            const float *s1 = (t >= 1 ? xs + (t - 1) * (long)kHop * M : hs) + (long)(2 * lane + eo) * M;
+            const float *s2 = xs + t * (long)kHop * M + (long)(2 * lane + eo) * M;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                fr[j] = s1[(long)64 * j * M + ma];
+                fi[j] = s1[(long)64 * j * M + mb];
+                fr[j + 16] = s2[(long)64 * j * M + ma];
+                fi[j + 16] = s2[(long)64 * j * M + mb];
+            }
+        }
+    };
+    if (r0 < r1) request(r0);
+    __syncthreads();  // twiddles
+
+    for (long r = r0; r < r1; ++r) {
+        const int s = (int)(r / rounds_per_stream);
+        const long f0 = (r % rounds_per_stream) * FPR;
+        // ---- pass 1: window + FFT-1024 of the even or the odd samples of (frame f0 + fs, pair p) into this half-wavefront's slot ---------------
+        if (has_pair && f0 + fs < a.n_frames) {
+            double re[32], im[32];
+            const double bs = (2 * p + 1 < M) ? 1.0 : 0.0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const double h = a.win[2 * (32 * j + lane) + eo];  // through L1: the LDS is full
+                re[j] = (double)fr[j] * h;                           // buf[j]*hann_win[i]  (util.h:235)
+                im[j] = (double)fi[j] * (h * bs);
+            }
+            fft1024p_fwd_A<double>(re, im, lane, s_tw, slot);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_B<double>(re, lane, slot);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_C<double, false>(im, lane, slot);
+            __builtin_amdgcn_wave_barrier();
+            fft1024p_D<double, -1>(re, im, lane, slot);
+            __builtin_amdgcn_wave_barrier();
+            f64x2 *zo = reinterpret_cast<f64x2 *>(slot) + lane;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) zo[32 * brev5(i)] = f64x2{re[i], im[i]};
+        }
+        __syncthreads();
+        if (r + 1 < r1) request(r + 1);  // lands while the per-bin pass runs
+        // ---- pass 2: the per-bin stage of the FPR frames; X[k] = E[k mod 1024] +- W^(k mod 1024) O[k mod 1024] formed on the read ------------
+        const f64x2 *zs = reinterpret_cast<const f64x2 *>(lds + 2048);
+#pragma unroll
+        for (int n = 0; n < NIT; ++n) {
+            const int f = it_f[n];
+            if (f0 + f >= a.n_frames) continue;
+            const int q = it_q[n], j = q_bin(q);
+            cd X[MP];
+            load_X_split<MP>(zs + (long)f * NPc * 2048, a.tw, q, M, X);
+            const long o = ((long)s * b.n_frames + f0 + f) * kYhStride + q;
+            if (ALGO == BF_DAS) {
+                const cd y = das_core<MP>(X, st[n], M);
+                st_y(b, o, q, y);
+            } else if (ALGO == BF_PHASE) {
+                const cd y = phase_core<MP>(X, st[n], M, j, b.cfg);
+                st_y(b, o, q, y);
+            } else {  // phasempf mask
+                if (j == 0) {
+                    b.Yh[o] = f64x2{X[0].x, X[0].y};
+                    aux[o] = 0.0;
+                } else {
+                    cd soi;
+                    double int2;
+                    mpf_mask_core<MP>(X, st[n], M, b.cfg, soi, int2);
+                    b.Yh[o] = f64x2{soi.x, soi.y};
+                    aux[o] = int2;
+                }
+            }
+        }
+        if (tid < 2 * FPR && f0 + (tid >> 1) < a.n_frames) {  // bins N/2 and N/2+1 of every frame of the round: X only
+            const int f = tid >> 1, q = kQMain + (tid & 1);
+            cd X[MP];
+            load_X_split<MP>(zs + (long)f * NPc * 2048, a.tw, q, M, X);
+            f64x2 *xt = xtail + (((long)s * b.n_frames + f0 + f) * 2 + (tid & 1)) * MP;
+#pragma unroll
+            for (int m = 0; m < MP; ++m) xt[m] = f64x2{X[m].x, X[m].y};
+        }
+        __syncthreads();  // the slots are rewritten by the next round
+    }
+}
+#endif
+
 }  // namespace
 
 // stft + per-bin stage of the history-free nodes in one launch; hipErrorNotSupported = use the two-kernel chain
@@ -1130,12 +1304,18 @@ hipError_t launch_stft_bins_fused(const StftArgs &a, const BinsArgs &b, int n_cu
     }
     if (e == hipSuccess && b.spectrum) e = launch_expand_spectrum(b.Yh, b.spectrum, (long)b.n_streams * b.n_frames, s);
     return e;
-#elif BF_NFFT == 128 || BF_NFFT == 256 || BF_NFFT == 512
+#elif BF_NFFT == 128 || BF_NFFT == 256 || BF_NFFT == 512 || BF_NFFT == 2048
     const int algo = b.cfg.algo;
     if (!(algo == BF_DAS || algo == BF_PHASE || algo == BF_PHASEMPF)) return hipErrorNotSupported;
     if (a.n_mics > 8 || a.n_fft_mics != a.n_mics || b.n_dirs != 1 || a.frame_off != 0 || b.n_streams != a.n_streams)
         return hipErrorNotSupported;
+#if BF_NFFT == 2048
+    const int fpr = a.n_mics <= 4 ? 2 : 1;  // frames per round
+#define BF_FUSED_KERNEL stft_bins_split_kernel
+#else
     const int fpr = (a.n_mics <= 4 ? 4 : 2) * (1024 / kN);  // frames per round
+#define BF_FUSED_KERNEL stft_bins_small_kernel
+#endif
     const long rps = (a.n_frames + fpr - 1) / fpr;
     const long total = rps * a.n_streams;
     long blocks = total < n_cus ? total : n_cus;
@@ -1149,7 +1329,7 @@ hipError_t launch_stft_bins_fused(const StftArgs &a, const BinsArgs &b, int n_cu
     const unsigned tail_blocks = (unsigned)((tail_items + 255) / 256);
 #define BF_FUSED_GO(L_, MP_, A_)                                                                                                                  \
     do {                                                                                                                                          \
-        hipLaunchKernelGGL((stft_bins_small_kernel<L_, MP_, A_>), dim3((unsigned)blocks), dim3(256), 0, s, a, b, rps, total, rpb, aux, xtail);    \
+        hipLaunchKernelGGL((BF_FUSED_KERNEL<L_, MP_, A_>), dim3((unsigned)blocks), dim3(256), 0, s, a, b, rps, total, rpb, aux, xtail);           \
         hipLaunchKernelGGL((fused_tail_kernel<MP_, A_>), dim3(tail_blocks), dim3(256), 0, s, b, (const f64x2 *)xtail, aux);                       \
     } while (0)
 #define BF_FUSED_ALGO(L_, MP_)                                   \
@@ -1165,6 +1345,7 @@ hipError_t launch_stft_bins_fused(const StftArgs &a, const BinsArgs &b, int n_cu
     }
 #undef BF_FUSED_ALGO
 #undef BF_FUSED_GO
+#undef BF_FUSED_KERNEL
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (algo == BF_PHASEMPF) {  // second pass of launch_phasempf: the recursion over frames

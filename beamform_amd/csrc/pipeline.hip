@@ -348,7 +348,7 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     // nodes without a frame history: STFT and per-bin stage in one launch, spectra never leave the CU (launch_stft_bins_fused;
     // BF_FUSED_BINS=0 selects the two-kernel chain) -- then the Z workspace (64 KB per frame at 8 microphones) is not needed at all
     static const int fuse_env = getenv("BF_FUSED_BINS") ? atoi(getenv("BF_FUSED_BINS")) : 1;
-    const bool try_fused = fuse_env != 0 && Phist_ == 0 && N_ <= 1024 && M_ <= 8 && MF_ == M_ && D_ == 1 &&  // (N = 128 / 256 / 512: stft_bins_small_kernel)
+    const bool try_fused = fuse_env != 0 && Phist_ == 0 && N_ <= 2048 && M_ <= 8 && MF_ == M_ && D_ == 1 &&  // (N = 128 / 256 / 512: stft_bins_small_kernel, 2048: stft_bins_split_kernel)
                            (cfg_.algo == BF_DAS || cfg_.algo == BF_PHASE || cfg_.algo == BF_PHASEMPF);
     int rc = BF_OK;
     if (!try_fused)

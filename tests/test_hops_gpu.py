@@ -326,7 +326,8 @@ from beamform_amd.synth import make_scene
 from conftest import rel_l2
 res = {}
 for algo, hop, M, F in (("mvdr", 256, 8, 45), ("phasempf", 128, 5, 33), ("gss", 64, 3, 41), ("mvdr", 1024, 7, 25), ("phase", 1024, 2, 9), ("mcra", 256, 1, 30),
-                        ("phase", 256, 8, 77), ("phase", 64, 3, 51), ("phasempf", 256, 8, 40), ("phase", 128, 7, 1)):
+                        ("phase", 256, 8, 77), ("phase", 64, 3, 51), ("phasempf", 256, 8, 40), ("phase", 128, 7, 1),
+                        ("phase", 1024, 8, 19), ("phasempf", 1024, 3, 12), ("phase", 1024, 5, 1)):
     interf = (-60.0,) if algo == "gss" else ()
     p = make_params(algo, n_mics=M, theta=35.0, hop=hop, interf=interf)
     x = make_scene(M, F, hop=hop, seed=hop + M)
@@ -343,7 +344,7 @@ print("RESULT " + json.dumps(res))
                          ids=["registers", "registers-unfused", "generic"])
 def test_fp64_nodes_stft_kernels_at_other_periods_and_their_switches(env):
     """stft_small_kernel / istft_small_kernel (N = 128 / 256 / 512: several frames per half-wavefront through one transpose plane),
-    stft_split_kernel / istft_split_kernel (N = 2048: FFT-1024 and a radix-2 step), stft_bins_small_kernel (phase / phasempf below 512: the STFT and
+    stft_split_kernel / istft_split_kernel (N = 2048: FFT-1024 and a radix-2 step), stft_bins_small_kernel / stft_bins_split_kernel (phase / phasempf below 512 / at 1024: the STFT and
     the per-bin stage in one launch; BF_FUSED_BINS=0: the chain) and the generic LDS-staged kernels they replace (BF_STFT_SMALL=0 / BF_STFT_SPLIT=0),
     against the oracle: odd microphone counts, one microphone, both layouts, frame counts that leave partial groups, rounds and short runs."""
     import json, os, subprocess, sys
@@ -351,4 +352,4 @@ def test_fp64_nodes_stft_kernels_at_other_periods_and_their_switches(env):
     out = subprocess.run([sys.executable, "-c", CHILD_STFT % dict(root=root)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
-    assert len(res) == 10 and max(res.values()) < TOL, res
+    assert len(res) == 13 and max(res.values()) < TOL, res
