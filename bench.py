@@ -569,6 +569,11 @@ def main():
                 n_settle += 1
             ms, _ = bm.time_device(xin.data_ptr(), F_, yo.data_ptr(), 5, sptr)
             bm.close()
+            if algo_ != "das":  # the fp64 chain of that node at this period: STFT and backward transform in registers, the history-free nodes in one launch
+                return {"workload": f"{algo_} {M}-mic, JACK period {hop_} (FFT {2 * hop_}), {F_} frames = the headline batch's samples; fp64 bin pipeline on "
+                                    "register-resident transforms (stft_istft.hip stft_small / stft_split / istft_small / istft_split kernels; phase: "
+                                    "mask_kernels.hip stft_bins_small / stft_bins_split kernel)",
+                        "ms_per_step": ms, "frames_per_s": F_ / (ms * 1e-3), "samples_per_s": F_ * hop_ / (ms * 1e-3)}
             how = ("two register-resident FFT-1024 passes per frame on the 64-lane transform (das_fused_w64.hip das_fused_2048_w64_kernel)" if hop_ == 1024 else
                    "1024 / N frames interleaved into one pass of the register-resident 1024-point machinery (das_fused.hip, the period-512 kernel in group mode)" if hop_ < 512 else
                    "LDS-staged radix-4 transforms (das_fused_gen.hip)")
@@ -602,6 +607,8 @@ def main():
         jobs.append(("das_dirs16", lambda: dirs_line(16)))
         jobs.append(("das_period256", lambda: other_period_line(256)))
         jobs.append(("das_period1024", lambda: other_period_line(1024)))
+        jobs.append(("phase_period256", lambda: other_period_line(256, "phase")))
+        jobs.append(("mvdr_period256", lambda: other_period_line(256, "mvdr")))
 
         def resample_line():
             # the output stage's sample-rate converter on the batch the headline step just produced (rosjack.cpp:311-338)
