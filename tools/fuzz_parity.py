@@ -26,7 +26,7 @@ for case in range(n_cases):
     if algo == "gsc":
         over["gsc_filter_size"] = int(rng.choice([16, 50, 64, 128, 200]))
     # das also at the other JACK periods (the frame-interleaving and split kernels); the other nodes at a reduced rate (generic transforms)
-    hop = int(rng.choice([64, 128, 256, 512, 512, 1024])) if (algo == "das" or rng.random() < 0.15) and algo != "gsc" else 512
+    hop = int(rng.choice([64, 128, 256, 512, 512, 1024])) if (algo == "das" or rng.random() < float(os.environ.get("BF_FUZZ_HOP_RATE", "0.15"))) and algo != "gsc" else 512
     if hop != 512:
         over["hop"] = hop
     p = make_params(algo, n_mics=M, theta=theta, interf=interf, **over)
