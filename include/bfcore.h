@@ -74,9 +74,10 @@ typedef struct bf_config {
     int n_mics;                    /* number_of_microphones (util.h:122) */
     int hop;                       /* rosjack_window_size = the JACK period (rosjack.cpp:131); fft_win = 2*hop (util.h:261).
                                       Any power of two from 64 to 4096 (what jackd -p accepts in that range).  512 is the tuned
-                                      shape (in-register FFT-1024 kernels); the other periods run das (BF_DAS_FUSED_F32) in one
-                                      fused fp32 kernel on LDS-staged radix-4 transforms and every other node through the fp64
-                                      bin pipeline on LDS-staged transforms (radix-4 autosort; radix-2 in place at 4096) */
+                                      shape (in-register FFT-1024 kernels); 64 ... 256 and 1024 run on the same register-resident
+                                      machinery (several short frames per transform, or two FFT-1024 per long frame) for das
+                                      (BF_DAS_FUSED_F32, one fused fp32 kernel) and for the fp64 bin pipeline of every other node;
+                                      2048 and 4096 on LDS-staged transforms (radix-4 autosort; radix-2 in place at 4096) */
     double sample_rate;            /* rosjack_sample_rate */
     double mic_x[BF_MAX_MICS];     /* RAW mic<i>.x / .y from beamform_config.yaml (util.h:82-92) */
     double mic_y[BF_MAX_MICS];
