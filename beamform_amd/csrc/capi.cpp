@@ -224,14 +224,14 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     // run, 16 runs per CU (das_fused_small.hip; BF_DAS_INTERLEAVE=0: the generic kernel, for A/B runs)
     // (=3: a full wavefront per run on the 64-lane transform, 12 runs per CU; =2: the half-wavefront version, 16 runs per CU; =1, the
     // default: the period-512 kernel itself in group mode -- one block per run, tails through its LDS ring, HBM sees every hop once --
-    // for planar input with up to 8 microphones, =3 otherwise)
+    // ; without BF_DAS_VARIANT=3: =3)
     static const int il_env = getenv("BF_DAS_INTERLEAVE") ? atoi(getenv("BF_DAS_INTERLEAVE")) : 1;
     // BF_DAS_VARIANT bit 0: ds_write_addtid transposes, bit 1: unrolled pair loop with in-loop prefetch; 0 / 1 select the older
     // forms for A/B runs (same arithmetic, bit-identical output)
     static const int das_variant = getenv("BF_DAS_VARIANT") ? atoi(getenv("BF_DAS_VARIANT")) : 3;
     const bool small = gen && h->N < 1024 && !spectrum_dev && il_env != 0 && h->d_gains_il[0] != nullptr && h->d_twiddle_1024 != nullptr;
     const long Rg = small ? 1024 / h->N : 1;
-    const bool small_ring = small && il_env == 1 && layout == BF_PLANAR && h->M <= 8 && das_variant == 3;
+    const bool small_ring = small && il_env == 1 && das_variant == 3;
     const bool small_w64 = small && !small_ring && il_env != 2 && h->d_twiddle_w64 != nullptr;
     long runs = (small_ring ? (long)h->n_cus : small_w64 ? (long)h->n_cus * 12 : small ? (long)h->n_cus * 16 : split_w64 ? (long)h->n_cus * 12 : split2048 ? (long)h->n_cus * 8 : gen ? (long)h->n_cus * gen_per_cu : (long)h->n_cus) / (shared ? h->n_streams : S);
     if (runs < 1) runs = 1;

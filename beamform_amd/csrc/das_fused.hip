@@ -122,50 +122,6 @@ __device__ __forceinline__ void wt_load_row(float (&v)[32], const float *rp) {
         v[4 * g + 0] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
     }
 }
-// forward / backward FFT-1024 of the half-wavefront's 32 x 32 points (same arithmetic as fft1024p_{fwd,inv}_A .. D)
-__device__ __forceinline__ void wt_fft_fwd(float (&re)[32], float (&im)[32], int lane, const cx<float> *tw, unsigned base,
-                                           const float *rp) {
-    fft32_dif<float, -1>(re, im);
-#pragma unroll
-    for (int i = 1; i < 32; ++i) {
-        const cx<float> w = tw[brev5(i) * 32 + lane];
-        const float xr = re[i], xi = im[i];
-        re[i] = xr * w.x - xi * w.y;
-        im[i] = xr * w.y + xi * w.x;
-    }
-    wt_store_plane<false>(re, base);
-    wt_load_row(re, rp);
-    wt_store_plane<false>(im, base);
-    wt_load_row(im, rp);
-    fft32_dif<float, -1>(re, im);
-}
-__device__ __forceinline__ void wt_fft_inv(float (&re)[32], float (&im)[32], int lane, const cx<float> *tw, unsigned base,
-                                           const float *rp) {
-    fft32_dit<float, +1>(re, im);
-#pragma unroll
-    for (int n2 = 1; n2 < 32; ++n2) {
-        const cx<float> w = tw[n2 * 32 + lane];
-        const float xr = re[n2], xi = im[n2];
-        re[n2] = xr * w.x + xi * w.y;
-        im[n2] = xi * w.x - xr * w.y;
-    }
-    wt_store_plane<true>(re, base);
-    wt_load_row(re, rp);
-    wt_store_plane<true>(im, base);
-    wt_load_row(im, rp);
-    fft32_dif<float, +1>(re, im);
-}
-
-// ---- paired tables (unrolled kernels) -------------------------------------------------------------------------------------
-// hipcc merges two ds_read_b64 of one table (twiddle rows k1 and k1', gains of positions i and i') into one ds_read2_b64, which
-// the LDS serves at HALF the rate of the two separate reads (8 cycles per 1 KiB instead of 2 x 2: MI355X guide, LDS table).
-// So the unrolled kernels re-pack both tables while filling the LDS: two entries a lane needs back to back become 16
-// contiguous bytes -> one ds_read_b128 at the full 256 B/clk.
-//   twiddles: [k < 16][lane][2] = { W1024^(k lane), W1024^((k + 16) lane) }   (forward: positions brev5(k), brev5(k) + 1;
-//                                                                             backward: positions k, k + 16)
-//   gains:    [pair][m < 16][lane][2] = { D[2m][lane], D[2m + 1][lane] }
-// SPLIT: the second 32-point pass stops after its stages 0..2 (fft32_dif_head); the caller finishes it four positions at a time
-// with fft32_dif_tail and takes every finished group straight into the weight-and-sum
 //
 // R > 1 (frame groups, see das_fused_kernel): the lanes of a half-wavefront carry the 32 residues n mod 32 in the order perm_lane<R> --
 // physical lane p holds logical lane (p mod (32 / R)) R + p / (32 / R), so that the 32 / R lanes of one frame sit side by side and a load
@@ -184,6 +140,66 @@ __device__ __forceinline__ void perm_regs_fwd(float (&v)[32]) {  // v[p] (column
         for (int p = 0; p < 32; ++p) v[p] = t[p];
     }
 }
+// forward / backward FFT-1024 of the half-wavefront's 32 x 32 points (same arithmetic as fft1024p_{fwd,inv}_A .. D)
+template <int R = 1>
+__device__ __forceinline__ void wt_fft_fwd(float (&re)[32], float (&im)[32], int lane, const cx<float> *tw, unsigned base,
+                                           const float *rp) {
+    fft32_dif<float, -1>(re, im);
+#pragma unroll
+    for (int i = 1; i < 32; ++i) {
+        const cx<float> w = tw[brev5(i) * 32 + lane];
+        const float xr = re[i], xi = im[i];
+        re[i] = xr * w.x - xi * w.y;
+        im[i] = xr * w.y + xi * w.x;
+    }
+    wt_store_plane<false>(re, base);
+    wt_load_row(re, rp);
+    wt_store_plane<false>(im, base);
+    wt_load_row(im, rp);
+    perm_regs_fwd<R>(re);
+    perm_regs_fwd<R>(im);
+    fft32_dif<float, -1>(re, im);
+}
+template <int R = 1>
+__device__ __forceinline__ void wt_fft_inv(float (&re)[32], float (&im)[32], int lane, const cx<float> *tw, unsigned base,
+                                           const float *rp) {
+    fft32_dit<float, +1>(re, im);
+#pragma unroll
+    for (int n2 = 1; n2 < 32; ++n2) {
+        const cx<float> w = tw[n2 * 32 + lane];
+        const float xr = re[n2], xi = im[n2];
+        re[n2] = xr * w.x + xi * w.y;
+        im[n2] = xi * w.x - xr * w.y;
+    }
+    if constexpr (R > 1) {  // row i of the plane receives register perm_lane(i): see wt_fft_inv_p2
+        float t[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t[i] = re[perm_lane<R>(i)];
+        wt_store_plane<true>(t, base);
+        wt_load_row(re, rp);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t[i] = im[perm_lane<R>(i)];
+        wt_store_plane<true>(t, base);
+        wt_load_row(im, rp);
+    } else {
+        wt_store_plane<true>(re, base);
+        wt_load_row(re, rp);
+        wt_store_plane<true>(im, base);
+        wt_load_row(im, rp);
+    }
+    fft32_dif<float, +1>(re, im);
+}
+
+// ---- paired tables (unrolled kernels) -------------------------------------------------------------------------------------
+// hipcc merges two ds_read_b64 of one table (twiddle rows k1 and k1', gains of positions i and i') into one ds_read2_b64, which
+// the LDS serves at HALF the rate of the two separate reads (8 cycles per 1 KiB instead of 2 x 2: MI355X guide, LDS table).
+// So the unrolled kernels re-pack both tables while filling the LDS: two entries a lane needs back to back become 16
+// contiguous bytes -> one ds_read_b128 at the full 256 B/clk.
+//   twiddles: [k < 16][lane][2] = { W1024^(k lane), W1024^((k + 16) lane) }   (forward: positions brev5(k), brev5(k) + 1;
+//                                                                             backward: positions k, k + 16)
+//   gains:    [pair][m < 16][lane][2] = { D[2m][lane], D[2m + 1][lane] }
+// SPLIT: the second 32-point pass stops after its stages 0..2 (fft32_dif_head); the caller finishes it four positions at a time
+// with fft32_dif_tail and takes every finished group straight into the weight-and-sum
 template <bool SPLIT = false, int R = 1>
 __device__ __forceinline__ void wt_fft_fwd_p2(float (&re)[32], float (&im)[32], int lane, const float4 *tw2, unsigned base,
                                               const float *rp BF_STAMP_PARAMS) {
@@ -491,7 +507,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
             }
 
             if (WT) {
-                wt_fft_fwd(re, im, lane, s_tw, wbase, wrowp);
+                wt_fft_fwd<R>(re, im, llane, s_tw, wbase, wrowp);
             } else {
                 fft1024p_fwd_A<float>(re, im, lane, s_tw, pbuf);
                 __builtin_amdgcn_wave_barrier();
@@ -536,7 +552,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
         if (kP2) {
             wt_fft_inv_p2<R>(Sr, Si, lane, reinterpret_cast<const float4 *>(lds), wbase, wrowp BF_STAMP_ARGS);
         } else if (WT) {
-            wt_fft_inv(Sr, Si, lane, s_tw, wbase, wrowp);
+            wt_fft_inv<R>(Sr, Si, lane, s_tw, wbase, wrowp);
         } else {
             fft1024p_inv_A<float>(Sr, Si, lane, s_tw, pbuf);
             __builtin_amdgcn_wave_barrier();
@@ -1345,24 +1361,29 @@ void launch_layout(const DasFusedArgs &a, unsigned blocks, hipStream_t stream) {
     // planar input with the wave-interleaved transposes: pair loop unrolled for the exact pair count, next pair's loads issued
     // from inside the gain loop (BF_DAS_VARIANT bit 1; same arithmetic, bit-identical output)
     const bool unr = LAYOUT == 0 && WT && (a.variant & 2);
+    if (a.group > 1) {  // frame groups (periods below 512): launch_das_fused checked the shape
+        if constexpr (WT) {
+#define BF_DAS_GRP(NPL_, UNR_)                                                                                                                    \
+    do {                                                                                                                                          \
+        if (a.group == 2) hipLaunchKernelGGL((das_fused_kernel<LAYOUT, NPL_, true, UNR_, 2>), dim3(blocks), dim3(kBlock), 0, stream, a);          \
+        else if (a.group == 4) hipLaunchKernelGGL((das_fused_kernel<LAYOUT, NPL_, true, UNR_, 4>), dim3(blocks), dim3(kBlock), 0, stream, a);     \
+        else hipLaunchKernelGGL((das_fused_kernel<LAYOUT, NPL_, true, UNR_, 8>), dim3(blocks), dim3(kBlock), 0, stream, a);                       \
+    } while (0)
+            if constexpr (LAYOUT == 0) {  // planar: the unrolled pair loop up to 8 microphones
+                if (np == 1) BF_DAS_GRP(1, 1); else if (np == 2) BF_DAS_GRP(2, 2); else if (np == 3) BF_DAS_GRP(4, 3); else if (np == 4) BF_DAS_GRP(4, 4);
+                else BF_DAS_GRP(0, 0);    // > 8 microphones: gains from L2
+            } else {
+                if (np == 1) BF_DAS_GRP(1, 0); else if (np == 2) BF_DAS_GRP(2, 0); else if (np <= 4) BF_DAS_GRP(4, 0); else BF_DAS_GRP(0, 0);
+            }
+#undef BF_DAS_GRP
+        }
+        return;
+    }
     if (LAYOUT == 1 && WT && (a.variant & 2) && (a.n_mics == 4 || a.n_mics == 8)) {  // 16-byte loads: two pairs per sample access
         if (a.n_mics == 4)  // one 16-byte load per sample = the whole sample: two frames per wavefront
             hipLaunchKernelGGL((das_fused_il_kernel<2, 1>), dim3(blocks), dim3(kBlock), 0, stream, a);
         else                // 8 microphones: one frame per wavefront, each half-wavefront loads its 16 bytes of the 32-byte sample
             hipLaunchKernelGGL(das_fused_il8_kernel, dim3(blocks), dim3(kBlock), 0, stream, a);
-        return;
-    }
-    if (a.group > 1) {  // frame groups (periods below 512): launch_das_fused checked the shape
-        if constexpr (LAYOUT == 0 && WT) {
-#define BF_DAS_GRP(NPL_, UNR_)                                                                                                                    \
-    do {                                                                                                                                          \
-        if (a.group == 2) hipLaunchKernelGGL((das_fused_kernel<0, NPL_, true, UNR_, 2>), dim3(blocks), dim3(kBlock), 0, stream, a);               \
-        else if (a.group == 4) hipLaunchKernelGGL((das_fused_kernel<0, NPL_, true, UNR_, 4>), dim3(blocks), dim3(kBlock), 0, stream, a);          \
-        else hipLaunchKernelGGL((das_fused_kernel<0, NPL_, true, UNR_, 8>), dim3(blocks), dim3(kBlock), 0, stream, a);                            \
-    } while (0)
-            if (np == 1) BF_DAS_GRP(1, 1); else if (np == 2) BF_DAS_GRP(2, 2); else if (np == 3) BF_DAS_GRP(4, 3); else BF_DAS_GRP(4, 4);
-#undef BF_DAS_GRP
-        }
         return;
     }
 #define BF_DAS_GO(NPL_, UNR_) hipLaunchKernelGGL((das_fused_kernel<LAYOUT, NPL_, WT, UNR_>), dim3(blocks), dim3(kBlock), 0, stream, a)
@@ -1413,10 +1434,10 @@ hipError_t prepare_das_fused(const DasFusedArgs &a, hipStream_t stream) {
     return hipSuccess;
 }
 
-// a.group = 2 / 4 / 8 (periods 256 / 128 / 64 as groups of interleaved frames): planar input, up to 8 microphones, the default
-// variant, no spectrum dump; a.frames_per_chunk a multiple of 16 * group
+// a.group = 2 / 4 / 8 (periods 256 / 128 / 64 as groups of interleaved frames): either layout, any microphone count, the default variant,
+// no spectrum dump; a.frames_per_chunk a multiple of 16 * group
 bool das_fused_takes_groups(const DasFusedArgs &a) {
-    return a.layout == 0 && (a.variant & 3) == 3 && a.n_mics <= 8 && a.sdump == nullptr && (a.group == 2 || a.group == 4 || a.group == 8);
+    return (a.variant & 3) == 3 && a.sdump == nullptr && (a.group == 2 || a.group == 4 || a.group == 8);
 }
 
 hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t stream) {

@@ -204,7 +204,7 @@ def test_fused_das_at_other_periods_layouts_streams_directions_cuts(hop):
         assert rel_l2(y[s], refs[s]) < TOL and rel_l2(yi[s], refs[s]) < TOL
         if hop >= 512:
             assert np.array_equal(y[s], yi[s])
-        else:  # below 512 the two layouts run different transforms (planar: the period-512 kernel in group mode; interleaved: the 64-lane one)
+        else:  # below 512 the two layouts run different instantiations of the group-mode kernel (unrolled / run-time pair loop)
             assert np.abs(y[s].astype(np.float64) - yi[s]).max() <= 2e-6 * np.abs(refs[s]).max()
     # look directions: every beam equals its own node
     thetas = [-60.0, 10.0, 75.0]
@@ -303,7 +303,7 @@ print("RESULT " + json.dumps(res))
 @pytest.mark.parametrize("il", ["1", "3", "2", "0"])
 def test_small_periods_interleaving_kernel_and_its_switch(il):
     """Periods 256 / 128 / 64 without a spectrum dump, 1024 / N frames interleaved into one 1024-point pass: das_fused_kernel in group mode
-    (BF_DAS_INTERLEAVE=1, the default; planar input with up to 8 microphones), das_fused_small_w64_kernel<R> (=3 and every other shape),
+    (BF_DAS_INTERLEAVE=1, the default), das_fused_small_w64_kernel<R> (=3),
     das_fused_small_kernel<R> (=2), and das_fused_gen_kernel<N> (=0) against the oracle: odd frame counts, one callback at a time,
     12 microphones, many runs per stream, a cut stream, interleaved input."""
     import json, os, subprocess, sys
