@@ -217,8 +217,11 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     // period 1024 without a dump: two FFT-1024 passes per frame on the in-register machinery, a half-wavefront per run, 16 runs per CU
     // -- or, the default, a full wavefront per run on the 64-lane transform, 12 runs per CU (BF_DAS_SPLIT2048=1: the half-wavefront
     // version, =0: the generic kernel; for A/B runs)
+    // (=3, the default: ONE 2048-point transform per frame on a full wavefront, eight frames in flight per block and the tails through an LDS
+    // ring -- das_fused.hip das_fused_wave2048_kernel)
     static const int split_env = getenv("BF_DAS_SPLIT2048") ? atoi(getenv("BF_DAS_SPLIT2048")) : 2;
-    const bool split2048 = gen && h->N == 2048 && !spectrum_dev && split_env != 0 && h->d_twiddle_split != nullptr;
+    const bool wave2048 = gen && h->N == 2048 && !spectrum_dev && split_env == 3;
+    const bool split2048 = gen && h->N == 2048 && !spectrum_dev && !wave2048 && split_env != 0 && h->d_twiddle_split != nullptr;
     const bool split_w64 = split2048 && split_env == 2 && h->d_twiddle_split_w64 != nullptr;
     // periods below 512 without a dump: 1024 / N frames interleaved into one pass of the 1024-point machinery, a half-wavefront per
     // run, 16 runs per CU (das_fused_small.hip; BF_DAS_INTERLEAVE=0: the generic kernel, for A/B runs)
@@ -233,11 +236,12 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     const long Rg = small ? 1024 / h->N : 1;
     const bool small_ring = small && il_env == 1 && das_variant == 3;
     const bool small_w64 = small && !small_ring && il_env != 2 && h->d_twiddle_w64 != nullptr;
-    long runs = (small_ring ? (long)h->n_cus : small_w64 ? (long)h->n_cus * 12 : small ? (long)h->n_cus * 16 : split_w64 ? (long)h->n_cus * 12 : split2048 ? (long)h->n_cus * 8 : gen ? (long)h->n_cus * gen_per_cu : (long)h->n_cus) / (shared ? h->n_streams : S);
+    long runs = (small_ring || wave2048 ? (long)h->n_cus : small_w64 ? (long)h->n_cus * 12 : small ? (long)h->n_cus * 16 : split_w64 ? (long)h->n_cus * 12 : split2048 ? (long)h->n_cus * 8 : gen ? (long)h->n_cus * gen_per_cu : (long)h->n_cus) / (shared ? h->n_streams : S);
     if (runs < 1) runs = 1;
     long fpc = (F + runs - 1) / runs;
     if (!gen) fpc = ((fpc + 15) / 16) * 16;
-    if (small_ring) fpc = ((fpc + 16 * Rg - 1) / (16 * Rg)) * (16 * Rg);  // sixteen groups per pass of a block
+    if (wave2048) fpc = ((fpc + 7) / 8) * 8;                              // eight frames per pass of a block
+    else if (small_ring) fpc = ((fpc + 16 * Rg - 1) / (16 * Rg)) * (16 * Rg);  // sixteen groups per pass of a block
     else if (small) fpc = ((fpc + Rg - 1) / Rg) * Rg;                     // whole groups of interleaved frames
     const long cps = (F + fpc - 1) / fpc;
 
@@ -275,7 +279,8 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     a.layout = layout;
     a.variant = das_variant;
     a.group = small_ring ? (int)Rg : 1;
-    if (!gen || small_ring) BF_HIP(h, prepare_das_fused(a, s));
+    if (wave2048) BF_HIP(h, prepare_das_fused_wave2048(a, s));
+    else if (!gen || small_ring) BF_HIP(h, prepare_das_fused(a, s));
     hipEvent_t k0 = nullptr, k1 = nullptr;
     {
         int trc = timing_acquire(h, &k0, &k1);
@@ -286,7 +291,8 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
         for (int d0 = 0; d0 < h->n_dirs; d0 += 16)
             BF_HIP(h, launch_das_fused_dirs(a, d0, h->n_dirs - d0 < 16 ? h->n_dirs - d0 : 16, s));
     } else {
-        BF_HIP(h, small_ring ? launch_das_fused(a, s)
+        BF_HIP(h, wave2048 ? launch_das_fused_wave2048(a, s)
+                  : small_ring ? launch_das_fused(a, s)
                   : small_w64 ? launch_das_fused_small_w64(a, h->N, h->d_twiddle_w64, s)
                   : small ? launch_das_fused_small(a, h->N, h->d_twiddle_1024, s)
                   : split_w64 ? launch_das_fused_2048_w64(a, h->d_twiddle_split_w64, s)

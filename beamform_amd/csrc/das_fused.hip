@@ -693,6 +693,231 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
 
 
 
+// ---- the 1024-frame JACK period: one FULL wavefront per 2048-sample frame on the same plane ------------------------------------------------
+// N = 2048 = 32 (registers) x 64 (lanes).  The shared transpose plane above was built for two independent 1024-point transforms, one per
+// half-wavefront: one store per register position writes a row [half 0: 32 columns | half 1: 32 columns], lane l of half h reads row l,
+// columns 32 h .. 32 h + 31.  Read the 64 columns of a row as ONE transform's n2 = 0..63 instead and the same stores / loads are the
+// transpose of a 32 x 64 decomposition; what is missing is one radix-2 stage over bit 5 of n2, between lane l of half 0 and lane l of half 1:
+// v_permlane32_swap hands each half the other's value (VALU, no LDS).
+//   forward:  fft32_dif over j (n = 64 j + lane64), twiddle W2048^(k1 lane64), transpose; now lane (k1, h) holds n2 = 32 h + c in register c.
+//             Cross-half DIF stage: h = 0 keeps a + b, h = 1 keeps (a - b) W64^c; fft32_dif over c: position i = bin k1 + 32 h + 64 brev5(i).
+//   backward: fft32_dit over i, cross-half DIT stage (h = 0: a + conj(W64^c) b, h = 1: a - conj(W64^c) b), transpose, conjugate twiddle,
+//             fft32_dif<+1>: position i of lane64 = sample 64 brev5(i) + lane64.
+// A frame costs about two period-512 frames; eight frames (one per wavefront) are in flight per block, second halves travel through a
+// 9-slot LDS ring of 1024 floats, run boundaries are completed by atomic adds into a zeroed hop -- das_fused_kernel's scheme with a
+// wavefront where it has a half-wavefront.  Gains (64 KB per direction at 8 microphones) come from L2: [pair][bin], natural order
+// (das_pair_gains_natural), a.twiddle = exp(-2 pi i m / 2048), m < 1024, a.window = 2048 floats (the generic kernel's tables).
+// The two-pass kernel of das_fused_w64.hip (0.74 ms per headline batch of samples) is BF_DAS_SPLIT2048=2.
+constexpr int kHop2 = 1024, kN2 = 2048, kWaves2 = kBlock / 64;
+constexpr int kWinRow2 = 36;  // floats per lane row of the window (32 + pad: float4 reads of 16-lane groups on distinct banks)
+constexpr int o2Tw = 0, o2Pl = o2Tw + 2 * 32 * 64, o2Win = o2Pl + kWaves2 * kWPlane, o2W64 = o2Win + 64 * kWinRow2, o2Tail = o2W64 + 64,
+              o2Flag = o2Tail + (kWaves2 + 1) * kHop2, kLds2048 = o2Flag + 32;
+
+// (lo, hi) = the value of `v` in this lane's twin of half 0 / half 1 (lanes l and l + 32)
+__device__ __forceinline__ void halves_pair(float v, float &lo, float &hi) {
+    float t = v;
+    asm volatile("" : "+v"(t));  // a second, formally independent copy: with identical operands the builtin's two results are folded into one
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, t), false, false);
+    lo = __builtin_bit_cast(float, r[0]);
+    hi = __builtin_bit_cast(float, r[1]);
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(kBlock, 2) void das_fused_wave2048_kernel(DasFusedArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[kLds2048];
+    cx<float> *s_tw = reinterpret_cast<cx<float> *>(lds + o2Tw);      // [k1][lane64] = W2048^(k1 lane64)
+    cx<float> *s_w64 = reinterpret_cast<cx<float> *>(lds + o2W64);    // [c] = W64^c, c < 32
+    float *s_win = lds + o2Win;                                        // [lane64][j] = window[64 j + lane64]
+    float *s_tails = lds + o2Tail;                                     // 9 slots of 1024 floats
+    volatile __attribute__((address_space(3))) int *s_flag = (volatile __attribute__((address_space(3))) int *)(lds + o2Flag);
+    const int tid = threadIdx.x, lane64 = tid & 63, l = tid & 31, h = (tid >> 5) & 1;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *wplane = lds + o2Pl + w * kWPlane;
+    const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float *)wplane);
+    const float *wrowp = wplane + l * kWRow + 32 * h;
+    const int M = a.n_mics, n_pairs = (M + 1) >> 1;
+    const int stream = blockIdx.x / a.chunks_per_stream;  // output stream = input stream * n_dirs + look direction
+    const long c_in_s = blockIdx.x - (long)stream * a.chunks_per_stream;
+    const int in_stream = stream / a.n_dirs;
+    const f32x2 *gains = a.gains + (long)(stream - in_stream * a.n_dirs) * n_pairs * kN2;  // [pair][bin], 1/N folded in
+    {
+        for (int i = tid; i < 32 * 64; i += kBlock) {
+            const int m = ((i >> 6) * (i & 63)) % kN2;  // a.twiddle[m] = W2048^m for m < 1024; W^(m + 1024) = -W^m
+            const f32x2 t = a.twiddle[m % 1024];
+            s_tw[i] = m < 1024 ? cx<float>{t.x, t.y} : cx<float>{-t.x, -t.y};
+        }
+        if (tid < 32) {
+            const f32x2 t = a.twiddle[32 * tid];  // W64^c = W2048^(32 c)
+            s_w64[tid] = cx<float>{t.x, t.y};
+        }
+        for (int i = tid; i < kN2; i += kBlock) s_win[(i & 63) * kWinRow2 + (i >> 6)] = a.window[i];
+    }
+    const long T0 = c_in_s * a.frames_per_chunk;
+    long T1 = T0 + a.frames_per_chunk;
+    if (T1 > a.n_frames) T1 = a.n_frames;
+    if (T0 == 0) {  // stream start: the overlap partner of frame 0 is the carried state (out_buff[0], util.h:302)
+        for (int i = tid; i < kHop2; i += kBlock) s_tails[i] = a.tail_in[(long)stream * kHop2 + i];
+    }
+    if (tid <= kWaves2) s_flag[tid] = (tid == 0) ? (int)(T0 - 1) : -2;  // slot 0 holds "frame T0-1" (state, or unused when T0 > 0)
+    __syncthreads();
+    const float4 *wrow = reinterpret_cast<const float4 *>(s_win + lane64 * kWinRow2);
+    const float *xs = a.x + (long)in_stream * a.stream_stride_x;
+    const float *hs = a.hist_in + (long)in_stream * M * kHop2;
+    float *ys = a.y + (long)stream * a.n_frames * kHop2;
+    const cx<float> w64c = cx<float>{0.f, 0.f};
+    (void)w64c;
+
+    const int n_iter = (int)((T1 - T0 + kWaves2 - 1) / kWaves2);
+    for (int it = 0; it < n_iter; ++it) {
+        const long t = T0 + (long)it * kWaves2 + w;
+        const bool valid = t < T1;
+        const long tc = valid ? t : T1 - 1;
+        float re[32], im[32], Sr[32], Si[32];
+        for (int p = 0; p < n_pairs; ++p) {
+            const int ma = 2 * p, mb = 2 * p + 1;
+            const bool b_ok = mb < M;
+            if (LAYOUT == 0) {
+                const float *a1 = (tc >= 1 ? xs + (long)ma * a.mic_stride + (tc - 1) * kHop2 : hs + ma * kHop2) + lane64;
+                const float *b1 = (!b_ok ? a.zeros : tc >= 1 ? xs + (long)mb * a.mic_stride + (tc - 1) * kHop2 : hs + mb * kHop2) + lane64;
+                const float *a2 = xs + (long)ma * a.mic_stride + tc * kHop2 + lane64;
+                const float *b2 = (!b_ok ? a.zeros : xs + (long)mb * a.mic_stride + tc * kHop2) + lane64;
+                const int bstep = b_ok ? 64 : 0;  // a.zeros holds 1024 floats
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    re[j] = a1[64 * j];
+                    im[j] = b1[bstep * j];
+                    re[j + 16] = a2[64 * j];
+                    im[j + 16] = b2[bstep * j];
+                }
+            } else {
+                const float *s1 = (tc >= 1 ? xs + (tc - 1) * (long)kHop2 * M : hs) + (long)lane64 * M;
+                const float *s2 = xs + tc * (long)kHop2 * M + (long)lane64 * M;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    re[j] = s1[(long)64 * j * M + ma];
+                    im[j] = b_ok ? s1[(long)64 * j * M + mb] : 0.f;
+                    re[j + 16] = s2[(long)64 * j * M + ma];
+                    im[j + 16] = b_ok ? s2[(long)64 * j * M + mb] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {  // buf[j]*hann_win[i]  (util.h:235)
+                const float4 hv = wrow[g];
+                re[4 * g + 0] *= hv.x; im[4 * g + 0] *= hv.x;
+                re[4 * g + 1] *= hv.y; im[4 * g + 1] *= hv.y;
+                re[4 * g + 2] *= hv.z; im[4 * g + 2] *= hv.z;
+                re[4 * g + 3] *= hv.w; im[4 * g + 3] *= hv.w;
+            }
+            fft32_dif<float, -1>(re, im);
+#pragma unroll
+            for (int i = 1; i < 32; ++i) {
+                const cx<float> tw = s_tw[brev5(i) * 64 + lane64];
+                const float xr = re[i], xi = im[i];
+                re[i] = xr * tw.x - xi * tw.y;
+                im[i] = xr * tw.y + xi * tw.x;
+            }
+            wt_store_plane<false>(re, wbase);
+            wt_load_row(re, wrowp);
+            wt_store_plane<false>(im, wbase);
+            wt_load_row(im, wrowp);
+            // lane (k1 = l, h): register c = n2 = 32 h + c.  Radix-2 DIF stage over h: half 0 keeps a + b, half 1 keeps (a - b) W64^c
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                float ar, br, ai, bi;
+                halves_pair(re[c], ar, br);
+                halves_pair(im[c], ai, bi);
+                const cx<float> tw = s_w64[c];
+                const float dr = ar - br, di = ai - bi;
+                re[c] = h ? dr * tw.x - di * tw.y : ar + br;
+                im[c] = h ? dr * tw.y + di * tw.x : ai + bi;
+            }
+            fft32_dif<float, -1>(re, im);
+            const f32x2 *gp = gains + (long)p * kN2 + lane64;  // position i = bin lane64 + 64 brev5(i)
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const f32x2 g = gp[64 * brev5(i)];
+                Sr[i] = bf_fma(-g.y, im[i], bf_fma(g.x, re[i], p == 0 ? 0.f : Sr[i]));
+                Si[i] = bf_fma(g.y, re[i], bf_fma(g.x, im[i], p == 0 ? 0.f : Si[i]));
+            }
+        }
+        // backward
+        fft32_dit<float, +1>(Sr, Si);
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {  // DIT stage over h: n2 = c + 32 h <- a + conj(W64^c) b (h = 0), a - conj(W64^c) b (h = 1)
+            float ar, br, ai, bi;
+            halves_pair(Sr[c], ar, br);
+            halves_pair(Si[c], ai, bi);
+            const cx<float> tw = s_w64[c];
+            const float tr = br * tw.x + bi * tw.y, ti = bi * tw.x - br * tw.y;
+            Sr[c] = h ? ar - tr : ar + tr;
+            Si[c] = h ? ai - ti : ai + ti;
+        }
+        wt_store_plane<true>(Sr, wbase);
+        wt_load_row(Sr, wrowp);
+        wt_store_plane<true>(Si, wbase);
+        wt_load_row(Si, wrowp);
+        // lane64 = n2 (l + 32 h: row l, columns of half h ... see below), register c = k1
+#pragma unroll
+        for (int c = 1; c < 32; ++c) {
+            const cx<float> tw = s_tw[c * 64 + lane64];  // conj applied
+            const float xr = Sr[c], xi = Si[c];
+            Sr[c] = xr * tw.x + xi * tw.y;
+            Si[c] = xi * tw.x - xr * tw.y;
+        }
+        fft32_dif<float, +1>(Sr, Si);
+        // position i holds sample n = 64 brev5(i) + lane64; even i -> first half, odd i -> n + 1024
+        float hh[32];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 hv = wrow[g];
+            hh[4 * g + 0] = hv.x; hh[4 * g + 1] = hv.y; hh[4 * g + 2] = hv.z; hh[4 * g + 3] = hv.w;
+        }
+        const int r = (int)(tc - T0);
+        const int my = (r + 1) % (kWaves2 + 1), pv = r % (kWaves2 + 1);
+        if (valid) {
+            float *my_slot = s_tails + my * kHop2 + lane64;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) my_slot[64 * brev5(2 * q)] = Sr[2 * q + 1] * hh[brev5(2 * q + 1)];
+            asm volatile("" ::: "memory");  // data then flag: LDS operations of one wavefront execute in issue order
+            if (lane64 == 0) s_flag[my] = (int)t;
+            float *yo = ys + t * kHop2 + lane64;
+            if (t == T0 && T0 > 0) {
+                // first hop of the run: the previous run adds its half separately (both into a zeroed hop)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) atomicAdd(yo + 64 * brev5(2 * q), Sr[2 * q] * hh[brev5(2 * q)]);
+            } else {
+                while (s_flag[pv] != (int)(t - 1)) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+                const float *prev = s_tails + pv * kHop2 + lane64;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+#pragma clang fp contract(off)
+                    yo[64 * brev5(2 * q)] = prev[64 * brev5(2 * q)] + Sr[2 * q] * hh[brev5(2 * q)];  // out = prev[H + n] + cur[n]  (util.h:301-302)
+                }
+            }
+            if (t == T1 - 1) {
+                if (T1 < a.n_frames) {  // last frame of the run: its second half belongs to the next run's first hop
+                    float *yn = ys + T1 * kHop2 + lane64;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) atomicAdd(yn + 64 * brev5(2 * q), Sr[2 * q + 1] * hh[brev5(2 * q + 1)]);
+                } else {
+                    // end of the batch: carried state for the next call (OLA tail and the last input hop)
+                    float *to = a.tail_out + (long)stream * kHop2 + lane64;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) to[64 * brev5(2 * q)] = Sr[2 * q + 1] * hh[brev5(2 * q + 1)];
+                    float *ho = a.hist_out + (long)in_stream * M * kHop2;  // every direction writes the same values
+                    if (LAYOUT == 0) {
+                        for (int m = 0; m < M; ++m)
+                            for (int j = 0; j < 16; ++j) ho[m * kHop2 + 64 * j + lane64] = xs[(long)m * a.mic_stride + t * kHop2 + 64 * j + lane64];
+                    } else {
+                        for (int j = 0; j < 16 * M; ++j) ho[64 * j + lane64] = xs[t * (long)kHop2 * M + 64 * j + lane64];
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- interleaved input [sample][mic], 4 or 8 microphones (BF_DAS_VARIANT bit 1) ---------------------------------------------
 // The generic kernel reads one pair (8 bytes) of every 4 M-byte sample per pass: at M = 8 a wave-instruction touches sixteen
 // 128-byte lines and uses a quarter of each, and the four passes of a frame fetch every line four times through the TCP
@@ -1486,6 +1711,27 @@ hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t stream) {
         }
     }
 #endif
+    return hipGetLastError();
+}
+
+// The 1024-frame period, a wavefront per frame (das_fused_wave2048_kernel): a.gains = das_pair_gains_natural tables [dir][pair][2048],
+// a.twiddle = exp(-2 pi i m / 2048) for m < 1024, a.window = 2048 floats, a.zeros >= 1024 floats; a.frames_per_chunk a multiple of 8; the first
+// hop of every run but the first of a stream must be zero beforehand (prepare_das_fused_wave2048); no spectrum dump
+hipError_t prepare_das_fused_wave2048(const DasFusedArgs &a, hipStream_t stream) {
+    if (a.chunks_per_stream > 1) {
+        for (int s = 0; s < a.n_streams; ++s) {
+            hipError_t e = hipMemset2DAsync(a.y + ((long)s * a.n_frames + a.frames_per_chunk) * kHop2, (size_t)a.frames_per_chunk * kHop2 * sizeof(float), 0,
+                                            kHop2 * sizeof(float), (size_t)a.chunks_per_stream - 1, stream);
+            if (e != hipSuccess) return e;
+        }
+    }
+    return hipSuccess;
+}
+hipError_t launch_das_fused_wave2048(const DasFusedArgs &a, hipStream_t stream) {
+    if (a.sdump != nullptr || a.frames_per_chunk % kWaves2 != 0) return hipErrorInvalidValue;
+    const unsigned blocks = (unsigned)((long)a.chunks_per_stream * a.n_streams);
+    if (a.layout == 0) hipLaunchKernelGGL(das_fused_wave2048_kernel<0>, dim3(blocks), dim3(kBlock), 0, stream, a);
+    else hipLaunchKernelGGL(das_fused_wave2048_kernel<1>, dim3(blocks), dim3(kBlock), 0, stream, a);
     return hipGetLastError();
 }
 

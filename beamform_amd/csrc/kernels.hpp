@@ -36,7 +36,10 @@ struct DasFusedArgs {
 hipError_t launch_das_fused_w64(const DasFusedArgs &a, hipStream_t stream);
 hipError_t prepare_das_fused(const DasFusedArgs &a, hipStream_t stream);  // zero the atomically-completed hops
 hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t stream);
-bool das_fused_takes_groups(const DasFusedArgs &a);  // whether launch_das_fused runs this shape with a.group > 1
+bool das_fused_takes_groups(const DasFusedArgs &a);
+// the 1024-frame period on a full wavefront per 2048-point frame (das_fused.hip das_fused_wave2048_kernel): the generic kernel's tables
+hipError_t prepare_das_fused_wave2048(const DasFusedArgs &a, hipStream_t stream);
+hipError_t launch_das_fused_wave2048(const DasFusedArgs &a, hipStream_t stream);  // whether launch_das_fused runs this shape with a.group > 1
 // look directions dir0 .. dir0 + n_here - 1 (n_here <= 16) from ONE set of forward transforms per frame (planar, <= 8 microphones, no
 // spectrum dump); a.chunks_per_stream / frames_per_chunk describe the runs of an INPUT stream; output equal to launch_das_fused's within float rounding, not bit for bit
 // (the window products are fused differently: a beam's low-order bits may change when n_dirs crosses BF_DAS_SHARED_DIRS)

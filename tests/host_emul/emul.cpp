@@ -280,6 +280,103 @@ extern "C" void emul_fft2048_split(const double *in, double *out, int dir) {
     }
 }
 
+// N = 2048 = 32 (registers) x 64 (lanes) as das_fused_wave2048_kernel runs it: first pass over the registers, twiddle, the two-half plane
+// transpose (row = register position, 64 columns; lane l of half h reads row l, columns 32 h ..), one radix-2 stage between the halves, a
+// 32-point pass per lane.  in / out: 2048 complex doubles.
+template <typename T>
+static void fft2048_wave_emul(const double *in, double *out, int dir) {
+    static T re[64][32], im[64][32], pr[32][64], pi_[32][64];
+    auto tw2048 = [&](long m) {
+        const double a = -2.0 * kPi * (double)(m % 2048) / 2048.0;
+        return cx<T>{(T)std::cos(a), (T)std::sin(a)};
+    };
+    auto transpose = [&](bool natural_rows) {
+        for (int ln = 0; ln < 64; ++ln)
+            for (int r = 0; r < 32; ++r) {
+                pr[natural_rows ? r : brev5(r)][ln] = re[ln][r];
+                pi_[natural_rows ? r : brev5(r)][ln] = im[ln][r];
+            }
+        for (int ln = 0; ln < 64; ++ln) {
+            const int l = ln & 31, h = ln >> 5;
+            for (int c = 0; c < 32; ++c) {
+                re[ln][c] = pr[l][32 * h + c];
+                im[ln][c] = pi_[l][32 * h + c];
+            }
+        }
+    };
+    if (dir < 0) {
+        for (int ln = 0; ln < 64; ++ln) {
+            for (int j = 0; j < 32; ++j) {
+                re[ln][j] = (T)in[2 * (64 * j + ln)];
+                im[ln][j] = (T)in[2 * (64 * j + ln) + 1];
+            }
+            fft32_dif<T, -1>(re[ln], im[ln]);
+            for (int i = 1; i < 32; ++i) {
+                const cx<T> w = tw2048((long)brev5(i) * ln);
+                const T xr = re[ln][i], xi = im[ln][i];
+                re[ln][i] = xr * w.x - xi * w.y;
+                im[ln][i] = xr * w.y + xi * w.x;
+            }
+        }
+        transpose(false);
+        for (int l = 0; l < 32; ++l)
+            for (int c = 0; c < 32; ++c) {  // radix-2 DIF stage between lane l of half 0 (a) and of half 1 (b)
+                const T ar = re[l][c], ai = im[l][c], br = re[l + 32][c], bi = im[l + 32][c];
+                const cx<T> w = tw2048(32L * c);  // W64^c
+                const T dr = ar - br, di = ai - bi;
+                re[l][c] = ar + br;
+                im[l][c] = ai + bi;
+                re[l + 32][c] = dr * w.x - di * w.y;
+                im[l + 32][c] = dr * w.y + di * w.x;
+            }
+        for (int ln = 0; ln < 64; ++ln) {
+            fft32_dif<T, -1>(re[ln], im[ln]);
+            for (int i = 0; i < 32; ++i) {
+                const int k = ln + 64 * brev5(i);
+                out[2 * k] = re[ln][i];
+                out[2 * k + 1] = im[ln][i];
+            }
+        }
+    } else {
+        for (int ln = 0; ln < 64; ++ln) {
+            for (int i = 0; i < 32; ++i) {
+                const int k = ln + 64 * brev5(i);
+                re[ln][i] = (T)in[2 * k];
+                im[ln][i] = (T)in[2 * k + 1];
+            }
+            fft32_dit<T, +1>(re[ln], im[ln]);
+        }
+        for (int l = 0; l < 32; ++l)
+            for (int c = 0; c < 32; ++c) {  // radix-2 DIT stage: n2 = c (half 0) <- a + conj(W64^c) b, n2 = c + 32 (half 1) <- a - conj(W64^c) b
+                const T ar = re[l][c], ai = im[l][c], br = re[l + 32][c], bi = im[l + 32][c];
+                const cx<T> w = tw2048(32L * c);
+                const T tr = br * w.x + bi * w.y, ti = bi * w.x - br * w.y;
+                re[l][c] = ar + tr;
+                im[l][c] = ai + ti;
+                re[l + 32][c] = ar - tr;
+                im[l + 32][c] = ai - ti;
+            }
+        transpose(true);
+        for (int ln = 0; ln < 64; ++ln) {
+            for (int c = 1; c < 32; ++c) {
+                const cx<T> w = tw2048((long)c * ln);  // conj applied
+                const T xr = re[ln][c], xi = im[ln][c];
+                re[ln][c] = xr * w.x + xi * w.y;
+                im[ln][c] = xi * w.x - xr * w.y;
+            }
+            fft32_dif<T, +1>(re[ln], im[ln]);
+            for (int i = 0; i < 32; ++i) {
+                const int n = 64 * brev5(i) + ln;
+                out[2 * n] = re[ln][i];
+                out[2 * n + 1] = im[ln][i];
+            }
+        }
+    }
+}
+extern "C" void emul_fft2048_wave(const double *in, double *out, int dir, int use_float) {
+    use_float ? fft2048_wave_emul<float>(in, out, dir) : fft2048_wave_emul<double>(in, out, dir);
+}
+
 extern "C" void emul_fft1024_w64(const double *in, double *out, int dir, int use_float) {
     if (use_float) fft1024_w64_emul<float>(in, out, dir); else fft1024_w64_emul<double>(in, out, dir);
 }

@@ -63,6 +63,8 @@ hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t) {
 hipError_t launch_das_fused_w64(const DasFusedArgs &a, hipStream_t s) { return launch_das_fused(a, s); }
 hipError_t launch_das_fused_2048(const DasFusedArgs &a, const f32x2 *, hipStream_t s) { return launch_das_fused(a, s); }
 hipError_t launch_das_fused_small(const DasFusedArgs &a, int, const f32x2 *, hipStream_t s) { return launch_das_fused(a, s); }
+hipError_t prepare_das_fused_wave2048(const DasFusedArgs &, hipStream_t) { return hipSuccess; }
+hipError_t launch_das_fused_wave2048(const DasFusedArgs &a, hipStream_t s) { return launch_das_fused(a, s); }
 hipError_t launch_das_fused_small_w64(const DasFusedArgs &a, int, const f32x2 *, hipStream_t s) { return launch_das_fused(a, s); }
 hipError_t launch_das_fused_2048_w64(const DasFusedArgs &a, const f32x2 *, hipStream_t s) { return launch_das_fused(a, s); }
 hipError_t launch_das_fused_dirs(const DasFusedArgs &a, int, int, hipStream_t s) { return launch_das_fused(a, s); }

@@ -242,28 +242,36 @@ from beamform_amd.params import make_params
 from beamform_amd.synth import make_scene
 from conftest import rel_l2
 res = {}
-for M, F in ((8, 300), (7, 41), (12, 33)):   # gains in LDS (<= 8 microphones, one direction) and from L2 (12)
+for M, F in ((8, 300), (7, 41), (12, 33), (8, 4501), (1, 9)):   # gains in LDS (<= 8 microphones, one direction) and from L2 (12); 4501 frames: many runs per stream
     p = make_params("das", n_mics=M, theta=35.0, hop=1024)
     x = make_scene(M, F, hop=1024, seed=1024 + M)
     ref, _ = oracle.OracleNode(p).process(x)
     y = Beamformer(p).process(x)
-    res[str(M)] = rel_l2(y, ref)
+    res[f"{M}/{F}"] = rel_l2(y, ref)
+    if F > 1000:  # a cut stream (carried hop and tail across batches) and interleaved input
+        from beamform_amd.capi import BF_INTERLEAVED
+        cut = (F // 3) * 1024
+        bfc = Beamformer(p)
+        yc = np.concatenate([bfc.process(np.ascontiguousarray(x[:, :cut])), bfc.process(np.ascontiguousarray(x[:, cut:]))])
+        res[f"{M}/{F}/cut"] = rel_l2(yc, ref)
+        res[f"{M}/{F}/interleaved"] = rel_l2(Beamformer(p, layout=BF_INTERLEAVED).process(np.ascontiguousarray(x.T)), ref)
 print("RESULT " + json.dumps(res))
 """
 
 
-@pytest.mark.parametrize("split", ["2", "1", "0"])
+@pytest.mark.parametrize("split", ["3", "2", "1", "0"])
 def test_period_1024_split_kernel_and_its_switch(split):
-    """The 1024-frame period without a spectrum dump: das_fused_2048_w64_kernel (two FFT-1024 passes per frame on the 64-lane transform, the
-    default = BF_DAS_SPLIT2048=2), das_fused_2048_kernel (=1: the half-wavefront version) and das_fused_gen_kernel<2048> (=0) against the
-    oracle; the switch is read once per process."""
+    """The 1024-frame period without a spectrum dump: das_fused_wave2048_kernel (one 2048-point transform per frame on a full wavefront, tails
+    through an LDS ring, run boundaries by atomics: the default = BF_DAS_SPLIT2048=3), das_fused_2048_w64_kernel (=2: two FFT-1024 passes per frame
+    on the 64-lane transform), das_fused_2048_kernel (=1: the half-wavefront version) and das_fused_gen_kernel<2048> (=0) against the oracle:
+    odd and single microphone counts, many runs per stream, a cut stream, interleaved input; the switch is read once per process."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", CHILD_1024 % dict(root=root)], env=dict(os.environ, BF_DAS_SPLIT2048=split),
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
-    assert set(res) == {"8", "7", "12"} and max(res.values()) < TOL, res
+    assert len(res) == 7 and max(res.values()) < TOL, res
 
 
 CHILD_SMALL = r"""

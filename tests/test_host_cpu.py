@@ -60,6 +60,19 @@ def test_emulated_small_and_split_transforms(emul_lib):
     assert rel_l2(back, yr * 2048) < 1e-14
 
 
+def test_emulated_fft2048_on_a_full_wavefront(emul_lib):
+    """N = 2048 = 32 registers x 64 lanes (das_fused_wave2048_kernel): the two-half transpose plane read as one 64-column transform and the
+    radix-2 stage between the halves of the wavefront, both directions, against numpy."""
+    rng = np.random.default_rng(11)
+    for use_float, tol in ((0, 1e-14), (1, 5e-7)):
+        for d in (-1, 1):
+            x = rng.standard_normal(2048) + 1j * rng.standard_normal(2048)
+            o = np.empty(2048, np.complex128)
+            emul_lib.emul_fft2048_wave(_ptr(x), _ptr(o), d, use_float)
+            ref = np.fft.fft(x) if d < 0 else np.fft.ifft(x) * 2048
+            assert rel_l2(o, ref) < tol
+
+
 def test_emulated_fft1024_w64(emul_lib):
     """64-lane x 16-point three-pass factorisation (fft1024_w64.hpp): index maps and twiddles."""
     rng = np.random.default_rng(1)
