@@ -219,7 +219,7 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     // version, =0: the generic kernel; for A/B runs)
     // (=3, the default: ONE 2048-point transform per frame on a full wavefront, eight frames in flight per block and the tails through an LDS
     // ring -- das_fused.hip das_fused_wave2048_kernel)
-    static const int split_env = getenv("BF_DAS_SPLIT2048") ? atoi(getenv("BF_DAS_SPLIT2048")) : 2;
+    static const int split_env = getenv("BF_DAS_SPLIT2048") ? atoi(getenv("BF_DAS_SPLIT2048")) : 3;
     const bool wave2048 = gen && h->N == 2048 && !spectrum_dev && split_env == 3;
     const bool split2048 = gen && h->N == 2048 && !spectrum_dev && !wave2048 && split_env != 0 && h->d_twiddle_split != nullptr;
     const bool split_w64 = split2048 && split_env == 2 && h->d_twiddle_split_w64 != nullptr;

@@ -713,13 +713,15 @@ constexpr int kWinRow2 = 36;  // floats per lane row of the window (32 + pad: fl
 constexpr int o2Tw = 0, o2Pl = o2Tw + 2 * 32 * 64, o2Win = o2Pl + kWaves2 * kWPlane, o2W64 = o2Win + 64 * kWinRow2, o2Tail = o2W64 + 64,
               o2Flag = o2Tail + (kWaves2 + 1) * kHop2, kLds2048 = o2Flag + 32;
 
-// (lo, hi) = the value of `v` in this lane's twin of half 0 / half 1 (lanes l and l + 32)
+// (lo, hi) = the value of `v` in this lane's twin of half 0 / half 1 (lanes l and l + 32).  v_permlane32_swap_b32 vdst, vsrc exchanges
+// vdst[32..63] with vsrc[0..31]: with both operands holding v, vdst becomes half 0's value in both halves and vsrc half 1's.  Written as
+// inline assembly: through __builtin_amdgcn_permlane32_swap this compiler (ROCm 7.2) uses the first result for both (lo - hi came out as
+// v_sub v, v).  The s_nop covers the VALU-write -> permlane-read wait states the compiler would have inserted.
 __device__ __forceinline__ void halves_pair(float v, float &lo, float &hi) {
-    float t = v;
-    asm volatile("" : "+v"(t));  // a second, formally independent copy: with identical operands the builtin's two results are folded into one
-    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, t), false, false);
-    lo = __builtin_bit_cast(float, r[0]);
-    hi = __builtin_bit_cast(float, r[1]);
+    float a_ = v, b_ = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a_), "+v"(b_));
+    lo = a_;
+    hi = b_;
 }
 
 template <int LAYOUT>
@@ -768,30 +770,42 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_wave2048_kernel(DasFusedA
     (void)w64c;
 
     const int n_iter = (int)((T1 - T0 + kWaves2 - 1) / kWaves2);
-    for (int it = 0; it < n_iter; ++it) {
+    float re[32], im[32], Sr[32], Si[32];
+    auto frame_of = [&](int it) -> long {  // the frame of this wavefront at iteration `it` (clamped into the run: spare slots redo its last frame)
         const long t = T0 + (long)it * kWaves2 + w;
-        const bool valid = t < T1;
-        const long tc = valid ? t : T1 - 1;
-        float re[32], im[32], Sr[32], Si[32];
-        for (int p = 0; p < n_pairs; ++p) {
-            const int ma = 2 * p, mb = 2 * p + 1;
-            const bool b_ok = mb < M;
-            if (LAYOUT == 0) {
-                const float *a1 = (tc >= 1 ? xs + (long)ma * a.mic_stride + (tc - 1) * kHop2 : hs + ma * kHop2) + lane64;
-                const float *b1 = (!b_ok ? a.zeros : tc >= 1 ? xs + (long)mb * a.mic_stride + (tc - 1) * kHop2 : hs + mb * kHop2) + lane64;
-                const float *a2 = xs + (long)ma * a.mic_stride + tc * kHop2 + lane64;
-                const float *b2 = (!b_ok ? a.zeros : xs + (long)mb * a.mic_stride + tc * kHop2) + lane64;
-                const int bstep = b_ok ? 64 : 0;  // a.zeros holds 1024 floats
+        return t < T1 ? t : T1 - 1;
+    };
+    // raw samples of microphone pair p of frame tc into re (mic 2p) / im (mic 2p+1): register j <-> sample 64 j + lane64
+    auto issue_loads = [&](long tc, int p) {
+        const int ma = 2 * p, mb = 2 * p + 1;
+        const bool b_ok = mb < M;  // odd microphone count: the last pair's partner channel reads the zero buffer
+        if (LAYOUT == 0) {
+            const float *a1 = (tc >= 1 ? xs + (long)ma * a.mic_stride + (tc - 1) * kHop2 : hs + ma * kHop2) + lane64;
+            const float *b1 = (!b_ok ? a.zeros : tc >= 1 ? xs + (long)mb * a.mic_stride + (tc - 1) * kHop2 : hs + mb * kHop2) + lane64;
+            const float *a2 = xs + (long)ma * a.mic_stride + tc * kHop2 + lane64;
+            const float *b2 = (!b_ok ? a.zeros : xs + (long)mb * a.mic_stride + tc * kHop2) + lane64;
+            const int bstep = b_ok ? 64 : 0;  // a.zeros holds 2048 floats
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                re[j] = a1[64 * j];
+                im[j] = b1[bstep * j];
+                re[j + 16] = a2[64 * j];
+                im[j + 16] = b2[bstep * j];
+            }
+        } else {
+            const float *s1 = (tc >= 1 ? xs + (tc - 1) * (long)kHop2 * M : hs) + (long)lane64 * M;
+            const float *s2 = xs + tc * (long)kHop2 * M + (long)lane64 * M;
+            if (b_ok && (M & 1) == 0) {  // the two microphones of a pair are adjacent: one 8-byte load per sample
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    re[j] = a1[64 * j];
-                    im[j] = b1[bstep * j];
-                    re[j + 16] = a2[64 * j];
-                    im[j + 16] = b2[bstep * j];
+                    const float2 u = *reinterpret_cast<const float2 *>(s1 + (long)64 * j * M + ma);
+                    const float2 v = *reinterpret_cast<const float2 *>(s2 + (long)64 * j * M + ma);
+                    re[j] = u.x;
+                    im[j] = u.y;
+                    re[j + 16] = v.x;
+                    im[j + 16] = v.y;
                 }
             } else {
-                const float *s1 = (tc >= 1 ? xs + (tc - 1) * (long)kHop2 * M : hs) + (long)lane64 * M;
-                const float *s2 = xs + tc * (long)kHop2 * M + (long)lane64 * M;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     re[j] = s1[(long)64 * j * M + ma];
@@ -800,6 +814,15 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_wave2048_kernel(DasFusedA
                     im[j + 16] = b_ok ? s2[(long)64 * j * M + mb] : 0.f;
                 }
             }
+        }
+    };
+    if (n_iter > 0) issue_loads(frame_of(0), 0);
+    for (int it = 0; it < n_iter; ++it) {
+        const long t = T0 + (long)it * kWaves2 + w;
+        const bool valid = t < T1;
+        const long tc = valid ? t : T1 - 1;
+        for (int p = 0; p < n_pairs; ++p) {
+            if (p > 0) issue_loads(tc, p);
 #pragma unroll
             for (int g = 0; g < 8; ++g) {  // buf[j]*hann_win[i]  (util.h:235)
                 const float4 hv = wrow[g];
@@ -840,7 +863,8 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_wave2048_kernel(DasFusedA
                 Si[i] = bf_fma(g.y, re[i], bf_fma(g.x, im[i], p == 0 ? 0.f : Si[i]));
             }
         }
-        // backward
+        // the next frame's first pair streams in while the backward transform runs on (Sr, Si)
+        if (it + 1 < n_iter) issue_loads(frame_of(it + 1), 0);
         fft32_dit<float, +1>(Sr, Si);
 #pragma unroll
         for (int c = 0; c < 32; ++c) {  // DIT stage over h: n2 = c + 32 h <- a + conj(W64^c) b (h = 0), a - conj(W64^c) b (h = 1)

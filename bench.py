@@ -555,7 +555,7 @@ def main():
 
         def other_period_line(hop_, algo_="das"):
             # JACK periods other than 512 frames (rosjack.cpp:131; fft_win = 2 * period): one fused fp32 kernel on LDS-staged radix-4
-            # transforms (das_fused_gen.hip; period 1024: das_fused_w64.hip's split kernel; below 512: das_fused.hip's group mode); same number of SAMPLES as the headline batch
+            # transforms (das_fused_gen.hip; period 1024: das_fused.hip's wavefront-per-frame kernel; below 512: das_fused.hip's group mode); same number of SAMPLES as the headline batch
             pm = make_params(algo_, n_mics=M, hop=hop_)
             F_ = F * HOP // hop_
             bm = Beamformer(pm, device=local_rank)
@@ -574,7 +574,7 @@ def main():
                                     "register-resident transforms (stft_istft.hip stft_small / stft_split / istft_small / istft_split kernels; phase: "
                                     "mask_kernels.hip stft_bins_small / stft_bins_split kernel)",
                         "ms_per_step": ms, "frames_per_s": F_ / (ms * 1e-3), "samples_per_s": F_ * hop_ / (ms * 1e-3)}
-            how = ("two register-resident FFT-1024 passes per frame on the 64-lane transform (das_fused_w64.hip das_fused_2048_w64_kernel)" if hop_ == 1024 else
+            how = ("one register-resident 2048-point transform per frame on a full wavefront (das_fused.hip das_fused_wave2048_kernel)" if hop_ == 1024 else
                    "1024 / N frames interleaved into one pass of the register-resident 1024-point machinery (das_fused.hip, the period-512 kernel in group mode)" if hop_ < 512 else
                    "LDS-staged radix-4 transforms (das_fused_gen.hip)")
             return {"workload": f"{algo_} {M}-mic, JACK period {hop_} (FFT {2 * hop_}), {F_} frames = the headline batch's samples; fused fp32 kernel on " + how,
