@@ -1261,6 +1261,142 @@ __global__ __launch_bounds__(256) void istft_small_kernel(IstftArgs a, int L) {
 #endif
 
 #if BF_NFFT == 2048
+// ---- N = 2048 as ONE transform per FULL wavefront: 32 registers x 64 lanes (das_fused.hip das_fused_wave2048_kernel has the scheme) -----------
+// First pass over the registers (n = 64 j + lane64), twiddle W2048^(k1 lane64), a 32 x 64 plane transpose through LDS (row = register position,
+// 64 columns; lane l of half h reads row l, columns 32 h .. 32 h + 31), one radix-2 stage between lane l of half 0 and of half 1
+// (v_permlane32_swap_b32 on the two dwords of a double), a second 32-point pass: position i of lane64 = bin lane64 + 64 brev5(i), a store writes 64
+// consecutive bins.  No even / odd passes, no second read of the samples, 128 data registers.  stft_split_kernel (two FFT-1024 and a radix-2
+// step, the first transform waiting in the accumulator registers): 1.27 ms z48 / 1.46 ms c128 per 32 768 frames of 8 microphones.
+__device__ __forceinline__ void halves_pair_d(double v, double &lo, double &hi) {  // the value of v in lane l of half 0 / of half 1
+    unsigned a0 = (unsigned)__double2loint(v), a1 = (unsigned)__double2hiint(v), b0 = a0, b1 = a1;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 0" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+    lo = __hiloint2double((int)a1, (int)a0);
+    hi = __hiloint2double((int)b1, (int)b0);
+}
+
+template <int LAYOUT, bool Z48>
+__global__ __launch_bounds__(256) void stft_wave2048_kernel(StftArgs a) {
+    constexpr int kBlock = 256, kWaves = kBlock / 64, kRS = 66, kWinRow = 34;  // 66-double rows: 16-lane ds_read_b128 groups on distinct banks
+    __shared__ __attribute__((aligned(16))) double lds[2 * 32 * 64 + 64 + kWaves * 32 * kRS + 64 * kWinRow];
+    cx<double> *s_tw = reinterpret_cast<cx<double> *>(lds);              // [k1][lane64] = W2048^(k1 lane64)
+    cx<double> *s_w64 = reinterpret_cast<cx<double> *>(lds + 2 * 32 * 64);  // [c] = W64^c
+    const int tid = threadIdx.x, lane64 = tid & 63, l = tid & 31, h = (tid >> 5) & 1;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *pl = lds + 2 * 32 * 64 + 64 + w * 32 * kRS;
+    double *s_win = lds + 2 * 32 * 64 + 64 + kWaves * 32 * kRS;  // [lane64][j] = win[64 j + lane64]
+    {
+        for (int i = tid; i < 32 * 64; i += kBlock) {
+            const int m = ((i >> 6) * (i & 63)) % kN;  // a.tw[m] = W2048^m for m < 1024, W^(m + 1024) = -W^m
+            const f64x2 t = a.tw[m % 1024];
+            s_tw[i] = m < 1024 ? cx<double>{t.x, t.y} : cx<double>{-t.x, -t.y};
+        }
+        if (tid < 32) {
+            const f64x2 t = a.tw[32 * tid];  // W64^c = W2048^(32 c)
+            s_w64[tid] = cx<double>{t.x, t.y};
+        }
+        for (int i = tid; i < kN; i += kBlock) s_win[(i & 63) * kWinRow + (i >> 6)] = a.win[i] * (Z48 ? 0.5 : 1.0);  // z48 spectra are stored halved (exact)
+        __syncthreads();
+    }
+    const f64x2 *wrow = reinterpret_cast<const f64x2 *>(s_win + lane64 * kWinRow);
+    const int M = a.n_mics, MF = a.n_fft_mics, NP = (MF + 1) >> 1, L = a.run_len;
+    const long runs = (a.n_frames + L - 1) / L;
+    const long total = (long)a.n_streams * runs * NP;
+    const long stride = (long)gridDim.x * kWaves;
+    for (long item = (long)blockIdx.x * kWaves + w; item < total; item += stride) {  // no block barrier below
+        const int p = (int)(item % NP);
+        const long sr = item / NP;
+        const long run = sr % runs;
+        const int s = (int)(sr / runs);
+        const float *xs = a.x + (long)s * a.stream_stride_x;
+        const float *hs = a.hist + (long)s * M * kHop;
+        const int ma = 2 * p;
+        const bool b_ok = 2 * p + 1 < MF;
+        const int mb = b_ok ? 2 * p + 1 : ma;
+        const double bs = b_ok ? 1.0 : 0.0;
+        long te = (run + 1) * L;
+        if (te > a.n_frames) te = a.n_frames;
+        for (long t = run * L; t < te; ++t) {
+            double re[32], im[32];
+            if (LAYOUT == 0) {
+                const float *pa = (t >= 1 ? xs + (long)ma * a.mic_stride + (t - 1) * kHop : hs + ma * kHop) + lane64;
+                const float *pb = (t >= 1 ? xs + (long)mb * a.mic_stride + (t - 1) * kHop : hs + mb * kHop) + lane64;
+                const float *ca = xs + (long)ma * a.mic_stride + t * kHop + lane64, *cb = xs + (long)mb * a.mic_stride + t * kHop + lane64;
+#pragma unroll
+                for (int j = 0; j < 16; j += 2) {
+                    const f64x2 w1 = wrow[j >> 1], w2 = wrow[8 + (j >> 1)];  // win[64 j + lane64], win[64 (j + 1) + lane64] / the same for j + 16
+                    re[j] = (double)pa[64 * j] * w1.x;  // buf[j]*hann_win[i]  (util.h:235)
+                    im[j] = (double)pb[64 * j] * (w1.x * bs);
+                    re[j + 1] = (double)pa[64 * (j + 1)] * w1.y;
+                    im[j + 1] = (double)pb[64 * (j + 1)] * (w1.y * bs);
+                    re[j + 16] = (double)ca[64 * j] * w2.x;
+                    im[j + 16] = (double)cb[64 * j] * (w2.x * bs);
+                    re[j + 17] = (double)ca[64 * (j + 1)] * w2.y;
+                    im[j + 17] = (double)cb[64 * (j + 1)] * (w2.y * bs);
+                }
+            } else {
+                const float *ps = (t >= 1 ? xs + (t - 1) * (long)kHop * M : hs) + (long)lane64 * M, *cs = xs + t * (long)kHop * M + (long)lane64 * M;
+#pragma unroll
+                for (int j = 0; j < 16; j += 2) {
+                    const f64x2 w1 = wrow[j >> 1], w2 = wrow[8 + (j >> 1)];
+                    re[j] = (double)ps[(long)64 * j * M + ma] * w1.x;
+                    im[j] = (double)ps[(long)64 * j * M + mb] * (w1.x * bs);
+                    re[j + 1] = (double)ps[(long)64 * (j + 1) * M + ma] * w1.y;
+                    im[j + 1] = (double)ps[(long)64 * (j + 1) * M + mb] * (w1.y * bs);
+                    re[j + 16] = (double)cs[(long)64 * j * M + ma] * w2.x;
+                    im[j + 16] = (double)cs[(long)64 * j * M + mb] * (w2.x * bs);
+                    re[j + 17] = (double)cs[(long)64 * (j + 1) * M + ma] * w2.y;
+                    im[j + 17] = (double)cs[(long)64 * (j + 1) * M + mb] * (w2.y * bs);
+                }
+            }
+            fft32_dif<double, -1>(re, im);
+#pragma unroll
+            for (int i = 1; i < 32; ++i) {
+                const cx<double> tw = s_tw[brev5(i) * 64 + lane64];
+                const double xr = re[i], xi = im[i];
+                re[i] = xr * tw.x - xi * tw.y;
+                im[i] = xr * tw.y + xi * tw.x;
+            }
+            const double *rowp = pl + l * kRS + 32 * h;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) pl[brev5(i) * kRS + lane64] = re[i];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < 32; ++c) re[c] = rowp[c];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 32; ++i) pl[brev5(i) * kRS + lane64] = im[i];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < 32; ++c) im[c] = rowp[c];
+            __builtin_amdgcn_wave_barrier();
+            // lane (k1 = l, h): register c = n2 = 32 h + c.  Radix-2 DIF stage over h: half 0 keeps a + b, half 1 keeps (a - b) W64^c
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                double ar, br, ai, bi;
+                halves_pair_d(re[c], ar, br);
+                halves_pair_d(im[c], ai, bi);
+                const cx<double> tw = s_w64[c];
+                const double dr = ar - br, di = ai - bi;
+                re[c] = h ? dr * tw.x - di * tw.y : ar + br;
+                im[c] = h ? dr * tw.y + di * tw.x : ai + bi;
+            }
+            fft32_dif<double, -1>(re, im);
+            const long zoff = (((long)s * a.frames_ws + a.frame_off + t) * NP + p) * kN + lane64;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int row = 64 * brev5(i);  // bins row .. row + 63 of this store
+                if (row > a.skip_lo && row + 63 < a.skip_hi) continue;  // band-limited nodes never read these bins
+                if (Z48)
+                    reinterpret_cast<z48 *>(a.Z)[zoff + row] = enc48(re[i], im[i]);
+                else
+                    a.Z[zoff + row] = f64x2{re[i], im[i]};
+            }
+        }
+    }
+}
+#endif
+
+#if BF_NFFT == 2048
 // ---- backward side of stft_split_kernel: ONE FFT-1024 per frame ------------------------------------------------------------------------------
 // y real: its even samples have the spectrum A[k] = Y[k] + Y[k + 1024], its odd samples B[k] = (Y[k] - Y[k + 1024]) conj(W2048^k) (one radix-2
 // decimation-in-frequency step of the backward transform), both Hermitian over 1024 bins -- so IFFT1024(A + i B) = y_even + i y_odd: one complex
@@ -1574,8 +1710,31 @@ hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
     }
 #endif
 #if BF_NFFT == 2048
-    // two register-resident FFT-1024 passes per frame (BF_STFT_SPLIT=0: the generic kernel, for A/B runs)
-    static const bool split_on = !(getenv("BF_STFT_SPLIT") && atoi(getenv("BF_STFT_SPLIT")) == 0);
+    // one 2048-point transform per full wavefront (BF_STFT_SPLIT=2: two register-resident FFT-1024 per frame and a radix-2 step; =0: the generic
+    // kernel; for A/B runs)
+    static const int split_env = getenv("BF_STFT_SPLIT") ? atoi(getenv("BF_STFT_SPLIT")) : 1;
+    const bool split_on = split_env != 0;
+    if (split_env == 1) {
+        constexpr int waves = 4;
+        const long np = (a.n_fft_mics + 1) / 2;
+        StftArgs b = a;
+        const long slots = (long)n_cus * waves * 2;
+        long L = ((long)a.n_streams * a.n_frames * np + slots - 1) / slots;
+        if (L > 256) L = 256;
+        if (L < 1) L = 1;
+        b.run_len = (int)L;
+        const long items = (long)a.n_streams * ((a.n_frames + L - 1) / L) * np;
+        long blocks = (items + waves - 1) / waves;
+        if (blocks > (long)n_cus * 4) blocks = (long)n_cus * 4;
+        if (a.layout == 0) {
+            if (a.z48) hipLaunchKernelGGL((stft_wave2048_kernel<0, true>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+            else hipLaunchKernelGGL((stft_wave2048_kernel<0, false>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+        } else {
+            if (a.z48) hipLaunchKernelGGL((stft_wave2048_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+            else hipLaunchKernelGGL((stft_wave2048_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+        }
+        return hipGetLastError();
+    }
     if (split_on) {
         constexpr int halves = 8;
         const long np = (a.n_fft_mics + 1) / 2;

@@ -348,11 +348,13 @@ print("RESULT " + json.dumps(res))
 """
 
 
-@pytest.mark.parametrize("env", [{}, {"BF_FUSED_BINS": "0"}, {"BF_STFT_SMALL": "0", "BF_STFT_SPLIT": "0", "BF_FUSED_BINS": "0"}],
-                         ids=["registers", "registers-unfused", "generic"])
+@pytest.mark.parametrize("env", [{}, {"BF_FUSED_BINS": "0"}, {"BF_STFT_SPLIT": "2", "BF_FUSED_BINS": "0"},
+                                 {"BF_STFT_SMALL": "0", "BF_STFT_SPLIT": "0", "BF_FUSED_BINS": "0"}],
+                         ids=["registers", "registers-unfused", "split-unfused", "generic"])
 def test_fp64_nodes_stft_kernels_at_other_periods_and_their_switches(env):
     """stft_small_kernel / istft_small_kernel (N = 128 / 256 / 512: several frames per half-wavefront through one transpose plane),
-    stft_split_kernel / istft_split_kernel (N = 2048: FFT-1024 and a radix-2 step), stft_bins_small_kernel / stft_bins_split_kernel (phase / phasempf below 512 / at 1024: the STFT and
+    stft_wave2048_kernel (N = 2048: one transform per full wavefront; BF_STFT_SPLIT=2: stft_split_kernel, two FFT-1024 and a radix-2 step) /
+    istft_split_kernel, stft_bins_small_kernel / stft_bins_split_kernel (phase / phasempf below 512 / at 1024: the STFT and
     the per-bin stage in one launch; BF_FUSED_BINS=0: the chain) and the generic LDS-staged kernels they replace (BF_STFT_SMALL=0 / BF_STFT_SPLIT=0),
     against the oracle: odd microphone counts, one microphone, both layouts, frame counts that leave partial groups, rounds and short runs."""
     import json, os, subprocess, sys
