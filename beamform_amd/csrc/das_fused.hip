@@ -717,11 +717,13 @@ constexpr int o2Tw = 0, o2Pl = o2Tw + 2 * 32 * 64, o2Win = o2Pl + kWaves2 * kWPl
 // vdst[32..63] with vsrc[0..31]: with both operands holding v, vdst becomes half 0's value in both halves and vsrc half 1's.  Written as
 // inline assembly: through __builtin_amdgcn_permlane32_swap this compiler (ROCm 7.2) uses the first result for both (lo - hi came out as
 // v_sub v, v).  The s_nop covers the VALU-write -> permlane-read wait states the compiler would have inserted.
-__device__ __forceinline__ void halves_pair(float v, float &lo, float &hi) {
-    float a_ = v, b_ = v;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a_), "+v"(b_));
-    lo = a_;
-    hi = b_;
+// Four values per statement: the two wait states between the copies and the first swap are paid once.
+__device__ __forceinline__ void halves_quad(const float (&v)[4], float (&lo)[4], float (&hi)[4]) {
+    float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], b0 = v[0], b1 = v[1], b2 = v[2], b3 = v[3];
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+    lo[0] = a0; lo[1] = a1; lo[2] = a2; lo[3] = a3;
+    hi[0] = b0; hi[1] = b1; hi[2] = b2; hi[3] = b3;
 }
 
 template <int LAYOUT>
@@ -845,14 +847,18 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_wave2048_kernel(DasFusedA
             wt_load_row(im, wrowp);
             // lane (k1 = l, h): register c = n2 = 32 h + c.  Radix-2 DIF stage over h: half 0 keeps a + b, half 1 keeps (a - b) W64^c
 #pragma unroll
-            for (int c = 0; c < 32; ++c) {
-                float ar, br, ai, bi;
-                halves_pair(re[c], ar, br);
-                halves_pair(im[c], ai, bi);
-                const cx<float> tw = s_w64[c];
-                const float dr = ar - br, di = ai - bi;
-                re[c] = h ? dr * tw.x - di * tw.y : ar + br;
-                im[c] = h ? dr * tw.y + di * tw.x : ai + bi;
+            for (int c = 0; c < 32; c += 2) {
+                const float v[4] = {re[c], im[c], re[c + 1], im[c + 1]};
+                float lo[4], hi[4];
+                halves_quad(v, lo, hi);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float ar = lo[2 * e], ai = lo[2 * e + 1], br = hi[2 * e], bi = hi[2 * e + 1];
+                    const cx<float> tw = s_w64[c + e];
+                    const float dr = ar - br, di = ai - bi;
+                    re[c + e] = h ? dr * tw.x - di * tw.y : ar + br;
+                    im[c + e] = h ? dr * tw.y + di * tw.x : ai + bi;
+                }
             }
             fft32_dif<float, -1>(re, im);
             const f32x2 *gp = gains + (long)p * kN2 + lane64;  // position i = bin lane64 + 64 brev5(i)
@@ -867,14 +873,18 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_wave2048_kernel(DasFusedA
         if (it + 1 < n_iter) issue_loads(frame_of(it + 1), 0);
         fft32_dit<float, +1>(Sr, Si);
 #pragma unroll
-        for (int c = 0; c < 32; ++c) {  // DIT stage over h: n2 = c + 32 h <- a + conj(W64^c) b (h = 0), a - conj(W64^c) b (h = 1)
-            float ar, br, ai, bi;
-            halves_pair(Sr[c], ar, br);
-            halves_pair(Si[c], ai, bi);
-            const cx<float> tw = s_w64[c];
-            const float tr = br * tw.x + bi * tw.y, ti = bi * tw.x - br * tw.y;
-            Sr[c] = h ? ar - tr : ar + tr;
-            Si[c] = h ? ai - ti : ai + ti;
+        for (int c = 0; c < 32; c += 2) {  // DIT stage over h: n2 = c + 32 h <- a + conj(W64^c) b (h = 0), a - conj(W64^c) b (h = 1)
+            const float v[4] = {Sr[c], Si[c], Sr[c + 1], Si[c + 1]};
+            float lo[4], hi[4];
+            halves_quad(v, lo, hi);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float ar = lo[2 * e], ai = lo[2 * e + 1], br = hi[2 * e], bi = hi[2 * e + 1];
+                const cx<float> tw = s_w64[c + e];
+                const float tr = br * tw.x + bi * tw.y, ti = bi * tw.x - br * tw.y;
+                Sr[c + e] = h ? ar - tr : ar + tr;
+                Si[c + e] = h ? ai - ti : ai + ti;
+            }
         }
         wt_store_plane<true>(Sr, wbase);
         wt_load_row(Sr, wrowp);

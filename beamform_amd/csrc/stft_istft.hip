@@ -1269,7 +1269,7 @@ __global__ __launch_bounds__(256) void istft_small_kernel(IstftArgs a, int L) {
 // step, the first transform waiting in the accumulator registers): 1.27 ms z48 / 1.46 ms c128 per 32 768 frames of 8 microphones.
 __device__ __forceinline__ void halves_pair_d(double v, double &lo, double &hi) {  // the value of v in lane l of half 0 / of half 1
     unsigned a0 = (unsigned)__double2loint(v), a1 = (unsigned)__double2hiint(v), b0 = a0, b1 = a1;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 0" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
     lo = __hiloint2double((int)a1, (int)a0);
     hi = __hiloint2double((int)b1, (int)b0);
 }
