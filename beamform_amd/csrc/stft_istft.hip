@@ -879,14 +879,16 @@ constexpr int kNL = kN / 32, kG = 32 / kNL, kLogNL = gen_log2(kNL);
 template <int LAYOUT, bool Z48>
 __global__ __launch_bounds__(256) void stft_small_kernel(StftArgs a) {
     constexpr int kBlock = 256, kHalves = kBlock / 32, kWinRow = 34;
-    __shared__ __attribute__((aligned(16))) double lds[2 * 32 * kNL + kHalves * 32 * kPSd + kNL * kWinRow];
-    cx<double> *s_tw = reinterpret_cast<cx<double> *>(lds);  // [k1][n2] = W_N^(k1 n2)
+    // the twiddle row k1 = 0 (all ones) is not stored: at N = 512 the block then takes exactly half of the CU's LDS and two blocks (two wavefronts per
+    // SIMD) are resident
+    __shared__ __attribute__((aligned(16))) double lds[2 * 31 * kNL + kHalves * 32 * kPSd + kNL * kWinRow];
+    cx<double> *s_tw = reinterpret_cast<cx<double> *>(lds);  // [k1 - 1][n2] = W_N^(k1 n2), k1 = 1..31
     const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
-    double *pbuf = lds + 2 * 32 * kNL + hw * 32 * kPSd;
-    double *s_win = lds + 2 * 32 * kNL + kHalves * 32 * kPSd;  // [n2][j] = win[NL j + n2]
+    double *pbuf = lds + 2 * 31 * kNL + hw * 32 * kPSd;
+    double *s_win = lds + 2 * 31 * kNL + kHalves * 32 * kPSd;  // [n2][j] = win[NL j + n2]
     {
-        for (int i = tid; i < 32 * kNL; i += kBlock) {
-            const int m = ((i / kNL) * (i % kNL)) % kN;  // a.tw[m] = exp(-2 pi i m / N) for m < N / 2; W^(m + N/2) = -W^m
+        for (int i = tid; i < 31 * kNL; i += kBlock) {
+            const int m = ((i / kNL + 1) * (i % kNL)) % kN;  // a.tw[m] = exp(-2 pi i m / N) for m < N / 2; W^(m + N/2) = -W^m
             const f64x2 w = a.tw[m % (kN / 2)];
             s_tw[i] = m < kN / 2 ? cx<double>{w.x, w.y} : cx<double>{-w.x, -w.y};
         }
@@ -951,7 +953,7 @@ __global__ __launch_bounds__(256) void stft_small_kernel(StftArgs a) {
             fft32_dif<double, -1>(re, im);
 #pragma unroll
             for (int i = 1; i < 32; ++i) {
-                const cx<double> w = s_tw[brev5(i) * kNL + n2];
+                const cx<double> w = s_tw[(brev5(i) - 1) * kNL + n2];
                 const double xr = re[i], xi = im[i];
                 re[i] = xr * w.x - xi * w.y;
                 im[i] = xr * w.y + xi * w.x;
