@@ -51,6 +51,10 @@ oracle:
 ubench:
 	for f in valu_rate fetch_calib w64_test rowbc vmem_issue rsq_test f64_rate launch_lds realtime_cal; do $(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fno-slp-vectorize -Wno-unused-result tools/ubench/$$f.hip -o tools/ubench/$$f.bin; done
 
+# which kernels run for which (node, period, layout, microphones, directions, dump): traced from the library itself (needs a GPU)
+dispatch-table: $(LIB)
+	python tools/dispatch_table.py docs/DISPATCH.md
+
 emul:
 	g++ -O2 -std=c++17 -fPIC -shared -o tests/host_emul/libemul.so tests/host_emul/emul.cpp
 
@@ -58,4 +62,4 @@ clean:
 	rm -rf build $(LIB) tests/host_emul/libemul.so examples/file_node examples/theta_scan examples/shard_node
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle emul ubench clean
+.PHONY: all oracle emul ubench clean dispatch-table

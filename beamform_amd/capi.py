@@ -26,7 +26,7 @@ EXPORTS = (
     "bf_version", "bf_strerror", "bf_last_error", "bf_device_count", "bf_config_init", "bf_config_load_yaml",
     "bf_config_parse_yaml", "bf_create", "bf_destroy", "bf_set_theta", "bf_set_interference", "bf_process_hop",
     "bf_process_batch", "bf_process_batch_device", "bf_get_weights", "bf_state_size", "bf_get_state", "bf_set_state",
-    "bf_reset", "bf_reset_async", "bf_shard_halo", "bf_shard_plan", "bf_shard_run", "bf_shard_first_feed", "bf_shard_n_feed", "bf_shard_n_drop", "bf_process_batch_device_strided", "bf_kernel_timing_begin", "bf_kernel_timing_end", "bf_time_batch_device", "bf_n_interferers", "bf_set_theta_dir", "bf_set_thetas", "bf_stream_rms", "bf_host_alloc", "bf_host_free",
+    "bf_reset", "bf_reset_async", "bf_shard_halo", "bf_shard_plan", "bf_shard_run", "bf_shard_first_feed", "bf_shard_n_feed", "bf_shard_n_drop", "bf_process_batch_device_strided", "bf_kernel_timing_begin", "bf_kernel_timing_end", "bf_trace_begin", "bf_trace_end", "bf_time_batch_device", "bf_n_interferers", "bf_set_theta_dir", "bf_set_thetas", "bf_stream_rms", "bf_host_alloc", "bf_host_free",
     "bf_wav_writer_open", "bf_wav_writer_write", "bf_wav_writer_write_pcm16", "bf_wav_writer_close", "bf_float_to_pcm16",
     "bf_float_to_pcm16_device", "bf_wav_read", "bf_planar_f32_read", "bf_wav_free",
     "bf_resampler_create", "bf_resampler_set_table", "bf_resampler_reset", "bf_resampler_out_count", "bf_resampler_latency",
@@ -136,6 +136,9 @@ def load():
     L.bf_process_batch_device_strided.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_long]
     L.bf_kernel_timing_begin.argtypes = [C.c_void_p]
     L.bf_kernel_timing_end.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.bf_trace_begin.argtypes = []
+    L.bf_trace_end.argtypes = [C.c_char_p, C.c_size_t]
+    L.bf_trace_end.restype = C.c_long
     L.bf_time_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int,
                                        C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.bf_wav_writer_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
@@ -169,6 +172,28 @@ def load():
 
 
 # ---- rosjack output stage, file half (rosjack.cpp:189-210, 404-409) and the batch front-end ---------------------------------
+class launch_trace:
+    """with launch_trace() as t: ... ; t.kernels = the kernels this thread launched through the library inside the block, in launch
+    order, named as rocprofv3 names them (bf_trace_begin / bf_trace_end)."""
+
+    def __enter__(self):
+        L = load()
+        rc = L.bf_trace_begin()
+        if rc != 0:
+            raise BfError(rc, "bf_trace_begin", "a trace is already open on this thread")
+        self.kernels = []
+        return self
+
+    def __exit__(self, *exc):
+        L = load()
+        buf = C.create_string_buffer(1 << 16)
+        n = L.bf_trace_end(buf, len(buf))
+        if n < 0:
+            raise BfError(int(n), "bf_trace_end")
+        self.kernels = [k for k in buf.value.decode().split("\n") if k]
+        return False
+
+
 class WavWriter:
     """sf_open(..., SFM_WRITE, WAV | PCM_16, mono) / sf_write_float per callback / sf_close."""
 

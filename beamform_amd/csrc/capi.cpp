@@ -14,14 +14,23 @@
 #include <string>
 #include <vector>
 
+#include <cxxabi.h>
+
 #include "../../include/bfcore.h"
 #include "geometry.hpp"
 #include "kernels.hpp"
+#include "launch_trace.hpp"
 #include "pipeline.hpp"
 
 using namespace bf;
 
 static thread_local std::string g_last_error;
+
+// ---- launch trace (launch_trace.hpp): the kernels the calling thread launches between bf_trace_begin and bf_trace_end ----------
+static thread_local std::vector<const void *> *g_trace = nullptr;
+void bf::trace_note(const void *host_fn) {
+    if (g_trace) g_trace->push_back(host_fn);
+}
 
 struct bf_handle {
     bf_config cfg;
@@ -849,6 +858,50 @@ int bf_kernel_timing_begin(bf_handle *h) {
     h->ev_used = 0;
     h->timing = 1;
     return BF_OK;
+}
+
+int bf_trace_begin(void) {
+    if (g_trace) return BF_EINVAL;
+    g_trace = new std::vector<const void *>();
+    return BF_OK;
+}
+
+// rocprofv3's spelling of a kernel name: the demangled name without its parameter list, "void" prefix and anonymous namespaces
+static std::string trace_kernel_name(const void *fn) {
+    const char *m = hipKernelNameRefByPtr(fn, nullptr);
+    if (!m) return "?";
+    int st = 0;
+    char *d = abi::__cxa_demangle(m, nullptr, nullptr, &st);
+    std::string n = (st == 0 && d) ? d : m;
+    free(d);
+    int depth = 0;   // cut the parameter list: the last '(' at template depth 0
+    size_t cut = std::string::npos;
+    for (size_t i = 0; i < n.size(); ++i) {
+        if (n[i] == '<') ++depth;
+        else if (n[i] == '>') --depth;
+        else if (n[i] == '(' && depth == 0 && n.compare(i, 21, "(anonymous namespace)") != 0) { cut = i; break; }
+    }
+    if (cut != std::string::npos) n.resize(cut);
+    if (n.compare(0, 5, "void ") == 0) n.erase(0, 5);
+    for (size_t p; (p = n.find("(anonymous namespace)::")) != std::string::npos;) n.erase(p, 23);
+    return n;
+}
+
+long bf_trace_end(char *buf, size_t cap) {
+    if (!g_trace) return BF_EINVAL;
+    std::string out;
+    for (const void *fn : *g_trace) {
+        if (!out.empty()) out += '\n';
+        out += trace_kernel_name(fn);
+    }
+    delete g_trace;
+    g_trace = nullptr;
+    if (buf && cap) {
+        const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
+        memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    return (long)out.size();
 }
 
 int bf_kernel_timing_end(bf_handle *h, float *ms_mean, int *n_launches) {

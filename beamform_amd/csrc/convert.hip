@@ -5,6 +5,7 @@
 
 #include <cstdint>
 
+#include "launch_trace.hpp"
 #include "../../include/bfcore.h"
 
 namespace {
@@ -37,6 +38,6 @@ extern "C" int bf_float_to_pcm16_device(const float *src_dev, int16_t *dst_dev, 
     size_t blocks = (n / 8 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(pcm16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, src_dev, dst_dev, n);
+    BF_LAUNCH(pcm16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, src_dev, dst_dev, n);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EIO;
 }

@@ -1,5 +1,6 @@
 // cov_kernels.hip -- mvdr / lcmv: sliding per-bin covariance + Cholesky-based constrained solve, four mappings of a problem
 // onto lanes (thread-per-problem, row-per-lane over LDS, cyclic rows over DPP quads, row-per-lane over DPP rows).
+#include "launch_trace.hpp"
 #include "bins_common.hpp"
 
 #include <cmath>
@@ -1321,7 +1322,7 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
     const bool lcmv_fast = !no_fast && a.cfg.algo == BF_LCMV && lcmv_fast_on && M <= 8 && a.kp1 <= 4;
     (void)band_hits_nyquist;
 #define BF_LAUNCH_ML(MP_, KM_)                                                                                   \
-    hipLaunchKernelGGL((mvdr_lcmv_kernel<MP_, KM_>), dim3(tps * a.n_streams, (kNQ + (256 / MP_) - 1) / (256 / MP_)), \
+    BF_LAUNCH((mvdr_lcmv_kernel<MP_, KM_>), dim3(tps * a.n_streams, (kNQ + (256 / MP_) - 1) / (256 / MP_)), \
                        dim3(256), 0, s, a, tile, tps)
     // beyond the tuned shapes -- more than 3 interferers (lcmv.cpp:258-309 appends without a cap; the yaml lists
     // angle_interf1..15) or more than 16 microphones -- the row-per-lane group kernel runs with the next larger
@@ -1359,11 +1360,11 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
         const int tps = (int)((a.n_frames + tile - 1) / tile);
         const dim3 grid((unsigned)(((long)tps * a.n_streams + 7) / 8 * 8 * ((kNQ + 15) / 16)));  // (unit, problem group) -> XCD-aware order in the kernel
         if (km == 1) {
-            if (cov2d == 3) hipLaunchKernelGGL((cov2d_kernel<1, 3>), grid, dim3(256), 0, s, a, tile, tps);
-            else hipLaunchKernelGGL((cov2d_kernel<1, 2>), grid, dim3(256), 0, s, a, tile, tps);
+            if (cov2d == 3) BF_LAUNCH((cov2d_kernel<1, 3>), grid, dim3(256), 0, s, a, tile, tps);
+            else BF_LAUNCH((cov2d_kernel<1, 2>), grid, dim3(256), 0, s, a, tile, tps);
         } else {
-            if (cov2d == 3) hipLaunchKernelGGL((cov2d_kernel<4, 3>), grid, dim3(256), 0, s, a, tile, tps);
-            else hipLaunchKernelGGL((cov2d_kernel<4, 2>), grid, dim3(256), 0, s, a, tile, tps);
+            if (cov2d == 3) BF_LAUNCH((cov2d_kernel<4, 3>), grid, dim3(256), 0, s, a, tile, tps);
+            else BF_LAUNCH((cov2d_kernel<4, 2>), grid, dim3(256), 0, s, a, tile, tps);
         }
         return hipGetLastError();
     }
@@ -1371,9 +1372,9 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
     if (!no_fast && a.cfg.algo == BF_LCMV && M > 8) {
         const dim3 grid(tps * a.n_streams, (kNQ + 15) / 16);  // x: tile * stream (can exceed 65535), y: bin blocks
         if (km == 1)
-            hipLaunchKernelGGL((mvdr_lcmv_row_kernel<1>), grid, dim3(256), 0, s, a, tile, tps);
+            BF_LAUNCH((mvdr_lcmv_row_kernel<1>), grid, dim3(256), 0, s, a, tile, tps);
         else
-            hipLaunchKernelGGL((mvdr_lcmv_row_kernel<4>), grid, dim3(256), 0, s, a, tile, tps);
+            BF_LAUNCH((mvdr_lcmv_row_kernel<4>), grid, dim3(256), 0, s, a, tile, tps);
         return hipGetLastError();
     }
     // lanes kernel: mvdr with 9..16 microphones (12.7 vs 26 ms per 32 768 frames at 16) and lcmv with up to 8
@@ -1385,13 +1386,13 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
         const int ltps = (int)((a.n_frames + lt - 1) / lt);
         if (M <= 4) {
             const dim3 grid(ltps * a.n_streams, (kNQ + 31) / 32);  // x: tile * stream (can exceed 65535), y: bin blocks
-            hipLaunchKernelGGL((mvdr_lcmv_lanes_kernel<4, 2, 4>), grid, dim3(64), 0, s, a, lt, ltps);
+            BF_LAUNCH((mvdr_lcmv_lanes_kernel<4, 2, 4>), grid, dim3(64), 0, s, a, lt, ltps);
         } else if (M <= 8) {
             const dim3 grid(ltps * a.n_streams, (kNQ + 31) / 32);  // x: tile * stream (can exceed 65535), y: bin blocks
-            hipLaunchKernelGGL((mvdr_lcmv_lanes_kernel<8, 2, 4>), grid, dim3(64), 0, s, a, lt, ltps);
+            BF_LAUNCH((mvdr_lcmv_lanes_kernel<8, 2, 4>), grid, dim3(64), 0, s, a, lt, ltps);
         } else {
             const dim3 grid(ltps * a.n_streams, (kNQ + 15) / 16);  // x: tile * stream (can exceed 65535), y: bin blocks
-            hipLaunchKernelGGL((mvdr_lcmv_lanes_kernel<16, 4, 1>), grid, dim3(64), 0, s, a, lt, ltps);
+            BF_LAUNCH((mvdr_lcmv_lanes_kernel<16, 4, 1>), grid, dim3(64), 0, s, a, lt, ltps);
         }
         return hipGetLastError();
     }
@@ -1442,7 +1443,7 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
         else if (a.yh_lo == 0 && fp.nb < kNQ)  // f32x2 rows that the backward transform reads in full (a band up to the Nyquist problems) while part of them is out of band
             (void)hipMemsetAsync(a.Yh, 0, (size_t)a.n_streams * a.n_frames * kYhStride * sizeof(f32x2), s);
         const dim3 grid((unsigned)((long)fp.waves_per_stream * a.n_streams));
-#define BF_FAST_GO(MP_, KC_) hipLaunchKernelGGL((mvdr_fast_kernel<MP_, KC_>), grid, dim3(64), 0, s, a, fp)
+#define BF_FAST_GO(MP_, KC_) BF_LAUNCH((mvdr_fast_kernel<MP_, KC_>), grid, dim3(64), 0, s, a, fp)
         if (!lcmv_fast || a.kp1 <= 1) {  // lcmv without interferers = mvdr except problem 0
             if (M <= 2) BF_FAST_GO(2, 1);
             else if (M <= 4) BF_FAST_GO(4, 1);

@@ -26,7 +26,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstring>
 
+#include "launch_trace.hpp"
 #include "pipeline_kernels.hpp"
 #include "w64_f64_dev.hpp"
 
@@ -327,33 +329,111 @@ __global__ __launch_bounds__(kBlock) void das_f64_w64_kernel(DasF64Args a, int f
 #endif
 constexpr int kGRow = 65;                                  // complex entries per gain row
 constexpr int kGMic = 8 * kGRow;                           // per microphone
-constexpr int kStepP = 2 * kWaves;                         // frames of one round of the block's wavefronts (run lengths are multiples)
 constexpr int kSlots = 64;                                 // boundary states in flight (<= 2 pairs per wavefront are): a ring
 constexpr int kTwP = 2 * (960 + 4 * kTw2RowW64Rot);        // tw1 rows k1 = 1 .. 15 (row 0 is all ones and never read) + tw2'
 constexpr int pTw = 0;
 constexpr int pPlane = kTwP;
 constexpr int pGain = pPlane + kWaves * kPlaneD;
 constexpr int pFlag = pGain + 8 * kGMic * 2;
-constexpr int pWin = pFlag + (kSlots + 4) / 2;           // kSlots + 1 ints, padded to 16 bytes
+constexpr int pWin = pFlag + (kSlots + 4) / 2;           // kSlots ints + the 64-bit work word, padded to 16 bytes
 constexpr int kLdsP = pWin + 64 * kWinRow;
 static_assert(kLdsP * 8 <= 160 * 1024, "LDS");
 static_assert((pGain & 1) == 0 && (pWin & 1) == 0, "16-byte alignment");
 
 
 typedef volatile __attribute__((address_space(3))) int *lds_int_t;
+typedef volatile __attribute__((address_space(3))) unsigned long long *lds_u64_t;
 __device__ __forceinline__ int lds_fetch_add(lds_int_t p, int v, int lane) {
     int old = 0;
     if (lane == 0) old = __hip_atomic_fetch_add((__attribute__((address_space(3))) int *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return __builtin_amdgcn_readfirstlane(old);
 }
-// the next frame pair of the run (wavefront-uniform)
-__device__ __forceinline__ int take_pair(lds_int_t counter, int lane) { return lds_fetch_add(counter, 1, lane); }
-// Boundary b lives in slot b mod kSlots; over its life the slot gains 4 (two claims of 1, one publication of 2), so generation b / kSlots
-// starts at 4 (b / kSlots).  claim: 0 = first to arrive; otherwise the other side has claimed (1) or already published (3).
-__device__ __forceinline__ int claim_boundary(lds_int_t st, int b, int lane) { return lds_fetch_add(st + (b & (kSlots - 1)), 1, lane) - 4 * (b / kSlots); }
-__device__ __forceinline__ void publish_boundary(lds_int_t st, int b, int lane) { (void)lds_fetch_add(st + (b & (kSlots - 1)), 2, lane); }
-__device__ __forceinline__ void await_boundary(lds_int_t st, int b) {
-    while (st[b & (kSlots - 1)] - 4 * (b / kSlots) < 3) __builtin_amdgcn_s_sleep(1);
+__device__ __forceinline__ unsigned long long lds_fetch_add64(lds_u64_t p, int lane) {
+    unsigned long long old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned long long *)p, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)old), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(old >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+struct DasSched {           // the work queue of das_f64_pair_kernel (written by das_f64_sched_kernel on the launch stream)
+    const int4 *chunks;     // [n_chunks] {stream, first frame, frames, 0}: runs of consecutive frames of one stream, biggest first
+    unsigned *counter;      // next chunk to hand out (starts at the grid size: block b begins with chunk b)
+    int n_chunks;
+};
+// ---- work queue ------------------------------------------------------------------------------------------------------------------
+// The batch is cut into CHUNKS of consecutive frames of one stream (das_f64_sched_kernel writes the table, biggest chunks first).
+// Blocks are persistent: block b starts with chunk b and takes further chunks from one global counter, so a block on a fast XCD (the
+// eight XCDs finish equal static runs 4-5 % apart: profiles/r05_finish_hist_static.txt) simply ends up with more of the small chunks
+// at the table's end.  Inside a block the frame pairs of the current chunk are handed to the eight wavefronts through ONE 64-bit LDS
+// word  [ virtual index of the chunk's first pair : 24 | chunk : 20 | pairs in the chunk : 10 | next pair : 10 ],  advanced by an LDS
+// atomic add: whoever draws pair == pairs (the first one past the end) fetches the next chunk from the global counter and installs
+// it; later arrivals spin on the word until the chunk field changes.  The virtual index numbers the pairs a block has drawn 0, 1, 2, ...
+// across chunks: boundary state slot = virtual index mod kSlots, whatever the chunks' sizes.
+constexpr int kChunkEnd = 0xFFFFF;       // chunk field: the table is exhausted
+constexpr int kMaxChunkPairs = 1000;     // pairs per chunk (10 bits, and up to 8 draws past the end before the word is replaced)
+__device__ __forceinline__ unsigned long long pack_work(unsigned vbase, int chunk, int pairs, int next) {
+    return ((unsigned long long)(vbase & 0xFFFFFFu) << 40) | ((unsigned long long)(unsigned)chunk << 20) | ((unsigned long long)(unsigned)pairs << 10) | (unsigned)next;
+}
+struct PairWork {   // wavefront-uniform
+    int4 d;         // the chunk: {stream, first frame, frames, 0}
+    int pos;        // this pair inside the chunk
+    int len;        // pairs of the chunk
+    unsigned u;     // virtual index
+    bool have;
+};
+__device__ __forceinline__ int4 load_chunk(const int4 *chunks, int k) {
+    const int4 d = chunks[k];
+    return int4{__builtin_amdgcn_readfirstlane(d.x), __builtin_amdgcn_readfirstlane(d.y), __builtin_amdgcn_readfirstlane(d.z), 0};
+}
+__device__ __forceinline__ PairWork draw_pair(lds_u64_t work, const DasSched &sc, int lane) {
+    PairWork r;
+    r.have = false;
+    r.d = int4{0, 0, 0, 0};
+    r.pos = r.len = 0;
+    r.u = 0;
+    for (;;) {
+        const unsigned long long old = lds_fetch_add64(work, lane);
+        const int pos = (int)(old & 1023u), len = (int)((old >> 10) & 1023u), k = (int)((old >> 20) & 0xFFFFFu);
+        const unsigned vb = (unsigned)(old >> 40);
+        if (k == kChunkEnd) return r;
+        if (pos < len) {
+            r.d = load_chunk(sc.chunks, k);
+            r.pos = pos; r.len = len; r.u = vb + (unsigned)pos; r.have = true;
+            return r;
+        }
+        if (pos == len) {  // first past the end: install the next chunk (the others spin below meanwhile)
+            unsigned k2 = 0;
+            if (lane == 0) k2 = __hip_atomic_fetch_add(sc.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            k2 = (unsigned)__builtin_amdgcn_readfirstlane((int)k2);
+            if (k2 >= (unsigned)sc.n_chunks) {
+                if (lane == 0) *work = pack_work(vb + (unsigned)len, kChunkEnd, 0, 0);
+                return r;
+            }
+            r.d = load_chunk(sc.chunks, (int)k2);
+            r.len = (r.d.z + 1) >> 1;
+            r.pos = 0; r.u = vb + (unsigned)len; r.have = true;
+            if (lane == 0) *work = pack_work(r.u, (int)k2, r.len, 1);   // (a plain store: adds that land before it belong to spinners, who draw again)
+            return r;
+        }
+        while ((int)((*work >> 20) & 0xFFFFFu) == k) __builtin_amdgcn_s_sleep(2);
+    }
+}
+// Boundary b (between the pairs of virtual index b and b + 1) lives in slot b mod kSlots; over its life the slot gains 4 (two claims of 1,
+// one publication of 2 -- or 4 at once where b + 1 belongs to another chunk and there is nothing to hand over), so generation b / kSlots
+// starts at 4 (b / kSlots).  claim: 0 = first to arrive; otherwise the other side has claimed (1) or already published (3).  A claim waits
+// until the slot's previous generation is complete (a wavefront 64 pairs behind its siblings: never seen, but nothing else forbids it).
+__device__ __forceinline__ int claim_boundary(lds_int_t st, unsigned b, int lane) {
+    const int base = 4 * (int)(b / kSlots);
+    while (st[b & (kSlots - 1)] < base) __builtin_amdgcn_s_sleep(1);
+    return lds_fetch_add(st + (b & (kSlots - 1)), 1, lane) - base;
+}
+__device__ __forceinline__ void publish_boundary(lds_int_t st, unsigned b, int lane) { (void)lds_fetch_add(st + (b & (kSlots - 1)), 2, lane); }
+__device__ __forceinline__ void skip_boundary(lds_int_t st, unsigned b, int lane) {
+    const int base = 4 * (int)(b / kSlots);
+    while (st[b & (kSlots - 1)] < base) __builtin_amdgcn_s_sleep(1);
+    (void)lds_fetch_add(st + (b & (kSlots - 1)), 4, lane);
+}
+__device__ __forceinline__ void await_boundary(lds_int_t st, unsigned b) {
+    while (st[b & (kSlots - 1)] - 4 * (int)(b / kSlots) < 3) __builtin_amdgcn_s_sleep(1);
 }
 
 #ifdef BF_W64_STATS  // debug build (tools/ab_w64.sh stats -DBF_W64_STATS): how the hand-offs of das_f64_pair_kernel went, per wavefront
@@ -371,30 +451,20 @@ __device__ unsigned long long g_stats[256 * 8 * 5];
 #define BF_STAT_WAIT_END
 #define BF_STATS_FLUSH
 #endif
-#ifdef BF_W64_STAMPS  // debug build (tools/ab_w64.sh stamps -DBF_W64_STAMPS [-DBF_W64_FINE]): s_memrealtime (100 MHz) per wavefront
+#ifdef BF_W64_STAMPS  // debug build (tools/ab_w64.sh stamps -DBF_W64_STAMPS): s_memrealtime (100 MHz) per wavefront: entry, tables done, exit
 __device__ unsigned long long g_stamps[256 * 8 * 64];
-#define BF_STAMP_RAW(slot) do { if (lane == 0 && blockIdx.x < 256 && (slot) < 64) g_stamps[(blockIdx.x * 8 + w) * 64 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#ifdef BF_W64_FINE  // the phases inside step 8 instead of the steps of the run
-#define BF_STAMP(slot) do { } while (0)
-#define BF_FSTAMP(k) do { if (it == 8) BF_STAMP_RAW(6 * m + (k)); } while (0)
-#define BF_BSTAMP(k) do { if (it == 8) BF_STAMP_RAW(48 + (k)); } while (0)
-#else
-#define BF_STAMP(slot) BF_STAMP_RAW(slot)
-#define BF_FSTAMP(k) do { } while (0)
-#define BF_BSTAMP(k) do { } while (0)
-#endif
+#define BF_STAMP(slot) do { if (lane == 0 && blockIdx.x < 256 && (slot) < 64) g_stamps[(blockIdx.x * 8 + w) * 64 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define BF_STAMP(slot) do { } while (0)
-#define BF_FSTAMP(k) do { } while (0)
-#define BF_BSTAMP(k) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int frames_per_chunk, int chunks_per_stream) {
+__global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasSched sc) {
     __shared__ __attribute__((aligned(16))) double lds[kLdsP];
     const cx<double> *s_tw1 = reinterpret_cast<const cx<double> *>(lds + pTw) - 64;  // row k1 starts at 64 (k1 - 1)
     const cx<double> *s_tw2 = reinterpret_cast<const cx<double> *>(lds + pTw) + 960;
     const cx<double> *s_gain = reinterpret_cast<const cx<double> *>(lds + pGain);
-    lds_int_t s_state = (lds_int_t)(lds + pFlag);  // kSlots boundary states, then the next frame pair to hand out
+    lds_int_t s_state = (lds_int_t)(lds + pFlag);              // kSlots boundary states
+    lds_u64_t s_work = (lds_u64_t)(lds + pFlag + kSlots / 2);  // the block's work word (above)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -402,36 +472,50 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
     double *plane = lds + pPlane + w * kPlaneD;
     double *wcol = plane + w64_col_rot(lane);
     double *row16 = plane + (lane & 15) * kRS + 16 * (lane >> 4);
-
-    const int stream = blockIdx.x / chunks_per_stream;
-    const long c_in_s = blockIdx.x - (long)stream * chunks_per_stream;
     const double *wrow = lds + pWin + lane * kWinRow;
+    // the gain rows lie beyond the 64 KB a DS offset field reaches: a per-lane base register that hipcc cannot split back into
+    // "lane + constant" (it then spent 16 v_add_u32 per microphone on the sixteen row addresses)
+    typedef double cxa __attribute__((ext_vector_type(2)));  // 16-byte aligned (re, im): one ds_read_b128
+    typedef const __attribute__((address_space(3))) cxa *lds_gain_t;
+    unsigned gd0 = (unsigned)(size_t)(lds_gain_t)(s_gain + lane);
+    asm volatile("" : "+v"(gd0));
+    gd0 &= ~15u;  // (what the asm hid: 16-byte alignment)
+    const unsigned g_mirror = 2u * (unsigned)(size_t)(lds_gain_t)s_gain + 1024u;  // byte address of column 64 - lane = g_mirror - that of column lane
 
-    const long T0 = c_in_s * frames_per_chunk;
-    long T1 = T0 + frames_per_chunk;
-    if (T1 > a.n_frames) T1 = a.n_frames;
-    const float *xs = a.x + (long)stream * a.stream_stride_x;
-    const float *hs = a.hist + (long)stream * M * kHop;
-    float *ys = a.y + (long)stream * a.n_frames * kHop;
-
-    // hops tA - 1 (hop -1 = the carried hop), tA, tA + 1 of microphone m: register j <- sample 64 j + lane of the hop
+    // hops tA - 1 (hop -1 = the carried hop), tA, tA + 1 of one microphone: register j <- sample 64 j + lane of the hop.  h1 = hop tA.
     float n0[8], n1[8], n2[8];
-    auto request = [&](long tA, int m) {
-        const float *xm = xs + (long)m * a.mic_stride;
-        const float *h0 = tA >= 1 ? xm + (tA - 1) * kHop : hs + m * kHop;
-        const float *h1 = xm + tA * kHop;
-        const float *h2 = xm + (tA + 1 < a.n_frames ? tA + 1 : tA) * kHop;  // a lone last frame: any readable hop, unused
+#ifndef BF_PAIR_NT
+#define BF_PAIR_NT 0
+#endif
+    auto request = [&](const float *h0, const float *h1, const float *h2) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            n0[j] = h0[(unsigned)(64 * j + lane)];
-            n1[j] = h1[(unsigned)(64 * j + lane)];
-            n2[j] = h2[(unsigned)(64 * j + lane)];
+            n0[j] = (BF_PAIR_NT & 2) ? __builtin_nontemporal_load(h0 + (unsigned)(64 * j + lane)) : h0[(unsigned)(64 * j + lane)];
+            n1[j] = (BF_PAIR_NT & 1) ? __builtin_nontemporal_load(h1 + (unsigned)(64 * j + lane)) : h1[(unsigned)(64 * j + lane)];
+            n2[j] = (BF_PAIR_NT & 4) ? __builtin_nontemporal_load(h2 + (unsigned)(64 * j + lane)) : h2[(unsigned)(64 * j + lane)];
         }
+    };
+    // the three hop pointers of microphone m of the pair that starts with frame tA of `stream`
+    auto request_pair_mic = [&](int stream, long tA, int m) {
+        const float *h1 = a.x + (long)stream * a.stream_stride_x + (long)m * a.mic_stride + tA * kHop;
+        const float *h0 = tA >= 1 ? h1 - kHop : a.hist + ((long)stream * M + m) * kHop;
+        const float *h2 = tA + 1 < a.n_frames ? h1 + kHop : h1;  // a lone last frame: any readable hop, unused
+        request(h0, h1, h2);
     };
 
     BF_STAMP(0);
-    const int n_pairs = (int)((T1 - T0 + 1) >> 1);  // frame pairs of this run (the last one may be a lone frame)
-    if (w < n_pairs) request(T0 + 2 * w, 0);       // the first kWaves pairs are handed out statically: their samples travel during the table copy
+#ifdef BF_W64_STAMPS
+    if (lane == 0 && blockIdx.x < 256) g_stamps[(blockIdx.x * 8 + w) * 64 + 59] = __builtin_amdgcn_s_memtime();
+#endif
+    // the first kWaves pairs of the block's first chunk are handed out statically: their samples travel during the table copy
+    PairWork cur;
+    cur.d = load_chunk(sc.chunks, (int)blockIdx.x);
+    cur.len = (cur.d.z + 1) >> 1;
+    const int n_static = cur.len < kWaves ? cur.len : kWaves;
+    cur.pos = w;
+    cur.u = (unsigned)w;
+    cur.have = w < n_static;
+    if (cur.have) request_pair_mic(cur.d.x, cur.d.y + 2L * w, 0);
     {
         const f64x2 *tw2 = a.tw + 64, *g2 = a.gains_mic;
         f64x2 *ltw = reinterpret_cast<f64x2 *>(lds + pTw), *lg = reinterpret_cast<f64x2 *>(lds + pGain);
@@ -441,22 +525,32 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
         for (int i = tid; i < M * kGMic; i += kBlock) lg[i] = g2[i];
 #pragma unroll 2
         for (int i = tid; i < 1024; i += kBlock) lds[pWin + (i & 63) * kWinRow + (i >> 6)] = a.win[i];
-        if (tid <= kSlots) s_state[tid] = tid == kSlots ? kWaves : 0;
+        if (tid < kSlots) s_state[tid] = 0;
+        if (tid == 0) *s_work = pack_work(0u, (int)blockIdx.x, cur.len, n_static);
     }
     __syncthreads();
     BF_STAMP(1);
     BF_STATS_DECL;
-    int P = w, it = 0;  // this wavefront's frame pair; `it`: how many it has done (debug stamps)
-    while (P < n_pairs) {  // wavefront-uniform; no block barrier below
-        const long tA = T0 + 2L * P;
-        const bool pair = tA + 1 < T1;       // false: the odd last frame of the batch on its own (imaginary input zero)
+    int it = 0;  // pairs this wavefront has done (debug stamps)
+    if (!cur.have) {
+        cur = draw_pair(s_work, sc, lane);
+        if (cur.have) request_pair_mic(cur.d.x, cur.d.y + 2L * cur.pos, 0);
+    }
+    while (cur.have) {  // wavefront-uniform; no block barrier below
+        const int stream = cur.d.x;
+        const long T0 = cur.d.y, T1 = T0 + cur.d.z;  // the chunk
+        const long tA = T0 + 2L * cur.pos;
+        const bool pair = tA + 1 < T1;       // false: the odd last frame of a stream on its own (imaginary input zero)
         const long tL = pair ? tA + 1 : tA;  // the frame whose second half leaves this wavefront
-        int Pn = n_pairs;                    // the pair after this one: taken when the last microphone starts
+        const unsigned u = cur.u;
+        const bool has_t = cur.pos + 1 < cur.len, has_h = cur.pos > 0;  // boundaries u (behind this pair) and u - 1 (in front of it) inside the chunk
+        float *ys = a.y + (long)stream * a.n_frames * kHop;
+        PairWork nxt;
+        nxt.have = false;
 
         double Sr[16], Si[16];
         for (int m = 0; m < M; ++m) {
             double re[16], im[16];
-            BF_FSTAMP(0);
             // buf[j]*hann_win[i] (util.h:235) and the first butterfly stage in one (see the kernel above); hop tA is the second half of
             // frame tA and the first half of frame tA + 1
 #pragma unroll
@@ -466,25 +560,25 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
                 const double t = (double)n0[j] * w0;
                 re[j] = fma(c, w1, t);
                 re[j + 8] = fma(-c, w1, t);
-                const double t2 = c * w0, u = (double)n2[j];
-                im[j] = fma(u, w1, t2);
-                im[j + 8] = fma(-u, w1, t2);
+                const double t2 = c * w0, u2 = (double)n2[j];
+                im[j] = fma(u2, w1, t2);
+                im[j + 8] = fma(-u2, w1, t2);
             }
-            if (!pair) {
+            if (__builtin_expect(!pair, 0)) {  // a wavefront-uniform BRANCH (the asm keeps hipcc from turning it into 32 v_cndmask per microphone)
+#ifndef BF_PAIR_CNDMASK
+                asm volatile("" ::: "memory");
+#endif
 #pragma unroll
                 for (int j = 0; j < 16; ++j) im[j] = 0.0;
             }
-            {  // the next microphone, or the first one of this wavefront's next pair (none left: this pair's again, unused)
-                long tn = tA;
-                int mn = m + 1;
-                if (mn == M) {
-                    mn = 0;
-                    Pn = take_pair(s_state + kSlots, lane);
-                    if (Pn < n_pairs) tn = T0 + 2L * Pn;
-                }
-                request(tn, mn);
+            // the next microphone, or the first one of this wavefront's next pair (none left: this pair's first again, unused)
+            if (m + 1 < M) {
+                request_pair_mic(stream, tA, m + 1);
+            } else {
+                nxt = draw_pair(s_work, sc, lane);
+                if (nxt.have) request_pair_mic(nxt.d.x, nxt.d.y + 2L * nxt.pos, 0);
+                else request_pair_mic(stream, tA, 0);
             }
-            BF_FSTAMP(1);
             cx<double> tw[15];
             BF_STAGE();
             load_tw1<1, 9>(tw, s_tw1, lane);
@@ -497,9 +591,7 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
             BF_STAGE();
             mul_tw<false, 9, 16>(re, im, tw);
             BF_STAGE();
-            BF_FSTAMP(2);
             T1_fwd(re, im, wcol, row16);
-            BF_FSTAMP(3);
             load_tw2<1, 9>(tw, s_tw2, lane);
             BF_STAGE();
             fft16_core<double, -1, true>(re, im);
@@ -510,12 +602,10 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
             BF_STAGE();
             mul_tw<false, 9, 16>(re, im, tw);
             BF_STAGE();
-            BF_FSTAMP(4);
             w64_T2_any<true>(re, im, row16 - 16 * (lane >> 4), lane >> 4);
-            BF_FSTAMP(5);
-            cx<double> g[16];
-            const cx<double> *gd = s_gain + m * kGMic + lane;         // k3 < 2: row (g, k3), column lane
-            const cx<double> *gm = s_gain + m * kGMic + (64 - lane);  // k3 >= 2: row (3 - g, 3 - k3), column 64 - lane, conjugated
+            cxa g[16];
+            const lds_gain_t gd = (lds_gain_t)(size_t)(gd0 + (unsigned)(m * kGMic * 16));  // k3 < 2: row (g, k3), column lane
+            const lds_gain_t gm = (lds_gain_t)(size_t)((g_mirror + (unsigned)(2 * m * kGMic * 16)) - (gd0 + (unsigned)(m * kGMic * 16)));  // k3 >= 2: row (3 - g, 3 - k3), column 64 - lane, conjugated
             BF_STAGE();
 #pragma unroll
             for (int r = 0; r < 8; ++r)
@@ -540,8 +630,6 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
                 }
             }
         }
-        BF_STAMP(2 + 3 * it);
-        BF_BSTAMP(0);
         float *yo = ys + tA * kHop;
         cx<double> tw[15];
         BF_STAGE();
@@ -549,7 +637,6 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
         BF_STAGE();
         w64_inv_p3<double>(Sr, Si);
         w64_T2_any<false>(Sr, Si, row16 - 16 * (lane >> 4), lane >> 4);
-        BF_BSTAMP(1);
         BF_STAGE();
         mul_tw<true, 1, 16>(Sr, Si, tw);
         BF_STAGE();
@@ -557,16 +644,12 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
         BF_STAGE();
         fft16_core<double, +1, false>(Sr, Si);
         BF_STAGE();
-        BF_BSTAMP(2);
         T1_inv(Sr, Si, row16, wcol);
-        BF_BSTAMP(3);
         BF_STAGE();
         mul_tw<true, 1, 16>(Sr, Si, tw);
         fft16_core<double, +1, false>(Sr, Si);
 
         // register j: sample n = 64 j + lane of frame tA (real part) and of frame tA + 1 (imaginary part); util.h:247-252, float stores
-        BF_STAMP(3 + 3 * it);
-        BF_BSTAMP(4);
         // Overlap-add across wavefronts, first come first served: the hop between two frame pairs is the float sum of the second half of
         // the earlier pair's last frame and the first half of the later pair's first frame (util.h:302; a + b == b + a bit for bit).
         // Whichever side gets there first claims the boundary (LDS atomic), parks its half in the output hop itself and publishes it
@@ -586,15 +669,16 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
                 tl[j] = (float)((double)f1 * wrow[j + 8]);
             }
         }
-        const bool has_t = tL + 1 < T1, has_h = P > 0;  // boundaries P (behind this pair) and P - 1 (in front of it) inside the run
         float *yn = ys + (tL + 1) * kHop;
         int oT = -1, oH = -1;                            // what the claim found: 0 = nobody yet
         if (has_t) {
-            oT = claim_boundary(s_state, P, lane);
+            oT = claim_boundary(s_state, u, lane);
             if (oT == 0) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) yn[(unsigned)(64 * j + lane)] = tl[j];
             }
+        } else {
+            skip_boundary(s_state, u, lane);             // the chunk ends here: nobody else will touch this slot's generation
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -611,7 +695,7 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
             }
         }
         if (has_h) {
-            oH = claim_boundary(s_state, P - 1, lane);
+            oH = claim_boundary(s_state, u - 1, lane);
             if (oH == 0) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) yo[(unsigned)(64 * j + lane)] = oA[j];
@@ -620,19 +704,19 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
             const float *ti = a.tail_in + (long)stream * kHop;
 #pragma unroll
             for (int j = 0; j < 8; ++j) yo[(unsigned)(64 * j + lane)] = ti[(unsigned)(64 * j + lane)] + oA[j];
-        } else {               // first hop of a run: the previous run adds its half separately, both into a hop zeroed beforehand
+        } else {               // first hop of a chunk: the previous chunk adds its half separately, both into a hop zeroed beforehand
 #pragma unroll
             for (int j = 0; j < 8; ++j) atomicAdd(yo + (unsigned)(64 * j + lane), oA[j]);
         }
         if (oT == 0 || oH == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the parked halves have reached L2 (one CU: one L1) before anyone is told
-            if (oT == 0) publish_boundary(s_state, P, lane);
-            if (oH == 0) publish_boundary(s_state, P - 1, lane);
+            if (oT == 0) publish_boundary(s_state, u, lane);
+            if (oH == 0) publish_boundary(s_state, u - 1, lane);
         }
         if (oT > 0) {
             BF_STAT(2);
             BF_STAT_WAIT_BEGIN;
-            await_boundary(s_state, P);
+            await_boundary(s_state, u);
             BF_STAT_WAIT_END;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             float o[8];
@@ -646,7 +730,7 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
         if (oH > 0) {
             BF_STAT(2);
             BF_STAT_WAIT_BEGIN;
-            await_boundary(s_state, P - 1);
+            await_boundary(s_state, u - 1);
             BF_STAT_WAIT_END;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             float o[8];
@@ -657,11 +741,11 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
         } else {
             BF_STAT(1);
         }
-        if (tL == T1 - 1) {
+        if (!has_t) {  // the chunk's last frame: its second half belongs to the next chunk's first hop -- or to the next call
             if (T1 < a.n_frames) {
-                float *yn = ys + T1 * kHop;
+                float *ynx = ys + T1 * kHop;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) atomicAdd(yn + (unsigned)(64 * j + lane), tl[j]);
+                for (int j = 0; j < 8; ++j) atomicAdd(ynx + (unsigned)(64 * j + lane), tl[j]);
             } else {
                 float *to = a.tail_out + (long)stream * kHop;
 #pragma unroll
@@ -670,6 +754,7 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
                 // still be reading the current one)
                 if (a.hist_out != nullptr) {
                     float *ho = a.hist_out + (long)stream * M * kHop;
+                    const float *xs = a.x + (long)stream * a.stream_stride_x;
                     for (int m = 0; m < M; ++m) {
                         const float *xl = xs + (long)m * a.mic_stride + tL * kHop;
 #pragma unroll
@@ -678,13 +763,52 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
                 }
             }
         }
-        BF_STAMP(4 + 3 * it);
-        BF_BSTAMP(5);
-        P = Pn;
+        cur = nxt;
         ++it;
-        (void)it;
     }
     BF_STATS_FLUSH;
+#ifdef BF_W64_STAMPS  // when each wavefront left the kernel and how many frame pairs it took (tools/finish_hist.py)
+    if (lane == 0 && blockIdx.x < 256) {
+        g_stamps[(blockIdx.x * 8 + w) * 64 + 63] = __builtin_amdgcn_s_memrealtime();
+        g_stamps[(blockIdx.x * 8 + w) * 64 + 60] = __builtin_amdgcn_s_memtime();
+        g_stamps[(blockIdx.x * 8 + w) * 64 + 62] = (unsigned long long)it;
+        g_stamps[(blockIdx.x * 8 + w) * 64 + 61] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID
+    }
+#endif
+    (void)it;
+}
+
+// The chunk table of one launch + the zeroing of every hop that two chunks complete by atomic adds + the reset of the counter: one
+// small launch in front of the kernel (it replaces the hipMemset2DAsync of the static-run version).  Block k = chunk k.
+// Levels: per stream, level i holds cnt[i] chunks of size[i] pairs (the last chunk of a stream may be shorter); level-major order over
+// all streams, so the table starts with every block's big first chunk and ends with the small ones that level the finishing times.
+struct DasSchedPlan {
+    int n_levels;
+    int cnt[8], size[8];   // chunks per stream / pairs per chunk of each level
+    int n_chunks;          // over all streams
+    int grid;              // persistent blocks
+};
+__global__ void das_f64_sched_kernel(DasSchedPlan p, int4 *chunks, unsigned *counter, float *y, long n_frames, int n_streams) {
+    const int k = blockIdx.x;
+    int lvl = 0, kk = k;
+    long pair0 = 0;  // pairs of a stream in front of level lvl
+    while (lvl < p.n_levels - 1 && kk >= p.cnt[lvl] * n_streams) {
+        kk -= p.cnt[lvl] * n_streams;
+        pair0 += (long)p.cnt[lvl] * p.size[lvl];
+        ++lvl;
+    }
+    const int stream = kk / p.cnt[lvl], j = kk - stream * p.cnt[lvl];
+    const long t0 = 2 * (pair0 + (long)j * p.size[lvl]);
+    long n = 2L * p.size[lvl];
+    if (t0 + n > n_frames) n = n_frames - t0;
+    if (threadIdx.x == 0) {
+        chunks[k] = int4{stream, (int)t0, (int)n, 0};
+        if (k == 0) *counter = (unsigned)p.grid;
+    }
+    if (t0 > 0) {
+        float4 *h = reinterpret_cast<float4 *>(y + ((long)stream * n_frames + t0) * kHop);
+        for (int i = threadIdx.x; i < kHop / 4; i += blockDim.x) h[i] = float4{0.f, 0.f, 0.f, 0.f};
+    }
 }
 
 }  // namespace
@@ -692,14 +816,78 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, int 
 // BF_DAS_F64_PAIR=0: the microphone-pair kernel for planar input too (A/B runs)
 static bool use_pair_kernel(const DasF64Args &a) {
     static const bool on = !(getenv("BF_DAS_F64_PAIR") && atoi(getenv("BF_DAS_F64_PAIR")) == 0);
-    return on && a.layout == 0 && a.gains_mic != nullptr;
+    return on && a.layout == 0 && a.gains_mic != nullptr && a.sched_ws != nullptr;
 }
 
 bool das_f64_writes_hist(const DasF64Args &a) { return use_pair_kernel(a) && a.hist_out != nullptr; }
 
-// frames per run: a multiple of one step of the block (8 frames, 16 in the frame-pair kernel), about one run per CU
+// ---- the frame-pair kernel's work queue ------------------------------------------------------------------------------------------
+// Per stream: nb = blocks per stream (n_cus / n_streams, at least 1).  Level 0 gives every block one long chunk (kSchedFirst of its
+// equal share: consecutive pairs on one CU share their input hop through L1 / L2 and hand over their output hop through LDS flags),
+// the following levels halve the chunk until kSchedLast pairs; what is left goes out in chunks of kSchedLast pairs.  A chunk edge costs
+// one input hop read twice and two atomic adds per output sample, so the small chunks are kept to the last ~12 % of the batch.
+// BF_DAS_F64_SCHED=0: one level of equal chunks (the static runs of round 4); BF_DAS_F64_SCHED="88,16,8,4,2": explicit chunk sizes in pairs.
+constexpr int kSchedMaxChunks = 16384;
+constexpr size_t kSchedCounterBytes = 256;
+size_t das_f64_sched_ws_bytes() { return kSchedCounterBytes + (size_t)kSchedMaxChunks * sizeof(int4); }
+
+static DasSchedPlan das_f64_plan(long n_frames, int n_streams, int n_cus) {
+    DasSchedPlan p{};
+    const long pairs = (n_frames + 1) / 2;
+    long nb = (long)n_cus / n_streams;
+    if (nb < 1) nb = 1;
+    static const char *env = getenv("BF_DAS_F64_SCHED");
+    int sizes[8], n_sizes = 0;
+    const long share = (pairs + nb - 1) / nb;  // pairs per block if they were dealt out evenly
+    if (env && strchr(env, ',')) {
+        const char *c = env;
+        while (*c && n_sizes < 8) {
+            sizes[n_sizes++] = atoi(c);
+            c = strchr(c, ',');
+            if (!c) break;
+            ++c;
+        }
+    } else if (!(env && atoi(env) == 0) && share >= 48) {
+        int first = (int)(share * 13 / 16) & ~7;          // 81 % of the share, a multiple of 8 pairs
+        if (first > kMaxChunkPairs) first = kMaxChunkPairs & ~7;
+        sizes[n_sizes++] = first;
+        long rest = share - first;
+        for (int sz = 8; sz >= 4 && n_sizes < 7; sz >>= 1)
+            if (rest >= 3 * sz) { sizes[n_sizes++] = sz; rest -= sz; }
+        sizes[n_sizes++] = 2;
+    }
+    if (n_sizes == 0) {  // equal chunks
+        long sz = ((share + 7) / 8) * 8;
+        if (sz > kMaxChunkPairs) sz = kMaxChunkPairs & ~7;
+        sizes[n_sizes++] = (int)sz;
+    }
+    long left = pairs;
+    for (int i = 0; i < n_sizes && left > 0; ++i) {
+        int sz = sizes[i] < 1 ? 1 : (sizes[i] > kMaxChunkPairs ? kMaxChunkPairs : sizes[i]);
+        long cnt = (i == n_sizes - 1) ? (left + sz - 1) / sz : nb;
+        if (cnt * sz > left) cnt = (left + sz - 1) / sz;
+        p.size[p.n_levels] = sz;
+        p.cnt[p.n_levels] = (int)cnt;
+        ++p.n_levels;
+        left -= cnt * sz;
+    }
+    long total = 0;
+    for (int i = 0; i < p.n_levels; ++i) total += (long)p.cnt[i] * n_streams;
+    if (total > kSchedMaxChunks || total >= kChunkEnd) {  // too fine for the table: one level of the largest chunks that fit
+        long sz = kMaxChunkPairs & ~7;
+        p.n_levels = 1;
+        p.size[0] = (int)sz;
+        p.cnt[0] = (int)((pairs + sz - 1) / sz);
+        total = (long)p.cnt[0] * n_streams;
+    }
+    p.n_chunks = (int)total;
+    p.grid = (int)(total < n_cus ? total : n_cus);
+    return p;
+}
+
+// frames per run of the microphone-pair kernel: a multiple of one step of the block (8 frames), about one run per CU
 static void das_f64_w64_runs(const DasF64Args &a, int n_cus, long *fpc, long *cps) {
-    const long step = use_pair_kernel(a) ? kStepP : kWaves;
+    const long step = kWaves;
     long runs = (long)n_cus / a.n_streams;
     if (runs < 1) runs = 1;
     long f = (a.n_frames + runs - 1) / runs;
@@ -708,9 +896,18 @@ static void das_f64_w64_runs(const DasF64Args &a, int n_cus, long *fpc, long *cp
     *cps = (a.n_frames + f - 1) / f;
 }
 
-// the first hop of every run but the first of a stream is completed by atomic adds: zero them on `s` beforehand
+// what has to happen on `s` before the kernel: the frame-pair kernel's chunk table, counter and zeroed chunk-boundary hops (one small
+// launch); the microphone-pair kernel: the first hop of every run but the first of a stream zeroed (it is completed by atomic adds)
 hipError_t prepare_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s) {
     if (a.n_mics > 8) return hipErrorNotSupported;  // the gain tables fill the LDS
+    if (use_pair_kernel(a)) {
+        if (a.sched_ws_bytes < das_f64_sched_ws_bytes() || (long)a.n_streams * ((a.n_frames + 1) / 2) >= (1L << 31)) return hipErrorNotSupported;
+        const DasSchedPlan p = das_f64_plan(a.n_frames, a.n_streams, n_cus);
+        unsigned *counter = reinterpret_cast<unsigned *>(a.sched_ws);
+        int4 *chunks = reinterpret_cast<int4 *>(reinterpret_cast<char *>(a.sched_ws) + kSchedCounterBytes);
+        BF_LAUNCH(das_f64_sched_kernel, dim3((unsigned)p.n_chunks), dim3(128), 0, s, p, chunks, counter, a.y, a.n_frames, a.n_streams);
+        return hipGetLastError();
+    }
     long fpc, cps;
     das_f64_w64_runs(a, n_cus, &fpc, &cps);
     if (cps > 1)
@@ -724,14 +921,21 @@ hipError_t prepare_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s) {
 
 hipError_t launch_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s) {
     if (a.n_mics > 8) return hipErrorNotSupported;
+    if (use_pair_kernel(a)) {
+        const DasSchedPlan p = das_f64_plan(a.n_frames, a.n_streams, n_cus);
+        DasSched sc;
+        sc.counter = reinterpret_cast<unsigned *>(a.sched_ws);
+        sc.chunks = reinterpret_cast<const int4 *>(reinterpret_cast<char *>(a.sched_ws) + kSchedCounterBytes);
+        sc.n_chunks = p.n_chunks;
+        BF_LAUNCH(das_f64_pair_kernel, dim3((unsigned)p.grid), dim3(kBlock), 0, s, a, sc);
+        return hipGetLastError();
+    }
     long fpc, cps;
     das_f64_w64_runs(a, n_cus, &fpc, &cps);
-    if (use_pair_kernel(a))
-        hipLaunchKernelGGL(das_f64_pair_kernel, dim3((unsigned)(cps * a.n_streams)), dim3(kBlock), 0, s, a, (int)fpc, (int)cps);
-    else if (a.layout == 0)
-        hipLaunchKernelGGL(das_f64_w64_kernel<0>, dim3((unsigned)(cps * a.n_streams)), dim3(kBlock), 0, s, a, (int)fpc, (int)cps);
+    if (a.layout == 0)
+        BF_LAUNCH(das_f64_w64_kernel<0>, dim3((unsigned)(cps * a.n_streams)), dim3(kBlock), 0, s, a, (int)fpc, (int)cps);
     else
-        hipLaunchKernelGGL(das_f64_w64_kernel<1>, dim3((unsigned)(cps * a.n_streams)), dim3(kBlock), 0, s, a, (int)fpc, (int)cps);
+        BF_LAUNCH(das_f64_w64_kernel<1>, dim3((unsigned)(cps * a.n_streams)), dim3(kBlock), 0, s, a, (int)fpc, (int)cps);
     return hipGetLastError();
 }
 

@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include "launch_trace.hpp"
 #include "fft1024.hpp"
 #include "kernels.hpp"
 
@@ -1624,9 +1625,9 @@ void launch_layout(const DasFusedArgs &a, unsigned blocks, hipStream_t stream) {
         if constexpr (WT) {
 #define BF_DAS_GRP(NPL_, UNR_)                                                                                                                    \
     do {                                                                                                                                          \
-        if (a.group == 2) hipLaunchKernelGGL((das_fused_kernel<LAYOUT, NPL_, true, UNR_, 2>), dim3(blocks), dim3(kBlock), 0, stream, a);          \
-        else if (a.group == 4) hipLaunchKernelGGL((das_fused_kernel<LAYOUT, NPL_, true, UNR_, 4>), dim3(blocks), dim3(kBlock), 0, stream, a);     \
-        else hipLaunchKernelGGL((das_fused_kernel<LAYOUT, NPL_, true, UNR_, 8>), dim3(blocks), dim3(kBlock), 0, stream, a);                       \
+        if (a.group == 2) BF_LAUNCH((das_fused_kernel<LAYOUT, NPL_, true, UNR_, 2>), dim3(blocks), dim3(kBlock), 0, stream, a);          \
+        else if (a.group == 4) BF_LAUNCH((das_fused_kernel<LAYOUT, NPL_, true, UNR_, 4>), dim3(blocks), dim3(kBlock), 0, stream, a);     \
+        else BF_LAUNCH((das_fused_kernel<LAYOUT, NPL_, true, UNR_, 8>), dim3(blocks), dim3(kBlock), 0, stream, a);                       \
     } while (0)
             if constexpr (LAYOUT == 0) {  // planar: the unrolled pair loop up to 8 microphones
                 if (np == 1) BF_DAS_GRP(1, 1); else if (np == 2) BF_DAS_GRP(2, 2); else if (np == 3) BF_DAS_GRP(4, 3); else if (np == 4) BF_DAS_GRP(4, 4);
@@ -1640,12 +1641,12 @@ void launch_layout(const DasFusedArgs &a, unsigned blocks, hipStream_t stream) {
     }
     if (LAYOUT == 1 && WT && (a.variant & 2) && (a.n_mics == 4 || a.n_mics == 8)) {  // 16-byte loads: two pairs per sample access
         if (a.n_mics == 4)  // one 16-byte load per sample = the whole sample: two frames per wavefront
-            hipLaunchKernelGGL((das_fused_il_kernel<2, 1>), dim3(blocks), dim3(kBlock), 0, stream, a);
+            BF_LAUNCH((das_fused_il_kernel<2, 1>), dim3(blocks), dim3(kBlock), 0, stream, a);
         else                // 8 microphones: one frame per wavefront, each half-wavefront loads its 16 bytes of the 32-byte sample
-            hipLaunchKernelGGL(das_fused_il8_kernel, dim3(blocks), dim3(kBlock), 0, stream, a);
+            BF_LAUNCH(das_fused_il8_kernel, dim3(blocks), dim3(kBlock), 0, stream, a);
         return;
     }
-#define BF_DAS_GO(NPL_, UNR_) hipLaunchKernelGGL((das_fused_kernel<LAYOUT, NPL_, WT, UNR_>), dim3(blocks), dim3(kBlock), 0, stream, a)
+#define BF_DAS_GO(NPL_, UNR_) BF_LAUNCH((das_fused_kernel<LAYOUT, NPL_, WT, UNR_>), dim3(blocks), dim3(kBlock), 0, stream, a)
     if (np <= 1) {
         if (unr) BF_DAS_GO(1, 1); else BF_DAS_GO(1, 0);
     } else if (np <= 2) {
@@ -1764,8 +1765,8 @@ hipError_t prepare_das_fused_wave2048(const DasFusedArgs &a, hipStream_t stream)
 hipError_t launch_das_fused_wave2048(const DasFusedArgs &a, hipStream_t stream) {
     if (a.sdump != nullptr || a.frames_per_chunk % kWaves2 != 0) return hipErrorInvalidValue;
     const unsigned blocks = (unsigned)((long)a.chunks_per_stream * a.n_streams);
-    if (a.layout == 0) hipLaunchKernelGGL(das_fused_wave2048_kernel<0>, dim3(blocks), dim3(kBlock), 0, stream, a);
-    else hipLaunchKernelGGL(das_fused_wave2048_kernel<1>, dim3(blocks), dim3(kBlock), 0, stream, a);
+    if (a.layout == 0) BF_LAUNCH(das_fused_wave2048_kernel<0>, dim3(blocks), dim3(kBlock), 0, stream, a);
+    else BF_LAUNCH(das_fused_wave2048_kernel<1>, dim3(blocks), dim3(kBlock), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -1774,7 +1775,7 @@ hipError_t launch_das_fused_wave2048(const DasFusedArgs &a, hipStream_t stream) 
 hipError_t launch_das_fused_dirs(const DasFusedArgs &a, int dir0, int n_here, hipStream_t stream) {
     if (a.layout != 0 || a.n_mics > 8 || n_here < 1 || n_here > 16 || a.sdump != nullptr) return hipErrorInvalidValue;
     const unsigned blocks = (unsigned)((long)a.chunks_per_stream * (a.n_streams / a.n_dirs));
-    hipLaunchKernelGGL(das_fused_dirs_kernel, dim3(blocks), dim3(kBlock), 0, stream, a, dir0, n_here);
+    BF_LAUNCH(das_fused_dirs_kernel, dim3(blocks), dim3(kBlock), 0, stream, a, dir0, n_here);
     return hipGetLastError();
 }
 
@@ -1784,13 +1785,13 @@ hipError_t launch_stream_rms(const float *y, long n_samples, int n_streams, doub
     long bx = (n_samples + 256L * 64 - 1) / (256L * 64);
     if (bx < 1) bx = 1;
     if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(stream_sumsq_kernel, dim3((unsigned)bx, (unsigned)n_streams), dim3(256), 0, stream, y, n_samples, sumsq);
+    BF_LAUNCH(stream_sumsq_kernel, dim3((unsigned)bx, (unsigned)n_streams), dim3(256), 0, stream, y, n_samples, sumsq);
     return hipGetLastError();
 }
 
 hipError_t launch_das_hermitian_dump(const f32x2 *sdump, f64x2 *out, long n_frames_total, hipStream_t stream) {
     const long total = n_frames_total * kNfft;
-    hipLaunchKernelGGL(das_hermitian_dump_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, sdump, out,
+    BF_LAUNCH(das_hermitian_dump_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, sdump, out,
                        total);
     return hipGetLastError();
 }

@@ -22,6 +22,7 @@
 // MI355X, 8 microphones, 32 768 frames: 1.03 ms against 1.61 ms for the generic kernel (BF_DAS_SPLIT2048=0).
 #include <hip/hip_runtime.h>
 
+#include "launch_trace.hpp"
 #include "fft1024.hpp"
 #include "kernels.hpp"
 
@@ -214,9 +215,9 @@ hipError_t launch_das_fused_2048(const DasFusedArgs &a, const f32x2 *tw_split, h
     const long items = (long)a.chunks_per_stream * a.n_streams;
     const unsigned blocks = (unsigned)((items + kHalves - 1) / kHalves);
     if (a.layout == 0)
-        hipLaunchKernelGGL(das_fused_2048_kernel<0>, dim3(blocks), dim3(kBlk), 0, stream, a, tw_split);
+        BF_LAUNCH(das_fused_2048_kernel<0>, dim3(blocks), dim3(kBlk), 0, stream, a, tw_split);
     else
-        hipLaunchKernelGGL(das_fused_2048_kernel<1>, dim3(blocks), dim3(kBlk), 0, stream, a, tw_split);
+        BF_LAUNCH(das_fused_2048_kernel<1>, dim3(blocks), dim3(kBlk), 0, stream, a, tw_split);
     return hipGetLastError();
 }
 

@@ -11,6 +11,7 @@
 // previous frame for that tail.  N = 8192 reads twiddles and window through L1 (its two transform buffers fill the LDS).
 #include <hip/hip_runtime.h>
 
+#include "launch_trace.hpp"
 #include "kernels.hpp"
 
 namespace bf {
@@ -198,7 +199,7 @@ __global__ void das_hermitian_dump_gen_kernel(const f32x2 *s, f64x2 *out, long t
 
 hipError_t launch_das_fused_gen(const DasFusedArgs &a, int n_fft, hipStream_t stream) {
     const unsigned blocks = (unsigned)((long)a.chunks_per_stream * a.n_streams);
-#define BF_GEN(N_) case N_: hipLaunchKernelGGL(das_fused_gen_kernel<N_>, dim3(blocks), dim3(gen_block(N_)), 0, stream, a); break
+#define BF_GEN(N_) case N_: BF_LAUNCH(das_fused_gen_kernel<N_>, dim3(blocks), dim3(gen_block(N_)), 0, stream, a); break
     switch (n_fft) {
         BF_GEN(128); BF_GEN(256); BF_GEN(512); BF_GEN(2048); BF_GEN(4096); BF_GEN(8192);
         default: return hipErrorInvalidValue;
@@ -209,7 +210,7 @@ hipError_t launch_das_fused_gen(const DasFusedArgs &a, int n_fft, hipStream_t st
 
 hipError_t launch_das_hermitian_dump_gen(const f32x2 *sdump, f64x2 *out, long n_frames_total, int n_fft, hipStream_t stream) {
     const long total = n_frames_total * n_fft;
-    hipLaunchKernelGGL(das_hermitian_dump_gen_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, sdump, out, total, n_fft);
+    BF_LAUNCH(das_hermitian_dump_gen_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, sdump, out, total, n_fft);
     return hipGetLastError();
 }
 

@@ -18,6 +18,7 @@
 // L2).  No spectrum dump: capi.cpp keeps das_fused_gen_kernel for that.
 #include <hip/hip_runtime.h>
 
+#include "launch_trace.hpp"
 #include "fft1024.hpp"
 #include "kernels.hpp"
 
@@ -187,9 +188,9 @@ __global__ __launch_bounds__(kBlk) void das_fused_small_kernel(DasFusedArgs a, c
 
 template <int LAYOUT>
 hipError_t launch_r(const DasFusedArgs &a, int R, const f32x2 *tw1024, unsigned blocks, hipStream_t stream) {
-    if (R == 2) hipLaunchKernelGGL((das_fused_small_kernel<LAYOUT, 2>), dim3(blocks), dim3(kBlk), 0, stream, a, tw1024);
-    else if (R == 4) hipLaunchKernelGGL((das_fused_small_kernel<LAYOUT, 4>), dim3(blocks), dim3(kBlk), 0, stream, a, tw1024);
-    else if (R == 8) hipLaunchKernelGGL((das_fused_small_kernel<LAYOUT, 8>), dim3(blocks), dim3(kBlk), 0, stream, a, tw1024);
+    if (R == 2) BF_LAUNCH((das_fused_small_kernel<LAYOUT, 2>), dim3(blocks), dim3(kBlk), 0, stream, a, tw1024);
+    else if (R == 4) BF_LAUNCH((das_fused_small_kernel<LAYOUT, 4>), dim3(blocks), dim3(kBlk), 0, stream, a, tw1024);
+    else if (R == 8) BF_LAUNCH((das_fused_small_kernel<LAYOUT, 8>), dim3(blocks), dim3(kBlk), 0, stream, a, tw1024);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

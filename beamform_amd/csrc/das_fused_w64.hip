@@ -20,6 +20,7 @@
 //     slot, as in das_fused.hip.
 #include <hip/hip_runtime.h>
 
+#include "launch_trace.hpp"
 #include "fft1024.hpp"
 #include "fft1024_w64.hpp"
 #include "kernels.hpp"
@@ -656,9 +657,9 @@ __global__ __launch_bounds__(kBlk3) void das_fused_small_w64_kernel(DasFusedArgs
 
 template <int LAYOUT>
 hipError_t launch_small_r(const DasFusedArgs &a, int R, const f32x2 *tw_w64, unsigned blocks, hipStream_t stream) {
-    if (R == 2) hipLaunchKernelGGL((das_fused_small_w64_kernel<LAYOUT, 2>), dim3(blocks), dim3(kBlk3), 0, stream, a, tw_w64);
-    else if (R == 4) hipLaunchKernelGGL((das_fused_small_w64_kernel<LAYOUT, 4>), dim3(blocks), dim3(kBlk3), 0, stream, a, tw_w64);
-    else if (R == 8) hipLaunchKernelGGL((das_fused_small_w64_kernel<LAYOUT, 8>), dim3(blocks), dim3(kBlk3), 0, stream, a, tw_w64);
+    if (R == 2) BF_LAUNCH((das_fused_small_w64_kernel<LAYOUT, 2>), dim3(blocks), dim3(kBlk3), 0, stream, a, tw_w64);
+    else if (R == 4) BF_LAUNCH((das_fused_small_w64_kernel<LAYOUT, 4>), dim3(blocks), dim3(kBlk3), 0, stream, a, tw_w64);
+    else if (R == 8) BF_LAUNCH((das_fused_small_w64_kernel<LAYOUT, 8>), dim3(blocks), dim3(kBlk3), 0, stream, a, tw_w64);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -667,9 +668,9 @@ template <int LAYOUT>
 void launch_layout(const DasFusedArgs &a, unsigned blocks, hipStream_t stream) {
     const int np = (a.n_mics + 1) / 2;
     if (np <= 4)
-        hipLaunchKernelGGL((das_fused_w64_kernel<LAYOUT, 4>), dim3(blocks), dim3(kBlock), 0, stream, a);
+        BF_LAUNCH((das_fused_w64_kernel<LAYOUT, 4>), dim3(blocks), dim3(kBlock), 0, stream, a);
     else  // > 8 mics: gains from L2
-        hipLaunchKernelGGL((das_fused_w64_kernel<LAYOUT, 0>), dim3(blocks), dim3(kBlock), 0, stream, a);
+        BF_LAUNCH((das_fused_w64_kernel<LAYOUT, 0>), dim3(blocks), dim3(kBlock), 0, stream, a);
 }
 
 }  // namespace
@@ -701,9 +702,9 @@ hipError_t launch_das_fused_2048_w64(const DasFusedArgs &a, const f32x2 *tw_spli
     const long items = (long)a.chunks_per_stream * a.n_streams;
     const unsigned blocks = (unsigned)((items + kWaves2 - 1) / kWaves2);
     if (a.layout == 0)
-        hipLaunchKernelGGL(das_fused_2048_w64_kernel<0>, dim3(blocks), dim3(kBlk2), 0, stream, a, tw_split);
+        BF_LAUNCH(das_fused_2048_w64_kernel<0>, dim3(blocks), dim3(kBlk2), 0, stream, a, tw_split);
     else
-        hipLaunchKernelGGL(das_fused_2048_w64_kernel<1>, dim3(blocks), dim3(kBlk2), 0, stream, a, tw_split);
+        BF_LAUNCH(das_fused_2048_w64_kernel<1>, dim3(blocks), dim3(kBlk2), 0, stream, a, tw_split);
     return hipGetLastError();
 }
 

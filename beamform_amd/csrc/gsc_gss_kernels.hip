@@ -2,6 +2,7 @@
 // + sample-serial float32 NLMS).
 #include <cstdlib>
 
+#include "launch_trace.hpp"
 #include "bins_common.hpp"
 
 namespace bf {
@@ -765,7 +766,7 @@ hipError_t launch_gss(const BinsArgs &a, int n_cus, hipStream_t s) {
     const int M = a.n_mics, km = a.kp1 <= 1 ? 1 : 4;
     const int groups = a.n_streams * kNQ;
 #define BF_LAUNCH_GSS(MP_, KM_) \
-    hipLaunchKernelGGL((gss_kernel<MP_, KM_>), dim3((groups + (256 / MP_) - 1) / (256 / MP_)), dim3(256), 0, s, a)
+    BF_LAUNCH((gss_kernel<MP_, KM_>), dim3((groups + (256 / MP_) - 1) / (256 / MP_)), dim3(256), 0, s, a)
     if (a.kp1 > 4 || M > 16) {  // beyond the tuned shapes: more interferers (up to 15) or microphones (up to 32)
         if (a.kp1 > 16 || M > 32) return hipErrorInvalidValue;
         if (a.kp1 <= 1) BF_LAUNCH_GSS(32, 1);
@@ -800,7 +801,7 @@ hipError_t launch_gsc_nlms(const float *aligned, float *y, float *state, long n_
     if (nw > 1 && nb <= 15) {
         const int nbl = (nb + nw - 1) / nw;  // <= 4 at nw = 4, <= 8 at nw = 2
 #define BF_MW(NW_, NBL_, KPL_)                                                                                                     \
-    hipLaunchKernelGGL((gsc_nlms_mw_kernel<NW_, NBL_, KPL_>), dim3((unsigned)n_streams), dim3(64 * NW_), lds, s, aligned, y, state, \
+    BF_LAUNCH((gsc_nlms_mw_kernel<NW_, NBL_, KPL_>), dim3((unsigned)n_streams), dim3(64 * NW_), lds, s, aligned, y, state, \
                        n_samples, n_mics, fs, cfg.gsc_use_vad, cfg.gsc_vad_threshold, cfg.gsc_mu0, cfg.gsc_mu_max)
 #define BF_MW_K(NW_, NBL_)                     \
     do {                                       \
@@ -822,10 +823,10 @@ hipError_t launch_gsc_nlms(const float *aligned, float *y, float *state, long n_
 #define BF_NLMS(NBM_, KPL_)                                                                                                        \
     do {                                                                                                                            \
         if (serial)                                                                                                                 \
-            hipLaunchKernelGGL((gsc_nlms_kernel<NBM_, KPL_>), dim3((unsigned)n_streams), dim3(64), lds, s, aligned, y, state,       \
+            BF_LAUNCH((gsc_nlms_kernel<NBM_, KPL_>), dim3((unsigned)n_streams), dim3(64), lds, s, aligned, y, state,       \
                                n_samples, n_mics, fs, cfg.gsc_use_vad, cfg.gsc_vad_threshold, cfg.gsc_mu0, cfg.gsc_mu_max);         \
         else                                                                                                                        \
-            hipLaunchKernelGGL((gsc_nlms_par_kernel<NBM_, KPL_>), dim3((unsigned)n_streams), dim3(64), lds, s, aligned, y, state,   \
+            BF_LAUNCH((gsc_nlms_par_kernel<NBM_, KPL_>), dim3((unsigned)n_streams), dim3(64), lds, s, aligned, y, state,   \
                                n_samples, n_mics, fs, cfg.gsc_use_vad, cfg.gsc_vad_threshold, cfg.gsc_mu0, cfg.gsc_mu_max);         \
     } while (0)
 #define BF_NLMS_K(NBM_)                     \
@@ -845,7 +846,7 @@ hipError_t launch_gsc_nlms(const float *aligned, float *y, float *state, long n_
 
 hipError_t launch_gsc_align(const BinsArgs &a, hipStream_t s) {
     const long total = (long)a.n_streams * a.n_frames * kNQ;
-    hipLaunchKernelGGL(gsc_align_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    BF_LAUNCH(gsc_align_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -1,6 +1,7 @@
 // mask_kernels.hip -- the pointwise nodes (das in fp64, phase), phasempf (mask + MCRA/MPF recursion) and the mcra node.
 #include <cstdlib>
 
+#include "launch_trace.hpp"
 #include "bins_common.hpp"
 #include "fft_small.hpp"
 #if BF_NFFT == 1024
@@ -1275,12 +1276,12 @@ hipError_t launch_stft_bins_fused(const StftArgs &a, const BinsArgs &b, int n_cu
 #define BF_FUSED_GO(L_, MP_, A_)                                                                                             \
     do {                                                                                                                      \
         if (w64)                                                                                                              \
-            hipLaunchKernelGGL((stft_bins_w64_kernel<L_, MP_, A_>), dim3((unsigned)wblocks), dim3(512), 0, s, a, b, wfpb, wtotal, aux, \
+            BF_LAUNCH((stft_bins_w64_kernel<L_, MP_, A_>), dim3((unsigned)wblocks), dim3(512), 0, s, a, b, wfpb, wtotal, aux, \
                                xtail);                                                                                        \
         else                                                                                                                  \
-            hipLaunchKernelGGL((stft_bins_fused_kernel<L_, MP_, A_>), dim3((unsigned)blocks), dim3(256), 0, s, a, b, gps, total, gpb, \
+            BF_LAUNCH((stft_bins_fused_kernel<L_, MP_, A_>), dim3((unsigned)blocks), dim3(256), 0, s, a, b, gps, total, gpb, \
                                aux, xtail);                                                                                   \
-        hipLaunchKernelGGL((fused_tail_kernel<MP_, A_>), dim3(tail_blocks), dim3(256), 0, s, b, (const f64x2 *)xtail, aux);   \
+        BF_LAUNCH((fused_tail_kernel<MP_, A_>), dim3(tail_blocks), dim3(256), 0, s, b, (const f64x2 *)xtail, aux);   \
     } while (0)
 #define BF_FUSED_ALGO(L_, MP_)                                   \
     do {                                                          \
@@ -1299,7 +1300,7 @@ hipError_t launch_stft_bins_fused(const StftArgs &a, const BinsArgs &b, int n_cu
     if (e != hipSuccess) return e;
     if (algo == BF_PHASEMPF) {  // second pass of launch_phasempf: the recursion over frames
         const int nthr = b.n_streams * kNQ;
-        hipLaunchKernelGGL(mpf_recursion_kernel, dim3((nthr + 63) / 64), dim3(64), 0, s, b, aux);
+        BF_LAUNCH(mpf_recursion_kernel, dim3((nthr + 63) / 64), dim3(64), 0, s, b, aux);
         e = hipGetLastError();
     }
     if (e == hipSuccess && b.spectrum) e = launch_expand_spectrum(b.Yh, b.spectrum, (long)b.n_streams * b.n_frames, s);
@@ -1329,8 +1330,8 @@ hipError_t launch_stft_bins_fused(const StftArgs &a, const BinsArgs &b, int n_cu
     const unsigned tail_blocks = (unsigned)((tail_items + 255) / 256);
 #define BF_FUSED_GO(L_, MP_, A_)                                                                                                                  \
     do {                                                                                                                                          \
-        hipLaunchKernelGGL((BF_FUSED_KERNEL<L_, MP_, A_>), dim3((unsigned)blocks), dim3(256), 0, s, a, b, rps, total, rpb, aux, xtail);           \
-        hipLaunchKernelGGL((fused_tail_kernel<MP_, A_>), dim3(tail_blocks), dim3(256), 0, s, b, (const f64x2 *)xtail, aux);                       \
+        BF_LAUNCH((BF_FUSED_KERNEL<L_, MP_, A_>), dim3((unsigned)blocks), dim3(256), 0, s, a, b, rps, total, rpb, aux, xtail);           \
+        BF_LAUNCH((fused_tail_kernel<MP_, A_>), dim3(tail_blocks), dim3(256), 0, s, b, (const f64x2 *)xtail, aux);                       \
     } while (0)
 #define BF_FUSED_ALGO(L_, MP_)                                   \
     do {                                                          \
@@ -1350,7 +1351,7 @@ hipError_t launch_stft_bins_fused(const StftArgs &a, const BinsArgs &b, int n_cu
     if (e != hipSuccess) return e;
     if (algo == BF_PHASEMPF) {  // second pass of launch_phasempf: the recursion over frames
         const int nthr = b.n_streams * kNQ;
-        hipLaunchKernelGGL(mpf_recursion_kernel, dim3((nthr + 63) / 64), dim3(64), 0, s, b, aux);
+        BF_LAUNCH(mpf_recursion_kernel, dim3((nthr + 63) / 64), dim3(64), 0, s, b, aux);
         e = hipGetLastError();
     }
     if (e == hipSuccess && b.spectrum) e = launch_expand_spectrum(b.Yh, b.spectrum, (long)b.n_streams * b.n_frames, s);
@@ -1367,17 +1368,17 @@ hipError_t launch_phasempf(const BinsArgs &a, int n_cus, hipStream_t s) {
     const long total = (long)a.n_streams * a.n_frames * kNQ;
     const unsigned blocks = (unsigned)((total + 255) / 256);
     if (a.n_mics <= 4)
-        hipLaunchKernelGGL((mpf_mask_kernel<4>), dim3(blocks), dim3(256), 0, s, a, aux);
+        BF_LAUNCH((mpf_mask_kernel<4>), dim3(blocks), dim3(256), 0, s, a, aux);
     else if (a.n_mics <= 8)
-        hipLaunchKernelGGL((mpf_mask_kernel<8>), dim3(blocks), dim3(256), 0, s, a, aux);
+        BF_LAUNCH((mpf_mask_kernel<8>), dim3(blocks), dim3(256), 0, s, a, aux);
     else if (a.n_mics <= 16)
-        hipLaunchKernelGGL((mpf_mask_kernel<16>), dim3(blocks), dim3(256), 0, s, a, aux);
+        BF_LAUNCH((mpf_mask_kernel<16>), dim3(blocks), dim3(256), 0, s, a, aux);
     else
-        hipLaunchKernelGGL((mpf_mask_kernel<32>), dim3(blocks), dim3(256), 0, s, a, aux);
+        BF_LAUNCH((mpf_mask_kernel<32>), dim3(blocks), dim3(256), 0, s, a, aux);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int nthr = a.n_streams * kNQ;
-    hipLaunchKernelGGL(mpf_recursion_kernel, dim3((nthr + 63) / 64), dim3(64), 0, s, a, aux);
+    BF_LAUNCH(mpf_recursion_kernel, dim3((nthr + 63) / 64), dim3(64), 0, s, a, aux);
     return hipGetLastError();
 }
 
@@ -1386,13 +1387,13 @@ static void launch_pointwise_t(const BinsArgs &a, hipStream_t s) {
     const long total = (long)a.n_streams * a.n_frames * kNQ;
     const unsigned blocks = (unsigned)((total + 255) / 256);
     if (a.n_mics <= 4)
-        hipLaunchKernelGGL((pointwise_bins_kernel<4, ALGO>), dim3(blocks), dim3(256), 0, s, a);
+        BF_LAUNCH((pointwise_bins_kernel<4, ALGO>), dim3(blocks), dim3(256), 0, s, a);
     else if (a.n_mics <= 8)
-        hipLaunchKernelGGL((pointwise_bins_kernel<8, ALGO>), dim3(blocks), dim3(256), 0, s, a);
+        BF_LAUNCH((pointwise_bins_kernel<8, ALGO>), dim3(blocks), dim3(256), 0, s, a);
     else if (a.n_mics <= 16)
-        hipLaunchKernelGGL((pointwise_bins_kernel<16, ALGO>), dim3(blocks), dim3(256), 0, s, a);
+        BF_LAUNCH((pointwise_bins_kernel<16, ALGO>), dim3(blocks), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((pointwise_bins_kernel<32, ALGO>), dim3(blocks), dim3(256), 0, s, a);
+        BF_LAUNCH((pointwise_bins_kernel<32, ALGO>), dim3(blocks), dim3(256), 0, s, a);
 }
 
 hipError_t launch_pointwise(const BinsArgs &a, hipStream_t s) {
@@ -1404,7 +1405,7 @@ hipError_t launch_pointwise(const BinsArgs &a, hipStream_t s) {
 }
 
 hipError_t launch_mcra_node(const BinsArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(mcra_node_kernel, dim3((a.n_streams * kNQ + 63) / 64), dim3(64), 0, s, a);
+    BF_LAUNCH(mcra_node_kernel, dim3((a.n_streams * kNQ + 63) / 64), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

@@ -113,6 +113,7 @@ class BinPipelineImpl : public BinPipeline {
             for (int i = 0; i < 2; ++i) PIPE_HIP(hipMalloc((void **)&d_dasg_[i], (size_t)4 * 1024 * sizeof(f64x2)));
             for (int i = 0; i < 2; ++i) PIPE_HIP(hipMalloc((void **)&d_dasg_w64_[i], (size_t)4 * 1024 * sizeof(f64x2)));
             for (int i = 0; i < 2; ++i) PIPE_HIP(hipMalloc((void **)&d_dasg_mic_[i], (size_t)8 * kDasMicGainRows * kDasMicGainRow * sizeof(f64x2)));
+            PIPE_HIP(hipMalloc(&d_das_sched_, das_f64_sched_ws_bytes()));  // das_f64_pair_kernel's work queue (chunk table + counter)
         }
         if (N_ == 1024) {
             const std::vector<f64x2> tw64 = twiddle_table_w64_rot();
@@ -255,7 +256,7 @@ class BinPipelineImpl : public BinPipeline {
     }
 
     void free_all() {
-        void *ptrs[] = {d_dasg_[0], d_dasg_[1], d_dasg_w64_[0], d_dasg_w64_[1], d_dasg_mic_[0], d_dasg_mic_[1], d_tw_w64_, d_tw32_, d_tw_, d_win_, d_freq_, d_steer_[0], d_steer_[1], d_hist2_[0], d_hist2_[1], d_tail_[0], d_tail_[1], d_zhist_,
+        void *ptrs[] = {d_dasg_[0], d_dasg_[1], d_dasg_w64_[0], d_dasg_w64_[1], d_dasg_mic_[0], d_dasg_mic_[1], d_das_sched_, d_tw_w64_, d_tw32_, d_tw_, d_win_, d_freq_, d_steer_[0], d_steer_[1], d_hist2_[0], d_hist2_[1], d_tail_[0], d_tail_[1], d_zhist_,
                         d_gssW_, d_mpf_, d_smooth_, d_nlms_, d_Z_, d_Yh_, d_yraw_, d_frames_};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
@@ -276,6 +277,7 @@ class BinPipelineImpl : public BinPipeline {
     f64x2 *d_dasg_[2] = {nullptr, nullptr};  // das_pair_gains_t<f64x2> of look direction 0 (das_one_launch_shape)
     f64x2 *d_dasg_w64_[2] = {nullptr, nullptr};  // das_pair_gains_w64_f64 of the same
     f64x2 *d_tw_w64_ = nullptr;                  // twiddle_table_w64_rot
+    void *d_das_sched_ = nullptr;                // das_f64_pair_kernel: chunk table + counter (das_f64_sched_ws_bytes())
     f64x2 *d_dasg_mic_[2] = {nullptr, nullptr};  // das_mic_gains_w64_f64 (frame-pair kernel)
     int steer_cur_ = 0;
     float *d_hist2_[2] = {nullptr, nullptr};  // ring hop in front of the next batch; two buffers: das_f64_pair_kernel writes the carry itself
@@ -318,6 +320,7 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
         // BF_DAS_F64_W64=0: the 32 x 32 half-wavefront kernel (das_f64_fused_kernel) instead of the 64-lane one
         da.layout = layout;
         if (w64 && snap.das_gains_w64 != nullptr) { da.gains = snap.das_gains_w64; da.gains_mic = snap.das_gains_mic; da.tw = d_tw_w64_; }
+        da.sched_ws = d_das_sched_; da.sched_ws_bytes = d_das_sched_ ? das_f64_sched_ws_bytes() : 0;
         const bool use_w64 = w64 && snap.das_gains_w64 != nullptr;
         hipError_t de = use_w64 ? prepare_das_f64_w64(da, n_cus_, stream) : hipSuccess;
         if (de == hipSuccess) {

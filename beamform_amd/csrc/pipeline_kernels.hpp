@@ -115,6 +115,8 @@ struct DasF64Args {
     int layout = 0;        // bf_layout of x and hist; 1 (interleaved) only with launch_das_f64_w64
     float *hist_out = nullptr;         // das_f64_pair_kernel: receives the last hop of the batch (the ring-buffer carry), layout as hist
     const f64x2 *gains_mic = nullptr;  // das_mic_gains_w64_f64: per-microphone Hermitian gains of the frame-pair kernel (planar input)
+    void *sched_ws = nullptr;          // das_f64_pair_kernel: device workspace of its work queue (das_f64_sched_ws_bytes())
+    size_t sched_ws_bytes = 0;
 };
 
 // the same node on one full wavefront per frame (das_f64_w64.hip; N = 1024 only): `gains` = das_pair_gains_w64_f64, `tw` =
@@ -122,6 +124,7 @@ struct DasF64Args {
 // launch.  hipErrorNotSupported above 8 microphones.
 hipError_t prepare_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s);
 hipError_t launch_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s);
+size_t das_f64_sched_ws_bytes();
 bool das_f64_writes_hist(const DasF64Args &a);  // the kernel launch_das_f64_w64 picks stores a.hist_out itself (no copy behind it)
 
 #ifdef BF_NFFT

@@ -34,6 +34,7 @@
 #include <new>
 #include <vector>
 
+#include "launch_trace.hpp"
 #include "../../include/bfcore.h"
 
 namespace {
@@ -365,7 +366,7 @@ static int build_poly(bf_resampler *r) {
     q.coeff_half_len = r->table_len - 2;
     q.index_inc = r->index_inc;
     q.table = r->d_table;
-    hipLaunchKernelGGL(poly_build_kernel, dim3((unsigned)L), dim3(64), 0, nullptr, q);
+    BF_LAUNCH(poly_build_kernel, dim3((unsigned)L), dim3(64), 0, nullptr, q);
     if (hipDeviceSynchronize() != hipSuccess) return BF_EIO;
     r->poly_L = (int)L;
     r->poly_row = row;
@@ -499,16 +500,16 @@ static int process_locked(bf_resampler *r, const float *d_in, size_t n_in, float
             const long win = (255 * r->in_rate) / r->out_rate + 2 + r->poly_row;
             const size_t lds_bytes = (size_t)r->poly_L * r->poly_row * sizeof(double) + (size_t)r->poly_L * sizeof(int2) + (size_t)win * sizeof(float);
             if (lds_bytes <= 64 * 1024)
-                hipLaunchKernelGGL(sinc_poly_lds_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, s, a, q, (int)win);
+                BF_LAUNCH(sinc_poly_lds_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, s, a, q, (int)win);
             else
-                hipLaunchKernelGGL(sinc_poly_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, q);
+                BF_LAUNCH(sinc_poly_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, q);
         } else {
             if (blocks > 256 * 32) blocks = 256 * 32;
-            hipLaunchKernelGGL(sinc_resample_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+            BF_LAUNCH(sinc_resample_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
         }
     }
     if (n_in > 0) {
-        hipLaunchKernelGGL(hist_roll_kernel, dim3((unsigned)((r->hist_len + 255) / 256)), dim3(256), 0, s, r->d_hist[r->hist_cur], d_in,
+        BF_LAUNCH(hist_roll_kernel, dim3((unsigned)((r->hist_len + 255) / 256)), dim3(256), 0, s, r->d_hist[r->hist_cur], d_in,
                            r->hist_len, (long)n_in, r->d_hist[r->hist_cur ^ 1]);
         r->hist_cur ^= 1;
     }

@@ -2,6 +2,7 @@
 // (Hermitian extension, backward FFT, synthesis window, overlap-add), the full-spectrum dump and phasempf's output smoothing.
 #include <cstdlib>
 
+#include "launch_trace.hpp"
 #include "bins_common.hpp"
 #include "fft_small.hpp"
 #if BF_NFFT == 1024
@@ -1598,7 +1599,7 @@ hipError_t launch_das_f64_fused(const DasF64Args &a, int n_cus, hipStream_t s) {
     const long total = (long)a.n_streams * ((a.n_frames + L - 1) / L);
     long blocks = (total + 7) / 8;
     if (blocks > n_cus) blocks = n_cus;
-    hipLaunchKernelGGL(das_f64_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, s, b);
+    BF_LAUNCH(das_f64_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, s, b);
     return hipGetLastError();
 }
 
@@ -1619,11 +1620,11 @@ hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
         const long ipb = (total + blocks - 1) / blocks;
         blocks = (total + ipb - 1) / ipb;
         if (a.layout == 0) {
-            if (a.z48) hipLaunchKernelGGL((stft_w64_kernel<0, true>), dim3((unsigned)blocks), dim3(512), 0, s, b, ipb);
-            else hipLaunchKernelGGL((stft_w64_kernel<0, false>), dim3((unsigned)blocks), dim3(512), 0, s, b, ipb);
+            if (a.z48) BF_LAUNCH((stft_w64_kernel<0, true>), dim3((unsigned)blocks), dim3(512), 0, s, b, ipb);
+            else BF_LAUNCH((stft_w64_kernel<0, false>), dim3((unsigned)blocks), dim3(512), 0, s, b, ipb);
         } else {
-            if (a.z48) hipLaunchKernelGGL((stft_w64_kernel<1, true>), dim3((unsigned)blocks), dim3(512), 0, s, b, ipb);
-            else hipLaunchKernelGGL((stft_w64_kernel<1, false>), dim3((unsigned)blocks), dim3(512), 0, s, b, ipb);
+            if (a.z48) BF_LAUNCH((stft_w64_kernel<1, true>), dim3((unsigned)blocks), dim3(512), 0, s, b, ipb);
+            else BF_LAUNCH((stft_w64_kernel<1, false>), dim3((unsigned)blocks), dim3(512), 0, s, b, ipb);
         }
         return hipGetLastError();
     }
@@ -1643,11 +1644,11 @@ hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
     const long cap = (long)n_cus * 4;
     if (blocks > cap) blocks = cap;
     if (a.layout == 0) {
-        if (a.z48) hipLaunchKernelGGL((stft_kernel<0, true>), dim3((unsigned)blocks), dim3(nb), 0, s, b);
-        else hipLaunchKernelGGL((stft_kernel<0, false>), dim3((unsigned)blocks), dim3(nb), 0, s, b);
+        if (a.z48) BF_LAUNCH((stft_kernel<0, true>), dim3((unsigned)blocks), dim3(nb), 0, s, b);
+        else BF_LAUNCH((stft_kernel<0, false>), dim3((unsigned)blocks), dim3(nb), 0, s, b);
     } else {
-        if (a.z48) hipLaunchKernelGGL((stft_kernel<1, true>), dim3((unsigned)blocks), dim3(nb), 0, s, b);
-        else hipLaunchKernelGGL((stft_kernel<1, false>), dim3((unsigned)blocks), dim3(nb), 0, s, b);
+        if (a.z48) BF_LAUNCH((stft_kernel<1, true>), dim3((unsigned)blocks), dim3(nb), 0, s, b);
+        else BF_LAUNCH((stft_kernel<1, false>), dim3((unsigned)blocks), dim3(nb), 0, s, b);
     }
     return hipGetLastError();
 }
@@ -1664,9 +1665,9 @@ hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s) {
         const long chunks = cps * a.n_streams;
         const dim3 grid((unsigned)((chunks + kI32Halves - 1) / kI32Halves));
         if (a.yh32)
-            hipLaunchKernelGGL(istft32_kernel<true>, grid, dim3(kI32Block), 0, s, a, (int)fpc, (int)cps);
+            BF_LAUNCH(istft32_kernel<true>, grid, dim3(kI32Block), 0, s, a, (int)fpc, (int)cps);
         else
-            hipLaunchKernelGGL(istft32_kernel<false>, grid, dim3(kI32Block), 0, s, a, (int)fpc, (int)cps);
+            BF_LAUNCH(istft32_kernel<false>, grid, dim3(kI32Block), 0, s, a, (int)fpc, (int)cps);
         return hipGetLastError();
     }
     const long pairs = (a.n_frames + 1) / 2;
@@ -1676,7 +1677,7 @@ hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s) {
     const long ppc = (pairs + cps - 1) / cps;
     cps = (pairs + ppc - 1) / ppc;
     const long chunks = cps * a.n_streams;
-    hipLaunchKernelGGL(istft_kernel, dim3((unsigned)((chunks + kIstftHalves - 1) / kIstftHalves)), dim3(kIstftBlock), 0, s, a,
+    BF_LAUNCH(istft_kernel, dim3((unsigned)((chunks + kIstftHalves - 1) / kIstftHalves)), dim3(kIstftBlock), 0, s, a,
                        (int)ppc, (int)cps);
     return hipGetLastError();
 }
@@ -1702,11 +1703,11 @@ hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
         long blocks = (items + halves - 1) / halves;
         if (blocks > (long)n_cus * 4) blocks = (long)n_cus * 4;
         if (a.layout == 0) {
-            if (a.z48) hipLaunchKernelGGL((stft_small_kernel<0, true>), dim3((unsigned)blocks), dim3(256), 0, s, b);
-            else hipLaunchKernelGGL((stft_small_kernel<0, false>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+            if (a.z48) BF_LAUNCH((stft_small_kernel<0, true>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+            else BF_LAUNCH((stft_small_kernel<0, false>), dim3((unsigned)blocks), dim3(256), 0, s, b);
         } else {
-            if (a.z48) hipLaunchKernelGGL((stft_small_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, s, b);
-            else hipLaunchKernelGGL((stft_small_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+            if (a.z48) BF_LAUNCH((stft_small_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+            else BF_LAUNCH((stft_small_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, s, b);
         }
         return hipGetLastError();
     }
@@ -1729,11 +1730,11 @@ hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
         long blocks = (items + waves - 1) / waves;
         if (blocks > (long)n_cus * 4) blocks = (long)n_cus * 4;
         if (a.layout == 0) {
-            if (a.z48) hipLaunchKernelGGL((stft_wave2048_kernel<0, true>), dim3((unsigned)blocks), dim3(256), 0, s, b);
-            else hipLaunchKernelGGL((stft_wave2048_kernel<0, false>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+            if (a.z48) BF_LAUNCH((stft_wave2048_kernel<0, true>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+            else BF_LAUNCH((stft_wave2048_kernel<0, false>), dim3((unsigned)blocks), dim3(256), 0, s, b);
         } else {
-            if (a.z48) hipLaunchKernelGGL((stft_wave2048_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, s, b);
-            else hipLaunchKernelGGL((stft_wave2048_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+            if (a.z48) BF_LAUNCH((stft_wave2048_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+            else BF_LAUNCH((stft_wave2048_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, s, b);
         }
         return hipGetLastError();
     }
@@ -1750,11 +1751,11 @@ hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
         long blocks = (items + halves - 1) / halves;
         if (blocks > (long)n_cus * 4) blocks = (long)n_cus * 4;
         if (a.layout == 0) {
-            if (a.z48) hipLaunchKernelGGL((stft_split_kernel<0, true>), dim3((unsigned)blocks), dim3(256), 0, s, b);
-            else hipLaunchKernelGGL((stft_split_kernel<0, false>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+            if (a.z48) BF_LAUNCH((stft_split_kernel<0, true>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+            else BF_LAUNCH((stft_split_kernel<0, false>), dim3((unsigned)blocks), dim3(256), 0, s, b);
         } else {
-            if (a.z48) hipLaunchKernelGGL((stft_split_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, s, b);
-            else hipLaunchKernelGGL((stft_split_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+            if (a.z48) BF_LAUNCH((stft_split_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+            else BF_LAUNCH((stft_split_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, s, b);
         }
         return hipGetLastError();
     }
@@ -1763,9 +1764,9 @@ hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
     long blocks = total < (long)n_cus * 8 ? total : (long)n_cus * 8;
     if (blocks < 1) blocks = 1;
     if (a.layout == 0)
-        hipLaunchKernelGGL(stft_generic_kernel<0>, dim3((unsigned)blocks), dim3(kGenBlock), 0, s, a);
+        BF_LAUNCH(stft_generic_kernel<0>, dim3((unsigned)blocks), dim3(kGenBlock), 0, s, a);
     else
-        hipLaunchKernelGGL(stft_generic_kernel<1>, dim3((unsigned)blocks), dim3(kGenBlock), 0, s, a);
+        BF_LAUNCH(stft_generic_kernel<1>, dim3((unsigned)blocks), dim3(kGenBlock), 0, s, a);
     return hipGetLastError();
 }
 
@@ -1781,7 +1782,7 @@ hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s) {
         if (L < 4 * kG) L = 4 * kG;    // a run recomputes one group
         const long items = (long)a.n_streams * ((a.n_frames + L - 1) / L);
         long blocks = (items + halves - 1) / halves;
-        hipLaunchKernelGGL(istft_small_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, (int)L);
+        BF_LAUNCH(istft_small_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, (int)L);
         return hipGetLastError();
     }
 #endif
@@ -1794,7 +1795,7 @@ hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s) {
         long L = ((long)a.n_streams * a.n_frames + slots - 1) / slots;
         if (L < 8) L = 8;  // a run recomputes one frame
         const long items = (long)a.n_streams * ((a.n_frames + L - 1) / L);
-        hipLaunchKernelGGL(istft_split_kernel, dim3((unsigned)((items + halves - 1) / halves)), dim3(256), 0, s, a, (int)L);
+        BF_LAUNCH(istft_split_kernel, dim3((unsigned)((items + halves - 1) / halves)), dim3(256), 0, s, a, (int)L);
         return hipGetLastError();
     }
 #endif
@@ -1802,9 +1803,9 @@ hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s) {
     const long total = (long)a.n_streams * a.n_frames;
     long blocks = total < (long)n_cus * 8 ? total : (long)n_cus * 8;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(istft_generic_kernel, dim3((unsigned)blocks), dim3(kGenBlock), 0, s, a);
+    BF_LAUNCH(istft_generic_kernel, dim3((unsigned)blocks), dim3(kGenBlock), 0, s, a);
     const long samples = total * kHop;
-    hipLaunchKernelGGL(ola_generic_kernel, dim3((unsigned)((samples + 255) / 256)), dim3(256), 0, s, a);
+    BF_LAUNCH(ola_generic_kernel, dim3((unsigned)((samples + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -1816,7 +1817,7 @@ hipError_t launch_smooth(const float *yraw, float *y, double *state, long n_fram
     const long total = n * n_streams;
     const bool al = ((reinterpret_cast<size_t>(yraw) | reinterpret_cast<size_t>(y)) & 15) == 0 && (n & 3) == 0;
     const dim3 g4((unsigned)((total / 4 + 255) / 256));
-#define BF_SM4(SZ_) hipLaunchKernelGGL((smooth4_kernel<SZ_>), g4, dim3(256), 0, s, yraw, y, state, n, n_streams)
+#define BF_SM4(SZ_) BF_LAUNCH((smooth4_kernel<SZ_>), g4, dim3(256), 0, s, yraw, y, state, n, n_streams)
     if (al && smooth_size == 1) BF_SM4(1);
     else if (al && smooth_size == 2) BF_SM4(2);
     else if (al && smooth_size == 3) BF_SM4(3);
@@ -1826,16 +1827,16 @@ hipError_t launch_smooth(const float *yraw, float *y, double *state, long n_fram
     else if (al && smooth_size == 7) BF_SM4(7);
     else if (al && smooth_size == 8) BF_SM4(8);
     else
-        hipLaunchKernelGGL(smooth_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, yraw, y, state, n, n_streams,
+        BF_LAUNCH(smooth_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, yraw, y, state, n, n_streams,
                            smooth_size);
 #undef BF_SM4
-    hipLaunchKernelGGL(smooth_state_kernel, dim3((unsigned)((64 * n_streams + 255) / 256)), dim3(256), 0, s, yraw, state, n,
+    BF_LAUNCH(smooth_state_kernel, dim3((unsigned)((64 * n_streams + 255) / 256)), dim3(256), 0, s, yraw, state, n,
                        n_streams);
     return hipGetLastError();
 }
 
 hipError_t launch_expand_spectrum(const f64x2 *Yh, f64x2 *spectrum, long frames, hipStream_t s) {
-    hipLaunchKernelGGL(expand_spectrum_kernel, dim3((unsigned)((frames * kN + 255) / 256)), dim3(256), 0, s, Yh, spectrum, frames);
+    BF_LAUNCH(expand_spectrum_kernel, dim3((unsigned)((frames * kN + 255) / 256)), dim3(256), 0, s, Yh, spectrum, frames);
     return hipGetLastError();
 }
 

@@ -38,6 +38,7 @@ HOP = 512
 NFFT = 1024
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 FP64_VECTOR_PEAK_TF = 78.6  # AMD's public MI355X FP64 vector figure (not in the guide)
+GATHER_TIMEOUT_RC = 3       # exit code of every rank when the gather watchdog fires (the compute-only line is printed first)
 
 
 def algorithmic_bytes_per_frame(n_mics: int) -> int:
@@ -198,8 +199,8 @@ def main():
                          "to rank 0 point-to-point while the next piece computes (shard.run_shard_overlapped)")
     ap.add_argument("--gather-timeout-s", type=float, default=180.0,
                     help="N > 1: if the gather timings (which follow the compute timing) have not finished after this long, rank 0 prints\n"
-                         "the line with the compute figures and gather_error set, and every rank exits: a collective that hangs on\n"
-                         "hardware this build never saw must not cost the run its result")
+                         "the line with the compute figures and gather_error set, and every rank exits with code 3: a collective that\n"
+                         "hangs on hardware this build never saw must not cost the run its compute figures, and must not pass as a success")
     ap.add_argument("--pieces", type=int, default=4)
     ap.add_argument("--cpu-frames", type=int, default=196608,
                     help="frames in the CPU-baseline sample (0 = skip); the default is ~12 s of single-core work (its oracle, with the FFT plan cached, does ~16 k frames per second)")
@@ -422,7 +423,11 @@ def main():
                                      "compute figures only")
             if rank == 0:
                 print(json.dumps(make_line(gather_state["dt_g"], gather_state["dt_o"], gather_state["error"], None)), flush=True)
-            os._exit(0)  # the hung collective cannot be cancelled from here; every rank's own watchdog does the same
+            else:
+                time.sleep(2.0)  # grace: the launcher tears every rank down as soon as one exits non-zero; rank 0 prints first
+            # the hung collective cannot be cancelled from here (every rank's own watchdog does the same), and a run whose gather never
+            # finished is a FAILED run: the compute-only line is on stdout, the exit code says so (GATHER_TIMEOUT_RC)
+            os._exit(GATHER_TIMEOUT_RC)
 
         watchdog = threading.Timer(args.gather_timeout_s, on_gather_timeout)
         watchdog.daemon = True

@@ -254,6 +254,13 @@ int bf_time_batch_device(bf_handle *h, const float *x_dev, size_t n_frames, floa
  * roofline duration from the very launches its step time covers).  end: mean ms per launch, number of launches. */
 int bf_kernel_timing_begin(bf_handle *h);
 int bf_kernel_timing_end(bf_handle *h, float *ms_mean, int *n_launches);
+/* Launch trace (diagnostics; no counterpart in the reference): the names of the kernels the CALLING THREAD launches through this library
+ * between begin and end, in launch order, '\n'-separated, spelled as rocprofv3 spells them (demangled, no parameter list, e.g.
+ * "bf::das_f64_pair_kernel", "bf::n1024::stft_kernel<0, true>").  end returns the length of the full list (snprintf convention: the
+ * list is truncated to cap - 1 bytes) or a negative error when no trace is open.  tools/dispatch_table.py prints DESIGN.md's
+ * dispatch table from it; bench.py prints a `traffic` figure only beside the kernels the counter file was taken on. */
+int bf_trace_begin(void);
+long bf_trace_end(char *buf, size_t cap);
 
 /* ---- rosjack output stage, file half, and the batch front-end ----------------------------------------
  * rosjack.cpp:189-210: sf_open(audio_file_path, SFM_WRITE, {WAV | PCM_16, 1 channel, JACK or resampled rate});

@@ -89,12 +89,14 @@ def test_bench_spawns_its_own_ranks_when_no_launcher_is_present():
 
 def test_bench_gather_watchdog_prints_the_compute_line():
     """A gather that does not finish (here: a time-out far below what two ranks need to build their channels) must not cost the
-    run its result: rank 0 prints the line with the compute figures and gather_error, every rank exits 0."""
+    run its compute figures -- and must not pass as a success: rank 0 prints the line with the compute figures and gather_error,
+    then every rank exits with bench.GATHER_TIMEOUT_RC, so the launcher's return code is non-zero."""
     env = dict(os.environ, BF_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29655", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "65536", "--steps", "40", "--warmup", "1",
            "--settle-ms", "0", "--no-extra", "--no-cpu", "--gather-timeout-s", "0.05"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode != 0, "a gather that never finished must fail the run"
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 2 and d["value"] > 0 and "did not finish" in d["gather_error"]
     assert d["value_including_overlapped_gather"] is None

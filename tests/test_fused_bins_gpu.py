@@ -213,10 +213,56 @@ def test_das_f64_one_launch_at_the_baseline_size():
     torch.cuda.synchronize()
     assert ((y - y32).norm() / y.norm()).item() < 1e-6
     rng = np.random.default_rng(9)
-    starts = [0, 3, 14, 15, 16, 17, 30, 31, 32, 33, 63, 64, F - n] + [int(v) for v in rng.integers(2, F - n, 8)]  # run length 32 at this size
+    # chunk edges of the kernel's work queue at this size (das_f64_plan: 256 chunks of 104 pairs, then 8-, 4- and 2-pair chunks): windows
+    # across the first edges of every level, the level switches and the end of the batch
+    starts = [0, 3, 14, 15, 16, 17, 30, 31, 32, 33, 63, 64, 200, 207, 208, 400, 53230, 53248, 53260, 57340, 57344, 59390, 59392, 59400,
+              F - 2 * n, F - n] + [int(v) for v in rng.integers(2, F - n, 8)]
     for t0 in starts:
         a = max(t0 - 2, 0)
         seg = x[:, a * 512:(t0 + n) * 512].cpu().numpy()
         y_ref, _ = oracle.OracleNode(p).process(np.ascontiguousarray(seg))
         got = y[t0 * 512:(t0 + n) * 512].cpu().numpy()
         assert rel_l2(got, y_ref[(t0 - a) * 512:]) < 1e-6, t0
+
+
+def _sha1_of_das_f64_batch(reps, F=65536, M=8):
+    import hashlib
+    import torch
+    from beamform_amd.capi import BF_DAS_BINS_F64, Beamformer
+    p = make_params("das", n_mics=M, theta=35.0)
+    g = torch.Generator(device="cuda").manual_seed(33)
+    x = torch.rand(M, F * 512, device="cuda", generator=g) - 0.5
+    y = torch.empty(F * 512, device="cuda")
+    digests = []
+    for rep in range(reps):
+        bf = Beamformer(p, das_impl=BF_DAS_BINS_F64)   # a cold handle: the same carried state every time
+        y.fill_(float("nan"))
+        bf.process_device(x.data_ptr(), F, y.data_ptr())
+        torch.cuda.synchronize()
+        bf.close()
+        digests.append(hashlib.sha1(y.cpu().numpy().tobytes()).hexdigest())
+    return digests
+
+
+def test_das_f64_pair_kernel_is_deterministic():
+    """The headline kernel hands frame pairs to wavefronts and chunks to blocks dynamically, completes the hop between two pairs
+    first come first served and the hop between two chunks by two float atomic adds into a zeroed hop.  Which frames share a transform is
+    fixed by the batch position and a + b == b + a, so every launch must produce the same BYTES: 32 launches of the 65 536-frame batch,
+    sha1 of the output (a hop completed from a stale or missing partner half shows up as a different digest; NaN pre-fill catches a hop
+    nobody stored)."""
+    d = _sha1_of_das_f64_batch(32)
+    assert len(set(d)) == 1, sorted(set(d))
+
+
+def test_das_f64_pair_kernel_output_does_not_depend_on_the_chunk_plan():
+    """Chunks start on even frames, so the pairs are the same whatever the plan; an edge inside a chunk is one float addition, an edge
+    between chunks is 0 + a + b by atomics: the same float.  Static equal runs, the default guided plan and a plan of tiny chunks (every
+    second hop completed by atomics, 8 wavefronts of a block spread over several chunks) must agree bit for bit."""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_fused_bins_gpu as t; print(t._sha1_of_das_f64_batch(3, F=16400)[-1])"
+            % (ROOT, os.path.join(ROOT, "tests")))
+    out = {}
+    for plan in ("0", "1", "3,2,1", "40,7,5,3"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BF_DAS_F64_SCHED=plan), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[plan] = r.stdout.strip().splitlines()[-1]
+    assert len(set(out.values())) == 1, out
