@@ -140,7 +140,7 @@ class _StagedSend:
 
 
 def run_shard_overlapped(bf, x_feed, y_feed, n_frames: int, world: int, rank: int, halo: int, n_pieces: int = 4, dst: int = 0,
-                         out=None, stream: int = 0, host_staged: bool = False):
+                         out=None, stream: int = 0, host_staged: bool = False, self_loop: bool = False):
     """run_shard with the final gather overlapped: the rank's slice is walked in `n_pieces` pieces (state carries from piece
     to piece), and as soon as a piece is enqueued its owned hops are handed to an ASYNCHRONOUS point-to-point transfer to
     `dst`, which the backend orders behind the compute stream's work so far and runs on its own stream -- piece c travels
@@ -151,6 +151,9 @@ def run_shard_overlapped(bf, x_feed, y_feed, n_frames: int, world: int, rank: in
     the receiver knows each sender's piece sizes without a handshake.
     host_staged: carry the pieces through host buffers (a backend without device-tensor point-to-point, e.g. gloo: the one-GPU
     test hook); the schedule -- who sends what in which round -- is the same.
+    self_loop: `dst` moves its OWN pieces through the backend as well (one grouped isend + irecv to itself per piece instead of the
+    local copy): on a one-rank group this is the whole point-to-point path of the N > 1 run executed on one GPU (bench.py
+    BF_BENCH_FORCE_DIST=1).
     Returns the pending work handles: wait on them (or synchronise the device) before reading `out`."""
     import contextlib
     import torch
@@ -164,10 +167,10 @@ def run_shard_overlapped(bf, x_feed, y_feed, n_frames: int, world: int, rank: in
     if x_feed.is_cuda and stream != torch.cuda.current_stream(x_feed.device).cuda_stream:
         ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream, device=x_feed.device))
     with ctx:
-        return _run_shard_overlapped(bf, x_feed, y_feed, n_frames, world, rank, halo, n_pieces, dst, out, stream, sh, H, dist, host_staged)
+        return _run_shard_overlapped(bf, x_feed, y_feed, n_frames, world, rank, halo, n_pieces, dst, out, stream, sh, H, dist, host_staged, self_loop)
 
 
-def _run_shard_overlapped(bf, x_feed, y_feed, n_frames, world, rank, halo, n_pieces, dst, out, stream, sh, H, dist, host_staged):
+def _run_shard_overlapped(bf, x_feed, y_feed, n_frames, world, rank, halo, n_pieces, dst, out, stream, sh, H, dist, host_staged, self_loop=False):
     import torch
     bf.reset_async(stream)
     peers = {r: pieces(plan(n_frames, world, r, halo), n_pieces) for r in range(world)} if rank == dst else None
@@ -181,7 +184,11 @@ def _run_shard_overlapped(bf, x_feed, y_feed, n_frames, world, rank, halo, n_pie
             bf.process_device_strided(x_feed[:, f0 * H:].data_ptr(), f1 - f0, y_feed[f0 * H:].data_ptr(), sh.n_feed * H, stream)
             mine = y_feed[(sh.n_drop + own0) * H:(sh.n_drop + own0 + n_own) * H]
         if rank == dst:
-            if n_own > 0:
+            if n_own > 0 and self_loop and not host_staged:
+                # to itself through the backend: send and receive in ONE group (an ungrouped send to oneself never meets its receive)
+                sl = out[(sh.lo + own0) * H:(sh.lo + own0 + n_own) * H]
+                works += dist.batch_isend_irecv([dist.P2POp(dist.isend, mine, dst), dist.P2POp(dist.irecv, sl, dst)])
+            elif n_own > 0:
                 out[(sh.lo + own0) * H:(sh.lo + own0 + n_own) * H].copy_(mine, non_blocking=True)
             for r in range(world):
                 if r == rank or c >= len(peers[r]):

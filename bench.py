@@ -147,16 +147,48 @@ def cpu_baseline_all_cores(algo: str, n_mics: int, frames_per_core: int):
                       f"{wall:.1f} s wall incl. pool start-up and scene synthesis"}
 
 
-def load_traffic(tag: str):
-    """HBM bytes per launch from a committed rocprofv3 --pmc summary (profiles/), or None."""
+def norm_kernel_name(n: str) -> str:
+    """A kernel name as bf_trace_end spells it, from rocprofv3's spelling (possibly truncated): no 'void ', no parameter list, no
+    anonymous namespaces, no 'bf::'."""
+    n = n.strip()
+    if n.startswith("void "):
+        n = n[5:]
+    n = n.replace("(anonymous namespace)::", "")
+    depth = 0
+    for i, c in enumerate(n):
+        if c == "<":
+            depth += 1
+        elif c == ">":
+            depth -= 1
+        elif c == "(" and depth == 0:
+            n = n[:i]
+            break
+    return n.replace("bf::", "").strip()
+
+
+def load_traffic(tag: str, launched=None):
+    """(HBM-side bytes per step from a committed rocprofv3 --pmc summary under profiles/, note).  The figure is handed out only when
+    the kernels named INSIDE the file are the kernels this run just launched (`launched`: names from bf_trace_end); otherwise
+    (None, why) -- a counter figure printed beside a kernel it was not measured on is worse than none."""
     path = os.path.join(ROOT, "profiles", f"traffic_{tag}.json")
-    if os.path.exists(path):
-        try:
-            with open(path) as f:
-                return json.load(f).get("hbm_bytes_per_launch")
-        except Exception:
-            return None
-    return None
+    if not os.path.exists(path):
+        return None, None
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except Exception as e:
+        return None, f"profiles/traffic_{tag}.json unreadable: {e}"
+    names = d.get("kernel_names")
+    if names is None:  # files written before the names were stored separately: the keys of "kernels" (rocprofv3's spelling, cut at 90)
+        names = [k for k in d.get("kernels", {})] or ([d["kernel"]] if "kernel" in d else [])
+    had = sorted({norm_kernel_name(k) for k in names})
+    if launched is not None:
+        now = sorted({norm_kernel_name(k) for k in launched})
+        # (a file that names one kernel by a substring -- the round-1 format -- matches when that substring names a launched kernel)
+        ok = (had == now) or (len(had) == 1 and "kernel" in d and any(had[0] in k for k in now) and len(now) == 1)
+        if not ok:
+            return None, (f"profiles/traffic_{tag}.json (git {d.get('git_head', '?')}) was taken on {had}; this run launched {now}")
+    return d.get("hbm_bytes_per_launch"), None
 
 
 def spawn_ranks(n: int) -> int:
@@ -217,6 +249,11 @@ def main():
         sys.exit(spawn_ranks(args.gpus))          # nothing has touched the GPU in this process
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # BF_BENCH_FORCE_DIST=1 with --gpus 1: run the multi-rank code path (init_process_group("nccl"), shard plan, cold handle per step,
+    # final gather, overlapped gather with every piece going out and coming back through RCCL point-to-point) on a one-rank group, so that
+    # the RCCL calls have executed on hardware before a real N > 1 run depends on them.  The figures of such a run are not a result.
+    force_dist = world == 1 and os.environ.get("BF_BENCH_FORCE_DIST", "0") == "1"
+    use_dist = world > 1 or force_dist
 
     import torch
     import torch.distributed as dist
@@ -229,7 +266,7 @@ def main():
     # CPU baselines first (rank 0, N = 1 only): the all-cores pool forks, which must happen before this process
     # initialises the GPU; the untimed settle phase below brings the clocks back up afterwards
     cpu_line = None
-    if world == 1 and not args.no_cpu and args.cpu_frames > 0:
+    if world == 1 and not force_dist and not args.no_cpu and args.cpu_frames > 0:
         cpu_line = cpu_baseline(args.algo, args.mics, args.cpu_frames)
         if args.cpu_all_cores_frames > 0:
             try:
@@ -251,15 +288,19 @@ def main():
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dist:
+            os.environ.setdefault("MASTER_PORT", "29671")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if one_dev:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
 
     n_ranks_seen = 1
-    if world > 1:  # every rank really joined the group: a sum of ones
+    if use_dist:  # every rank really joined the group: a sum of ones
         ones = torch.ones(1, device="cpu" if one_dev else dev, dtype=torch.float64)
         dist.all_reduce(ones)
         n_ranks_seen = int(ones.item())
@@ -281,7 +322,7 @@ def main():
     sptr = stream.cuda_stream
 
     # ---- what this rank processes ------------------------------------------------------------------------------
-    sharded = world > 1 and not args.independent
+    sharded = use_dist and not args.independent
     sh = None
     if sharded:
         halo = shard.halo_frames(p)
@@ -327,18 +368,18 @@ def main():
 
     def timed(n_steps, with_gather=False):
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(n_steps):
             step(with_gather)
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
-        return all_max([dt])[0] if world > 1 else dt
+        return all_max([dt])[0] if use_dist else dt
 
     settle_launches = 0
     if args.settle_ms > 0:  # untimed: let DVFS settle (a cold chip runs the first ~50 launches up to 45 % slower)
@@ -350,6 +391,10 @@ def main():
             settle_launches += 8
     for _ in range(args.warmup):
         step()
+    from beamform_amd.capi import launch_trace
+    with launch_trace() as tr0:   # which kernels a step launches (untimed): `traffic` is printed only beside the kernels it was taken on
+        step()
+    launched_headline = tr0.kernels
     # the K timed steps, with every launch of the dominant kernel bracketed by its own HIP event pair on the launch stream: the
     # roofline duration comes from the very launches the step time covers (so kernel_ms <= ms_per_step by construction)
     bf.kernel_timing_begin()
@@ -366,6 +411,7 @@ def main():
         k_ms = ms_kernel if ms_kernel > 0 else ms_call
         achieved = bpf * units_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         tag = f"{args.algo}{M}" + ("_f64" if das_impl == BF_DAS_BINS_F64 else "")
+        traffic, traffic_note = (load_traffic(tag, launched_headline) if (n_feed == 65536 and S == 1 and args.layout == "planar") else (None, None))
         if sharded:
             shl = shard.plan(F_total, world, world - 1, halo)
             wl = (f"{args.algo} {M}-mic 1024-pt (hop 512), ONE {F_total}-frame stream frame-sharded x{world} by shard.plan "
@@ -393,16 +439,23 @@ def main():
                        "settle_launches_before_warmup": settle_launches},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         # PMC traffic exists for the profiled workloads only (profiles/traffic_<tag>.json)
-                         "traffic": load_traffic(tag) if (n_feed == 65536 and S == 1 and args.layout == "planar") else None,
+                         # PMC traffic exists for the profiled workloads only (profiles/traffic_<tag>.json), and only while the
+                         # file's kernels are the ones this run launched
+                         "traffic": traffic,
                          "kernel": ("das_fused_kernel" if das_impl == BF_DAS_FUSED_F32 else ("das_f64_pair_kernel" if args.layout == "planar" else "das_f64_w64_kernel<1>")) if args.algo == "das"
                                    else "bin pipeline (stft + per-bin kernel + istft)",
+                         "kernels_launched_per_step": sorted({norm_kernel_name(k) for k in launched_headline}),
                          "kernel_ms": k_ms, "call_ms": ms_call, "kernel_launches_timed": n_timed_launches,
                          "kernel_ms_source": "one HIP event pair per launch on the launch stream, inside the K timed steps",
                          "algorithmic_bytes_per_frame": bpf,
                          "frames_per_launch": units_per_launch, "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
         }
+        if traffic_note:
+            out["roofline"]["traffic_stale"] = traffic_note
         out["n_ranks_seen"] = n_ranks_seen
+        if force_dist:
+            out["forced_dist"] = ("BF_BENCH_FORCE_DIST=1: the N > 1 code path on a one-rank RCCL group (every piece of the overlapped gather sent "
+                                  "to and received from rank 0 itself); an execution check, not a scaling result")
         if gather_error:
             out["gather_error"] = gather_error
         out["cpu_baseline"] = cpu_line  # None at N > 1 (the contract asks for it on rank 0 at N = 1 only)
@@ -443,7 +496,7 @@ def main():
         out_full = torch.empty(F_total * HOP, device=dev, dtype=torch.float32) if rank == 0 else None
         def step_overlapped():
             for w in shard.run_shard_overlapped(bf, x, y, F_total, world, rank, halo, n_pieces=args.pieces, out=out_full, stream=sptr,
-                                                host_staged=one_dev):
+                                                host_staged=one_dev, self_loop=force_dist):
                 w.wait()                            # stream-level wait: the next step's kernels queue behind it
         step_overlapped()
         torch.cuda.synchronize(dev)
@@ -477,6 +530,9 @@ def main():
             bm.process_device(xin.data_ptr(), F_, yo.data_ptr(), 0, sptr)
             torch.cuda.synchronize(dev)
             n_settle += 1
+        with launch_trace() as trn:
+            bm.process_device(xin.data_ptr(), F_, yo.data_ptr(), 0, sptr)
+        torch.cuda.synchronize(dev)
         ms, ms_k = bm.time_device(xin.data_ptr(), F_, yo.data_ptr(), iters, sptr)
         bm.close()
         fr = S_ * F_
@@ -492,21 +548,28 @@ def main():
             line["frac_of_fp64_vector_peak"] = fl * fr / (ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TF
         if roofline_kernel and ms_k > 0:  # a one-kernel node: the same block the headline carries (event pair per launch, on the launch stream)
             ach = bpf * fr / (ms_k * 1e-3) / 1e9
+            tr_b, tr_note = load_traffic(traffic_tag, trn.kernels) if traffic_tag else (None, None)
             line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                "traffic": load_traffic(traffic_tag) if traffic_tag else None, "kernel": roofline_kernel,
+                                "traffic": tr_b, "kernel": roofline_kernel,
                                 "kernel_ms": ms_k, "call_ms": ms, "kernel_launches_timed": iters,
                                 "algorithmic_bytes_per_frame": bpf, "frames_per_launch": fr,
                                 "frac_of_measured_copy_ceiling_6290": ach / 6290.0}
+            if tr_note:
+                line["roofline"]["traffic_stale"] = tr_note
+        line["kernels"] = sorted({norm_kernel_name(k) for k in trn.kernels})
         if layout_ != BF_PLANAR or not with_traffic:  # the committed counter files are for the noise input, planar
             return line
         tag = traffic_tag or {"das": "das8_f64", "mvdr": "mvdr8", "phasempf": "phasempf8", "phase": "phase8", "lcmv": "lcmv16"}.get(algo)
-        tr = load_traffic(tag) if tag else None
+        tr, note = load_traffic(tag, trn.kernels) if tag else (None, None)
         if tr is not None:
             line["traffic"] = tr
+        if note:
+            line["traffic"] = None
+            line["traffic_stale"] = note
         return line
 
     extra = None
-    if rank == 0 and world == 1 and args.algo == "das" and not args.no_extra and S == 1 and layout == BF_PLANAR:
+    if rank == 0 and world == 1 and not force_dist and args.algo == "das" and not args.no_extra and S == 1 and layout == BF_PLANAR:
         extra = {}
         noise = ("input = uniform noise in [-0.5, 0.5): every in-band bin passes the magnitude gate, so every bin-frame "
                  "takes the covariance solve (the worst case; real scenes close part of the gates)")
@@ -677,7 +740,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(make_line(dt_g, dt_o, gather_state["error"], extra)), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

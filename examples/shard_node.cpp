@@ -12,6 +12,8 @@
 //       BF_SHARD_STUB=1: the same schedule with the transfers carried by named pipes through host memory instead of RCCL (which
 //       refuses two ranks on one device): every ncclSend / ncclRecv of the real run has its counterpart, sizes are checked at the
 //       receiving end and an unmatched transfer blocks -- the way to run all ranks of the gather on a one-GPU box.
+//       BF_SHARD_SELF=1: rank 0 sends its own pieces to itself through RCCL as well (grouped ncclSend + ncclRecv): `world` = 1 then
+//       executes the communicator set-up and the point-to-point path of the gather on one GPU.
 //   shard_node <algo> <n_mics> <total_frames> <world> logical
 //       no RCCL: one process plays all `world` ranks one after the other on one GPU (device-to-device copies instead of the
 //       gather) and compares the assembled output with the unsharded run of the same stream -- the check that the plan,
@@ -312,6 +314,9 @@ int main(int argc, char **argv) {
 
     // ---- one process per rank, RCCL for the gather -----------------------------------------------------------------------
     const bool stub = getenv("BF_SHARD_STUB") && atoi(getenv("BF_SHARD_STUB")) != 0;
+    // BF_SHARD_SELF=1 (RCCL only): rank 0 moves its own pieces through the communicator too -- with world = 1 the whole grouped
+    // send / recv path of the gather runs on a one-GPU box (the execution check in front of the first real multi-GPU run)
+    const bool self_loop = !stub && getenv("BF_SHARD_SELF") && atoi(getenv("BF_SHARD_SELF")) != 0;
     Transport tr;
     if (tr.init(world, rank, id_file, stub)) {
         fprintf(stderr, "rank %d: transport set-up failed\n", rank);
@@ -337,9 +342,13 @@ int main(int argc, char **argv) {
             // piece c of every rank moves while piece c+1 is computed: the gather stream waits for this piece only
             CK(hipEventRecord(piece_done, cs));
             CK(hipStreamWaitEvent(gs, piece_done, 0));
-            if (rank == 0 && n > 0)
+            if (rank == 0 && n > 0 && !self_loop)
                 CK(hipMemcpyAsync(out + own0 * H, me.y + (me.n_drop + own0) * H, (size_t)n * H * sizeof(float), hipMemcpyDeviceToDevice, gs));
             if (tr.group_start()) return 1;
+            if (rank == 0 && n > 0 && self_loop) {  // BF_SHARD_SELF=1: rank 0's own piece through ncclSend + ncclRecv to itself, inside the group
+                if (tr.send(me.y + (me.n_drop + own0) * H, (size_t)n * H, 0, gs)) return 1;
+                if (tr.recv(out + own0 * H, (size_t)n * H, 0, gs)) return 1;
+            }
             if (rank != 0) {
                 if (n > 0 && tr.send(me.y + (me.n_drop + own0) * H, (size_t)n * H, 0, gs)) return 1;
             } else {

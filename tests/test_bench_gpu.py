@@ -100,3 +100,79 @@ def test_bench_gather_watchdog_prints_the_compute_line():
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 2 and d["value"] > 0 and "did not finish" in d["gather_error"]
     assert d["value_including_overlapped_gather"] is None
+
+
+def test_bench_runs_the_rccl_code_path_on_one_rank():
+    """BF_BENCH_FORCE_DIST=1: init_process_group("nccl") for real, the shard plan, the final gather (dist.gather of device tensors) and
+    the overlapped gather with every piece sent to and received from rank 0 itself (grouped isend + irecv over RCCL) -- the calls a
+    real N > 1 run makes, executed once on this one-GPU box.  The output of the overlapped walk must be the stream's output."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(BF_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29672")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--frames", "8192"] + SMALL[2:] + ["--no-cpu"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 1 and "forced_dist" in d and d["n_ranks_seen"] == 1 and "gather_error" not in d
+    assert d["config"]["gather"] == "overlap" and d["config"]["global_stream_frames"] == 8192
+    assert d["value_including_final_gather"] and d["value_including_overlapped_gather"]
+
+
+def test_self_loop_gather_reproduces_the_stream():
+    """shard.run_shard_overlapped(self_loop=True) on a one-rank RCCL group: the pieces that went out and came back through
+    ncclSend / ncclRecv are the output of the unsharded batch, bit for bit on the deterministic fp32 path."""
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29673", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from beamform_amd import shard
+from beamform_amd.capi import Beamformer
+from beamform_amd.params import make_params
+p = make_params("das", n_mics=8)
+F, H = 3001, 512
+x = torch.rand(8, F * H, device="cuda") - 0.5
+y = torch.empty(F * H, device="cuda"); out = torch.full((F * H,), float("nan"), device="cuda"); ref = torch.empty(F * H, device="cuda")
+bf = Beamformer(p)
+for w in shard.run_shard_overlapped(bf, x, y, F, 1, 0, shard.halo_frames(p), n_pieces=5, out=out, stream=torch.cuda.current_stream().cuda_stream, self_loop=True):
+    w.wait()
+torch.cuda.synchronize()
+Beamformer(p).process_device(x.data_ptr(), F, ref.data_ptr())
+torch.cuda.synchronize()
+assert torch.equal(out, ref), float((out - ref).abs().max())
+dist.destroy_process_group()
+print("self-loop ok")
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0 and "self-loop ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_traffic_files_name_the_kernels_that_run():
+    """bench.py prints a `traffic` figure from profiles/traffic_<tag>.json only when the kernels named in that file are the kernels the
+    node launches today (bf_trace_begin / bf_trace_end): a counter figure beside a kernel it was not taken on is reported as
+    traffic: null + traffic_stale.  Here: every committed traffic file must match the kernels of its configuration (re-take the file with
+    tools/gpu_profile_all.sh after changing a default kernel), and a deliberately wrong launch list must be refused."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from beamform_amd.capi import BF_DAS_BINS_F64, BF_DAS_FUSED_F32, Beamformer, launch_trace
+    from beamform_amd.params import make_params
+    cases = {"das8_f64": ("das", 8, 65536, 1, (), BF_DAS_BINS_F64), "das8": ("das", 8, 65536, 1, (), BF_DAS_FUSED_F32),
+             "mvdr8": ("mvdr", 8, 65536, 1, (), 0), "phase8": ("phase", 8, 65536, 1, (), 0),
+             "phasempf8": ("phasempf", 8, 256, 256, (), 0), "lcmv16": ("lcmv", 16, 32768, 1, (-60.0, 90.0, 150.0), 0)}
+    for tag, (algo, M, F, S, interf, impl) in cases.items():
+        bf = Beamformer(make_params(algo, n_mics=M, interf=interf), n_streams=S, das_impl=impl)
+        x = torch.rand((S, M, F * 512), device="cuda") - 0.5
+        y = torch.empty((S, F * 512), device="cuda")
+        bf.process_device(x.data_ptr(), F, y.data_ptr())
+        with launch_trace() as t:
+            bf.process_device(x.data_ptr(), F, y.data_ptr())
+        torch.cuda.synchronize()
+        bf.close()
+        del x, y
+        assert t.kernels, tag
+        val, note = bench.load_traffic(tag, t.kernels)
+        assert note is None and val and val > 0, (tag, note)
+        val2, note2 = bench.load_traffic(tag, t.kernels + ["bf::some_other_kernel"])
+        assert val2 is None and "was taken on" in note2

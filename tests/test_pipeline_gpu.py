@@ -441,6 +441,13 @@ def test_c_shard_node_example_reproduces_the_unsharded_stream():
     # one rank, RCCL initialised for real: communicator of size 1, the overlapped walk, no peer
     out = subprocess.run([exe, "das", "8", "8192", "1", "0", "/tmp/bf_shard_node_test.id", "4", "2"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ms_per_step_with_overlapped_gather" in out.stdout, out.stdout + out.stderr
+    # ... and with rank 0's own pieces going through grouped ncclSend + ncclRecv to itself (BF_SHARD_SELF=1): the gather's point-to-point
+    # path executed on this one-GPU box; same checksum as the local-copy run
+    out2 = subprocess.run([exe, "das", "8", "8192", "1", "0", "/tmp/bf_shard_node_test2.id", "4", "2"], capture_output=True, text=True,
+                          timeout=300, env=dict(os.environ, BF_SHARD_SELF="1"))
+    assert out2.returncode == 0 and "ms_per_step_with_overlapped_gather" in out2.stdout, out2.stdout + out2.stderr
+    import json
+    assert json.loads(out.stdout.strip().splitlines()[-1])["checksum"] == json.loads(out2.stdout.strip().splitlines()[-1])["checksum"]
 
 
 @pytest.mark.parametrize("algo,M,F,world,chunks", [("das", 8, 10, 2, 4), ("das", 8, 4099, 3, 4), ("mvdr", 8, 1500, 2, 3), ("das", 4, 37, 4, 5)])

@@ -2,6 +2,8 @@
 # Round profile set, run on the GPU box from the repo root: tools/gpu_profile_all.sh <tag>   -> gpurun_out/<tag>_*
 tag=$1
 export TMPDIR=/tmp
+# the tree the numbers belong to (the GPU box has no .git: gpu_job.sh exports BF_GIT_HEAD before calling this)
+export BF_GIT_HEAD=${BF_GIT_HEAD:-$(git rev-parse --short=12 HEAD 2>/dev/null)}
 P="timeout 300 rocprofv3 --kernel-trace --output-format csv"
 mkdir -p gpurun_out
 # 1. the driver-shaped bench line, un-profiled and under the kernel trace
@@ -28,8 +30,8 @@ run() {  # name, step kernel, run_das args...
 run das8_f64 das_f64_pair --algo das --das-f64
 run das8 das_fused --algo das
 run mvdr8 stft_kernel --algo mvdr
-run phase8 stft_bins_fused --algo phase
-run phasempf8 stft_bins_fused --algo phasempf --streams 256 --frames 256
+run phase8 stft_bins_w64 --algo phase
+run phasempf8 stft_bins_w64 --algo phasempf --streams 256 --frames 256
 run lcmv16 stft_kernel --algo lcmv --mics 16 --frames 32768
 # 4. SQ / LDS counters of the headline kernel (das in double), separate passes
 i=0

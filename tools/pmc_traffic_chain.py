@@ -10,7 +10,10 @@ import collections
 import csv
 import glob
 import json
+import os
+import subprocess
 import sys
+import time
 
 
 def per_kernel(d, name):
@@ -39,7 +42,19 @@ except Exception:
 F, W = per_kernel(kf, "FETCH_SIZE"), per_kernel(kw, "WRITE_SIZE")
 ours = sorted(k for k in set(F) | set(W) if "bf::" in k or "das_fused" in k)
 steps = max(len(v) for k, v in F.items() if step in k)
-res = {"calibration": {"known_bytes": GiB, "fetch_factor_x4": fetch_factor, "fetch_factor_dword": fetch_factor_dword,
+def git_head():
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        return subprocess.run(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+# the git hash: of the tree the numbers were taken on (the GPU box has no .git: BF_GIT_HEAD, exported by the job script, or the
+# repo's own HEAD when this runs in the checkout)
+res = {"git_head": os.environ.get("BF_GIT_HEAD") or git_head(), "taken_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
+       "kernel_names": ours,   # rocprofv3's full spelling; bench.py compares them (normalised) with the kernels it launches
+       "calibration": {"known_bytes": GiB, "fetch_factor_x4": fetch_factor, "fetch_factor_dword": fetch_factor_dword,
                        "write_factor_x4": write_factor, "fetch_factor_x3": fetch_factor_x3, "write_factor_x3": write_factor_x3},
        "steps_profiled": steps, "kernels": {}}
 tr = tw = 0.0
