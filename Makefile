@@ -6,7 +6,7 @@ SRC := beamform_amd/csrc
 OBJ := build/obj
 LIB := beamform_amd/lib/libbfcore.so
 
-HIP_SRCS := $(SRC)/das_fused.hip $(SRC)/das_fused_gen.hip $(SRC)/das_fused_2048.hip $(SRC)/das_fused_small.hip $(SRC)/das_fused_w64.hip $(SRC)/das_f64_w64.hip $(SRC)/pipeline.hip $(SRC)/convert.hip $(SRC)/resample.hip
+HIP_SRCS := $(SRC)/das_fused.hip $(SRC)/das_fused_gen.hip $(SRC)/das_f64_w64.hip $(SRC)/pipeline.hip $(SRC)/convert.hip $(SRC)/resample.hip
 # bin-pipeline kernels: one object per supported FFT size (JACK periods 64 ... 4096 frames -> -DBF_NFFT=128 ... 8192)
 BIN_SRCS := pipeline_kernels stft_istft mask_kernels cov_kernels gsc_gss_kernels
 NFFTS := 128 256 512 1024 2048 4096 8192

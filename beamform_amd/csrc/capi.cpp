@@ -52,13 +52,8 @@ struct bf_handle {
     f32x2 *d_gains[2] = {nullptr, nullptr};
     int gains_cur = 0;
     f32x2 *d_twiddle = nullptr;
-    f32x2 *d_twiddle_w64 = nullptr;
-    f32x2 *d_twiddle_split = nullptr;  // hop 1024: twiddle_table_split2048() (das_fused_2048.hip)
-    f32x2 *d_gains_il[2] = {nullptr, nullptr};  // hop < 512: das_pair_gains_interleaved tables (das_fused_small.hip), double-buffered with d_gains
+    f32x2 *d_gains_il[2] = {nullptr, nullptr};  // hop < 512: das_pair_gains_interleaved tables (das_fused.hip, group mode), double-buffered with d_gains
     f32x2 *d_twiddle_1024 = nullptr;            // hop < 512: twiddle_table_32x32 (the frame-interleaving kernel runs the 1024-point machinery)
-    f32x2 *d_twiddle_split_w64 = nullptr;  // hop 1024: twiddle_table_split2048_w64() (das_fused_w64.hip das_fused_2048_w64_kernel)
-    f32x2 *d_gains_w64[2] = {nullptr, nullptr};
-    bool use_w64 = false;
     float *d_window = nullptr;
     float *d_zeros = nullptr;
     float *d_hist[2] = {nullptr, nullptr};  // the hop before the next frame (the reference's ring buffer content)
@@ -134,7 +129,7 @@ int sync_tables(bf_handle *h, hipStream_t s, RunSnapshot *snap) {
     }
     if (uses_fused_das(h)) {
         const int np = (h->M + 1) / 2;
-        std::vector<f32x2> g, g64, gil;  // [dir][pair][1024]
+        std::vector<f32x2> g, gil;  // [dir][pair][1024]
         for (int d = 0; d < h->n_dirs; ++d) {
             if (h->d_gains_il[0]) {
                 const std::vector<f32x2> gi = das_pair_gains_interleaved(h->steer[d], np);
@@ -142,15 +137,9 @@ int sync_tables(bf_handle *h, hipStream_t s, RunSnapshot *snap) {
             }
             const std::vector<f32x2> gd = fused_das_gen(h) ? das_pair_gains_natural(h->steer[d], np) : das_pair_gains(h->steer[d], np);
             g.insert(g.end(), gd.begin(), gd.end());
-            if (h->use_w64) {
-                const std::vector<f32x2> gw = das_pair_gains_w64(gd, np);
-                g64.insert(g64.end(), gw.begin(), gw.end());
-            }
         }
         const int nxt = h->gains_cur ^ 1;
         BF_HIP(h, hipMemcpyAsync(h->d_gains[nxt], g.data(), g.size() * sizeof(f32x2), hipMemcpyHostToDevice, s));
-        if (h->use_w64)
-            BF_HIP(h, hipMemcpyAsync(h->d_gains_w64[nxt], g64.data(), g64.size() * sizeof(f32x2), hipMemcpyHostToDevice, s));
         if (h->d_gains_il[0])
             BF_HIP(h, hipMemcpyAsync(h->d_gains_il[nxt], gil.data(), gil.size() * sizeof(f32x2), hipMemcpyHostToDevice, s));
         BF_HIP(h, hipStreamSynchronize(s));  // pageable staging vectors go out of scope
@@ -220,38 +209,25 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     // several look directions, planar input, <= 8 microphones, no dump: one set of forward transforms per frame serves up to 16
     // directions (das_fused_dirs_kernel); BF_DAS_SHARED_DIRS = the smallest direction count that takes it (0: never)
     static const int shared_min = getenv("BF_DAS_SHARED_DIRS") ? atoi(getenv("BF_DAS_SHARED_DIRS")) : 6;
-    const bool shared = !gen && !h->use_w64 && layout == BF_PLANAR && h->M <= 8 && !spectrum_dev && shared_min > 0 && h->n_dirs >= shared_min;
+    const bool shared = !gen && layout == BF_PLANAR && h->M <= 8 && !spectrum_dev && shared_min > 0 && h->n_dirs >= shared_min;
     // (generic periods: blocks of 13 N bytes of LDS -- 26 N at N = 8192 -- share a CU: 8 at N <= 512, 3 at 2048, 1 from 4096 on)
     const int gen_per_cu = h->N <= 512 ? 8 : h->N <= 1024 ? 6 : h->N <= 2048 ? 3 : 1;
-    // period 1024 without a dump: two FFT-1024 passes per frame on the in-register machinery, a half-wavefront per run, 16 runs per CU
-    // -- or, the default, a full wavefront per run on the 64-lane transform, 12 runs per CU (BF_DAS_SPLIT2048=1: the half-wavefront
-    // version, =0: the generic kernel; for A/B runs)
-    // (=3, the default: ONE 2048-point transform per frame on a full wavefront, eight frames in flight per block and the tails through an LDS
-    // ring -- das_fused.hip das_fused_wave2048_kernel)
+    // period 1024 without a dump: ONE 2048-point transform per frame on a full wavefront, eight frames in flight per block and the tails
+    // through an LDS ring (das_fused.hip das_fused_wave2048_kernel); BF_DAS_SPLIT2048=0: the generic kernel (cross-checks)
     static const int split_env = getenv("BF_DAS_SPLIT2048") ? atoi(getenv("BF_DAS_SPLIT2048")) : 3;
-    const bool wave2048 = gen && h->N == 2048 && !spectrum_dev && split_env == 3;
-    const bool split2048 = gen && h->N == 2048 && !spectrum_dev && !wave2048 && split_env != 0 && h->d_twiddle_split != nullptr;
-    const bool split_w64 = split2048 && split_env == 2 && h->d_twiddle_split_w64 != nullptr;
-    // periods below 512 without a dump: 1024 / N frames interleaved into one pass of the 1024-point machinery, a half-wavefront per
-    // run, 16 runs per CU (das_fused_small.hip; BF_DAS_INTERLEAVE=0: the generic kernel, for A/B runs)
-    // (=3: a full wavefront per run on the 64-lane transform, 12 runs per CU; =2: the half-wavefront version, 16 runs per CU; =1, the
-    // default: the period-512 kernel itself in group mode -- one block per run, tails through its LDS ring, HBM sees every hop once --
-    // ; without BF_DAS_VARIANT=3: =3)
+    const bool wave2048 = gen && h->N == 2048 && !spectrum_dev && split_env != 0;
+    // periods below 512 without a dump: 1024 / N frames interleaved into one pass of the 1024-point machinery -- the period-512 kernel
+    // itself in group mode: one block per run, tails through its LDS ring, HBM sees every hop once; BF_DAS_INTERLEAVE=0: the generic
+    // kernel (cross-checks)
     static const int il_env = getenv("BF_DAS_INTERLEAVE") ? atoi(getenv("BF_DAS_INTERLEAVE")) : 1;
-    // BF_DAS_VARIANT bit 0: ds_write_addtid transposes, bit 1: unrolled pair loop with in-loop prefetch; 0 / 1 select the older
-    // forms for A/B runs (same arithmetic, bit-identical output)
-    static const int das_variant = getenv("BF_DAS_VARIANT") ? atoi(getenv("BF_DAS_VARIANT")) : 3;
-    const bool small = gen && h->N < 1024 && !spectrum_dev && il_env != 0 && h->d_gains_il[0] != nullptr && h->d_twiddle_1024 != nullptr;
-    const long Rg = small ? 1024 / h->N : 1;
-    const bool small_ring = small && il_env == 1 && das_variant == 3;
-    const bool small_w64 = small && !small_ring && il_env != 2 && h->d_twiddle_w64 != nullptr;
-    long runs = (small_ring || wave2048 ? (long)h->n_cus : small_w64 ? (long)h->n_cus * 12 : small ? (long)h->n_cus * 16 : split_w64 ? (long)h->n_cus * 12 : split2048 ? (long)h->n_cus * 8 : gen ? (long)h->n_cus * gen_per_cu : (long)h->n_cus) / (shared ? h->n_streams : S);
+    const bool small_ring = gen && h->N < 1024 && !spectrum_dev && il_env != 0 && h->d_gains_il[0] != nullptr && h->d_twiddle_1024 != nullptr;
+    const long Rg = small_ring ? 1024 / h->N : 1;
+    long runs = (small_ring || wave2048 ? (long)h->n_cus : gen ? (long)h->n_cus * gen_per_cu : (long)h->n_cus) / (shared ? h->n_streams : S);
     if (runs < 1) runs = 1;
     long fpc = (F + runs - 1) / runs;
     if (!gen) fpc = ((fpc + 15) / 16) * 16;
     if (wave2048) fpc = ((fpc + 7) / 8) * 8;                              // eight frames per pass of a block
     else if (small_ring) fpc = ((fpc + 16 * Rg - 1) / (16 * Rg)) * (16 * Rg);  // sixteen groups per pass of a block
-    else if (small) fpc = ((fpc + Rg - 1) / Rg) * Rg;                     // whole groups of interleaved frames
     const long cps = (F + fpc - 1) / fpc;
 
     if (spectrum_dev) {
@@ -272,8 +248,8 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     a.y = y_dev;
     a.tail_in = h->d_tail[h->tail_cur];
     a.tail_out = h->d_tail[h->tail_cur ^ 1];
-    a.gains = small ? h->d_gains_il[h->gains_cur] : h->use_w64 ? h->d_gains_w64[h->gains_cur] : h->d_gains[h->gains_cur];
-    a.twiddle = small_ring ? h->d_twiddle_1024 : h->use_w64 ? h->d_twiddle_w64 : h->d_twiddle;
+    a.gains = small_ring ? h->d_gains_il[h->gains_cur] : h->d_gains[h->gains_cur];
+    a.twiddle = small_ring ? h->d_twiddle_1024 : h->d_twiddle;
     a.window = h->d_window;
     a.zeros = h->d_zeros;
     a.sdump = spectrum_dev ? h->d_sdump : nullptr;
@@ -286,7 +262,6 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     a.frames_per_chunk = (int)fpc;
     a.chunks_per_stream = (int)cps;
     a.layout = layout;
-    a.variant = das_variant;
     a.group = small_ring ? (int)Rg : 1;
     if (wave2048) BF_HIP(h, prepare_das_fused_wave2048(a, s));
     else if (!gen || small_ring) BF_HIP(h, prepare_das_fused(a, s));
@@ -302,12 +277,8 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
     } else {
         BF_HIP(h, wave2048 ? launch_das_fused_wave2048(a, s)
                   : small_ring ? launch_das_fused(a, s)
-                  : small_w64 ? launch_das_fused_small_w64(a, h->N, h->d_twiddle_w64, s)
-                  : small ? launch_das_fused_small(a, h->N, h->d_twiddle_1024, s)
-                  : split_w64 ? launch_das_fused_2048_w64(a, h->d_twiddle_split_w64, s)
-                  : split2048 ? launch_das_fused_2048(a, h->d_twiddle_split, s)
                   : gen     ? launch_das_fused_gen(a, h->N, s)
-                  : h->use_w64 ? launch_das_fused_w64(a, s) : launch_das_fused(a, s));
+                  : launch_das_fused(a, s));
     }
     if (k1) BF_HIP(h, hipEventRecord(k1, s));
     h->tail_cur ^= 1;
@@ -449,14 +420,6 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
         const size_t gsz = (size_t)((h->M + 1) / 2) * h->N * h->n_dirs;
         BF_CREATE_HIP(hipMalloc((void **)&h->d_gains[0], gsz * sizeof(f32x2)));
         BF_CREATE_HIP(hipMalloc((void **)&h->d_gains[1], gsz * sizeof(f32x2)));
-        BF_CREATE_HIP(hipMalloc((void **)&h->d_gains_w64[0], gsz * sizeof(f32x2)));
-        BF_CREATE_HIP(hipMalloc((void **)&h->d_gains_w64[1], gsz * sizeof(f32x2)));
-        {
-            std::vector<f32x2> tw64 = twiddle_table_w64();
-            BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle_w64, tw64.size() * sizeof(f32x2)));
-            BF_CREATE_HIP(hipMemcpy(h->d_twiddle_w64, tw64.data(), tw64.size() * sizeof(f32x2), hipMemcpyHostToDevice));
-        }
-        h->use_w64 = !fused_das_gen(h) && getenv("BF_DAS_W64") && atoi(getenv("BF_DAS_W64")) != 0;
         std::vector<f32x2> tw = twiddle_table_32x32<f32x2>();
         if (fused_das_gen(h)) tw = stockham_twiddles<f32x2>(h->N);  // W^m, m < N/2, + the per-pass radix-4 blocks (geometry.hpp)
         if (h->N < 1024) {
@@ -465,14 +428,6 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
             BF_CREATE_HIP(hipMemcpy(h->d_twiddle_1024, t32.data(), t32.size() * sizeof(f32x2), hipMemcpyHostToDevice));
             const size_t gil = (size_t)((h->M + 1) / 2) * 1024 * h->n_dirs;
             for (int i = 0; i < 2; ++i) BF_CREATE_HIP(hipMalloc((void **)&h->d_gains_il[i], gil * sizeof(f32x2)));
-        }
-        if (h->N == 2048) {
-            const std::vector<f32x2> ts = twiddle_table_split2048();
-            BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle_split, ts.size() * sizeof(f32x2)));
-            BF_CREATE_HIP(hipMemcpy(h->d_twiddle_split, ts.data(), ts.size() * sizeof(f32x2), hipMemcpyHostToDevice));
-            const std::vector<f32x2> tsw = twiddle_table_split2048_w64();
-            BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle_split_w64, tsw.size() * sizeof(f32x2)));
-            BF_CREATE_HIP(hipMemcpy(h->d_twiddle_split_w64, tsw.data(), tsw.size() * sizeof(f32x2), hipMemcpyHostToDevice));
         }
         BF_CREATE_HIP(hipMalloc((void **)&h->d_twiddle, tw.size() * sizeof(f32x2)));
         BF_CREATE_HIP(hipMemcpy(h->d_twiddle, tw.data(), tw.size() * sizeof(f32x2), hipMemcpyHostToDevice));
@@ -517,14 +472,10 @@ void bf_destroy(bf_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int i = 0; i < 2; ++i) {
         if (h->d_gains[i]) (void)hipFree(h->d_gains[i]);
-        if (h->d_gains_w64[i]) (void)hipFree(h->d_gains_w64[i]);
         if (h->d_tail[i]) (void)hipFree(h->d_tail[i]);
         if (h->d_hist[i]) (void)hipFree(h->d_hist[i]);
     }
     if (h->d_twiddle) (void)hipFree(h->d_twiddle);
-    if (h->d_twiddle_w64) (void)hipFree(h->d_twiddle_w64);
-    if (h->d_twiddle_split) (void)hipFree(h->d_twiddle_split);
-    if (h->d_twiddle_split_w64) (void)hipFree(h->d_twiddle_split_w64);
     if (h->d_twiddle_1024) (void)hipFree(h->d_twiddle_1024);
     for (int i = 0; i < 2; ++i)
         if (h->d_gains_il[i]) (void)hipFree(h->d_gains_il[i]);

@@ -516,280 +516,7 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
 }
 
 
-// ---- mvdr / lcmv "lanes" kernel: L lanes per problem, rows dealt cyclically, exchange by DPP -------------
-// For 9..16 microphones (and lcmv with up to 8) a problem does not fit one lane's registers.  Instead of one lane per
-// row (mvdr_lcmv_kernel: 16 lanes per problem, half of them idle on average, every column through LDS) lane q of an
-// L-lane group (L = 4 for M <= 16, 2 for M <= 8; a group never straddles a quad) owns rows i = r*L + q of R and of its
-// Cholesky factor.  Cyclic rows keep every lane busy until the last column, the column / pivot / right-hand-side
-// exchange is a quad_perm DPP broadcast, and a wavefront carries 64/L problems.  R (its stored rows: 40 complex per
-// lane at M = 16) lives in LDS, lane-contiguous, so the working copy and the right-hand sides fit the register file of
-// a wavefront that owns its SIMD.  Maths identical to mvdr_lcmv_kernel:
-//   R o whiteR = L L^H,  U = L^-1 [C | x],  G = U_C^H U_C,  g = U_C^H u_x,  y = (G^-1 g)_0.
-template <int L>
-struct LaneGrp;
-template <>
-struct LaneGrp<4> {
-    template <int SRC>
-    static __device__ __forceinline__ int bc(int v) { return __builtin_amdgcn_update_dpp(0, v, SRC * 0x55, 0xF, 0xF, true); }
-    static __device__ __forceinline__ int x1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
-    static __device__ __forceinline__ int x2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true); }
-};
-template <>
-struct LaneGrp<2> {
-    template <int SRC>
-    static __device__ __forceinline__ int bc(int v) {
-        return __builtin_amdgcn_update_dpp(0, v, SRC | (SRC << 2) | ((2 + SRC) << 4) | ((2 + SRC) << 6), 0xF, 0xF, true);
-    }
-    static __device__ __forceinline__ int x1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
-    static __device__ __forceinline__ int x2(int v) { return v; }
-};
-template <int L, int SRC>
-__device__ __forceinline__ double bcast_d(double v) {
-    const long long b = __builtin_bit_cast(long long, v);
-    const int lo = LaneGrp<L>::template bc<SRC>((int)(b & 0xffffffffLL)), hi = LaneGrp<L>::template bc<SRC>((int)(b >> 32));
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
-template <int L>
-__device__ __forceinline__ double bcast_from(int src, double v) {  // src is a compile-time constant after unrolling
-    if (L == 2) return src == 0 ? bcast_d<L, 0>(v) : bcast_d<L, 1>(v);
-    return src == 0 ? bcast_d<L, 0>(v) : src == 1 ? bcast_d<L, 1>(v) : src == 2 ? bcast_d<L, 2>(v) : bcast_d<L, 3>(v);
-}
-template <int L>
-__device__ __forceinline__ cd bcast_from(int src, cd v) { return cd{bcast_from<L>(src, v.x), bcast_from<L>(src, v.y)}; }
-template <int L>
-__device__ __forceinline__ double grp_sum(double v) {
-    auto sh = [](double x, bool second) {
-        const long long b = __builtin_bit_cast(long long, x);
-        const int lo = second ? LaneGrp<L>::x2((int)(b & 0xffffffffLL)) : LaneGrp<L>::x1((int)(b & 0xffffffffLL));
-        const int hi = second ? LaneGrp<L>::x2((int)(b >> 32)) : LaneGrp<L>::x1((int)(b >> 32));
-        return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-    };
-    v += sh(v, false);
-    if (L == 4) v += sh(v, true);
-    return v;
-}
-
-template <int MP, int L, int KM>
-__global__ __launch_bounds__(64, 1) void mvdr_lcmv_lanes_kernel(BinsArgs a, int tile, int tiles_per_stream) {
-    constexpr int RPL = MP / L;               // rows per lane
-    constexpr int PPW = 64 / L;               // problems per wavefront
-    constexpr int NB = KM + 1;
-    constexpr int NG = GramIdx<KM>::NG, NE = GramIdx<KM>::NE;
-    constexpr int NT = L * RPL * (RPL + 1) / 2;  // stored entries per lane: slot r keeps columns 0 .. r*L+L-1
-#define TIX(r, c) (L * (r) * ((r) + 1) / 2 + (c))
-    __shared__ __attribute__((aligned(16))) f64x2 s_R[NT][64];  // R rows of this lane: s_R[TIX(r, c)][lane]
-    const int lane = threadIdx.x;
-    const int q = lane % L;
-    const int pq = blockIdx.y * PPW + lane / L;  // problem (bin) index
-    const int s = blockIdx.x / tiles_per_stream;
-    const long tA = (long)(blockIdx.x % tiles_per_stream) * tile;
-    long tB = tA + tile;
-    if (tB > a.n_frames) tB = a.n_frames;
-    const int M = a.n_mics, NP = (M + 1) >> 1, KP1 = a.kp1, P = a.cfg.past_windows;
-    const bool live = pq < kNQ;
-    const int qq = live ? pq : kNQ - 1;
-    const int j = q_bin(qq);
-    const bool lcmv = a.cfg.algo == BF_LCMV;
-    const double f = fabs(a.freqs[j]);
-    const bool inband = live && f >= a.cfg.freq_min && f <= a.cfg.freq_max && !(j == 0 && !lcmv);
-    const long yidx = ((long)s * a.n_frames) * kYhStride + qq;
-    const z48 *Zs = reinterpret_cast<const z48 *>(a.Z) + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
-    const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
-    const int ksrc = q_src_bin(qq), kneg = (kN - ksrc) & (kN - 1);
-    auto load_mic = [&](long t, int m) -> cd {  // spectrum of microphone m at this bin, frame t
-        if (m >= M) return cd{0, 0};
-        const z48 *Zf = Zs + t * NP * kN + (m >> 1) * kN;
-        const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
-        cd x;
-        if ((m & 1) == 0) {
-            x = z + zc;  // z48 spectra are stored halved
-        } else {
-            const cd d = z - zc;
-            x = cd{d.y, -d.x};
-        }
-        return qq == kQX ? conj(x) : x;
-    };
-    if (__builtin_amdgcn_ballot_w64(inband) == 0) {  // nothing to solve in this wavefront
-        if (live && q == 0)
-            for (long t = tA; t < tB; ++t) {
-                cd y{0, 0};
-                if (j == 0 && !lcmv) y = load_mic(t, 0);  // mvdr.cpp:76
-                st_y(a, yidx + t * kYhStride, qq, y);
-            }
-        return;
-    }
-    // this lane's entries of the constraint columns (weights[j](i, c)) are re-read every frame (L2-resident table)
-    // straight into the right-hand sides: keeping them would cost 64 more registers at M = 16, K + 1 = 4
-    auto load_cst = [&](int r, int c) -> cd {
-        const int i = r * L + q;
-        return (c < KP1 && i < M) ? ld(steer + ((long)c * M + i) * kN + j) : cd{0, 0};
-    };
-#pragma unroll
-    for (int e = 0; e < NT; ++e) s_R[e][lane] = f64x2{0, 0};
-    // R[i][c] += x_i conj(x_c) (- xo_i conj(xo_c)) on the stored rows; x_c comes from its owner lane by DPP
-    auto rank1 = [&](const cd (&xl)[RPL], const cd (&xo)[RPL], bool with_old) {
-#pragma unroll
-        for (int c = 0; c < MP; ++c) {
-            const cd xc = bcast_from<L>(c % L, xl[c / L]);
-            const cd xoc = with_old ? bcast_from<L>(c % L, xo[c / L]) : cd{0, 0};
-#pragma unroll
-            for (int r = c / L; r < RPL; ++r) {
-                const int i = r * L + q;
-                if (c <= i) {
-                    cd v = ld(&s_R[TIX(r, c)][lane]);
-                    v = cfma_conj(v, xl[r], xc);
-                    if (with_old) v = cfms_conj(v, xo[r], xoc);
-                    s_R[TIX(r, c)][lane] = f64x2{v.x, v.y};
-                }
-            }
-        }
-    };
-    for (int p = 1; p <= P; ++p) {
-        cd xl[RPL];
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) xl[r] = load_mic(tA - p, r * L + q);
-        rank1(xl, xl, false);
-    }
-
-    for (long t = tA; t < tB; ++t) {
-        cd xl[RPL], xo[RPL];
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) {
-            xl[r] = load_mic(t, r * L + q);
-            xo[r] = load_mic(t - P, r * L + q);
-        }
-        double mag = 0.0;
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) mag += fast_sqrt(norm2(xl[r]));  // padded rows are 0
-        mag = grp_sum<L>(mag) / (double)((unsigned)M * (unsigned)kN);
-        const cd x0 = bcast_from<L>(0, xl[0]);
-        cd y;
-        if (mag > a.cfg.freq_mag_threshold) {
-            cd A[NT], b[RPL][NB];
-#pragma unroll
-            for (int r = 0; r < RPL; ++r) {
-#pragma unroll
-                for (int c = 0; c < KM; ++c) b[r][c] = load_cst(r, c);
-                b[r][KM] = xl[r];
-            }
-#pragma unroll
-            for (int r = 0; r < RPL; ++r) {
-                const int i = r * L + q;
-#pragma unroll
-                for (int c = 0; c < (r + 1) * L; ++c) {
-                    cd v = ld(&s_R[TIX(r, c)][lane]);
-                    if (c == i) v = (i < M) ? v * 1.001 : cd{1.0, 0.0};  // whiteR diagonal; padding rows = identity
-                    if (i >= M && c != i) v = cd{0, 0};
-                    A[TIX(r, c)] = v;
-                }
-            }
-#pragma unroll
-            for (int jj = 0; jj < MP; ++jj) {
-                const int ro = jj / L, qo = jj % L;  // owner slot / lane of row jj
-                const double inv = fast_rsqrt1(bcast_from<L>(qo, A[TIX(ro, jj)].x));
-                cd Lc[RPL];  // scaled column jj of the local rows (meaningful where row > jj)
-#pragma unroll
-                for (int r = ro; r < RPL; ++r) Lc[r] = A[TIX(r, jj)] * inv;
-#pragma unroll
-                for (int col = 0; col < NB; ++col) {  // right-hand sides: u_jj = b_jj / L_jj, then b_i -= L_ij u_jj
-                    const cd u = bcast_from<L>(qo, b[ro][col] * inv);
-                    if (q == qo) b[ro][col] = u;
-#pragma unroll
-                    for (int r = ro; r < RPL; ++r) {
-                        const int i = r * L + q;
-                        if (i > jj) b[r][col] = cfms(b[r][col], Lc[r], u);
-                    }
-                }
-#pragma unroll
-                for (int c = jj + 1; c < MP; ++c) {  // trailing update A_ic -= L_ij conj(L_cj), jj < c <= i
-                    const cd Lcj = bcast_from<L>(c % L, Lc[c / L]);
-#pragma unroll
-                    for (int r = c / L; r < RPL; ++r) {
-                        const int i = r * L + q;
-                        if (c <= i) A[TIX(r, c)] = cfms_conj(A[TIX(r, c)], Lc[r], Lcj);
-                    }
-                }
-            }
-            // b holds the local rows of U = L^-1 [C | x]; Gram entries, reduced over the group
-            cd ge[NE];
-            {
-                int e = 0;
-#pragma unroll
-                for (int r1 = 0; r1 < KM; ++r1)
-#pragma unroll
-                    for (int r2 = r1; r2 < KM; ++r2) {
-                        cd acc{0, 0};
-#pragma unroll
-                        for (int r = 0; r < RPL; ++r)
-                            if (r * L + q < M) acc = cfma_conj(acc, b[r][r2], b[r][r1]);
-                        ge[e++] = cd{grp_sum<L>(acc.x), grp_sum<L>(acc.y)};
-                    }
-#pragma unroll
-                for (int r1 = 0; r1 < KM; ++r1) {
-                    cd acc{0, 0};
-#pragma unroll
-                    for (int r = 0; r < RPL; ++r)
-                        if (r * L + q < M) acc = cfma_conj(acc, b[r][KM], b[r][r1]);
-                    ge[NG + r1] = cd{grp_sum<L>(acc.x), grp_sum<L>(acc.y)};
-                }
-            }
-            cd Gm[KM][KM], gv[KM];
-            {
-                int e = 0;
-#pragma unroll
-                for (int r1 = 0; r1 < KM; ++r1)
-#pragma unroll
-                    for (int r2 = r1; r2 < KM; ++r2) {
-                        const cd v = ge[e++];
-                        Gm[r1][r2] = v;
-                        Gm[r2][r1] = conj(v);
-                    }
-#pragma unroll
-                for (int r1 = 0; r1 < KM; ++r1) gv[r1] = ge[NG + r1];
-#pragma unroll
-                for (int r1 = 0; r1 < KM; ++r1)
-                    if (r1 >= KP1) {
-#pragma unroll
-                        for (int r2 = 0; r2 < KM; ++r2) {
-                            Gm[r1][r2] = cd{r1 == r2 ? 1.0 : 0.0, 0.0};
-                            Gm[r2][r1] = cd{r1 == r2 ? 1.0 : 0.0, 0.0};
-                        }
-                        gv[r1] = cd{0, 0};
-                    }
-            }
-            cd pinvs[KM];  // reciprocals of the pivots: formed once, used by the elimination and by the back substitution
-#pragma unroll
-            for (int k = 0; k < KM; ++k) {  // Gaussian elimination (G is Hermitian positive definite)
-                const cd pinv = crcp(Gm[k][k]);
-                pinvs[k] = pinv;
-#pragma unroll
-                for (int r1 = k + 1; r1 < KM; ++r1) {
-                    const cd fct = Gm[r1][k] * pinv;
-#pragma unroll
-                    for (int c = k + 1; c < KM; ++c) Gm[r1][c] = Gm[r1][c] - fct * Gm[k][c];
-                    gv[r1] = gv[r1] - fct * gv[k];
-                }
-            }
-#pragma unroll
-            for (int k = KM - 1; k >= 0; --k) {
-                cd acc = gv[k];
-#pragma unroll
-                for (int c = k + 1; c < KM; ++c) acc = acc - Gm[k][c] * gv[c];
-                gv[k] = acc * pinvs[k];
-            }
-            y = gv[0];
-        } else {
-            y = x0 * 0.01;  // mvdr.cpp:96
-        }
-        if (!inband) y = (j == 0 && !lcmv) ? x0 : cd{0, 0};
-        if (live && q == 0) st_y(a, yidx + t * kYhStride, qq, y);
-        rank1(xl, xo, true);  // slide the covariance window (mvdr.cpp:100-101)
-    }
-#undef TIX
-}
-
-
-// ---- lcmv / mvdr, 9..16 microphones: one problem per 16-lane DPP row, exchange by row_newbcast ----------
+// ---- 16-lane DPP row helpers (row_newbcast exchange) of cov2d_kernel below; round 2's one-problem-per-row kernel is gone (EXPERIMENTS.md) ----------
 // Same row-per-lane factorisation as mvdr_lcmv_kernel<16, KM>, but a problem occupies exactly one DPP row, so the
 // pivot, the scaled column and the right-hand sides travel by `v_mov_b32_dpp row_newbcast:n` (lane n of every row to
 // the whole row, one instruction per dword, VALU latency) instead of an LDS write -> s_waitcnt -> read round trip per
@@ -833,168 +560,6 @@ struct RowStep<MP, MP> {
     template <typename F>
     static __device__ __forceinline__ void run(F &&) {}
 };
-
-template <int KM>
-__global__ __launch_bounds__(256, 2) void mvdr_lcmv_row_kernel(BinsArgs a, int tile, int tiles_per_stream) {
-    constexpr int MP = 16, GPB = 256 / MP, NB = KM + 1;
-    constexpr int NG = GramIdx<KM>::NG, NE = GramIdx<KM>::NE;
-    const int grp = threadIdx.x / MP;
-    const int i = threadIdx.x % MP;
-    const int q = blockIdx.y * GPB + grp;
-    if (q >= kNQ) return;
-    const int s = blockIdx.x / tiles_per_stream;
-    const long tA = (long)(blockIdx.x % tiles_per_stream) * tile;
-    long tB = tA + tile;
-    if (tB > a.n_frames) tB = a.n_frames;
-    const int M = a.n_mics, NP = (M + 1) >> 1, KP1 = a.kp1, P = a.cfg.past_windows;
-    const int j = q_bin(q);
-    const bool lcmv = a.cfg.algo == BF_LCMV;
-    const long yidx = ((long)s * a.n_frames) * kYhStride + q;
-    const z48 *Zs = reinterpret_cast<const z48 *>(a.Z) + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
-    const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
-    const int ksrc = q_src_bin(q), kneg = (kN - ksrc) & (kN - 1);
-    auto load_xi = [&](long t) -> cd {
-        if (i >= M) return cd{0, 0};
-        const z48 *Zf = Zs + t * NP * kN + (i >> 1) * kN;
-        const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
-        cd x;
-        if ((i & 1) == 0) {
-            x = z + zc;  // z48 spectra are stored halved
-        } else {
-            const cd d = z - zc;
-            x = cd{d.y, -d.x};
-        }
-        return q == kQX ? conj(x) : x;
-    };
-    const double f = fabs(a.freqs[j]);
-    const bool inband = f >= a.cfg.freq_min && f <= a.cfg.freq_max;
-    if (!inband || (!lcmv && j == 0)) {  // uniform per row
-        for (long t = tA; t < tB; ++t) {
-            cd y{0, 0};
-            if (!lcmv && j == 0) y = rowbc<0>(load_xi(t));  // mvdr.cpp:76
-            if (i == 0) st_y(a, yidx + t * kYhStride, q, y);
-        }
-        return;
-    }
-    // this microphone's entries of the constraint columns are re-read per frame (L2-resident) straight into the
-    // right-hand sides: holding them costs the 16 registers that decide between one and two wavefronts per SIMD
-    auto load_cst = [&](int r) -> cd { return (r < KP1 && i < M) ? ld(steer + ((long)r * M + i) * kN + j) : cd{0, 0}; };
-
-    cd R[MP];  // row i of R
-#pragma unroll
-    for (int c = 0; c < MP; ++c) R[c] = cd{0, 0};
-    for (int p = 1; p <= P; ++p) {
-        const cd x = load_xi(tA - p);
-        RowStep<0, MP>::run([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            R[c] = cfma_conj(R[c], x, rowbc<c>(x));
-        });
-    }
-    for (long t = tA; t < tB; ++t) {
-        const cd x = load_xi(t);
-        const double mag = row_sum(fast_sqrt(norm2(x))) / (double)((unsigned)M * (unsigned)kN);
-        cd y;
-        if (mag > a.cfg.freq_mag_threshold) {  // uniform per row
-            cd A[MP], b[NB];
-#pragma unroll
-            for (int c = 0; c < MP; ++c) A[c] = R[c];
-            if (i < M) {
-#pragma unroll
-                for (int c = 0; c < MP; ++c)
-                    if (c == i) A[c] = A[c] * 1.001;  // cwiseProduct(whiteR) (mvdr.cpp:239-243)
-            } else {
-#pragma unroll
-                for (int c = 0; c < MP; ++c) A[c] = cd{c == i ? 1.0 : 0.0, 0.0};  // padding rows = identity
-            }
-#pragma unroll
-            for (int r = 0; r < KM; ++r) b[r] = load_cst(r);
-            b[KM] = x;
-            RowStep<0, MP>::run([&](auto jc) {
-                constexpr int jj = decltype(jc)::value;
-                const double inv = fast_rsqrt1(rowbc<jj>(A[jj].x));  // 1 / L_jj from the owner's diagonal
-                const cd Lij = A[jj] * inv;                   // my row's entry of the scaled column (valid for i > jj)
-#pragma unroll
-                for (int r = 0; r < NB; ++r) {
-                    const cd bs = b[r] * inv;
-                    const cd ujj = rowbc<jj>(bs);  // u_jj = b_jj / L_jj
-                    if (i > jj)
-                        b[r] = cfms(b[r], Lij, ujj);
-                    else if (i == jj)
-                        b[r] = bs;
-                }
-                RowStep<jj + 1, MP>::run([&](auto cc) {  // trailing update A_ic -= L_ij conj(L_cj), jj < c <= i
-                    constexpr int c = decltype(cc)::value;
-                    const cd Lcj = rowbc<c>(Lij);
-                    if (i >= c) A[c] = cfms_conj(A[c], Lij, Lcj);
-                });
-            });
-            // b[r] = row i of U = L^-1 [C | x]; Gram entries by row reduction
-            cd ge[NE];
-            {
-                int e = 0;
-#pragma unroll
-                for (int r1 = 0; r1 < KM; ++r1)
-#pragma unroll
-                    for (int r2 = r1; r2 < KM; ++r2) {
-                        cd pr = (i < M) ? cfma_conj(cd{0, 0}, b[r2], b[r1]) : cd{0, 0};
-                        ge[e++] = cd{row_sum(pr.x), row_sum(pr.y)};
-                    }
-#pragma unroll
-                for (int r1 = 0; r1 < KM; ++r1) {
-                    cd pr = (i < M) ? cfma_conj(cd{0, 0}, b[KM], b[r1]) : cd{0, 0};
-                    ge[NG + r1] = cd{row_sum(pr.x), row_sum(pr.y)};
-                }
-            }
-            // (K+1) x (K+1) system G y = g on the upper triangle only (G and every Schur complement are Hermitian):
-            // U[r][c], r <= c, is ge[] itself; rows / columns beyond the live constraints are the identity
-            cd gv[KM];
-            auto UI = [](int r, int c) { return r * KM - r * (r - 1) / 2 + (c - r); };
-#pragma unroll
-            for (int r1 = 0; r1 < KM; ++r1) gv[r1] = ge[NG + r1];
-#pragma unroll
-            for (int r1 = 0; r1 < KM; ++r1)
-                if (r1 >= KP1) {
-#pragma unroll
-                    for (int r2 = 0; r2 < r1; ++r2) ge[UI(r2, r1)] = cd{0, 0};
-                    ge[UI(r1, r1)] = cd{1.0, 0.0};
-#pragma unroll
-                    for (int c = r1 + 1; c < KM; ++c) ge[UI(r1, c)] = cd{0, 0};
-                    gv[r1] = cd{0, 0};
-                }
-            cd pinvs[KM];  // reciprocals of the pivots: formed once, used by the elimination and by the back substitution
-#pragma unroll
-            for (int k = 0; k < KM; ++k) {
-                const cd pinv = crcp(ge[UI(k, k)]);
-                pinvs[k] = pinv;
-#pragma unroll
-                for (int r1 = k + 1; r1 < KM; ++r1) {
-                    const cd fct = conj(ge[UI(k, r1)]) * pinv;  // G[r1][k] / G[k][k]
-#pragma unroll
-                    for (int c = r1; c < KM; ++c) ge[UI(r1, c)] = ge[UI(r1, c)] - fct * ge[UI(k, c)];
-                    gv[r1] = gv[r1] - fct * gv[k];
-                }
-            }
-#pragma unroll
-            for (int k = KM - 1; k >= 0; --k) {
-                cd acc = gv[k];
-#pragma unroll
-                for (int c = k + 1; c < KM; ++c) acc = acc - ge[UI(k, c)] * gv[c];
-                gv[k] = acc * pinvs[k];
-            }
-            y = gv[0];
-        } else {
-            y = rowbc<0>(x) * 0.01;  // in_fft(0,j)*0.01 (mvdr.cpp:96)
-        }
-        if (i == 0) st_y(a, yidx + t * kYhStride, q, y);
-        // slide the covariance window: + x_t x_t^H - x_{t-P} x_{t-P}^H (mvdr.cpp:100-101)
-        const cd xo = load_xi(t - P);  // loaded late: 4 registers less across the factorisation
-        RowStep<0, MP>::run([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            R[c] = cfms_conj(cfma_conj(R[c], x, rowbc<c>(x)), xo, rowbc<c>(xo));
-        });
-    }
-}
-
 
 // ---- lcmv / mvdr, 9..16 microphones: 2-D cyclic 4 x 4 lanes per problem -------------------------------------------------
 // One problem (stream, bin) per 16-lane DPP row, like mvdr_lcmv_row_kernel, but the lanes form a 4 x 4 grid (p = lane >> 2,
@@ -1317,9 +882,8 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
     const double f_qx = (double)(kN / 2 - 1) * a.cfg.sample_rate / (double)kN;
     const bool band_hits_nyquist = (0.0 >= a.cfg.freq_min && 0.0 <= a.cfg.freq_max) || (f_qx >= a.cfg.freq_min && f_qx <= a.cfg.freq_max);
     // lcmv with up to 8 microphones rides mvdr_fast_kernel while its columns fit the register file beside R and its working copy:
-    // any K <= 3 up to 6 microphones, K <= 2 at 7-8 (BF_LCMV_FAST=0: the lanes kernel, for A/B runs)
-    static const bool lcmv_fast_on = !(getenv("BF_LCMV_FAST") && atoi(getenv("BF_LCMV_FAST")) == 0);
-    const bool lcmv_fast = !no_fast && a.cfg.algo == BF_LCMV && lcmv_fast_on && M <= 8 && a.kp1 <= 4;
+    // any K <= 3 up to 6 microphones, K <= 2 at 7-8 (K = 3 at 7-8 spills 36 registers and still beats every other kernel)
+    const bool lcmv_fast = !no_fast && a.cfg.algo == BF_LCMV && M <= 8 && a.kp1 <= 4;
     (void)band_hits_nyquist;
 #define BF_LAUNCH_ML(MP_, KM_)                                                                                   \
     BF_LAUNCH((mvdr_lcmv_kernel<MP_, KM_>), dim3(tps * a.n_streams, (kNQ + (256 / MP_) - 1) / (256 / MP_)), \
@@ -1343,57 +907,13 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
         }
         return hipGetLastError();
     }
-    // 9..16 microphones, up to 3 interferers: 2-D cyclic 4 x 4 lanes per problem (lcmv 16-mic K=3 19.5 -> 15.8 ms per 32 768 frames,
-    // lcmv 12-mic 19.0 -> 14.7, mvdr 16-mic 11.0 -> 10.2).  BF_COV2D=0 selects the row / lanes kernels below for A/B runs, =2 the
-    // two-wavefronts-per-SIMD build.
-    static const int cov2d_env = getenv("BF_COV2D") ? atoi(getenv("BF_COV2D")) : -1;
-    // wavefronts per SIMD: with constraint columns (lcmv) the three-wavefront build spills 30 registers per lane and the spill
-    // traffic alone is 6 GB per 32 768 frames of 16 microphones: two wavefronts at 211 registers are 7 % faster; without
-    // constraints (mvdr, > 8 microphones) three wavefronts win by 12 %
-    const int cov2d = cov2d_env >= 0 ? cov2d_env : (km == 1 ? 3 : 2);
-    static const int tile2d_env = getenv("BF_COV2D_TILE") ? atoi(getenv("BF_COV2D_TILE")) : 0;
-    if (cov2d && !no_fast && M > 8 && M <= 16) {
-        if (tile2d_env > 0) {
-            tile = tile2d_env;
-            if (a.n_frames < tile) tile = (int)a.n_frames;
-        }
-        const int tps = (int)((a.n_frames + tile - 1) / tile);
+    // 9..16 microphones, up to 3 interferers: 2-D cyclic 4 x 4 lanes per problem.  Wavefronts per SIMD: with constraint columns (lcmv) the
+    // three-wavefront build spills 30 registers per lane and the spill traffic alone is 6 GB per 32 768 frames of 16 microphones: two
+    // wavefronts at 211 registers are 7 % faster; without constraints (mvdr) three wavefronts win by 12 %
+    if (!no_fast && M > 8 && M <= 16) {
         const dim3 grid((unsigned)(((long)tps * a.n_streams + 7) / 8 * 8 * ((kNQ + 15) / 16)));  // (unit, problem group) -> XCD-aware order in the kernel
-        if (km == 1) {
-            if (cov2d == 3) BF_LAUNCH((cov2d_kernel<1, 3>), grid, dim3(256), 0, s, a, tile, tps);
-            else BF_LAUNCH((cov2d_kernel<1, 2>), grid, dim3(256), 0, s, a, tile, tps);
-        } else {
-            if (cov2d == 3) BF_LAUNCH((cov2d_kernel<4, 3>), grid, dim3(256), 0, s, a, tile, tps);
-            else BF_LAUNCH((cov2d_kernel<4, 2>), grid, dim3(256), 0, s, a, tile, tps);
-        }
-        return hipGetLastError();
-    }
-    // lcmv with 9..16 microphones: one problem per DPP row, row_newbcast exchange (34.2 -> 27.6 ms per 32 768 frames at 16)
-    if (!no_fast && a.cfg.algo == BF_LCMV && M > 8) {
-        const dim3 grid(tps * a.n_streams, (kNQ + 15) / 16);  // x: tile * stream (can exceed 65535), y: bin blocks
-        if (km == 1)
-            BF_LAUNCH((mvdr_lcmv_row_kernel<1>), grid, dim3(256), 0, s, a, tile, tps);
-        else
-            BF_LAUNCH((mvdr_lcmv_row_kernel<4>), grid, dim3(256), 0, s, a, tile, tps);
-        return hipGetLastError();
-    }
-    // lanes kernel: mvdr with 9..16 microphones (12.7 vs 26 ms per 32 768 frames at 16) and lcmv with up to 8
-    // (9.4 vs 15.4 ms per 65 536 frames).  lcmv with 9..16 microphones keeps the row-per-lane kernel: 40 complex of
-    // working copy + 5 right-hand sides x 4 rows do not fit 512 registers (736 B of scratch, 5x slower).
-    if (!no_fast && ((a.cfg.algo == BF_MVDR && M > 8) || (a.cfg.algo == BF_LCMV && M <= 8 && !lcmv_fast))) {
-        int lt = 32;
-        if (a.n_frames < lt) lt = (int)a.n_frames;
-        const int ltps = (int)((a.n_frames + lt - 1) / lt);
-        if (M <= 4) {
-            const dim3 grid(ltps * a.n_streams, (kNQ + 31) / 32);  // x: tile * stream (can exceed 65535), y: bin blocks
-            BF_LAUNCH((mvdr_lcmv_lanes_kernel<4, 2, 4>), grid, dim3(64), 0, s, a, lt, ltps);
-        } else if (M <= 8) {
-            const dim3 grid(ltps * a.n_streams, (kNQ + 31) / 32);  // x: tile * stream (can exceed 65535), y: bin blocks
-            BF_LAUNCH((mvdr_lcmv_lanes_kernel<8, 2, 4>), grid, dim3(64), 0, s, a, lt, ltps);
-        } else {
-            const dim3 grid(ltps * a.n_streams, (kNQ + 15) / 16);  // x: tile * stream (can exceed 65535), y: bin blocks
-            BF_LAUNCH((mvdr_lcmv_lanes_kernel<16, 4, 1>), grid, dim3(64), 0, s, a, lt, ltps);
-        }
+        if (km == 1) BF_LAUNCH((cov2d_kernel<1, 3>), grid, dim3(256), 0, s, a, tile, tps);
+        else BF_LAUNCH((cov2d_kernel<4, 2>), grid, dim3(256), 0, s, a, tile, tps);
         return hipGetLastError();
     }
     if ((a.cfg.algo == BF_MVDR || lcmv_fast) && M <= 8 && !no_fast) {
@@ -1417,7 +937,8 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
         fp.solve0 = (a.cfg.algo == BF_LCMV && inb(0)) ? 1 : 0;
         fp.nb = 1 + fp.n_main + fp.n_extra;
         // tile length: the wavefronts (64 lanes = 64 (tile, problem) pairs) should fill the 4 x CUs slots a whole number of times;
-        // cost of a choice = rounds x (frames walked + P warm-up frames)
+        // cost of a choice = rounds x (frames walked + P warm-up frames); BF_MVDR_TILE forces a length (tests: lanes that straddle tiles,
+        // a short last tile)
         static const int ft_env = getenv("BF_MVDR_TILE") ? atoi(getenv("BF_MVDR_TILE")) : 0;
         // resident wavefronts per CU: the prefetch buffers (2 x 2 MP rows of 1 KiB in LDS) and the register count of the instantiation
         // that will run decide -- 8 microphones: one per SIMD (512 registers); fewer microphones: more

@@ -813,11 +813,8 @@ __global__ void das_f64_sched_kernel(DasSchedPlan p, int4 *chunks, unsigned *cou
 
 }  // namespace
 
-// BF_DAS_F64_PAIR=0: the microphone-pair kernel for planar input too (A/B runs)
-static bool use_pair_kernel(const DasF64Args &a) {
-    static const bool on = !(getenv("BF_DAS_F64_PAIR") && atoi(getenv("BF_DAS_F64_PAIR")) == 0);
-    return on && a.layout == 0 && a.gains_mic != nullptr && a.sched_ws != nullptr;
-}
+// planar input: the frame-pair kernel; [sample][mic] input: the microphone-pair kernel
+static bool use_pair_kernel(const DasF64Args &a) { return a.layout == 0 && a.gains_mic != nullptr && a.sched_ws != nullptr; }
 
 bool das_f64_writes_hist(const DasF64Args &a) { return use_pair_kernel(a) && a.hist_out != nullptr; }
 
@@ -932,10 +929,8 @@ hipError_t launch_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s) {
     }
     long fpc, cps;
     das_f64_w64_runs(a, n_cus, &fpc, &cps);
-    if (a.layout == 0)
-        BF_LAUNCH(das_f64_w64_kernel<0>, dim3((unsigned)(cps * a.n_streams)), dim3(kBlock), 0, s, a, (int)fpc, (int)cps);
-    else
-        BF_LAUNCH(das_f64_w64_kernel<1>, dim3((unsigned)(cps * a.n_streams)), dim3(kBlock), 0, s, a, (int)fpc, (int)cps);
+    if (a.layout == 0) return hipErrorNotSupported;  // (planar input without the pair kernel's tables: the chain serves it)
+    BF_LAUNCH(das_f64_w64_kernel<1>, dim3((unsigned)(cps * a.n_streams)), dim3(kBlock), 0, s, a, (int)fpc, (int)cps);
     return hipGetLastError();
 }
 

@@ -296,7 +296,7 @@ __device__ __forceinline__ void wt_fft_inv_p2(float (&re)[32], float (&im)[32], 
 // slot, 32 / R lanes to the left, for the frames inside a group; in the previous group's slot, (R - 1) 32 / R lanes to the right, for
 // its first frame; the run boundaries' atomics touch the hop of that one frame.  a.gains = das_pair_gains_interleaved
 // tables, a.window = the N-point window, a.frames_per_chunk a multiple of 16 R; T0 / T1 / t below count groups.
-template <int LAYOUT, int NPL, bool WT, int UNR = 0, int R = 1>
+template <int LAYOUT, int NPL, int UNR = 0, int R = 1>
 __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
     constexpr int H = kHop / R, JS = 32 / R;  // hop of a frame; samples between a lane's consecutive registers
     __shared__ __attribute__((aligned(16))) float lds[kLdsFixed + NPL * 2048 + 17 * kHop + 32];
@@ -319,8 +319,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
     const int hw = tid >> 5;
     const int fi = lane / JS, c = lane % JS;  // frame inside the group and sample offset (R = 1: 0 and the lane)
     const int llane = perm_lane<R>(lane);     // the residue n mod 32 this lane carries (R = 1: the lane)
-    float *pbuf = lds + kLdsTw + hw * kLdsPlane;
-    // WT: the two halves of a wavefront share one interleaved plane (8 x 8.5 KiB inside the same 72 KiB region)
+    // the two halves of a wavefront share one interleaved plane (8 x 8.5 KiB inside the same 72 KiB region)
     float *wplane = lds + kLdsTw + (hw >> 1) * kWPlane;
     const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float *)wplane);
     const float *wrowp = wplane + lane * kWRow + 32 * (hw & 1);
@@ -331,7 +330,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
     const long c_in_s = blockIdx.x - (long)stream * a.chunks_per_stream;
     const int in_stream = stream / a.n_dirs;
     const f32x2 *gains = a.gains + (long)(stream - in_stream * a.n_dirs) * n_pairs * 1024;
-    constexpr bool kP2 = UNR > 0 && LAYOUT == 0 && NPL > 0 && WT;  // paired tables (see wt_fft_fwd_p2)
+    constexpr bool kP2 = UNR > 0 && LAYOUT == 0 && NPL > 0;  // paired tables (see wt_fft_fwd_p2)
     {
         const f32x2 *twc = a.twiddle;
         f32x2 *ltw = reinterpret_cast<f32x2 *>(lds);
@@ -411,7 +410,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
         const bool valid = t < T1;
         const long tc = valid ? t : T1 - 1;
 
-        if constexpr (UNR > 0 && LAYOUT == 0 && NPL > 0 && WT) {
+        if constexpr (UNR > 0 && LAYOUT == 0 && NPL > 0) {
             // exact pair count, planar input: the pair loop is unrolled and the loads of pair p + 1 are issued from inside
             // pair p's gain loop, eight register positions at a time, into the registers that loop has just consumed
             auto rows = [&](int p, int i0, int n) {
@@ -507,18 +506,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
                 re[4 * g + 3] *= hv.w; im[4 * g + 3] *= hv.w;
             }
 
-            if (WT) {
-                wt_fft_fwd<R>(re, im, llane, s_tw, wbase, wrowp);
-            } else {
-                fft1024p_fwd_A<float>(re, im, lane, s_tw, pbuf);
-                __builtin_amdgcn_wave_barrier();
-                fft1024p_B<float>(re, lane, pbuf);
-                __builtin_amdgcn_wave_barrier();
-                fft1024p_C<float, false>(im, lane, pbuf);
-                __builtin_amdgcn_wave_barrier();
-                fft1024p_D<float, -1>(re, im, lane, pbuf);
-                __builtin_amdgcn_wave_barrier();
-            }
+            wt_fft_fwd<R>(re, im, llane, s_tw, wbase, wrowp);
 
             const cx<float> *gp = (NPL > 0 ? s_gain : reinterpret_cast<const cx<float> *>(gains)) + (long)p * 1024 + lane;
             if (p == 0) {
@@ -552,17 +540,8 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
 
         if (kP2) {
             wt_fft_inv_p2<R>(Sr, Si, lane, reinterpret_cast<const float4 *>(lds), wbase, wrowp BF_STAMP_ARGS);
-        } else if (WT) {
-            wt_fft_inv<R>(Sr, Si, lane, s_tw, wbase, wrowp);
         } else {
-            fft1024p_inv_A<float>(Sr, Si, lane, s_tw, pbuf);
-            __builtin_amdgcn_wave_barrier();
-            fft1024p_B<float>(Sr, lane, pbuf);
-            __builtin_amdgcn_wave_barrier();
-            fft1024p_C<float, true>(Si, lane, pbuf);
-            __builtin_amdgcn_wave_barrier();
-            fft1024p_D<float, +1>(Sr, Si, lane, pbuf);
-            __builtin_amdgcn_wave_barrier();
+            wt_fft_inv<R>(Sr, Si, lane, s_tw, wbase, wrowp);
         }
 
         // position i holds sample n = 32*brev5(i) + lane; even i -> first half, odd i -> n + 512
@@ -1615,49 +1594,40 @@ __global__ void das_hermitian_dump_kernel(const f32x2 *s, f64x2 *out, long total
     out[idx] = f64x2{0.5 * kNfft * ((double)u.x + (double)v.x), 0.5 * kNfft * ((double)u.y - (double)v.y)};
 }
 
-template <int LAYOUT, bool WT>
+template <int LAYOUT>
 void launch_layout(const DasFusedArgs &a, unsigned blocks, hipStream_t stream) {
     const int np = (a.n_mics + 1) / 2;
-    // planar input with the wave-interleaved transposes: pair loop unrolled for the exact pair count, next pair's loads issued
-    // from inside the gain loop (BF_DAS_VARIANT bit 1; same arithmetic, bit-identical output)
-    const bool unr = LAYOUT == 0 && WT && (a.variant & 2);
+    // planar input: pair loop unrolled for the exact pair count, next pair's loads issued from inside the gain loop
     if (a.group > 1) {  // frame groups (periods below 512): launch_das_fused checked the shape
-        if constexpr (WT) {
-#define BF_DAS_GRP(NPL_, UNR_)                                                                                                                    \
-    do {                                                                                                                                          \
-        if (a.group == 2) BF_LAUNCH((das_fused_kernel<LAYOUT, NPL_, true, UNR_, 2>), dim3(blocks), dim3(kBlock), 0, stream, a);          \
-        else if (a.group == 4) BF_LAUNCH((das_fused_kernel<LAYOUT, NPL_, true, UNR_, 4>), dim3(blocks), dim3(kBlock), 0, stream, a);     \
-        else BF_LAUNCH((das_fused_kernel<LAYOUT, NPL_, true, UNR_, 8>), dim3(blocks), dim3(kBlock), 0, stream, a);                       \
+#define BF_DAS_GRP(NPL_, UNR_)                                                                                                              \
+    do {                                                                                                                                    \
+        if (a.group == 2) BF_LAUNCH((das_fused_kernel<LAYOUT, NPL_, UNR_, 2>), dim3(blocks), dim3(kBlock), 0, stream, a);                   \
+        else if (a.group == 4) BF_LAUNCH((das_fused_kernel<LAYOUT, NPL_, UNR_, 4>), dim3(blocks), dim3(kBlock), 0, stream, a);              \
+        else BF_LAUNCH((das_fused_kernel<LAYOUT, NPL_, UNR_, 8>), dim3(blocks), dim3(kBlock), 0, stream, a);                                \
     } while (0)
-            if constexpr (LAYOUT == 0) {  // planar: the unrolled pair loop up to 8 microphones
-                if (np == 1) BF_DAS_GRP(1, 1); else if (np == 2) BF_DAS_GRP(2, 2); else if (np == 3) BF_DAS_GRP(4, 3); else if (np == 4) BF_DAS_GRP(4, 4);
-                else BF_DAS_GRP(0, 0);    // > 8 microphones: gains from L2
-            } else {
-                if (np == 1) BF_DAS_GRP(1, 0); else if (np == 2) BF_DAS_GRP(2, 0); else if (np <= 4) BF_DAS_GRP(4, 0); else BF_DAS_GRP(0, 0);
-            }
-#undef BF_DAS_GRP
+        if constexpr (LAYOUT == 0) {  // planar: the unrolled pair loop up to 8 microphones
+            if (np == 1) BF_DAS_GRP(1, 1); else if (np == 2) BF_DAS_GRP(2, 2); else if (np == 3) BF_DAS_GRP(4, 3); else if (np == 4) BF_DAS_GRP(4, 4);
+            else BF_DAS_GRP(0, 0);    // > 8 microphones: gains from L2
+        } else {
+            if (np == 1) BF_DAS_GRP(1, 0); else if (np == 2) BF_DAS_GRP(2, 0); else if (np <= 4) BF_DAS_GRP(4, 0); else BF_DAS_GRP(0, 0);
         }
+#undef BF_DAS_GRP
         return;
     }
-    if (LAYOUT == 1 && WT && (a.variant & 2) && (a.n_mics == 4 || a.n_mics == 8)) {  // 16-byte loads: two pairs per sample access
+    if (LAYOUT == 1 && (a.n_mics == 4 || a.n_mics == 8)) {  // 16-byte loads: two pairs per sample access
         if (a.n_mics == 4)  // one 16-byte load per sample = the whole sample: two frames per wavefront
             BF_LAUNCH((das_fused_il_kernel<2, 1>), dim3(blocks), dim3(kBlock), 0, stream, a);
         else                // 8 microphones: one frame per wavefront, each half-wavefront loads its 16 bytes of the 32-byte sample
             BF_LAUNCH(das_fused_il8_kernel, dim3(blocks), dim3(kBlock), 0, stream, a);
         return;
     }
-#define BF_DAS_GO(NPL_, UNR_) BF_LAUNCH((das_fused_kernel<LAYOUT, NPL_, WT, UNR_>), dim3(blocks), dim3(kBlock), 0, stream, a)
-    if (np <= 1) {
-        if (unr) BF_DAS_GO(1, 1); else BF_DAS_GO(1, 0);
-    } else if (np <= 2) {
-        if (unr) BF_DAS_GO(2, 2); else BF_DAS_GO(2, 0);
-    } else if (np == 3) {
-        if (unr) BF_DAS_GO(4, 3); else BF_DAS_GO(4, 0);
-    } else if (np == 4) {
-        if (unr) BF_DAS_GO(4, 4); else BF_DAS_GO(4, 0);
-    } else {  // > 8 mics: the gain tables no longer fit beside the transpose buffers and the tail ring
-        BF_DAS_GO(0, 0);
-    }
+    constexpr bool unr = LAYOUT == 0;
+#define BF_DAS_GO(NPL_, UNR_) BF_LAUNCH((das_fused_kernel<LAYOUT, NPL_, (unr ? UNR_ : 0)>), dim3(blocks), dim3(kBlock), 0, stream, a)
+    if (np <= 1) BF_DAS_GO(1, 1);
+    else if (np <= 2) BF_DAS_GO(2, 2);
+    else if (np == 3) BF_DAS_GO(4, 3);
+    else if (np == 4) BF_DAS_GO(4, 4);
+    else BF_DAS_GO(0, 0);  // > 8 mics: the gain tables no longer fit beside the transpose buffers and the tail ring
 #undef BF_DAS_GO
 }
 
@@ -1694,19 +1664,17 @@ hipError_t prepare_das_fused(const DasFusedArgs &a, hipStream_t stream) {
     return hipSuccess;
 }
 
-// a.group = 2 / 4 / 8 (periods 256 / 128 / 64 as groups of interleaved frames): either layout, any microphone count, the default variant,
+// a.group = 2 / 4 / 8 (periods 256 / 128 / 64 as groups of interleaved frames): either layout, any microphone count,
 // no spectrum dump; a.frames_per_chunk a multiple of 16 * group
 bool das_fused_takes_groups(const DasFusedArgs &a) {
-    return (a.variant & 3) == 3 && a.sdump == nullptr && (a.group == 2 || a.group == 4 || a.group == 8);
+    return a.sdump == nullptr && (a.group == 2 || a.group == 4 || a.group == 8);
 }
 
 hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t stream) {
     if (a.group > 1 && !(das_fused_takes_groups(a) && a.frames_per_chunk % (16 * a.group) == 0)) return hipErrorInvalidValue;
     const unsigned blocks = (unsigned)((long)a.chunks_per_stream * a.n_streams);
-    if (a.layout == 0)
-        { if (a.variant & 1) launch_layout<0, true>(a, blocks, stream); else launch_layout<0, false>(a, blocks, stream); }
-    else
-        { if (a.variant & 1) launch_layout<1, true>(a, blocks, stream); else launch_layout<1, false>(a, blocks, stream); }
+    if (a.layout == 0) launch_layout<0>(a, blocks, stream);
+    else launch_layout<1>(a, blocks, stream);
 #ifdef BF_DAS_STAMPS
     {
         static int n_launch = 0;  // sums accumulate over back-to-back launches; read out only when asked (no sync otherwise)

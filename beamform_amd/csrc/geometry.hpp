@@ -197,38 +197,6 @@ inline std::vector<f32x2> das_pair_gains_interleaved(const SteeringSet &s, int n
     return D;
 }
 
-// Same gains in the register/lane order of the 64-lane factorisation (fft1024_w64.hpp):
-// [pair][register r][lane] = D_p[w64_bin(lane, r)].
-inline std::vector<f32x2> das_pair_gains_w64(const std::vector<f32x2> &D32, int n_pairs) {
-    std::vector<f32x2> D((size_t)n_pairs * 1024);
-    for (int p = 0; p < n_pairs; ++p) {
-        // invert the 32x32 layout: position i, lane l -> bin l + 32*brev5(i)
-        std::vector<f32x2> nat(1024);
-        for (int i = 0; i < 32; ++i)
-            for (int l = 0; l < 32; ++l) nat[l + 32 * brev5(i)] = D32[((size_t)p * 32 + i) * 32 + l];
-        for (int r = 0; r < 16; ++r)
-            for (int l = 0; l < 64; ++l) D[((size_t)p * 16 + r) * 64 + l] = nat[w64_bin(l, r)];
-    }
-    return D;
-}
-
-// twiddles of the 64-lane factorisation: [0, 1024) = W1024^(k1*lane) laid out [k1][lane];
-// [1024, 1088) = W64^(b*k2) laid out [b][k2]
-inline std::vector<f32x2> twiddle_table_w64() {
-    std::vector<f32x2> t(1024 + 64);
-    for (int k = 0; k < 16; ++k)
-        for (int l = 0; l < 64; ++l) {
-            double a = -2.0 * kPi * (double)(k * l) / 1024.0;
-            t[k * 64 + l] = f32x2{(float)std::cos(a), (float)std::sin(a)};
-        }
-    for (int b = 0; b < 4; ++b)
-        for (int k = 0; k < 16; ++k) {
-            double a = -2.0 * kPi * (double)(b * k) / 64.0;
-            t[1024 + b * 16 + k] = f32x2{(float)std::cos(a), (float)std::sin(a)};
-        }
-    return t;
-}
-
 // Twiddles of the LDS-staged autosort (Stockham) transforms of the generic FFT sizes (das_fused_gen.hip, stft_istft.hip):
 //   [0, N/2)            W^m = exp(-2 pi i m / N): the closing radix-2 pass of N = 2 * 4^k reads it in order (and the in-place
 //                       transform of N = 8192 with its own strides);
@@ -255,28 +223,6 @@ inline std::vector<V> stockham_twiddles(int N) {
                 const double a = -2.0 * kPi * (double)((long)(q + 1) * k * (N / (4 * ns))) / (double)N;
                 t[(size_t)N / 2 + (ns - 1) + (size_t)q * ns + k] = V{(T)std::cos(a), (T)std::sin(a)};
             }
-    return t;
-}
-
-// das_fused_2048.hip: [0, 1024) the 32 x 32 inter-pass twiddles of the FFT-1024 machinery, [1024, 2048) W^n = exp(-2 pi i n / 2048), n < 1024
-inline std::vector<f32x2> twiddle_table_split2048() {
-    std::vector<f32x2> t = twiddle_table_32x32<f32x2>();
-    t.resize(2048);
-    for (int n = 0; n < 1024; ++n) {
-        const double a = -2.0 * kPi * (double)n / 2048.0;
-        t[1024 + n] = f32x2{(float)std::cos(a), (float)std::sin(a)};
-    }
-    return t;
-}
-
-// the same for das_fused_w64.hip das_fused_2048_w64_kernel: [twiddle_table_w64() (1088 entries) | W2048^n, n < 1024]
-inline std::vector<f32x2> twiddle_table_split2048_w64() {
-    std::vector<f32x2> t = twiddle_table_w64();
-    t.resize(1088 + 1024);
-    for (int n = 0; n < 1024; ++n) {
-        const double a = -2.0 * kPi * (double)n / 2048.0;
-        t[1088 + n] = f32x2{(float)std::cos(a), (float)std::sin(a)};
-    }
     return t;
 }
 

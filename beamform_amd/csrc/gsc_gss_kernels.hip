@@ -789,11 +789,10 @@ hipError_t launch_gsc_nlms(const float *aligned, float *y, float *state, long n_
     const int fs = cfg.gsc_filter_size, nb = n_mics - 1, nbr = nb > 0 ? nb : 1;
     const int kpl = (fs + 63) / 64, kp = kpl <= 1 ? 1 : kpl <= 2 ? 2 : 4;
     // BF_GSC_SERIAL=1: the sums in the reference's tap order, one branch per lane (gsc_nlms_kernel); default: taps over the lanes, the
-    // branches dealt out to BF_GSC_WAVES wavefronts per stream (default 8 from five branches on, 4 from three, 2 at two; 1: gsc_nlms_par_kernel;
-    // 8 microphones, 256 streams x 64 frames: 52.6 / 54.2 / 43.1 / 36.8 ms at 1 / 2 / 4 / 8)
+    // branches dealt out to 8 wavefronts per stream from five branches on, 4 from three, 2 at two, one branch: gsc_nlms_par_kernel
+    // (8 microphones, 256 streams x 64 frames: 52.6 / 54.2 / 43.1 / 36.8 ms at 1 / 2 / 4 / 8 wavefronts)
     static const bool serial = getenv("BF_GSC_SERIAL") && atoi(getenv("BF_GSC_SERIAL")) == 1;
-    static const int waves_env = getenv("BF_GSC_WAVES") ? atoi(getenv("BF_GSC_WAVES")) : 0;
-    const int nw = serial ? 1 : waves_env > 0 ? (waves_env >= 8 ? 8 : waves_env >= 4 ? 4 : waves_env >= 2 ? 2 : 1) : (nb >= 5 ? 8 : nb >= 3 ? 4 : nb >= 2 ? 2 : 1);
+    const int nw = serial ? 1 : (nb >= 5 ? 8 : nb >= 3 ? 4 : nb >= 2 ? 2 : 1);
     const size_t lds_serial = sizeof(float) * ((size_t)nbr * ((fs + 64 * kp + 8) | 1) + (size_t)nbr * ((64 * kp + 8) | 1) + 2 * fs + 16 +
                                                (size_t)nbr * 64 + 64 + 16 + 64);
     const size_t lds_par = sizeof(float) * ((size_t)nbr * ((fs + 64 * kp + 8) | 1) + 2 * fs + 64 * kp + 16 + (size_t)nbr * 64 + 64 + 64 + 32);

@@ -29,11 +29,8 @@ struct DasFusedArgs {
     int frames_per_chunk;
     int chunks_per_stream;
     int layout;            // bf_layout
-    int variant;           // bit 0: wave-interleaved transposes stored with ds_write_addtid_b32 (default on)
     int group = 1;         // launch_das_fused only: R = 1024 / n_fft frames of a period below 512 interleaved per unit of work (1: period 512)
 };
-// 64-lane variant (das_fused_w64.hip): `gains` / `twiddle` must be the *_w64 tables
-hipError_t launch_das_fused_w64(const DasFusedArgs &a, hipStream_t stream);
 hipError_t prepare_das_fused(const DasFusedArgs &a, hipStream_t stream);  // zero the atomically-completed hops
 hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t stream);
 bool das_fused_takes_groups(const DasFusedArgs &a);
@@ -55,18 +52,6 @@ hipError_t launch_das_hermitian_dump(const f32x2 *sdump, f64x2 *out, long n_fram
 // `twiddle` = exp(-2 pi i m / n_fft) for m < n_fft / 2, `window` n_fft floats; frames_per_chunk is free (no multiple of 16), no
 // prepare step (a run that does not start the stream recomputes its previous frame); sdump rows are n_fft long, natural order
 hipError_t launch_das_fused_gen(const DasFusedArgs &a, int n_fft, hipStream_t stream);
-// JACK period 1024 (FFT 2048) on the in-register FFT-1024 machinery, two passes per frame (das_fused_2048.hip): `gains` as for
-// launch_das_fused_gen, tw_split = twiddle_table_split2048(); a.frames_per_chunk / a.chunks_per_stream = frames per run / runs per OUTPUT
-// stream (a half-wavefront per run).  hipErrorNotSupported with a spectrum dump (launch_das_fused_gen serves that).
-hipError_t launch_das_fused_2048(const DasFusedArgs &a, const f32x2 *tw_split, hipStream_t stream);
-// JACK periods 256 / 128 / 64 (n_fft = 512 / 256 / 128; das_fused_small.hip): 1024 / n_fft frames interleaved into one pass of the 1024-point
-// machinery.  a.gains = das_pair_gains_interleaved tables [dir][pair][1024], a.window = the n_fft-point window, tw1024 = twiddle_table_32x32;
-// a.frames_per_chunk (a multiple of 1024 / n_fft) / a.chunks_per_stream = frames per run / runs per OUTPUT stream; no spectrum dump
-hipError_t launch_das_fused_small(const DasFusedArgs &a, int n_fft, const f32x2 *tw1024, hipStream_t stream);
-// the same on the 64-lane transform, one full wavefront per run (das_fused_w64.hip); tw_w64 = twiddle_table_w64()
-hipError_t launch_das_fused_small_w64(const DasFusedArgs &a, int n_fft, const f32x2 *tw_w64, hipStream_t stream);
-// the same on the 64-lane transform, one full wavefront per run (das_fused_w64.hip); tw_split = twiddle_table_split2048_w64()
-hipError_t launch_das_fused_2048_w64(const DasFusedArgs &a, const f32x2 *tw_split, hipStream_t stream);
 hipError_t launch_das_hermitian_dump_gen(const f32x2 *sdump, f64x2 *out, long n_frames_total, int n_fft, hipStream_t stream);
 
 }  // namespace bf

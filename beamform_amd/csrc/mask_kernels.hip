@@ -484,160 +484,14 @@ __global__ __launch_bounds__(64) void mcra_node_kernel(BinsArgs a) {
 // ======================================================================================
 //            STFT + pointwise per-bin stage in one kernel (das fp64, phase, phasempf mask)
 // ======================================================================================
-// The nodes without a frame history need a frame's spectra exactly once, so they never have to reach HBM: a 256-thread block
-// transforms the microphone pairs of FPR frames (8 half-wavefronts = FPR frames x MP/2 pairs, one 1024-point fp64 FFT each, as
-// stft_kernel) into LDS -- 16 KB of packed pair spectrum per half-wavefront, the slot doubling as its transpose plane during
-// the transform -- and then turns to the per-bin arithmetic of those frames with one (frame, bin) item per thread and pass,
-// reading the spectra back from LDS through the same load_X / *_core functions the unfused kernels use (bit-identical results).
-// HBM sees the input samples, the per-bin output rows (8 KB per frame) and nothing else: 2.3 GB instead of 11.6 GB per
-// 65 536-frame batch at 8 microphones.  LDS = 16 KB twiddles + 128 KB spectra: one block, one wavefront per SIMD, so the
-// kernel hides its own latencies: the next frames' samples are requested before the per-bin pass starts (they sit in
-// otherwise idle registers as float), and every thread keeps the steering entries of its bins in registers for the whole run
-// (the (frame, bin) items of a thread are the same in every round).  LDS: 16 KB twiddles + 128 KB spectra + 8 KB window.
-template <int LAYOUT, int MP, int ALGO>
-__global__ __launch_bounds__(256, 1) void stft_bins_fused_kernel(StftArgs a, BinsArgs b, long groups_per_stream, long total_groups,
-                                                                 long groups_per_block, double *aux, f64x2 *xtail) {
-    constexpr int NPc = MP / 2;            // pair slots per frame
-    constexpr int FPR = 8 / NPc;           // frames per round
-    // problems 0 .. N/2-1 of the FPR frames fill whole 256-thread passes; the two odd ones per frame (bins N/2 and N/2+1) would
-    // cost every wavefront one more pass for a handful of lanes (a fifth on top of four at 8 microphones), so their unpacked
-    // spectra go to `xtail` and fused_tail_kernel finishes them
-    constexpr int kQMain = kN / 2;
-    constexpr int NIT = FPR * kQMain / 256;
-    __shared__ __attribute__((aligned(16))) double lds[2048 + 8 * 2048 + 32 * 33];
-    const cx<double> *s_tw = reinterpret_cast<const cx<double> *>(lds);
-    const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
-    double *slot = lds + 2048 + hw * 2048;  // this half-wavefront's spectrum [1024] c128; transpose plane while it transforms
-    double *s_win = lds + 2048 + 8 * 2048;  // analysis window, [lane][j], rows padded to 33 doubles (a 256-byte row stride would put every lane on one bank)
-    {
-        const double *twf = reinterpret_cast<const double *>(a.tw);
-        for (int i = tid; i < 2048; i += 256) lds[i] = twf[i];
-        for (int i = tid; i < kN; i += 256) s_win[(i & 31) * 33 + (i >> 5)] = a.win[i];
-    }
-    const int M = a.n_mics, NP = (M + 1) >> 1;
-    const int fs = hw / NPc, p = hw % NPc;
-    const bool has_pair = p < NP;
-    const double *hwin = s_win + lane * 33;  // window of this lane's samples 32 j + lane
-
-    // the (frame slot, problem) items of this thread and their steering entries: the same in every round
-    int it_f[NIT], it_q[NIT];
-    cd st[NIT][MP];
-#pragma unroll
-    for (int n = 0; n < NIT; ++n) {
-        const int idx = tid + 256 * n;
-        it_f[n] = idx / kQMain;
-        it_q[n] = idx % kQMain;
-        load_steer<MP>(b.steer, q_bin(it_q[n]), M, st[n]);
-    }
-
-    const long g0 = (long)blockIdx.x * groups_per_block;
-    long g1 = g0 + groups_per_block;
-    if (g1 > total_groups) g1 = total_groups;
-
-    float fr[32], fi[32];  // raw samples of this half-wavefront's next (frame, pair)
-    auto request = [&](long g) {
-        const int s = (int)(g / groups_per_stream);
-        const long t = (g % groups_per_stream) * FPR + fs;
-        if (!has_pair || t >= a.n_frames) return;
-        const float *xs = a.x + (long)s * a.stream_stride_x;
-        const float *hs = a.hist + (long)s * M * kHop;
-        const int ma = 2 * p;
-        const int mb = (2 * p + 1 < M) ? 2 * p + 1 : ma;
-        if (LAYOUT == 0) {
-            const float *a1 = (t >= 1 ? xs + (long)ma * a.mic_stride + (t - 1) * kHop : hs + ma * kHop) + lane;
-            const float *b1 = (t >= 1 ? xs + (long)mb * a.mic_stride + (t - 1) * kHop : hs + mb * kHop) + lane;
-            const float *a2 = xs + (long)ma * a.mic_stride + t * kHop + lane;
-            const float *b2 = xs + (long)mb * a.mic_stride + t * kHop + lane;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                fr[j] = a1[32 * j];
-                fi[j] = b1[32 * j];
-                fr[j + 16] = a2[32 * j];
-                fi[j + 16] = b2[32 * j];
-            }
-        } else {
-            const float *s1 = (t >= 1 ? xs + (t - 1) * (long)kHop * M : hs) + (long)lane * M;
-            const float *s2 = xs + t * (long)kHop * M + (long)lane * M;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                fr[j] = s1[(long)32 * j * M + ma];
-                fi[j] = s1[(long)32 * j * M + mb];
-                fr[j + 16] = s2[(long)32 * j * M + ma];
-                fi[j + 16] = s2[(long)32 * j * M + mb];
-            }
-        }
-    };
-    if (g0 < g1) request(g0);
-    __syncthreads();  // twiddles
-
-    for (long g = g0; g < g1; ++g) {
-        const int s = (int)(g / groups_per_stream);
-        const long f0 = (g % groups_per_stream) * FPR;
-        // ---- pass 1: window + forward FFT of (frame f0 + fs, pair p) into this half-wavefront's slot -------------------------
-        if (has_pair && f0 + fs < a.n_frames) {
-            double re[32], im[32];
-            const double bs = (2 * p + 1 < M) ? 1.0 : 0.0;
-#pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                re[j] = (double)fr[j] * hwin[j];          // buf[j]*hann_win[i]  (util.h:235)
-                im[j] = (double)fi[j] * (hwin[j] * bs);
-            }
-            fft1024p_fwd_A<double>(re, im, lane, s_tw, slot);
-            __builtin_amdgcn_wave_barrier();
-            fft1024p_B<double>(re, lane, slot);
-            __builtin_amdgcn_wave_barrier();
-            fft1024p_C<double, false>(im, lane, slot);
-            __builtin_amdgcn_wave_barrier();
-            fft1024p_D<double, -1>(re, im, lane, slot);
-            __builtin_amdgcn_wave_barrier();
-            f64x2 *zo = reinterpret_cast<f64x2 *>(slot) + lane;
-#pragma unroll
-            for (int i = 0; i < 32; ++i) zo[32 * brev5(i)] = f64x2{re[i], im[i]};
-        }
-        __syncthreads();
-        if (g + 1 < g1) request(g + 1);  // lands while the per-bin pass runs
-        // ---- pass 2: the per-bin stage of the FPR frames, spectra read back from LDS ----------------------------------------
-        const f64x2 *zs = reinterpret_cast<const f64x2 *>(lds + 2048);
-#pragma unroll
-        for (int n = 0; n < NIT; ++n) {
-            const int f = it_f[n];
-            if (f0 + f >= a.n_frames) continue;
-            const int q = it_q[n], j = q_bin(q);
-            cd X[MP];
-            load_X<MP>(zs + (long)f * NPc * kN, q, M, X);
-            const long o = ((long)s * b.n_frames + f0 + f) * kYhStride + q;
-            if (ALGO == BF_DAS) {
-                const cd y = das_core<MP>(X, st[n], M);
-                st_y(b, o, q, y);
-            } else if (ALGO == BF_PHASE) {
-                const cd y = phase_core<MP>(X, st[n], M, j, b.cfg);
-                st_y(b, o, q, y);
-            } else {  // phasempf mask
-                if (j == 0) {
-                    b.Yh[o] = f64x2{X[0].x, X[0].y};
-                    aux[o] = 0.0;
-                } else {
-                    cd soi;
-                    double int2;
-                    mpf_mask_core<MP>(X, st[n], M, b.cfg, soi, int2);
-                    b.Yh[o] = f64x2{soi.x, soi.y};
-                    aux[o] = int2;
-                }
-            }
-        }
-        if (tid < 2 * FPR && f0 + (tid >> 1) < a.n_frames) {  // bins N/2 and N/2+1 of every frame of the round: X only
-            const int f = tid >> 1, q = kQMain + (tid & 1);
-            cd X[MP];
-            load_X<MP>(zs + (long)f * NPc * kN, q, M, X);
-            f64x2 *xt = xtail + (((long)s * b.n_frames + f0 + f) * 2 + (tid & 1)) * MP;
-#pragma unroll
-            for (int m = 0; m < MP; ++m) xt[m] = f64x2{X[m].x, X[m].y};
-        }
-        __syncthreads();  // the slots are rewritten by the next round
-    }
-}
-
-// The same node on the 64-lane x 16-point transform (fft1024_w64.hpp, w64_f64_dev.hpp) with no block barrier in the loop: a 512-thread
+// The nodes without a frame history need a frame's spectra exactly once, so they never have to reach HBM: a block transforms the
+// microphone pairs of a frame into LDS -- 16 KB of packed pair spectrum per pair -- and then turns to the per-bin arithmetic of that
+// frame, reading the spectra back from LDS through the same load_X / *_core functions the unfused kernels use.  HBM sees the input
+// samples, the per-bin output rows (8 KB per frame) and nothing else: 2.3 GB instead of 11.6 GB per 65 536-frame batch at 8 microphones.
+// (Round 2 / 3 ran this on the 32 x 32 half-wavefront transform with two frames per round between block barriers -- stft_bins_fused_kernel,
+// 1.145 ms for phase against 1.03 for the team kernel below: EXPERIMENTS.md, round 4; removed in round 5.)
+//
+// On the 64-lane x 16-point transform (fft1024_w64.hpp, w64_f64_dev.hpp) with no block barrier in the loop: a 512-thread
 // block is 8 / NPc TEAMS of NPc wavefronts; a team owns one frame at a time -- one full wavefront per microphone pair transforms it into
 // the team's LDS slots (64 data registers per lane instead of 128: two wavefronts per SIMD), a team barrier (LDS counter), the team's
 // threads run the per-bin stage of that frame out of LDS (the code above, bit-identical per bin; the transform's rounding differs from
@@ -1253,21 +1107,12 @@ hipError_t launch_stft_bins_fused(const StftArgs &a, const BinsArgs &b, int n_cu
     if (!(algo == BF_DAS || algo == BF_PHASE || algo == BF_PHASEMPF)) return hipErrorNotSupported;
     if (a.n_mics > 8 || a.n_fft_mics != a.n_mics || b.n_dirs != 1 || a.frame_off != 0 || b.n_streams != a.n_streams)
         return hipErrorNotSupported;
-    const int fpr = a.n_mics <= 4 ? 4 : 2;
-    const long gps = (a.n_frames + fpr - 1) / fpr;
-    const long total = gps * a.n_streams;
-    long blocks = total < n_cus ? total : n_cus;
-    if (blocks < 1) blocks = 1;
-    const long gpb = (total + blocks - 1) / blocks;
-    blocks = (total + gpb - 1) / gpb;
     double *aux = reinterpret_cast<double *>(b.Yh + (long)b.n_streams * b.n_frames * kYhStride);
     f64x2 *xtail = a.Z;  // [stream][frame][2][MP]: the caller sizes the Z workspace for it (fused_tail_elems)
     if (!xtail) return hipErrorInvalidValue;
     const long tail_items = (long)b.n_streams * b.n_frames * 2;
     const unsigned tail_blocks = (unsigned)((tail_items + 255) / 256);
-    // BF_BINS_W64=0: the half-wavefront (32 x 32) version, one wavefront per SIMD
-    static const bool w64_on = !(getenv("BF_BINS_W64") && atoi(getenv("BF_BINS_W64")) == 0);
-    const bool w64 = w64_on && a.tw_w64 != nullptr;
+    if (a.tw_w64 == nullptr) return hipErrorNotSupported;
     const long wtotal = a.n_frames * a.n_streams;  // frames, numbered stream * n_frames + frame; one contiguous range per block
     long wblocks = wtotal < n_cus ? wtotal : n_cus;
     if (wblocks < 1) wblocks = 1;
@@ -1275,12 +1120,7 @@ hipError_t launch_stft_bins_fused(const StftArgs &a, const BinsArgs &b, int n_cu
     wblocks = (wtotal + wfpb - 1) / wfpb;
 #define BF_FUSED_GO(L_, MP_, A_)                                                                                             \
     do {                                                                                                                      \
-        if (w64)                                                                                                              \
-            BF_LAUNCH((stft_bins_w64_kernel<L_, MP_, A_>), dim3((unsigned)wblocks), dim3(512), 0, s, a, b, wfpb, wtotal, aux, \
-                               xtail);                                                                                        \
-        else                                                                                                                  \
-            BF_LAUNCH((stft_bins_fused_kernel<L_, MP_, A_>), dim3((unsigned)blocks), dim3(256), 0, s, a, b, gps, total, gpb, \
-                               aux, xtail);                                                                                   \
+        BF_LAUNCH((stft_bins_w64_kernel<L_, MP_, A_>), dim3((unsigned)wblocks), dim3(512), 0, s, a, b, wfpb, wtotal, aux, xtail);   \
         BF_LAUNCH((fused_tail_kernel<MP_, A_>), dim3(tail_blocks), dim3(256), 0, s, b, (const f64x2 *)xtail, aux);   \
     } while (0)
 #define BF_FUSED_ALGO(L_, MP_)                                   \

@@ -110,7 +110,6 @@ class BinPipelineImpl : public BinPipeline {
         for (int i = 0; i < 2; ++i)
             PIPE_HIP(hipMalloc((void **)&d_steer_[i], steer_bytes()));
         if (das_one_launch_shape()) {
-            for (int i = 0; i < 2; ++i) PIPE_HIP(hipMalloc((void **)&d_dasg_[i], (size_t)4 * 1024 * sizeof(f64x2)));
             for (int i = 0; i < 2; ++i) PIPE_HIP(hipMalloc((void **)&d_dasg_w64_[i], (size_t)4 * 1024 * sizeof(f64x2)));
             for (int i = 0; i < 2; ++i) PIPE_HIP(hipMalloc((void **)&d_dasg_mic_[i], (size_t)8 * kDasMicGainRows * kDasMicGainRow * sizeof(f64x2)));
             PIPE_HIP(hipMalloc(&d_das_sched_, das_f64_sched_ws_bytes()));  // das_f64_pair_kernel's work queue (chunk table + counter)
@@ -168,7 +167,6 @@ class BinPipelineImpl : public BinPipeline {
         if (das_one_launch_shape()) {
             dg = das_pair_gains_t<f64x2>(dirs[0], 4);
             dg64 = das_pair_gains_w64_f64(dg, 4);
-            PIPE_HIP(hipMemcpyAsync(d_dasg_[nxt], dg.data(), dg.size() * sizeof(f64x2), hipMemcpyHostToDevice, stream));
             PIPE_HIP(hipMemcpyAsync(d_dasg_w64_[nxt], dg64.data(), dg64.size() * sizeof(f64x2), hipMemcpyHostToDevice, stream));
             dgm = das_mic_gains_w64_f64(dirs[0], 8);
             PIPE_HIP(hipMemcpyAsync(d_dasg_mic_[nxt], dgm.data(), dgm.size() * sizeof(f64x2), hipMemcpyHostToDevice, stream));
@@ -192,7 +190,6 @@ class BinPipelineImpl : public BinPipeline {
         sn.gss_reset_mask = gss_reset_mask_;
         sn.steer = d_steer_[steer_cur_];
         sn.steer_dir_stride = steer_dir_stride_;
-        sn.das_gains = d_dasg_[steer_cur_];
         sn.das_gains_w64 = d_dasg_w64_[steer_cur_];
         sn.das_gains_mic = d_dasg_mic_[steer_cur_];
         gss_reset_mask_ = 0;
@@ -256,7 +253,7 @@ class BinPipelineImpl : public BinPipeline {
     }
 
     void free_all() {
-        void *ptrs[] = {d_dasg_[0], d_dasg_[1], d_dasg_w64_[0], d_dasg_w64_[1], d_dasg_mic_[0], d_dasg_mic_[1], d_das_sched_, d_tw_w64_, d_tw32_, d_tw_, d_win_, d_freq_, d_steer_[0], d_steer_[1], d_hist2_[0], d_hist2_[1], d_tail_[0], d_tail_[1], d_zhist_,
+        void *ptrs[] = {d_dasg_w64_[0], d_dasg_w64_[1], d_dasg_mic_[0], d_dasg_mic_[1], d_das_sched_, d_tw_w64_, d_tw32_, d_tw_, d_win_, d_freq_, d_steer_[0], d_steer_[1], d_hist2_[0], d_hist2_[1], d_tail_[0], d_tail_[1], d_zhist_,
                         d_gssW_, d_mpf_, d_smooth_, d_nlms_, d_Z_, d_Yh_, d_yraw_, d_frames_};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
@@ -274,7 +271,6 @@ class BinPipelineImpl : public BinPipeline {
     f32x2 *d_tw32_ = nullptr;
     double *d_win_ = nullptr, *d_freq_ = nullptr;
     f64x2 *d_steer_[2] = {nullptr, nullptr};
-    f64x2 *d_dasg_[2] = {nullptr, nullptr};  // das_pair_gains_t<f64x2> of look direction 0 (das_one_launch_shape)
     f64x2 *d_dasg_w64_[2] = {nullptr, nullptr};  // das_pair_gains_w64_f64 of the same
     f64x2 *d_tw_w64_ = nullptr;                  // twiddle_table_w64_rot
     void *d_das_sched_ = nullptr;                // das_f64_pair_kernel: chunk table + counter (das_f64_sched_ws_bytes())
@@ -306,33 +302,28 @@ int BinPipelineImpl::run(const float *x, long F, float *y, f64x2 *spectrum, hipS
 
 int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, hipStream_t stream, int layout,
                              long mic_stride, const RunSnapshot &snap) {
-    // das at the reference's precision on the tuned shape, planar input, no spectrum dump: ONE launch, spectra never leave the CU
-    // (BF_FUSED_BINS=0 / =2 keep the chains below for A/B runs)
+    // das at the reference's precision on the tuned shape, no spectrum dump: ONE launch, spectra never leave the CU (das_f64_w64.hip:
+    // planar input das_f64_pair_kernel, [sample][mic] input das_f64_w64_kernel<1>); BF_FUSED_BINS=0 keeps the chain below (cross-checks)
     static const int fuse_env0 = getenv("BF_FUSED_BINS") ? atoi(getenv("BF_FUSED_BINS")) : 1;
-    static const int w64 = getenv("BF_DAS_F64_W64") ? atoi(getenv("BF_DAS_F64_W64")) : 1;
-    // (interleaved input: the 64-lane kernel only)
-    if (das_one_launch_shape() && fuse_env0 == 1 && spectrum == nullptr && snap.das_gains != nullptr &&
-        (layout == BF_PLANAR || (w64 && snap.das_gains_w64 != nullptr))) {
+    if (das_one_launch_shape() && fuse_env0 == 1 && spectrum == nullptr && snap.das_gains_w64 != nullptr) {
         DasF64Args da;
         da.x = x; da.hist = d_hist2_[hist_cur_]; da.hist_out = d_hist2_[hist_cur_ ^ 1]; da.y = y; da.tail_in = d_tail_[tail_cur_]; da.tail_out = d_tail_[tail_cur_ ^ 1];
-        da.gains = snap.das_gains; da.tw = d_tw_; da.win = d_win_; da.n_frames = F; da.mic_stride = mic_stride;
+        da.win = d_win_; da.n_frames = F; da.mic_stride = mic_stride;
         da.stream_stride_x = (long)M_ * F * H_; da.n_streams = S_; da.n_mics = M_; da.run_len = 1;
-        // BF_DAS_F64_W64=0: the 32 x 32 half-wavefront kernel (das_f64_fused_kernel) instead of the 64-lane one
         da.layout = layout;
-        if (w64 && snap.das_gains_w64 != nullptr) { da.gains = snap.das_gains_w64; da.gains_mic = snap.das_gains_mic; da.tw = d_tw_w64_; }
+        da.gains = snap.das_gains_w64; da.gains_mic = snap.das_gains_mic; da.tw = d_tw_w64_;
         da.sched_ws = d_das_sched_; da.sched_ws_bytes = d_das_sched_ ? das_f64_sched_ws_bytes() : 0;
-        const bool use_w64 = w64 && snap.das_gains_w64 != nullptr;
-        hipError_t de = use_w64 ? prepare_das_f64_w64(da, n_cus_, stream) : hipSuccess;
+        hipError_t de = prepare_das_f64_w64(da, n_cus_, stream);
         if (de == hipSuccess) {
             if (kev0) PIPE_HIP(hipEventRecord(kev0, stream));
-            de = use_w64 ? launch_das_f64_w64(da, n_cus_, stream) : ks_->das_f64(da, n_cus_, stream);
+            de = launch_das_f64_w64(da, n_cus_, stream);
             if (kev1 && de == hipSuccess) {
                 PIPE_HIP(hipEventRecord(kev1, stream));
                 kev_recorded = true;
             }
         }
         if (de == hipSuccess) {  // ring-buffer carry (util.h:305-308)
-            if (use_w64 && das_f64_writes_hist(da)) {
+            if (das_f64_writes_hist(da)) {
                 hist_cur_ ^= 1;  // das_f64_pair_kernel stored the last hop into the other buffer
             } else if (layout == BF_PLANAR)
                 PIPE_HIP(hipMemcpy2DAsync(d_hist2_[hist_cur_], H_ * sizeof(float), x + (F - 1) * H_, (size_t)mic_stride * sizeof(float),
@@ -350,8 +341,7 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     const long FT = Phist_ + F;  // frames in the Z workspace per stream
     // nodes without a frame history: STFT and per-bin stage in one launch, spectra never leave the CU (launch_stft_bins_fused;
     // BF_FUSED_BINS=0 selects the two-kernel chain) -- then the Z workspace (64 KB per frame at 8 microphones) is not needed at all
-    static const int fuse_env = getenv("BF_FUSED_BINS") ? atoi(getenv("BF_FUSED_BINS")) : 1;
-    const bool try_fused = fuse_env != 0 && Phist_ == 0 && N_ <= 2048 && M_ <= 8 && MF_ == M_ && D_ == 1 &&  // (N = 128 / 256 / 512: stft_bins_small_kernel, 2048: stft_bins_split_kernel)
+    const bool try_fused = fuse_env0 != 0 && Phist_ == 0 && N_ <= 2048 && M_ <= 8 && MF_ == M_ && D_ == 1 &&  // (N = 128 / 256 / 512: stft_bins_small_kernel, 2048: stft_bins_split_kernel)
                            (cfg_.algo == BF_DAS || cfg_.algo == BF_PHASE || cfg_.algo == BF_PHASEMPF);
     int rc = BF_OK;
     if (!try_fused)

@@ -23,7 +23,6 @@ struct RunSnapshot {
     unsigned long long gss_reset_mask = 0;
     const f64x2 *steer = nullptr;
     long steer_dir_stride = 0;
-    const f64x2 *das_gains = nullptr;  // das fp64, one launch: pair gains of this batch's look direction (pipeline_kernels.hpp DasF64Args)
     const f64x2 *das_gains_mic = nullptr;  // per-microphone Hermitian gains of the frame-pair kernel (das_f64_pair_kernel)
     const f64x2 *das_gains_w64 = nullptr;  // the same gains in the register / lane order of the 64-lane kernel (das_f64_w64.hip)
 };

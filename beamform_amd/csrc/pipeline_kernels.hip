@@ -32,7 +32,7 @@ hipError_t launch_bins(const BinsArgs &a, int n_cus, hipStream_t s) {
 const KernelSet *BF_CAT2(kernel_set_n, BF_NFFT)() {
     static const KernelSet ks = {BF_NFFT, &BF_NTAG::launch_stft, &BF_NTAG::launch_bins, &BF_NTAG::launch_stft_bins_fused,
                                  &BF_NTAG::launch_istft,
-                                 &BF_NTAG::launch_smooth, &BF_NTAG::launch_gsc_nlms, &BF_NTAG::launch_das_f64_fused};
+                                 &BF_NTAG::launch_smooth, &BF_NTAG::launch_gsc_nlms};
     return &ks;
 }
 

@@ -99,15 +99,14 @@ struct IstftArgs {
     double post_amp;
     int use_post_amp;
 };
-// das at the reference's precision in ONE launch (N = 1024, planar, <= 8 microphones, one look direction, no spectrum dump):
-// the fused fp32 kernel's formulation -- Re IFFT(sum_p D_p Z_p), D_p from das_pair_gains -- in double
+// das at the reference's precision in ONE launch (N = 1024, <= 8 microphones, one look direction, no spectrum dump): das_f64_w64.hip
 struct DasF64Args {
     const float *x;
     const float *hist;     // hop before frame 0 [stream][mic][hop]
     float *y;              // [stream][n_frames*hop]
     const float *tail_in;  // [stream][hop]
     float *tail_out;
-    const f64x2 *gains;    // [pair][pos][lane] = D_p[lane + 32*brev5(pos)], 1/N folded in (das_pair_gains<f64x2>)
+    const f64x2 *gains;    // das_pair_gains_w64_f64: Hermitian-part pair gains in the 64-lane kernel's register / lane order, 1/N folded in
     const f64x2 *tw;
     const double *win;
     long n_frames, mic_stride, stream_stride_x;
@@ -129,7 +128,6 @@ bool das_f64_writes_hist(const DasF64Args &a);  // the kernel launch_das_f64_w64
 
 #ifdef BF_NFFT
 namespace BF_NTAG {
-hipError_t launch_das_f64_fused(const DasF64Args &a, int n_cus, hipStream_t s);  // hipErrorNotSupported outside N = 1024
 hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s);
 hipError_t launch_bins(const BinsArgs &a, int n_cus, hipStream_t s);
 // stft + per-bin stage in one launch for the nodes without a frame history (das fp64, phase, phasempf; N = 1024, <= 8 mics,
@@ -164,7 +162,6 @@ struct KernelSet {
     hipError_t (*istft)(const IstftArgs &, int, hipStream_t);
     hipError_t (*smooth)(const float *, float *, double *, long, int, int, hipStream_t);
     hipError_t (*gsc_nlms)(const float *, float *, float *, long, int, int, const bf_config &, hipStream_t);
-    hipError_t (*das_f64)(const DasF64Args &, int, hipStream_t);
 };
 const KernelSet *kernel_set_n128();
 const KernelSet *kernel_set_n256();

@@ -138,304 +138,6 @@ __global__ __launch_bounds__(256) void stft_kernel(StftArgs a) {
     }
 }
 
-// The same transform on the 64-lane x 16-point factorisation (fft1024_w64.hpp, w64_f64_dev.hpp): one full wavefront per (stream,
-// microphone pair, run), 64 data registers per lane, so a 512-thread block runs TWO wavefronts per SIMD and covers its own load and
-// LDS latencies.  Runs are short (32 frames) and the eight wavefronts of a block take them from an LDS counter: the two wavefronts of
-// a SIMD do not share it evenly (das_f64_w64.hip), the faster one simply takes more runs.  First-pass lane = sample: every load is one
-// contiguous 256-byte row; register 4 g + k3 of lane l is bin l + 64 g + 256 k3: every store is one contiguous row of 64 bins.
-// LDS: 17 KB twiddles + 8 x 8.1 KB exchange planes + 9 KB window rows.
-template <int LAYOUT, bool Z48>
-__global__ __launch_bounds__(512) void stft_w64_kernel(StftArgs a, long items_per_block) {
-    constexpr int kTwD = 2 * (1024 + 4 * kTw2RowW64Rot);
-    constexpr int kWinRow = 18;
-    constexpr int oPlane = kTwD, oWin = oPlane + 8 * kPlaneD, oCnt = oWin + 64 * kWinRow;
-    __shared__ __attribute__((aligned(16))) double lds[oCnt + 2];
-    const cx<double> *s_tw1 = reinterpret_cast<const cx<double> *>(lds);
-    const cx<double> *s_tw2 = s_tw1 + 1024;
-    typedef volatile __attribute__((address_space(3))) int *lds_cnt_t;
-    lds_cnt_t s_next = (lds_cnt_t)(lds + oCnt);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double *plane = lds + oPlane + w * kPlaneD;
-    double *wcol = plane + w64_col_rot(lane);
-    double *row16 = plane + (lane & 15) * kRS + 16 * (lane >> 4);
-    const double *wrow = lds + oWin + lane * kWinRow;  // window[64 j + lane], j = 0..15 (halved for z48: the spectra are stored halved, exact)
-    {
-        const f64x2 *tw2 = a.tw_w64;
-        f64x2 *ltw = reinterpret_cast<f64x2 *>(lds);
-        for (int i = tid; i < kTwD / 2; i += 512) ltw[i] = tw2[i];
-        for (int i = tid; i < kN; i += 512) lds[oWin + (i & 63) * kWinRow + (i >> 6)] = a.win[i] * (Z48 ? 0.5 : 1.0);
-        if (tid == 0) *s_next = 8;  // the first eight runs are handed out statically
-    }
-    __syncthreads();
-    const int M = a.n_mics, MF = a.n_fft_mics, NP = (MF + 1) >> 1, L = a.run_len;
-    const long runs = (a.n_frames + L - 1) / L;
-    const long total = (long)a.n_streams * runs * NP;
-    const long i0 = (long)blockIdx.x * items_per_block;
-    long i1 = i0 + items_per_block;
-    if (i1 > total) i1 = total;
-    const int n_local = (int)(i1 - i0);
-    for (int li = w; li < n_local;) {  // wavefront-uniform; no block barrier below
-        const long item = i0 + li;
-        const int p = (int)(item % NP);
-        const long sr = item / NP;
-        const long run = sr % runs;
-        const int s = (int)(sr / runs);
-        const long t0 = run * L;
-        const float *xs = a.x + (long)s * a.stream_stride_x;
-        const float *hs = a.hist + (long)s * M * kHop;
-        const int ma = 2 * p;
-        const bool b_ok = 2 * p + 1 < MF;
-        const int mb = b_ok ? 2 * p + 1 : ma;
-        // hop h of this pair (h = -1: the carried hop in front of the batch) as raw samples: register j <- sample 64 j + lane
-        auto load_hop = [&](long h, float (&va)[8], float (&vb)[8]) {
-            if (LAYOUT == 0) {
-                const float *pa = h >= 0 ? xs + (long)ma * a.mic_stride + h * kHop : hs + ma * kHop;
-                const float *pb = h >= 0 ? xs + (long)mb * a.mic_stride + h * kHop : hs + mb * kHop;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    va[j] = pa[(unsigned)(64 * j + lane)];
-                    vb[j] = pb[(unsigned)(64 * j + lane)];
-                }
-            } else {
-                const float *ps = h >= 0 ? xs + h * (long)kHop * M : hs;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    va[j] = ps[(unsigned)((64 * j + lane) * M + ma)];
-                    vb[j] = ps[(unsigned)((64 * j + lane) * M + mb)];
-                }
-            }
-        };
-        float pa[8], pb[8], ca[8], cb[8], na[8], nb[8];
-        load_hop(t0 - 1, pa, pb);
-        load_hop(t0, ca, cb);
-        long te = t0 + L;
-        if (te > a.n_frames) te = a.n_frames;
-        for (long t = t0; t < te; ++t) {
-            {  // next hop: in flight during this frame's transform
-                long tn = t + 1;
-                if (tn >= a.n_frames) tn = a.n_frames - 1;
-                load_hop(tn, na, nb);
-            }
-            double re[16], im[16];
-            // buf[j]*hann_win[i] (util.h:235) and the first butterfly stage of the transform in one (das_f64_w64.hip)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const double w0 = wrow[j], w1 = wrow[j + 8];
-                const double t0w = (double)pa[j] * w0, u = (double)ca[j];
-                re[j] = fma(u, w1, t0w);
-                re[j + 8] = fma(-u, w1, t0w);
-            }
-            if (b_ok) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const double w0 = wrow[j], w1 = wrow[j + 8];
-                    const double t0w = (double)pb[j] * w0, u = (double)cb[j];
-                    im[j] = fma(u, w1, t0w);
-                    im[j + 8] = fma(-u, w1, t0w);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) im[j] = 0.0;
-            }
-            cx<double> tw[15];
-            BF_STAGE();
-            load_tw1<1, 9>(tw, s_tw1, lane);
-            BF_STAGE();
-            fft16_core<double, -1, true, 1>(re, im);  // stage 0 is done
-            BF_STAGE();
-            load_tw1<9, 16>(tw, s_tw1, lane);
-            BF_STAGE();
-            mul_tw<false, 1, 9>(re, im, tw);
-            BF_STAGE();
-            mul_tw<false, 9, 16>(re, im, tw);
-            BF_STAGE();
-            T1_fwd(re, im, wcol, row16);
-            load_tw2<1, 9>(tw, s_tw2, lane);
-            BF_STAGE();
-            fft16_core<double, -1, true>(re, im);
-            BF_STAGE();
-            load_tw2<9, 16>(tw, s_tw2, lane);
-            BF_STAGE();
-            mul_tw<false, 1, 9>(re, im, tw);
-            BF_STAGE();
-            mul_tw<false, 9, 16>(re, im, tw);
-            BF_STAGE();
-            w64_T2<true>(re, im);
-            w64_fwd_p3<double>(re, im);
-            const long zoff = (((long)s * a.frames_ws + a.frame_off + t) * NP + p) * kN + lane;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 64 * (r >> 2) + 256 * (r & 3);  // bins row .. row + 63 of this store
-                if (row > a.skip_lo && row + 63 < a.skip_hi) continue;  // band-limited nodes never read these bins
-                if (Z48)
-                    reinterpret_cast<z48 *>(a.Z)[zoff + row] = enc48(re[r], im[r]);
-                else
-                    a.Z[zoff + row] = f64x2{re[r], im[r]};
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                pa[j] = ca[j];
-                pb[j] = cb[j];
-                ca[j] = na[j];
-                cb[j] = nb[j];
-            }
-        }
-        int nx = 0;
-        if (lane == 0) nx = __hip_atomic_fetch_add((__attribute__((address_space(3))) int *)s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        li = __builtin_amdgcn_readfirstlane(nx);
-    }
-}
-
-// ======================================================================================
-//                     das at the reference's precision, one launch
-// ======================================================================================
-// The fused fp32 kernel's formulation in double: per frame four packed forward transforms, S += D_p Z_p with the pair gains
-// D_p = ce_a - i ce_b (geometry.hpp das_pair_gains_t: the Hermitian part of the reference's own weights, so the non-conjugate
-// quirk-Q1 bins are exact and no mirror access exists), one backward transform, (float)(Re / N) [1/N folded into D: a power of
-// two], float x double window, float overlap-add (das.cpp:47-70, util.h:217-253,301-302).  Spectra never leave the CU: HBM sees
-// the input and the output (the three-kernel chain moved 2.40 GB per 65 536 frames, 1.98 x algorithmic).
-// A half-wavefront owns (stream, run of frames) and walks the run with the overlap-add tail in registers; the first frame of a
-// run is recomputed for its tail (runs start from the carried state at frame 0).  One 256-thread block per CU: 16 KB twiddles
-// + 8 x 8.5 KB transpose planes + 64 KB of pair gains = 148 KB of LDS, one wavefront per SIMD with 512 registers: the raw
-// samples of the next pair are requested before the current pair is transformed.
-__global__ __launch_bounds__(256) void das_f64_fused_kernel(DasF64Args a) {
-    constexpr int kBlock = 256, kHalves = kBlock / 32;
-    constexpr int kWinRow = 34;  // window as [lane][j] rows in LDS (as stft_kernel): 64 registers less beside 128 of data and 128 of accumulator
-    __shared__ __attribute__((aligned(16))) double lds[2048 + kHalves * 32 * kPSd + 4 * 2048 + 32 * kWinRow];
-    const cx<double> *s_tw = reinterpret_cast<const cx<double> *>(lds);
-    const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
-    double *pbuf = lds + 2048 + hw * 32 * kPSd;
-    const f64x2 *s_gain = reinterpret_cast<const f64x2 *>(lds + 2048 + kHalves * 32 * kPSd);
-    double *s_win = lds + 2048 + kHalves * 32 * kPSd + 4 * 2048;
-    const int M = a.n_mics, NP = (M + 1) >> 1;
-    {
-        const double *twf = reinterpret_cast<const double *>(a.tw), *gf = reinterpret_cast<const double *>(a.gains);
-        for (int i = tid; i < 2048; i += kBlock) lds[i] = twf[i];
-        double *lg = lds + 2048 + kHalves * 32 * kPSd;
-        for (int i = tid; i < NP * 2048; i += kBlock) lg[i] = gf[i];
-        for (int i = tid; i < kN; i += kBlock) s_win[(i & 31) * kWinRow + (i >> 5)] = a.win[i];
-        __syncthreads();
-    }
-    const f64x2 *wrow = reinterpret_cast<const f64x2 *>(s_win + lane * kWinRow);
-    const int L = a.run_len;
-    const long runs = (a.n_frames + L - 1) / L;
-    const long total = (long)a.n_streams * runs;
-    const long stride = (long)gridDim.x * kHalves;
-    const long rounds = (total + stride - 1) / stride;
-    for (long r = 0; r < rounds; ++r) {
-        long item = r * stride + (long)blockIdx.x * kHalves + hw;
-        const bool ok = item < total;
-        if (!ok) item = total - 1;
-        const long run = item % runs;
-        const int s = (int)(item / runs);
-        const long t0 = run * L;
-        const float *xs = a.x + (long)s * a.stream_stride_x;
-        const float *hs = a.hist + (long)s * M * kHop;
-        float *ys = a.y + (long)s * a.n_frames * kHop;
-        // raw samples of pair p of frame t (hop t-1 | hop t; hop -1 = the carried hop), lane l <- sample 32 j + l
-        auto load_pair = [&](long t, int p, float (&va)[32], float (&vb)[32]) {
-            const int ma = 2 * p, mb = (2 * p + 1 < M) ? 2 * p + 1 : ma;
-            const float *a1 = (t >= 1 ? xs + (long)ma * a.mic_stride + (t - 1) * kHop : hs + ma * kHop) + lane;
-            const float *b1 = (t >= 1 ? xs + (long)mb * a.mic_stride + (t - 1) * kHop : hs + mb * kHop) + lane;
-            const float *a2 = xs + (long)ma * a.mic_stride + t * kHop + lane;
-            const float *b2 = xs + (long)mb * a.mic_stride + t * kHop + lane;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                va[j] = a1[32 * j];
-                vb[j] = b1[32 * j];
-                va[j + 16] = a2[32 * j];
-                vb[j + 16] = b2[32 * j];
-            }
-        };
-        float tail[16];  // second half of the previous frame, as the reference keeps it: float (out_buff[0], util.h:302)
-        if (t0 == 0) {
-            const float *ti = a.tail_in + (long)s * kHop + lane;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) tail[q] = ti[32 * brev5(2 * q)];
-        }
-        const long tb = t0 == 0 ? 0 : t0 - 1;  // t0 - 1: warm-up frame, only its second half is used
-        long te = t0 + L;
-        if (te > a.n_frames) te = a.n_frames;
-        float na[32], nb[32];
-        load_pair(tb, 0, na, nb);
-        for (long t = tb; t < te; ++t) {
-            double Sr[32], Si[32];
-            for (int p = 0; p < NP; ++p) {
-                double re[32], im[32];
-                const double bs = (2 * p + 1 < M) ? 1.0 : 0.0;
-#pragma unroll
-                for (int j = 0; j < 32; j += 2) {
-                    const f64x2 w = wrow[j >> 1];
-                    re[j] = (double)na[j] * w.x;  // buf[j]*hann_win[i]  (util.h:235)
-                    im[j] = (double)nb[j] * (w.x * bs);
-                    re[j + 1] = (double)na[j + 1] * w.y;
-                    im[j + 1] = (double)nb[j + 1] * (w.y * bs);
-                }
-                {  // next pair (or the next frame's first one): in flight during this transform
-                    long tn = t;
-                    int pn = p + 1;
-                    if (pn == NP) {
-                        pn = 0;
-                        tn = t + 1 < te ? t + 1 : t;
-                    }
-                    load_pair(tn, pn, na, nb);
-                }
-                fft1024p_fwd_A<double>(re, im, lane, s_tw, pbuf);
-                __builtin_amdgcn_wave_barrier();
-                fft1024p_B<double>(re, lane, pbuf);
-                __builtin_amdgcn_wave_barrier();
-                fft1024p_C<double, false>(im, lane, pbuf);
-                __builtin_amdgcn_wave_barrier();
-                fft1024p_D<double, -1>(re, im, lane, pbuf);
-                __builtin_amdgcn_wave_barrier();
-                const f64x2 *gp = s_gain + p * 1024 + lane;
-#pragma unroll
-                for (int i = 0; i < 32; ++i) {
-                    const f64x2 g = gp[32 * i];
-                    const double sr = p == 0 ? 0.0 : Sr[i], si = p == 0 ? 0.0 : Si[i];
-                    Sr[i] = fma(-g.y, im[i], fma(g.x, re[i], sr));
-                    Si[i] = fma(g.y, re[i], fma(g.x, im[i], si));
-                }
-            }
-            fft1024p_inv_A<double>(Sr, Si, lane, s_tw, pbuf);
-            __builtin_amdgcn_wave_barrier();
-            fft1024p_B<double>(Sr, lane, pbuf);
-            __builtin_amdgcn_wave_barrier();
-            fft1024p_C<double, true>(Si, lane, pbuf);
-            __builtin_amdgcn_wave_barrier();
-            fft1024p_D<double, +1>(Sr, Si, lane, pbuf);
-            __builtin_amdgcn_wave_barrier();
-            // position i: sample n = 32*brev5(i) + lane (even i: first half, odd i: second half); util.h:247-252 with the float stores
-            float o[32];
-            double win[32];
-#pragma unroll
-            for (int j = 0; j < 32; j += 2) {
-                const f64x2 w = wrow[j >> 1];
-                win[j] = w.x;
-                win[j + 1] = w.y;
-            }
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const float f = (float)Sr[i];                 // (float)(Re / N): 1/N is inside the gains
-                o[i] = (float)((double)f * win[brev5(i)]);    // o *= hann_win[n]: sample 32*brev5(i) + lane <-> win[brev5(i)]
-            }
-            if (ok && t >= t0) {
-                float *yo = ys + t * kHop + lane;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) yo[32 * brev5(2 * q)] = tail[q] + o[2 * q];
-                if (t == a.n_frames - 1) {
-                    float *to = a.tail_out + (long)s * kHop + lane;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) to[32 * brev5(2 * q)] = o[2 * q + 1];
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) tail[q] = o[2 * q + 1];
-        }
-    }
-}
-
 // ======================================================================================
 //                                        ISTFT
 // ======================================================================================
@@ -990,124 +692,6 @@ __global__ __launch_bounds__(256) void stft_small_kernel(StftArgs a) {
 }
 #endif
 
-#if BF_NFFT == 2048
-// ---- N = 2048 as two register-resident FFT-1024 and one radix-2 decimation-in-time step behind them ------------------------------------
-//   E = FFT1024(even samples of the windowed frame), O = FFT1024(odd samples):  X[k] = E[k] + W2048^k O[k],  X[k + 1024] = E[k] - W2048^k O[k]
-// both on fft1024.hpp's 32 x 32 machinery, a half-wavefront per (stream, microphone pair, run of frames).  A lane loads the even and the odd
-// sample of an index pair together (planar input: one 8-byte load, a fully used 256-byte row per instruction) and every store writes 32
-// consecutive bins.  E waits in registers while O is transformed (one wavefront per SIMD: the accumulator file takes the overflow).
-// The generic kernel above: 2.85 ms per 32 768 frames of 8 microphones; the decimation-in-frequency variant of this kernel (even / odd bins from
-// two passes over contiguous halves, stores of 16 bytes at a 32-byte stride): 1.59 ms with z48 spectra, 2.62 ms with c128.
-template <int LAYOUT, bool Z48>
-__global__ __launch_bounds__(256) void stft_split_kernel(StftArgs a) {
-    constexpr int kBlock = 256, kHalves = kBlock / 32, kWinRow = 66;
-    __shared__ __attribute__((aligned(16))) double lds[2048 + 2048 + kHalves * 32 * kPSd + 32 * kWinRow];
-    cx<double> *s_tw = reinterpret_cast<cx<double> *>(lds);         // [k1][n2] = W1024^(k1 n2)
-    cx<double> *s_w2 = reinterpret_cast<cx<double> *>(lds + 2048);  // [k] = W2048^k, k < 1024
-    const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
-    double *pbuf = lds + 4096 + hw * 32 * kPSd;
-    double *s_win = lds + 4096 + kHalves * 32 * kPSd;  // [lane][2 j + q] = win[2 (32 j + lane) + q], j < 32
-    {
-        for (int i = tid; i < 1024; i += kBlock) {
-            const int m = (2 * (i >> 5) * (i & 31)) % kN;  // W1024^(k1 n2) = W2048^(2 k1 n2); a.tw[m] = W2048^m for m < 1024, W^(m + 1024) = -W^m
-            const f64x2 w = a.tw[m % 1024];
-            s_tw[i] = m < 1024 ? cx<double>{w.x, w.y} : cx<double>{-w.x, -w.y};
-            const f64x2 v = a.tw[i];
-            s_w2[i] = cx<double>{v.x, v.y};
-        }
-        for (int i = tid; i < kN; i += kBlock) {
-            const int m = i >> 1;
-            s_win[(m & 31) * kWinRow + 2 * (m >> 5) + (i & 1)] = a.win[i] * (Z48 ? 0.5 : 1.0);  // z48 spectra are stored halved (exact)
-        }
-        __syncthreads();
-    }
-    const f64x2 *wrow = reinterpret_cast<const f64x2 *>(s_win + lane * kWinRow);
-    const int M = a.n_mics, MF = a.n_fft_mics, NP = (MF + 1) >> 1, L = a.run_len;
-    const long runs = (a.n_frames + L - 1) / L;
-    const long total = (long)a.n_streams * runs * NP;
-    const long stride = (long)gridDim.x * kHalves;
-    for (long item = (long)blockIdx.x * kHalves + hw; item < total; item += stride) {  // no block barrier below
-        const int p = (int)(item % NP);
-        const long sr = item / NP;
-        const long run = sr % runs;
-        const int s = (int)(sr / runs);
-        const float *xs = a.x + (long)s * a.stream_stride_x;
-        const float *hs = a.hist + (long)s * M * kHop;
-        const int ma = 2 * p;
-        const bool b_ok = 2 * p + 1 < MF;
-        const int mb = b_ok ? 2 * p + 1 : ma;
-        const double bs = b_ok ? 1.0 : 0.0;
-        long te = (run + 1) * L;
-        if (te > a.n_frames) te = a.n_frames;
-        for (long t = run * L; t < te; ++t) {
-            // register j <-> index pair m = 32 j + lane: samples 2 m (E) and 2 m + 1 (O) of the frame; j < 16: the hop before hop t (t = 0: the
-            // carried hop).  Both passes fetch the pair (the second time from L1 / L2): holding the odd samples across the first transform spills.
-            auto load_half = [&](int odd, double (&vr)[32], double (&vi)[32]) {
-                if (LAYOUT == 0) {
-                    const float2 *pa = reinterpret_cast<const float2 *>(t >= 1 ? xs + (long)ma * a.mic_stride + (t - 1) * kHop : hs + ma * kHop) + lane;
-                    const float2 *pb = reinterpret_cast<const float2 *>(t >= 1 ? xs + (long)mb * a.mic_stride + (t - 1) * kHop : hs + mb * kHop) + lane;
-                    const float2 *ca = reinterpret_cast<const float2 *>(xs + (long)ma * a.mic_stride + t * kHop) + lane;
-                    const float2 *cb = reinterpret_cast<const float2 *>(xs + (long)mb * a.mic_stride + t * kHop) + lane;
-#pragma unroll
-                    for (int j = 0; j < 32; ++j) {
-                        const float2 va = j < 16 ? pa[32 * j] : ca[32 * (j - 16)], vb = j < 16 ? pb[32 * j] : cb[32 * (j - 16)];
-                        const f64x2 w2 = wrow[j];
-                        const double w = odd ? w2.y : w2.x;
-                        vr[j] = (double)(odd ? va.y : va.x) * w;  // buf[j]*hann_win[i]  (util.h:235)
-                        vi[j] = (double)(odd ? vb.y : vb.x) * (w * bs);
-                    }
-                } else {
-                    const float *ps = (t >= 1 ? xs + (t - 1) * (long)kHop * M : hs) + (long)(2 * lane + odd) * M;
-                    const float *cs = xs + t * (long)kHop * M + (long)(2 * lane + odd) * M;
-#pragma unroll
-                    for (int j = 0; j < 32; ++j) {
-                        const float *q = j < 16 ? ps + (long)64 * j * M : cs + (long)64 * (j - 16) * M;
-                        const f64x2 w2 = wrow[j];
-                        const double w = odd ? w2.y : w2.x;
-                        vr[j] = (double)q[ma] * w;
-                        vi[j] = (double)q[mb] * (w * bs);
-                    }
-                }
-            };
-            auto fwd = [&](double (&vr)[32], double (&vi)[32]) {
-                fft1024p_fwd_A<double>(vr, vi, lane, s_tw, pbuf);
-                __builtin_amdgcn_wave_barrier();
-                fft1024p_B<double>(vr, lane, pbuf);
-                __builtin_amdgcn_wave_barrier();
-                fft1024p_C<double, false>(vi, lane, pbuf);
-                __builtin_amdgcn_wave_barrier();
-                fft1024p_D<double, -1>(vr, vi, lane, pbuf);
-                __builtin_amdgcn_wave_barrier();
-            };
-            double er[32], ei[32], re[32], im[32];
-            load_half(0, er, ei);
-            fwd(er, ei);
-            __builtin_amdgcn_sched_barrier(0);  // keeps the second pass' 64 loads from being hoisted over the first transform
-            load_half(1, re, im);
-            fwd(re, im);
-            __builtin_amdgcn_sched_barrier(0);
-            // position i of lane k1: E[k], O[k] at k = k1 + 32 brev5(i)
-            const long zoff = (((long)s * a.frames_ws + a.frame_off + t) * NP + p) * kN + lane;
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const int row = 32 * brev5(i);  // bins row .. row + 31 and the same + 1024 of these two stores
-                const bool lo_skip = row > a.skip_lo && row + 31 < a.skip_hi, hi_skip = row + 1024 > a.skip_lo && row + 1024 + 31 < a.skip_hi;
-                if (lo_skip && hi_skip) continue;  // band-limited nodes never read these bins
-                const cx<double> w = s_w2[row + lane];
-                const double tr = re[i] * w.x - im[i] * w.y, ti = re[i] * w.y + im[i] * w.x;
-                if (!lo_skip) {
-                    if (Z48) reinterpret_cast<z48 *>(a.Z)[zoff + row] = enc48(er[i] + tr, ei[i] + ti);
-                    else a.Z[zoff + row] = f64x2{er[i] + tr, ei[i] + ti};
-                }
-                if (!hi_skip) {
-                    if (Z48) reinterpret_cast<z48 *>(a.Z)[zoff + row + 1024] = enc48(er[i] - tr, ei[i] - ti);
-                    else a.Z[zoff + row + 1024] = f64x2{er[i] - tr, ei[i] - ti};
-                }
-            }
-        }
-    }
-}
-#endif
 
 // Hermitian part of y_fft at bin k (0..N-1) from the per-bin kernels' output row.
 __device__ __forceinline__ cd herm_gen(const f64x2 *row, int k) {
@@ -1400,7 +984,7 @@ __global__ __launch_bounds__(256) void stft_wave2048_kernel(StftArgs a) {
 #endif
 
 #if BF_NFFT == 2048
-// ---- backward side of stft_split_kernel: ONE FFT-1024 per frame ------------------------------------------------------------------------------
+// ---- backward side at N = 2048: ONE FFT-1024 per frame ------------------------------------------------------------------------------
 // y real: its even samples have the spectrum A[k] = Y[k] + Y[k + 1024], its odd samples B[k] = (Y[k] - Y[k + 1024]) conj(W2048^k) (one radix-2
 // decimation-in-frequency step of the backward transform), both Hermitian over 1024 bins -- so IFFT1024(A + i B) = y_even + i y_odd: one complex
 // transform on fft1024.hpp's machinery returns the whole frame, sample pair (2 m, 2 m + 1) in (re, im) of one register.  Window, the reference's
@@ -1588,47 +1172,8 @@ __global__ void smooth_state_kernel(const float *yraw, double *state, long n, in
 }  // namespace
 
 #if BF_NFFT == 1024
-hipError_t launch_das_f64_fused(const DasF64Args &a, int n_cus, hipStream_t s) {
-    if (a.n_mics > 8) return hipErrorNotSupported;  // the four pair-gain tables fill the LDS
-    DasF64Args b = a;
-    const long slots = (long)n_cus * 8;  // one run per half-wavefront slot: a run recomputes its first frame (1 / 2 / 4 runs: 0.790 / 0.817 / 0.868 ms)
-    long L = ((long)a.n_streams * a.n_frames + slots - 1) / slots;
-    if (L < 1) L = 1;
-    if (L > 512) L = 512;
-    b.run_len = (int)L;
-    const long total = (long)a.n_streams * ((a.n_frames + L - 1) / L);
-    long blocks = (total + 7) / 8;
-    if (blocks > n_cus) blocks = n_cus;
-    BF_LAUNCH(das_f64_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, s, b);
-    return hipGetLastError();
-}
-
 hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
     const long np = (a.n_fft_mics + 1) / 2;
-#if BF_NFFT == 1024
-    // BF_STFT_W64=1: the 64-lane kernel (two wavefronts per SIMD, runs handed out dynamically).  Off by default: the STFT in front of
-    // mvdr / lcmv / gss moves 3.3 GB at 5 TB/s either way (0.62-0.74 ms against 0.67 for the half-wavefront kernel, box to box)
-    static const bool w64_on = getenv("BF_STFT_W64") && atoi(getenv("BF_STFT_W64")) == 1;
-    if (w64_on && a.tw_w64 != nullptr) {
-        StftArgs b = a;
-        static const long L_env = getenv("BF_STFT_W64_L") ? atol(getenv("BF_STFT_W64_L")) : 32;
-        long L = L_env;  // a run re-reads its leading hop: 3 % of the input; short runs level the eight wavefronts of a block
-        if (L > a.n_frames) L = a.n_frames;
-        b.run_len = (int)L;
-        const long total = (long)a.n_streams * ((a.n_frames + L - 1) / L) * np;
-        long blocks = total < n_cus ? total : n_cus;
-        const long ipb = (total + blocks - 1) / blocks;
-        blocks = (total + ipb - 1) / ipb;
-        if (a.layout == 0) {
-            if (a.z48) BF_LAUNCH((stft_w64_kernel<0, true>), dim3((unsigned)blocks), dim3(512), 0, s, b, ipb);
-            else BF_LAUNCH((stft_w64_kernel<0, false>), dim3((unsigned)blocks), dim3(512), 0, s, b, ipb);
-        } else {
-            if (a.z48) BF_LAUNCH((stft_w64_kernel<1, true>), dim3((unsigned)blocks), dim3(512), 0, s, b, ipb);
-            else BF_LAUNCH((stft_w64_kernel<1, false>), dim3((unsigned)blocks), dim3(512), 0, s, b, ipb);
-        }
-        return hipGetLastError();
-    }
-#endif
     // 256 threads, twiddles in LDS: a 512-thread block spills (44 VGPRs) and twiddles read from global memory cost 40 % (measured)
     constexpr int nb = 256, halves = nb / 32;
     // frames per run: one run per half-wavefront slot (one block per CU) when the batch is long enough -- the first frame of a
@@ -1683,8 +1228,6 @@ hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s) {
 }
 
 #else
-hipError_t launch_das_f64_fused(const DasF64Args &, int, hipStream_t) { return hipErrorNotSupported; }
-
 hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
 #if BF_NFFT == 128 || BF_NFFT == 256 || BF_NFFT == 512
     // the in-register kernel (BF_STFT_SMALL=0: the generic one, for A/B runs)
@@ -1713,11 +1256,9 @@ hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
     }
 #endif
 #if BF_NFFT == 2048
-    // one 2048-point transform per full wavefront (BF_STFT_SPLIT=2: two register-resident FFT-1024 per frame and a radix-2 step; =0: the generic
-    // kernel; for A/B runs)
-    static const int split_env = getenv("BF_STFT_SPLIT") ? atoi(getenv("BF_STFT_SPLIT")) : 1;
-    const bool split_on = split_env != 0;
-    if (split_env == 1) {
+    // one 2048-point transform per full wavefront (BF_STFT_SPLIT=0: the generic kernel, for cross-checks)
+    static const bool split_on = !(getenv("BF_STFT_SPLIT") && atoi(getenv("BF_STFT_SPLIT")) == 0);
+    if (split_on) {
         constexpr int waves = 4;
         const long np = (a.n_fft_mics + 1) / 2;
         StftArgs b = a;
@@ -1735,27 +1276,6 @@ hipError_t launch_stft(const StftArgs &a, int n_cus, hipStream_t s) {
         } else {
             if (a.z48) BF_LAUNCH((stft_wave2048_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, s, b);
             else BF_LAUNCH((stft_wave2048_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, s, b);
-        }
-        return hipGetLastError();
-    }
-    if (split_on) {
-        constexpr int halves = 8;
-        const long np = (a.n_fft_mics + 1) / 2;
-        StftArgs b = a;
-        const long slots = (long)n_cus * halves * 2;
-        long L = ((long)a.n_streams * a.n_frames * np + slots - 1) / slots;
-        if (L > 256) L = 256;
-        if (L < 1) L = 1;
-        b.run_len = (int)L;
-        const long items = (long)a.n_streams * ((a.n_frames + L - 1) / L) * np;
-        long blocks = (items + halves - 1) / halves;
-        if (blocks > (long)n_cus * 4) blocks = (long)n_cus * 4;
-        if (a.layout == 0) {
-            if (a.z48) BF_LAUNCH((stft_split_kernel<0, true>), dim3((unsigned)blocks), dim3(256), 0, s, b);
-            else BF_LAUNCH((stft_split_kernel<0, false>), dim3((unsigned)blocks), dim3(256), 0, s, b);
-        } else {
-            if (a.z48) BF_LAUNCH((stft_split_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, s, b);
-            else BF_LAUNCH((stft_split_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, s, b);
         }
         return hipGetLastError();
     }

@@ -20,7 +20,6 @@ constexpr int kPlaneD = 16 * kRS;   // doubles per wavefront
 // semantics checked on the device by tools/ubench/permswap.hip; inline asm for the reason given in das_fused_w64.hip).  One block
 // moves the low and the high dwords of four doubles: the four independent swaps between a register's two swaps cover the wait
 // states a swap needs behind the instruction that wrote its operand; the leading s_nop covers the VALU in front of the block.
-#ifndef BF_W64_SWAP_ASM
 __device__ __forceinline__ void swap32(unsigned &a, unsigned &b) {
     auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
     a = r[0];
@@ -41,23 +40,6 @@ __device__ __forceinline__ void row_transpose4(double &d0, double &d1, double &d
     d2 = __hiloint2double((int)h2, (int)l2);
     d3 = __hiloint2double((int)h3, (int)l3);
 }
-#else
-__device__ __forceinline__ void row_transpose4(double &d0, double &d1, double &d2, double &d3) {
-    unsigned l0 = (unsigned)__double2loint(d0), l1 = (unsigned)__double2loint(d1), l2 = (unsigned)__double2loint(d2), l3 = (unsigned)__double2loint(d3);
-    unsigned h0 = (unsigned)__double2hiint(d0), h1 = (unsigned)__double2hiint(d1), h2 = (unsigned)__double2hiint(d2), h3 = (unsigned)__double2hiint(d3);
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"
-        "v_permlane32_swap_b32 %4, %6\n\tv_permlane32_swap_b32 %5, %7\n\t"
-        "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
-        "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7"
-        : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3), "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3));
-    d0 = __hiloint2double((int)h0, (int)l0);
-    d1 = __hiloint2double((int)h1, (int)l1);
-    d2 = __hiloint2double((int)h2, (int)l2);
-    d3 = __hiloint2double((int)h3, (int)l3);
-}
-#endif
 constexpr int brev2c(int i) { return ((i & 1) << 1) | ((i >> 1) & 1); }
 
 // T2: position brev2(g) + 4*brev2(q) (row b)  <->  register 4*g + b (row q)   (as das_fused_w64.hip)
@@ -95,59 +77,13 @@ __device__ __forceinline__ void w64_T2(double (&re)[16], double (&im)[16]) {
 #define BF_T1_RD(p) (*(const volatile __attribute__((address_space(3))) double *)(p))
 #endif
 
-// ---- T2 through the exchange plane ---------------------------------------------------------------------------------------------
-// The same 4 x 4 transpose as w64_T2 without the permlane swaps (128 swaps of a transform = 1 000 of its ~3 500 vector cycles): lane
-// (b, k1) writes its 16 values into row k1 of the plane, lane (q, k1) reads its 16 back (and the reverse for the backward transform).
-// Element (q, g, b) of row k1 sits at column  f = 32 (b & 1) + 16 ((q ^ b) & 1) + 4 g + 2 (q >> 1) + (b >> 1):  rows are kRS = 65
-// doubles apart, so the 16 lanes of a ds_write_b64 group (one b or q, k1 = 0..15) cover 16 bank pairs, and the two 16-lane groups
-// of a ds_read_b64 pass (q or b = 0, 1 / 2, 3) sit 16 bank pairs apart: no conflicts in either direction.
-// prow = plane + (lane & 15) * kRS, hi = lane >> 4.
-// Measured (das_f64_pair_kernel, one box): 0.575 ms against 0.545 with the swaps -- the two more LDS round trips per transform cost more than
-// the 1 000 vector cycles they free.  Kept for A/B runs: -DBF_T2_LDS.
-template <bool FWD>
-__device__ __forceinline__ void w64_T2_lds(double (&re)[16], double (&im)[16], double *prow, int hi) {
-    // this lane as the "b side" (forward writer / backward reader): q, g compile-time
-    double *bE = prow + 48 * (hi & 1) + (hi >> 1);        // q even: f = 48 (b&1) + (b>>1) + 4 g + 2 (q>>1)
-    double *bO = prow + 16 + 16 * (hi & 1) + (hi >> 1);   // q odd : f = 16 + 16 (b&1) + (b>>1) + 4 g + 2 (q>>1)
-    // this lane as the "q side" (forward reader / backward writer): g, b compile-time
-    double *qE = prow + 16 * (hi & 1) + 2 * (hi >> 1);        // b even: f = 16 (q&1) + 2 (q>>1) + 4 g + (b>>1)
-    double *qO = prow + 48 - 16 * (hi & 1) + 2 * (hi >> 1);   // b odd : f = 48 - 16 (q&1) + 2 (q>>1) + 4 g + (b>>1)
-    auto pass = [&](double (&v)[16]) {
-        if (FWD) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) ((q & 1) ? bO : bE)[4 * g + 2 * (q >> 1)] = v[brev2c(g) + 4 * brev2c(q)];
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) v[4 * g + b] = BF_T1_RD(((b & 1) ? qO : qE) + 4 * g + (b >> 1));
-        } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) ((b & 1) ? qO : qE)[4 * g + (b >> 1)] = v[4 * g + b];
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[brev2c(g) + 4 * brev2c(q)] = BF_T1_RD(((q & 1) ? bO : bE) + 4 * g + 2 * (q >> 1));
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
-    pass(re);
-    pass(im);
-}
-// the second transpose of a transform: by permlane swaps (default) or through LDS (-DBF_T2_LDS)
+// (The same transpose through the exchange plane instead of the swaps -- 64 ds_write_b64 + 64 ds_read_b64 per transform on a conflict-free
+// column map -- was measured in round 4: 0.575 ms against 0.545 for das_f64_pair_kernel; the two extra LDS round trips per transform cost more
+// than the 1 000 vector cycles they free.  EXPERIMENTS.md, round 4; the code is gone.)
 template <bool FWD>
 __device__ __forceinline__ void w64_T2_any(double (&re)[16], double (&im)[16], double *prow, int hi) {
-#ifdef BF_T2_LDS
-    w64_T2_lds<FWD>(re, im, prow, hi);
-#else
     (void)prow; (void)hi;
     w64_T2<FWD>(re, im);
-#endif
 }
 
 // ---- T1 through one scalar plane (real parts, then imaginary parts) -----------------------------------------------------------

@@ -20,6 +20,7 @@ struct hipDeviceProp_t {
 
 static inline const char *hipGetErrorString(hipError_t) { return "stub"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char *hipKernelNameRefByPtr(const void *, hipStream_t) { return "stub_kernel"; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 256; return hipSuccess; }

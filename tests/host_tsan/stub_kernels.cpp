@@ -50,6 +50,7 @@ const KernelSet *kernel_set_n8192() { return &g_stub_set; }
 hipError_t prepare_das_f64_w64(const DasF64Args &, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_das_f64_w64(const DasF64Args &, int, hipStream_t) { return hipSuccess; }
 bool das_f64_writes_hist(const DasF64Args &) { return false; }
+size_t das_f64_sched_ws_bytes() { return 256; }
 
 hipError_t prepare_das_fused(const DasFusedArgs &, hipStream_t) { return hipSuccess; }
 hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t) {
@@ -60,13 +61,8 @@ hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t) {
     if (!(acc == acc)) g_inconsistent++;
     return hipSuccess;
 }
-hipError_t launch_das_fused_w64(const DasFusedArgs &a, hipStream_t s) { return launch_das_fused(a, s); }
-hipError_t launch_das_fused_2048(const DasFusedArgs &a, const f32x2 *, hipStream_t s) { return launch_das_fused(a, s); }
-hipError_t launch_das_fused_small(const DasFusedArgs &a, int, const f32x2 *, hipStream_t s) { return launch_das_fused(a, s); }
 hipError_t prepare_das_fused_wave2048(const DasFusedArgs &, hipStream_t) { return hipSuccess; }
 hipError_t launch_das_fused_wave2048(const DasFusedArgs &a, hipStream_t s) { return launch_das_fused(a, s); }
-hipError_t launch_das_fused_small_w64(const DasFusedArgs &a, int, const f32x2 *, hipStream_t s) { return launch_das_fused(a, s); }
-hipError_t launch_das_fused_2048_w64(const DasFusedArgs &a, const f32x2 *, hipStream_t s) { return launch_das_fused(a, s); }
 hipError_t launch_das_fused_dirs(const DasFusedArgs &a, int, int, hipStream_t s) { return launch_das_fused(a, s); }
 hipError_t launch_stream_rms(const float *, long, int, double *, hipStream_t) { return hipSuccess; }
 hipError_t launch_das_hermitian_dump(const f32x2 *, f64x2 *, long, hipStream_t) { return hipSuccess; }

@@ -195,28 +195,6 @@ def test_das_large_batch_random_oracle_windows():
         assert rel_l2(got, ref) < TOL_TIME, t0
 
 
-def test_das_w64_variant_matches_oracle(monkeypatch):
-    """The experimental 64-lane x 16-point FFT factorisation (BF_DAS_W64=1, das_fused_w64.hip) must agree with
-    the oracle like the default kernel does (measured slower in round 1, kept as the round-2 base)."""
-    import oracle
-    from beamform_amd.capi import Beamformer
-    torch = _torch()
-    monkeypatch.setenv("BF_DAS_W64", "1")
-    for M, F in [(8, 37), (3, 18)]:
-        p = make_params("das", n_mics=M, theta=-25.0)
-        x = make_scene(M, F, seed=7 + M)
-        y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
-        bf = Beamformer(p)
-        xd = torch.from_numpy(x).cuda()
-        yd = torch.empty(F * 512, dtype=torch.float32, device="cuda")
-        Yd = torch.empty((F, 1024, 2), dtype=torch.float64, device="cuda")
-        bf.process_device(xd.data_ptr(), F, yd.data_ptr(), Yd.data_ptr())
-        torch.cuda.synchronize()
-        assert rel_l2(yd.cpu().numpy(), y_ref) < TOL_TIME
-        Yh = Yd.cpu().numpy().view(np.complex128)[..., 0]
-        assert max(rel_l2(Yh[t], _herm(Y_ref)[t]) for t in range(F)) < TOL_SPECTRUM
-
-
 @pytest.mark.parametrize("M", [8, 4])
 def test_das_interleaved_equals_planar_at_the_baseline_size(M):
     """65 536 frames: the 16-byte-load kernel for [sample][mic] input against the planar kernel on the transposed data

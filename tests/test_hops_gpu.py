@@ -259,11 +259,10 @@ print("RESULT " + json.dumps(res))
 """
 
 
-@pytest.mark.parametrize("split", ["3", "2", "1", "0"])
+@pytest.mark.parametrize("split", ["3", "0"])
 def test_period_1024_split_kernel_and_its_switch(split):
     """The 1024-frame period without a spectrum dump: das_fused_wave2048_kernel (one 2048-point transform per frame on a full wavefront, tails
-    through an LDS ring, run boundaries by atomics: the default = BF_DAS_SPLIT2048=3), das_fused_2048_w64_kernel (=2: two FFT-1024 passes per frame
-    on the 64-lane transform), das_fused_2048_kernel (=1: the half-wavefront version) and das_fused_gen_kernel<2048> (=0) against the oracle:
+    through an LDS ring, run boundaries by atomics: the default = BF_DAS_SPLIT2048=3) and das_fused_gen_kernel<2048> (=0) against the oracle:
     odd and single microphone counts, many runs per stream, a cut stream, interleaved input; the switch is read once per process."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -308,11 +307,10 @@ print("RESULT " + json.dumps(res))
 """
 
 
-@pytest.mark.parametrize("il", ["1", "3", "2", "0"])
+@pytest.mark.parametrize("il", ["1", "0"])
 def test_small_periods_interleaving_kernel_and_its_switch(il):
     """Periods 256 / 128 / 64 without a spectrum dump, 1024 / N frames interleaved into one 1024-point pass: das_fused_kernel in group mode
-    (BF_DAS_INTERLEAVE=1, the default), das_fused_small_w64_kernel<R> (=3),
-    das_fused_small_kernel<R> (=2), and das_fused_gen_kernel<N> (=0) against the oracle: odd frame counts, one callback at a time,
+    (BF_DAS_INTERLEAVE=1, the default) and das_fused_gen_kernel<N> (=0) against the oracle: odd frame counts, one callback at a time,
     12 microphones, many runs per stream, a cut stream, interleaved input."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -348,12 +346,11 @@ print("RESULT " + json.dumps(res))
 """
 
 
-@pytest.mark.parametrize("env", [{}, {"BF_FUSED_BINS": "0"}, {"BF_STFT_SPLIT": "2", "BF_FUSED_BINS": "0"},
-                                 {"BF_STFT_SMALL": "0", "BF_STFT_SPLIT": "0", "BF_FUSED_BINS": "0"}],
-                         ids=["registers", "registers-unfused", "split-unfused", "generic"])
+@pytest.mark.parametrize("env", [{}, {"BF_FUSED_BINS": "0"}, {"BF_STFT_SMALL": "0", "BF_STFT_SPLIT": "0", "BF_FUSED_BINS": "0"}],
+                         ids=["registers", "registers-unfused", "generic"])
 def test_fp64_nodes_stft_kernels_at_other_periods_and_their_switches(env):
     """stft_small_kernel / istft_small_kernel (N = 128 / 256 / 512: several frames per half-wavefront through one transpose plane),
-    stft_wave2048_kernel (N = 2048: one transform per full wavefront; BF_STFT_SPLIT=2: stft_split_kernel, two FFT-1024 and a radix-2 step) /
+    stft_wave2048_kernel (N = 2048: one transform per full wavefront) /
     istft_split_kernel, stft_bins_small_kernel / stft_bins_split_kernel (phase / phasempf below 512 / at 1024: the STFT and
     the per-bin stage in one launch; BF_FUSED_BINS=0: the chain) and the generic LDS-staged kernels they replace (BF_STFT_SMALL=0 / BF_STFT_SPLIT=0),
     against the oracle: odd microphone counts, one microphone, both layouts, frame counts that leave partial groups, rounds and short runs."""

@@ -46,36 +46,23 @@ print("RESULT " + json.dumps(res))
 
 CASES = [
     # (environment, algo, mics, interferers, frames, spectrum dump)
-    ({"BF_COV2D": "0"}, "lcmv", 16, (-60.0, 90.0, 150.0), 24, True),   # row-per-lane DPP kernel (mvdr_lcmv_row_kernel)
-    ({"BF_COV2D": "0"}, "mvdr", 12, (), 24, True),                     # lanes kernel, 9..16 microphones
-    ({"BF_COV2D": "2"}, "lcmv", 16, (-60.0, 90.0, 150.0), 24, True),   # two-wavefront build of the 2-D cyclic kernel
-    ({"BF_COV2D": "2"}, "mvdr", 16, (), 24, False),
     ({"BF_MVDR_GROUP": "1"}, "mvdr", 8, (), 30, True),                 # group-per-problem kernel over LDS
     ({"BF_MVDR_GROUP": "1"}, "lcmv", 8, (-60.0, 90.0), 30, False),
-    ({"BF_LCMV_FAST": "0"}, "lcmv", 8, (-60.0, 90.0), 30, True),       # lanes kernel (lcmv <= 8 microphones before mvdr_fast_kernel<MP, KC>)
-    ({"BF_LCMV_FAST": "0"}, "lcmv", 3, (90.0,), 24, False),
     ({"BF_MVDR_TILE": "7"}, "lcmv", 8, (-60.0, 90.0), 40, True),       # mvdr_fast_kernel<8, 3>: lanes straddle tiles, short last tile
     ({"BF_MVDR_TILE": "7"}, "mvdr", 8, (), 40, False),                 # mvdr_fast_kernel: lanes straddle tiles, short last tile
-    ({"BF_DAS_VARIANT": "0"}, "das", 8, (), 37, True),                 # round-1 transposes, run-time pair loop
-    ({"BF_DAS_VARIANT": "1"}, "das", 8, (), 37, True),                 # ds_write_addtid transposes, run-time pair loop
-    ({"BF_DAS_VARIANT": "1"}, "das", 5, (), 21, True),
     ({"BF_ISTFT_F64": "1"}, "mvdr", 8, (), 30, False),                 # fp64 backward transform behind every node
     ({"BF_ISTFT_F64": "1"}, "phase", 8, (), 24, True),
     ({"BF_Z48": "0"}, "mvdr", 8, (), 30, True),                        # full-double spectra in HBM (no z48 packing), group kernel
     ({"BF_Z48": "0"}, "lcmv", 16, (-60.0, 90.0, 150.0), 24, True),
     ({"BF_GSC_SERIAL": "1"}, "gsc", 4, (), 10, False),                  # gsc_nlms_kernel: the sums in the reference's tap order, one branch per lane
     ({"BF_GSC_SERIAL": "1"}, "gsc", 8, (), 8, False),
-    ({"BF_GSC_WAVES": "1"}, "gsc", 8, (), 8, False),                    # gsc_nlms_par_kernel: one wavefront per stream
-    ({"BF_GSC_WAVES": "2"}, "gsc", 6, (), 8, False),                    # gsc_nlms_mw_kernel<2, ...>
-    ({"BF_STFT_W64": "1"}, "mvdr", 8, (), 30, True),                   # stft_w64_kernel in front of the covariance nodes (z48 rows)
-    ({"BF_STFT_W64": "1"}, "gss", 5, (-60.0,), 30, True),              # ... and full-double rows, odd microphone count
-    ({"BF_BINS_W64": "0"}, "phase", 8, (), 24, True),                  # stft_bins_fused_kernel: the 32 x 32 half-wavefront version of the fused STFT + per-bin kernel
-    ({"BF_BINS_W64": "0"}, "phasempf", 5, (), 30, True),
-    ({"BF_DAS_F64_W64": "0"}, "das", 8, (), 37, False),                # (only the fp64 das node reads it; the fp32 node must not care)
+    ({}, "gsc", 2, (), 8, False),                                       # one blocking branch: gsc_nlms_par_kernel (one wavefront per stream)
+    ({}, "gsc", 3, (), 8, False),                                       # two branches: gsc_nlms_mw_kernel<2, ...>
+    ({}, "gsc", 5, (), 8, False),                                       # four branches: gsc_nlms_mw_kernel<4, ...>
 ]
 
 
-@pytest.mark.parametrize("env,algo,M,interf,F,dump", CASES, ids=[f"{'_'.join(f'{k}={v}' for k, v in c[0].items())}-{c[1]}{c[2]}" for c in CASES])
+@pytest.mark.parametrize("env,algo,M,interf,F,dump", CASES, ids=[f"{'_'.join(f'{k}={v}' for k, v in c[0].items()) or 'default'}-{c[1]}{c[2]}" for c in CASES])
 def test_env_selected_kernel_matches_oracle(env, algo, M, interf, F, dump):
     code = CHILD % dict(root=ROOT, algo=algo, M=M, interf=tuple(interf), F=F, dump=dump)
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
@@ -156,11 +143,11 @@ print("RESULT " + json.dumps(res))
 """
 
 
-@pytest.mark.parametrize("env", [{}, {"BF_DAS_F64_PAIR": "0"}, {"BF_DAS_F64_W64": "0"}], ids=["default", "BF_DAS_F64_PAIR=0", "BF_DAS_F64_W64=0"])
+@pytest.mark.parametrize("env", [{}, {"BF_DAS_F64_SCHED": "0"}, {"BF_DAS_F64_SCHED": "5,3,1"}], ids=["default", "equal-chunks", "tiny-chunks"])
 def test_das_in_double_every_one_launch_kernel(env):
-    """das at the reference's precision without a spectrum dump: das_f64_pair_kernel (planar, the default), das_f64_w64_kernel
-    (BF_DAS_F64_PAIR=0; the interleaved layout always) and das_f64_fused_kernel (BF_DAS_F64_W64=0) against the oracle -- a batch that
-    is cut into runs, an odd microphone count with an odd number of frames, one lone frame."""
+    """das at the reference's precision without a spectrum dump: das_f64_pair_kernel (planar input; its default chunk plan, equal static
+    chunks and a plan of tiny chunks) and das_f64_w64_kernel<1> ([sample][mic] input) against the oracle -- a batch that is cut into
+    chunks, an odd microphone count with an odd number of frames, one lone frame."""
     out = subprocess.run([sys.executable, "-c", CHILD_F64 % dict(root=ROOT)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])

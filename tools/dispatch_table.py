@@ -17,7 +17,11 @@ FRAMES = 96   # enough for every kernel's main path (chunks, tiles, rings) to be
 
 
 def kernels_of(algo, hop=512, layout=BF_PLANAR, M=8, dirs=1, dump=False, impl=BF_DAS_FUSED_F32, interf=()):
-    p = make_params(algo, n_mics=M, hop=hop, interf=interf)
+    over = {}
+    if M > 16:  # beyond the yaml's 16 positions: a circle of 0.2 m
+        import math
+        over["mics"] = [(0.2 * math.cos(2 * math.pi * m / M), 0.2 * math.sin(2 * math.pi * m / M)) for m in range(M)]
+    p = make_params(algo, n_mics=M, hop=hop, interf=interf, **over)
     bf = Beamformer(p, layout=layout, das_impl=impl, n_dirs=dirs)
     if dirs > 1:
         bf.set_thetas([-180.0 + 360.0 * d / dirs for d in range(dirs)])

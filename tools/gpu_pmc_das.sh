@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/gpu_pmc_das.sh <tag>   (BF_DAS_VARIANT etc. from the environment)
+# usage: tools/gpu_pmc_das.sh <tag>   (the fused fp32 das kernel)
 tag=$1
 export TMPDIR=/tmp
 P="rocprofv3 --kernel-trace --output-format csv"

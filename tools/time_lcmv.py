@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""lcmv over microphone / interferer counts, 65 536-frame batches of noise (BF_LCMV_FAST=0 selects the lanes kernel for A/B runs)."""
+"""lcmv over microphone / interferer counts, 65 536-frame batches of noise."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
