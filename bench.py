@@ -724,6 +724,21 @@ def main():
                 out[f"{algo_}_us_per_callback"] = ts[len(ts) // 2] * 1e6
             return out
 
+        def strict_line(algo_):
+            # the same node with nothing narrower than the reference's doubles anywhere: full c128 spectra in HBM (BF_Z48=0: the group-per-problem
+            # kernel reads them) and the fp64 backward transform (BF_ISTFT_F64=1).  The switches are read once per process: a child bench.py.
+            cmd = [sys.executable, os.path.abspath(__file__), "--algo", algo_, "--mics", str(M), "--frames", str(F), "--steps", "5", "--warmup", "2",
+                   "--settle-ms", "120", "--no-cpu", "--no-extra"]
+            r = subprocess.run(cmd, env=dict(os.environ, BF_Z48="0", BF_ISTFT_F64="1"), capture_output=True, text=True, timeout=600)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                return {"error": (r.stderr or r.stdout)[-400:]}
+            d = json.loads(lines[-1])
+            return {"workload": f"{algo_} {M}-mic 1024-pt, {F} frames with BF_Z48=0 BF_ISTFT_F64=1: c128 spectra in HBM, fp64 backward transform -- what the "
+                                "default line's z48 spectra (36-bit mantissa), fp32 gate pre-decision and fp32 backward transform buy",
+                    "ms_per_step": d["ms_per_step"], "frames_per_s": d["value"], "kernels": d["roofline"].get("kernels_launched_per_step")}
+
+        jobs.append(("mvdr_strict", lambda: strict_line("mvdr")))
         jobs.append(("resample_48k_16k", resample_line))
         jobs.append(("streaming_callback", hop_line))
         for name, job in jobs:
