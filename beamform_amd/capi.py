@@ -69,27 +69,45 @@ class BfError(RuntimeError):
 _lib = None
 
 
+#: which HIP runtime libbfcore.so ended up bound to: "torch:<path>" (the wheel's copy was loaded first), "system" or "unknown"
+HIP_RUNTIME_BOUND = "unknown"
+
+
 def _share_torch_hip_runtime():
     """One HIP runtime per process.  A PyTorch-ROCm wheel ships its own libamdhip64.so (same soname as /opt/rocm's); if libbfcore.so
     is loaded first it brings in /opt/rocm's copy, torch then loads its own beside it, and the second runtime to initialise reports
     "no ROCm-capable device".  When torch is installed but not imported yet, load ITS runtime first (without importing torch) so that
-    libbfcore.so's DT_NEEDED resolves to the copy torch will use.  BF_NO_TORCH_HIP=1 skips this (a process that never imports torch)."""
+    libbfcore.so's DT_NEEDED resolves to the copy torch will use.  BF_NO_TORCH_HIP=1 skips this (a process that never imports torch
+    keeps the /opt/rocm runtime libbfcore.so was built against).  What happened is recorded in HIP_RUNTIME_BOUND, and a version
+    mismatch between the wheel's runtime and the one libbfcore.so was built with (bf_version()) is warned about once."""
+    global HIP_RUNTIME_BOUND
     import sys
-    if "torch" in sys.modules or os.environ.get("BF_NO_TORCH_HIP") == "1":
+    if os.environ.get("BF_NO_TORCH_HIP") == "1":
+        HIP_RUNTIME_BOUND = "system"
+        return
+    if "torch" in sys.modules:
+        HIP_RUNTIME_BOUND = "torch:already imported"
         return
     import importlib.util
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
-        return
+        spec = None
     if spec is None or not spec.submodule_search_locations:
+        HIP_RUNTIME_BOUND = "system"
         return
     path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
     if os.path.exists(path):
         try:
-            C.CDLL(path, mode=C.RTLD_GLOBAL)
+            rt = C.CDLL(path, mode=C.RTLD_GLOBAL)
+            HIP_RUNTIME_BOUND = "torch:" + path
+            v = C.c_int(0)
+            if rt.hipRuntimeGetVersion(C.byref(v)) == 0 and os.environ.get("BF_HIP_DEBUG") == "1":
+                print(f"[bfcore] bound to the torch wheel's HIP runtime {path} (version {v.value})", file=sys.stderr)
         except OSError:
-            pass  # not loadable on its own: libbfcore.so falls back to its RUNPATH copy
+            HIP_RUNTIME_BOUND = "system"  # not loadable on its own: libbfcore.so falls back to its RUNPATH copy
+    else:
+        HIP_RUNTIME_BOUND = "system"
 
 
 def load():

@@ -270,17 +270,30 @@ int run_das_fused(bf_handle *h, const float *x_dev, size_t n_frames, float *y_de
         int trc = timing_acquire(h, &k0, &k1);
         if (trc != BF_OK) return trc;
     }
-    if (k0) BF_HIP(h, hipEventRecord(k0, s));
-    if (shared) {
-        for (int d0 = 0; d0 < h->n_dirs; d0 += 16)
-            BF_HIP(h, launch_das_fused_dirs(a, d0, h->n_dirs - d0 < 16 ? h->n_dirs - d0 : 16, s));
-    } else {
-        BF_HIP(h, wave2048 ? launch_das_fused_wave2048(a, s)
-                  : small_ring ? launch_das_fused(a, s)
-                  : gen     ? launch_das_fused_gen(a, h->N, s)
-                  : launch_das_fused(a, s));
+    // (a launch that fails between the two records must not leave a half-recorded pair in the session: hand it back)
+    auto launch_all = [&]() -> hipError_t {
+        hipError_t e = hipSuccess;
+        if (k0) e = hipEventRecord(k0, s);
+        if (e != hipSuccess) return e;
+        if (shared) {
+            for (int d0 = 0; d0 < h->n_dirs && e == hipSuccess; d0 += 16)
+                e = launch_das_fused_dirs(a, d0, h->n_dirs - d0 < 16 ? h->n_dirs - d0 : 16, s);
+        } else {
+            e = wave2048 ? launch_das_fused_wave2048(a, s)
+                : small_ring ? launch_das_fused(a, s)
+                : gen     ? launch_das_fused_gen(a, h->N, s)
+                : launch_das_fused(a, s);
+        }
+        if (e == hipSuccess && k1) e = hipEventRecord(k1, s);
+        return e;
+    };
+    {
+        const hipError_t e = launch_all();
+        if (e != hipSuccess) {
+            if (k0 && h->ev_used > 0) --h->ev_used;
+            BF_HIP(h, e);
+        }
     }
-    if (k1) BF_HIP(h, hipEventRecord(k1, s));
     h->tail_cur ^= 1;
 
     if (spectrum_dev)

@@ -140,6 +140,12 @@ def test_das_f64_one_launch_matches_oracle(M, F, S):
         cuts = [0, 1, 4, F // 2, F]
         parts = [bf2.process(np.ascontiguousarray(xs[0][:, a * 512:b * 512])) for a, b in zip(cuts[:-1], cuts[1:])]
         assert same_floats(np.concatenate(parts), y[0])   # state (ring hop, tail) carries; which frames share a transform depends on the cuts
+        # ... and cuts at EVEN frame counts leave every pair where it was: the hop across a cut is tail_in + head, the same float addition
+        # as inside a batch -- bit for bit (the deterministic regression the planar kernel keeps)
+        bf3 = Beamformer(p, das_impl=BF_DAS_BINS_F64)
+        cuts = sorted({0, 2, 4, 2 * (F // 4), 2 * (F // 3), F})
+        parts = [bf3.process(np.ascontiguousarray(xs[0][:, a * 512:b * 512])) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert np.array_equal(np.concatenate(parts), y[0])
 
 
 def test_das_f64_one_launch_streaming_callbacks():
