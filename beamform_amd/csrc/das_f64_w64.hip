@@ -27,6 +27,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "launch_trace.hpp"
 #include "pipeline_kernels.hpp"
@@ -549,8 +550,16 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
         nxt.have = false;
 
         double Sr[16], Si[16];
-        for (int m = 0; m < M; ++m) {
+        // one microphone: forward transform of (frame tA, frame tA + 1) and S += ce_m Z_m.  Instantiated twice (FIRST: the microphone
+        // that starts the sum with a multiplication): a run-time test per accumulator cost 32 scalar branches per microphone
+        auto one_mic = [&](const int m, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             double re[16], im[16];
+#ifndef BF_PAIR_NO_VMWAIT
+            // this microphone's 24 loads were requested a transform ago and nothing younger is in flight: ONE wait instead of the sixteen
+            // counted ones hipcc places between the conversions (not for the first microphone: the previous pair's stores are still in flight)
+            if constexpr (!FIRST) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), lgkmcnt / expcnt untouched
+#endif
             // buf[j]*hann_win[i] (util.h:235) and the first butterfly stage in one (see the kernel above); hop tA is the second half of
             // frame tA and the first half of frame tA + 1
 #pragma unroll
@@ -621,7 +630,7 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
             for (int r = 0; r < 16; ++r) {
                 if (r == 8) BF_STAGE();
                 const double gx = g[r].x, gy = (r & 3) < 2 ? g[r].y : -g[r].y;
-                if (m == 0) {  // the first microphone starts the sum
+                if constexpr (FIRST) {  // the first microphone starts the sum
                     Sr[r] = fma(-gy, im[r], gx * re[r]);
                     Si[r] = fma(gy, re[r], gx * im[r]);
                 } else {
@@ -629,7 +638,9 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
                     Si[r] = fma(gy, re[r], fma(gx, im[r], Si[r]));
                 }
             }
-        }
+        };
+        one_mic(0, std::true_type{});
+        for (int m = 1; m < M; ++m) one_mic(m, std::false_type{});
         float *yo = ys + tA * kHop;
         cx<double> tw[15];
         BF_STAGE();
