@@ -548,6 +548,12 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
         float *ys = a.y + (long)stream * a.n_frames * kHop;
         PairWork nxt;
         nxt.have = false;
+        // hop tA of the microphone whose loads are in flight (request_pair_mic asked for microphone 0 of this pair); the carried hop
+        // stands in for hop -1, the last frame of a stream has no hop behind it
+        const float *hp = a.x + (long)stream * a.stream_stride_x + tA * kHop;
+        const float *hist0 = a.hist + (long)stream * M * kHop;
+        const bool first_hop = tA < 1, last_hop = !(tA + 1 < a.n_frames);
+        (void)hp; (void)hist0; (void)first_hop; (void)last_hop;
 
         double Sr[16], Si[16];
         // one microphone: forward transform of (frame tA, frame tA + 1) and S += ce_m Z_m.  Instantiated twice (FIRST: the microphone
@@ -582,7 +588,13 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
             }
             // the next microphone, or the first one of this wavefront's next pair (none left: this pair's first again, unused)
             if (m + 1 < M) {
+#ifdef BF_PAIR_PTR_MUL
                 request_pair_mic(stream, tA, m + 1);
+#else
+                // the next microphone's hop tA is one mic_stride further (a running pointer: two scalar adds instead of the 64-bit products)
+                hp += a.mic_stride;
+                request(first_hop ? hist0 + (m + 1) * kHop : hp - kHop, hp, last_hop ? hp : hp + kHop);
+#endif
             } else {
                 nxt = draw_pair(s_work, sc, lane);
                 if (nxt.have) request_pair_mic(nxt.d.x, nxt.d.y + 2L * nxt.pos, 0);
@@ -856,12 +868,21 @@ static DasSchedPlan das_f64_plan(long n_frames, int n_streams, int n_cus) {
             ++c;
         }
     } else if (!(env && atoi(env) == 0) && share >= 48) {
-        int first = (int)(share * 13 / 16) & ~7;          // 81 % of the share, a multiple of 8 pairs
-        if (first > kMaxChunkPairs) first = kMaxChunkPairs & ~7;
-        sizes[n_sizes++] = first;
-        long rest = share - first;
-        for (int sz = 8; sz >= 4 && n_sizes < 7; sz >>= 1)
-            if (rest >= 3 * sz) { sizes[n_sizes++] = sz; rest -= sz; }
+        long front = (share * 13 / 16) & ~7L;             // 81 % of the share in long chunks, a multiple of 8 pairs
+        long rest = share - front;
+        while (front > kMaxChunkPairs && n_sizes < 3) {    // (a chunk holds at most kMaxChunkPairs pairs: very long batches get several)
+            sizes[n_sizes++] = kMaxChunkPairs;
+            front -= kMaxChunkPairs;
+        }
+        if (front > kMaxChunkPairs) { rest += front - kMaxChunkPairs; front = kMaxChunkPairs; }
+        sizes[n_sizes++] = (int)front;
+        while (n_sizes < 6 && rest >= 24) {                // the rest in chunks that halve it level by level: 8 at the headline size
+            long sz = (rest / 2) & ~7L;
+            if (sz > kMaxChunkPairs) sz = kMaxChunkPairs;
+            sizes[n_sizes++] = (int)sz;
+            rest -= sz;
+        }
+        if (rest >= 12) { sizes[n_sizes++] = 4; rest -= 4; }
         sizes[n_sizes++] = 2;
     }
     if (n_sizes == 0) {  // equal chunks
