@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "launch_trace.hpp"
+#include "das_f64_plan.hpp"
 #include "pipeline_kernels.hpp"
 #include "w64_f64_dev.hpp"
 
@@ -369,8 +370,8 @@ struct DasSched {           // the work queue of das_f64_pair_kernel (written by
 // atomic add: whoever draws pair == pairs (the first one past the end) fetches the next chunk from the global counter and installs
 // it; later arrivals spin on the word until the chunk field changes.  The virtual index numbers the pairs a block has drawn 0, 1, 2, ...
 // across chunks: boundary state slot = virtual index mod kSlots, whatever the chunks' sizes.
-constexpr int kChunkEnd = 0xFFFFF;       // chunk field: the table is exhausted
-constexpr int kMaxChunkPairs = 1000;     // pairs per chunk (10 bits, and up to 8 draws past the end before the word is replaced)
+// (kChunkEnd = 0xFFFFF in the chunk field: the table is exhausted; kMaxChunkPairs = 1000 pairs per chunk: 10 bits, and up to 8 draws past the
+// end before the word is replaced -- das_f64_plan.hpp)
 __device__ __forceinline__ unsigned long long pack_work(unsigned vbase, int chunk, int pairs, int next) {
     return ((unsigned long long)(vbase & 0xFFFFFFu) << 40) | ((unsigned long long)(unsigned)chunk << 20) | ((unsigned long long)(unsigned)pairs << 10) | (unsigned)next;
 }
@@ -805,25 +806,11 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
 // small launch in front of the kernel (it replaces the hipMemset2DAsync of the static-run version).  Block k = chunk k.
 // Levels: per stream, level i holds cnt[i] chunks of size[i] pairs (the last chunk of a stream may be shorter); level-major order over
 // all streams, so the table starts with every block's big first chunk and ends with the small ones that level the finishing times.
-struct DasSchedPlan {
-    int n_levels;
-    int cnt[8], size[8];   // chunks per stream / pairs per chunk of each level
-    int n_chunks;          // over all streams
-    int grid;              // persistent blocks
-};
 __global__ void das_f64_sched_kernel(DasSchedPlan p, int4 *chunks, unsigned *counter, float *y, long n_frames, int n_streams) {
     const int k = blockIdx.x;
-    int lvl = 0, kk = k;
-    long pair0 = 0;  // pairs of a stream in front of level lvl
-    while (lvl < p.n_levels - 1 && kk >= p.cnt[lvl] * n_streams) {
-        kk -= p.cnt[lvl] * n_streams;
-        pair0 += (long)p.cnt[lvl] * p.size[lvl];
-        ++lvl;
-    }
-    const int stream = kk / p.cnt[lvl], j = kk - stream * p.cnt[lvl];
-    const long t0 = 2 * (pair0 + (long)j * p.size[lvl]);
-    long n = 2L * p.size[lvl];
-    if (t0 + n > n_frames) n = n_frames - t0;
+    int stream;
+    long t0, n;
+    das_f64_chunk(p, n_frames, n_streams, k, &stream, &t0, &n);
     if (threadIdx.x == 0) {
         chunks[k] = int4{stream, (int)t0, (int)n, 0};
         if (k == 0) *counter = (unsigned)p.grid;
@@ -847,72 +834,8 @@ bool das_f64_writes_hist(const DasF64Args &a) { return use_pair_kernel(a) && a.h
 // the following levels halve the chunk until kSchedLast pairs; what is left goes out in chunks of kSchedLast pairs.  A chunk edge costs
 // one input hop read twice and two atomic adds per output sample, so the small chunks are kept to the last ~12 % of the batch.
 // BF_DAS_F64_SCHED=0: one level of equal chunks (the static runs of round 4); BF_DAS_F64_SCHED="88,16,8,4,2": explicit chunk sizes in pairs.
-constexpr int kSchedMaxChunks = 16384;
 constexpr size_t kSchedCounterBytes = 256;
 size_t das_f64_sched_ws_bytes() { return kSchedCounterBytes + (size_t)kSchedMaxChunks * sizeof(int4); }
-
-static DasSchedPlan das_f64_plan(long n_frames, int n_streams, int n_cus) {
-    DasSchedPlan p{};
-    const long pairs = (n_frames + 1) / 2;
-    long nb = (long)n_cus / n_streams;
-    if (nb < 1) nb = 1;
-    static const char *env = getenv("BF_DAS_F64_SCHED");
-    int sizes[8], n_sizes = 0;
-    const long share = (pairs + nb - 1) / nb;  // pairs per block if they were dealt out evenly
-    if (env && strchr(env, ',')) {
-        const char *c = env;
-        while (*c && n_sizes < 8) {
-            sizes[n_sizes++] = atoi(c);
-            c = strchr(c, ',');
-            if (!c) break;
-            ++c;
-        }
-    } else if (!(env && atoi(env) == 0) && share >= 48) {
-        long front = (share * 13 / 16) & ~7L;             // 81 % of the share in long chunks, a multiple of 8 pairs
-        long rest = share - front;
-        while (front > kMaxChunkPairs && n_sizes < 3) {    // (a chunk holds at most kMaxChunkPairs pairs: very long batches get several)
-            sizes[n_sizes++] = kMaxChunkPairs;
-            front -= kMaxChunkPairs;
-        }
-        if (front > kMaxChunkPairs) { rest += front - kMaxChunkPairs; front = kMaxChunkPairs; }
-        sizes[n_sizes++] = (int)front;
-        while (n_sizes < 6 && rest >= 24) {                // the rest in chunks that halve it level by level: 8 at the headline size
-            long sz = (rest / 2) & ~7L;
-            if (sz > kMaxChunkPairs) sz = kMaxChunkPairs;
-            sizes[n_sizes++] = (int)sz;
-            rest -= sz;
-        }
-        if (rest >= 12) { sizes[n_sizes++] = 4; rest -= 4; }
-        sizes[n_sizes++] = 2;
-    }
-    if (n_sizes == 0) {  // equal chunks
-        long sz = ((share + 7) / 8) * 8;
-        if (sz > kMaxChunkPairs) sz = kMaxChunkPairs & ~7;
-        sizes[n_sizes++] = (int)sz;
-    }
-    long left = pairs;
-    for (int i = 0; i < n_sizes && left > 0; ++i) {
-        int sz = sizes[i] < 1 ? 1 : (sizes[i] > kMaxChunkPairs ? kMaxChunkPairs : sizes[i]);
-        long cnt = (i == n_sizes - 1) ? (left + sz - 1) / sz : nb;
-        if (cnt * sz > left) cnt = (left + sz - 1) / sz;
-        p.size[p.n_levels] = sz;
-        p.cnt[p.n_levels] = (int)cnt;
-        ++p.n_levels;
-        left -= cnt * sz;
-    }
-    long total = 0;
-    for (int i = 0; i < p.n_levels; ++i) total += (long)p.cnt[i] * n_streams;
-    if (total > kSchedMaxChunks || total >= kChunkEnd) {  // too fine for the table: one level of the largest chunks that fit
-        long sz = kMaxChunkPairs & ~7;
-        p.n_levels = 1;
-        p.size[0] = (int)sz;
-        p.cnt[0] = (int)((pairs + sz - 1) / sz);
-        total = (long)p.cnt[0] * n_streams;
-    }
-    p.n_chunks = (int)total;
-    p.grid = (int)(total < n_cus ? total : n_cus);
-    return p;
-}
 
 // frames per run of the microphone-pair kernel: a multiple of one step of the block (8 frames), about one run per CU
 static void das_f64_w64_runs(const DasF64Args &a, int n_cus, long *fpc, long *cps) {
@@ -931,7 +854,8 @@ hipError_t prepare_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s) {
     if (a.n_mics > 8) return hipErrorNotSupported;  // the gain tables fill the LDS
     if (use_pair_kernel(a)) {
         if (a.sched_ws_bytes < das_f64_sched_ws_bytes() || (long)a.n_streams * ((a.n_frames + 1) / 2) >= (1L << 31)) return hipErrorNotSupported;
-        const DasSchedPlan p = das_f64_plan(a.n_frames, a.n_streams, n_cus);
+        const DasSchedPlan p = das_f64_plan(a.n_frames, a.n_streams, n_cus, getenv("BF_DAS_F64_SCHED"));
+        if (p.n_chunks < 1 || p.n_chunks > kSchedMaxChunks) return hipErrorNotSupported;  // (more streams than the table has rows: the chain serves them)
         unsigned *counter = reinterpret_cast<unsigned *>(a.sched_ws);
         int4 *chunks = reinterpret_cast<int4 *>(reinterpret_cast<char *>(a.sched_ws) + kSchedCounterBytes);
         BF_LAUNCH(das_f64_sched_kernel, dim3((unsigned)p.n_chunks), dim3(128), 0, s, p, chunks, counter, a.y, a.n_frames, a.n_streams);
@@ -951,7 +875,7 @@ hipError_t prepare_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s) {
 hipError_t launch_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s) {
     if (a.n_mics > 8) return hipErrorNotSupported;
     if (use_pair_kernel(a)) {
-        const DasSchedPlan p = das_f64_plan(a.n_frames, a.n_streams, n_cus);
+        const DasSchedPlan p = das_f64_plan(a.n_frames, a.n_streams, n_cus, getenv("BF_DAS_F64_SCHED"));
         DasSched sc;
         sc.counter = reinterpret_cast<unsigned *>(a.sched_ws);
         sc.chunks = reinterpret_cast<const int4 *>(reinterpret_cast<char *>(a.sched_ws) + kSchedCounterBytes);

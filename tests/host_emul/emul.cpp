@@ -588,3 +588,14 @@ void emul_hann(int N, double *h) {
     memcpy(h, v.data(), sizeof(double) * N);
 }
 }
+
+// ---- das_f64_pair_kernel's chunk plan (csrc/das_f64_plan.hpp): the table as das_f64_sched_kernel writes it --------------------------------
+#include "../../beamform_amd/csrc/das_f64_plan.hpp"
+// fills stream / t0 / n (capacity `cap` rows) and returns the number of chunks (negative: more than `cap`); *grid = persistent blocks
+extern "C" int emul_das_plan(long n_frames, int n_streams, int n_cus, const char *env, int cap, int *stream, long *t0, long *n, int *grid) {
+    const bf::DasSchedPlan p = bf::das_f64_plan(n_frames, n_streams, n_cus, (env && *env) ? env : nullptr);
+    *grid = p.grid;
+    if (p.n_chunks > cap) return -p.n_chunks;
+    for (int k = 0; k < p.n_chunks; ++k) bf::das_f64_chunk(p, n_frames, n_streams, k, &stream[k], &t0[k], &n[k]);
+    return p.n_chunks;
+}

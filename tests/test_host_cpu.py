@@ -259,3 +259,39 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(import|from)\s+oracle|liboracle|bf_oracle|np_oracle", txt, re.M):
                     bad.append(fn)
     assert not bad, bad
+
+
+def test_das_f64_chunk_plan_tiles_every_stream(emul_lib):
+    """The work queue of das_f64_pair_kernel (csrc/das_f64_plan.hpp, the host arithmetic das_f64_sched_kernel runs per chunk): for any
+    batch shape and plan the chunks must tile every stream exactly once, start on even frames (so that WHICH frames share a transform
+    never depends on the plan), hold at most 1000 pairs (the 10-bit fields of the kernel's work word), fit the table, and come longest
+    first inside a stream's level order."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    shapes = [(65536, 1, 256), (65537, 1, 256), (1, 1, 256), (2, 1, 256), (7, 3, 256), (256, 256, 256), (300, 5, 256), (1_000_000, 1, 256),
+              (4_000_000, 1, 256), (20_000, 300, 256), (2049, 1, 256), (16400, 1, 256), (33, 2, 304), (100_000, 7, 64)]
+    shapes += [(int(rng.integers(1, 300_000)), int(rng.integers(1, 40)), int(rng.choice([64, 256, 304]))) for _ in range(40)]
+    cap = 16384
+    st, t0, n = (C.c_int * cap)(), (C.c_long * cap)(), (C.c_long * cap)()
+    grid = C.c_int()
+    emul_lib.emul_das_plan.restype = C.c_int
+    emul_lib.emul_das_plan.argtypes = [C.c_long, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    for env in (b"", b"0", b"5,3,1", b"104,8,4,2", b"40,7,5,3", b"1"):
+        for F, S, cus in shapes:
+            k = emul_lib.emul_das_plan(F, S, cus, env, cap, st, t0, n, C.byref(grid))
+            assert 0 < k <= cap, (F, S, cus, env, k)
+            assert 1 <= grid.value <= min(k, cus)
+            seen = {s: [] for s in range(S)}
+            for i in range(k):
+                assert 0 <= st[i] < S and n[i] >= 1 and t0[i] % 2 == 0 and (n[i] + 1) // 2 <= 1000, (F, S, env, i, st[i], t0[i], n[i])
+                seen[st[i]].append((t0[i], n[i]))
+            for s in range(S):
+                pos = 0
+                for a, b in sorted(seen[s]):
+                    assert a == pos, (F, S, env, s, a, pos)      # no gap, no overlap
+                    assert b % 2 == 0 or a + b == F               # only a stream's last chunk ends on a lone frame
+                    pos = a + b
+                assert pos == F, (F, S, env, s, pos)
+            if env == b"" and k > grid.value:   # level-major order: the table starts with one long chunk per block-share of every stream
+                first = [n[i] for i in range(min(grid.value, k))]
+                assert min(first) >= max(n[i] for i in range(k - 1, k)), (F, S)
