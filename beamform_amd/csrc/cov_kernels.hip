@@ -562,7 +562,7 @@ struct RowStep<MP, MP> {
 };
 
 // ---- lcmv / mvdr, 9..16 microphones: 2-D cyclic 4 x 4 lanes per problem -------------------------------------------------
-// One problem (stream, bin) per 16-lane DPP row, like mvdr_lcmv_row_kernel, but the lanes form a 4 x 4 grid (p = lane >> 2,
+// One problem (stream, bin) per 16-lane DPP row (as round 2's row-per-lane kernel had it), but the lanes form a 4 x 4 grid (p = lane >> 2,
 // q = lane & 3 inside the row) and matrix entry (i, c) lives in lane (i mod 4, c mod 4) at local index (i / 4, c / 4):
 // every lane owns a 4 x 4 block of R and of the working copy (its lower triangle + diagonal: 10 entries), so
 //   * the triangular trailing update keeps all 16 lanes busy until the last 4 x 4 block (the row-per-lane kernel idles half
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
 #pragma unroll
             for (int e = 0; e < NE; ++e) ge[e] = ld(&s_g[wv][grp][fs][e]);
             __builtin_amdgcn_wave_barrier();
-            // (K+1) x (K+1) system G y = g on the upper triangle (as in mvdr_lcmv_row_kernel)
+            // (K+1) x (K+1) system G y = g on the upper triangle (one system per lane)
             cd gv[KM];
             auto UI = [](int r, int c) { return r * KM - r * (r - 1) / 2 + (c - r); };
 #pragma unroll

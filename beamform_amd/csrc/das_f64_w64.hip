@@ -6,12 +6,12 @@
 //                        U = sum_m ce_m Z_m with the per-microphone Hermitian gains, one backward transform returns both frames
 //                        (real / imaginary part): 4.5 transforms per frame.  Frame pairs are handed out to the eight wavefronts of
 //                        a block through an LDS counter, the overlap-add between pairs is first come first served (below).
-//   das_f64_w64_kernel   [sample][mic] input (and BF_DAS_F64_PAIR=0).  A transform carries two microphones of one frame (one 8-byte
+//   das_f64_w64_kernel   [sample][mic] input.  A transform carries two microphones of one frame (one 8-byte
 //                        load per sample), S += D_p Z_p with the Hermitian-part pair gains (das_pair_gains_t), Re of the backward
 //                        transform: 5 transforms per frame; wavefront w of a block takes frame T0 + 8 it + w.
 // Both: (float)Re, float x double window, float overlap-add (util.h:247-252,301-302), 1/N inside the gains.
 //
-// Mapping onto the chip (what differs from the 32 x 32 das_f64_fused_kernel of stft_istft.hip):
+// Mapping onto the chip (what differs from round 3's 32 x 32 half-wavefront kernel):
 //   * 64 lanes x 16 points per lane: 64 data + 64 accumulator registers, so TWO wavefronts share a SIMD (the 32 x 32 kernel needs
 //     256 + 206 registers, one wavefront per SIMD, ~1 000 v_accvgpr moves per frame).
 //   * a 512-thread block per CU walks a run of consecutive frames.  First-pass lane = sample, so every global load is one

@@ -289,7 +289,7 @@ __device__ __forceinline__ void wt_fft_inv_p2(float (&re)[32], float (&im)[32], 
 //
 // R > 1 (JACK periods 256 / 128 / 64, frames of N = 1024 / R samples): the unit of work is a GROUP of R consecutive frames
 // interleaved into one 1024-point sequence (z[R m + i] = frame_{R g + i}[m]; the N-point pair gains repeated R times act on every
-// frame separately -- das_fused_small.hip has the identity).  Lane p holds frame p / (32 / R), samples (32 / R) j + p mod (32 / R): the
+// frame separately -- an LTI identity: DESIGN.md 3.3).  Lane p holds frame p / (32 / R), samples (32 / R) j + p mod (32 / R): the
 // lanes of a frame side by side (perm_lane above; with the frames alternating from lane to lane the texture addresser served 4x the
 // cache accesses of R = 1 and was 75 % busy -- profiles/r04_e_pmc_small.txt).  A group yields 512 output samples like a frame does at
 // R = 1, parks the same 512-float second half in the ring, and differs only in where the overlap-add partner sits: in the group's own
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_kernel(DasFusedArgs a) {
 // 9-slot LDS ring of 1024 floats, run boundaries are completed by atomic adds into a zeroed hop -- das_fused_kernel's scheme with a
 // wavefront where it has a half-wavefront.  Gains (64 KB per direction at 8 microphones) come from L2: [pair][bin], natural order
 // (das_pair_gains_natural), a.twiddle = exp(-2 pi i m / 2048), m < 1024, a.window = 2048 floats (the generic kernel's tables).
-// The two-pass kernel of das_fused_w64.hip (0.74 ms per headline batch of samples) is BF_DAS_SPLIT2048=2.
+// (Round 4's two-pass kernels -- two FFT-1024 per frame -- took 0.74 ms per headline batch of samples: removed in round 5.)
 constexpr int kHop2 = 1024, kN2 = 2048, kWaves2 = kBlock / 64;
 constexpr int kWinRow2 = 36;  // floats per lane row of the window (32 + pad: float4 reads of 16-lane groups on distinct banks)
 constexpr int o2Tw = 0, o2Pl = o2Tw + 2 * 32 * 64, o2Win = o2Pl + kWaves2 * kWPlane, o2W64 = o2Win + 64 * kWinRow2, o2Tail = o2W64 + 64,
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(kBlock, 2) void das_fused_wave2048_kernel(DasFusedA
     }
 }
 
-// ---- interleaved input [sample][mic], 4 or 8 microphones (BF_DAS_VARIANT bit 1) ---------------------------------------------
+// ---- interleaved input [sample][mic], 4 or 8 microphones -----------------------------------------------------------------------
 // The generic kernel reads one pair (8 bytes) of every 4 M-byte sample per pass: at M = 8 a wave-instruction touches sixteen
 // 128-byte lines and uses a quarter of each, and the four passes of a frame fetch every line four times through the TCP
 // (0.69 ms per 65 536-frame batch against 0.35 planar).  Here one 16-byte load brings the two pairs of a group (microphones

@@ -177,7 +177,7 @@ inline std::vector<f32x2> das_pair_gains_natural(const SteeringSet &s, int n_pai
 }
 
 
-// Frame-interleaving kernel (das_fused_small.hip; N = 512 / 256 / 128): the N-point pair gains repeated 1024 / N times over the bins of
+// Frame-interleaving (das_fused.hip, group mode; N = 512 / 256 / 128): the N-point pair gains repeated 1024 / N times over the bins of
 // the 1024-point transform, 1/1024 folded in, in the register / lane order of fft1024: [pair][position i][lane l] = D_p[(l + 32 brev5(i)) mod N]
 inline std::vector<f32x2> das_pair_gains_interleaved(const SteeringSet &s, int n_pairs_alloc) {
     const int N = s.n_fft, M = s.n_mics;

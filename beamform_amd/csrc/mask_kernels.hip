@@ -702,7 +702,7 @@ __global__ __launch_bounds__(512) void stft_bins_w64_kernel(StftArgs a, BinsArgs
 
 #endif
 
-// the two deferred problems per frame of stft_bins_fused_kernel: one thread per (stream, frame, q in {N/2, N/2+1})
+// the two deferred problems per frame of the fused STFT + per-bin kernels: one thread per (stream, frame, q in {N/2, N/2+1})
 template <int MP, int ALGO>
 __global__ __launch_bounds__(256) void fused_tail_kernel(BinsArgs b, const f64x2 *xtail, double *aux) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(256, 1) void stft_bins_small_kernel(StftArgs a, Bin
 
 #if BF_NFFT == 2048
 // ---- the same fusion at the 1024-frame JACK period ------------------------------------------------------------------------------------------------
-// X[k] = E[k] + W^k O[k], X[k + 1024] = E[k] - W^k O[k] with E, O = FFT-1024 of the even / odd samples (stft_split_kernel).  Here the two transforms
+// X[k] = E[k] + W^k O[k], X[k + 1024] = E[k] - W^k O[k] with E, O = FFT-1024 of the even / odd samples (as round 4's stft_split_kernel had it).  Here the two transforms
 // of a (frame, microphone pair) run on TWO half-wavefronts side by side, each into its own 16 KB LDS slot, and the radix-2 step is folded into
 // the per-bin stage's spectrum read: eight half-wavefronts = the eight transforms of one frame at 8 microphones (two frames up to 4), 128 KB of
 // slots + 16 KB of inter-pass twiddles; the window and W2048^k come through L1 (the LDS is full).  The c128 spectra (4.3 GB each way per headline

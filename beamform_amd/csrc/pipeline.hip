@@ -212,7 +212,7 @@ class BinPipelineImpl : public BinPipeline {
     int set_state(const void *host) override { return copy_state((char *)host, false); }
 
    private:
-    // das through this pipeline on the tuned shape: eligible for das_f64_fused_kernel (run_one decides per batch)
+    // das through this pipeline on the tuned shape: eligible for the one-launch kernels of das_f64_w64.hip (run_one decides per batch)
     bool das_one_launch_shape() const { return cfg_.algo == BF_DAS && N_ == 1024 && M_ <= 8 && D_ == 1; }
     size_t steer_bytes() const { return (size_t)D_ * N_ * M_ * kMaxCols * sizeof(f64x2); }
     size_t zhist_bytes() const { return Phist_ ? (size_t)S_ * Phist_ * NP_ * N_ * zsz_ : 0; }

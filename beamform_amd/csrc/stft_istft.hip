@@ -852,7 +852,7 @@ __global__ __launch_bounds__(256) void istft_small_kernel(IstftArgs a, int L) {
 // First pass over the registers (n = 64 j + lane64), twiddle W2048^(k1 lane64), a 32 x 64 plane transpose through LDS (row = register position,
 // 64 columns; lane l of half h reads row l, columns 32 h .. 32 h + 31), one radix-2 stage between lane l of half 0 and of half 1
 // (v_permlane32_swap_b32 on the two dwords of a double), a second 32-point pass: position i of lane64 = bin lane64 + 64 brev5(i), a store writes 64
-// consecutive bins.  No even / odd passes, no second read of the samples, 128 data registers.  stft_split_kernel (two FFT-1024 and a radix-2
+// consecutive bins.  No even / odd passes, no second read of the samples, 128 data registers.  Round 4's stft_split_kernel (two FFT-1024 and a radix-2
 // step, the first transform waiting in the accumulator registers): 1.27 ms z48 / 1.46 ms c128 per 32 768 frames of 8 microphones.
 __device__ __forceinline__ void halves_pair_d(double v, double &lo, double &hi) {  // the value of v in lane l of half 0 / of half 1
     unsigned a0 = (unsigned)__double2loint(v), a1 = (unsigned)__double2hiint(v), b0 = a0, b1 = a1;

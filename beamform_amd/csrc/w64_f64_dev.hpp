@@ -17,7 +17,7 @@ constexpr int kPlaneD = 16 * kRS;   // doubles per wavefront
 
 // ---- T2: 4 x 4 transpose across the four 16-lane rows, for doubles (two dwords each) --------------------------------------
 // v_permlane32_swap a, b: rows {2,3} of a <-> rows {0,1} of b;  v_permlane16_swap a, b: odd rows of a <-> even rows of b (lane
-// semantics checked on the device by tools/ubench/permswap.hip; inline asm for the reason given in das_fused_w64.hip).  One block
+// semantics checked on the device by tools/ubench/permswap.hip; the builtins, not inline asm: tied 32-bit halves cost ~4 v_mov per block).  One block
 // moves the low and the high dwords of four doubles: the four independent swaps between a register's two swaps cover the wait
 // states a swap needs behind the instruction that wrote its operand; the leading s_nop covers the VALU in front of the block.
 __device__ __forceinline__ void swap32(unsigned &a, unsigned &b) {
@@ -42,7 +42,7 @@ __device__ __forceinline__ void row_transpose4(double &d0, double &d1, double &d
 }
 constexpr int brev2c(int i) { return ((i & 1) << 1) | ((i >> 1) & 1); }
 
-// T2: position brev2(g) + 4*brev2(q) (row b)  <->  register 4*g + b (row q)   (as das_fused_w64.hip)
+// T2: position brev2(g) + 4*brev2(q) (row b)  <->  register 4*g + b (row q)   
 template <bool FWD>
 __device__ __forceinline__ void w64_T2(double (&re)[16], double (&im)[16]) {
     double nr[16], ni[16];

@@ -241,7 +241,7 @@ extern "C" int emul_fft_small(int n, const double *in, double *out, int dir) {
     return 0;
 }
 
-// N = 2048 around FFT-1024 (stft_split_kernel / istft_split_kernel).  Forward: in = 2048 complex samples, E / O = FFT-1024 of the even / odd ones,
+// N = 2048 around FFT-1024 (istft_split_kernel, stft_bins_split_kernel).  Forward: in = 2048 complex samples, E / O = FFT-1024 of the even / odd ones,
 // X[k] = E[k] + W^k O[k], X[k + 1024] = E[k] - W^k O[k].  Backward (the spectrum of a REAL frame, 2048 complex bins in): A = Y[k] + Y[k + 1024],
 // B = (Y[k] - Y[k + 1024]) conj(W^k), one backward FFT-1024 of A + i B returns sample 2 m in its real and 2 m + 1 in its imaginary part; out = 2048 reals.
 extern "C" void emul_fft2048_split(const double *in, double *out, int dir) {

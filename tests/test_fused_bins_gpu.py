@@ -112,7 +112,7 @@ def same_floats(a, b):
 
 @pytest.mark.parametrize("M,F,S", [(8, 33, 1), (7, 5, 1), (5, 18, 2), (4, 27, 1), (3, 9, 3), (2, 40, 1), (1, 6, 1), (8, 1, 1), (6, 700, 1)])
 def test_das_f64_one_launch_matches_oracle(M, F, S):
-    """das_f64_fused_kernel (BF_DAS_BINS_F64 without a spectrum dump, planar input): the time output against the oracle, odd
+    """das_f64_pair_kernel / das_f64_w64_kernel<1> (BF_DAS_BINS_F64 without a spectrum dump): the time output against the oracle, odd
     microphone counts, several streams, runs that recompute their first frame (F = 700 is cut into runs), and batch cuts."""
     import oracle
     from beamform_amd.capi import BF_DAS_BINS_F64, Beamformer
@@ -196,7 +196,7 @@ def test_fused_equals_two_kernel_chain_at_the_baseline_size(tmp_path):
 
 
 def test_das_f64_one_launch_at_the_baseline_size():
-    """65 536 frames through das_f64_fused_kernel: oracle windows at random offsets and at the kernel's run boundaries (a frame's
+    """65 536 frames through das_f64_pair_kernel: oracle windows at random offsets and at the kernel's chunk boundaries (a frame's
     output hop depends on three input hops only), and equality with the fused fp32 kernel to float accuracy."""
     import oracle
     import torch

@@ -188,7 +188,7 @@ def test_more_than_sixteen_microphones(algo, M, interf, radius, band):
 
 @pytest.mark.parametrize("hop", [64, 256, 1024, 4096])
 def test_fused_das_at_other_periods_layouts_streams_directions_cuts(hop):
-    """The fused fp32 das kernels at the JACK periods other than 512 (das_fused_small.hip below 512, das_fused_w64.hip's split kernel at 1024,
+    """The fused fp32 das kernels at the JACK periods other than 512 (das_fused.hip's group mode below 512, das_fused_wave2048_kernel at 1024,
     das_fused_gen.hip above): interleaved input, several streams, look directions, a long batch cut into runs (every run but the first
     recomputes its previous frame or group), uneven batch cuts -- against the oracle."""
     import oracle
@@ -226,7 +226,7 @@ def test_fused_das_at_other_periods_layouts_streams_directions_cuts(hop):
     if hop >= 512:
         assert np.array_equal(parts, whole)
     else:
-        # below 512 frames 1024 / N consecutive frames share one transform (das_fused_small.hip): which ones depends on where a batch starts, so
+        # below 512 frames 1024 / N consecutive frames share one transform (das_fused.hip, group mode): which ones depends on where a batch starts, so
         # the cuts agree to the rounding of the fp32 transform (1e-7 of the signal's scale), not bit for bit
         assert np.abs(parts.astype(np.float64) - whole).max() <= 1e-6 * np.abs(whole).max()
         assert rel_l2(parts, ref) < TOL

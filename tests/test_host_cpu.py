@@ -38,7 +38,7 @@ def test_emulated_fft32_and_fft1024(emul_lib):
 
 def test_emulated_small_and_split_transforms(emul_lib):
     """fft_small.hpp (N = 32 x NL: 1024 / N frames side by side through one transpose plane, an NL-point second pass per frame -- the transforms of
-    stft_small_kernel / istft_small_kernel) and the radix-2 steps around FFT-1024 that stft_split_kernel / istft_split_kernel use at N = 2048,
+    stft_small_kernel / istft_small_kernel) and the radix-2 steps around FFT-1024 that istft_split_kernel / stft_bins_split_kernel use at N = 2048,
     instantiated on the CPU against numpy: index maps, twiddles, the one-transform backward path of a real frame."""
     rng = np.random.default_rng(7)
     for n in (512, 256, 128):
