@@ -48,12 +48,23 @@ struct FastPlan {
     int tile, tiles, waves_per_stream;
 };
 
+// one row of 64 stored elements, global -> LDS (lane l's 12 or 16 bytes land at row + 16 l)
+template <bool Z128>
+__device__ __forceinline__ void lds_dma(const char *g, void *l) {
+    if constexpr (Z128)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+    else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 12, 0, 0);
+}
+
 // KC = constraint columns: 1 = mvdr (the steering vector); 2..4 = lcmv with up to KC - 1 interferers (lcmv.cpp:102-130): the
 // columns C ride through the factorisation like the steering vector does (U = L^-1 C, v = L^-1 x), then G = U^H U, g = U^H v and
 // y = (G^-1 g)_0 -- the first row of W^H x with W = R^-1 C (C^H R^-1 C)^-1.  Unused columns are padded with the identity.
-template <int MP, int KC>
+// Z128: the spectra are complex doubles (BF_Z48=0: 16 bytes per element, stored unhalved) instead of z48 (12 bytes, stored halved)
+template <int MP, int KC, bool Z128>
 __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan fp) {
     constexpr int NT = MP * (MP + 1) / 2;
+    constexpr long kZB = Z128 ? (long)sizeof(f64x2) : (long)sizeof(z48);  // bytes per stored element
     const int lane = threadIdx.x;
     const int s = blockIdx.x / fp.waves_per_stream;  // output stream: uniform per wavefront
     const int id0 = (blockIdx.x - s * fp.waves_per_stream) * 64;
@@ -74,12 +85,11 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
     if (!live) cnt = 0;
     const int M = a.n_mics, NP = (M + 1) >> 1, P = a.cfg.past_windows;
     // frame tA0 of this stream's packed spectra (uniform) + a 32-bit per-lane byte offset: SGPR base + VGPR offset addressing
-    const char *Zu = reinterpret_cast<const char *>(reinterpret_cast<const z48 *>(a.Z) +
-                                                    ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off + tA0) * NP * kN);
+    const char *Zu = reinterpret_cast<const char *>(a.Z) + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off + tA0) * NP * kN * kZB;
     const int ksrc = q_src_bin(q), kneg = (kN - ksrc) & (kN - 1);
-    const unsigned vk = (unsigned)(((long)dt * NP * kN + ksrc) * (long)sizeof(z48));
-    const unsigned vn = (unsigned)(((long)dt * NP * kN + kneg) * (long)sizeof(z48));
-    const long frame_bytes = (long)NP * kN * (long)sizeof(z48);
+    const unsigned vk = (unsigned)(((long)dt * NP * kN + ksrc) * kZB);
+    const unsigned vn = (unsigned)(((long)dt * NP * kN + kneg) * kZB);
+    const long frame_bytes = (long)NP * kN * kZB;
     const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride + j;
     const long yidx = ((long)s * a.n_frames + tA0 + dt) * kYhStride + q;
 
@@ -96,24 +106,26 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
         const char *bn = Zu + i * frame_bytes, *bo = Zu + (i - P) * frame_bytes;
 #pragma unroll
         for (int p = 0; p < MP / 2; ++p) {
-                const long po = (long)p * kN * (long)sizeof(z48);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bn + po + vk),
-                                                 (__attribute__((address_space(3))) void *)&s_pf[buf][2 * p][0], 12, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bn + po + vn),
-                                                 (__attribute__((address_space(3))) void *)&s_pf[buf][2 * p + 1][0], 12, 0, 0);
+                const long po = (long)p * kN * kZB;
+                lds_dma<Z128>(bn + po + vk, &s_pf[buf][2 * p][0]);
+                lds_dma<Z128>(bn + po + vn, &s_pf[buf][2 * p + 1][0]);
                 if (with_old) {
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bo + po + vk),
-                                                     (__attribute__((address_space(3))) void *)&s_pf[buf][MP + 2 * p][0], 12, 0, 0);
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bo + po + vn),
-                                                     (__attribute__((address_space(3))) void *)&s_pf[buf][MP + 2 * p + 1][0], 12, 0, 0);
+                    lds_dma<Z128>(bo + po + vk, &s_pf[buf][MP + 2 * p][0]);
+                    lds_dma<Z128>(bo + po + vn, &s_pf[buf][MP + 2 * p + 1][0]);
                 }
             }
     };
     auto unpack = [&](int buf, int base, cd (&X)[MP]) {  // microphone spectra out of the prefetched rows (z48 is stored halved)
 #pragma unroll
         for (int p = 0; p < MP / 2; ++p) {
-            const cd z = dec48(s_pf[buf][base + 2 * p][lane].v);
-            const cd c = dec48(s_pf[buf][base + 2 * p + 1][lane].v);  // Z[N-k], conjugated on the fly
+            cd z, c;  // Z[k] / 2 and Z[N-k] / 2 (the latter conjugated on the fly)
+            if constexpr (Z128) {
+                z = ld(reinterpret_cast<const f64x2 *>(&s_pf[buf][base + 2 * p][lane])) * 0.5;
+                c = ld(reinterpret_cast<const f64x2 *>(&s_pf[buf][base + 2 * p + 1][lane])) * 0.5;
+            } else {
+                z = dec48(s_pf[buf][base + 2 * p][lane].v);
+                c = dec48(s_pf[buf][base + 2 * p + 1][lane].v);
+            }
             X[2 * p] = cd{z.x + c.x, z.y - c.y};      // (Z[k] + conj Z[N-k]) / 2
             X[2 * p + 1] = cd{z.y + c.y, c.x - z.x};  // (Z[k] - conj Z[N-k]) / (2i)
         }
@@ -877,7 +889,8 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
     const int tps = (int)((a.n_frames + tile - 1) / tile);
     const int M = a.n_mics, km = a.kp1 <= 1 ? 1 : 4;
     static const bool no_fast_env = getenv("BF_MVDR_GROUP") && atoi(getenv("BF_MVDR_GROUP")) != 0;
-    const bool no_fast = no_fast_env || !a.z48;  // full-double spectra (BF_Z48=0): the group-per-problem kernel reads them
+    const bool no_fast = no_fast_env;
+    const bool no_2d = no_fast_env || !a.z48;  // cov2d_kernel reads z48 spectra only (BF_Z48=0 at 9..16 microphones: the group-per-problem kernel)
     // frequencies of the irregular problems (quirk Q1, util.h:190-199): f[N/2] = 0, f[N/2+1] = -(N/2-1) sr/N
     const double f_qx = (double)(kN / 2 - 1) * a.cfg.sample_rate / (double)kN;
     const bool band_hits_nyquist = (0.0 >= a.cfg.freq_min && 0.0 <= a.cfg.freq_max) || (f_qx >= a.cfg.freq_min && f_qx <= a.cfg.freq_max);
@@ -910,7 +923,7 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
     // 9..16 microphones, up to 3 interferers: 2-D cyclic 4 x 4 lanes per problem.  Wavefronts per SIMD: with constraint columns (lcmv) the
     // three-wavefront build spills 30 registers per lane and the spill traffic alone is 6 GB per 32 768 frames of 16 microphones: two
     // wavefronts at 211 registers are 7 % faster; without constraints (mvdr) three wavefronts win by 12 %
-    if (!no_fast && M > 8 && M <= 16) {
+    if (!no_2d && M > 8 && M <= 16) {
         const dim3 grid((unsigned)(((long)tps * a.n_streams + 7) / 8 * 8 * ((kNQ + 15) / 16)));  // (unit, problem group) -> XCD-aware order in the kernel
         if (km == 1) BF_LAUNCH((cov2d_kernel<1, 3>), grid, dim3(256), 0, s, a, tile, tps);
         else BF_LAUNCH((cov2d_kernel<4, 2>), grid, dim3(256), 0, s, a, tile, tps);
@@ -964,7 +977,11 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
         else if (a.yh_lo == 0 && fp.nb < kNQ)  // f32x2 rows that the backward transform reads in full (a band up to the Nyquist problems) while part of them is out of band
             (void)hipMemsetAsync(a.Yh, 0, (size_t)a.n_streams * a.n_frames * kYhStride * sizeof(f32x2), s);
         const dim3 grid((unsigned)((long)fp.waves_per_stream * a.n_streams));
-#define BF_FAST_GO(MP_, KC_) BF_LAUNCH((mvdr_fast_kernel<MP_, KC_>), grid, dim3(64), 0, s, a, fp)
+#define BF_FAST_GO(MP_, KC_)                                                                     \
+    do {                                                                                         \
+        if (a.z48) BF_LAUNCH((mvdr_fast_kernel<MP_, KC_, false>), grid, dim3(64), 0, s, a, fp);  \
+        else BF_LAUNCH((mvdr_fast_kernel<MP_, KC_, true>), grid, dim3(64), 0, s, a, fp);         \
+    } while (0)
         if (!lcmv_fast || a.kp1 <= 1) {  // lcmv without interferers = mvdr except problem 0
             if (M <= 2) BF_FAST_GO(2, 1);
             else if (M <= 4) BF_FAST_GO(4, 1);

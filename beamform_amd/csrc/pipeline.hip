@@ -347,7 +347,7 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     if (!try_fused)
         // (+ 512 frames of slack behind the last stream: mvdr_fast_kernel's lanes of a short last tile prefetch up to one tile
         // length past the end of their stream and never use what they fetched)
-        rc = ensure((void **)&d_Z_, &Z_cap_, ((size_t)S_ * FT + (z48_ ? 512 : 0)) * NP_ * N_ * zsz_);
+        rc = ensure((void **)&d_Z_, &Z_cap_, ((size_t)S_ * FT + ((cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV) ? 512 : 0)) * NP_ * N_ * zsz_);
     else  // the fused kernel parks the unpacked spectra of two bins per frame here (stream x frame x 2 x 8 microphones)
         rc = ensure((void **)&d_Z_, &Z_cap_, (size_t)S_ * F * 2 * 8 * sizeof(f64x2));
     if (rc != BF_OK) return rc;

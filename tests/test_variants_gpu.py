@@ -52,8 +52,11 @@ CASES = [
     ({"BF_MVDR_TILE": "7"}, "mvdr", 8, (), 40, False),                 # mvdr_fast_kernel: lanes straddle tiles, short last tile
     ({"BF_ISTFT_F64": "1"}, "mvdr", 8, (), 30, False),                 # fp64 backward transform behind every node
     ({"BF_ISTFT_F64": "1"}, "phase", 8, (), 24, True),
-    ({"BF_Z48": "0"}, "mvdr", 8, (), 30, True),                        # full-double spectra in HBM (no z48 packing), group kernel
-    ({"BF_Z48": "0"}, "lcmv", 16, (-60.0, 90.0, 150.0), 24, True),
+    ({"BF_Z48": "0"}, "mvdr", 8, (), 30, True),                        # full-double spectra in HBM (no z48 packing): mvdr_fast_kernel<8, 1, true>
+    ({"BF_Z48": "0", "BF_MVDR_TILE": "7"}, "lcmv", 8, (-60.0, 90.0), 40, True),   # ... <8, 3, true>, lanes straddle tiles
+    ({"BF_Z48": "0"}, "mvdr", 3, (), 30, False),                       # ... <4, 1, true>: an odd microphone count's zero partner channel
+    ({"BF_Z48": "0", "BF_MVDR_GROUP": "1"}, "mvdr", 8, (), 30, True),  # ... read by the group-per-problem kernel
+    ({"BF_Z48": "0"}, "lcmv", 16, (-60.0, 90.0, 150.0), 24, True),     # 9..16 microphones: group kernel (cov2d_kernel reads z48 only)
     ({"BF_GSC_SERIAL": "1"}, "gsc", 4, (), 10, False),                  # gsc_nlms_kernel: the sums in the reference's tap order, one branch per lane
     ({"BF_GSC_SERIAL": "1"}, "gsc", 8, (), 8, False),
     ({}, "gsc", 2, (), 8, False),                                       # one blocking branch: gsc_nlms_par_kernel (one wavefront per stream)
