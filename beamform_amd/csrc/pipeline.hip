@@ -5,7 +5,7 @@
 //                   packed spectra Z_p = FFT(a + i b) go to an HBM workspace
 //   *_bins_kernel : the node's per-bin loop of apply_weights(); unpacks
 //                   X_a[k] = (Z[k] + conj Z[N-k])/2, X_b[k] = (Z[k] - conj Z[N-k])/(2i) on load
-//   istft_kernel  : fftw_execute(y_inverse) + overlap_and_add_prepare_output + do_overlap's
+//   istft_w64_kernel / istft32_kernel : fftw_execute(y_inverse) + overlap_and_add_prepare_output + do_overlap's
 //                   overlap-add (das.cpp:66, util.h:244-253,301-302), two frames per complex
 //                   IFFT (Hermitian half-spectra in, real frames out as re / im)
 //
@@ -455,6 +455,7 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     ia.Yh = d_Yh_; ia.y = (cfg_.algo == BF_PHASEMPF || cfg_.algo == BF_GSC) ? d_yraw_ : y; ia.tail_in = d_tail_[tail_cur_];
     ia.tail_out = d_tail_[tail_cur_ ^ 1]; ia.tw = d_tw_; ia.win = d_win_; ia.n_frames = F; ia.n_streams = So_;
     ia.tw32 = istft32 ? d_tw32_ : nullptr;
+    ia.tw_w64 = d_tw_w64_;
     ia.yh32 = ba.yh32; ia.yh_lo = ba.yh_lo; ia.yh_hi = ba.yh_hi;
     if (ba.mpf32) {  // rows of 8-byte elements behind the f64x2 rows (where aux lives), every problem written
         ia.Yh = d_Yh_ + (size_t)So_ * F * YS_;

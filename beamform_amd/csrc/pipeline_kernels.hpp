@@ -92,6 +92,7 @@ struct IstftArgs {
     float *tail_out;
     const f64x2 *tw;
     const f32x2 *tw32;     // non-null: backward FFT in fp32, one frame per transform (istft32_kernel; N = 1024 only)
+    const f64x2 *tw_w64 = nullptr;  // non-null (N = 1024): twiddle_table_w64_rot, the fp64 backward transform runs istft_w64_kernel
     float *frames;         // N != 1024: [stream][n_frames][N] windowed frames (generic kernel), overlap-added by a second pass
     const double *win;
     long n_frames;

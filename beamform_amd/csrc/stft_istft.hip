@@ -139,171 +139,168 @@ __global__ __launch_bounds__(256) void stft_kernel(StftArgs a) {
 }
 
 // ======================================================================================
-//                                        ISTFT
+//                 ISTFT in double on the 64-lane transform (BF_ISTFT_F64=1, and gsc always)
 // ======================================================================================
-constexpr int kIstftBlock = 256;
-constexpr int kIstftHalves = kIstftBlock / 32;
+// The back half of das_f64_pair_kernel as a kernel of its own: one full wavefront per transform (64 lanes x 16 points, fft1024_w64.hpp),
+// two frames per complex transform (Ya + i Yb -> real part = frame a, imaginary part = frame b), a run of consecutive frames per
+// wavefront with the overlap-add tail carried in registers (one warm-up frame per run), two wavefronts per SIMD.  Register r = 4 g + k3 of
+// lane l holds bin l + 64 g + 256 k3 (w64_bin): k3 < 2 reads row[l + 64 g + 256 k3], k3 >= 2 the conjugate of row[(64 - l) + 64 (3 - g) +
+// 256 (3 - k3)]: 1 KiB per wave-instruction either way.  util.h:244-253, 301-302.  0.157 ms per 65 536 frames (round 4's half-wavefront
+// kernel, one 32 x 32 transform per 32 lanes at one wavefront per SIMD: 0.55; the fp32 istft32_kernel below: 0.148).
+constexpr int kIw64Block = 256;
+constexpr int kIw64Waves = kIw64Block / 64;
+constexpr int kIw64TwD = 2 * (960 + 4 * kTw2RowW64Rot);  // tw1 rows k1 = 1..15 + tw2' (a.tw_w64 + 64), in doubles
+constexpr int kIw64WinRow = 18;                          // window as [lane][j] rows of 16 doubles + 2
+constexpr int oIwPlane = kIw64TwD;
+constexpr int oIwWin = oIwPlane + kIw64Waves * kPlaneD;
+constexpr int kIw64Lds = oIwWin + 64 * kIw64WinRow;
 
-// Hermitian part of y_fft at bin k (0..1023) from the per-bin kernels' output row.
-__device__ __forceinline__ cd herm_at(const f64x2 *row, int k) {
-    if (k == 0 || k == 512) return cd{row[k].x, 0.0};
-    if (k == 511) {
-        const cd u = ld(row + 511), v = conj(ld(row + 513));
-        return (u + v) * 0.5;
-    }
-    if (k == 513) {
-        const cd u = ld(row + 513), v = conj(ld(row + 511));
-        return (u + v) * 0.5;
-    }
-    if (k < 512) return ld(row + k);
-    return conj(ld(row + (kN - k)));
-}
-
-__global__ __launch_bounds__(kIstftBlock) void istft_kernel(IstftArgs a, int pairs_per_chunk, int chunks_per_stream) {
-    __shared__ __attribute__((aligned(16))) double lds[2048 + kIstftHalves * 32 * kPSd];
-    const cx<double> *s_tw = reinterpret_cast<const cx<double> *>(lds);
-    const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
-    double *pbuf = lds + 2048 + hw * 32 * kPSd;
+__global__ __launch_bounds__(kIw64Block, 2) void istft_w64_kernel(IstftArgs a, int pairs_per_run, int runs_per_stream) {
+    __shared__ __attribute__((aligned(16))) double lds[kIw64Lds];
+    const cx<double> *s_tw1 = reinterpret_cast<const cx<double> *>(lds) - 64;  // row k1 starts at 64 (k1 - 1)
+    const cx<double> *s_tw2 = reinterpret_cast<const cx<double> *>(lds) + 960;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *plane = lds + oIwPlane + w * kPlaneD;
+    double *wcol = plane + w64_col_rot(lane);
+    double *row16 = plane + (lane & 15) * kRS + 16 * (lane >> 4);
+    const double *wrow = lds + oIwWin + lane * kIw64WinRow;
     {
-        const double *twf = reinterpret_cast<const double *>(a.tw);
-        for (int i = tid; i < 2048; i += kIstftBlock) lds[i] = twf[i];
+        const f64x2 *tw2 = a.tw_w64 + 64;
+        f64x2 *ltw = reinterpret_cast<f64x2 *>(lds);
+        for (int i = tid; i < kIw64TwD / 2; i += kIw64Block) ltw[i] = tw2[i];
+        for (int i = tid; i < 1024; i += kIw64Block) lds[oIwWin + (i & 63) * kIw64WinRow + (i >> 6)] = a.win[i];
     }
     __syncthreads();
-    const double *gwin = a.win + lane;
-    const long chunk = (long)blockIdx.x * kIstftHalves + hw;
-    int s = (int)(chunk / chunks_per_stream);
-    const long c_in_s = chunk - (long)s * chunks_per_stream;
-    const bool chunk_ok = s < a.n_streams;
-    if (!chunk_ok) s = a.n_streams - 1;
-    const long t0 = c_in_s * 2L * pairs_per_chunk;  // first frame of this run (even)
+    const long run = (long)blockIdx.x * kIw64Waves + w;
+    int s = (int)(run / runs_per_stream);
+    const long r_in_s = run - (long)s * runs_per_stream;
+    const bool run_ok = s < a.n_streams;  // wavefront-uniform; no block barrier below
+    if (!run_ok) return;
+    const long t0 = r_in_s * 2L * pairs_per_run;  // first frame of this run (even)
+    if (t0 >= a.n_frames) return;
+    long t1 = t0 + 2L * pairs_per_run;
+    if (t1 > a.n_frames) t1 = a.n_frames;
     const f64x2 *Ys = a.Yh + (long)s * a.n_frames * kYhStride;
     float *ys = a.y + (long)s * a.n_frames * kHop;
 
-    float tail[16];  // second half of the previous frame, as float (out_buff[0], util.h:302)
+    // Each step takes frames (t, t + 1) through one transform -- or frame t alone: the warm-up frame t0 - 1 (only its second half, the
+    // overlap-add tail, is used), the last frame of an odd run, and any pair with a non-finite value in it (a frame the reference turns
+    // into NaN / Inf -- mvdr / lcmv: inverse of an all-zero covariance -- would poison its partner through the shared transform).
+    float tail[8];  // second half of the previous frame, as float (out_buff[0], util.h:302): register j <- sample 512 + 64 j + lane
+    long t = t0;
+    if (t0 == 0) {  // stream start: the tail is the carried state
+        const float *ti = a.tail_in + (long)s * kHop;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) tail[q] = 0.f;
-    double re[32], im[32];
-
-    for (int it = 0; it <= pairs_per_chunk; ++it) {
-        const long ta = t0 - 2 + 2L * it;  // frames (ta, ta+1); it == 0 is the warm-up pair
-        const bool va = ta >= 0 && ta < a.n_frames;
-        const bool vb = ta + 1 >= 0 && ta + 1 < a.n_frames;
-        const f64x2 *ra = Ys + (va ? ta : 0) * kYhStride;
-        const f64x2 *rb = Ys + (vb ? ta + 1 : 0) * kYhStride;
-        float oa[32], ob[32];
-        // Two frames share one complex IFFT (Ya + i*Yb -> re = frame a, im = frame b).  A frame the
-        // reference turns into NaN/Inf (mvdr/lcmv: inverse of an all-zero covariance) would
-        // poison its partner through the shared transform, so such pairs are transformed one at a time.
-        // Hermitian extension of both rows straight into Ya + i*Yb.  Position i holds bin k = lane + 32*brev5(i): even i
-        // are bins < 512 (the stored row), odd i are bins >= 512 (conjugate of row[1024 - k]); only three positions touch
-        // the irregular bins 0 / 511 / 512 / 513 (quirk Q1), so the rest is branch-free.
-        auto load_pair = [&](bool useA, bool useB) {
+        for (int j = 0; j < 8; ++j) tail[j] = ti[(unsigned)(64 * j + lane)];
+    } else {
+        t = t0 - 1;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                constexpr int dummy = 0;
-                (void)dummy;
-                const int kb = 32 * brev5(i);
-                cd u{0, 0}, v{0, 0};
-                if (kb < 512) {
-                    if (useA) u = ld(ra + kb + lane);
-                    if (useB) v = ld(rb + kb + lane);
-                } else {
-                    if (useA) u = conj(ld(ra + (kN - kb) - lane));
-                    if (useB) v = conj(ld(rb + (kN - kb) - lane));
-                }
-                if (i == 0 && lane == 0) {  // bin 0: real part only
-                    u.y = 0.0;
-                    v.y = 0.0;
-                }
-                if (i == 1) {  // bins 512 (lane 0: real part only) and 513 (lane 1: (Y[513] + conj Y[511]) / 2)
-                    if (lane == 0) {
-                        u.y = 0.0;
-                        v.y = 0.0;
-                    } else if (lane == 1) {
-                        if (useA) u = (ld(ra + 513) + u) * 0.5;
-                        if (useB) v = (ld(rb + 513) + v) * 0.5;
-                    }
-                }
-                if (i == 30 && lane == 31) {  // bin 511: (Y[511] + conj Y[513]) / 2
-                    if (useA) u = (u + conj(ld(ra + 513))) * 0.5;
-                    if (useB) v = (v + conj(ld(rb + 513))) * 0.5;
-                }
-                re[i] = u.x - v.y;  // Ya + i*Yb
-                im[i] = u.y + v.x;
-            }
-        };
-        load_pair(va, vb);
-        bool bad = false;  // a non-finite value in either frame makes the combination non-finite
+        for (int j = 0; j < 8; ++j) tail[j] = 0.f;
+    }
+    // Hermitian extension of a row (register r of lane l <- bin l + 64 g + 256 k3); the irregular bins 0 / 511 / 512 / 513 (quirk Q1):
+    // Y[511] and Y[513] averaged with each other's conjugate, Y[0] and Y[512] real, by selects.  Every load is unconditional.
+    auto load_row = [&](const f64x2 *row, cd (&u)[16]) {
+        const cd y513 = ld(row + 513);
 #pragma unroll
-        for (int i = 0; i < 32; ++i) bad = bad || !(isfinite(re[i]) && isfinite(im[i]));
-        const bool split = __any(bad ? 1 : 0) != 0;
-        for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
-            const bool useA = va && (!split || pass == 0);
-            const bool useB = vb && (!split || pass == 1);
-            if (split) load_pair(useA, useB);  // rare: one frame at a time
-            fft1024p_inv_A<double>(re, im, lane, s_tw, pbuf);
-            __builtin_amdgcn_wave_barrier();
-            fft1024p_B<double>(re, lane, pbuf);
-            __builtin_amdgcn_wave_barrier();
-            fft1024p_C<double, true>(im, lane, pbuf);
-            __builtin_amdgcn_wave_barrier();
-            fft1024p_D<double, +1>(re, im, lane, pbuf);
-            __builtin_amdgcn_wave_barrier();
-
-            // position i: sample n = 32*brev5(i) + lane.  re -> frame ta, im -> frame ta+1.
-            // overlap_and_add_prepare_output (util.h:247-252) with the reference's float stores.
+        for (int r = 0; r < 16; ++r) {
+            const int g = r >> 2, k3 = r & 3;
+            if (k3 < 2) u[r] = ld(row + (unsigned)(lane + 64 * g + 256 * k3));
+            else u[r] = conj(ld(row + (unsigned)(64 * (3 - g) + 256 * (3 - k3) + 64 - lane)));
+        }
+        u[0].y = lane == 0 ? 0.0 : u[0].y;  // bins 0 and 512: real part only
+        const cd m513 = (y513 + u[2]) * 0.5, m511 = (u[13] + conj(y513)) * 0.5;
+        u[2].x = lane == 1 ? m513.x : u[2].x;  // bin 513: (Y[513] + conj Y[511]) / 2
+        u[2].y = lane == 1 ? m513.y : lane == 0 ? 0.0 : u[2].y;
+        u[13].x = lane == 63 ? m511.x : u[13].x;  // bin 511 = 63 + 64 * 3 + 256: (Y[511] + conj Y[513]) / 2
+        u[13].y = lane == 63 ? m511.y : u[13].y;
+    };
+    // register j: sample n = 64 j + lane.  overlap_and_add_prepare_output (util.h:247-252) with the reference's float stores
+    auto window = [&](const double (&x)[16], float (&o)[16]) {
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const double h = gwin[32 * brev5(i)];
-                float fa = (float)(re[i] / 1024.0);
-                fa = (float)((double)fa * h);
-                float fb = (float)(im[i] / 1024.0);
-                fb = (float)((double)fb * h);
-                if (a.use_post_amp) {  // mvdr.cpp:112-114
-                    fa = (float)((double)fa * a.post_amp);
-                    fb = (float)((double)fb * a.post_amp);
-                }
-                if (useA || (!va && pass == 0)) oa[i] = fa;
-                if (useB || (!vb && pass == 0)) ob[i] = fb;
+        for (int j = 0; j < 16; ++j) {
+            float f = (float)(x[j] * (1.0 / 1024.0));
+            f = (float)((double)f * wrow[j]);
+            if (a.use_post_amp) f = (float)((double)f * a.post_amp);  // mvdr.cpp:112-114
+            o[j] = f;
+        }
+    };
+    while (t < t1) {
+        const bool warm = t < t0;
+        bool pair = !warm && t + 1 < t1;
+        const f64x2 *ra = Ys + t * kYhStride, *rb = pair ? ra + kYhStride : ra;
+        double re[16], im[16];
+        {
+            cd u[16];
+            load_row(ra, u);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                re[r] = u[r].x;
+                im[r] = u[r].y;
             }
         }
-        const bool st_a = chunk_ok && it > 0 && va;
-        const bool st_b = chunk_ok && it > 0 && vb;
-        if (it == 0 && t0 == 0) {  // stream start: tail comes from the carried state, not from frame -1
-            const float *ti = a.tail_in + (long)s * kHop + lane;
+        BF_STAGE();
+        if (pair) {
+            cd v[16];
+            load_row(rb, v);
+            int bad = 0;  // (no short circuit: v_cmp_class, not branches)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) tail[q] = ti[32 * brev5(2 * q)];
-        } else if (it == 0) {
+            for (int r = 0; r < 16; ++r) bad |= (int)!isfinite(re[r]) | (int)!isfinite(im[r]) | (int)!isfinite(v[r].x) | (int)!isfinite(v[r].y);
+            pair = __builtin_amdgcn_ballot_w64(bad != 0) == 0;
+            if (pair) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) tail[q] = ob[2 * q + 1];
+                for (int r = 0; r < 16; ++r) {  // Ya + i Yb
+                    re[r] -= v[r].y;
+                    im[r] += v[r].x;
+                }
+            }
         }
-        if (it > 0) {
-            if (st_a) {
-                float *yo = ys + ta * kHop + lane;
+        cx<double> tw[15];
+        BF_STAGE();
+        load_tw2<1, 16>(tw, s_tw2, lane);
+        BF_STAGE();
+        w64_inv_p3<double>(re, im);
+        w64_T2_any<false>(re, im, row16 - 16 * (lane >> 4), lane >> 4);
+        BF_STAGE();
+        mul_tw<true, 1, 16>(re, im, tw);
+        BF_STAGE();
+        load_tw1<1, 16>(tw, s_tw1, lane);
+        BF_STAGE();
+        fft16_core<double, +1, false>(re, im);
+        BF_STAGE();
+        T1_inv(re, im, row16, wcol);
+        BF_STAGE();
+        mul_tw<true, 1, 16>(re, im, tw);
+        fft16_core<double, +1, false>(re, im);
+        BF_STAGE();
+        float oa[16];
+        window(re, oa);  // real part: frame t
+        if (!warm) {
+            float *yo = ys + t * kHop;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) yo[32 * brev5(2 * q)] = tail[q] + oa[2 * q];
-            }
-            if (st_b) {
-                float *yo = ys + (ta + 1) * kHop + lane;
+            for (int j = 0; j < 8; ++j) yo[(unsigned)(64 * j + lane)] = tail[j] + oa[j];
+        }
+        if (pair) {
+            float ob[16];
+            window(im, ob);  // imaginary part: frame t + 1
+            float *yo = ys + (t + 1) * kHop;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) yo[32 * brev5(2 * q)] = oa[2 * q + 1] + ob[2 * q];
-            }
-            if (st_a && ta == a.n_frames - 1) {  // odd frame count: the batch ends on frame a
-                float *to = a.tail_out + (long)s * kHop + lane;
+            for (int j = 0; j < 8; ++j) yo[(unsigned)(64 * j + lane)] = oa[j + 8] + ob[j];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) to[32 * brev5(2 * q)] = oa[2 * q + 1];
-            }
-            if (st_b && ta + 1 == a.n_frames - 1) {
-                float *to = a.tail_out + (long)s * kHop + lane;
+            for (int j = 0; j < 8; ++j) tail[j] = ob[j + 8];
+            t += 2;
+        } else {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) to[32 * brev5(2 * q)] = ob[2 * q + 1];
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) tail[q] = ob[2 * q + 1];
+            for (int j = 0; j < 8; ++j) tail[j] = oa[j + 8];
+            t += 1;
         }
     }
+    if (t1 == a.n_frames) {  // the batch ends in this run: out_buff[0] of the next call
+        float *to = a.tail_out + (long)s * kHop;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) to[(unsigned)(64 * j + lane)] = tail[j];
+    }
 }
-
 
 // ======================================================================================
 //                          ISTFT, single-precision transform
@@ -1217,14 +1214,15 @@ hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s) {
         return hipGetLastError();
     }
     const long pairs = (a.n_frames + 1) / 2;
-    long slots = (long)n_cus * kIstftHalves * 2 / a.n_streams;
+    if (a.tw_w64 == nullptr) return hipErrorInvalidValue;
+    // one run per wavefront slot (2 blocks x 4 wavefronts per CU), every run recomputes one warm-up frame
+    long slots = (long)n_cus * kIw64Waves * 2 / a.n_streams;
     if (slots < 1) slots = 1;
-    long cps = slots < pairs ? slots : pairs;
-    const long ppc = (pairs + cps - 1) / cps;
-    cps = (pairs + ppc - 1) / ppc;
-    const long chunks = cps * a.n_streams;
-    BF_LAUNCH(istft_kernel, dim3((unsigned)((chunks + kIstftHalves - 1) / kIstftHalves)), dim3(kIstftBlock), 0, s, a,
-                       (int)ppc, (int)cps);
+    long rps = slots < pairs ? slots : pairs;
+    const long ppr = (pairs + rps - 1) / rps;
+    rps = (pairs + ppr - 1) / ppr;
+    const long runs = rps * a.n_streams;
+    BF_LAUNCH(istft_w64_kernel, dim3((unsigned)((runs + kIw64Waves - 1) / kIw64Waves)), dim3(kIw64Block), 0, s, a, (int)ppr, (int)rps);
     return hipGetLastError();
 }
 
