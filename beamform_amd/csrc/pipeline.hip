@@ -396,15 +396,19 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     ba.n_dirs = D_; ba.steer_dir_stride = snap.steer_dir_stride;
     ba.z48 = z48_ ? 1 : 0;
     ba.cfg = cfg_; ba.gssW = d_gssW_; ba.mpf = d_mpf_; ba.gss_reset_mask = snap.gss_reset_mask;
-    // backward transform in fp32 (no error amplification behind the per-bin stage; output is float32), except for gsc, whose
-    // sample-serial NLMS branches on the aligned signals
+    // Backward transform: in fp32 behind the per-bin stages that hand it f32x2 rows (das / phase through the bin pipeline, mvdr / lcmv,
+    // phasempf: no error amplification behind the per-bin stage, the output is a float32 sample); in double (istft_w64_kernel: the same
+    // 0.15 ms per 65 536 frames) wherever the rows are f64x2 anyway -- gss, mcra, gsc (whose sample-serial NLMS branches on the aligned
+    // signals), any node with a spectrum dump -- and everywhere under BF_ISTFT_F64=1
     static const bool istft_f64 = getenv("BF_ISTFT_F64") && atoi(getenv("BF_ISTFT_F64")) != 0;
-    const bool istft32 = !(cfg_.algo == BF_GSC || istft_f64 || N_ != 1024);
+    const bool want32 = !(cfg_.algo == BF_GSC || istft_f64 || N_ != 1024) && spectrum == nullptr;
     // mvdr / lcmv hand the fp32 transform f32x2 rows holding only problem 0 and the in-band problems (everything else is zero,
-    // mvdr.cpp:103); a spectrum dump keeps the f64x2 rows
-    // das / phase through the bin pipeline: f32x2 rows too (every problem written), their per-bin stage has no reader but the transform
-    const bool pointwise32 = (cfg_.algo == BF_DAS || cfg_.algo == BF_PHASE) && istft32 && spectrum == nullptr;
-    ba.yh32 = ((z48_ && istft32 && spectrum == nullptr) || pointwise32) ? 1 : 0;
+    // mvdr.cpp:103); das / phase through the bin pipeline: f32x2 rows too (every problem written)
+    const bool pointwise32 = (cfg_.algo == BF_DAS || cfg_.algo == BF_PHASE) && want32;
+    ba.yh32 = ((z48_ && want32) || pointwise32) ? 1 : 0;
+    // phasempf: the recursion's y_fft has no reader but the fp32 backward transform either: f32x2 rows in the |out_int|^2 slots
+    ba.mpf32 = (cfg_.algo == BF_PHASEMPF && want32) ? 1 : 0;
+    const bool istft32 = ba.yh32 != 0 || ba.mpf32 != 0;
     ba.yh_lo = 0; ba.yh_hi = NQ_ - 1;
     if (ba.yh32 && z48_) {
         int klo = N_, khi = 0;
@@ -415,8 +419,6 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
         if (khi < N_ / 2 - 1 && klo <= khi) { ba.yh_lo = klo; ba.yh_hi = khi; }
         else if (klo > khi) { ba.yh_lo = 1; ba.yh_hi = 0; }  // empty band: only problem 0
     }
-    // phasempf: the recursion's y_fft has no reader but the fp32 backward transform either: f32x2 rows in the |out_int|^2 slots
-    ba.mpf32 = (cfg_.algo == BF_PHASEMPF && istft32 && spectrum == nullptr) ? 1 : 0;
     bool fused = false;
     if (try_fused) {
         const hipError_t fe = ks_->stft_bins(sa, ba, n_cus_, stream);

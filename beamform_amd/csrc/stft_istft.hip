@@ -147,6 +147,19 @@ __global__ __launch_bounds__(256) void stft_kernel(StftArgs a) {
 // lane l holds bin l + 64 g + 256 k3 (w64_bin): k3 < 2 reads row[l + 64 g + 256 k3], k3 >= 2 the conjugate of row[(64 - l) + 64 (3 - g) +
 // 256 (3 - k3)]: 1 KiB per wave-instruction either way.  util.h:244-253, 301-302.  0.157 ms per 65 536 frames (round 4's half-wavefront
 // kernel, one 32 x 32 transform per 32 lanes at one wavefront per SIMD: 0.55; the fp32 istft32_kernel below: 0.148).
+// |x| as an unsigned integer that orders like the magnitude (high word without the sign; NaN / Inf >= 0x7FF00000)
+__device__ __forceinline__ unsigned hi_abs(double x) { return (unsigned)((unsigned long long)__double_as_longlong(x) >> 32) & 0x7fffffffu; }
+// the largest value over the 64 lanes, in every lane (prefix maxima along the rows by DPP, lane 15 of each row to the next rows, lane 63)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true));  // row_shr:1
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true));  // row_shr:2
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true));  // row_shr:4
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true));  // row_shr:8
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true));  // row_bcast:15 into rows 1 and 3
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true));  // row_bcast:31 into rows 2 and 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 constexpr int kIw64Block = 256;
 constexpr int kIw64Waves = kIw64Block / 64;
 constexpr int kIw64TwD = 2 * (960 + 4 * kTw2RowW64Rot);  // tw1 rows k1 = 1..15 + tw2' (a.tw_w64 + 64), in doubles
@@ -243,10 +256,19 @@ __global__ __launch_bounds__(kIw64Block, 2) void istft_w64_kernel(IstftArgs a, i
         if (pair) {
             cd v[16];
             load_row(rb, v);
-            int bad = 0;  // (no short circuit: v_cmp_class, not branches)
+            // Two frames share a transform only if neither holds a non-finite value and their largest magnitudes are within 2^20 of each
+            // other: the transform's rounding error (1e-16 of the LOUDER frame) lands in both outputs.  A frame of 1e300s beside an
+            // ordinary one (gss / lcmv on a rank-deficient covariance), or any frame beside an all-zero one, goes alone.
+            unsigned ha = 0, hb = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) bad |= (int)!isfinite(re[r]) | (int)!isfinite(im[r]) | (int)!isfinite(v[r].x) | (int)!isfinite(v[r].y);
-            pair = __builtin_amdgcn_ballot_w64(bad != 0) == 0;
+            for (int r = 0; r < 16; ++r) {
+                ha = max(ha, max(hi_abs(re[r]), hi_abs(im[r])));
+                hb = max(hb, max(hi_abs(v[r].x), hi_abs(v[r].y)));
+            }
+            ha = wave_max_u32(ha);
+            hb = wave_max_u32(hb);
+            const int ea = (int)(ha >> 20), eb = (int)(hb >> 20);  // biased exponents; 0x7FF: NaN / Inf
+            pair = ea < 0x7FF && eb < 0x7FF && ea - eb <= 20 && eb - ea <= 20;
             if (pair) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {  // Ya + i Yb
@@ -315,7 +337,6 @@ constexpr int kI32Halves = kI32Block / 32;
 constexpr int kPSf = plane_stride<float>::value;  // 36
 
 // (three blocks per CU -- __launch_bounds__(256, 3): 168 registers, 20-32 of them spilled -- 0.148 -> 0.202 ms for phase: round 5)
-template <bool YH32>
 __global__ __launch_bounds__(kI32Block) void istft32_kernel(IstftArgs a, int frames_per_chunk, int chunks_per_stream) {
     __shared__ __attribute__((aligned(16))) float lds[2048 + kI32Halves * 32 * kPSf];
     const cx<float> *s_tw = reinterpret_cast<const cx<float> *>(lds);
@@ -335,7 +356,6 @@ __global__ __launch_bounds__(kI32Block) void istft32_kernel(IstftArgs a, int fra
     const long t0 = c_in_s * (long)frames_per_chunk;
     long t1 = t0 + frames_per_chunk;
     if (t1 > a.n_frames) t1 = a.n_frames;
-    const f64x2 *Ys = a.Yh + (long)s * a.n_frames * kYhStride;
     float *ys = a.y + (long)s * a.n_frames * kHop;
 
     float tail[16];  // second half of the previous frame (out_buff[0], util.h:302)
@@ -346,61 +366,38 @@ __global__ __launch_bounds__(kI32Block) void istft32_kernel(IstftArgs a, int fra
     }
     float re[32], im[32];
     for (long t = (t0 == 0 ? 0 : t0 - 1); t < t1; ++t) {  // t0 - 1: warm-up frame, only its second half is used
-        const f64x2 *row = Ys + t * kYhStride;
         // Hermitian extension of the stored row: position i holds bin k = lane + 32*brev5(i); even i are bins < 512, odd i
         // bins >= 512 (conjugate of row[1024 - k]); bins 0 / 511 / 512 / 513 are irregular (quirk Q1)
-        if (YH32) {
-            // f32x2 rows of the band-limited covariance nodes: only problems 0 and yh_lo..yh_hi exist, the rest is zero
-            // (mvdr.cpp:103) and was never written -- groups of 32 bins outside the band cost no load at all
-            const f32x2 *row32 = reinterpret_cast<const f32x2 *>(a.Yh) + ((long)s * a.n_frames + t) * kYhStride;
-            const int ylo = a.yh_lo, yhi = a.yh_hi;
-            auto ldr = [&](int k) -> f32x2 {
-                if (k == 0 || (k >= ylo && k <= yhi)) return row32[k];
-                return f32x2{0.f, 0.f};
-            };
+        // f32x2 rows of the band-limited covariance nodes: only problems 0 and yh_lo..yh_hi exist, the rest is zero
+        // (mvdr.cpp:103) and was never written -- groups of 32 bins outside the band cost no load at all
+        const f32x2 *row32 = reinterpret_cast<const f32x2 *>(a.Yh) + ((long)s * a.n_frames + t) * kYhStride;
+        const int ylo = a.yh_lo, yhi = a.yh_hi;
+        auto ldr = [&](int k) -> f32x2 {
+            if (k == 0 || (k >= ylo && k <= yhi)) return row32[k];
+            return f32x2{0.f, 0.f};
+        };
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const int kb = 32 * brev5(i);
-                const int glo = kb < 512 ? kb : kN - kb - 31;  // rows this position reads: glo .. glo + 31
-                f32x2 u{0.f, 0.f};
-                if (!(glo > yhi || (glo + 31 < ylo && glo > 0))) u = ldr(kb < 512 ? kb + lane : (kN - kb) - lane);
-                if (kb >= 512) u.y = -u.y;
-                if (i == 0 && lane == 0) u.y = 0.f;
-                if (i == 1) {
-                    if (lane == 0) {
-                        u.y = 0.f;
-                    } else if (lane == 1 && yhi >= 511) {
-                        const f32x2 v = ldr(513);
-                        u = f32x2{(v.x + u.x) * 0.5f, (v.y + u.y) * 0.5f};
-                    }
-                }
-                if (i == 30 && lane == 31 && yhi >= 511) {
+        for (int i = 0; i < 32; ++i) {
+            const int kb = 32 * brev5(i);
+            const int glo = kb < 512 ? kb : kN - kb - 31;  // rows this position reads: glo .. glo + 31
+            f32x2 u{0.f, 0.f};
+            if (!(glo > yhi || (glo + 31 < ylo && glo > 0))) u = ldr(kb < 512 ? kb + lane : (kN - kb) - lane);
+            if (kb >= 512) u.y = -u.y;
+            if (i == 0 && lane == 0) u.y = 0.f;
+            if (i == 1) {
+                if (lane == 0) {
+                    u.y = 0.f;
+                } else if (lane == 1 && yhi >= 511) {
                     const f32x2 v = ldr(513);
-                    u = f32x2{(u.x + v.x) * 0.5f, (u.y - v.y) * 0.5f};
+                    u = f32x2{(v.x + u.x) * 0.5f, (v.y + u.y) * 0.5f};
                 }
-                re[i] = u.x;
-                im[i] = u.y;
             }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const int kb = 32 * brev5(i);
-                cd u;
-                if (kb < 512)
-                    u = ld(row + kb + lane);
-                else
-                    u = conj(ld(row + (kN - kb) - lane));
-                if (i == 0 && lane == 0) u.y = 0.0;
-                if (i == 1) {
-                    if (lane == 0)
-                        u.y = 0.0;
-                    else if (lane == 1)
-                        u = (ld(row + 513) + u) * 0.5;
-                }
-                if (i == 30 && lane == 31) u = (u + conj(ld(row + 513))) * 0.5;
-                re[i] = (float)u.x;
-                im[i] = (float)u.y;
+            if (i == 30 && lane == 31 && yhi >= 511) {
+                const f32x2 v = ldr(513);
+                u = f32x2{(u.x + v.x) * 0.5f, (u.y - v.y) * 0.5f};
             }
+            re[i] = u.x;
+            im[i] = u.y;
         }
         fft1024p_inv_A<float>(re, im, lane, s_tw, pbuf);
         __builtin_amdgcn_wave_barrier();
@@ -1207,10 +1204,8 @@ hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s) {
         cps = (a.n_frames + fpc - 1) / fpc;
         const long chunks = cps * a.n_streams;
         const dim3 grid((unsigned)((chunks + kI32Halves - 1) / kI32Halves));
-        if (a.yh32)
-            BF_LAUNCH(istft32_kernel<true>, grid, dim3(kI32Block), 0, s, a, (int)fpc, (int)cps);
-        else
-            BF_LAUNCH(istft32_kernel<false>, grid, dim3(kI32Block), 0, s, a, (int)fpc, (int)cps);
+        if (!a.yh32) return hipErrorInvalidValue;  // (f64x2 rows go through istft_w64_kernel)
+        BF_LAUNCH(istft32_kernel, grid, dim3(kI32Block), 0, s, a, (int)fpc, (int)cps);
         return hipGetLastError();
     }
     const long pairs = (a.n_frames + 1) / 2;
