@@ -396,12 +396,15 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     ba.n_dirs = D_; ba.steer_dir_stride = snap.steer_dir_stride;
     ba.z48 = z48_ ? 1 : 0;
     ba.cfg = cfg_; ba.gssW = d_gssW_; ba.mpf = d_mpf_; ba.gss_reset_mask = snap.gss_reset_mask;
-    // Backward transform: in fp32 behind the per-bin stages that hand it f32x2 rows (das / phase through the bin pipeline, mvdr / lcmv,
-    // phasempf: no error amplification behind the per-bin stage, the output is a float32 sample); in double (istft_w64_kernel: the same
-    // 0.15 ms per 65 536 frames) wherever the rows are f64x2 anyway -- gss, mcra, gsc (whose sample-serial NLMS branches on the aligned
-    // signals), any node with a spectrum dump -- and everywhere under BF_ISTFT_F64=1
-    static const bool istft_f64 = getenv("BF_ISTFT_F64") && atoi(getenv("BF_ISTFT_F64")) != 0;
-    const bool want32 = !(cfg_.algo == BF_GSC || istft_f64 || N_ != 1024) && spectrum == nullptr;
+    // Backward transform.  Default: in double (istft_w64_kernel, 0.157 ms per 65 536 frames against the fp32 kernel's 0.148) for every
+    // node but mvdr / lcmv -- with it the float output of das, phase, phasempf, gss and mcra equals the oracle's bit for bit -- and in
+    // fp32 behind mvdr / lcmv, whose solve hands it band-limited f32x2 rows (half the row traffic, no zero-fill: 2.16 against 2.3 ms).
+    // BF_ISTFT_F64=1: in double everywhere; BF_ISTFT_F64=0: in fp32 wherever a per-bin stage can emit f32x2 rows (das / phase through the
+    // bin pipeline, phasempf, mvdr, lcmv: round 4's default).  gsc (its sample-serial NLMS branches on the aligned signals), a spectrum
+    // dump and the other FFT sizes: always in double.
+    static const int istft_env = getenv("BF_ISTFT_F64") ? atoi(getenv("BF_ISTFT_F64")) : -1;
+    const bool cov_node = cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV;
+    const bool want32 = (istft_env == 0 || (istft_env < 0 && cov_node)) && cfg_.algo != BF_GSC && N_ == 1024 && spectrum == nullptr;
     // mvdr / lcmv hand the fp32 transform f32x2 rows holding only problem 0 and the in-band problems (everything else is zero,
     // mvdr.cpp:103); das / phase through the bin pipeline: f32x2 rows too (every problem written)
     const bool pointwise32 = (cfg_.algo == BF_DAS || cfg_.algo == BF_PHASE) && want32;

@@ -50,8 +50,10 @@ CASES = [
     ({"BF_MVDR_GROUP": "1"}, "lcmv", 8, (-60.0, 90.0), 30, False),
     ({"BF_MVDR_TILE": "7"}, "lcmv", 8, (-60.0, 90.0), 40, True),       # mvdr_fast_kernel<8, 3>: lanes straddle tiles, short last tile
     ({"BF_MVDR_TILE": "7"}, "mvdr", 8, (), 40, False),                 # mvdr_fast_kernel: lanes straddle tiles, short last tile
-    ({"BF_ISTFT_F64": "1"}, "mvdr", 8, (), 30, False),                 # fp64 backward transform behind every node
-    ({"BF_ISTFT_F64": "1"}, "phase", 8, (), 24, True),
+    ({"BF_ISTFT_F64": "1"}, "mvdr", 8, (), 30, False),                 # fp64 backward transform behind every node (f64x2 rows out of mvdr_fast_kernel)
+    ({"BF_ISTFT_F64": "1"}, "lcmv", 16, (-60.0, 90.0), 24, False),     # ... out of cov2d_kernel
+    ({"BF_ISTFT_F64": "0"}, "phase", 8, (), 24, False),                # fp32 backward transform wherever a per-bin stage can emit f32x2 rows
+    ({"BF_ISTFT_F64": "0"}, "phasempf", 8, (), 24, False),
     ({"BF_Z48": "0"}, "mvdr", 8, (), 30, True),                        # full-double spectra in HBM (no z48 packing): mvdr_fast_kernel<8, 1, true>
     ({"BF_Z48": "0", "BF_MVDR_TILE": "7"}, "lcmv", 8, (-60.0, 90.0), 40, True),   # ... <8, 3, true>, lanes straddle tiles
     ({"BF_Z48": "0"}, "mvdr", 3, (), 30, False),                       # ... <4, 1, true>: an odd microphone count's zero partner channel
