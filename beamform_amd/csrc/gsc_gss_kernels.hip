@@ -415,8 +415,9 @@ __global__ __launch_bounds__(64) void gsc_nlms_par_kernel(const float *aligned, 
 }
 
 // The same with the blocking branches dealt out to NW wavefronts of one block (branch i belongs to wavefront i mod NW): 256 streams
-// of 8 microphones keep 1 024 wavefronts busy instead of 256.  Per sample two block barriers: behind the branch sums (every wavefront
-// then forms `out`, the output power and the adapt decision from the same numbers, in the same order) and behind the ring updates.
+// of 8 microphones keep 1 024 wavefronts busy instead of 256.  Per sample ONE block barrier, behind the branch sums (every wavefront
+// then forms `out`, the output power and the adapt decision from the same numbers, in the same order); each wavefront moves the rings
+// of its own branches on (round 4: a second barrier behind ring updates done by wavefront 0: 36.3 ms per 256 x 64 frames).
 // Arithmetic and summation order are gsc_nlms_par_kernel's: the results are the same bit for bit.
 template <int NW, int NBL, int KPL>  // NBL >= ceil((M - 1) / NW) branches per wavefront, KPL >= ceil(filter_size / 64)
 __global__ __launch_bounds__(64 * NW) void gsc_nlms_mw_kernel(const float *aligned, float *y, float *state, long n, int M, int fs,
@@ -433,8 +434,8 @@ __global__ __launch_bounds__(64 * NW) void gsc_nlms_mw_kernel(const float *align
     float *s_d = s_lo + 2 * fs + 64 * KPL + 16;      // [nb][64] neighbour differences of the current tile
     float *s_das = s_d + nbr * 64;                   // [64] upper beamformer of the current tile
     float *s_out = s_das + 64;                       // [64]
-    float *s_bo = s_out + 64;                        // [16] block_out_i of the current sample
-    float *s_pw = s_bo + 16;                         // [16] window power of branch i; [15]: of the output window
+    float *s_bo = s_out + 64;                        // [2][16] block_out_i of the current sample (two samples in flight: parity of jj)
+    float *s_pw = s_bo + 32;                         // [2][16] window power of branch i; [15]: of the output window
     const int s = blockIdx.x;
     const float *as = aligned + (long)s * M * n;
     float *ys = y + (long)s * n;
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(64 * NW) void gsc_nlms_mw_kernel(const float *align
         for (int jj = 0; jj < cnt; ++jj) {
             const float das = s_das[jj];
             const int h1 = (h + 1 == fs) ? 0 : h + 1;  // window = [h1, h1 + fs)
+            float *bo = s_bo + 16 * (jj & 1), *pw = s_pw + 16 * (jj & 1);
             // ---- this wavefront's branches: block_out_i and the window power --------------------------------------------------------
             float bmv[NBL][KPL];
 #pragma unroll
@@ -516,8 +518,8 @@ __global__ __launch_bounds__(64 * NW) void gsc_nlms_mw_kernel(const float *align
                 if (i < nb) {  // uniform
                     const float sb = gsc_wave_sum(pb), sp = gsc_wave_sum(pp);
                     if (lane == 0) {
-                        s_bo[i] = sb;
-                        s_pw[i] = sp;
+                        bo[i] = sb;
+                        pw[i] = sp;
                     }
                 }
             }
@@ -529,17 +531,17 @@ __global__ __launch_bounds__(64 * NW) void gsc_nlms_mw_kernel(const float *align
                     pl = (pl + (v * v));
                 }
                 const float sl = gsc_wave_sum(pl);
-                if (lane == 0) s_pw[15] = sl;
+                if (lane == 0) pw[15] = sl;
             }
             __syncthreads();
             // ---- every wavefront: out, the output power, the adapt decision (same numbers, same order) ---------------------------------
             float out = das;
-            for (int i = 0; i < nb; ++i) out = out - s_bo[i];
-            const float lop = __fsqrt_rn(__fdiv_rn((s_pw[15] + (out * out)), fsz));  // calculate_power(last_outputs)
+            for (int i = 0; i < nb; ++i) out = out - bo[i];
+            const float lop = __fsqrt_rn(__fdiv_rn((pw[15] + (out * out)), fsz));  // calculate_power(last_outputs)
             const bool adapt = ((double)lop < vad_threshold) || !use_vad;          // gsc.cpp:147
             if (adapt && nb > 0) {
                 // lane i works out branch i's step size (gsc.cpp:153-157, double arithmetic); this wavefront's branches take theirs by v_readlane
-                const float mypw = lane < nb ? s_pw[lane] : 0.f;
+                const float mypw = lane < nb ? pw[lane] : 0.f;
                 const float bp = __fsqrt_rn(__fdiv_rn(mypw, fsz));
                 float mu;
                 if (mu0 * (double)bp / (double)lop < mu_max)
@@ -562,19 +564,24 @@ __global__ __launch_bounds__(64 * NW) void gsc_nlms_mw_kernel(const float *align
                     }
                 }
             }
-            if (wv == 0) {  // the rings move on: this sample's output, the next sample's blocking-matrix inputs
-                if (lane == 0) {
-                    s_lo[h] = out;
-                    s_lo[h + fs] = out;
-                    s_out[jj] = out;
-                }
-                if (jj + 1 < cnt && lane < nb) {
-                    const float d = s_d[lane * 64 + jj + 1];
-                    s_bm[lane * bstride + h1] = d;
-                    s_bm[lane * bstride + h1 + fs] = d;
+            // The rings move on.  The output ring has one reader and one writer, wavefront 0; the ring of branch i is read by the wavefront
+            // that owns the branch, and that wavefront feeds it: no second block barrier (LDS operations of one wavefront execute in
+            // issue order).  A wavefront that runs ahead writes the next sample's sums into the other half of s_bo / s_pw and meets the
+            // others at that sample's barrier.
+            if (wv == 0 && lane == 0) {
+                s_lo[h] = out;
+                s_lo[h + fs] = out;
+                s_out[jj] = out;
+            }
+            if (jj + 1 < cnt && lane < NBL) {
+                const int i = wv + NW * lane;
+                if (i < nb) {
+                    const float d = s_d[i * 64 + jj + 1];
+                    s_bm[i * bstride + h1] = d;
+                    s_bm[i * bstride + h1 + fs] = d;
                 }
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
             h = h1;
         }
         if (wv == 0 && lane < cnt) ys[n0 + lane] = s_out[lane];
@@ -795,7 +802,7 @@ hipError_t launch_gsc_nlms(const float *aligned, float *y, float *state, long n_
     const int nw = serial ? 1 : (nb >= 5 ? 8 : nb >= 3 ? 4 : nb >= 2 ? 2 : 1);
     const size_t lds_serial = sizeof(float) * ((size_t)nbr * ((fs + 64 * kp + 8) | 1) + (size_t)nbr * ((64 * kp + 8) | 1) + 2 * fs + 16 +
                                                (size_t)nbr * 64 + 64 + 16 + 64);
-    const size_t lds_par = sizeof(float) * ((size_t)nbr * ((fs + 64 * kp + 8) | 1) + 2 * fs + 64 * kp + 16 + (size_t)nbr * 64 + 64 + 64 + 32);
+    const size_t lds_par = sizeof(float) * ((size_t)nbr * ((fs + 64 * kp + 8) | 1) + 2 * fs + 64 * kp + 16 + (size_t)nbr * 64 + 64 + 64 + 64);
     const size_t lds = serial ? lds_serial : lds_par;
     if (nw > 1 && nb <= 15) {
         const int nbl = (nb + nw - 1) / nw;  // <= 4 at nw = 4, <= 8 at nw = 2
