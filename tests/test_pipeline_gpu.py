@@ -79,6 +79,29 @@ def test_float_output_equals_the_oracles(algo, M, interf):
     assert (y != y_ref).mean() < 1e-3
 
 
+def test_backward_transform_keeps_frames_of_different_scale_apart():
+    """istft_w64_kernel takes two frames through one complex transform only when their largest magnitudes are within 2^20 of each
+    other: a transform's rounding error is 1e-16 of the LOUDER frame and lands in both.  Frames of exact zeros between loud ones must
+    come out as the oracle's (exact zeros where the overlap-add has nothing to add), and a stretch 2^-40 below the rest must keep its
+    own relative accuracy."""
+    import oracle
+    from beamform_amd.capi import Beamformer
+    M, F = 8, 36   # phase: stft_bins_w64_kernel (two MICROPHONES per forward transform: a zero frame has a zero spectrum) + istft_w64_kernel
+    p = make_params("phase", n_mics=M, theta=-35.0)
+    x = make_scene(M, F, seed=777, silent_frac=0.0)
+    x[:, 6 * 512:11 * 512] = 0.0                 # frames 6..9 all zero (frame t = hops t-1, t)
+    x[:, 20 * 512:26 * 512] *= np.float32(2.0 ** -40)
+    y_ref, _ = oracle.OracleNode(p).process(x)
+    y = Beamformer(p).process(x).reshape(-1)
+    assert rel_l2(y, y_ref) < 1e-8
+    hops0 = [h for h in range(F) if not y_ref[h * 512:(h + 1) * 512].any()]   # output hops whose two frames are both zero
+    assert len(hops0) >= 2
+    for h in hops0:
+        assert not y[h * 512:(h + 1) * 512].any()
+    q = slice(21 * 512, 25 * 512)                # the quiet stretch on its own scale
+    assert rel_l2(y[q], y_ref[q]) < 1e-8
+
+
 @pytest.mark.parametrize("M,theta,F", [(8, 20.0, 40), (4, 0.0, 21), (2, 45.0, 8)])
 def test_phase_matches_oracle(M, theta, F):
     import oracle
