@@ -189,7 +189,10 @@ int bf_process_hop(bf_handle *h, const float *const *in, float *out, uint32_t nf
  * as consecutive callbacks would.  Rounding: the das kernels that pack several frames of a batch into one transform (das in double on
  * planar input: two; fp32 das at periods below 512 frames: 1024 / (2 hop)) choose the frames by their position in the batch, so the same
  * stream cut differently agrees to the last bits of the float output (<= 1e-6 of its scale), not bit for bit; every cut is within the
- * stated tolerance of the reference arithmetic. */
+ * stated tolerance of the reference arithmetic.  Frames that share a transform also share its rounding error, 1e-16 of the LOUDER
+ * one: beside an ordinary frame a frame of exact zeros comes out as 1e-17s where the reference writes zeros, and a frame 2^-40 below
+ * its neighbour loses its own last 40 bits (das in double only: the other nodes' kernels pair microphones in the forward transform
+ * and, in the backward one, only frames of comparable scale). */
 int bf_process_batch(bf_handle *h, const float *x_host, size_t n_frames, float *y_host);
 
 /* Same, buffers already resident in HBM; enqueued on `hip_stream`
