@@ -162,9 +162,12 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
         pb ^= 1;
     }
     const float thr32 = (float)(a.cfg.freq_mag_threshold * (double)((unsigned)M * (unsigned)kN));
+    cd y_prev{0, 0};  // frame it - 1's output: stored one iteration late, behind the wait below and in front of the next DMA, so that the
+                      // s_waitcnt vmcnt(0) at the top of an iteration never waits for a store issued a few instructions earlier
     for (long it = 0; it < n_it; ++it) {
         BF_DMA_WAIT();  // frame it (and it - P) have landed in s_pf[pb]
         __builtin_amdgcn_wave_barrier();
+        if (it > 0 && it - 1 < cnt) st_y(a, yidx + (it - 1) * kYhStride, q, y_prev);
         if (it > 0) {
             // slide the covariance window over the PREVIOUS frame (mvdr.cpp:100-101), whose rows still sit in the other buffer:
             // done here, not behind the solve, so that the updated R is at once the factorisation's working copy -- R itself
@@ -307,9 +310,10 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
                 if (open && solve_q) y = gv[0];
             }
         }
-        if (it < cnt) st_y(a, yidx + it * kYhStride, q, y);
+        y_prev = y;
         pb ^= 1;
     }
+    if (n_it > 0 && n_it - 1 < cnt) st_y(a, yidx + (n_it - 1) * kYhStride, q, y_prev);
 #undef BF_DMA_WAIT
 }
 

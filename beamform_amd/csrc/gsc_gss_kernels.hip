@@ -767,11 +767,168 @@ __global__ __launch_bounds__(256) void gss_kernel(BinsArgs a) {
         if (r < S && m < M) Wg[(long)r * M + m] = f64x2{W[r].x, W[r].y};
 }
 
+
+// ---- gss, one LANE per (stream, problem): the tuned shapes (<= 8 microphones, <= 4 sources) ------------------------------------------
+// The group kernel above spends most of its instructions on DPP sums over the MP lanes of a problem (ten 64-bit group sums per frame).
+// Here the whole S x M demixing matrix of a problem lives in one lane's registers (4 x 8 complex = 128 VGPRs: two wavefronts per SIMD),
+// every sum is a chain of FMAs inside the lane, the 64 lanes of a wavefront are 64 consecutive problems of one stream (their spectrum rows
+// are contiguous: 1 KiB per wave-instruction) and the rows of the next frame travel by global -> LDS DMA while this one is worked on
+// (as in mvdr_fast_kernel).  The recursion over the frames (gss.cpp:136) stays serial per problem; 256 streams x 341 in-band problems
+// are 1 364 wavefronts, all resident at once.  Sums over the microphones run m = 0, 1, ... (the group kernel: pairwise).
+template <int MP, int KM>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void gss_lane_kernel(BinsArgs a) {
+    const int lane = threadIdx.x;
+    constexpr int wps = (kNQ + 63) / 64;  // wavefronts per stream
+    const int s = blockIdx.x / wps;
+    int q = (blockIdx.x - s * wps) * 64 + lane;
+    const bool live = q < kNQ;
+    if (!live) q = kNQ - 1;
+    const int j = q_bin(q);
+    const int M = a.n_mics, NP = (M + 1) >> 1, S = a.kp1;
+    f64x2 *yout = a.Yh + ((long)s * a.n_frames) * kYhStride + q;
+    const double f = fabs(a.freqs[j]);
+    const bool inband = live && f >= a.cfg.freq_min && f <= a.cfg.freq_max;
+    if (__builtin_amdgcn_ballot_w64(inband) == 0) {  // nothing to separate in this wavefront (gss.cpp:150: y_fft = 0 out of band)
+        if (live)
+            for (long t = 0; t < a.n_frames; ++t) yout[t * kYhStride] = f64x2{0, 0};
+        return;
+    }
+    // frame 0 of this stream's spectra (uniform) + a per-lane byte offset; rows 2p / 2p + 1 of a buffer = Z_t[p][k] / Z_t[p][N - k]
+    const char *Zu = reinterpret_cast<const char *>(a.Z + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN);
+    const int ksrc = q_src_bin(q), kneg = (kN - ksrc) & (kN - 1);
+    const unsigned vk = (unsigned)ksrc * 16u, vn = (unsigned)kneg * 16u;
+    const long frame_bytes = (long)NP * kN * 16;
+    __shared__ __attribute__((aligned(16))) f64x2 s_pf[2][MP][64];
+    auto dma_frame = [&](long t, int buf) {
+        const char *b = Zu + t * frame_bytes;
+#pragma unroll
+        for (int p = 0; p < MP / 2; ++p)
+            if (p < NP) {  // uniform
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(b + (long)p * kN * 16 + vk),
+                                                 (__attribute__((address_space(3))) void *)&s_pf[buf][2 * p][0], 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(b + (long)p * kN * 16 + vn),
+                                                 (__attribute__((address_space(3))) void *)&s_pf[buf][2 * p + 1][0], 16, 0, 0);
+            }
+    };
+    const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
+    f64x2 *Wg = a.gssW + (((long)s * kN + j) * S) * M;
+    cd W[KM][MP], C0[MP];
+    const bool reset = ((a.gss_reset_mask >> (s % a.n_dirs)) & 1ull) != 0;
+#pragma unroll
+    for (int r = 0; r < KM; ++r)
+#pragma unroll
+        for (int m = 0; m < MP; ++m) {
+            cd w{0, 0};
+            if (r < S && m < M) w = reset ? conj(ld(steer + ((long)r * M + m) * kN + j)) : ld(Wg + (long)r * M + m);  // sep_matrix[j] = weights[j].adjoint() (gss.cpp:92)
+            W[r][m] = w;
+        }
+#pragma unroll
+    for (int m = 0; m < MP; ++m) C0[m] = (KM == 1 && m < M) ? ld(steer + (long)m * kN + j) : cd{0, 0};  // only S == 1 reads the constraint in the loop
+    const double mu = a.cfg.mu, keep = 1 - a.cfg.lambda_ * a.cfg.mu;
+    const double c2 = (double)(size_t)(2 * (1 / (size_t)S));  // integer arithmetic, quirk Q13
+    const float thr32 = (float)(a.cfg.freq_mag_threshold * (double)((unsigned)M * (unsigned)kN));
+    int pb = 0;
+    dma_frame(0, pb);
+    cd y_prev{0, 0};  // frame t - 1's output: stored one iteration late (behind the wait, in front of the next DMA), so that the wait at the
+                      // top of an iteration never waits for a store issued a few instructions earlier
+    for (long t = 0; t < a.n_frames; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // frame t has landed in s_pf[pb]
+        __builtin_amdgcn_wave_barrier();
+        if (t > 0 && live) yout[(t - 1) * kYhStride] = f64x2{y_prev.x, y_prev.y};
+        if (t + 1 < a.n_frames) dma_frame(t + 1, pb ^ 1);
+        cd X[MP];
+#pragma unroll
+        for (int p = 0; p < MP / 2; ++p) {
+            const cd z = ld(&s_pf[pb][2 * p][lane]), zc = conj(ld(&s_pf[pb][2 * p + 1][lane]));
+            const cd d = z - zc;
+            X[2 * p] = (2 * p < M) ? (z + zc) * 0.5 : cd{0, 0};
+            X[2 * p + 1] = (2 * p + 1 < M) ? cd{0.5 * d.y, -0.5 * d.x} : cd{0, 0};  // (an odd count's partner channel is rounding residue, not zero)
+        }
+        if (q == kQX) {
+#pragma unroll
+            for (int m = 0; m < MP; ++m) X[m].y = -X[m].y;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows have been read: the DMA after next may overwrite them
+        // magnitude gate (gss.cpp:118): decided in fp32 unless the fp32 sum is within 1e-4 of the threshold
+        float m32 = 0.f;
+#pragma unroll
+        for (int m = 0; m < MP; ++m) m32 += __builtin_amdgcn_sqrtf((float)norm2(X[m]));
+        bool open = m32 > thr32;
+        if (__builtin_amdgcn_ballot_w64(__builtin_fabsf(m32 - thr32) <= 1e-4f * thr32) != 0) {
+            double mag = 0.0;
+#pragma unroll
+            for (int m = 0; m < MP; ++m) mag += cabs(X[m]);
+            mag /= (double)((unsigned)M * (unsigned)kN);
+            open = mag > a.cfg.freq_mag_threshold;
+        }
+        open = open && inband;
+        cd y = X[0] * 0.01;  // gate closed (gss.cpp:152)
+        if (__builtin_amdgcn_ballot_w64(open) != 0) {
+            double alpha = 0.0;
+#pragma unroll
+            for (int m = 0; m < MP; ++m) alpha += norm2(X[m]);
+            cd yf[KM];
+#pragma unroll
+            for (int r = 0; r < KM; ++r) {
+                cd acc{0, 0};
+#pragma unroll
+                for (int m = 0; m < MP; ++m) acc = acc + W[r][m] * X[m];
+                yf[r] = acc;
+            }
+            alpha *= alpha;
+            // a lane whose gate is closed keeps its matrix: W * 1 - (.. * 0 + d2) * 0 is W bit for bit -- three selects per frame instead of
+            // four per matrix entry
+            const double c1 = open ? (double)(4 * (size_t)S) * (1 / alpha) : 0.0;
+            const double keep_l = open ? keep : 1.0, mu_l = open ? mu : 0.0;
+            cd Ey[KM];
+#pragma unroll
+            for (int r = 0; r < KM; ++r) {
+                cd acc{0, 0};
+#pragma unroll
+                for (int r2 = 0; r2 < KM; ++r2)
+                    if (r2 != r && r < S && r2 < S) acc = acc + (yf[r] * conj(yf[r2])) * yf[r2];
+                Ey[r] = acc;
+            }
+            cd wc{0, 0};
+            if (KM == 1 && c2 != 0.0) {  // only S == 1: dj2 = 2 (W C - I) C^H
+#pragma unroll
+                for (int m = 0; m < MP; ++m) wc = wc + W[0][m] * C0[m];
+                wc.x -= 1.0;
+            }
+#pragma unroll
+            for (int r = 0; r < KM; ++r)
+                if (r < S) {  // uniform
+#pragma unroll
+                    for (int m = 0; m < MP; ++m) {
+                        cd d2{0, 0};
+                        if (KM == 1 && r == 0 && c2 != 0.0) d2 = (wc * conj(C0[m])) * c2;
+                        W[r][m] = (W[r][m] * keep_l) - ((Ey[r] * conj(X[m])) * c1 + d2) * mu_l;
+                    }
+                }
+            if (open) y = yf[0];
+        }
+        if (!inband) y = cd{0, 0};
+        y_prev = y;
+        pb ^= 1;
+    }
+    if (live && a.n_frames > 0) yout[(a.n_frames - 1) * kYhStride] = f64x2{y_prev.x, y_prev.y};
+#pragma unroll
+    for (int r = 0; r < KM; ++r)
+#pragma unroll
+        for (int m = 0; m < MP; ++m)
+            if (inband && r < S && m < M) Wg[(long)r * M + m] = f64x2{W[r][m].x, W[r][m].y};
+}
+
 }  // namespace
 
 hipError_t launch_gss(const BinsArgs &a, int n_cus, hipStream_t s) {
     const int M = a.n_mics, km = a.kp1 <= 1 ? 1 : 4;
     const int groups = a.n_streams * kNQ;
+    // One lane per problem pays once the lanes fill the chip: 256 streams x 256 frames 3.33 -> 2.10 ms (4 microphones 1.76 -> 1.24), but ONE
+    // stream of 65 536 frames 69 -> 145 ms (9 wavefronts; a frame step is 2.2 us in one lane, 1.06 us spread over 8): lane kernel from two
+    // wavefronts per CU on.  BF_GSS_GROUP=1 / 0 force the group / the lane kernel (tests, A/B).
+    static const int group_env = getenv("BF_GSS_GROUP") ? atoi(getenv("BF_GSS_GROUP")) : -1;
+    const bool lane_kernel = group_env >= 0 ? group_env == 0 : (long)a.n_streams * ((kNQ + 63) / 64) >= 2L * n_cus;
 #define BF_LAUNCH_GSS(MP_, KM_) \
     BF_LAUNCH((gss_kernel<MP_, KM_>), dim3((groups + (256 / MP_) - 1) / (256 / MP_)), dim3(256), 0, s, a)
     if (a.kp1 > 4 || M > 16) {  // beyond the tuned shapes: more interferers (up to 15) or microphones (up to 32)
@@ -780,6 +937,13 @@ hipError_t launch_gss(const BinsArgs &a, int n_cus, hipStream_t s) {
         else if (a.kp1 <= 4) BF_LAUNCH_GSS(32, 4);
         else if (a.kp1 <= 8) { if (M <= 8) BF_LAUNCH_GSS(8, 8); else if (M <= 16) BF_LAUNCH_GSS(16, 8); else BF_LAUNCH_GSS(32, 8); }
         else { if (M <= 16) BF_LAUNCH_GSS(16, 16); else BF_LAUNCH_GSS(32, 16); }
+    } else if (M <= 8 && lane_kernel) {  // one lane per problem
+        const dim3 grid((unsigned)(a.n_streams * ((kNQ + 63) / 64)));
+        if (M <= 4) {
+            if (km == 1) BF_LAUNCH((gss_lane_kernel<4, 1>), grid, dim3(64), 0, s, a); else BF_LAUNCH((gss_lane_kernel<4, 4>), grid, dim3(64), 0, s, a);
+        } else {
+            if (km == 1) BF_LAUNCH((gss_lane_kernel<8, 1>), grid, dim3(64), 0, s, a); else BF_LAUNCH((gss_lane_kernel<8, 4>), grid, dim3(64), 0, s, a);
+        }
     } else if (M <= 4) {
         if (km == 1) BF_LAUNCH_GSS(4, 1); else BF_LAUNCH_GSS(4, 4);
     } else if (M <= 8) {

@@ -59,6 +59,10 @@ CASES = [
     ({"BF_Z48": "0"}, "mvdr", 3, (), 30, False),                       # ... <4, 1, true>: an odd microphone count's zero partner channel
     ({"BF_Z48": "0", "BF_MVDR_GROUP": "1"}, "mvdr", 8, (), 30, True),  # ... read by the group-per-problem kernel
     ({"BF_Z48": "0"}, "lcmv", 16, (-60.0, 90.0, 150.0), 24, True),     # 9..16 microphones: group kernel (cov2d_kernel reads z48 only)
+    ({"BF_GSS_GROUP": "0"}, "gss", 8, (-60.0, 90.0), 30, True),         # gss_lane_kernel<8, 4> (one lane per problem: the default from 57 streams on)
+    ({"BF_GSS_GROUP": "0"}, "gss", 8, (), 24, True),                     # ... <8, 1>: one source, the constraint term
+    ({"BF_GSS_GROUP": "0"}, "gss", 3, (90.0,), 24, False),               # ... <4, 4>, an odd microphone count
+    ({"BF_GSS_GROUP": "1"}, "gss", 4, (-60.0, 90.0, 150.0), 24, False),  # the group-per-problem kernel where the lane kernel would run
     ({"BF_GSC_SERIAL": "1"}, "gsc", 4, (), 10, False),                  # gsc_nlms_kernel: the sums in the reference's tap order, one branch per lane
     ({"BF_GSC_SERIAL": "1"}, "gsc", 8, (), 8, False),
     ({}, "gsc", 2, (), 8, False),                                       # one blocking branch: gsc_nlms_par_kernel (one wavefront per stream)
