@@ -309,25 +309,29 @@ def test_multi_stream_phasempf_config4_shape():
         check(y[s], Y[s], y_ref, Y_ref)
 
 
-@pytest.mark.parametrize("M,interf", [(8, (-60.0, 90.0)), (7, (150.0,)), (4, ()), (2, (90.0,))])
-def test_gss_many_streams_one_lane_per_problem(M, interf):
+@pytest.mark.parametrize("M,interf,hop", [(8, (-60.0, 90.0), 512), (7, (150.0,), 512), (4, (), 512), (2, (90.0,), 512),
+                                          (6, (-60.0, 90.0, 150.0), 128), (3, (), 2048)])
+def test_gss_many_streams_one_lane_per_problem(M, interf, hop):
     """From two wavefronts per CU on (57 streams) gss runs gss_lane_kernel: one lane per (stream, problem), the demixing matrix in
     registers.  64 independent streams in two uneven batches (the matrices are carried between them) against the oracle per stream."""
     import oracle
     from beamform_amd.capi import Beamformer, launch_trace
     _torch()
-    S, F = 64, 14
-    p = make_params("gss", n_mics=M, interf=interf, theta=20.0)
-    xs = np.stack([make_scene(M, F, seed=9100 + 7 * s + M) for s in range(S)])
+    # streams: enough for two wavefronts per CU (N = 256: 3 wavefronts per stream; N = 1024: 9; N = 4096: 33)
+    S, F = {128: (176, 10), 512: (64, 14), 2048: (32, 8)}[hop]
+    over = {} if hop == 512 else {"hop": hop}
+    p = make_params("gss", n_mics=M, interf=interf, theta=20.0, **over)
+    xs = np.stack([make_scene(M, F, hop=hop, seed=9100 + 7 * s + M) for s in range(S)])
     bf = Beamformer(p, n_streams=S)
     with launch_trace() as tr:
-        y1 = bf.process(np.ascontiguousarray(xs[:, :, :5 * 512]))
+        y1 = bf.process(np.ascontiguousarray(xs[:, :, :5 * hop]))
     assert any("gss_lane_kernel" in k for k in tr.kernels), tr.kernels
-    y2 = bf.process(np.ascontiguousarray(xs[:, :, 5 * 512:]))
+    y2 = bf.process(np.ascontiguousarray(xs[:, :, 5 * hop:]))
     y = np.concatenate([y1, y2], axis=1)
-    for s in (0, 1, 17, 40, 63):
+    for s in (0, 1, 17, S - 1):
         y_ref, _ = oracle.OracleNode(p).process(xs[s])
-        assert rel_l2(y[s], y_ref) < 1e-8, (s, rel_l2(y[s], y_ref))   # (backward transform in double: float output to the last bit)
+        # N = 1024: backward transform in double on the 64-lane factorisation, float output to the last bit; other sizes: generic transforms
+        assert rel_l2(y[s], y_ref) < (1e-8 if hop == 512 else 1e-5), (s, rel_l2(y[s], y_ref))
 
 
 @pytest.mark.parametrize("algo", ["lcmv", "gss"])
