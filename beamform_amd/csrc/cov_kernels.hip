@@ -658,11 +658,20 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
     const int ksrc = q_src_bin(qq), kneg = (kN - ksrc) & (kN - 1);
     const int addrT = 4 * ((lane & ~15) | (q << 2) | p);  // my transpose partner (q, p)
 
-    // microphone l16's spectrum at this bin, frame t (may be negative: history)
-    auto load_mic = [&](long t) -> cd {
+    // microphone l16's spectrum at this bin, frame t (may be negative: history).  Requested a frame ahead (load_raw) and unpacked
+    // where it is needed (finish_mic): a load issued where its value is used costs its full latency every frame -- the compiler cannot
+    // move it above the st_y in between -- and two wavefronts per SIMD do not hide that
+    struct RawMic {
+        z48 z, zc;
+    };
+    const int mic_pair = (l16 < M ? l16 : 0) >> 1;
+    auto load_raw = [&](long t) -> RawMic {
+        const z48 *Zf = Zs + t * NP * kN + mic_pair * kN;
+        return RawMic{Zf[ksrc], Zf[kneg]};
+    };
+    auto finish_mic = [&](const RawMic &r) -> cd {
         if (l16 >= M) return cd{0, 0};
-        const z48 *Zf = Zs + t * NP * kN + (l16 >> 1) * kN;
-        const cd z = ld(Zf + ksrc), zc = conj(ld(Zf + kneg));
+        const cd z = dec48(r.z), zc = conj(dec48(r.zc));
         cd x;
         if ((l16 & 1) == 0) {
             x = z + zc;  // z48 spectra are stored halved
@@ -672,6 +681,7 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
         }
         return qq == kQX ? conj(x) : x;
     };
+    auto load_mic = [&](long t) -> cd { return finish_mic(load_raw(t)); };
     // one microphone per lane -> LDS -> this lane's four row entries x(4a+p) and four column entries x(4b+q).
     // LDS operations of one wavefront execute in issue order: compiler barriers only.
     auto spread = [&](cd x, int slot, cd (&xr)[4], cd (&xc)[4]) {
@@ -716,9 +726,15 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
     cd R[10];
 #pragma unroll
     for (int e = 0; e < 10; ++e) R[e] = cd{0, 0};
+    // (the three-wavefront build has no registers for the 12 raw dwords in flight: 132 bytes of scratch, mvdr 16-mic 9.4 -> 10.0 ms; it
+    // keeps the loads where the values are used.  Two-wavefront build, lcmv 16-mic K = 3: 10.7 -> 10.2 ms)
+    constexpr bool kAhead = WPS == 2;
+    RawMic nxt = load_raw(kAhead ? (P > 0 ? tA - 1 : tA) : tA);
     for (int pp = 1; pp <= P; ++pp) {  // covariance of the P frames in front of the tile
+        const RawMic cur = kAhead ? nxt : load_raw(tA - pp);
+        if (kAhead) nxt = load_raw(pp < P ? tA - pp - 1 : tA);  // (the last one: the tile's first frame)
         cd xr[4], xc[4];
-        spread(load_mic(tA - pp), 0, xr, xc);
+        spread(finish_mic(cur), 0, xr, xc);
 #pragma unroll
         for (int ar = 0; ar < 4; ++ar)
 #pragma unroll
@@ -730,7 +746,12 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
     unsigned open_mask = 0;  // frame slots of this row whose system waits (uniform per row)
     for (long t = tA; t < tB; ++t) {
         const int slot = (int)(t - tA) & 3;
-        const cd xm = load_mic(t);
+        const cd xm = finish_mic(kAhead ? nxt : load_raw(t));
+        RawMic old = nxt;
+        if (kAhead) {
+            old = load_raw(t - P);                       // needed behind the factorisation
+            nxt = load_raw(t + 1 < tB ? t + 1 : t);      // next iteration's frame
+        }
         cd xr[4], xc[4];
         spread(xm, 0, xr, xc);
         const double mag = row_sum(fast_sqrt(norm2(xm))) / (double)((unsigned)M * (unsigned)kN);
@@ -872,7 +893,7 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
         // slide the covariance window: + x_t x_t^H - x_{t-P} x_{t-P}^H (mvdr.cpp:100-101).  x_t is read back from its LDS slot
         // (still there) instead of being kept in 32 registers across the factorisation.
         cd xor_[4], xoc[4];
-        spread(load_mic(t - P), 1, xor_, xoc);
+        spread(finish_mic(kAhead ? old : load_raw(t - P)), 1, xor_, xoc);
 #pragma unroll
         for (int ar = 0; ar < 4; ++ar) {
             const cd xra = kKeepC ? xr[ar] : ld(&s_x[wv][0][grp][4 * ar + p]);
