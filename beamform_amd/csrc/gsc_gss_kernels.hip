@@ -828,7 +828,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const double c2 = (double)(size_t)(2 * (1 / (size_t)S));  // integer arithmetic, quirk Q13
     const float thr32 = (float)(a.cfg.freq_mag_threshold * (double)((unsigned)M * (unsigned)kN));
     int pb = 0;
-    dma_frame(0, pb);
+    if (a.n_frames > 0) dma_frame(0, pb);
     cd y_prev{0, 0};  // frame t - 1's output: stored one iteration late (behind the wait, in front of the next DMA), so that the wait at the
                       // top of an iteration never waits for a store issued a few instructions earlier
     for (long t = 0; t < a.n_frames; ++t) {
