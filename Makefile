@@ -49,7 +49,7 @@ oracle:
 	$(MAKE) -C oracle -s
 
 ubench:
-	for f in valu_rate fetch_calib rowbc vmem_issue rsq_test f64_rate launch_lds realtime_cal; do $(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fno-slp-vectorize -Wno-unused-result tools/ubench/$$f.hip -o tools/ubench/$$f.bin; done
+	for f in valu_rate fetch_calib rowbc vmem_issue rsq_test f64_rate launch_lds realtime_cal power_clock; do $(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fno-slp-vectorize -Wno-unused-result tools/ubench/$$f.hip -o tools/ubench/$$f.bin; done
 
 # which kernels run for which (node, period, layout, microphones, directions, dump): traced from the library itself (needs a GPU)
 dispatch-table: $(LIB)
