@@ -336,7 +336,7 @@ constexpr int kTwP = 2 * (960 + 4 * kTw2RowW64Rot);        // tw1 rows k1 = 1 ..
 constexpr int pTw = 0;
 constexpr int pPlane = kTwP;
 constexpr int pGain = pPlane + kWaves * kPlaneD;
-constexpr int pFlag = pGain + 8 * kGMic * 2;
+constexpr int pFlag = pGain + 7 * kGMic * 2;       // microphones 1 .. 7 (microphone 0 has no gains: below)
 constexpr int pWin = pFlag + (kSlots + 4) / 2;           // kSlots ints + the 64-bit work word, padded to 16 bytes
 constexpr int kLdsP = pWin + 64 * kWinRow;
 static_assert(kLdsP * 8 <= 160 * 1024, "LDS");
@@ -504,6 +504,12 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
         const float *h2 = tA + 1 < a.n_frames ? h1 + kHop : h1;  // a lone last frame: any readable hop, unused
         request(h0, h1, h2);
     };
+    // Microphone 0 is never transformed.  Its weight row is identically 1 (das.cpp:33-38: written once, tau_0 = 0), so its term of
+    // das.cpp:60-63 is X_0[j] / M and FFT -> IFFT / N of it is the windowed frame itself: h[n] x_0[n] / M (util.h:235,247-252), added in
+    // double to Re(u[n]) / N in front of the float cast.  4.0 transforms per frame instead of 4.5.  Its three hops are requested when
+    // the backward transform starts (re / im are dead then: registers to spare) and are there when it ends.
+    float q0[8], q1[8], q2[8];
+    const double inv_m = 1.0 / (double)M;
 
     BF_STAMP(0);
 #ifdef BF_W64_STAMPS
@@ -517,14 +523,14 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
     cur.pos = w;
     cur.u = (unsigned)w;
     cur.have = w < n_static;
-    if (cur.have) request_pair_mic(cur.d.x, cur.d.y + 2L * w, 0);
+    if (cur.have) request_pair_mic(cur.d.x, cur.d.y + 2L * w, 1);
     {
-        const f64x2 *tw2 = a.tw + 64, *g2 = a.gains_mic;
+        const f64x2 *tw2 = a.tw + 64, *g2 = a.gains_mic + kGMic;  // gains of microphones 1 .. M - 1
         f64x2 *ltw = reinterpret_cast<f64x2 *>(lds + pTw), *lg = reinterpret_cast<f64x2 *>(lds + pGain);
 #pragma unroll 4
         for (int i = tid; i < kTwP / 2; i += kBlock) ltw[i] = tw2[i];
 #pragma unroll 8
-        for (int i = tid; i < M * kGMic; i += kBlock) lg[i] = g2[i];
+        for (int i = tid; i < (M - 1) * kGMic; i += kBlock) lg[i] = g2[i];
 #pragma unroll 2
         for (int i = tid; i < 1024; i += kBlock) lds[pWin + (i & 63) * kWinRow + (i >> 6)] = a.win[i];
         if (tid < kSlots) s_state[tid] = 0;
@@ -536,7 +542,7 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
     int it = 0;  // pairs this wavefront has done (debug stamps)
     if (!cur.have) {
         cur = draw_pair(s_work, sc, lane);
-        if (cur.have) request_pair_mic(cur.d.x, cur.d.y + 2L * cur.pos, 0);
+        if (cur.have) request_pair_mic(cur.d.x, cur.d.y + 2L * cur.pos, 1);
     }
     while (cur.have) {  // wavefront-uniform; no block barrier below
         const int stream = cur.d.x;
@@ -549,12 +555,13 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
         float *ys = a.y + (long)stream * a.n_frames * kHop;
         PairWork nxt;
         nxt.have = false;
-        // hop tA of the microphone whose loads are in flight (request_pair_mic asked for microphone 0 of this pair); the carried hop
+        // hop tA of the microphone whose loads are in flight (request_pair_mic asked for microphone 1 of this pair); the carried hop
         // stands in for hop -1, the last frame of a stream has no hop behind it
-        const float *hp = a.x + (long)stream * a.stream_stride_x + tA * kHop;
+        const float *hp0 = a.x + (long)stream * a.stream_stride_x + tA * kHop;  // microphone 0's
+        const float *hp = hp0 + a.mic_stride;
         const float *hist0 = a.hist + (long)stream * M * kHop;
         const bool first_hop = tA < 1, last_hop = !(tA + 1 < a.n_frames);
-        (void)hp; (void)hist0; (void)first_hop; (void)last_hop;
+        (void)hp; (void)hp0; (void)hist0; (void)first_hop; (void)last_hop;
 
         double Sr[16], Si[16];
         // one microphone: forward transform of (frame tA, frame tA + 1) and S += ce_m Z_m.  Instantiated twice (FIRST: the microphone
@@ -598,8 +605,8 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
 #endif
             } else {
                 nxt = draw_pair(s_work, sc, lane);
-                if (nxt.have) request_pair_mic(nxt.d.x, nxt.d.y + 2L * nxt.pos, 0);
-                else request_pair_mic(stream, tA, 0);
+                if (nxt.have) request_pair_mic(nxt.d.x, nxt.d.y + 2L * nxt.pos, 1);
+                else request_pair_mic(stream, tA, 1);
             }
             cx<double> tw[15];
             BF_STAGE();
@@ -626,8 +633,8 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
             BF_STAGE();
             w64_T2_any<true>(re, im, row16 - 16 * (lane >> 4), lane >> 4);
             cxa g[16];
-            const lds_gain_t gd = (lds_gain_t)(size_t)(gd0 + (unsigned)(m * kGMic * 16));  // k3 < 2: row (g, k3), column lane
-            const lds_gain_t gm = (lds_gain_t)(size_t)((g_mirror + (unsigned)(2 * m * kGMic * 16)) - (gd0 + (unsigned)(m * kGMic * 16)));  // k3 >= 2: row (3 - g, 3 - k3), column 64 - lane, conjugated
+            const lds_gain_t gd = (lds_gain_t)(size_t)(gd0 + (unsigned)((m - 1) * kGMic * 16));  // k3 < 2: row (g, k3), column lane
+            const lds_gain_t gm = (lds_gain_t)(size_t)((g_mirror + (unsigned)(2 * (m - 1) * kGMic * 16)) - (gd0 + (unsigned)((m - 1) * kGMic * 16)));  // k3 >= 2: row (3 - g, 3 - k3), column 64 - lane, conjugated
             BF_STAGE();
 #pragma unroll
             for (int r = 0; r < 8; ++r)
@@ -652,10 +659,20 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
                 }
             }
         };
-        one_mic(0, std::true_type{});
-        for (int m = 1; m < M; ++m) one_mic(m, std::false_type{});
+        one_mic(1, std::true_type{});
+        for (int m = 2; m < M; ++m) one_mic(m, std::false_type{});
         float *yo = ys + tA * kHop;
         cx<double> tw[15];
+        BF_STAGE();
+        {  // microphone 0's hops tA - 1, tA, tA + 1: in flight during the backward transform
+            const float *h0 = first_hop ? hist0 : hp0 - kHop, *h2 = last_hop ? hp0 : hp0 + kHop;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                q0[j] = h0[(unsigned)(64 * j + lane)];
+                q1[j] = hp0[(unsigned)(64 * j + lane)];
+                q2[j] = h2[(unsigned)(64 * j + lane)];
+            }
+        }
         BF_STAGE();
         load_tw2<1, 16>(tw, s_tw2, lane);
         BF_STAGE();
@@ -679,6 +696,17 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
         // Whichever side gets there first claims the boundary (LDS atomic), parks its half in the output hop itself and publishes it
         // once the stores are acknowledged; the other side finds the claim, reads the hop back, adds its half and stores the hop for
         // good.  Nobody waits for anybody's arithmetic -- at most for a store acknowledgement when both arrive within a microsecond.
+        // microphone 0: h[n] x_0[n] / M joins Re / N in double (frame tA in the real, frame tA + 1 in the imaginary part; a lone frame's
+        // imaginary part is not used)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double w0 = wrow[j], w1 = wrow[j + 8];
+            const double c = (double)q1[j];
+            Sr[j] = fma((double)q0[j] * w0, inv_m, Sr[j]);
+            Sr[j + 8] = fma(c * w1, inv_m, Sr[j + 8]);
+            Si[j] = fma(c * w0, inv_m, Si[j]);
+            Si[j + 8] = fma((double)q2[j] * w1, inv_m, Si[j + 8]);
+        }
         float oA[16], tl[8];
         if (pair) {
 #pragma unroll
@@ -824,7 +852,11 @@ __global__ void das_f64_sched_kernel(DasSchedPlan p, int4 *chunks, unsigned *cou
 }  // namespace
 
 // planar input: the frame-pair kernel; [sample][mic] input: the microphone-pair kernel
-static bool use_pair_kernel(const DasF64Args &a) { return a.layout == 0 && a.gains_mic != nullptr && a.sched_ws != nullptr; }
+// (the frame-pair kernel never transforms microphone 0: it needs the reference's unit weight row there -- das.cpp:33-38, always true for das
+// on a handle that started cold -- and a second microphone; anything else goes through the chain)
+static bool use_pair_kernel(const DasF64Args &a) {
+    return a.layout == 0 && a.gains_mic != nullptr && a.sched_ws != nullptr && a.mic0_unit != 0 && a.n_mics >= 2;
+}
 
 bool das_f64_writes_hist(const DasF64Args &a) { return use_pair_kernel(a) && a.hist_out != nullptr; }
 
@@ -861,6 +893,7 @@ hipError_t prepare_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s) {
         BF_LAUNCH(das_f64_sched_kernel, dim3((unsigned)p.n_chunks), dim3(128), 0, s, p, chunks, counter, a.y, a.n_frames, a.n_streams);
         return hipGetLastError();
     }
+    if (a.layout == 0) return hipErrorNotSupported;  // (planar input without the pair kernel's tables or with a non-unit row 0: the chain serves it)
     long fpc, cps;
     das_f64_w64_runs(a, n_cus, &fpc, &cps);
     if (cps > 1)

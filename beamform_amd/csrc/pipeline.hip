@@ -170,6 +170,9 @@ class BinPipelineImpl : public BinPipeline {
             PIPE_HIP(hipMemcpyAsync(d_dasg_w64_[nxt], dg64.data(), dg64.size() * sizeof(f64x2), hipMemcpyHostToDevice, stream));
             dgm = das_mic_gains_w64_f64(dirs[0], 8);
             PIPE_HIP(hipMemcpyAsync(d_dasg_mic_[nxt], dgm.data(), dgm.size() * sizeof(f64x2), hipMemcpyHostToDevice, stream));
+            bool unit = true;  // das.cpp:33-38 writes weights(0, j) = 1 once; only then may the pair kernel skip microphone 0's transform
+            for (int j = 0; j < N_ && unit; ++j) unit = dirs[0].at(j, 0, 0) == cplxd(1.0, 0.0);
+            das_mic0_unit_[nxt] = unit;
         }
         PIPE_HIP(hipMemcpyAsync(d_steer_[nxt], t.data(), t.size() * sizeof(f64x2), hipMemcpyHostToDevice, stream));
         PIPE_HIP(hipStreamSynchronize(stream));  // `t` is pageable and about to go out of scope
@@ -192,6 +195,7 @@ class BinPipelineImpl : public BinPipeline {
         sn.steer_dir_stride = steer_dir_stride_;
         sn.das_gains_w64 = d_dasg_w64_[steer_cur_];
         sn.das_gains_mic = d_dasg_mic_[steer_cur_];
+        sn.das_mic0_unit = das_mic0_unit_[steer_cur_];
         gss_reset_mask_ = 0;
         return sn;
     }
@@ -275,6 +279,7 @@ class BinPipelineImpl : public BinPipeline {
     f64x2 *d_tw_w64_ = nullptr;                  // twiddle_table_w64_rot
     void *d_das_sched_ = nullptr;                // das_f64_pair_kernel: chunk table + counter (das_f64_sched_ws_bytes())
     f64x2 *d_dasg_mic_[2] = {nullptr, nullptr};  // das_mic_gains_w64_f64 (frame-pair kernel)
+    bool das_mic0_unit_[2] = {false, false};     // ... and whether microphone 0's weight row in that table is identically 1
     int steer_cur_ = 0;
     float *d_hist2_[2] = {nullptr, nullptr};  // ring hop in front of the next batch; two buffers: das_f64_pair_kernel writes the carry itself
     int hist_cur_ = 0;
@@ -312,6 +317,7 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
         da.stream_stride_x = (long)M_ * F * H_; da.n_streams = S_; da.n_mics = M_; da.run_len = 1;
         da.layout = layout;
         da.gains = snap.das_gains_w64; da.gains_mic = snap.das_gains_mic; da.tw = d_tw_w64_;
+        da.mic0_unit = snap.das_mic0_unit ? 1 : 0;
         da.sched_ws = d_das_sched_; da.sched_ws_bytes = d_das_sched_ ? das_f64_sched_ws_bytes() : 0;
         hipError_t de = prepare_das_f64_w64(da, n_cus_, stream);
         if (de == hipSuccess) {

@@ -24,6 +24,7 @@ struct RunSnapshot {
     const f64x2 *steer = nullptr;
     long steer_dir_stride = 0;
     const f64x2 *das_gains_mic = nullptr;  // per-microphone Hermitian gains of the frame-pair kernel (das_f64_pair_kernel)
+    bool das_mic0_unit = false;            // row 0 of the das weights is identically 1 in that table (das.cpp:33-38; quirk Q3 can leave it 0)
     const f64x2 *das_gains_w64 = nullptr;  // the same gains in the register / lane order of the 64-lane kernel (das_f64_w64.hip)
 };
 
