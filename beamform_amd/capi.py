@@ -19,7 +19,8 @@ LIB_PATH = os.environ.get("BFCORE_LIB") or os.path.join(_HERE, "lib", "libbfcore
 BF_MAX_MICS = 32
 BF_MAX_INTERF = 15
 BF_PLANAR, BF_INTERLEAVED = 0, 1
-BF_DAS_FUSED_F32, BF_DAS_BINS_F64 = 0, 1
+BF_PRECISION_REFERENCE, BF_PRECISION_MIXED = 0, 1   # bf_precision: doubles between the transforms (default) / z48 spectra + fp32 backward transform
+BF_DAS_FUSED_F32, BF_DAS_F64 = 0, 1   # bf_das_impl: fp32 opt-in / double like the reference (the default, as in bf_config_init)
 
 #: every symbol include/bfcore.h declares
 EXPORTS = (
@@ -50,7 +51,7 @@ class BfConfig(C.Structure):
         ("mpf_alphaS", C.c_double), ("mpf_eta", C.c_double), ("mpf_rev_gamma", C.c_double),
         ("mpf_rev_delta", C.c_double), ("noise_floor", C.c_double),
         ("out_only_noise", C.c_int), ("out_only_mcra", C.c_int),
-        ("device", C.c_int), ("n_streams", C.c_int), ("layout", C.c_int), ("das_impl", C.c_int), ("n_dirs", C.c_int),
+        ("device", C.c_int), ("n_streams", C.c_int), ("layout", C.c_int), ("das_impl", C.c_int), ("precision", C.c_int), ("n_dirs", C.c_int),
         ("gsc_use_vad", C.c_int), ("gsc_vad_threshold", C.c_double), ("gsc_mu0", C.c_double), ("gsc_mu_max", C.c_double),
         ("gsc_filter_size", C.c_int),
     ]
@@ -376,7 +377,7 @@ def resampler_default_table():
 
 
 def config_from_params(p: dict, device: int = 0, n_streams: int = 1, layout: int = BF_PLANAR,
-                       das_impl: int = BF_DAS_FUSED_F32, n_dirs: int = 1) -> BfConfig:
+                       das_impl: int = BF_DAS_F64, n_dirs: int = 1, precision: int = BF_PRECISION_REFERENCE) -> BfConfig:
     """bf_config from a beamform_amd.params dict (launch defaults first, then overrides)."""
     L = load()
     c = BfConfig()
@@ -399,6 +400,7 @@ def config_from_params(p: dict, device: int = 0, n_streams: int = 1, layout: int
               "gsc_filter_size"):
         setattr(c, k, p[k] if k in p else _LATER_KEYS[k])  # fixtures written before a key existed
     c.device, c.n_streams, c.layout, c.das_impl, c.n_dirs = device, n_streams, layout, das_impl, n_dirs
+    c.precision = precision
     return c
 
 
@@ -420,9 +422,9 @@ class Beamformer:
     """One beamformer node behind the C ABI (das|mvdr|lcmv|gss|phase|phasempf|mcra|gsc)."""
 
     def __init__(self, params: dict, device: int = 0, n_streams: int = 1, layout: int = BF_PLANAR,
-                 das_impl: int = BF_DAS_FUSED_F32, n_dirs: int = 1):
+                 das_impl: int = BF_DAS_F64, n_dirs: int = 1, precision: int = BF_PRECISION_REFERENCE):
         self._L = load()
-        self.cfg = config_from_params(params, device, n_streams, layout, das_impl, n_dirs)
+        self.cfg = config_from_params(params, device, n_streams, layout, das_impl, n_dirs, precision)
         self.n_dirs = max(1, n_dirs)
         self.n_out = n_streams * self.n_dirs  # output streams: [stream][dir]
         self.M, self.H, self.N = params["n_mics"], params["hop"], 2 * params["hop"]

@@ -382,6 +382,8 @@ int bf_create(const bf_config *cfg, bf_handle **out) {
         return fail(nullptr, BF_ENOSYS, "look-direction batches: mcra has no look direction, gsc is not built for them");
     if (cfg->n_interf < 0 || cfg->n_interf > BF_MAX_INTERF) return fail(nullptr, BF_EINVAL, "n_interf out of range");
     if (cfg->layout != BF_PLANAR && cfg->layout != BF_INTERLEAVED) return fail(nullptr, BF_EINVAL, "layout");
+    if (cfg->precision != BF_PRECISION_REFERENCE && cfg->precision != BF_PRECISION_MIXED) return fail(nullptr, BF_EINVAL, "precision");
+    if (cfg->das_impl != BF_DAS_FUSED_F32 && cfg->das_impl != BF_DAS_F64) return fail(nullptr, BF_EINVAL, "das_impl");
     int ndev = bf_device_count();
     if (ndev <= 0) return fail(nullptr, BF_ENODEV, "no HIP device visible; libbfcore has no CPU fallback");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, BF_ENODEV, "device ordinal out of range");
@@ -939,7 +941,7 @@ static uint64_t state_cfg_hash(const bf_handle *h) {
                         c.mcra_alphaS, c.mcra_alphaD, c.mcra_alphaD2, c.mcra_delta, c.mpf_alphaS, c.mpf_eta, c.mpf_rev_gamma,
                         c.mpf_rev_delta, c.gsc_mu0, c.gsc_mu_max};
     mix(d, sizeof(d));
-    const int i[] = {c.past_windows, c.smooth_size, c.mcra_L, c.layout, c.gsc_filter_size, h->n_dirs};
+    const int i[] = {c.past_windows, c.smooth_size, c.mcra_L, c.layout, c.gsc_filter_size, h->n_dirs, c.precision};  // (precision: the stored element of the covariance history)
     mix(i, sizeof(i));
     return x;
 }

@@ -106,7 +106,8 @@ int bf_config_init(bf_config *c, int algo) {
     c->device = 0;
     c->n_streams = 1;
     c->layout = BF_PLANAR;
-    c->das_impl = BF_DAS_FUSED_F32;
+    c->das_impl = BF_DAS_F64;  // the reference's arithmetic (das.cpp:16-24); BF_DAS_FUSED_F32 is the opt-in
+    c->precision = BF_PRECISION_REFERENCE;  // ... between the transforms too; BF_PRECISION_MIXED is the opt-in
     return BF_OK;
 }
 

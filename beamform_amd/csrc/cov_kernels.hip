@@ -60,7 +60,7 @@ __device__ __forceinline__ void lds_dma(const char *g, void *l) {
 // KC = constraint columns: 1 = mvdr (the steering vector); 2..4 = lcmv with up to KC - 1 interferers (lcmv.cpp:102-130): the
 // columns C ride through the factorisation like the steering vector does (U = L^-1 C, v = L^-1 x), then G = U^H U, g = U^H v and
 // y = (G^-1 g)_0 -- the first row of W^H x with W = R^-1 C (C^H R^-1 C)^-1.  Unused columns are padded with the identity.
-// Z128: the spectra are complex doubles (BF_Z48=0: 16 bytes per element, stored unhalved) instead of z48 (12 bytes, stored halved)
+// Z128: the spectra are complex doubles (the default, BF_PRECISION_REFERENCE: 16 bytes per element, stored unhalved) instead of z48 (BF_PRECISION_MIXED: 12 bytes, stored halved)
 template <int MP, int KC, bool Z128>
 __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan fp) {
     constexpr int NT = MP * (MP + 1) / 2;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
     const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
 
     // one microphone's spectrum at this problem's bin, frame t (may be negative: history); z48 elements (stored halved) or,
-    // with BF_Z48=0, full doubles (halved here)
+    // (the default) full doubles (halved here)
     const int ksrc = q_src_bin(q), kneg = (kN - ksrc) & (kN - 1);
     auto ldz = [&](long e) -> cd { return a.z48 ? ld(reinterpret_cast<const z48 *>(a.Z) + e) : ld(a.Z + e) * 0.5; };
     auto load_xi = [&](long t) -> cd {
@@ -619,7 +619,8 @@ __device__ __forceinline__ double quads_sum(double v) {
 // local lower triangle (a >= b) of a 4 x 4 block, row-major
 __device__ constexpr int LT(int a, int b) { return a * (a + 1) / 2 + b; }
 
-template <int KM, int WPS>
+// Z128: the spectra are complex doubles (the default, BF_PRECISION_REFERENCE: 16 bytes per element, stored unhalved) instead of z48
+template <int KM, int WPS, bool Z128>
 __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, int tiles_per_stream) {
     constexpr int NB = KM + 1, NS = (NB + 3) / 4;  // right-hand sides, slots per lane
     constexpr int NG = GramIdx<KM>::NG, NE = GramIdx<KM>::NE;
@@ -653,7 +654,8 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
     const int j = q_bin(qq);
     const bool lcmv = a.cfg.algo == BF_LCMV;
     const long yidx = ((long)s * a.n_frames) * kYhStride + qq;
-    const z48 *Zs = reinterpret_cast<const z48 *>(a.Z) + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
+    typedef typename std::conditional<Z128, f64x2, z48>::type zel;  // stored element
+    const zel *Zs = reinterpret_cast<const zel *>(a.Z) + ((long)(s / a.n_dirs) * a.frames_ws + a.frame_off) * NP * kN;
     const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
     const int ksrc = q_src_bin(qq), kneg = (kN - ksrc) & (kN - 1);
     const int addrT = 4 * ((lane & ~15) | (q << 2) | p);  // my transpose partner (q, p)
@@ -662,16 +664,20 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
     // where it is needed (finish_mic): a load issued where its value is used costs its full latency every frame -- the compiler cannot
     // move it above the st_y in between -- and two wavefronts per SIMD do not hide that
     struct RawMic {
-        z48 z, zc;
+        zel z, zc;
     };
     const int mic_pair = (l16 < M ? l16 : 0) >> 1;
     auto load_raw = [&](long t) -> RawMic {
-        const z48 *Zf = Zs + t * NP * kN + mic_pair * kN;
+        const zel *Zf = Zs + t * NP * kN + mic_pair * kN;
         return RawMic{Zf[ksrc], Zf[kneg]};
+    };
+    auto dec = [](const zel &v) -> cd {
+        if constexpr (Z128) return cd{v.x * 0.5, v.y * 0.5};  // (exact)
+        else return dec48(v);
     };
     auto finish_mic = [&](const RawMic &r) -> cd {
         if (l16 >= M) return cd{0, 0};
-        const cd z = dec48(r.z), zc = conj(dec48(r.zc));
+        const cd z = dec(r.z), zc = conj(dec(r.zc));
         cd x;
         if ((l16 & 1) == 0) {
             x = z + zc;  // z48 spectra are stored halved
@@ -915,7 +921,7 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
     const int M = a.n_mics, km = a.kp1 <= 1 ? 1 : 4;
     static const bool no_fast_env = getenv("BF_MVDR_GROUP") && atoi(getenv("BF_MVDR_GROUP")) != 0;
     const bool no_fast = no_fast_env;
-    const bool no_2d = no_fast_env || !a.z48;  // cov2d_kernel reads z48 spectra only (BF_Z48=0 at 9..16 microphones: the group-per-problem kernel)
+    const bool no_2d = no_fast_env;
     // frequencies of the irregular problems (quirk Q1, util.h:190-199): f[N/2] = 0, f[N/2+1] = -(N/2-1) sr/N
     const double f_qx = (double)(kN / 2 - 1) * a.cfg.sample_rate / (double)kN;
     const bool band_hits_nyquist = (0.0 >= a.cfg.freq_min && 0.0 <= a.cfg.freq_max) || (f_qx >= a.cfg.freq_min && f_qx <= a.cfg.freq_max);
@@ -950,8 +956,13 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
     // wavefronts at 211 registers are 7 % faster; without constraints (mvdr) three wavefronts win by 12 %
     if (!no_2d && M > 8 && M <= 16) {
         const dim3 grid((unsigned)(((long)tps * a.n_streams + 7) / 8 * 8 * ((kNQ + 15) / 16)));  // (unit, problem group) -> XCD-aware order in the kernel
-        if (km == 1) BF_LAUNCH((cov2d_kernel<1, 3>), grid, dim3(256), 0, s, a, tile, tps);
-        else BF_LAUNCH((cov2d_kernel<4, 2>), grid, dim3(256), 0, s, a, tile, tps);
+        if (km == 1) {
+            if (a.z48) BF_LAUNCH((cov2d_kernel<1, 3, false>), grid, dim3(256), 0, s, a, tile, tps);
+            else BF_LAUNCH((cov2d_kernel<1, 3, true>), grid, dim3(256), 0, s, a, tile, tps);
+        } else {
+            if (a.z48) BF_LAUNCH((cov2d_kernel<4, 2, false>), grid, dim3(256), 0, s, a, tile, tps);
+            else BF_LAUNCH((cov2d_kernel<4, 2, true>), grid, dim3(256), 0, s, a, tile, tps);
+        }
         return hipGetLastError();
     }
     if ((a.cfg.algo == BF_MVDR || lcmv_fast) && M <= 8 && !no_fast) {

@@ -60,10 +60,8 @@ class BinPipelineImpl : public BinPipeline {
         const bool multi = (c.algo == BF_LCMV || c.algo == BF_GSS);
         KP1_ = multi ? c.n_interf + 1 : 1;
         Phist_ = (c.algo == BF_MVDR || c.algo == BF_LCMV) ? c.past_windows : 0;
-        // packed spectra as 12-byte z48 elements (pipeline_kernels.hpp); BF_Z48=0 keeps full doubles and the group-per-problem kernel:
-        // the switch for comparing against the reference on ill-conditioned scenes (36 mantissa bits x cond(R))
-        static const bool z48_off = getenv("BF_Z48") && atoi(getenv("BF_Z48")) == 0;
-        z48_ = (c.algo == BF_MVDR || c.algo == BF_LCMV) && !z48_off;
+        // BF_PRECISION_MIXED: mvdr / lcmv park their spectra as 12-byte z48 elements (pipeline_kernels.hpp); the default keeps complex doubles
+        z48_ = (c.algo == BF_MVDR || c.algo == BF_LCMV) && c.precision == BF_PRECISION_MIXED;
         zsz_ = z48_ ? sizeof(z48) : sizeof(f64x2);
     }
     ~BinPipelineImpl() override { free_all(); }
@@ -402,15 +400,12 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     ba.n_dirs = D_; ba.steer_dir_stride = snap.steer_dir_stride;
     ba.z48 = z48_ ? 1 : 0;
     ba.cfg = cfg_; ba.gssW = d_gssW_; ba.mpf = d_mpf_; ba.gss_reset_mask = snap.gss_reset_mask;
-    // Backward transform.  Default: in double (istft_w64_kernel, 0.157 ms per 65 536 frames against the fp32 kernel's 0.148) for every
-    // node but mvdr / lcmv -- with it the float output of das, phase, phasempf, gss and mcra equals the oracle's bit for bit -- and in
-    // fp32 behind mvdr / lcmv, whose solve hands it band-limited f32x2 rows (half the row traffic, no zero-fill: 2.16 against 2.3 ms).
-    // BF_ISTFT_F64=1: in double everywhere; BF_ISTFT_F64=0: in fp32 wherever a per-bin stage can emit f32x2 rows (das / phase through the
-    // bin pipeline, phasempf, mvdr, lcmv: round 4's default).  gsc (its sample-serial NLMS branches on the aligned signals), a spectrum
-    // dump and the other FFT sizes: always in double.
-    static const int istft_env = getenv("BF_ISTFT_F64") ? atoi(getenv("BF_ISTFT_F64")) : -1;
-    const bool cov_node = cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV;
-    const bool want32 = (istft_env == 0 || (istft_env < 0 && cov_node)) && cfg_.algo != BF_GSC && N_ == 1024 && spectrum == nullptr;
+    // Backward transform.  BF_PRECISION_REFERENCE (the default): in double behind every node (istft_w64_kernel at N = 1024: with it the float
+    // output of das, phase, phasempf, gss and mcra equals the oracle's bit for bit).  BF_PRECISION_MIXED: in fp32 (istft32_kernel) wherever
+    // the per-bin stage can emit f32x2 rows: mvdr / lcmv (band-limited rows: half the row traffic, no zero-fill), das / phase through the
+    // bin pipeline, phasempf.  gsc (its sample-serial NLMS branches on the aligned signals), a spectrum dump and the other FFT sizes: always
+    // in double.
+    const bool want32 = cfg_.precision == BF_PRECISION_MIXED && cfg_.algo != BF_GSC && N_ == 1024 && spectrum == nullptr;
     // mvdr / lcmv hand the fp32 transform f32x2 rows holding only problem 0 and the in-band problems (everything else is zero,
     // mvdr.cpp:103); das / phase through the bin pipeline: f32x2 rows too (every problem written)
     const bool pointwise32 = (cfg_.algo == BF_DAS || cfg_.algo == BF_PHASE) && want32;

@@ -217,8 +217,9 @@ def main():
     ap.add_argument("--frames", type=int, default=65536, help="frames per GPU per step (per stream)")
     ap.add_argument("--streams", type=int, default=1)
     ap.add_argument("--layout", default="planar", choices=["planar", "interleaved"])
-    ap.add_argument("--das-f64", action="store_true", help="das in double, the reference's arithmetic (BF_DAS_BINS_F64): the default")
+    ap.add_argument("--das-f64", action="store_true", help="das in double, the reference's arithmetic (BF_DAS_F64): the default")
     ap.add_argument("--das-f32", action="store_true", help="das through the fused fp32 kernel (BF_DAS_FUSED_F32) as the headline")
+    ap.add_argument("--mixed", action="store_true", help="bf_config.precision = BF_PRECISION_MIXED (z48 spectra for mvdr / lcmv, fp32 backward transform); default: the reference's doubles")
     ap.add_argument("--strong", action="store_true",
                     help="N > 1: keep the global stream at --total-frames for every N (strong scaling)")
     ap.add_argument("--total-frames", type=int, default=0,
@@ -259,7 +260,7 @@ def main():
     import torch.distributed as dist
 
     from beamform_amd import shard
-    from beamform_amd.capi import BF_DAS_BINS_F64, BF_DAS_FUSED_F32, BF_INTERLEAVED, BF_PLANAR, Beamformer
+    from beamform_amd.capi import BF_DAS_F64, BF_DAS_FUSED_F32, BF_INTERLEAVED, BF_PLANAR, BF_PRECISION_MIXED, BF_PRECISION_REFERENCE, Beamformer
     from beamform_amd.params import make_params
     from beamform_amd.synth import stream_noise
 
@@ -316,8 +317,9 @@ def main():
     interf = (-60.0, 90.0, 150.0) if args.algo in ("lcmv", "gss") else ()
     p = make_params(args.algo, n_mics=M, interf=interf)
     layout = BF_PLANAR if args.layout == "planar" else BF_INTERLEAVED
-    das_impl = BF_DAS_FUSED_F32 if (args.das_f32 and not args.das_f64) else BF_DAS_BINS_F64   # only das looks at it
-    bf = Beamformer(p, device=local_rank, n_streams=S, layout=layout, das_impl=das_impl)
+    das_impl = BF_DAS_FUSED_F32 if (args.das_f32 and not args.das_f64) else BF_DAS_F64   # only das looks at it
+    precision = BF_PRECISION_MIXED if args.mixed else BF_PRECISION_REFERENCE
+    bf = Beamformer(p, device=local_rank, n_streams=S, layout=layout, das_impl=das_impl, precision=precision)
     stream = torch.cuda.current_stream(dev)
     sptr = stream.cuda_stream
 
@@ -410,7 +412,7 @@ def main():
         # fused das: its one kernel; the other nodes run a chain of kernels (stft -> per-bin -> istft): the chain's duration
         k_ms = ms_kernel if ms_kernel > 0 else ms_call
         achieved = bpf * units_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        tag = f"{args.algo}{M}" + ("_f64" if das_impl == BF_DAS_BINS_F64 else "")
+        tag = f"{args.algo}{M}" + ("_f64" if das_impl == BF_DAS_F64 else "")
         traffic, traffic_note = (load_traffic(tag, launched_headline) if (n_feed == 65536 and S == 1 and args.layout == "planar") else (None, None))
         if sharded:
             shl = shard.plan(F_total, world, world - 1, halo)
@@ -515,9 +517,9 @@ def main():
 
     # ---- secondary lines: the other BASELINE configs, rank 0 at N = 1 -------------------------------------------
     def node_line(algo, M_, F_, S_, interf_=(), das_impl_=BF_DAS_FUSED_F32, iters=5, xin=None, note="", layout_=BF_PLANAR,
-                  with_traffic=True, roofline_kernel=None, traffic_tag=None):
+                  with_traffic=True, roofline_kernel=None, traffic_tag=None, precision_=BF_PRECISION_REFERENCE):
         pm = make_params(algo, n_mics=M_, interf=interf_)
-        bm = Beamformer(pm, device=local_rank, n_streams=S_, das_impl=das_impl_, layout=layout_)
+        bm = Beamformer(pm, device=local_rank, n_streams=S_, das_impl=das_impl_, layout=layout_, precision=precision_)
         if xin is None:
             gg = torch.Generator(device=dev).manual_seed(4321)
             xin = torch.rand((S_, M_, F_ * HOP), device=dev, generator=gg, dtype=torch.float32) - 0.5
@@ -541,8 +543,11 @@ def main():
                             + ("" if not note else "; " + note),
                 "ms_per_step": ms, "frames_per_s": fr / (ms * 1e-3),
                 "frac_of_hbm_roofline_algorithmic_bytes": bpf * fr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_frame": bpf}
-        if algo in ("mvdr", "lcmv") or das_impl_ == BF_DAS_BINS_F64:
+                "algorithmic_bytes_per_frame": bpf,
+                "arithmetic": ("fp32 (BF_DAS_FUSED_F32)" if (algo == "das" and das_impl_ == BF_DAS_FUSED_F32) else
+                               "f64 throughout, like the reference (BF_PRECISION_REFERENCE)" if precision_ == BF_PRECISION_REFERENCE else
+                               "f64 per-bin stage; z48 spectra (36-bit mantissa) in HBM for mvdr / lcmv, fp32 backward transform (BF_PRECISION_MIXED)")}
+        if algo in ("mvdr", "lcmv") or das_impl_ == BF_DAS_F64:
             fl = model_flops_per_frame(algo, M_, len(interf_), pm["past_windows"])
             line["model_flops_per_frame"] = fl
             line["frac_of_fp64_vector_peak"] = fl * fr / (ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TF
@@ -560,6 +565,8 @@ def main():
         if layout_ != BF_PLANAR or not with_traffic:  # the committed counter files are for the noise input, planar
             return line
         tag = traffic_tag or {"das": "das8_f64", "mvdr": "mvdr8", "phasempf": "phasempf8", "phase": "phase8", "lcmv": "lcmv16"}.get(algo)
+        if tag and precision_ == BF_PRECISION_MIXED:
+            tag += "_mixed"
         tr, note = load_traffic(tag, trn.kernels) if tag else (None, None)
         if tr is not None:
             line["traffic"] = tr
@@ -574,17 +581,19 @@ def main():
         noise = ("input = uniform noise in [-0.5, 0.5): every in-band bin passes the magnitude gate, so every bin-frame "
                  "takes the covariance solve (the worst case; real scenes close part of the gates)")
         jobs = [
-            ("mvdr", lambda: node_line("mvdr", M, F, 1, xin=x, note="BASELINE config 3; fp64 bin pipeline; " + noise)),
-            ("das_f32" if das_impl == BF_DAS_BINS_F64 else "das_f64",
+            ("mvdr", lambda: node_line("mvdr", M, F, 1, xin=x, note="BASELINE config 3; the library default: c128 spectra in HBM, fp64 backward transform; " + noise)),
+            ("mvdr_mixed", lambda: node_line("mvdr", M, F, 1, xin=x, precision_=BF_PRECISION_MIXED,
+                                             note="BASELINE config 3 with the BF_PRECISION_MIXED opt-in: z48 spectra, fp32 backward transform; " + noise)),
+            ("das_f32" if das_impl == BF_DAS_F64 else "das_f64",
              (lambda: node_line("das", M, F, 1, das_impl_=BF_DAS_FUSED_F32, xin=x, iters=20, roofline_kernel="das_fused_kernel", traffic_tag="das8",
                                 note="the headline batch through the fused fp32 kernel (das_fused_kernel): meets north_star's 1e-5 (1.5e-7 observed) but "
                                      "computes in single precision where the reference computes in double"))
-             if das_impl == BF_DAS_BINS_F64 else
-             (lambda: node_line("das", M, F, 1, das_impl_=BF_DAS_BINS_F64, xin=x, iters=20, roofline_kernel="das_f64_pair_kernel", traffic_tag="das8_f64",
+             if das_impl == BF_DAS_F64 else
+             (lambda: node_line("das", M, F, 1, das_impl_=BF_DAS_F64, xin=x, iters=20, roofline_kernel="das_f64_pair_kernel", traffic_tag="das8_f64",
                                 note="same precision as the reference: das_f64_pair_kernel, one launch"))),
             ("das_interleaved", lambda: node_line("das", M, F, 1, xin=x.reshape(1, F * HOP, M), layout_=BF_INTERLEAVED, iters=20,
                                                   note="the headline workload with [sample][mic] input (same bytes read as interleaved samples), fused fp32 kernel")),
-            ("das_f64_interleaved", lambda: node_line("das", M, F, 1, das_impl_=BF_DAS_BINS_F64, xin=x.reshape(1, F * HOP, M), layout_=BF_INTERLEAVED,
+            ("das_f64_interleaved", lambda: node_line("das", M, F, 1, das_impl_=BF_DAS_F64, xin=x.reshape(1, F * HOP, M), layout_=BF_INTERLEAVED,
                                                       iters=20, roofline_kernel="das_f64_w64_kernel<1>",
                                                       note="the headline kernel (double) on [sample][mic] input: a pair's two microphones are one 8-byte "
                                                            "load per sample, the four pairs of a frame re-read the same lines from L2")),
@@ -595,7 +604,9 @@ def main():
             ("phase_gate_open", lambda: node_line("phase", M, F, 1, xin=x * 8.0,
                                                   note="the same noise 8x louder: every bin passes mag_threshold and runs the 8 atan2 + 28 wrapped differences")),
             ("lcmv16", lambda: node_line("lcmv", 16, 32768, 1, (-60.0, 90.0, 150.0), iters=3,
-                                         note="BASELINE config 5, one GPU's shard of the 262144-frame stream; " + noise)),
+                                         note="BASELINE config 5, one GPU's shard of the 262144-frame stream; the library default (c128 spectra, fp64 backward transform); " + noise)),
+            ("lcmv16_mixed", lambda: node_line("lcmv", 16, 32768, 1, (-60.0, 90.0, 150.0), iters=3, precision_=BF_PRECISION_MIXED,
+                                               note="BASELINE config 5 shard with the BF_PRECISION_MIXED opt-in; " + noise)),
             ("gss", lambda: node_line("gss", 8, 256, 256, (-60.0, 90.0), with_traffic=False,
                                       note="gss 8-mic, 2 interferers, 256 streams x 256 frames (the demixing matrices recurse over the frames of a stream); " + noise)),
             ("gsc", lambda: node_line("gsc", 8, 64, 256, iters=3, with_traffic=False,
@@ -626,7 +637,7 @@ def main():
             # transforms (das_fused_gen.hip; period 1024: das_fused.hip's wavefront-per-frame kernel; below 512: das_fused.hip's group mode); same number of SAMPLES as the headline batch
             pm = make_params(algo_, n_mics=M, hop=hop_)
             F_ = F * HOP // hop_
-            bm = Beamformer(pm, device=local_rank)
+            bm = Beamformer(pm, device=local_rank, das_impl=BF_DAS_FUSED_F32)   # (only das looks at it: the fp32 opt-in's kernels)
             xin = x.reshape(1, M, F * HOP)
             yo = torch.empty((1, F_ * hop_), device=dev, dtype=torch.float32)
             ts = time.perf_counter()
@@ -652,7 +663,7 @@ def main():
             # D_ look directions of the headline batch in one call (a controller scanning candidate angles, scripts/energy2theta.py:62-101):
             # one set of forward transforms per frame serves all of them (das_fused_dirs_kernel)
             pm = make_params("das", n_mics=M)
-            bm = Beamformer(pm, device=local_rank, n_dirs=D_)
+            bm = Beamformer(pm, device=local_rank, n_dirs=D_, das_impl=BF_DAS_FUSED_F32)
             bm.set_thetas([-180.0 + 360.0 * d / D_ for d in range(D_)])
             yo = torch.empty((D_, F * HOP), device=dev, dtype=torch.float32)
             ts = time.perf_counter()
@@ -724,21 +735,6 @@ def main():
                 out[f"{algo_}_us_per_callback"] = ts[len(ts) // 2] * 1e6
             return out
 
-        def strict_line(algo_):
-            # the same node with nothing narrower than the reference's doubles anywhere: full c128 spectra in HBM (BF_Z48=0: the group-per-problem
-            # kernel reads them) and the fp64 backward transform (BF_ISTFT_F64=1).  The switches are read once per process: a child bench.py.
-            cmd = [sys.executable, os.path.abspath(__file__), "--algo", algo_, "--mics", str(M), "--frames", str(F), "--steps", "5", "--warmup", "2",
-                   "--settle-ms", "120", "--no-cpu", "--no-extra"]
-            r = subprocess.run(cmd, env=dict(os.environ, BF_Z48="0", BF_ISTFT_F64="1"), capture_output=True, text=True, timeout=600)
-            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-            if r.returncode != 0 or not lines:
-                return {"error": (r.stderr or r.stdout)[-400:]}
-            d = json.loads(lines[-1])
-            return {"workload": f"{algo_} {M}-mic 1024-pt, {F} frames with BF_Z48=0 BF_ISTFT_F64=1: c128 spectra in HBM, fp64 backward transform -- what the "
-                                "default line's z48 spectra (36-bit mantissa), fp32 gate pre-decision and fp32 backward transform buy",
-                    "ms_per_step": d["ms_per_step"], "frames_per_s": d["value"], "kernels": d["roofline"].get("kernels_launched_per_step")}
-
-        jobs.append(("mvdr_strict", lambda: strict_line("mvdr")))
         jobs.append(("resample_48k_16k", resample_line))
         jobs.append(("streaming_callback", hop_line))
         for name, job in jobs:
@@ -746,12 +742,15 @@ def main():
                 extra[name] = job()
             except Exception as e:  # the headline must not die on a secondary measurement
                 extra[name] = {"error": str(e)}
-        # round-1 field names kept for continuity
+        # round-1 field names kept for continuity (mvdr = the library default: the reference's arithmetic)
         if "ms_per_step" in extra.get("mvdr", {}):
             extra["mvdr_ms_per_step"] = extra["mvdr"]["ms_per_step"]
             extra["mvdr_frames_per_s"] = extra["mvdr"]["frames_per_s"]
             extra["mvdr_frac_of_hbm_roofline_algorithmic_bytes"] = extra["mvdr"]["frac_of_hbm_roofline_algorithmic_bytes"]
             extra["mvdr_frac_of_fp64_vector_peak"] = extra["mvdr"]["frac_of_fp64_vector_peak"]
+
+        # one figure per secondary line, LAST in the line: the round driver's record keeps the tail of it (tools/bench_tables.py reads it there)
+        extra["ms"] = {k: round(v["ms_per_step"], 4) for k, v in extra.items() if isinstance(v, dict) and isinstance(v.get("ms_per_step"), float)}
 
     if rank == 0:
         print(json.dumps(make_line(dt_g, dt_o, gather_state["error"], extra)), flush=True)

@@ -57,10 +57,26 @@ enum bf_layout {
     BF_INTERLEAVED = 1  /* [stream][sample][mic]  -- interleaved frame buffer */
 };
 
-/* DAS implementation selector (other algorithms always use the f64 bin pipeline). */
+/* Arithmetic of the das node.  The reference computes in std::complex<double> end to end (das.cpp:16-24,47-70): BF_DAS_F64 is the
+ * default (bf_config_init) and what the bench headline measures.  Other algorithms always compute in double. */
 enum bf_das_impl {
-    BF_DAS_FUSED_F32 = 0, /* one fused kernel, fp32 arithmetic (headline path) */
-    BF_DAS_BINS_F64 = 1   /* STFT -> per-bin kernel -> ISTFT in fp64; dumps the full N-bin spectrum */
+    BF_DAS_FUSED_F32 = 0, /* opt-in: one fused kernel in fp32 arithmetic (narrower than the reference's; 1.5e-7 from it, inside the 1e-5
+                             bar); also the only das path with register-resident kernels at JACK periods other than 512 and with
+                             look directions that share their forward transforms */
+    BF_DAS_F64 = 1        /* default: double arithmetic like das.cpp.  Period 512, <= 8 microphones, one look direction, no spectrum
+                             dump: ONE launch (das_f64_pair_kernel: planar input; das_f64_w64_kernel: [sample][mic]); anything else
+                             runs STFT -> per-bin kernel -> ISTFT and can dump the full N-bin spectrum */
+};
+
+/* Arithmetic of what lies between the transforms (every node computes its per-bin stage in double).
+ * BF_PRECISION_REFERENCE (bf_config_init's default): nothing is narrower than the reference's std::complex<double>: spectra cross HBM as
+ * complex doubles, the backward transform runs in double (mvdr.cpp:76-115 between fftw_execute(x_forward) and fftw_execute(y_inverse)).
+ * BF_PRECISION_MIXED (opt-in, throughput): mvdr / lcmv park their spectra as 12-byte elements (36-bit mantissa: < 1e-10 on the solved
+ * spectrum at cond(R) = 3e4) and every node whose per-bin stage can emit float rows runs the backward transform in fp32 (1.1e-7 on the
+ * output instead of bit-identity with the double path).  Both are inside the 1e-5 parity bar; only REFERENCE is the reference's arithmetic. */
+enum bf_precision {
+    BF_PRECISION_REFERENCE = 0,
+    BF_PRECISION_MIXED = 1
 };
 
 /*
@@ -76,7 +92,7 @@ typedef struct bf_config {
                                       Any power of two from 64 to 4096 (what jackd -p accepts in that range).  512 is the tuned
                                       shape (in-register FFT-1024 kernels); 64 ... 256 and 1024 run on the same register-resident
                                       machinery (several short frames per transform, or two FFT-1024 per long frame) for das
-                                      (BF_DAS_FUSED_F32, one fused fp32 kernel) and for the fp64 bin pipeline of every other node;
+                                      (with the BF_DAS_FUSED_F32 opt-in: one fused fp32 kernel) and for the fp64 bin pipeline of das in double and of every other node;
                                       2048 and 4096 on LDS-staged transforms (radix-4 autosort; radix-2 in place at 4096) */
     double sample_rate;            /* rosjack_sample_rate */
     double mic_x[BF_MAX_MICS];     /* RAW mic<i>.x / .y from beamform_config.yaml (util.h:82-92) */
@@ -107,7 +123,8 @@ typedef struct bf_config {
     int device;                    /* HIP device ordinal */
     int n_streams;                 /* independent audio streams per batch (each = one reference node's state) */
     int layout;                    /* enum bf_layout for bf_process_batch* input */
-    int das_impl;                  /* enum bf_das_impl */
+    int das_impl;                  /* enum bf_das_impl; bf_config_init: BF_DAS_F64 (the reference's arithmetic) */
+    int precision;                 /* enum bf_precision; bf_config_init: BF_PRECISION_REFERENCE */
     int n_dirs;                    /* look directions evaluated per input stream from the SAME samples (0/1 = one, the
                                       reference node).  Output stream index = stream * n_dirs + dir.  Every node except mcra
                                       (no look direction) and gsc; gss / phasempf keep their recursive state per beam.

@@ -128,17 +128,17 @@ os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29673", RANK="0", WORLD_
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 from beamform_amd import shard
-from beamform_amd.capi import Beamformer
+from beamform_amd.capi import BF_DAS_FUSED_F32, Beamformer
 from beamform_amd.params import make_params
 p = make_params("das", n_mics=8)
 F, H = 3001, 512
 x = torch.rand(8, F * H, device="cuda") - 0.5
 y = torch.empty(F * H, device="cuda"); out = torch.full((F * H,), float("nan"), device="cuda"); ref = torch.empty(F * H, device="cuda")
-bf = Beamformer(p)
+bf = Beamformer(p, das_impl=BF_DAS_FUSED_F32)
 for w in shard.run_shard_overlapped(bf, x, y, F, 1, 0, shard.halo_frames(p), n_pieces=5, out=out, stream=torch.cuda.current_stream().cuda_stream, self_loop=True):
     w.wait()
 torch.cuda.synchronize()
-Beamformer(p).process_device(x.data_ptr(), F, ref.data_ptr())
+Beamformer(p, das_impl=BF_DAS_FUSED_F32).process_device(x.data_ptr(), F, ref.data_ptr())
 torch.cuda.synchronize()
 assert torch.equal(out, ref), float((out - ref).abs().max())
 dist.destroy_process_group()
@@ -156,9 +156,9 @@ def test_traffic_files_name_the_kernels_that_run():
     import torch
     sys.path.insert(0, ROOT)
     import bench
-    from beamform_amd.capi import BF_DAS_BINS_F64, BF_DAS_FUSED_F32, Beamformer, launch_trace
+    from beamform_amd.capi import BF_DAS_F64, BF_DAS_FUSED_F32, Beamformer, launch_trace
     from beamform_amd.params import make_params
-    cases = {"das8_f64": ("das", 8, 65536, 1, (), BF_DAS_BINS_F64), "das8": ("das", 8, 65536, 1, (), BF_DAS_FUSED_F32),
+    cases = {"das8_f64": ("das", 8, 65536, 1, (), BF_DAS_F64), "das8": ("das", 8, 65536, 1, (), BF_DAS_FUSED_F32),
              "mvdr8": ("mvdr", 8, 65536, 1, (), 0), "phase8": ("phase", 8, 65536, 1, (), 0),
              "phasempf8": ("phasempf", 8, 256, 256, (), 0), "lcmv16": ("lcmv", 16, 32768, 1, (-60.0, 90.0, 150.0), 0)}
     for tag, (algo, M, F, S, interf, impl) in cases.items():

@@ -1,4 +1,5 @@
-"""GPU parity of the fused fp32 DAS kernel against the CPU oracle (through the C ABI)."""
+"""GPU parity of the das node against the CPU oracle (through the C ABI), once per arithmetic: double like the reference (the default:
+das_f64_pair_kernel / das_f64_w64_kernel / the fp64 bin pipeline with a spectrum dump) and the fused fp32 opt-in (conftest.das_impls)."""
 import numpy as np
 import pytest
 
@@ -6,7 +7,7 @@ from beamform_amd.params import make_params
 from beamform_amd.synth import make_scene
 from conftest import rel_l2
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("das_impls")]
 
 # north_star tolerance: 1e-5 relative on the complex spectrum (per-frame relative L2)
 TOL_SPECTRUM = 1e-5
@@ -30,7 +31,7 @@ def _herm(Y):
 @pytest.mark.parametrize("M,theta,F", [(8, 0.0, 40), (8, 20.0, 64), (4, -35.0, 33), (3, 60.0, 17), (16, 90.0, 24), (1, 0.0, 5)])
 def test_das_fused_matches_oracle(M, theta, F):
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     torch = _torch()
     mics = None if M <= 16 else None
     p = make_params("das", n_mics=M, theta=theta)
@@ -44,7 +45,7 @@ def test_das_fused_matches_oracle(M, theta, F):
     bf.process_device(xd.data_ptr(), F, yd.data_ptr(), Yd.data_ptr())
     torch.cuda.synchronize()
     y = yd.cpu().numpy()
-    Yh = Yd.cpu().numpy().view(np.complex128)[..., 0]
+    Yh = _herm(Yd.cpu().numpy().view(np.complex128)[..., 0])   # (the fp32 kernel dumps the Hermitian part, the fp64 pipeline the full y_fft)
 
     assert rel_l2(y, y_ref) < TOL_TIME
     Yh_ref = _herm(Y_ref)
@@ -55,7 +56,7 @@ def test_das_fused_matches_oracle(M, theta, F):
 def test_das_streaming_equals_batch_and_oracle():
     """bf_process_hop one callback at a time == one batch == oracle; state carries across calls."""
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     _torch()
     M, F = 4, 12
     p = make_params("das", n_mics=M, theta=15.0)
@@ -74,7 +75,7 @@ def test_das_streaming_equals_batch_and_oracle():
 
 def test_das_set_theta_takes_effect_next_batch():
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     _torch()
     M, F = 8, 10
     p = make_params("das", n_mics=M, theta=0.0)
@@ -96,7 +97,8 @@ def test_das_interleaved_layout_and_streams(M, F, S):
     """[sample][mic] input: 4 and 8 microphones take the 16-byte-load kernel (two pairs per access), the rest the generic one;
     F = 300 crosses run boundaries (atomic first hops) and ends inside a 16-frame iteration."""
     import oracle
-    from beamform_amd.capi import Beamformer, BF_INTERLEAVED
+    from beamform_amd.capi import BF_INTERLEAVED
+    from conftest import Beamformer
     _torch()
     p = make_params("das", n_mics=M, theta=33.0)
     xs = [make_scene(M, F, seed=20 + s) for s in range(S)]
@@ -111,7 +113,7 @@ def test_das_interleaved_layout_and_streams(M, F, S):
 
 
 def test_das_checkpoint_roundtrip():
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     _torch()
     M, F = 8, 8
     p = make_params("das", n_mics=M, theta=10.0)
@@ -132,7 +134,7 @@ def test_das_large_batch_properties():
         (util.h:301-302 + sqrt-Hann^2 COLA; the only known-answer property the reference offers, jack_ref.cpp);
     (b) linearity: DAS(a*x1 + x2) == a*DAS(x1) + DAS(x2);
     (c) chunk independence: a sub-batch cut out of the middle reproduces the same samples."""
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     torch = _torch()
     M, F = 8, 65536
     co = [(0.0, 0.0)] * M                     # co-located mics: every delay is 0
@@ -175,7 +177,7 @@ def test_das_large_batch_random_oracle_windows():
     compute them in the middle of the stream.  Windows at random offsets, at run boundaries of the kernel's frame walk
     (multiples of 256 and of 16) and at both ends of the batch."""
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     torch = _torch()
     M, F, n = 8, 65536, 24
     p = make_params("das", n_mics=M, theta=-40.0)
@@ -200,7 +202,8 @@ def test_das_interleaved_equals_planar_at_the_baseline_size(M):
     """65 536 frames: the 16-byte-load kernel for [sample][mic] input against the planar kernel on the transposed data
     (same transform; the two kernels round the window multiply differently, hence a tolerance of a few float ulps)."""
     torch = _torch()
-    from beamform_amd.capi import Beamformer, BF_INTERLEAVED
+    from beamform_amd.capi import BF_INTERLEAVED
+    from conftest import Beamformer
     F = 65536
     g = torch.Generator(device="cuda").manual_seed(5)
     x = torch.rand((M, F * 512), device="cuda", generator=g) - 0.5

@@ -10,7 +10,7 @@ from beamform_amd.params import make_params
 from beamform_amd.synth import make_scene
 from conftest import rel_l2
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("das_f32")]
 TOL_TIME = 1e-5
 
 
@@ -28,7 +28,7 @@ def _same(y, ref, x):
 
 def _run(p, x, thetas, cuts=None, n_streams=1):
     import torch
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     assert torch.cuda.is_available()
     F = x.shape[-1] // 512
     D = len(thetas)
@@ -47,7 +47,7 @@ def _run(p, x, thetas, cuts=None, n_streams=1):
 
 
 def _single(p, x, theta):
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     return Beamformer(dict(p, theta=theta)).process(x)
 
 
@@ -84,7 +84,7 @@ def test_shared_forward_transforms_across_uneven_batches_and_streams():
 def test_shared_forward_transforms_at_the_baseline_size():
     """65 536 frames, 16 directions: every run boundary (two atomic adds into a zeroed hop) against the single-direction node."""
     import torch
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     M, F, D = 8, 65536, 16
     p = make_params("das", n_mics=M, theta=0.0)
     g = torch.Generator(device="cuda").manual_seed(5)
@@ -115,7 +115,7 @@ def test_block_per_direction_path_still_serves_many_directions():
 import sys, json, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
 import torch, oracle
-from beamform_amd.capi import Beamformer
+from conftest import Beamformer_f32 as Beamformer   # look directions that share their forward transforms: the fp32 opt-in
 from beamform_amd.params import make_params
 from beamform_amd.synth import make_scene
 from conftest import rel_l2

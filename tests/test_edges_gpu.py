@@ -8,7 +8,7 @@ from beamform_amd.params import make_params
 from beamform_amd.synth import make_scene
 from conftest import rel_l2
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("das_impls")]
 TOL = 1e-5  # north_star tolerance
 
 
@@ -22,7 +22,7 @@ def _torch():
 def test_empty_batch_is_a_no_op(algo):
     """n_frames = 0 returns BF_OK and leaves the carried state alone (a JACK client that is not yet READY)."""
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     torch = _torch()
     M, F = 4, 10
     p = make_params(algo, n_mics=M, theta=15.0)
@@ -41,7 +41,8 @@ def test_empty_batch_is_a_no_op(algo):
 
 
 def test_bad_arguments_are_rejected_not_fatal():
-    from beamform_amd.capi import Beamformer, BfError
+    from beamform_amd.capi import BfError
+    from conftest import Beamformer
     torch = _torch()
     p = make_params("das", n_mics=4)
     bf = Beamformer(p)
@@ -74,7 +75,7 @@ def test_bad_arguments_are_rejected_not_fatal():
 def test_das_maximum_microphone_counts(M):
     """BF_MAX_MICS = 32; > 8 microphones take the kernel variant whose gain tables stay in L2; odd counts pad the pair."""
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     _torch()
     rng = np.random.default_rng(M)
     mics = [(0.0, 0.0)] + [tuple(rng.uniform(-0.25, 0.25, 2)) for _ in range(M - 1)]
@@ -87,7 +88,7 @@ def test_das_maximum_microphone_counts(M):
 
 def test_phase_with_32_microphones():
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     _torch()
     rng = np.random.default_rng(5)
     M = 32
@@ -103,7 +104,7 @@ def test_digital_silence(algo):
     """All-zero input: every node must do what the reference does with it.  The magnitude gates of mvdr/lcmv/gss
     (mvdr.cpp:85) stay closed, so no zero covariance is inverted and every node emits exact zeros."""
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     _torch()
     M, F = 4, 14
     p = make_params(algo, n_mics=M, interf=(-60.0,) if algo in ("lcmv", "gss") else ())
@@ -118,7 +119,7 @@ def test_digital_silence(algo):
 def test_full_scale_square_wave_input():
     """+-1.0 full-scale, spectrally dense input (every odd harmonic): no overflow surprises in the fp32 path."""
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     _torch()
     M, F = 8, 12
     t = np.arange(F * 512)
@@ -130,7 +131,7 @@ def test_full_scale_square_wave_input():
 def test_maximum_look_directions():
     """BF_MAX_DIRS = 64 beams from one input; spot-check a few against their own oracle node."""
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     _torch()
     M, F, D = 8, 24, 64
     thetas = list(np.linspace(-180.0, 175.0, D))
@@ -148,7 +149,7 @@ def test_mvdr_many_streams_times_tiles_exceeds_65535_blocks():
     """tiles x streams goes into grid.x (2^31-1), not grid.y (65535): 40 streams x 2048-frame batches = 2560 tile-streams
     here; the launch geometry is the same code path as 64 streams x 65536 frames = 131072."""
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     _torch()
     M, S, F = 4, 40, 96
     p = make_params("mvdr", n_mics=M, theta=10.0)
@@ -165,7 +166,8 @@ def test_mvdr_many_streams_times_tiles_exceeds_65535_blocks():
 def test_long_host_batch_is_pipelined_in_chunks(algo, layout):
     """bf_process_batch splits long single-stream batches into 8 chunks (copy / compute / copy overlap on three streams):
     the result must be the one-shot device-path result, with pageable and with page-locked host buffers."""
-    from beamform_amd.capi import BF_INTERLEAVED, BF_PLANAR, Beamformer, host_array
+    from beamform_amd.capi import BF_INTERLEAVED, BF_PLANAR, host_array
+    from conftest import Beamformer
     torch = _torch()
     M, F = 4, 8192 + 37  # ragged last chunk
     p = make_params(algo, n_mics=M, theta=25.0)

@@ -30,21 +30,21 @@ def _node(algo, M, theta, **over):
 @pytest.mark.parametrize("M,F", [(8, 33), (7, 5), (5, 18), (4, 27), (3, 9), (2, 40), (1, 6), (8, 1), (4, 3)])
 def test_fused_matches_oracle(algo, M, F):
     import oracle
-    from beamform_amd.capi import BF_DAS_BINS_F64, BF_DAS_FUSED_F32
+    from beamform_amd.capi import BF_DAS_F64, BF_DAS_FUSED_F32
     p = _node(algo, M, 25.0)
     x = make_scene(M, F, seed=900 + 10 * M + F)
     y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
-    y, Y = run_gpu(p, x, das_impl=BF_DAS_BINS_F64 if algo == "das_f64" else BF_DAS_FUSED_F32)
+    y, Y = run_gpu(p, x, das_impl=BF_DAS_F64 if algo == "das_f64" else BF_DAS_FUSED_F32)
     check(y, Y, y_ref, Y_ref)
 
 
 @pytest.mark.parametrize("algo", ["das_f64", "phase", "phasempf"])
 def test_fused_streams_and_interleaved(algo):
     import oracle
-    from beamform_amd.capi import BF_DAS_BINS_F64, BF_DAS_FUSED_F32, BF_INTERLEAVED
+    from beamform_amd.capi import BF_DAS_F64, BF_DAS_FUSED_F32, BF_INTERLEAVED
     M, F, S = 6, 11, 3
     p = _node(algo, M, -40.0)
-    impl = BF_DAS_BINS_F64 if algo == "das_f64" else BF_DAS_FUSED_F32
+    impl = BF_DAS_F64 if algo == "das_f64" else BF_DAS_FUSED_F32
     xs = np.stack([make_scene(M, F, seed=950 + s) for s in range(S)])           # [S, M, T]
     refs = [oracle.OracleNode(p).process(xs[s], want_spectrum=True) for s in range(S)]
     y, Y = run_gpu(p, xs, n_streams=S, F=F, das_impl=impl)
@@ -71,7 +71,7 @@ CHILD = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)
 import torch
-from beamform_amd.capi import Beamformer, BF_DAS_BINS_F64, BF_DAS_FUSED_F32
+from beamform_amd.capi import Beamformer, BF_DAS_F64, BF_DAS_FUSED_F32
 from beamform_amd.params import make_params
 from beamform_amd.synth import make_scene
 out = {}
@@ -80,7 +80,7 @@ for algo, M, F in [("das", 8, 21), ("phase", 8, 21), ("phasempf", 5, 30), ("phas
     if algo == "phase":
         p["mag_threshold"] = 0.0005
     x = make_scene(M, F, seed=990 + M)
-    out[f"{algo}{M}"] = Beamformer(p, das_impl=BF_DAS_BINS_F64 if algo == "das" else BF_DAS_FUSED_F32).process(x)
+    out[f"{algo}{M}"] = Beamformer(p, das_impl=BF_DAS_F64 if algo == "das" else BF_DAS_FUSED_F32).process(x)
 np.savez(sys.argv[1], **out)
 """
 
@@ -112,13 +112,13 @@ def same_floats(a, b):
 
 @pytest.mark.parametrize("M,F,S", [(8, 33, 1), (7, 5, 1), (5, 18, 2), (4, 27, 1), (3, 9, 3), (2, 40, 1), (1, 6, 1), (8, 1, 1), (6, 700, 1)])
 def test_das_f64_one_launch_matches_oracle(M, F, S):
-    """das_f64_pair_kernel / das_f64_w64_kernel<1> (BF_DAS_BINS_F64 without a spectrum dump): the time output against the oracle, odd
+    """das_f64_pair_kernel / das_f64_w64_kernel<1> (BF_DAS_F64 without a spectrum dump): the time output against the oracle, odd
     microphone counts, several streams, runs that recompute their first frame (F = 700 is cut into runs), and batch cuts."""
     import oracle
-    from beamform_amd.capi import BF_DAS_BINS_F64, Beamformer
+    from beamform_amd.capi import BF_DAS_F64, Beamformer
     p = make_params("das", n_mics=M, theta=-50.0)
     xs = np.stack([make_scene(M, F, seed=1200 + 7 * M + s) for s in range(S)])
-    bf = Beamformer(p, n_streams=S, das_impl=BF_DAS_BINS_F64)
+    bf = Beamformer(p, n_streams=S, das_impl=BF_DAS_F64)
     y = bf.process(xs if S > 1 else xs[0]).reshape(S, -1)
     for s in range(S):
         y_ref, _ = oracle.OracleNode(p).process(xs[s])
@@ -128,21 +128,21 @@ def test_das_f64_one_launch_matches_oracle(M, F, S):
     # differently at 1e-16 -- equal up to the last bit of the float stores, not bit for bit
     from beamform_amd.capi import BF_INTERLEAVED
     xi = np.ascontiguousarray(xs.transpose(0, 2, 1))
-    yi = Beamformer(p, n_streams=S, das_impl=BF_DAS_BINS_F64, layout=BF_INTERLEAVED).process(xi if S > 1 else xi[0]).reshape(S, -1)
+    yi = Beamformer(p, n_streams=S, das_impl=BF_DAS_F64, layout=BF_INTERLEAVED).process(xi if S > 1 else xi[0]).reshape(S, -1)
     assert same_floats(yi, y)
     if S == 1 and F >= 9:
-        bi = Beamformer(p, das_impl=BF_DAS_BINS_F64, layout=BF_INTERLEAVED)   # carried hop in the interleaved layout across batch cuts
+        bi = Beamformer(p, das_impl=BF_DAS_F64, layout=BF_INTERLEAVED)   # carried hop in the interleaved layout across batch cuts
         cuts = [0, 2, F // 2, F]
         parts = [bi.process(np.ascontiguousarray(xi[0][a * 512:b * 512])) for a, b in zip(cuts[:-1], cuts[1:])]
         assert np.array_equal(np.concatenate(parts), yi[0])   # one frame per transform there: bit for bit whatever the cuts
     if S == 1 and F >= 9:
-        bf2 = Beamformer(p, das_impl=BF_DAS_BINS_F64)
+        bf2 = Beamformer(p, das_impl=BF_DAS_F64)
         cuts = [0, 1, 4, F // 2, F]
         parts = [bf2.process(np.ascontiguousarray(xs[0][:, a * 512:b * 512])) for a, b in zip(cuts[:-1], cuts[1:])]
         assert same_floats(np.concatenate(parts), y[0])   # state (ring hop, tail) carries; which frames share a transform depends on the cuts
         # ... and cuts at EVEN frame counts leave every pair where it was: the hop across a cut is tail_in + head, the same float addition
         # as inside a batch -- bit for bit (the deterministic regression the planar kernel keeps)
-        bf3 = Beamformer(p, das_impl=BF_DAS_BINS_F64)
+        bf3 = Beamformer(p, das_impl=BF_DAS_F64)
         cuts = sorted({0, 2, 4, 2 * (F // 4), 2 * (F // 3), F})
         parts = [bf3.process(np.ascontiguousarray(xs[0][:, a * 512:b * 512])) for a, b in zip(cuts[:-1], cuts[1:])]
         assert np.array_equal(np.concatenate(parts), y[0])
@@ -150,12 +150,12 @@ def test_das_f64_one_launch_matches_oracle(M, F, S):
 
 def test_das_f64_one_launch_streaming_callbacks():
     """bf_process_hop on the fp64 das node: one callback at a time == batch."""
-    from beamform_amd.capi import BF_DAS_BINS_F64, Beamformer
+    from beamform_amd.capi import BF_DAS_F64, Beamformer
     M, F = 8, 12
     p = make_params("das", n_mics=M, theta=15.0)
     x = make_scene(M, F, seed=31)
-    whole = Beamformer(p, das_impl=BF_DAS_BINS_F64).process(x)
-    bf = Beamformer(p, das_impl=BF_DAS_BINS_F64)
+    whole = Beamformer(p, das_impl=BF_DAS_F64).process(x)
+    bf = Beamformer(p, das_impl=BF_DAS_F64)
     hops = [bf.process_hop(np.ascontiguousarray(x[:, t * 512:(t + 1) * 512])) for t in range(F)]
     assert same_floats(np.concatenate([np.asarray(h).reshape(-1) for h in hops]), whole)   # a callback is a lone frame, the batch pairs them
 
@@ -164,14 +164,14 @@ CHILD_FULL = r"""
 import sys, hashlib, numpy as np
 sys.path.insert(0, %r)
 import torch
-from beamform_amd.capi import Beamformer, BF_DAS_BINS_F64, BF_DAS_FUSED_F32
+from beamform_amd.capi import Beamformer, BF_DAS_F64, BF_DAS_FUSED_F32
 from beamform_amd.params import make_params
 M, F = 8, 65536
 g = torch.Generator(device="cuda").manual_seed(5)
 x = (torch.rand((M, F * 512), device="cuda", generator=g) - 0.5) * 6.0     # loud enough to open phase's magnitude gate
 y = torch.empty(F * 512, device="cuda")
 for algo in ("das", "phase"):
-    bf = Beamformer(make_params(algo, n_mics=M, theta=-15.0), das_impl=BF_DAS_BINS_F64 if algo == "das" else BF_DAS_FUSED_F32)
+    bf = Beamformer(make_params(algo, n_mics=M, theta=-15.0), das_impl=BF_DAS_F64 if algo == "das" else BF_DAS_FUSED_F32)
     bf.process_device(x.data_ptr(), F, y.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     print(algo, hashlib.sha1(y.cpu().numpy().tobytes()).hexdigest(), float(y.abs().mean()))
@@ -200,15 +200,15 @@ def test_das_f64_one_launch_at_the_baseline_size():
     output hop depends on three input hops only), and equality with the fused fp32 kernel to float accuracy."""
     import oracle
     import torch
-    from beamform_amd.capi import BF_DAS_BINS_F64, Beamformer
+    from beamform_amd.capi import BF_DAS_F64, BF_DAS_FUSED_F32, Beamformer
     M, F, n = 8, 65536, 20
     p = make_params("das", n_mics=M, theta=35.0)
     g = torch.Generator(device="cuda").manual_seed(21)
     x = torch.rand(M, F * 512, device="cuda", generator=g) - 0.5
     y = torch.empty(F * 512, device="cuda")
-    Beamformer(p, das_impl=BF_DAS_BINS_F64).process_device(x.data_ptr(), F, y.data_ptr())
+    Beamformer(p, das_impl=BF_DAS_F64).process_device(x.data_ptr(), F, y.data_ptr())
     y32 = torch.empty(F * 512, device="cuda")
-    Beamformer(p).process_device(x.data_ptr(), F, y32.data_ptr())
+    Beamformer(p, das_impl=BF_DAS_FUSED_F32).process_device(x.data_ptr(), F, y32.data_ptr())
     torch.cuda.synchronize()
     assert ((y - y32).norm() / y.norm()).item() < 1e-6
     rng = np.random.default_rng(9)
@@ -227,14 +227,14 @@ def test_das_f64_one_launch_at_the_baseline_size():
 def _sha1_of_das_f64_batch(reps, F=65536, M=8):
     import hashlib
     import torch
-    from beamform_amd.capi import BF_DAS_BINS_F64, Beamformer
+    from beamform_amd.capi import BF_DAS_F64, Beamformer
     p = make_params("das", n_mics=M, theta=35.0)
     g = torch.Generator(device="cuda").manual_seed(33)
     x = torch.rand(M, F * 512, device="cuda", generator=g) - 0.5
     y = torch.empty(F * 512, device="cuda")
     digests = []
     for rep in range(reps):
-        bf = Beamformer(p, das_impl=BF_DAS_BINS_F64)   # a cold handle: the same carried state every time
+        bf = Beamformer(p, das_impl=BF_DAS_F64)   # a cold handle: the same carried state every time
         y.fill_(float("nan"))
         bf.process_device(x.data_ptr(), F, y.data_ptr())
         torch.cuda.synchronize()

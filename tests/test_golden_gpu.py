@@ -16,13 +16,13 @@ GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "gold
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
 def test_gpu_reproduces_golden(path):
     import torch
-    from beamform_amd.capi import BF_DAS_BINS_F64, BF_DAS_FUSED_F32, Beamformer
+    from beamform_amd.capi import BF_DAS_F64, BF_DAS_FUSED_F32, Beamformer
     d = np.load(path)
     p = json.loads(str(d["params"]))
     p["mics"] = [tuple(m) for m in p["mics"]]
     x, y_ref, Y_ref = d["x"], d["y"], d["Y"]
     F = x.shape[1] // 512
-    impls = [BF_DAS_FUSED_F32, BF_DAS_BINS_F64] if p["algo"] == "das" else [BF_DAS_FUSED_F32]
+    impls = [BF_DAS_FUSED_F32, BF_DAS_F64] if p["algo"] == "das" else [BF_DAS_FUSED_F32]
     for impl in impls:
         bf = Beamformer(p, das_impl=impl)
         xd = torch.from_numpy(x).cuda()

@@ -9,7 +9,7 @@ from beamform_amd.params import make_params
 from beamform_amd.synth import make_scene
 from conftest import rel_l2
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("das_impls")]
 
 TOL = 1e-5  # north_star tolerance: relative L2, per frame on the complex spectrum and on the time signal
 
@@ -22,7 +22,7 @@ def _torch():
 
 def run(p, x, n_streams=1):
     torch = _torch()
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     H = p["hop"]
     F = x.shape[-1] // H
     bf = Beamformer(p, n_streams=n_streams)
@@ -57,20 +57,16 @@ CASES = [(hop,) + n for hop in (256, 1024) for n in ALL_NODES] + [(hop,) + n for
 
 
 @pytest.mark.parametrize("hop,algo,M,interf", CASES)
-def test_nodes_at_other_jack_periods(hop, algo, M, interf):
+def test_nodes_at_other_jack_periods(hop, algo, M, interf, das_impls):
     import oracle
     p = make_params(algo, n_mics=M, interf=interf, theta=20.0, hop=hop)
     F = {64: 96, 128: 64, 256: 48, 1024: 30, 2048: 24, 4096: 20}[hop]   # enough frames behind the covariance window / MCRA start-up
     x = make_scene(M, F, hop=hop, seed=300 + M + hop // 256)
     y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
     _, y, Y = run(p, x)
-    if algo == "das":  # the fused fp32 kernels (das_fused_gen.hip at these periods) dump the Hermitian part of y_fft: the part that reaches Re(ifft)
+    if algo == "das" and das_impls == "f32":  # the fused fp32 kernels (das_fused_gen.hip at these periods) dump the Hermitian part of y_fft: the part that reaches Re(ifft)
         Y_ref = 0.5 * (Y_ref + np.conj(np.roll(Y_ref[:, ::-1], 1, axis=1)))
-    check(y[0], Y[0], y_ref, Y_ref)
-    if algo == "das":  # and the same node at the reference's precision keeps the fp64 pipeline with the full y_fft
-        from beamform_amd.capi import BF_DAS_BINS_F64, Beamformer
-        y64 = Beamformer(p, das_impl=BF_DAS_BINS_F64).process(x)
-        assert rel_l2(y64, y_ref) < TOL
+    check(y[0], Y[0], y_ref, Y_ref)   # (das in double, the default: the fp64 pipeline with the full y_fft)
 
 
 @pytest.mark.parametrize("hop", [64, 128, 256, 1024, 2048, 4096])
@@ -78,7 +74,7 @@ def test_nodes_at_other_jack_periods(hop, algo, M, interf):
 def test_streaming_callbacks_at_other_jack_periods(hop, algo):
     """bf_process_hop with nframes = the configured period, one callback at a time == batch == oracle; theta in between."""
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     _torch()
     M, F = 4, 14
     p = make_params(algo, n_mics=M, theta=10.0, hop=hop)
@@ -101,7 +97,8 @@ def test_streaming_callbacks_at_other_jack_periods(hop, algo):
 
 
 def test_unsupported_period_is_refused():
-    from beamform_amd.capi import Beamformer, BfError
+    from beamform_amd.capi import BfError
+    from conftest import Beamformer
     _torch()
     with pytest.raises(BfError):
         Beamformer(make_params("das", n_mics=4, hop=384))      # not a power of two
@@ -144,7 +141,7 @@ def test_as_many_constraints_as_microphones_runs_without_a_parity_claim():
 def test_interferers_appended_at_run_time_beyond_three():
     """/theta_interference keeps appending (lcmv.cpp:282-305): 2 -> 6 interferers one callback apart, then one removed."""
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     _torch()
     M, F = 16, 36
     p = make_params("lcmv", n_mics=M, interf=(-60.0, 90.0), theta=20.0)
@@ -187,13 +184,16 @@ def test_more_than_sixteen_microphones(algo, M, interf, radius, band):
 
 
 @pytest.mark.parametrize("hop", [64, 256, 1024, 4096])
-def test_fused_das_at_other_periods_layouts_streams_directions_cuts(hop):
+def test_fused_das_at_other_periods_layouts_streams_directions_cuts(hop, das_impls):
     """The fused fp32 das kernels at the JACK periods other than 512 (das_fused.hip's group mode below 512, das_fused_wave2048_kernel at 1024,
     das_fused_gen.hip above): interleaved input, several streams, look directions, a long batch cut into runs (every run but the first
     recomputes its previous frame or group), uneven batch cuts -- against the oracle."""
     import oracle
-    from beamform_amd.capi import BF_INTERLEAVED, Beamformer
+    from beamform_amd.capi import BF_INTERLEAVED
+    from conftest import Beamformer
     _torch()
+    if das_impls != "f32":
+        pytest.skip("about the fp32 opt-in's kernels; das in double at these periods: test_nodes_at_other_jack_periods, test_streaming_callbacks_...")
     M, S, F = 5, 2, 40
     p = make_params("das", n_mics=M, theta=-30.0, hop=hop)
     xs = np.stack([make_scene(M, F, hop=hop, seed=70 + s) for s in range(S)])
@@ -237,7 +237,7 @@ import sys, json, numpy as np
 sys.path.insert(0, %(root)r)
 sys.path.insert(0, %(root)r + "/tests")
 import oracle
-from beamform_amd.capi import Beamformer
+from conftest import Beamformer_f32 as Beamformer   # the register-resident das kernels of this period are the fp32 opt-in
 from beamform_amd.params import make_params
 from beamform_amd.synth import make_scene
 from conftest import rel_l2
@@ -260,11 +260,13 @@ print("RESULT " + json.dumps(res))
 
 
 @pytest.mark.parametrize("split", ["3", "0"])
-def test_period_1024_split_kernel_and_its_switch(split):
+def test_period_1024_split_kernel_and_its_switch(split, das_impls):
     """The 1024-frame period without a spectrum dump: das_fused_wave2048_kernel (one 2048-point transform per frame on a full wavefront, tails
     through an LDS ring, run boundaries by atomics: the default = BF_DAS_SPLIT2048=3) and das_fused_gen_kernel<2048> (=0) against the oracle:
     odd and single microphone counts, many runs per stream, a cut stream, interleaved input; the switch is read once per process."""
     import json, os, subprocess, sys
+    if das_impls != "f32":
+        pytest.skip("fp32-only kernels (das in double at this period runs the bin pipeline: test_every_jack_period)")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", CHILD_1024 % dict(root=root)], env=dict(os.environ, BF_DAS_SPLIT2048=split),
                          capture_output=True, text=True, timeout=600)
@@ -278,7 +280,8 @@ import sys, json, numpy as np
 sys.path.insert(0, %(root)r)
 sys.path.insert(0, %(root)r + "/tests")
 import oracle
-from beamform_amd.capi import Beamformer, BF_INTERLEAVED
+from beamform_amd.capi import BF_INTERLEAVED
+from conftest import Beamformer_f32 as Beamformer   # the register-resident das kernels of this period are the fp32 opt-in
 from beamform_amd.params import make_params
 from beamform_amd.synth import make_scene
 from conftest import rel_l2
@@ -308,11 +311,13 @@ print("RESULT " + json.dumps(res))
 
 
 @pytest.mark.parametrize("il", ["1", "0"])
-def test_small_periods_interleaving_kernel_and_its_switch(il):
+def test_small_periods_interleaving_kernel_and_its_switch(il, das_impls):
     """Periods 256 / 128 / 64 without a spectrum dump, 1024 / N frames interleaved into one 1024-point pass: das_fused_kernel in group mode
     (BF_DAS_INTERLEAVE=1, the default) and das_fused_gen_kernel<N> (=0) against the oracle: odd frame counts, one callback at a time,
     12 microphones, many runs per stream, a cut stream, interleaved input."""
     import json, os, subprocess, sys
+    if das_impls != "f32":
+        pytest.skip("fp32-only kernels (das in double at these periods runs the bin pipeline: test_every_jack_period)")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", CHILD_SMALL % dict(root=root)], env=dict(os.environ, BF_DAS_INTERLEAVE=il),
                          capture_output=True, text=True, timeout=600)
@@ -348,13 +353,15 @@ print("RESULT " + json.dumps(res))
 
 @pytest.mark.parametrize("env", [{}, {"BF_FUSED_BINS": "0"}, {"BF_STFT_SMALL": "0", "BF_STFT_SPLIT": "0", "BF_FUSED_BINS": "0"}],
                          ids=["registers", "registers-unfused", "generic"])
-def test_fp64_nodes_stft_kernels_at_other_periods_and_their_switches(env):
+def test_fp64_nodes_stft_kernels_at_other_periods_and_their_switches(env, das_impls):
     """stft_small_kernel / istft_small_kernel (N = 128 / 256 / 512: several frames per half-wavefront through one transpose plane),
     stft_wave2048_kernel (N = 2048: one transform per full wavefront) /
     istft_split_kernel, stft_bins_small_kernel / stft_bins_split_kernel (phase / phasempf below 512 / at 1024: the STFT and
     the per-bin stage in one launch; BF_FUSED_BINS=0: the chain) and the generic LDS-staged kernels they replace (BF_STFT_SMALL=0 / BF_STFT_SPLIT=0),
     against the oracle: odd microphone counts, one microphone, both layouts, frame counts that leave partial groups, rounds and short runs."""
     import json, os, subprocess, sys
+    if das_impls != "f64":
+        pytest.skip("no das in this test: once is enough")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", CHILD_STFT % dict(root=root)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]

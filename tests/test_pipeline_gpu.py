@@ -20,7 +20,7 @@ def _torch():
 
 def run_gpu(p, x, n_streams=1, F=None, **kw):
     """-> (y [F*512] float32, Y [F,1024] complex128) through bf_process_batch_device."""
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     torch = _torch()
     F = F or x.shape[-1] // 512
     bf = Beamformer(p, n_streams=n_streams, **kw)
@@ -47,15 +47,16 @@ def check(y, Y, y_ref, Y_ref, skip=0):
     assert rel_l2(y[ok], y_ref[ok]) < TOL_TIME
 
 
+@pytest.mark.usefixtures("precisions")
 @pytest.mark.parametrize("M,theta,F", [(8, 20.0, 32), (4, -35.0, 17), (3, 60.0, 9), (16, 90.0, 12)])
 def test_das_bins_f64_full_spectrum(M, theta, F):
     """The fp64 path reproduces the reference's FULL 1024-bin y_fft, including the non-conjugate Q1 bins."""
     import oracle
-    from beamform_amd.capi import BF_DAS_BINS_F64
+    from beamform_amd.capi import BF_DAS_F64
     p = make_params("das", n_mics=M, theta=theta)
     x = make_scene(M, F, seed=300 + M)
     y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
-    y, Y = run_gpu(p, x, das_impl=BF_DAS_BINS_F64)
+    y, Y = run_gpu(p, x, das_impl=BF_DAS_F64)
     check(y, Y, y_ref, Y_ref)
     assert np.abs(Y - Y_ref).max() < 1e-9 * np.abs(Y_ref).max()
 
@@ -68,12 +69,13 @@ def test_float_output_equals_the_oracles(algo, M, interf):
     (float) of util.h:249 only where a value sits on a rounding boundary.  No spectrum dump: the product's timed path.  The bound allows
     a few isolated last-bit flips in 20 000 samples; observed 0 on every seed tried (profiles/r05_fuzz2.txt: 3 200 cases)."""
     import oracle
-    from beamform_amd.capi import BF_DAS_BINS_F64, Beamformer
+    from beamform_amd.capi import BF_DAS_F64
+    from conftest import Beamformer
     F = 40
     p = make_params(algo, n_mics=M, theta=20.0, interf=interf)
     x = make_scene(M, F, seed=4300 + M)
     y_ref, _ = oracle.OracleNode(p).process(x)
-    y = Beamformer(p, das_impl=BF_DAS_BINS_F64).process(x).reshape(-1)
+    y = Beamformer(p, das_impl=BF_DAS_F64).process(x).reshape(-1)
     assert np.isfinite(y).all() and np.isfinite(y_ref).all()
     assert rel_l2(y, y_ref) < 1e-8, rel_l2(y, y_ref)
     assert (y != y_ref).mean() < 1e-3
@@ -85,7 +87,7 @@ def test_backward_transform_keeps_frames_of_different_scale_apart():
     come out as the oracle's (exact zeros where the overlap-add has nothing to add), and a stretch 2^-40 below the rest must keep its
     own relative accuracy."""
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     M, F = 8, 36   # phase: stft_bins_w64_kernel (two MICROPHONES per forward transform: a zero frame has a zero spectrum) + istft_w64_kernel
     p = make_params("phase", n_mics=M, theta=-35.0)
     x = make_scene(M, F, seed=777, silent_frac=0.0)
@@ -102,6 +104,7 @@ def test_backward_transform_keeps_frames_of_different_scale_apart():
     assert rel_l2(y[q], y_ref[q]) < 1e-8
 
 
+@pytest.mark.usefixtures("precisions")
 @pytest.mark.parametrize("M,theta,F", [(8, 20.0, 40), (4, 0.0, 21), (2, 45.0, 8)])
 def test_phase_matches_oracle(M, theta, F):
     import oracle
@@ -112,6 +115,7 @@ def test_phase_matches_oracle(M, theta, F):
     check(y, Y, y_ref, Y_ref)
 
 
+@pytest.mark.usefixtures("precisions")
 @pytest.mark.parametrize("algo,M,interf,F", [("mvdr", 8, (), 48), ("mvdr", 3, (), 30), ("mvdr", 16, (), 26),
                                               ("lcmv", 8, (-60.0, 90.0), 40), ("lcmv", 16, (-60.0, 90.0, 150.0), 26),
                                               ("lcmv", 4, (), 20),
@@ -128,13 +132,14 @@ def test_mvdr_lcmv_match_oracle(algo, M, interf, F):
     check(y, Y, y_ref, Y_ref)
     # without the spectrum dump the per-bin kernels hand the fp32 backward transform f32x2 rows holding the in-band problems
     # only (BinsArgs::yh32): the product's timed path
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     y2 = Beamformer(p).process(x)
     ok = np.isfinite(y_ref)
     assert (np.isfinite(y2) == ok).all()
     assert rel_l2(y2[ok], y_ref[ok]) < TOL_TIME
 
 
+@pytest.mark.usefixtures("precisions")
 @pytest.mark.parametrize("M,K", [(2, 0), (2, 1), (3, 1), (3, 2), (4, 1), (4, 2), (5, 2), (5, 3), (6, 1), (6, 3), (7, 2), (7, 3), (8, 1), (8, 3)])
 def test_lcmv_up_to_8_microphones_every_column_count(M, K):
     """lcmv with <= 8 microphones rides mvdr_fast_kernel<MP, KC>: every (padded microphone count, compiled column count) pair,
@@ -147,7 +152,7 @@ def test_lcmv_up_to_8_microphones_every_column_count(M, K):
     y_ref, Y_ref = oracle.OracleNode(p).process(x, want_spectrum=True)
     y, Y = run_gpu(p, x)
     check(y, Y, y_ref, Y_ref)
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     bf = Beamformer(p)
     y2 = np.concatenate([bf.process(np.ascontiguousarray(x[:, a * 512:b * 512])) for a, b in ((0, 5), (5, 6), (6, F))])  # yh32 rows, batch cuts
     ok = np.isfinite(y_ref)
@@ -155,10 +160,11 @@ def test_lcmv_up_to_8_microphones_every_column_count(M, K):
     assert rel_l2(y2[ok], y_ref[ok]) < TOL_TIME
 
 
+@pytest.mark.usefixtures("precisions")
 def test_mvdr_history_carries_across_batches():
     """Covariance history (previous P frames), ring hop and OLA tail survive a batch boundary."""
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     _torch()
     M, F = 8, 30
     p = make_params("mvdr", n_mics=M, theta=20.0)
@@ -190,12 +196,13 @@ def windows_vs_oracle(p, x, y, n_windows=6, warm=14, span=6, seed=0):
     return worst
 
 
+@pytest.mark.usefixtures("precisions")
 @pytest.mark.parametrize("algo,M,interf,F", [("mvdr", 8, (), 65536), ("lcmv", 16, (-60.0, 90.0, 150.0), 32768), ("lcmv", 8, (-60.0, 90.0), 32768)])
 def test_mvdr_lcmv_full_size_windows(algo, M, interf, F):
     """BASELINE configs 3 and 5 (per-GPU shard scaled to the test budget): random windows of the big
     batch against the oracle, plus chunk independence."""
     torch = _torch()
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     p = make_params(algo, n_mics=M, interf=interf, theta=20.0)
     base = make_scene(M, 2048, seed=900 + M, silent_frac=0.05)
     reps = F // 2048
@@ -210,6 +217,7 @@ def test_mvdr_lcmv_full_size_windows(algo, M, interf, F):
     assert windows_vs_oracle(p, x, y) < TOL_TIME
 
 
+@pytest.mark.usefixtures("precisions")
 @pytest.mark.parametrize("M,F,over", [(8, 120, {}), (4, 70, {}), (8, 60, dict(out_only_mcra=1)), (8, 60, dict(out_only_noise=1)),
                                       (3, 40, dict(smooth_size=7, mcra_L=10))])
 def test_phasempf_matches_oracle(M, F, over):
@@ -251,13 +259,14 @@ def test_gss_matches_oracle(M, interf, F):
     check(y, Y, y_ref, Y_ref)
 
 
+@pytest.mark.usefixtures("precisions")
 @pytest.mark.parametrize("algo,interf", [("phasempf", ()), ("gss", (-60.0, 90.0)), ("phase", ()), ("lcmv", (-60.0,)),
                                          ("mcra", ())])
 def test_recursive_state_carries_across_batches_and_theta(algo, interf):
     """Batches of uneven length == one stream; /theta in the middle == the oracle's set_theta
     (gss re-initialises its demixing matrices, gss.cpp:90-93)."""
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     _torch()
     M, F = 8, 36
     p = make_params(algo, n_mics=M, interf=interf, theta=20.0)
@@ -279,9 +288,10 @@ def test_recursive_state_carries_across_batches_and_theta(algo, interf):
     assert rel_l2(y[ok], y_ref[ok]) < TOL_TIME
 
 
+@pytest.mark.usefixtures("precisions")
 @pytest.mark.parametrize("algo", ["mvdr", "phasempf", "gss", "mcra"])
 def test_pipeline_checkpoint_roundtrip(algo):
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     _torch()
     M, F = 4, 16
     p = make_params(algo, n_mics=M, theta=10.0, interf=(-60.0,) if algo == "gss" else ())
@@ -315,7 +325,8 @@ def test_gss_many_streams_one_lane_per_problem(M, interf, hop):
     """From two wavefronts per CU on (57 streams) gss runs gss_lane_kernel: one lane per (stream, problem), the demixing matrix in
     registers.  64 independent streams in two uneven batches (the matrices are carried between them) against the oracle per stream."""
     import oracle
-    from beamform_amd.capi import Beamformer, launch_trace
+    from beamform_amd.capi import launch_trace
+    from conftest import Beamformer
     _torch()
     # streams: enough for two wavefronts per CU (N = 256: 3 wavefronts per stream; N = 1024: 9; N = 4096: 33)
     S, F = {128: (176, 10), 512: (64, 14), 2048: (32, 8)}[hop]
@@ -339,7 +350,7 @@ def test_interferer_update_add_remove(algo):
     """/theta_interference (lcmv.cpp:258-309): move an interferer, append one, remove one by moving it next to another --
     including the reference's quirk that a structural change leaves the reference-mic weight row at 0."""
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     _torch()
     M, F = 8, 40
     p = make_params(algo, n_mics=M, interf=(-60.0, 90.0), theta=20.0)
@@ -371,7 +382,7 @@ def test_gsc_matches_oracle(M, F, over):
     """per-microphone alignment through the STFT + the sample-serial float32 NLMS of gsc.cpp:120-181.
     The NLMS replays the reference's float32 operation order, so agreement is far inside the 1e-5 budget."""
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     _torch()
     p = make_params("gsc", n_mics=M, theta=20.0, **over)
     x = make_scene(M, F, seed=1200 + M)
@@ -384,7 +395,7 @@ def test_gsc_matches_oracle(M, F, over):
 
 def test_gsc_state_carries_across_batches_theta_and_streams():
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     _torch()
     M, F, S = 4, 14, 3
     p = make_params("gsc", n_mics=M, theta=20.0)
@@ -415,7 +426,7 @@ def test_phasempf_config4_full_size_streams():
     """BASELINE config 4 at its full shape: 256 independent streams x 256 frames in one call (the recursion runs per stream);
     three of the streams are replayed through the oracle."""
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     torch = _torch()
     M, S, F = 8, 256, 256
     p = make_params("phasempf", n_mics=M, theta=20.0)
@@ -440,7 +451,8 @@ def test_phasempf_config4_full_size_streams():
 def test_checkpoint_carries_the_control_plane():
     """A blob taken before the first run (gss: demixing reset still pending), after /theta and after an interferer was
     appended restores a handle that continues exactly like the original; a blob with another interferer count is refused."""
-    from beamform_amd.capi import Beamformer, BfError
+    from beamform_amd.capi import BfError
+    from conftest import Beamformer
     _torch()
     M, F = 4, 12
     p = make_params("gss", n_mics=M, theta=10.0, interf=(-60.0,))
@@ -473,7 +485,8 @@ def test_checkpoint_carries_the_control_plane():
 def test_checkpoint_is_refused_under_another_configuration():
     """bf_set_state: a blob restores covariance history next to the steering it was built under; a handle with another
     geometry, band, sample rate or window count must refuse it (the header alone -- algo, mics, streams, hop -- matches)."""
-    from beamform_amd.capi import Beamformer, BfError
+    from beamform_amd.capi import BfError
+    from conftest import Beamformer
     _torch()
     M, F = 8, 16
     p = make_params("mvdr", n_mics=M, theta=20.0)
@@ -551,6 +564,7 @@ def test_c_shard_node_gather_schedule_with_every_rank_on_one_gpu(algo, M, F, wor
     assert got["world"] == world and got["checksum"] == want and want > 0
 
 
+@pytest.mark.usefixtures("precisions")
 @pytest.mark.parametrize("algo,M,interf", [("mvdr", 8, ()), ("mvdr", 5, ()), ("lcmv", 8, (-60.0,)), ("lcmv", 16, (-60.0, 90.0, 150.0)), ("mvdr", 12, ()),
                                            ("lcmv", 3, (90.0,)), ("lcmv", 6, (-60.0, 90.0, 150.0)), ("mvdr", 2, ())])
 @pytest.mark.parametrize("band", [(0.0, 24000.0), (0.0, 23960.0), (0.0, 16000.0), (100.0, 24000.0), (300.0, 3400.0), (20000.0, 23000.0), (30.0, 40.0), (5.0, 20.0)])
@@ -561,7 +575,7 @@ def test_mvdr_lcmv_other_bands(algo, M, interf, band):
     band, a high band, a band of one bin (30-40 Hz holds no bin at all: 46.875 Hz spacing -- only problem 0 is non-zero) --
     spectrum dump (f64 rows) and the product's f32 band-limited rows both."""
     import oracle
-    from beamform_amd.capi import Beamformer
+    from conftest import Beamformer
     F = 26
     p = make_params(algo, n_mics=M, interf=interf, theta=20.0, freq_min=band[0], freq_max=band[1])
     x = make_scene(M, F, seed=700 + M)

@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Rewrite the measured-numbers tables of BASELINE.md (section 4) and README.md from the bench records themselves, so that no figure in
+either table is typed by hand:  python tools/bench_tables.py [--check]
+
+  column "driver"   the newest BENCH_rNN.json at the repo root (written by the round driver on its own box: `parsed` = the headline fields of
+                    bench.py's JSON line, `tail` = the last 2 000 characters of it, which is where bench.py puts `extra.ms` -- one figure
+                    per secondary line -- for exactly this reason)
+  column "builder"  min - max over the bench.py lines this round's profile runs left under profiles/ (rNN_*bench*.json, un-profiled ones)
+
+The block between <!-- BENCH:BEGIN --> and <!-- BENCH:END --> is replaced; --check exits 1 if a file would change (the CPU suite runs it)."""
+import glob
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BEGIN, END = "<!-- BENCH:BEGIN (tools/bench_tables.py: do not edit by hand) -->", "<!-- BENCH:END -->"
+
+# (key in extra.ms, what it is)
+ROWS = [
+    ("mvdr", "[2] mvdr 8-mic, 65 536 frames, the library default (c128 spectra, fp64 backward transform)"),
+    ("mvdr_mixed", "[2] same, `BF_PRECISION_MIXED` (z48 spectra, fp32 backward transform)"),
+    ("phasempf", "[3] phasempf 8-mic, 256 streams x 256 frames"),
+    ("lcmv16", "[4] lcmv 16-mic K=3, one GPU's shard of 32 768 frames, the library default"),
+    ("lcmv16_mixed", "[4] same, `BF_PRECISION_MIXED`"),
+    ("phase", "phase 8-mic, 65 536 frames (gates closed)"),
+    ("phase_gate_open", "phase, every gate open"),
+    ("das_f32", "[1] through the fused fp32 opt-in (`BF_DAS_FUSED_F32`)"),
+    ("das_interleaved", "[1] `[sample][mic]` input, fp32 opt-in"),
+    ("das_f64_interleaved", "[1] `[sample][mic]` input, double"),
+    ("gss", "gss 8-mic K=2, 256 x 256 frames"),
+    ("das_dirs16", "das fp32, 16 look directions of the headline batch"),
+    ("das_period256", "das fp32 at JACK period 256"),
+    ("das_period1024", "das fp32 at JACK period 1024"),
+]
+
+
+def newest_driver_record():
+    files = sorted(glob.glob(os.path.join(ROOT, "BENCH_r*.json")), key=lambda f: int(re.search(r"BENCH_r(\d+)", f).group(1)))
+    if not files:
+        return None, None
+    f = files[-1]
+    return os.path.basename(f), json.load(open(f))
+
+
+def extra_ms_from_tail(tail):
+    """extra.ms = {...} sits at the very end of bench.py's line; older records: whatever per-line figures the tail still holds"""
+    m = re.search(r'"ms": (\{[^{}]*\})\}\}\s*(?:$|\n)', tail or "")
+    out = {}
+    if m:
+        try:
+            out.update(json.loads(m.group(1)))
+        except ValueError:
+            pass
+    for m in re.finditer(r'"(\w+)": \{"workload": "(?:[^"\\]|\\.)*", "ms_per_step": ([0-9.eE+-]+)', tail or ""):
+        out.setdefault(m.group(1), float(m.group(2)))
+    m = re.search(r'"mvdr_ms_per_step": ([0-9.eE+-]+)', tail or "")
+    if m and "mvdr" not in out and "mvdr_strict" not in out:
+        out["mvdr"] = float(m.group(1))
+    return out
+
+
+def builder_lines(round_no):
+    """bench.py lines of this round's own runs (profiles/rNN_*bench*.json; the profiled ones run under rocprofv3 and are left out)"""
+    lines = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r{round_no:02d}_*bench*.json"))):
+        if "profiled" in f:
+            continue
+        try:
+            txt = [ln for ln in open(f).read().splitlines() if ln.startswith("{")]
+            if txt:
+                lines.append(json.loads(txt[-1]))
+        except (ValueError, OSError):
+            pass
+    return lines
+
+
+def rng(vals, fmt):
+    vals = [v for v in vals if isinstance(v, (int, float))]
+    if not vals:
+        return "—"
+    lo, hi = min(vals), max(vals)
+    return fmt % lo if abs(hi - lo) < 1e-12 else f"{fmt % lo} – {fmt % hi}"
+
+
+def build_block():
+    name, rec = newest_driver_record()
+    if rec is None:
+        return None
+    round_no = int(re.search(r"r(\d+)", name).group(1))
+    p = rec.get("parsed") or {}
+    rf = p.get("roofline") or {}
+    dms = extra_ms_from_tail(rec.get("tail"))
+    bl = builder_lines(round_no)
+    own = lambda f: [f(b) for b in bl]  # noqa: E731
+    g = lambda d, *ks: (g(d.get(ks[0], {}), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None  # noqa: E731
+    out = [BEGIN, "",
+           f"Driver = `{name}` (`head` {rec.get('head', '?')}, `{p.get('dtype', '?')}`, {p.get('steps', '?')} steps); builder = {len(bl)} un-profiled "
+           f"`bench.py` runs of round {round_no} under `profiles/` (box-to-box range).", "",
+           "| line | driver's box | builder's boxes |", "|---|---|---|"]
+    fmt3 = "%.3f"
+    out.append(f"| **[1] das 8-mic 1024-pt, 65 536 frames, double (headline)**: ms per step | **{p.get('ms_per_step', float('nan')):.4f}** | {rng(own(lambda b: b.get('ms_per_step')), '%.4f')} |")
+    out.append(f"| … `{rf.get('kernel', 'kernel')}` ms per launch (HIP event pairs inside the timed steps) | {rf.get('kernel_ms', float('nan')):.4f} | {rng(own(lambda b: g(b, 'roofline', 'kernel_ms')), '%.4f')} |")
+    out.append(f"| … `roofline.frac` of 8 TB/s (18 432 B per frame) | **{100 * rf.get('frac', float('nan')):.1f} %** | {rng([100 * v for v in own(lambda b: g(b, 'roofline', 'frac')) if v], '%.1f')} % |")
+    tr, tb = rf.get("traffic"), [v for v in own(lambda b: g(b, "roofline", "traffic")) if v]
+    algo_gb = 18432 * 65536 / 1e9
+    tr_s = "null" if not tr else f"{tr / 1e9:.3f} GB = {tr / 1e9 / algo_gb:.2f} x"
+    out.append(f"| … fabric traffic per launch (`profiles/traffic_das8_f64.json`) | {tr_s} | {rng([v / 1e9 for v in tb], fmt3)} GB |")
+    out.append(f"| … frames/s | {p.get('value', float('nan')):.3e} | {rng(own(lambda b: b.get('value')), '%.3e')} |")
+    cb = p.get("cpu_baseline") or {}
+    out.append(f"| CPU baseline (`{cb.get('kind', '?')}`, {cb.get('cores', '?')} core) frames/s | {cb.get('value', float('nan')):.3e} | {rng(own(lambda b: g(b, 'cpu_baseline', 'value')), '%.3e')} |")
+    for key, what in ROWS:
+        dv = dms.get(key)
+        if key == "mvdr" and dv is None:
+            dv = dms.get("mvdr_strict")
+        bv = own(lambda b, k=key: g(b, "extra", k, "ms_per_step"))
+        if dv is None and not [v for v in bv if v]:
+            continue
+        out.append(f"| {what}: ms per step | {'—' if dv is None else fmt3 % dv} | {rng(bv, fmt3)} |")
+    out += ["", END]
+    return "\n".join(out)
+
+
+def main():
+    check = "--check" in sys.argv
+    block = build_block()
+    if block is None:
+        print("no BENCH_r*.json")
+        return 0
+    changed = False
+    for fn in ("BASELINE.md", "README.md"):
+        path = os.path.join(ROOT, fn)
+        s = open(path).read()
+        if BEGIN not in s or END not in s:
+            print(f"{fn}: no BENCH markers")
+            continue
+        new = s[:s.index(BEGIN)] + block + s[s.index(END) + len(END):]
+        if new != s:
+            changed = True
+            if not check:
+                open(path, "w").write(new)
+                print(f"{fn}: table rewritten")
+    if check and changed:
+        print("bench tables are stale: run python tools/bench_tables.py")
+        return 1
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

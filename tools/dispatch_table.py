@@ -10,7 +10,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from beamform_amd.capi import BF_DAS_BINS_F64, BF_DAS_FUSED_F32, BF_INTERLEAVED, BF_PLANAR, Beamformer, launch_trace
+from beamform_amd.capi import BF_DAS_F64, BF_DAS_FUSED_F32, BF_INTERLEAVED, BF_PLANAR, Beamformer, launch_trace
 from beamform_amd.params import make_params
 
 FRAMES = 96   # enough for every kernel's main path (chunks, tiles, rings) to be entered
@@ -44,7 +44,7 @@ def kernels_of(algo, hop=512, layout=BF_PLANAR, M=8, dirs=1, dump=False, impl=BF
 
 def main():
     rows = []
-    nodes = [("das (double)", "das", BF_DAS_BINS_F64, ()), ("das (fp32)", "das", BF_DAS_FUSED_F32, ()), ("mvdr", "mvdr", 0, ()),
+    nodes = [("das (double)", "das", BF_DAS_F64, ()), ("das (fp32)", "das", BF_DAS_FUSED_F32, ()), ("mvdr", "mvdr", 0, ()),
              ("lcmv, 2 interferers", "lcmv", 0, (-60.0, 90.0)), ("gss, 2 interferers", "gss", 0, (-60.0, 90.0)), ("phase", "phase", 0, ()),
              ("phasempf", "phasempf", 0, ()), ("gsc", "gsc", 0, ())]
 

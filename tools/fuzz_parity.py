@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import oracle
-from beamform_amd.capi import Beamformer, BF_PLANAR, BF_INTERLEAVED, BF_DAS_BINS_F64, BF_DAS_FUSED_F32
+from beamform_amd.capi import Beamformer, BF_PLANAR, BF_INTERLEAVED, BF_DAS_F64, BF_DAS_FUSED_F32
 from beamform_amd.params import make_params
 from beamform_amd.synth import make_scene
 
@@ -33,7 +33,7 @@ for case in range(n_cases):
     x = make_scene(M, F, hop=hop, seed=int(rng.integers(1 << 30)), theta_s=float(rng.uniform(-180, 180)))
     layout = BF_INTERLEAVED if rng.random() < 0.3 else BF_PLANAR
     node = oracle.OracleNode(p)
-    impl = BF_DAS_BINS_F64 if (algo == "das" and rng.random() < 0.6) else BF_DAS_FUSED_F32   # das: in double (one-launch kernels) or fused fp32
+    impl = BF_DAS_F64 if (algo == "das" and rng.random() < 0.6) else BF_DAS_FUSED_F32   # das: in double (one-launch kernels) or fused fp32
     bf = Beamformer(p, layout=layout, das_impl=impl)
     cuts = sorted(set([0, F] + [int(c) for c in rng.integers(1, F, size=int(rng.integers(0, 3)))]))
     ys, refs = [], []

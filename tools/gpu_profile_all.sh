@@ -37,6 +37,8 @@ run mvdr8 stft_kernel --algo mvdr
 run phase8 stft_bins_w64 --algo phase
 run phasempf8 stft_bins_w64 --algo phasempf --streams 256 --frames 256
 run lcmv16 stft_kernel --algo lcmv --mics 16 --frames 32768
+run mvdr8_mixed stft_kernel --algo mvdr --mixed
+run lcmv16_mixed stft_kernel --algo lcmv --mics 16 --frames 32768 --mixed
 # 4. SQ / LDS counters of the headline kernel (das in double), separate passes
 if [ -n "$ONLY" ]; then exit 0; fi
 i=0

@@ -16,13 +16,14 @@ ap.add_argument("--layout", default="planar")
 ap.add_argument("--warmup", type=int, default=10)
 ap.add_argument("--settle-ms", type=float, default=80.0)
 ap.add_argument("--dirs", type=int, default=1, help="look directions per input stream (same input, n_dirs outputs)")
-ap.add_argument("--das-f64", action="store_true", help="das through the fp64 bin pipeline")
+ap.add_argument("--das-f64", action="store_true", help="das in double (BF_DAS_F64, the library default); without it this tool runs the fused fp32 opt-in")
+ap.add_argument("--mixed", action="store_true", help="bf_config.precision = BF_PRECISION_MIXED (z48 spectra, fp32 backward transform)")
 ap.add_argument("--hop", type=int, default=512, help="JACK period (frames are 2 * hop samples); --frames counts frames of that period")
 a = ap.parse_args()
 interf = (-60.0, 90.0, 150.0) if a.algo in ("lcmv", "gss") else ()
 p = make_params(a.algo, n_mics=a.mics, interf=interf, hop=a.hop)
 lay = BF_PLANAR if a.layout == "planar" else BF_INTERLEAVED
-bf = Beamformer(p, n_streams=a.streams, layout=lay, n_dirs=a.dirs, das_impl=1 if a.das_f64 else 0)
+bf = Beamformer(p, n_streams=a.streams, layout=lay, n_dirs=a.dirs, das_impl=1 if a.das_f64 else 0, precision=1 if a.mixed else 0)
 if a.dirs > 1:
     bf.set_thetas([-90.0 + 180.0 * d / (a.dirs - 1) for d in range(a.dirs)])
 shape = (a.streams, a.mics, a.frames * a.hop) if lay == BF_PLANAR else (a.streams, a.frames * a.hop, a.mics)

@@ -4,12 +4,12 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from beamform_amd import capi
-from beamform_amd.capi import BF_DAS_BINS_F64, Beamformer
+from beamform_amd.capi import BF_DAS_F64, Beamformer
 from beamform_amd.params import make_params
 M, F = 8, int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 x = torch.rand((M, F * 512), device="cuda") - 0.5
 y = torch.empty(F * 512, device="cuda")
-bf = Beamformer(make_params("das", n_mics=M), das_impl=BF_DAS_BINS_F64)
+bf = Beamformer(make_params("das", n_mics=M), das_impl=BF_DAS_F64)
 s = torch.cuda.current_stream().cuda_stream
 for _ in range(20):
     bf.process_device(x.data_ptr(), F, y.data_ptr(), 0, s)

@@ -4,7 +4,7 @@ beyond float rounding = a hop completed from a stale partner).  tools/stress_das
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from beamform_amd.capi import BF_DAS_BINS_F64, Beamformer
+from beamform_amd.capi import BF_DAS_F64, Beamformer
 from beamform_amd.params import make_params
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
@@ -18,7 +18,7 @@ Beamformer(p).process_device(x.data_ptr(), F, y32.data_ptr())
 torch.cuda.synchronize()
 n_bad = 0
 for rep in range(reps):
-    bf = Beamformer(p, das_impl=BF_DAS_BINS_F64)
+    bf = Beamformer(p, das_impl=BF_DAS_F64)
     y.fill_(float("nan"))
     bf.process_device(x.data_ptr(), F, y.data_ptr())
     torch.cuda.synchronize()

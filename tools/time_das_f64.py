@@ -3,7 +3,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from beamform_amd.capi import BF_DAS_BINS_F64, Beamformer
+from beamform_amd.capi import BF_DAS_F64, Beamformer
 from beamform_amd.params import make_params
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
@@ -11,7 +11,7 @@ p = make_params("das", n_mics=M)
 g = torch.Generator(device="cuda").manual_seed(7)
 x = torch.rand((M, F * 512), device="cuda", generator=g) - 0.5
 y = torch.empty(F * 512, device="cuda")
-bf = Beamformer(p, das_impl=BF_DAS_BINS_F64)
+bf = Beamformer(p, das_impl=BF_DAS_F64)
 s = torch.cuda.current_stream().cuda_stream
 for _ in range(30):
     bf.process_device(x.data_ptr(), F, y.data_ptr(), 0, s)
