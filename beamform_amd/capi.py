@@ -79,8 +79,9 @@ def _share_torch_hip_runtime():
     is loaded first it brings in /opt/rocm's copy, torch then loads its own beside it, and the second runtime to initialise reports
     "no ROCm-capable device".  When torch is installed but not imported yet, load ITS runtime first (without importing torch) so that
     libbfcore.so's DT_NEEDED resolves to the copy torch will use.  BF_NO_TORCH_HIP=1 skips this (a process that never imports torch
-    keeps the /opt/rocm runtime libbfcore.so was built against).  What happened is recorded in HIP_RUNTIME_BOUND, and a version
-    mismatch between the wheel's runtime and the one libbfcore.so was built with (bf_version()) is warned about once."""
+    keeps the /opt/rocm runtime libbfcore.so was built against).  What happened is recorded in HIP_RUNTIME_BOUND; BF_HIP_DEBUG=1 also
+    prints the runtime's version (that call initialises HIP, so it is made in debug runs only: load() itself stays a plain dlopen, safe
+    in front of a fork and for the host-only helpers -- wav, config, pcm16)."""
     global HIP_RUNTIME_BOUND
     import sys
     if os.environ.get("BF_NO_TORCH_HIP") == "1":
@@ -102,9 +103,10 @@ def _share_torch_hip_runtime():
         try:
             rt = C.CDLL(path, mode=C.RTLD_GLOBAL)
             HIP_RUNTIME_BOUND = "torch:" + path
-            v = C.c_int(0)
-            if rt.hipRuntimeGetVersion(C.byref(v)) == 0 and os.environ.get("BF_HIP_DEBUG") == "1":
-                print(f"[bfcore] bound to the torch wheel's HIP runtime {path} (version {v.value})", file=sys.stderr)
+            if os.environ.get("BF_HIP_DEBUG") == "1":
+                v = C.c_int(0)
+                if rt.hipRuntimeGetVersion(C.byref(v)) == 0:
+                    print(f"[bfcore] bound to the torch wheel's HIP runtime {path} (version {v.value})", file=sys.stderr)
         except OSError:
             HIP_RUNTIME_BOUND = "system"  # not loadable on its own: libbfcore.so falls back to its RUNPATH copy
     else:

@@ -235,6 +235,7 @@ def main():
                          "the line with the compute figures and gather_error set, and every rank exits with code 3: a collective that\n"
                          "hangs on hardware this build never saw must not cost the run its compute figures, and must not pass as a success")
     ap.add_argument("--pieces", type=int, default=4)
+    ap.add_argument("--dump-gathered", default="", help="rank 0 writes the stream its final gather assembled (float32 .npy): for tests")
     ap.add_argument("--cpu-frames", type=int, default=196608,
                     help="frames in the CPU-baseline sample (0 = skip); the default is ~12 s of single-core work (its oracle, with the FFT plan cached, does ~16 k frames per second)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -352,13 +353,18 @@ def main():
         n_feed = n_own = F
         frames_per_step_all_ranks = world * S * F
 
+    last_gather = {"parts": None}   # rank 0: what the most recent final gather received, one tensor of own_max hops per rank
+
     def gather_owned():
         if one_dev:
             host = torch.zeros(own_max * HOP, dtype=torch.float32)
             host[: n_own * HOP] = y_own.cpu()
-            dist.gather(host, [torch.empty_like(host) for _ in range(world)] if rank == 0 else None, dst=0)
+            parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+            dist.gather(host, parts, dst=0)
+            last_gather["parts"] = parts
         else:
             shard.gather_hops(y_own, F_total, world, rank, HOP, 0, out=gathered)
+            last_gather["parts"] = gathered
 
     def step(with_gather=False):
         if sharded:
@@ -514,6 +520,10 @@ def main():
     if watchdog is not None:
         watchdog.cancel()
     torch.cuda.synchronize(dev)
+    if sharded and rank == 0 and args.dump_gathered and last_gather["parts"] is not None:
+        import numpy as np
+        owns = [shard.plan(F_total, world, r, halo).n_own for r in range(world)]
+        np.save(args.dump_gathered, np.concatenate([last_gather["parts"][r][: owns[r] * HOP].cpu().numpy() for r in range(world)]))
 
     # ---- secondary lines: the other BASELINE configs, rank 0 at N = 1 -------------------------------------------
     def node_line(algo, M_, F_, S_, interf_=(), das_impl_=BF_DAS_FUSED_F32, iters=5, xin=None, note="", layout_=BF_PLANAR,

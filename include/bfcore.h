@@ -209,7 +209,10 @@ int bf_process_hop(bf_handle *h, const float *const *in, float *out, uint32_t nf
  * stated tolerance of the reference arithmetic.  Frames that share a transform also share its rounding error, 1e-16 of the LOUDER
  * one: beside an ordinary frame a frame of exact zeros comes out as 1e-17s where the reference writes zeros, and a frame 2^-40 below
  * its neighbour loses its own last 40 bits (das in double only: the other nodes' kernels pair microphones in the forward transform
- * and, in the backward one, only frames of comparable scale). */
+ * and, in the backward one, only frames of comparable scale).  gss: from 57 streams on a batch runs one lane per (stream, bin) problem
+ * (sums over the microphones as one FMA chain), below that a group of lanes per problem (pairwise sums): the demixing recursion of a
+ * stream rounds differently in a small and in a large batch, 1e-16 per step on a state with long memory -- the same stream alone and
+ * inside a 64-stream batch agrees to ~1e-12 on the spectrum (float output: equal but for rare last-bit flips), not bit for bit. */
 int bf_process_batch(bf_handle *h, const float *x_host, size_t n_frames, float *y_host);
 
 /* Same, buffers already resident in HBM; enqueued on `hip_stream`

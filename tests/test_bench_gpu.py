@@ -158,11 +158,12 @@ def test_traffic_files_name_the_kernels_that_run():
     import bench
     from beamform_amd.capi import BF_DAS_F64, BF_DAS_FUSED_F32, Beamformer, launch_trace
     from beamform_amd.params import make_params
-    cases = {"das8_f64": ("das", 8, 65536, 1, (), BF_DAS_F64), "das8": ("das", 8, 65536, 1, (), BF_DAS_FUSED_F32),
-             "mvdr8": ("mvdr", 8, 65536, 1, (), 0), "phase8": ("phase", 8, 65536, 1, (), 0),
-             "phasempf8": ("phasempf", 8, 256, 256, (), 0), "lcmv16": ("lcmv", 16, 32768, 1, (-60.0, 90.0, 150.0), 0)}
-    for tag, (algo, M, F, S, interf, impl) in cases.items():
-        bf = Beamformer(make_params(algo, n_mics=M, interf=interf), n_streams=S, das_impl=impl)
+    cases = {"das8_f64": ("das", 8, 65536, 1, (), BF_DAS_F64, 0), "das8": ("das", 8, 65536, 1, (), BF_DAS_FUSED_F32, 0),
+             "mvdr8": ("mvdr", 8, 65536, 1, (), 1, 0), "phase8": ("phase", 8, 65536, 1, (), 1, 0),
+             "phasempf8": ("phasempf", 8, 256, 256, (), 1, 0), "lcmv16": ("lcmv", 16, 32768, 1, (-60.0, 90.0, 150.0), 1, 0),
+             "mvdr8_mixed": ("mvdr", 8, 65536, 1, (), 1, 1), "lcmv16_mixed": ("lcmv", 16, 32768, 1, (-60.0, 90.0, 150.0), 1, 1)}   # last: bf_config.precision
+    for tag, (algo, M, F, S, interf, impl, prec) in cases.items():
+        bf = Beamformer(make_params(algo, n_mics=M, interf=interf), n_streams=S, das_impl=impl, precision=prec)
         x = torch.rand((S, M, F * 512), device="cuda") - 0.5
         y = torch.empty((S, F * 512), device="cuda")
         bf.process_device(x.data_ptr(), F, y.data_ptr())
@@ -176,3 +177,45 @@ def test_traffic_files_name_the_kernels_that_run():
         assert note is None and val and val > 0, (tag, note)
         val2, note2 = bench.load_traffic(tag, t.kernels + ["bf::some_other_kernel"])
         assert val2 is None and "was taken on" in note2
+
+
+def test_config5_command_line_with_8_ranks_on_one_gpu(tmp_path):
+    """BASELINE config 5 as the round driver would launch it on an 8-GPU node -- `bench.py --gpus 8 --strong --algo lcmv --mics 16` --
+    rehearsed with every rank on cuda:0 (BF_BENCH_ONE_DEVICE=1: gloo, host-staged gather): 8 ranks joined, ONE 262 144-frame stream cut
+    by shard.plan (P + 1 = 11 recomputed frames + a lead hop per rank), 7 x 64 MiB into rank 0, and the stream rank 0 assembled equals
+    the unsharded stream on sampled windows (window starts at shard edges included).  Scaling itself stays unmeasured on hardware."""
+    import numpy as np
+    import torch
+    from beamform_amd.capi import Beamformer
+    from beamform_amd.params import make_params
+    from beamform_amd.synth import stream_noise
+    dump = str(tmp_path / "gathered.npy")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(BF_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29677")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--strong", "--algo", "lcmv", "--mics", "16",
+                          "--steps", "2", "--warmup", "1", "--settle-ms", "0", "--no-extra", "--no-cpu", "--gather", "final",
+                          "--gather-timeout-s", "600", "--dump-gathered", dump],
+                         capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 8 and d["n_ranks_seen"] == 8 and d["scaling"] == "strong" and "gather_error" not in d
+    assert d["config"]["global_stream_frames"] == 262144 and d["config"]["frames_per_gpu"] == 32768
+    assert d["config"]["final_gather_bytes_into_rank0"] == 7 * 64 * 1024 * 1024
+    assert d["value_including_final_gather"] is not None and d["dtype"] == "f64"
+    got = np.load(dump)
+    assert got.shape == (262144 * 512,)
+    # the unsharded stream on this GPU (8 GiB of input, 34 GB of c128 spectra: resident), same counter-based noise
+    F, M, H = 262144, 16, 512
+    p = make_params("lcmv", n_mics=M, interf=(-60.0, 90.0, 150.0))
+    x = stream_noise(1234, M, 0, F * H, device="cuda")
+    y = torch.empty(F * H, device="cuda")
+    Beamformer(p).process_device(x.data_ptr(), F, y.data_ptr())
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(3)
+    starts = [0, 11, 32768 - 5, 32768, 32768 + 11, 5 * 32768 - 1, 7 * 32768, F - 40] + [int(v) for v in rng.integers(12, F - 40, 8)]
+    for t0 in starts:
+        ref = y[t0 * H:(t0 + 40) * H].cpu().numpy()
+        seg = got[t0 * H:(t0 + 40) * H]
+        ok = np.isfinite(ref)   # the cold start's first frames invert a zero covariance (mvdr.cpp:228-232): NaN on both sides
+        assert (np.isfinite(seg) == ok).all(), t0
+        assert np.linalg.norm(seg[ok] - ref[ok]) <= 1e-5 * np.linalg.norm(ref[ok]), t0

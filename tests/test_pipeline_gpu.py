@@ -345,6 +345,41 @@ def test_gss_many_streams_one_lane_per_problem(M, interf, hop):
         assert rel_l2(y[s], y_ref) < (1e-8 if hop == 512 else 1e-5), (s, rel_l2(y[s], y_ref))
 
 
+def test_gss_stream_alone_and_inside_a_large_batch():
+    """The kernel choice follows the batch (bfcore.h, bf_process_batch): one stream alone runs gss_kernel (a group of lanes per problem,
+    pairwise sums over the microphones), the same stream among 64 runs gss_lane_kernel (one FMA chain per sum).  The demixing recursion
+    has long memory, so the two round differently step after step: they must stay within 1e-10 of each other on the spectrum over
+    the whole stream, and each within the parity bar of the oracle."""
+    import oracle
+    import torch
+    from beamform_amd.capi import Beamformer, launch_trace
+    M, F, S = 8, 60, 64
+    p = make_params("gss", n_mics=M, interf=(-60.0, 90.0), theta=20.0)
+    xs = np.stack([make_scene(M, F, seed=7300 + s) for s in range(S)])
+
+    def spectra(x, n_streams):
+        bf = Beamformer(p, n_streams=n_streams)
+        xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        yd = torch.empty((n_streams, F * 512), dtype=torch.float32, device="cuda")
+        Yd = torch.empty((n_streams, F, 1024, 2), dtype=torch.float64, device="cuda")
+        with launch_trace() as tr:
+            bf.process_device(xd.data_ptr(), F, yd.data_ptr(), Yd.data_ptr())
+        torch.cuda.synchronize()
+        return yd.cpu().numpy(), Yd.cpu().numpy().view(np.complex128)[..., 0], tr.kernels
+
+    y_all, Y_all, k_all = spectra(xs, S)
+    assert any("gss_lane_kernel" in k for k in k_all), k_all
+    for s in (0, 37):
+        y_one, Y_one, k_one = spectra(xs[s], 1)
+        assert any("gss_kernel" in k for k in k_one) and not any("gss_lane_kernel" in k for k in k_one), k_one
+        _, Y_ref = oracle.OracleNode(p).process(xs[s], want_spectrum=True)
+        worst = max(rel_l2(Y_one[0][t], Y_all[s][t]) for t in range(F) if np.abs(Y_all[s][t]).max() > 0)
+        assert worst < 1e-10, worst
+        assert max(rel_l2(Y_one[0][t], Y_ref[t]) for t in range(F) if np.abs(Y_ref[t]).max() > 0) < 1e-5
+        assert max(rel_l2(Y_all[s][t], Y_ref[t]) for t in range(F) if np.abs(Y_ref[t]).max() > 0) < 1e-5
+        assert np.abs(y_one[0].astype(np.float64) - y_all[s]).max() <= 1e-6 * np.abs(y_all[s]).max()
+
+
 @pytest.mark.parametrize("algo", ["lcmv", "gss"])
 def test_interferer_update_add_remove(algo):
     """/theta_interference (lcmv.cpp:258-309): move an interferer, append one, remove one by moving it next to another --
