@@ -1008,9 +1008,10 @@ hipError_t launch_mvdr_lcmv(const BinsArgs &a, int n_cus, hipStream_t s) {
         fp.tile = (int)best_t;
         fp.tiles = (int)((F + best_t - 1) / best_t);
         fp.waves_per_stream = (int)(((long)fp.tiles * fp.nb + 63) / 64);
-        if (!a.yh32)  // f64x2 rows (spectrum dump / fp64 backward transform): the rows nobody solves read as zero (mvdr.cpp:103)
+        const bool band_rows = a.yh_lo > 0 || a.yh_hi < a.yh_lo;  // the consumer reads problem 0 and yh_lo..yh_hi only (a band below the Nyquist problems, no dump)
+        if (!a.yh32 && !band_rows)  // f64x2 rows read in full (spectrum dump, other FFT sizes, a band up to Nyquist): the rows nobody solves read as zero (mvdr.cpp:103)
             (void)hipMemsetAsync(a.Yh, 0, (size_t)a.n_streams * a.n_frames * kYhStride * sizeof(f64x2), s);
-        else if (a.yh_lo == 0 && fp.nb < kNQ)  // f32x2 rows that the backward transform reads in full (a band up to the Nyquist problems) while part of them is out of band
+        else if (a.yh32 && a.yh_lo == 0 && fp.nb < kNQ)  // f32x2 rows that the backward transform reads in full (a band up to the Nyquist problems) while part of them is out of band
             (void)hipMemsetAsync(a.Yh, 0, (size_t)a.n_streams * a.n_frames * kYhStride * sizeof(f32x2), s);
         const dim3 grid((unsigned)((long)fp.waves_per_stream * a.n_streams));
 #define BF_FAST_GO(MP_, KC_)                                                                     \

@@ -405,6 +405,7 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     // the per-bin stage can emit f32x2 rows: mvdr / lcmv (band-limited rows: half the row traffic, no zero-fill), das / phase through the
     // bin pipeline, phasempf.  gsc (its sample-serial NLMS branches on the aligned signals), a spectrum dump and the other FFT sizes: always
     // in double.
+    const bool cov_node = cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV;
     const bool want32 = cfg_.precision == BF_PRECISION_MIXED && cfg_.algo != BF_GSC && N_ == 1024 && spectrum == nullptr;
     // mvdr / lcmv hand the fp32 transform f32x2 rows holding only problem 0 and the in-band problems (everything else is zero,
     // mvdr.cpp:103); das / phase through the bin pipeline: f32x2 rows too (every problem written)
@@ -414,7 +415,9 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     ba.mpf32 = (cfg_.algo == BF_PHASEMPF && want32) ? 1 : 0;
     const bool istft32 = ba.yh32 != 0 || ba.mpf32 != 0;
     ba.yh_lo = 0; ba.yh_hi = NQ_ - 1;
-    if (ba.yh32 && z48_) {
+    // mvdr / lcmv rows in front of a backward transform (no dump): only problem 0 and the band's problems exist (everything else is zero,
+    // mvdr.cpp:103, and is neither written nor read): f32x2 rows into istft32_kernel, f64x2 rows into istft_w64_kernel<true>
+    if (cov_node && spectrum == nullptr && N_ == 1024) {
         int klo = N_, khi = 0;
         for (int q = 1; q < NQ_; ++q) {
             const double f = std::fabs(freqs_[q]);  // problem q = bin q for q <= N/2 + 1

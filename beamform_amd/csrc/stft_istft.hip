@@ -168,6 +168,9 @@ constexpr int oIwPlane = kIw64TwD;
 constexpr int oIwWin = oIwPlane + kIw64Waves * kPlaneD;
 constexpr int kIw64Lds = oIwWin + 64 * kIw64WinRow;
 
+// BAND: the rows hold problem 0 and the problems a.yh_lo .. a.yh_hi only (mvdr / lcmv with a band that ends below the Nyquist problems: everything
+// else is zero by definition, mvdr.cpp:103, was never written and is never read: no zero-fill of 0.54 GB per 65 536 frames in front of this kernel)
+template <bool BAND>
 __global__ __launch_bounds__(kIw64Block, 2) void istft_w64_kernel(IstftArgs a, int pairs_per_run, int runs_per_stream) {
     __shared__ __attribute__((aligned(16))) double lds[kIw64Lds];
     const cx<double> *s_tw1 = reinterpret_cast<const cx<double> *>(lds) - 64;  // row k1 starts at 64 (k1 - 1)
@@ -213,7 +216,20 @@ __global__ __launch_bounds__(kIw64Block, 2) void istft_w64_kernel(IstftArgs a, i
     }
     // Hermitian extension of a row (register r of lane l <- bin l + 64 g + 256 k3); the irregular bins 0 / 511 / 512 / 513 (quirk Q1):
     // Y[511] and Y[513] averaged with each other's conjugate, Y[0] and Y[512] real, by selects.  Every load is unconditional.
+    const int ylo = a.yh_lo, yhi = a.yh_hi;
     auto load_row = [&](const f64x2 *row, cd (&u)[16]) {
+        if constexpr (BAND) {  // problems 511 .. 513 are out of band: the plain Hermitian extension, addresses clamped to problem 0, zeros by select
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int g = r >> 2, k3 = r & 3;
+                const int qd = k3 < 2 ? lane + 64 * g + 256 * k3 : 64 * (3 - g) + 256 * (3 - k3) + 64 - lane;
+                const bool in = qd == 0 || (qd >= ylo && qd <= yhi);
+                const cd v = ld(row + (unsigned)(in ? qd : 0));
+                u[r] = cd{in ? v.x : 0.0, in ? (k3 < 2 ? v.y : -v.y) : 0.0};
+            }
+            u[0].y = lane == 0 ? 0.0 : u[0].y;  // bin 0: real part only
+            return;
+        }
         const cd y513 = ld(row + 513);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1217,7 +1233,9 @@ hipError_t launch_istft(const IstftArgs &a, int n_cus, hipStream_t s) {
     const long ppr = (pairs + rps - 1) / rps;
     rps = (pairs + ppr - 1) / ppr;
     const long runs = rps * a.n_streams;
-    BF_LAUNCH(istft_w64_kernel, dim3((unsigned)((runs + kIw64Waves - 1) / kIw64Waves)), dim3(kIw64Block), 0, s, a, (int)ppr, (int)rps);
+    const dim3 grid((unsigned)((runs + kIw64Waves - 1) / kIw64Waves));
+    if (a.yh_lo > 0 || a.yh_hi < a.yh_lo) BF_LAUNCH(istft_w64_kernel<true>, grid, dim3(kIw64Block), 0, s, a, (int)ppr, (int)rps);  // band-limited rows (mvdr / lcmv)
+    else BF_LAUNCH(istft_w64_kernel<false>, grid, dim3(kIw64Block), 0, s, a, (int)ppr, (int)rps);
     return hipGetLastError();
 }
 

@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import oracle
-from beamform_amd.capi import Beamformer, BF_PLANAR, BF_INTERLEAVED, BF_DAS_F64, BF_DAS_FUSED_F32
+from beamform_amd.capi import Beamformer, BF_PLANAR, BF_INTERLEAVED, BF_DAS_F64, BF_DAS_FUSED_F32, BF_PRECISION_MIXED, BF_PRECISION_REFERENCE
 from beamform_amd.params import make_params
 from beamform_amd.synth import make_scene
 
@@ -33,8 +33,9 @@ for case in range(n_cases):
     x = make_scene(M, F, hop=hop, seed=int(rng.integers(1 << 30)), theta_s=float(rng.uniform(-180, 180)))
     layout = BF_INTERLEAVED if rng.random() < 0.3 else BF_PLANAR
     node = oracle.OracleNode(p)
-    impl = BF_DAS_F64 if (algo == "das" and rng.random() < 0.6) else BF_DAS_FUSED_F32   # das: in double (one-launch kernels) or fused fp32
-    bf = Beamformer(p, layout=layout, das_impl=impl)
+    impl = BF_DAS_F64 if (algo == "das" and rng.random() < 0.6) else BF_DAS_FUSED_F32   # das: in double (the default; one-launch kernels) or the fused fp32 opt-in
+    prec = BF_PRECISION_MIXED if rng.random() < 0.35 else BF_PRECISION_REFERENCE          # the default (doubles between the transforms) or the z48 / fp32-ISTFT opt-in
+    bf = Beamformer(p, layout=layout, das_impl=impl, precision=prec)
     cuts = sorted(set([0, F] + [int(c) for c in rng.integers(1, F, size=int(rng.integers(0, 3)))]))
     ys, refs = [], []
     for a, b in zip(cuts[:-1], cuts[1:]):
@@ -49,7 +50,8 @@ for case in range(n_cases):
     same_nan = bool((np.isfinite(y) == ok).all())
     err = float(np.linalg.norm(y[ok] - r[ok]) / (np.linalg.norm(r[ok]) + 1e-300))
     tag = "ok" if (same_nan and err < 1e-5) else "FAIL"
-    worst[algo] = max(worst.get(algo, 0.0), err)
+    key = algo + ("/f32" if (algo == "das" and impl == BF_DAS_FUSED_F32) else "") + ("/mixed" if prec == BF_PRECISION_MIXED and algo in ("das", "mvdr", "lcmv", "phase", "phasempf") else "")
+    worst[key] = max(worst.get(key, 0.0), err)
     if tag == "FAIL":
-        print(f"{tag} case {case}: {algo} M={M} K={K} theta={theta:.1f} F={F} cuts={cuts} layout={layout} over={over} err={err:.2e} nan_ok={same_nan}")
+        print(f"{tag} case {case}: {algo} M={M} K={K} theta={theta:.1f} F={F} cuts={cuts} layout={layout} impl={impl} precision={prec} over={over} err={err:.2e} nan_ok={same_nan}")
 print("worst relative L2 per node:", {k: f"{v:.1e}" for k, v in sorted(worst.items())})
