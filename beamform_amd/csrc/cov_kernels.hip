@@ -540,12 +540,10 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
 // DPP note: every pattern in this file (quad_perm, row_newbcast, row mirrors) reads a valid source lane for every destination
 // lane, so the `old` operand is dead.  With bound_ctrl = false hipcc still materialises it (v_mov_b32 old, 0 in front of every
 // v_mov_b32_dpp: 812 + 812 instructions in the lcmv-16 solve block = 44 % of it); bound_ctrl = true drops the initialisation.
+// (row_newbcast is the one DPP control gfx950 encodes for 64-bit operands: one v_mov_b64_dpp per double instead of two v_mov_b32_dpp)
 template <int N>
 __device__ __forceinline__ double rowbc(double v) {
-    const long long b = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x150 + N, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + N, 0xF, 0xF, true);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + N, 0xF, 0xF, true);
 }
 template <int N>
 __device__ __forceinline__ cd rowbc(cd v) { return cd{rowbc<N>(v.x), rowbc<N>(v.y)}; }

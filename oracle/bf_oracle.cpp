@@ -412,7 +412,11 @@ static void apply_gss(orc_node *n) {
     }
 }
 
-/* phase.cpp:53-68 / phasempf.cpp:105-120 (recursive pair sum, same association) */
+/* phase.cpp:53-68 / phasempf.cpp:105-120 (recursive pair sum, same association).
+ * Toolchain-dependent reading: phase.cpp:58 calls an UNQUALIFIED abs() on a double.  It resolves to the floating overload only because
+ * libstdc++'s <cmath> / <stdlib.h> wrappers put std::abs(double) into the global namespace (true for the GCC 9 that ROS Noetic implies and
+ * for the GCC 11 of this image: SURVEY.md App. C probe 2 prints 2.7 for -2.7); with a C library's int abs(int) alone the difference would be
+ * truncated to an integer.  The oracle assumes the floating overload (std::abs below). */
 static double overall_phase_diff(const orc_node *n, int min_i, int *num_i) {
     if (min_i < n->M - 1) {
         double this_diff = 0;

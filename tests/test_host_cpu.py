@@ -295,3 +295,13 @@ def test_das_f64_chunk_plan_tiles_every_stream(emul_lib):
             if env == b"" and k > grid.value:   # level-major order: the table starts with one long chunk per block-share of every stream
                 first = [n[i] for i in range(min(grid.value, k))]
                 assert min(first) >= max(n[i] for i in range(k - 1, k)), (F, S)
+
+
+def test_bench_tables_in_the_docs_match_their_records():
+    """BASELINE.md section 4 and README.md carry ONE generated table of measured figures each (tools/bench_tables.py): regenerated from
+    the records the table itself names (the driver's BENCH_rNN.json, this build's profiles/rNN_*bench*.json) it must come out the same
+    text, i.e. no figure in it was typed or edited by hand."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_tables.py"), "--check"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr

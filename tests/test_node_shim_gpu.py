@@ -38,6 +38,8 @@ def test_file_node_matches_oracle(tmp_path, algo, interf):
     ok = np.isfinite(y_ref)
     assert y.shape == y_ref.shape and (np.isfinite(y) == ok).all()
     assert rel_l2(y[ok], y_ref[ok]) < 1e-5
+    if algo == "das":  # the default configuration computes in double like das.cpp:16-24 (bf_config_init: BF_DAS_F64): the float output is the oracle's
+        assert np.array_equal(y, y_ref)
 
 
 def test_theta_scan_picks_the_target_and_matches_oracle_energies(tmp_path):

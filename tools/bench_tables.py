@@ -7,7 +7,9 @@ either table is typed by hand:  python tools/bench_tables.py [--check]
                     per secondary line -- for exactly this reason)
   column "builder"  min - max over the bench.py lines this round's profile runs left under profiles/ (rNN_*bench*.json, un-profiled ones)
 
-The block between <!-- BENCH:BEGIN --> and <!-- BENCH:END --> is replaced; --check exits 1 if a file would change (the CPU suite runs it)."""
+The block between <!-- BENCH:BEGIN --> and <!-- BENCH:END --> is replaced.  --check (the CPU suite runs it) regenerates each block from the
+records the block itself names -- its BENCH file and its profiles round -- and exits 1 if the text differs: no figure in a table can be
+typed or edited by hand, and a table never silently mixes sources; a newer BENCH_rNN.json than the one a table names is reported."""
 import glob
 import json
 import os
@@ -36,12 +38,20 @@ ROWS = [
 ]
 
 
-def newest_driver_record():
+def driver_record(name=None):
+    """(file name, record) of BENCH_rNN.json: the named one, else the newest"""
     files = sorted(glob.glob(os.path.join(ROOT, "BENCH_r*.json")), key=lambda f: int(re.search(r"BENCH_r(\d+)", f).group(1)))
+    if name is not None:
+        files = [f for f in files if os.path.basename(f) == name]
     if not files:
         return None, None
     f = files[-1]
     return os.path.basename(f), json.load(open(f))
+
+
+def newest_profiles_round():
+    rs = [int(m.group(1)) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_*bench*.json")) for m in [re.match(r"r(\d+)_", os.path.basename(f))] if m]
+    return max(rs) if rs else 0
 
 
 def extra_ms_from_tail(tail):
@@ -84,21 +94,24 @@ def rng(vals, fmt):
     return fmt % lo if abs(hi - lo) < 1e-12 else f"{fmt % lo} – {fmt % hi}"
 
 
-def build_block():
-    name, rec = newest_driver_record()
+def build_block(bench_name=None, round_no=None):
+    name, rec = driver_record(bench_name)
     if rec is None:
         return None
-    round_no = int(re.search(r"r(\d+)", name).group(1))
+    if round_no is None:
+        round_no = newest_profiles_round()
     p = rec.get("parsed") or {}
     rf = p.get("roofline") or {}
     dms = extra_ms_from_tail(rec.get("tail"))
     bl = builder_lines(round_no)
+    drv_round = int(re.search(r"r(\d+)", name).group(1))
     own = lambda f: [f(b) for b in bl]  # noqa: E731
     g = lambda d, *ks: (g(d.get(ks[0], {}), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None  # noqa: E731
     out = [BEGIN, "",
-           f"Driver = `{name}` (`head` {rec.get('head', '?')}, `{p.get('dtype', '?')}`, {p.get('steps', '?')} steps); builder = {len(bl)} un-profiled "
-           f"`bench.py` runs of round {round_no} under `profiles/` (box-to-box range).", "",
-           "| line | driver's box | builder's boxes |", "|---|---|---|"]
+           f"Driver's box = `{name}` (`head` {rec.get('head', '?')}, `{p.get('dtype', '?')}`, {p.get('steps', '?')} steps: the round driver's own run of `bench.py` "
+           f"at the end of round {drv_round}); builder's boxes = the {len(bl)} un-profiled `bench.py` runs of round {round_no} "
+           f"under `profiles/r{round_no:02d}_*` (range). A driver column older than the builder column is the previous round's tree.", "",
+           f"| line | driver's box ({name[:-5]}) | builder's boxes (profiles r{round_no:02d}) |", "|---|---|---|"]
     fmt3 = "%.3f"
     out.append(f"| **[1] das 8-mic 1024-pt, 65 536 frames, double (headline)**: ms per step | **{p.get('ms_per_step', float('nan')):.4f}** | {rng(own(lambda b: b.get('ms_per_step')), '%.4f')} |")
     out.append(f"| … `{rf.get('kernel', 'kernel')}` ms per launch (HIP event pairs inside the timed steps) | {rf.get('kernel_ms', float('nan')):.4f} | {rng(own(lambda b: g(b, 'roofline', 'kernel_ms')), '%.4f')} |")
@@ -124,27 +137,32 @@ def build_block():
 
 def main():
     check = "--check" in sys.argv
-    block = build_block()
-    if block is None:
+    newest, _ = driver_record()
+    if newest is None:
         print("no BENCH_r*.json")
         return 0
-    changed = False
+    bad = False
     for fn in ("BASELINE.md", "README.md"):
         path = os.path.join(ROOT, fn)
         s = open(path).read()
         if BEGIN not in s or END not in s:
             print(f"{fn}: no BENCH markers")
+            bad = bad or check
             continue
-        new = s[:s.index(BEGIN)] + block + s[s.index(END) + len(END):]
+        old = s[s.index(BEGIN):s.index(END) + len(END)]
+        if check:  # regenerate from the sources the block names
+            m = re.search(r"Driver's box = `(BENCH_r\d+\.json)`.*?bench\.py` runs of round (\d+)", old, re.S)
+            if not m or build_block(m.group(1), int(m.group(2))) != old:
+                print(f"{fn}: the bench table does not match its records: run python tools/bench_tables.py")
+                bad = True
+            elif m.group(1) != newest:
+                print(f"{fn}: note: the table was written from {m.group(1)}; {newest} exists (python tools/bench_tables.py)")
+            continue
+        new = s[:s.index(BEGIN)] + build_block() + s[s.index(END) + len(END):]
         if new != s:
-            changed = True
-            if not check:
-                open(path, "w").write(new)
-                print(f"{fn}: table rewritten")
-    if check and changed:
-        print("bench tables are stale: run python tools/bench_tables.py")
-        return 1
-    return 0
+            open(path, "w").write(new)
+            print(f"{fn}: table rewritten")
+    return 1 if bad else 0
 
 
 if __name__ == "__main__":

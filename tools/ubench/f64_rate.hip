@@ -38,6 +38,22 @@ __global__ void k(double *out, int iters, double seed) {
                 asm volatile("v_mov_b64 %0, %1\n v_mov_b64 %1, %2\n v_mov_b64 %2, %3\n v_mov_b64 %3, %4\n"
                              "v_mov_b64 %4, %5\n v_mov_b64 %5, %6\n v_mov_b64 %6, %7\n v_mov_b64 %7, %0\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            else if (MODE == 8)  // v_fmac_f64 with a DPP row_newbcast source: the only fp64 arithmetic gfx950 encodes with DPP (VOP2), broadcast fused into the FMA
+                asm volatile("v_fmac_f64_dpp %0, %8, %9 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %1, %8, %9 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+                             "v_fmac_f64_dpp %2, %8, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %3, %8, %9 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+                             "v_fmac_f64_dpp %4, %8, %9 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %5, %8, %9 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+                             "v_fmac_f64_dpp %6, %8, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %7, %8, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));
+            else if (MODE == 9)  // v_mov_b64 with DPP row_newbcast (one instruction per double; the b32 form needs two)
+                asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+                             "v_mov_b64_dpp %2, %3 row_newbcast:7 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %3, %4 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+                             "v_mov_b64_dpp %4, %5 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %5, %6 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+                             "v_mov_b64_dpp %6, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %7, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            else if (MODE == 10)  // plain v_fmac_f64 (VOP2) for comparison with MODE 8
+                asm volatile("v_fmac_f64 %0, %8, %9\n v_fmac_f64 %1, %8, %9\n v_fmac_f64 %2, %8, %9\n v_fmac_f64 %3, %8, %9\n"
+                             "v_fmac_f64 %4, %8, %9\n v_fmac_f64 %5, %8, %9\n v_fmac_f64 %6, %8, %9\n v_fmac_f64 %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));
             else if (MODE == 7)  // fp64 fma with two constant operands from SGPRs, as the fused-twiddle butterflies have them
                 asm volatile("v_fma_f64 %0, %0, %8, %1\n v_fma_f64 %1, %1, %8, %2\n v_fma_f64 %2, %2, %8, %3\n v_fma_f64 %3, %3, %8, %4\n"
                              "v_fma_f64 %4, %4, %8, %5\n v_fma_f64 %5, %5, %8, %6\n v_fma_f64 %6, %6, %8, %7\n v_fma_f64 %7, %7, %8, %0\n"
@@ -67,5 +83,6 @@ void run(const char *name) {
 int main() {
     run<0>("v_fma_f64"); run<1>("v_add_f64"); run<2>("v_mul_f64"); run<7>("v_fma_f64 sgpr"); run<3>("v_cvt_f64_f32"); run<4>("v_cvt_f32_f64");
     run<5>("v_permlane_swap"); run<6>("v_mov_b64");
+    run<10>("v_fmac_f64"); run<8>("v_fmac_f64_dpp"); run<9>("v_mov_b64_dpp");
     return 0;
 }
