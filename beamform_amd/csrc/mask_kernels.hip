@@ -299,12 +299,16 @@ __device__ __forceinline__ cd mpf_step(MpfState &st, const bf_config &c, int j, 
         st.Smin = st.Smin > S ? S : st.Smin;
         st.Stmp = st.Stmp > S ? S : st.Stmp;
     }
-    if (firstL || S < st.Smin * c.mcra_delta || st.lam > soi2) {
-        const double ic = 1.0 / (double)cL;
-        if (firstL && ic > c.mcra_alphaD)
-            st.lam = ic * st.lam + (1.0 - ic) * soi2;
-        else
-            st.lam = c.mcra_alphaD2 * st.lam + (1.0 - c.mcra_alphaD) * soi2;  // quirk Q15g
+    {
+        // phasempf.cpp:172-183.  firstL and current_L are per stream, i.e. wavefront-uniform: the division 1 / current_L is formed only while
+        // the first search period runs (its result is read only then), and the update itself is a select instead of a divergent branch
+        const bool upd = firstL || S < st.Smin * c.mcra_delta || st.lam > soi2;
+        double lam_new = c.mcra_alphaD2 * st.lam + (1.0 - c.mcra_alphaD) * soi2;  // quirk Q15g
+        if (firstL) {
+            const double ic = 1.0 / (double)cL;
+            if (ic > c.mcra_alphaD) lam_new = ic * st.lam + (1.0 - ic) * soi2;
+        }
+        st.lam = upd ? lam_new : st.lam;
     }
     st.Sprev = S;
     st.Z = c.mpf_alphaS * st.Z + (1 - c.mpf_alphaS) * int2;
@@ -387,6 +391,273 @@ __global__ __launch_bounds__(64) void mpf_recursion_kernel(BinsArgs a, double *a
     }
 }
 
+#if BF_NFFT == 1024
+// ---- phasempf with many streams: the recursion and the backward transform in one kernel ---------------------------------------------
+// With as many streams as CUs the recursion (one lane per (stream, problem), serial over the frames) and the backward transform (one
+// wavefront per frame pair) can share a block per stream: the y_fft rows go from the recursion's lanes to the transform through LDS and
+// never reach HBM (0.54 GB written + read per 65 536 frames; mpf_recursion_kernel + istft_w64_kernel: 0.34 + 0.195 ms at 256 x 256).
+// Block = 7 wavefronts: 0..3 run the recursion of problems r and r + 256, wavefront 6 that of problems 512 and 513; wavefronts 4 and 5
+// transform the PREVIOUS batch of four frames (one frame pair each, the code of istft_w64_kernel) while the recursion works on the next:
+// two halves of four rows in LDS, one block barrier per batch.  Tails between the two pairs of a batch and between batches travel
+// through parity-double-buffered LDS slots (written in one phase, read behind the next barrier).  phasempf.cpp:140-191,254-295 +
+// util.h:244-253,301-302.
+constexpr int kRiNB = 4;
+constexpr int kRiThreads = 448;
+constexpr int kRiTwD = 2 * (960 + 4 * kTw2RowW64Rot);   // tw1 rows k1 = 1..15 + tw2' (a.rec_tw_w64 + 64), in doubles
+constexpr int kRiWinRow = 18;
+constexpr int kRiRowD = 2 * kYhStride;                  // doubles per y_fft row
+constexpr int oRiPlane = kRiTwD;
+constexpr int oRiWin = oRiPlane + 2 * kPlaneD;
+constexpr int oRiRows = oRiWin + 64 * kRiWinRow;        // [half][frame of the batch][kYhStride] c128
+constexpr int oRiTail = oRiRows + 2 * kRiNB * kRiRowD;  // floats: [parity][wavefront 4's tail | carried tail][512]
+constexpr int kRiLds = oRiTail + 2 * 2 * 512 / 2;
+static_assert(kRiLds * 8 <= 160 * 1024 && (oRiRows & 1) == 0 && (oRiWin & 1) == 0, "LDS");
+
+__global__ __launch_bounds__(kRiThreads) void mpf_rec_istft_kernel(BinsArgs a, double *aux) {
+    __shared__ __attribute__((aligned(16))) double lds[kRiLds];
+    const cx<double> *s_tw1 = reinterpret_cast<const cx<double> *>(lds) - 64;  // row k1 starts at 64 (k1 - 1)
+    const cx<double> *s_tw2 = reinterpret_cast<const cx<double> *>(lds) + 960;
+    float *s_tail = reinterpret_cast<float *>(lds + oRiTail);                  // [parity][0: wavefront 4's tail, 1: carry][512]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = blockIdx.x;
+    const long F = a.n_frames;
+    {
+        const f64x2 *tw2 = a.rec_tw_w64 + 64;
+        f64x2 *ltw = reinterpret_cast<f64x2 *>(lds);
+        for (int i = tid; i < kRiTwD / 2; i += kRiThreads) ltw[i] = tw2[i];
+        for (int i = tid; i < 1024; i += kRiThreads) lds[oRiWin + (i & 63) * kRiWinRow + (i >> 6)] = a.rec_win[i];
+        for (int i = tid; i < kHop; i += kRiThreads) s_tail[(0 * 2 + 1) * 512 + i] = a.rec_tail_in[(long)s * kHop + i];  // carry into batch 0
+    }
+    const int n_batches = (int)((F + kRiNB - 1) / kRiNB);
+    const bool worker = w == 4 || w == 5;
+    const int wk = w - 4;  // which pair of the batch
+    // ---- transform lanes ---------------------------------------------------------------------------------------------------------------
+    double *plane = lds + oRiPlane + (worker ? wk : 0) * kPlaneD;
+    double *wcol = plane + w64_col_rot(lane);
+    double *row16 = plane + (lane & 15) * kRS + 16 * (lane >> 4);
+    const double *wrow = lds + oRiWin + lane * kRiWinRow;
+    float *ys = a.rec_y + (long)s * F * kHop;
+    __syncthreads();
+
+    // The two roles run their own loops (wavefront-uniform branch; the same number of block barriers on either side), so that the
+    // registers of the recursion (input ring, two states) and of the transform are never live together.
+    if (!worker) {
+        // ---- recursion lanes: problems q0 (and q1) of this stream --------------------------------------------------------------------------
+        const int nq = w < 4 ? 2 : (w == 6 && lane < 2) ? 1 : 0;
+        const int q0 = w < 4 ? tid : 512 + lane, q1 = tid + 256;
+        double *sv = a.mpf + (long)s * (kMpfVecs * kN + 8);
+        MpfState st0{}, st1{};
+        if (nq >= 1) st0 = MpfState{sv[0 * kN + q_bin(q0)], sv[1 * kN + q_bin(q0)], sv[2 * kN + q_bin(q0)], sv[3 * kN + q_bin(q0)], sv[4 * kN + q_bin(q0)], sv[5 * kN + q_bin(q0)], sv[6 * kN + q_bin(q0)]};
+        if (nq >= 2) st1 = MpfState{sv[0 * kN + q_bin(q1)], sv[1 * kN + q_bin(q1)], sv[2 * kN + q_bin(q1)], sv[3 * kN + q_bin(q1)], sv[4 * kN + q_bin(q1)], sv[5 * kN + q_bin(q1)], sv[6 * kN + q_bin(q1)]};
+        int cL = (int)sv[kMpfVecs * kN + 0];
+        bool firstL = sv[kMpfVecs * kN + 1] == 0.0;
+        const f64x2 *row = a.Yh + ((long)s * F) * kYhStride;
+        const double *arow = aux + ((long)s * F) * kYhStride;
+        cd soi0[kRiNB], soi1[kRiNB];   // the next four frames' inputs: a ring of register sets, refilled as they are consumed
+        double in0[kRiNB], in1[kRiNB];
+    #pragma unroll
+        for (int k = 0; k < kRiNB; ++k) {
+            const long tt = k < F ? k : F - 1;
+            soi0[k] = soi1[k] = cd{0, 0};
+            in0[k] = in1[k] = 0.0;
+            if (nq >= 1) { soi0[k] = ld(row + tt * kYhStride + q0); in0[k] = arow[tt * kYhStride + q0]; }
+            if (nq >= 2) { soi1[k] = ld(row + tt * kYhStride + q1); in1[k] = arow[tt * kYhStride + q1]; }
+        }
+        for (int it = 0; it <= n_batches; ++it) {
+            const int par = it & 1;
+            if (nq > 0 && it < n_batches) {  // ---- the recursion of batch `it` into half `par` ----
+                f64x2 *rows = reinterpret_cast<f64x2 *>(lds + oRiRows) + (long)par * kRiNB * kYhStride;
+#pragma unroll
+                for (int k = 0; k < kRiNB; ++k) {
+                    const long t = (long)it * kRiNB + k;
+                    if (t >= F) break;
+                    const cd sa = soi0[k], sb = soi1[k];
+                    const double ia = in0[k], ib = in1[k];
+                    {
+                        const long tn = t + kRiNB < F ? t + kRiNB : F - 1;
+                        soi0[k] = ld(row + tn * kYhStride + q0);
+                        in0[k] = arow[tn * kYhStride + q0];
+                        if (nq >= 2) { soi1[k] = ld(row + tn * kYhStride + q1); in1[k] = arow[tn * kYhStride + q1]; }
+                    }
+                    const bool reset = cL > a.cfg.mcra_L;  // phasempf.cpp:161
+                    if (reset) {
+                        cL = 1;
+                        firstL = false;
+                    } else {
+                        cL++;
+                    }
+                    const cd ya = mpf_step(st0, a.cfg, q_bin(q0), sa, ia, reset, firstL, cL);
+                    rows[k * kYhStride + q0] = f64x2{ya.x, ya.y};
+                    if (nq >= 2) {
+                        const cd yb = mpf_step(st1, a.cfg, q_bin(q1), sb, ib, reset, firstL, cL);
+                        rows[k * kYhStride + q1] = f64x2{yb.x, yb.y};
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (nq >= 1) {
+            const int j0 = q_bin(q0);
+            sv[0 * kN + j0] = st0.Sprev; sv[1 * kN + j0] = st0.Stmp; sv[2 * kN + j0] = st0.Smin; sv[3 * kN + j0] = st0.lam;
+            sv[4 * kN + j0] = st0.Z; sv[5 * kN + j0] = st0.rev0; sv[6 * kN + j0] = st0.rev1;
+        }
+        if (nq >= 2) {
+            const int j1 = q_bin(q1);
+            sv[0 * kN + j1] = st1.Sprev; sv[1 * kN + j1] = st1.Stmp; sv[2 * kN + j1] = st1.Smin; sv[3 * kN + j1] = st1.lam;
+            sv[4 * kN + j1] = st1.Z; sv[5 * kN + j1] = st1.rev0; sv[6 * kN + j1] = st1.rev1;
+        }
+        if (tid == 0) {
+            sv[kMpfVecs * kN + 0] = (double)cL;
+            sv[kMpfVecs * kN + 1] = firstL ? 0.0 : 1.0;
+        }
+    } else {
+        for (int it = 0; it <= n_batches; ++it) {
+            const int par = it & 1;
+            float head[8], tl[8];
+            int nb_prev = 0;
+            long b0 = 0;
+            bool active = false, last = false;
+            if (it >= 1) {  // ---- the backward transforms of batch `it - 1` out of half `par ^ 1` ----
+                b0 = (long)(it - 1) * kRiNB;
+                nb_prev = (int)(F - b0 < kRiNB ? F - b0 : kRiNB);
+                const int fa = 2 * wk;
+                active = fa < nb_prev;
+                last = active && fa + 2 >= nb_prev;  // this wavefront holds the batch's last frame: its tail is the next batch's carry
+                if (active) {
+                    const f64x2 *rows = reinterpret_cast<const f64x2 *>(lds + oRiRows) + (long)(par ^ 1) * kRiNB * kYhStride;
+                    // Hermitian extension of a row (istft_w64_kernel): register r of lane l <- bin l + 64 g + 256 k3; bins 0 / 511 / 512 / 513 by selects
+                    auto load_row = [&](const f64x2 *rw, cd (&u)[16]) {
+                        const cd y513 = ld(rw + 513);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int g = r >> 2, k3 = r & 3;
+                            if (k3 < 2) u[r] = ld(rw + (unsigned)(lane + 64 * g + 256 * k3));
+                            else u[r] = conj(ld(rw + (unsigned)(64 * (3 - g) + 256 * (3 - k3) + 64 - lane)));
+                        }
+                        u[0].y = lane == 0 ? 0.0 : u[0].y;
+                        const cd m513 = (y513 + u[2]) * 0.5, m511 = (u[13] + conj(y513)) * 0.5;
+                        u[2].x = lane == 1 ? m513.x : u[2].x;
+                        u[2].y = lane == 1 ? m513.y : lane == 0 ? 0.0 : u[2].y;
+                        u[13].x = lane == 63 ? m511.x : u[13].x;
+                        u[13].y = lane == 63 ? m511.y : u[13].y;
+                    };
+                    auto window = [&](const double (&x)[16], float (&o)[16]) {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const float f = (float)(x[j] * (1.0 / 1024.0));
+                            o[j] = (float)((double)f * wrow[j]);
+                        }
+                    };
+                    int t = fa;
+                    const int t1 = fa + 2 < nb_prev ? fa + 2 : nb_prev;
+                    bool first = true;
+                    while (t < t1) {
+                        bool pair = t + 1 < t1;
+                        const f64x2 *ra = rows + t * kYhStride, *rb = pair ? ra + kYhStride : ra;
+                        double re[16], im[16];
+                        {
+                            cd u[16];
+                            load_row(ra, u);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                re[r] = u[r].x;
+                                im[r] = u[r].y;
+                            }
+                        }
+                        BF_STAGE();
+                        if (pair) {
+                            cd v[16];
+                            load_row(rb, v);
+                            unsigned ha = 0, hb = 0;  // frames share a transform only if both are finite and of comparable scale (istft_w64_kernel)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                ha = max(ha, max(hi_abs(re[r]), hi_abs(im[r])));
+                                hb = max(hb, max(hi_abs(v[r].x), hi_abs(v[r].y)));
+                            }
+                            ha = wave_max_u32(ha);
+                            hb = wave_max_u32(hb);
+                            const int ea = (int)(ha >> 20), eb = (int)(hb >> 20);
+                            pair = ea < 0x7FF && eb < 0x7FF && ea - eb <= 20 && eb - ea <= 20;
+                            if (pair) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    re[r] -= v[r].y;
+                                    im[r] += v[r].x;
+                                }
+                            }
+                        }
+                        cx<double> tw[15];
+                        BF_STAGE();
+                        load_tw2<1, 16>(tw, s_tw2, lane);
+                        BF_STAGE();
+                        w64_inv_p3<double>(re, im);
+                        w64_T2_any<false>(re, im, row16 - 16 * (lane >> 4), lane >> 4);
+                        BF_STAGE();
+                        mul_tw<true, 1, 16>(re, im, tw);
+                        BF_STAGE();
+                        load_tw1<1, 16>(tw, s_tw1, lane);
+                        BF_STAGE();
+                        fft16_core<double, +1, false>(re, im);
+                        BF_STAGE();
+                        T1_inv(re, im, row16, wcol);
+                        BF_STAGE();
+                        mul_tw<true, 1, 16>(re, im, tw);
+                        fft16_core<double, +1, false>(re, im);
+                        BF_STAGE();
+                        float oa[16];
+                        window(re, oa);
+                        if (first) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) head[j] = oa[j];  // completed behind the barrier with the tail in front of it
+                        } else {
+                            float *yo = ys + (b0 + t) * kHop;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) yo[(unsigned)(64 * j + lane)] = tl[j] + oa[j];
+                        }
+                        if (pair) {
+                            float ob[16];
+                            window(im, ob);
+                            float *yo = ys + (b0 + t + 1) * kHop;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) yo[(unsigned)(64 * j + lane)] = oa[j + 8] + ob[j];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) tl[j] = ob[j + 8];
+                            t += 2;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) tl[j] = oa[j + 8];
+                            t += 1;
+                        }
+                        first = false;
+                    }
+                    if (!last) {  // wavefront 4 with a second pair behind it: its tail meets wavefront 5's head behind the barrier
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) s_tail[(par * 2 + 0) * 512 + 64 * j + lane] = tl[j];
+                    }
+                }
+            }
+            __syncthreads();
+            if (active) {  // the hop in front of this wavefront's first frame: out_buff[0][j] + out_buff[1][j] as floats (util.h:302)
+                const float *tin = wk == 0 ? s_tail + ((par ^ 1) * 2 + 1) * 512 : s_tail + (par * 2 + 0) * 512;
+                float *yo = ys + (b0 + 2 * wk) * kHop;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) yo[(unsigned)(64 * j + lane)] = tin[64 * j + lane] + head[j];
+                if (last) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s_tail[(par * 2 + 1) * 512 + 64 * j + lane] = tl[j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {  // out_buff[0] of the next call: the carry the last batch left (written in iteration n_batches: parity n_batches & 1)
+        const float *c = s_tail + ((n_batches & 1) * 2 + 1) * 512;
+        for (int i = tid; i < kHop; i += kRiThreads) a.rec_tail_out[(long)s * kHop + i] = c[i];
+    }
+}
+#endif
+
 // ======================================================================================
 //                  mcra node: single-channel MCRA noise subtraction (mcra.cpp:64-155)
 // ======================================================================================
@@ -450,12 +721,14 @@ __global__ __launch_bounds__(64) void mcra_node_kernel(BinsArgs a) {
             Stmp = Stmp > S ? S : Stmp;
             cL++;
         }
-        if (firstL || S < Smin * delta || lam > x2) {  // mcra.cpp:116-124
-            const double invL = 1.0 / (double)cL;
-            if (firstL && invL > aD)
-                lam = invL * lam + (1.0 - invL) * x2;
-            else
-                lam = aD2 * lam + (1.0 - aD) * x2;
+        {  // mcra.cpp:116-124 (as mpf_step: the division only while the first search period runs, the update by select)
+            const bool upd = firstL || S < Smin * delta || lam > x2;
+            double lam_new = aD2 * lam + (1.0 - aD) * x2;
+            if (firstL) {
+                const double invL = 1.0 / (double)cL;
+                if (invL > aD) lam_new = invL * lam + (1.0 - invL) * x2;
+            }
+            lam = upd ? lam_new : lam;
         }
         cd y{0, 0};  // bin 0 is never written by the node (quirk Q16, mcra.cpp:127)
         if (j != 0) {
@@ -1138,9 +1411,13 @@ hipError_t launch_stft_bins_fused(const StftArgs &a, const BinsArgs &b, int n_cu
 #undef BF_FUSED_GO
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (algo == BF_PHASEMPF) {  // second pass of launch_phasempf: the recursion over frames
-        const int nthr = b.n_streams * kNQ;
-        BF_LAUNCH(mpf_recursion_kernel, dim3((nthr + 63) / 64), dim3(64), 0, s, b, aux);
+    if (algo == BF_PHASEMPF) {  // second pass of launch_phasempf: the recursion over frames (with many streams: and the backward transform)
+        if (b.rec_istft) {
+            BF_LAUNCH(mpf_rec_istft_kernel, dim3((unsigned)b.n_streams), dim3(kRiThreads), 0, s, b, aux);
+        } else {
+            const int nthr = b.n_streams * kNQ;
+            BF_LAUNCH(mpf_recursion_kernel, dim3((nthr + 63) / 64), dim3(64), 0, s, b, aux);
+        }
         e = hipGetLastError();
     }
     if (e == hipSuccess && b.spectrum) e = launch_expand_spectrum(b.Yh, b.spectrum, (long)b.n_streams * b.n_frames, s);
@@ -1217,6 +1494,12 @@ hipError_t launch_phasempf(const BinsArgs &a, int n_cus, hipStream_t s) {
         BF_LAUNCH((mpf_mask_kernel<32>), dim3(blocks), dim3(256), 0, s, a, aux);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+#if BF_NFFT == 1024
+    if (a.rec_istft) {
+        BF_LAUNCH(mpf_rec_istft_kernel, dim3((unsigned)a.n_streams), dim3(kRiThreads), 0, s, a, aux);
+        return hipGetLastError();
+    }
+#endif
     const int nthr = a.n_streams * kNQ;
     BF_LAUNCH(mpf_recursion_kernel, dim3((nthr + 63) / 64), dim3(64), 0, s, a, aux);
     return hipGetLastError();

@@ -426,6 +426,14 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
         if (khi < N_ / 2 - 1 && klo <= khi) { ba.yh_lo = klo; ba.yh_hi = khi; }
         else if (klo > khi) { ba.yh_lo = 1; ba.yh_hi = 0; }  // empty band: only problem 0
     }
+    // phasempf with at least a quarter as many streams as CUs, default precision, no dump: the recursion kernel runs the backward transform too
+    // (mask_kernels.hip mpf_rec_istft_kernel: a block per stream, the y_fft rows stay in LDS); with fewer streams its blocks leave the chip empty
+    const bool rec_istft = cfg_.algo == BF_PHASEMPF && N_ == 1024 && spectrum == nullptr && !ba.mpf32 && (long)So_ * 4 >= n_cus_;
+    if (rec_istft) {
+        ba.rec_istft = 1;
+        ba.rec_y = d_yraw_; ba.rec_tail_in = d_tail_[tail_cur_]; ba.rec_tail_out = d_tail_[tail_cur_ ^ 1];
+        ba.rec_tw_w64 = d_tw_w64_; ba.rec_win = d_win_;
+    }
     bool fused = false;
     if (try_fused) {
         const hipError_t fe = ks_->stft_bins(sa, ba, n_cus_, stream);
@@ -473,7 +481,7 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     ia.frames = d_frames_;
     ia.post_amp = (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS) ? cfg_.out_amp : 1.0;
     ia.use_post_amp = (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS) ? 1 : 0;
-    PIPE_HIP(ks_->istft(ia, n_cus_, stream));
+    if (!rec_istft) PIPE_HIP(ks_->istft(ia, n_cus_, stream));
     tail_cur_ ^= 1;
 
     if (cfg_.algo == BF_PHASEMPF)

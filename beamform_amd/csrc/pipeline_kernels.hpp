@@ -80,6 +80,14 @@ struct BinsArgs {
     unsigned long long gss_reset_mask;  // bit d: look direction d re-initialises W = C^H (gss.cpp:90-93) in this batch
     int z48;             // mvdr / lcmv: Z holds z48 elements (the default); 0 = full f64x2 spectra (BF_Z48=0: parity debugging on
                          // ill-conditioned scenes; only the group-per-problem kernel reads them)
+    // phasempf with many streams (N = 1024, default precision, no dump): the recursion kernel runs the backward transform too
+    // (mpf_rec_istft_kernel: one block per output stream; y_fft rows never reach HBM).  Set by the pipeline, which then skips its ISTFT launch.
+    int rec_istft = 0;
+    float *rec_y = nullptr;               // [stream][n_frames * hop]
+    const float *rec_tail_in = nullptr;   // [stream][hop]
+    float *rec_tail_out = nullptr;
+    const f64x2 *rec_tw_w64 = nullptr;    // twiddle_table_w64_rot
+    const double *rec_win = nullptr;
     int mpf32;           // phasempf in front of the fp32 backward transform: the recursion leaves y_fft as f32x2 rows in the slots of its
                          // |out_int|^2 input (8 bytes each, same [stream][frame][kYhStride] layout, behind the f64x2 rows)
 };

@@ -147,19 +147,7 @@ __global__ __launch_bounds__(256) void stft_kernel(StftArgs a) {
 // lane l holds bin l + 64 g + 256 k3 (w64_bin): k3 < 2 reads row[l + 64 g + 256 k3], k3 >= 2 the conjugate of row[(64 - l) + 64 (3 - g) +
 // 256 (3 - k3)]: 1 KiB per wave-instruction either way.  util.h:244-253, 301-302.  0.157 ms per 65 536 frames (round 4's half-wavefront
 // kernel, one 32 x 32 transform per 32 lanes at one wavefront per SIMD: 0.55; the fp32 istft32_kernel below: 0.148).
-// |x| as an unsigned integer that orders like the magnitude (high word without the sign; NaN / Inf >= 0x7FF00000)
-__device__ __forceinline__ unsigned hi_abs(double x) { return (unsigned)((unsigned long long)__double_as_longlong(x) >> 32) & 0x7fffffffu; }
-// the largest value over the 64 lanes, in every lane (prefix maxima along the rows by DPP, lane 15 of each row to the next rows, lane 63)
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true));  // row_shr:1
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true));  // row_shr:2
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true));  // row_shr:4
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true));  // row_shr:8
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true));  // row_bcast:15 into rows 1 and 3
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true));  // row_bcast:31 into rows 2 and 3
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-
+// (hi_abs / wave_max_u32: w64_f64_dev.hpp)
 constexpr int kIw64Block = 256;
 constexpr int kIw64Waves = kIw64Block / 64;
 constexpr int kIw64TwD = 2 * (960 + 4 * kTw2RowW64Rot);  // tw1 rows k1 = 1..15 + tw2' (a.tw_w64 + 64), in doubles

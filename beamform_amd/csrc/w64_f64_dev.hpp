@@ -119,6 +119,21 @@ __device__ __forceinline__ void T1_inv(double (&re)[16], double (&im)[16], doubl
     __builtin_amdgcn_wave_barrier();
 }
 
+// ---- frame-pairing test of the backward transforms (istft_w64_kernel, mpf_rec_istft_kernel) ---------------------------------------
+// |x| as an unsigned integer that orders like the magnitude (high word without the sign; NaN / Inf >= 0x7FF00000)
+__device__ __forceinline__ unsigned hi_abs(double x) { return (unsigned)((unsigned long long)__double_as_longlong(x) >> 32) & 0x7fffffffu; }
+// the largest value over the 64 lanes, in every lane (prefix maxima along the rows by DPP, lane 15 of each row to the next rows, lane 63)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true));  // row_shr:1
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true));  // row_shr:2
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true));  // row_shr:4
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true));  // row_shr:8
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true));  // row_bcast:15 into rows 1 and 3
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true));  // row_bcast:31 into rows 2 and 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+
 // ---- staged twiddle / gain access ------------------------------------------------------------------------------------------
 // The per-lane passes of fft1024_w64.hpp fetch each twiddle right where it is multiplied in; at 256 registers hipcc then keeps one or
 // two ds_read_b128 in flight and every fourth instruction waits a full LDS round trip (36 % of the wave cycles in s_waitcnt,

@@ -319,6 +319,36 @@ def test_multi_stream_phasempf_config4_shape():
         check(y[s], Y[s], y_ref, Y_ref)
 
 
+@pytest.mark.parametrize("M,F,cuts,over", [(8, 23, (0, 23), {}), (8, 23, (0, 1, 3, 8, 9, 23), {}), (4, 6, (0, 2, 6), dict(mcra_L=3)), (3, 1, (0, 1), {}),
+                                           (8, 13, (0, 5, 13), dict(smooth_size=7, out_only_mcra=1))])
+def test_phasempf_many_streams_recursion_and_backward_transform_in_one_kernel(M, F, cuts, over):
+    """From a quarter as many streams as CUs on, phasempf's recursion kernel runs the backward transform too (mpf_rec_istft_kernel: a block
+    per stream, batches of four frames through LDS, two transform wavefronts beside the recursion's).  64 streams in uneven batch cuts --
+    1, 2, 3, 5 frames: every partial-batch shape; carried recursion state, overlap-add tail and smoothing ring between the calls -- against
+    the oracle per stream, and bit for bit against the same stream through the two-kernel path (one stream alone)."""
+    import oracle
+    from beamform_amd.capi import launch_trace
+    from conftest import Beamformer
+    _torch()
+    S = 64
+    p = make_params("phasempf", n_mics=M, theta=20.0, **over)
+    xs = np.stack([make_scene(M, F, seed=6100 + 3 * s + M) for s in range(S)])
+    bf = Beamformer(p, n_streams=S)
+    parts = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        with launch_trace() as tr:
+            parts.append(bf.process(np.ascontiguousarray(xs[:, :, a * 512:b * 512])).reshape(S, -1))
+        assert any("mpf_rec_istft_kernel" in k for k in tr.kernels) and not any("istft_w64_kernel" in k for k in tr.kernels), tr.kernels
+    y = np.concatenate(parts, axis=1)
+    for s in (0, 1, 31, S - 1):
+        y_ref, _ = oracle.OracleNode(p).process(xs[s])
+        assert np.array_equal(y[s], y_ref), (s, rel_l2(y[s], y_ref))   # default precision: the float output is the oracle's
+        with launch_trace() as tr:
+            one = Beamformer(p).process(xs[s])
+        assert any("mpf_recursion_kernel" in k for k in tr.kernels)
+        assert np.array_equal(one, y[s])
+
+
 @pytest.mark.parametrize("M,interf,hop", [(8, (-60.0, 90.0), 512), (7, (150.0,), 512), (4, (), 512), (2, (90.0,), 512),
                                           (6, (-60.0, 90.0, 150.0), 128), (3, (), 2048)])
 def test_gss_many_streams_one_lane_per_problem(M, interf, hop):
