@@ -147,6 +147,17 @@ def cpu_baseline_all_cores(algo: str, n_mics: int, frames_per_core: int):
                       f"{wall:.1f} s wall incl. pool start-up and scene synthesis"}
 
 
+def git_head():
+    """The tree this line was measured on: BF_GIT_HEAD (the GPU box has no .git: the job script exports it) or `git rev-parse`."""
+    h = os.environ.get("BF_GIT_HEAD")
+    if h:
+        return h
+    try:
+        return subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
 def norm_kernel_name(n: str) -> str:
     """A kernel name as bf_trace_end spells it, from rocprofv3's spelling (possibly truncated): no 'void ', no parameter list, no
     anonymous namespaces, no 'bf::'."""
@@ -444,7 +455,7 @@ def main():
                        "parallelism": (f"frame-sharded x{world} (shard.plan: halo recomputed locally, no data-path collective)"
                                        if sharded else f"independent batches x{world}"),
                        "input": "uniform noise in [-0.5, 0.5) (counter-based global stream)" if sharded else "uniform noise in [-0.5, 0.5)",
-                       "settle_launches_before_warmup": settle_launches},
+                       "settle_launches_before_warmup": settle_launches, "git_head": git_head()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          # PMC traffic exists for the profiled workloads only (profiles/traffic_<tag>.json), and only while the

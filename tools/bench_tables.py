@@ -72,18 +72,24 @@ def extra_ms_from_tail(tail):
 
 
 def builder_lines(round_no):
-    """bench.py lines of this round's own runs (profiles/rNN_*bench*.json; the profiled ones run under rocprofv3 and are left out)"""
-    lines = []
+    """bench.py lines of this round's own runs of ONE tree (profiles/rNN_*bench*.json; the profiled ones run under rocprofv3 and are left
+    out): the files of the newest tag (rNN_<letter>) and every other file whose line carries the same config.git_head (other boxes)"""
+    found = []
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r{round_no:02d}_*bench*.json"))):
         if "profiled" in f:
             continue
         try:
             txt = [ln for ln in open(f).read().splitlines() if ln.startswith("{")]
             if txt:
-                lines.append(json.loads(txt[-1]))
+                m = re.match(r"(r\d+_[a-z]+)_", os.path.basename(f))
+                found.append((m.group(1) if m else "", json.loads(txt[-1])))
         except (ValueError, OSError):
             pass
-    return lines
+    if not found:
+        return []
+    newest = max(t for t, _ in found)
+    heads = {(d.get("config") or {}).get("git_head") for t, d in found if t == newest} - {None}
+    return [d for t, d in found if t == newest or (d.get("config") or {}).get("git_head") in heads]
 
 
 def rng(vals, fmt):
