@@ -510,6 +510,29 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
     // the backward transform starts (re / im are dead then: registers to spare) and are there when it ends.
     float q0[8], q1[8], q2[8];
     const double inv_m = 1.0 / (double)M;
+    // Microphones with IDENTICAL weight rows share a transform (the reference drops z -- util.h:82-92 -- so microphones 1 and 7 of its aira16
+    // array, beamform_config.yaml:21,27, have the same delays for every look direction): sum_m conj(w_m) X_m takes conj(w) FFT(h (x_a + x_b))
+    // for such a pair, x_a + x_b formed in double (exact).  The host puts ONE such pair into slot 0 (DasF64Args::slot_mic, extra_mic): the
+    // second microphone's three hops travel beside the first one's while the previous pair's backward transform runs (re / im dead).
+    float e0[8], e1[8], e2[8];
+    const int NT = a.n_tr, XM = a.extra_mic;
+    // (called on every path, `on` false = zeros: a conditional definition would keep the 24 registers live through the forward transforms)
+    auto request_extra = [&](bool on, int stream, long tA) {
+        if (!on) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e0[j] = e1[j] = e2[j] = 0.f;
+            return;
+        }
+        const float *h1 = a.x + (long)stream * a.stream_stride_x + (long)XM * a.mic_stride + tA * kHop;
+        const float *h0 = tA >= 1 ? h1 - kHop : a.hist + ((long)stream * M + XM) * kHop;
+        const float *h2 = tA + 1 < a.n_frames ? h1 + kHop : h1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            e0[j] = h0[(unsigned)(64 * j + lane)];
+            e1[j] = h1[(unsigned)(64 * j + lane)];
+            e2[j] = h2[(unsigned)(64 * j + lane)];
+        }
+    };
 
     BF_STAMP(0);
 #ifdef BF_W64_STAMPS
@@ -523,14 +546,22 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
     cur.pos = w;
     cur.u = (unsigned)w;
     cur.have = w < n_static;
-    if (cur.have) request_pair_mic(cur.d.x, cur.d.y + 2L * w, 1);
+    if (cur.have) {
+        request_pair_mic(cur.d.x, cur.d.y + 2L * w, a.slot_mic[0]);
+        request_extra(XM >= 0, cur.d.x, cur.d.y + 2L * w);
+    } else {
+        request_extra(false, 0, 0);
+    }
     {
-        const f64x2 *tw2 = a.tw + 64, *g2 = a.gains_mic + kGMic;  // gains of microphones 1 .. M - 1
+        const f64x2 *tw2 = a.tw + 64;
         f64x2 *ltw = reinterpret_cast<f64x2 *>(lds + pTw), *lg = reinterpret_cast<f64x2 *>(lds + pGain);
 #pragma unroll 4
         for (int i = tid; i < kTwP / 2; i += kBlock) ltw[i] = tw2[i];
-#pragma unroll 8
-        for (int i = tid; i < (M - 1) * kGMic; i += kBlock) lg[i] = g2[i];
+        for (int k = 0; k < NT; ++k) {  // the gains of slot k's microphone (microphone 0 has none: below)
+            const f64x2 *g2 = a.gains_mic + a.slot_mic[k] * kGMic;
+#pragma unroll 2
+            for (int i = tid; i < kGMic; i += kBlock) lg[k * kGMic + i] = g2[i];
+        }
 #pragma unroll 2
         for (int i = tid; i < 1024; i += kBlock) lds[pWin + (i & 63) * kWinRow + (i >> 6)] = a.win[i];
         if (tid < kSlots) s_state[tid] = 0;
@@ -542,7 +573,10 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
     int it = 0;  // pairs this wavefront has done (debug stamps)
     if (!cur.have) {
         cur = draw_pair(s_work, sc, lane);
-        if (cur.have) request_pair_mic(cur.d.x, cur.d.y + 2L * cur.pos, 1);
+        if (cur.have) {
+            request_pair_mic(cur.d.x, cur.d.y + 2L * cur.pos, a.slot_mic[0]);
+            request_extra(XM >= 0, cur.d.x, cur.d.y + 2L * cur.pos);
+        }
     }
     while (cur.have) {  // wavefront-uniform; no block barrier below
         const int stream = cur.d.x;
@@ -558,15 +592,14 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
         // hop tA of the microphone whose loads are in flight (request_pair_mic asked for microphone 1 of this pair); the carried hop
         // stands in for hop -1, the last frame of a stream has no hop behind it
         const float *hp0 = a.x + (long)stream * a.stream_stride_x + tA * kHop;  // microphone 0's
-        const float *hp = hp0 + a.mic_stride;
         const float *hist0 = a.hist + (long)stream * M * kHop;
         const bool first_hop = tA < 1, last_hop = !(tA + 1 < a.n_frames);
-        (void)hp; (void)hp0; (void)hist0; (void)first_hop; (void)last_hop;
+        (void)hp0; (void)hist0; (void)first_hop; (void)last_hop;
 
         double Sr[16], Si[16];
         // one microphone: forward transform of (frame tA, frame tA + 1) and S += ce_m Z_m.  Instantiated twice (FIRST: the microphone
         // that starts the sum with a multiplication): a run-time test per accumulator cost 32 scalar branches per microphone
-        auto one_mic = [&](const int m, auto first_tag) {
+        auto one_mic = [&](const int k, auto first_tag) {  // slot k of the pair
             constexpr bool FIRST = decltype(first_tag)::value;
             double re[16], im[16];
 #ifndef BF_PAIR_NO_VMWAIT
@@ -576,16 +609,30 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
 #endif
             // buf[j]*hann_win[i] (util.h:235) and the first butterfly stage in one (see the kernel above); hop tA is the second half of
             // frame tA and the first half of frame tA + 1
+            if (FIRST && XM >= 0) {  // slot 0 carries two microphones with the same weight row: their samples are added in double (exact) in front of the window
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const double w0 = wrow[j], w1 = wrow[j + 8];
-                const double c = (double)n1[j];
-                const double t = (double)n0[j] * w0;
-                re[j] = fma(c, w1, t);
-                re[j + 8] = fma(-c, w1, t);
-                const double t2 = c * w0, u2 = (double)n2[j];
-                im[j] = fma(u2, w1, t2);
-                im[j + 8] = fma(-u2, w1, t2);
+                for (int j = 0; j < 8; ++j) {
+                    const double w0 = wrow[j], w1 = wrow[j + 8];
+                    const double c = (double)n1[j] + (double)e1[j];
+                    const double t = ((double)n0[j] + (double)e0[j]) * w0;
+                    re[j] = fma(c, w1, t);
+                    re[j + 8] = fma(-c, w1, t);
+                    const double t2 = c * w0, u2 = (double)n2[j] + (double)e2[j];
+                    im[j] = fma(u2, w1, t2);
+                    im[j + 8] = fma(-u2, w1, t2);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double w0 = wrow[j], w1 = wrow[j + 8];
+                    const double c = (double)n1[j];
+                    const double t = (double)n0[j] * w0;
+                    re[j] = fma(c, w1, t);
+                    re[j + 8] = fma(-c, w1, t);
+                    const double t2 = c * w0, u2 = (double)n2[j];
+                    im[j] = fma(u2, w1, t2);
+                    im[j + 8] = fma(-u2, w1, t2);
+                }
             }
             if (__builtin_expect(!pair, 0)) {  // a wavefront-uniform BRANCH (the asm keeps hipcc from turning it into 32 v_cndmask per microphone)
 #ifndef BF_PAIR_CNDMASK
@@ -595,18 +642,12 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
                 for (int j = 0; j < 16; ++j) im[j] = 0.0;
             }
             // the next microphone, or the first one of this wavefront's next pair (none left: this pair's first again, unused)
-            if (m + 1 < M) {
-#ifdef BF_PAIR_PTR_MUL
-                request_pair_mic(stream, tA, m + 1);
-#else
-                // the next microphone's hop tA is one mic_stride further (a running pointer: two scalar adds instead of the 64-bit products)
-                hp += a.mic_stride;
-                request(first_hop ? hist0 + (m + 1) * kHop : hp - kHop, hp, last_hop ? hp : hp + kHop);
-#endif
+            if (k + 1 < NT) {
+                request_pair_mic(stream, tA, a.slot_mic[k + 1]);
             } else {
                 nxt = draw_pair(s_work, sc, lane);
-                if (nxt.have) request_pair_mic(nxt.d.x, nxt.d.y + 2L * nxt.pos, 1);
-                else request_pair_mic(stream, tA, 1);
+                if (nxt.have) request_pair_mic(nxt.d.x, nxt.d.y + 2L * nxt.pos, a.slot_mic[0]);
+                else request_pair_mic(stream, tA, a.slot_mic[0]);
             }
             cx<double> tw[15];
             BF_STAGE();
@@ -633,8 +674,8 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
             BF_STAGE();
             w64_T2_any<true>(re, im, row16 - 16 * (lane >> 4), lane >> 4);
             cxa g[16];
-            const lds_gain_t gd = (lds_gain_t)(size_t)(gd0 + (unsigned)((m - 1) * kGMic * 16));  // k3 < 2: row (g, k3), column lane
-            const lds_gain_t gm = (lds_gain_t)(size_t)((g_mirror + (unsigned)(2 * (m - 1) * kGMic * 16)) - (gd0 + (unsigned)((m - 1) * kGMic * 16)));  // k3 >= 2: row (3 - g, 3 - k3), column 64 - lane, conjugated
+            const lds_gain_t gd = (lds_gain_t)(size_t)(gd0 + (unsigned)(k * kGMic * 16));  // k3 < 2: row (g, k3), column lane
+            const lds_gain_t gm = (lds_gain_t)(size_t)((g_mirror + (unsigned)(2 * k * kGMic * 16)) - (gd0 + (unsigned)(k * kGMic * 16)));  // k3 >= 2: row (3 - g, 3 - k3), column 64 - lane, conjugated
             BF_STAGE();
 #pragma unroll
             for (int r = 0; r < 8; ++r)
@@ -659,8 +700,8 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
                 }
             }
         };
-        one_mic(1, std::true_type{});
-        for (int m = 2; m < M; ++m) one_mic(m, std::false_type{});
+        one_mic(0, std::true_type{});
+        for (int k = 1; k < NT; ++k) one_mic(k, std::false_type{});
         float *yo = ys + tA * kHop;
         cx<double> tw[15];
         BF_STAGE();
@@ -672,6 +713,7 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
                 q1[j] = hp0[(unsigned)(64 * j + lane)];
                 q2[j] = h2[(unsigned)(64 * j + lane)];
             }
+            request_extra(XM >= 0 && nxt.have, nxt.d.x, nxt.d.y + 2L * nxt.pos);  // ... and the next pair's second slot-0 microphone
         }
         BF_STAGE();
         load_tw2<1, 16>(tw, s_tw2, lane);
@@ -855,7 +897,7 @@ __global__ void das_f64_sched_kernel(DasSchedPlan p, int4 *chunks, unsigned *cou
 // (the frame-pair kernel never transforms microphone 0: it needs the reference's unit weight row there -- das.cpp:33-38, always true for das
 // on a handle that started cold -- and a second microphone; anything else goes through the chain)
 static bool use_pair_kernel(const DasF64Args &a) {
-    return a.layout == 0 && a.gains_mic != nullptr && a.sched_ws != nullptr && a.mic0_unit != 0 && a.n_mics >= 2;
+    return a.layout == 0 && a.gains_mic != nullptr && a.sched_ws != nullptr && a.mic0_unit != 0 && a.n_mics >= 2 && a.n_tr >= 1;
 }
 
 bool das_f64_writes_hist(const DasF64Args &a) { return use_pair_kernel(a) && a.hist_out != nullptr; }

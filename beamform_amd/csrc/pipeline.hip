@@ -171,6 +171,23 @@ class BinPipelineImpl : public BinPipeline {
             bool unit = true;  // das.cpp:33-38 writes weights(0, j) = 1 once; only then may the pair kernel skip microphone 0's transform
             for (int j = 0; j < N_ && unit; ++j) unit = dirs[0].at(j, 0, 0) == cplxd(1.0, 0.0);
             das_mic0_unit_[nxt] = unit;
+            // Microphones 1 .. M - 1 whose weight rows are bitwise identical (same delay: the reference drops z, util.h:82-92, so e.g. aira16's
+            // microphones 1 and 7 -- beamform_config.yaml:21,27 -- coincide for every look direction) share a forward transform in
+            // das_f64_pair_kernel: the first such pair goes into slot 0, the other microphones follow in ascending order.
+            DasSlots sl;
+            int pa = -1, pb = -1;
+            for (int m1 = 1; m1 < M_ && pa < 0; ++m1)
+                for (int m2 = m1 + 1; m2 < M_ && pa < 0; ++m2) {
+                    bool same = true;
+                    for (int j = 0; j < N_ && same; ++j) same = dirs[0].at(j, m1, 0) == dirs[0].at(j, m2, 0);
+                    if (same) { pa = m1; pb = m2; }
+                }
+            sl.n_tr = 0;
+            if (pa >= 0) sl.slot_mic[sl.n_tr++] = pa;
+            for (int m = 1; m < M_; ++m)
+                if (m != pa && m != pb) sl.slot_mic[sl.n_tr++] = m;
+            sl.extra_mic = pb;
+            das_slots_[nxt] = sl;
         }
         PIPE_HIP(hipMemcpyAsync(d_steer_[nxt], t.data(), t.size() * sizeof(f64x2), hipMemcpyHostToDevice, stream));
         PIPE_HIP(hipStreamSynchronize(stream));  // `t` is pageable and about to go out of scope
@@ -194,6 +211,7 @@ class BinPipelineImpl : public BinPipeline {
         sn.das_gains_w64 = d_dasg_w64_[steer_cur_];
         sn.das_gains_mic = d_dasg_mic_[steer_cur_];
         sn.das_mic0_unit = das_mic0_unit_[steer_cur_];
+        sn.das_slots = das_slots_[steer_cur_];
         gss_reset_mask_ = 0;
         return sn;
     }
@@ -278,6 +296,7 @@ class BinPipelineImpl : public BinPipeline {
     void *d_das_sched_ = nullptr;                // das_f64_pair_kernel: chunk table + counter (das_f64_sched_ws_bytes())
     f64x2 *d_dasg_mic_[2] = {nullptr, nullptr};  // das_mic_gains_w64_f64 (frame-pair kernel)
     bool das_mic0_unit_[2] = {false, false};     // ... and whether microphone 0's weight row in that table is identically 1
+    DasSlots das_slots_[2];                      // ... and which microphones get a forward transform in which order (identical rows merged)
     int steer_cur_ = 0;
     float *d_hist2_[2] = {nullptr, nullptr};  // ring hop in front of the next batch; two buffers: das_f64_pair_kernel writes the carry itself
     int hist_cur_ = 0;
@@ -316,6 +335,8 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
         da.layout = layout;
         da.gains = snap.das_gains_w64; da.gains_mic = snap.das_gains_mic; da.tw = d_tw_w64_;
         da.mic0_unit = snap.das_mic0_unit ? 1 : 0;
+        da.n_tr = snap.das_slots.n_tr; da.extra_mic = snap.das_slots.extra_mic;
+        for (int k = 0; k < 8; ++k) da.slot_mic[k] = snap.das_slots.slot_mic[k];
         da.sched_ws = d_das_sched_; da.sched_ws_bytes = d_das_sched_ ? das_f64_sched_ws_bytes() : 0;
         hipError_t de = prepare_das_f64_w64(da, n_cus_, stream);
         if (de == hipSuccess) {

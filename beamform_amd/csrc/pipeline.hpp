@@ -18,12 +18,19 @@ namespace bf {
 // taken under the handle's mutex right after the table upload, so a batch sees ONE consistent
 // {column count, steering table, pending demixing resets} (the reference guards the same window with READY=false
 // plus a sleep, lcmv.cpp:262-307).
+// das_f64_pair_kernel's walk over the microphones (pipeline_kernels.hpp DasF64Args::slot_mic / extra_mic)
+struct DasSlots {
+    int n_tr = 0, extra_mic = -1;
+    int slot_mic[8] = {1, 2, 3, 4, 5, 6, 7, 0};
+};
+
 struct RunSnapshot {
     int kp1 = 1;
     unsigned long long gss_reset_mask = 0;
     const f64x2 *steer = nullptr;
     long steer_dir_stride = 0;
     const f64x2 *das_gains_mic = nullptr;  // per-microphone Hermitian gains of the frame-pair kernel (das_f64_pair_kernel)
+    DasSlots das_slots;
     bool das_mic0_unit = false;            // row 0 of the das weights is identically 1 in that table (das.cpp:33-38; quirk Q3 can leave it 0)
     const f64x2 *das_gains_w64 = nullptr;  // the same gains in the register / lane order of the 64-lane kernel (das_f64_w64.hip)
 };

@@ -123,6 +123,11 @@ struct DasF64Args {
     int layout = 0;        // bf_layout of x and hist; 1 (interleaved) only with launch_das_f64_w64
     float *hist_out = nullptr;         // das_f64_pair_kernel: receives the last hop of the batch (the ring-buffer carry), layout as hist
     const f64x2 *gains_mic = nullptr;  // das_mic_gains_w64_f64: per-microphone Hermitian gains of the frame-pair kernel (planar input)
+    // das_f64_pair_kernel: the microphones that get a forward transform, in the order the kernel walks them (slot k -> microphone slot_mic[k],
+    // never microphone 0), and at most one more microphone whose weight row is bitwise identical to slot 0's (extra_mic, -1 = none): it
+    // shares slot 0's transform (das.cpp:60-63 is linear in the microphones; the reference drops z, so aira16's microphones 1 and 7 coincide)
+    int n_tr = 0, extra_mic = -1;
+    int slot_mic[8] = {1, 2, 3, 4, 5, 6, 7, 0};
     int mic0_unit = 0;                 // the weight row of microphone 0 is identically 1 (das.cpp:33-38): das_f64_pair_kernel adds h x_0 / M in the time domain
     void *sched_ws = nullptr;          // das_f64_pair_kernel: device workspace of its work queue (das_f64_sched_ws_bytes())
     size_t sched_ws_bytes = 0;

@@ -335,6 +335,23 @@ def main():
     stream = torch.cuda.current_stream(dev)
     sptr = stream.cuda_stream
 
+    def identical_weight_rows(b):
+        """Groups of microphones (other than the reference microphone) whose weight rows are identical: they share a forward transform in
+        das_f64_pair_kernel.  The reference drops z (util.h:82-92), so microphones 1 and 7 of its aira16 array (beamform_config.yaml:21,27)
+        -- the first 8 of which are this benchmark's geometry since round 1 -- have the same delay for every look direction."""
+        import numpy as np
+        w = b.weights()[:, :, 0]
+        groups, seen = [], set()
+        for m1 in range(1, w.shape[1]):
+            if m1 in seen:
+                continue
+            g = [m1] + [m2 for m2 in range(m1 + 1, w.shape[1]) if np.array_equal(w[:, m1], w[:, m2])]
+            if len(g) > 1:
+                groups.append(g)
+                seen.update(g)
+        return groups
+    dup_rows = identical_weight_rows(bf) if args.algo == "das" else []
+
     # ---- what this rank processes ------------------------------------------------------------------------------
     sharded = use_dist and not args.independent
     sh = None
@@ -455,7 +472,11 @@ def main():
                        "parallelism": (f"frame-sharded x{world} (shard.plan: halo recomputed locally, no data-path collective)"
                                        if sharded else f"independent batches x{world}"),
                        "input": "uniform noise in [-0.5, 0.5) (counter-based global stream)" if sharded else "uniform noise in [-0.5, 0.5)",
-                       "settle_launches_before_warmup": settle_launches, "git_head": git_head()},
+                       "settle_launches_before_warmup": settle_launches, "git_head": git_head(),
+                       "geometry": (f"the first {M} microphones of the reference's aira16 array (beamform_config.yaml:20-35), z dropped as util.h:82-92 does"
+                                    if M <= 16 else "explicit"),
+                       "microphones_with_identical_weight_rows": dup_rows,
+                       "forward_transforms_per_frame_pair": ((M - 1 - (1 if dup_rows else 0)) if (args.algo == "das" and das_impl == BF_DAS_F64 and args.layout == "planar") else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          # PMC traffic exists for the profiled workloads only (profiles/traffic_<tag>.json), and only while the
@@ -537,9 +558,17 @@ def main():
         np.save(args.dump_gathered, np.concatenate([last_gather["parts"][r][: owns[r] * HOP].cpu().numpy() for r in range(world)]))
 
     # ---- secondary lines: the other BASELINE configs, rank 0 at N = 1 -------------------------------------------
+    def distinct_mics(M_):
+        from beamform_amd.params import AIRA16_XY
+        out = []
+        for xy in AIRA16_XY:
+            if xy not in out:
+                out.append(xy)
+        return out[:M_] if len(out) >= M_ else None
+
     def node_line(algo, M_, F_, S_, interf_=(), das_impl_=BF_DAS_FUSED_F32, iters=5, xin=None, note="", layout_=BF_PLANAR,
-                  with_traffic=True, roofline_kernel=None, traffic_tag=None, precision_=BF_PRECISION_REFERENCE):
-        pm = make_params(algo, n_mics=M_, interf=interf_)
+                  with_traffic=True, roofline_kernel=None, traffic_tag=None, precision_=BF_PRECISION_REFERENCE, mics_=None):
+        pm = make_params(algo, n_mics=M_, interf=interf_, **({"mics": mics_} if mics_ else {}))
         bm = Beamformer(pm, device=local_rank, n_streams=S_, das_impl=das_impl_, layout=layout_, precision=precision_)
         if xin is None:
             gg = torch.Generator(device=dev).manual_seed(4321)
@@ -612,6 +641,12 @@ def main():
              if das_impl == BF_DAS_F64 else
              (lambda: node_line("das", M, F, 1, das_impl_=BF_DAS_F64, xin=x, iters=20, roofline_kernel="das_f64_pair_kernel", traffic_tag="das8_f64",
                                 note="same precision as the reference: das_f64_pair_kernel, one launch"))),
+            ("das_f64_distinct_rows", lambda: node_line("das", M, F, 1, das_impl_=BF_DAS_F64, xin=x, iters=20, roofline_kernel="das_f64_pair_kernel",
+                                                        with_traffic=False, mics_=distinct_mics(M),
+                                                        note="the headline batch on a geometry WITHOUT coinciding microphones (aira16's microphone 7 "
+                                                             "replaced by its microphone 8): every microphone but the reference one gets its own forward "
+                                                             "transform: 4.0 transforms per frame where the headline geometry (microphones 1 and 7 share "
+                                                             "x, y and so their weight row) needs 3.5")),
             ("das_interleaved", lambda: node_line("das", M, F, 1, xin=x.reshape(1, F * HOP, M), layout_=BF_INTERLEAVED, iters=20,
                                                   note="the headline workload with [sample][mic] input (same bytes read as interleaved samples), fused fp32 kernel")),
             ("das_f64_interleaved", lambda: node_line("das", M, F, 1, das_impl_=BF_DAS_F64, xin=x.reshape(1, F * HOP, M), layout_=BF_INTERLEAVED,

@@ -110,6 +110,57 @@ def same_floats(a, b):
     return a.shape == b.shape and np.abs(a - b).max() <= 4e-7 * max(np.abs(b).max(), 1e-30)
 
 
+GEOMETRIES = {
+    # name: (x, y) per microphone.  The reference drops z (util.h:82-92): microphones 1 and 7 of its aira16 array (beamform_config.yaml:21,27)
+    # share x, y and therefore their weight row for every look direction -- the first case is make_params' default 8-microphone geometry
+    "aira16-first-8 (1 = 7)": None,
+    "all distinct": [(0.158, 0.115), (0.158, -0.115), (-0.045, 0.0), (-0.05, -0.188), (-0.195, 0.0), (-0.057, 0.186), (0.18, 0.0), (0.056, -0.171)],
+    "2 = 3 and 5 = 6 (one pair is merged, the other is not)": [(0.0, 0.0), (0.1, 0.02), (-0.05, 0.12), (-0.05, 0.12), (0.07, -0.11), (0.13, 0.09), (0.13, 0.09), (-0.2, 0.0)],
+    "1 = 2 = 3": [(0.0, 0.0), (0.1, 0.1), (0.1, 0.1), (0.1, 0.1), (-0.1, 0.05)],
+    "three microphones, 1 = 2": [(0.0, 0.0), (0.0, -0.18), (0.0, -0.18)],
+    "co-located (every row is 1)": [(0.0, 0.0)] * 6,
+    "symmetric about the look direction (theta = 0: y -> -y)": [(0.0, 0.0), (0.1, 0.07), (0.1, -0.07), (-0.12, 0.03), (-0.12, -0.03), (0.2, 0.0)],
+}
+
+
+@pytest.mark.parametrize("geo", list(GEOMETRIES))
+def test_das_f64_microphones_with_identical_weight_rows_share_a_transform(geo):
+    """das_f64_pair_kernel puts the first two microphones (other than the reference microphone) whose weight rows are bitwise identical into
+    one forward transform: conj(w) FFT(h (x_a + x_b)), the sum formed in double.  Geometries with one such pair, several, a triple, none,
+    rows that become identical only for the steered angle, and a re-steer that separates them again -- float output against the oracle
+    (bit for bit: the sums differ from the reference's at 1e-16) and a cut stream."""
+    import oracle
+    from beamform_amd.capi import BF_DAS_F64, Beamformer, launch_trace
+    mics = GEOMETRIES[geo]
+    M = 8 if mics is None else len(mics)
+    F = 21
+    theta = 0.0 if "symmetric" in geo else 35.0
+    p = make_params("das", n_mics=M, theta=theta, **({} if mics is None else {"mics": mics}))
+    x = make_scene(M, F, seed=3300 + M, mics=p["mics"])
+    node = oracle.OracleNode(p)
+    bf = Beamformer(p, das_impl=BF_DAS_F64)
+    w = bf.weights()[:, :, 0]
+    dup = any(np.array_equal(w[:, a], w[:, b]) for a in range(1, M) for b in range(a + 1, M))
+    assert dup == ("distinct" not in geo), geo
+    with launch_trace() as tr:
+        y1 = bf.process(np.ascontiguousarray(x[:, :9 * 512]))
+    assert any("das_f64_pair_kernel" in k for k in tr.kernels), tr.kernels
+    r1 = node.process(np.ascontiguousarray(x[:, :9 * 512]))[0]
+    # a new look direction between the batches: rows that coincided for the old angle may differ now (and the other way round)
+    bf.set_theta(-70.0)
+    node.set_theta(-70.0)
+    y2 = bf.process(np.ascontiguousarray(x[:, 9 * 512:]))
+    r2 = node.process(np.ascontiguousarray(x[:, 9 * 512:]))[0]
+    y, r = np.concatenate([y1, y2]), np.concatenate([r1, r2])
+    assert rel_l2(y, r) < 1e-6
+    # bit for bit wherever there is signal; where the output is the transforms' own rounding residue (silence: 1e-16 of the scene's scale)
+    # the two evaluation orders leave different residues
+    scale = float(np.abs(r).max())
+    loud = np.abs(r) > 1e-9 * scale
+    assert loud.mean() > 0.5 and np.array_equal(y[loud], r[loud]), float(np.abs(y.astype(np.float64) - r).max())
+    assert np.abs(y[~loud].astype(np.float64) - r[~loud]).max(initial=0.0) < 1e-12 * scale
+
+
 @pytest.mark.parametrize("M,F,S", [(8, 33, 1), (7, 5, 1), (5, 18, 2), (4, 27, 1), (3, 9, 3), (2, 40, 1), (1, 6, 1), (8, 1, 1), (6, 700, 1)])
 def test_das_f64_one_launch_matches_oracle(M, F, S):
     """das_f64_pair_kernel / das_f64_w64_kernel<1> (BF_DAS_F64 without a spectrum dump): the time output against the oracle, odd

@@ -21,6 +21,7 @@ BEGIN, END = "<!-- BENCH:BEGIN (tools/bench_tables.py: do not edit by hand) -->"
 
 # (key in extra.ms, what it is)
 ROWS = [
+    ("das_f64_distinct_rows", "[1] the headline batch on a geometry WITHOUT coinciding microphones (4.0 transforms per frame instead of 3.5)"),
     ("mvdr", "[2] mvdr 8-mic, 65 536 frames, the library default (c128 spectra, fp64 backward transform)"),
     ("mvdr_mixed", "[2] same, `BF_PRECISION_MIXED` (z48 spectra, fp32 backward transform)"),
     ("phasempf", "[3] phasempf 8-mic, 256 streams x 256 frames"),
