@@ -14,7 +14,8 @@ g = torch.Generator(device="cuda").manual_seed(21)
 x = torch.rand(M, F * 512, device="cuda", generator=g) - 0.5
 y = torch.empty(F * 512, device="cuda")
 y32 = torch.empty(F * 512, device="cuda")
-Beamformer(p).process_device(x.data_ptr(), F, y32.data_ptr())
+from beamform_amd.capi import BF_DAS_FUSED_F32
+Beamformer(p, das_impl=BF_DAS_FUSED_F32).process_device(x.data_ptr(), F, y32.data_ptr())
 torch.cuda.synchronize()
 n_bad = 0
 for rep in range(reps):
