@@ -891,6 +891,35 @@ __global__ void das_f64_sched_kernel(DasSchedPlan p, int4 *chunks, unsigned *cou
     }
 }
 
+// [sample][mic] -> planar, in front of das_f64_pair_kernel (round 6).  The pair kernel walks ONE microphone at a time, which on
+// [sample][mic] input makes every 128-byte line cross L2 -> L1 eight times (1.34 ms, EXPERIMENTS round 5); das_f64_w64_kernel<1> (two
+// microphones per transform, 5 transforms per frame, no microphone-0 / identical-row savings) takes 1.03 ms.  A plain transposition through
+// LDS -- 256 samples x M microphones per block, 16-byte accesses on both sides -- moves 2 x the input once (1.07 GB in, 1.07 GB out at
+// 8 microphones) and hands the pair kernel what it is fast on.  Tile rows are padded to M + 1 floats (bank conflicts of the gather).
+__global__ __launch_bounds__(256) void interleaved_to_planar_kernel(const float *x, float *out, long tiles_per_stream, int M, long in_stream_stride,
+                                                                    long out_mic_stride, long out_stream_stride) {
+    __shared__ float s_t[256 * 9];
+    const int tid = threadIdx.x;
+    const long s = blockIdx.x / tiles_per_stream, tile = blockIdx.x - s * tiles_per_stream;
+    const float4 *src = reinterpret_cast<const float4 *>(x + s * in_stream_stride + tile * 256 * M);
+    const int R = M + 1;
+    for (int i = tid; i < 64 * M; i += 256) {  // 256 M floats, 16 bytes per lane, contiguous
+        const float4 v = src[i];
+        const int e = 4 * i;
+        s_t[(e / M) * R + e % M] = v.x;
+        s_t[((e + 1) / M) * R + (e + 1) % M] = v.y;
+        s_t[((e + 2) / M) * R + (e + 2) % M] = v.z;
+        s_t[((e + 3) / M) * R + (e + 3) % M] = v.w;
+    }
+    __syncthreads();
+    float *dst = out + s * out_stream_stride + tile * 256;
+    for (int j = tid; j < 64 * M; j += 256) {  // per microphone 64 float4 = 256 consecutive samples
+        const int m = j >> 6, q = j & 63;
+        const float4 v{s_t[(4 * q) * R + m], s_t[(4 * q + 1) * R + m], s_t[(4 * q + 2) * R + m], s_t[(4 * q + 3) * R + m]};
+        reinterpret_cast<float4 *>(dst + (long)m * out_mic_stride)[q] = v;
+    }
+}
+
 }  // namespace
 
 // planar input: the frame-pair kernel; [sample][mic] input: the microphone-pair kernel
@@ -945,6 +974,14 @@ hipError_t prepare_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s) {
             if (e != hipSuccess) return e;
         }
     return hipSuccess;
+}
+
+// x = [stream][n][M] -> out = [stream][M][n] (n a multiple of 256 samples, M <= 8, both 16-byte aligned)
+hipError_t launch_interleaved_to_planar(const float *x, float *out, long n, int n_mics, int n_streams, hipStream_t s) {
+    if (n_mics < 1 || n_mics > 8 || (n & 255) != 0) return hipErrorNotSupported;
+    const long tiles = n / 256;
+    BF_LAUNCH(interleaved_to_planar_kernel, dim3((unsigned)(tiles * n_streams)), dim3(256), 0, s, x, out, tiles, n_mics, (long)n_mics * n, n, (long)n_mics * n);
+    return hipGetLastError();
 }
 
 hipError_t launch_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s) {

@@ -274,7 +274,7 @@ class BinPipelineImpl : public BinPipeline {
 
     void free_all() {
         void *ptrs[] = {d_dasg_w64_[0], d_dasg_w64_[1], d_dasg_mic_[0], d_dasg_mic_[1], d_das_sched_, d_tw_w64_, d_tw32_, d_tw_, d_win_, d_freq_, d_steer_[0], d_steer_[1], d_hist2_[0], d_hist2_[1], d_tail_[0], d_tail_[1], d_zhist_,
-                        d_gssW_, d_mpf_, d_smooth_, d_nlms_, d_Z_, d_Yh_, d_yraw_, d_frames_};
+                        d_gssW_, d_mpf_, d_smooth_, d_nlms_, d_Z_, d_Yh_, d_yraw_, d_frames_, d_planar_};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
     }
@@ -312,6 +312,7 @@ class BinPipelineImpl : public BinPipeline {
     f64x2 *d_Z_ = nullptr;   size_t Z_cap_ = 0;   // [stream][Phist+F][NP][1024]
     f64x2 *d_Yh_ = nullptr;  size_t Yh_cap_ = 0;  // [stream][F][kYhStride]
     float *d_yraw_ = nullptr; size_t yraw_cap_ = 0;
+    float *d_planar_ = nullptr; size_t planar_cap_ = 0;  // das in double on [sample][mic] input: the batch (+ carried hop) transposed for das_f64_pair_kernel
     float *d_frames_ = nullptr; size_t frames_cap_ = 0;  // N != 1024: windowed frames between the generic ISTFT and its overlap-add
 };
 
@@ -333,6 +334,22 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
         da.win = d_win_; da.n_frames = F; da.mic_stride = mic_stride;
         da.stream_stride_x = (long)M_ * F * H_; da.n_streams = S_; da.n_mics = M_; da.run_len = 1;
         da.layout = layout;
+        // [sample][mic] input: transposed into a planar scratch (batch + carried hop) in front of the frame-pair kernel, which then runs with its
+        // microphone-0 and identical-row savings (das_f64_w64.hip interleaved_to_planar_kernel); the carried hop stays in the handle's layout
+        if (layout == BF_INTERLEAVED && snap.das_mic0_unit && M_ >= 2 && snap.das_slots.n_tr >= 1 && d_das_sched_ != nullptr) {
+            const size_t nb = (size_t)S_ * M_ * F * H_, nh = (size_t)S_ * M_ * H_;
+            const int rc0 = ensure((void **)&d_planar_, &planar_cap_, (nb + nh) * sizeof(float));
+            if (rc0 != BF_OK) return rc0;
+            hipError_t te = launch_interleaved_to_planar(x, d_planar_, F * H_, M_, S_, stream);
+            if (te == hipSuccess) te = launch_interleaved_to_planar(d_hist2_[hist_cur_], d_planar_ + nb, H_, M_, S_, stream);
+            if (te == hipSuccess) {
+                da.x = d_planar_; da.hist = d_planar_ + nb; da.hist_out = nullptr; da.mic_stride = F * H_; da.layout = BF_PLANAR;
+            } else if (te != hipErrorNotSupported) {
+                PIPE_HIP(te);
+            } else {
+                (void)hipGetLastError();
+            }
+        }
         da.gains = snap.das_gains_w64; da.gains_mic = snap.das_gains_mic; da.tw = d_tw_w64_;
         da.mic0_unit = snap.das_mic0_unit ? 1 : 0;
         da.n_tr = snap.das_slots.n_tr; da.extra_mic = snap.das_slots.extra_mic;

@@ -139,6 +139,8 @@ struct DasF64Args {
 hipError_t prepare_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s);
 hipError_t launch_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s);
 size_t das_f64_sched_ws_bytes();
+// [stream][n][M] -> [stream][M][n] in front of the frame-pair kernel ([sample][mic] handles); n a multiple of 256, M <= 8
+hipError_t launch_interleaved_to_planar(const float *x, float *out, long n, int n_mics, int n_streams, hipStream_t s);
 bool das_f64_writes_hist(const DasF64Args &a);  // the kernel launch_das_f64_w64 picks stores a.hist_out itself (no copy behind it)
 
 #ifdef BF_NFFT

@@ -174,18 +174,27 @@ def test_das_f64_one_launch_matches_oracle(M, F, S):
     for s in range(S):
         y_ref, _ = oracle.OracleNode(p).process(xs[s])
         assert rel_l2(y[s], y_ref) < 1e-6       # double arithmetic up to the float stores: far inside the 1e-5 budget
-    # [sample][mic] input (the layout north_star names).  The planar kernel (das_f64_pair_kernel) transforms two consecutive frames of a
-    # microphone per complex FFT, the interleaved one (das_f64_w64_kernel<1>) two microphones of a frame: the same sums in double, rounded
-    # differently at 1e-16 -- equal up to the last bit of the float stores, not bit for bit
-    from beamform_amd.capi import BF_INTERLEAVED
+    # [sample][mic] input (the layout north_star names): transposed on the device into a planar scratch in front of the same kernel
+    # (interleaved_to_planar_kernel; one microphone: das_f64_w64_kernel<1>) -- the same bytes out as for planar input
+    from beamform_amd.capi import BF_INTERLEAVED, launch_trace
     xi = np.ascontiguousarray(xs.transpose(0, 2, 1))
-    yi = Beamformer(p, n_streams=S, das_impl=BF_DAS_F64, layout=BF_INTERLEAVED).process(xi if S > 1 else xi[0]).reshape(S, -1)
-    assert same_floats(yi, y)
+    bil = Beamformer(p, n_streams=S, das_impl=BF_DAS_F64, layout=BF_INTERLEAVED)
+    with launch_trace() as tr:
+        yi = bil.process(xi if S > 1 else xi[0]).reshape(S, -1)
+    if M >= 2:
+        assert any("interleaved_to_planar_kernel" in k for k in tr.kernels) and any("das_f64_pair_kernel" in k for k in tr.kernels), tr.kernels
+        assert np.array_equal(yi, y)
+    else:
+        assert same_floats(yi, y)
     if S == 1 and F >= 9:
         bi = Beamformer(p, das_impl=BF_DAS_F64, layout=BF_INTERLEAVED)   # carried hop in the interleaved layout across batch cuts
         cuts = [0, 2, F // 2, F]
         parts = [bi.process(np.ascontiguousarray(xi[0][a * 512:b * 512])) for a, b in zip(cuts[:-1], cuts[1:])]
-        assert np.array_equal(np.concatenate(parts), yi[0])   # one frame per transform there: bit for bit whatever the cuts
+        assert same_floats(np.concatenate(parts), yi[0])   # which frames share a transform depends on the cuts (as for planar input)
+        bi2 = Beamformer(p, das_impl=BF_DAS_F64, layout=BF_INTERLEAVED)
+        cuts = sorted({0, 2, 2 * (F // 4), F})
+        parts = [bi2.process(np.ascontiguousarray(xi[0][a * 512:b * 512])) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert np.array_equal(np.concatenate(parts), yi[0])   # even cuts keep every pair: bit for bit
     if S == 1 and F >= 9:
         bf2 = Beamformer(p, das_impl=BF_DAS_F64)
         cuts = [0, 1, 4, F // 2, F]
