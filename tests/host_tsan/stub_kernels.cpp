@@ -49,6 +49,7 @@ const KernelSet *kernel_set_n4096() { return &g_stub_set; }
 const KernelSet *kernel_set_n8192() { return &g_stub_set; }
 hipError_t prepare_das_f64_w64(const DasF64Args &, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_das_f64_w64(const DasF64Args &, int, hipStream_t) { return hipSuccess; }
+hipError_t launch_interleaved_to_planar(const float *, float *, long, int, int, hipStream_t) { return hipSuccess; }
 bool das_f64_writes_hist(const DasF64Args &) { return false; }
 size_t das_f64_sched_ws_bytes() { return 256; }
 
