@@ -60,7 +60,7 @@ __device__ __forceinline__ void lds_dma(const char *g, void *l) {
 // KC = constraint columns: 1 = mvdr (the steering vector); 2..4 = lcmv with up to KC - 1 interferers (lcmv.cpp:102-130): the
 // columns C ride through the factorisation like the steering vector does (U = L^-1 C, v = L^-1 x), then G = U^H U, g = U^H v and
 // y = (G^-1 g)_0 -- the first row of W^H x with W = R^-1 C (C^H R^-1 C)^-1.  Unused columns are padded with the identity.
-// Z128: the spectra are complex doubles (the default, BF_PRECISION_REFERENCE: 16 bytes per element, stored unhalved) instead of z48 (BF_PRECISION_MIXED: 12 bytes, stored halved)
+// Z128: the spectra are complex doubles (the default, BF_PRECISION_REFERENCE: 16 bytes per element) instead of z48 (BF_PRECISION_MIXED: 12 bytes); both stored halved
 template <int MP, int KC, bool Z128>
 __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan fp) {
     constexpr int NT = MP * (MP + 1) / 2;
@@ -118,10 +118,10 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
     auto unpack = [&](int buf, int base, cd (&X)[MP]) {  // microphone spectra out of the prefetched rows (z48 is stored halved)
 #pragma unroll
         for (int p = 0; p < MP / 2; ++p) {
-            cd z, c;  // Z[k] / 2 and Z[N-k] / 2 (the latter conjugated on the fly)
+            cd z, c;  // Z[k] / 2 and Z[N-k] / 2 (stored halved: StftArgs::halve; the latter conjugated on the fly)
             if constexpr (Z128) {
-                z = ld(reinterpret_cast<const f64x2 *>(&s_pf[buf][base + 2 * p][lane])) * 0.5;
-                c = ld(reinterpret_cast<const f64x2 *>(&s_pf[buf][base + 2 * p + 1][lane])) * 0.5;
+                z = ld(reinterpret_cast<const f64x2 *>(&s_pf[buf][base + 2 * p][lane]));
+                c = ld(reinterpret_cast<const f64x2 *>(&s_pf[buf][base + 2 * p + 1][lane]));
             } else {
                 z = dec48(s_pf[buf][base + 2 * p][lane].v);
                 c = dec48(s_pf[buf][base + 2 * p + 1][lane].v);
@@ -353,9 +353,9 @@ __global__ __launch_bounds__(256) void mvdr_lcmv_kernel(BinsArgs a, int tile, in
     const f64x2 *steer = a.steer + (long)(s % a.n_dirs) * a.steer_dir_stride;
 
     // one microphone's spectrum at this problem's bin, frame t (may be negative: history); z48 elements (stored halved) or,
-    // (the default) full doubles (halved here)
+    // (the default) full doubles; stored halved either way
     const int ksrc = q_src_bin(q), kneg = (kN - ksrc) & (kN - 1);
-    auto ldz = [&](long e) -> cd { return a.z48 ? ld(reinterpret_cast<const z48 *>(a.Z) + e) : ld(a.Z + e) * 0.5; };
+    auto ldz = [&](long e) -> cd { return a.z48 ? ld(reinterpret_cast<const z48 *>(a.Z) + e) : ld(a.Z + e); };  // (either way stored halved)
     auto load_xi = [&](long t) -> cd {
         if (i >= M) return cd{0, 0};
         const long ef = z0 + t * NP * kN + (long)(i >> 1) * kN;
@@ -617,7 +617,7 @@ __device__ __forceinline__ double quads_sum(double v) {
 // local lower triangle (a >= b) of a 4 x 4 block, row-major
 __device__ constexpr int LT(int a, int b) { return a * (a + 1) / 2 + b; }
 
-// Z128: the spectra are complex doubles (the default, BF_PRECISION_REFERENCE: 16 bytes per element, stored unhalved) instead of z48
+// Z128: the spectra are complex doubles (the default, BF_PRECISION_REFERENCE: 16 bytes per element, stored halved like z48) instead of z48
 template <int KM, int WPS, bool Z128>
 __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, int tiles_per_stream) {
     constexpr int NB = KM + 1, NS = (NB + 3) / 4;  // right-hand sides, slots per lane
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256, WPS) void cov2d_kernel(BinsArgs a, int tile, i
         return RawMic{Zf[ksrc], Zf[kneg]};
     };
     auto dec = [](const zel &v) -> cd {
-        if constexpr (Z128) return cd{v.x * 0.5, v.y * 0.5};  // (exact)
+        if constexpr (Z128) return cd{v.x, v.y};  // (stored halved, like z48)
         else return dec48(v);
     };
     auto finish_mic = [&](const RawMic &r) -> cd {

@@ -418,6 +418,7 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
     sa.stream_stride_x = (long)M_ * F * H_; sa.n_streams = S_; sa.n_mics = M_; sa.n_fft_mics = MF_; sa.layout = layout;
     sa.skip_lo = N_; sa.skip_hi = 0;  // store everything ...
     sa.z48 = z48_ ? 1 : 0; sa.run_len = 1; sa.tw_w64 = d_tw_w64_;
+    sa.halve = (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV) ? 1 : 0;
     if (cfg_.algo == BF_MVDR || cfg_.algo == BF_LCMV || cfg_.algo == BF_GSS) {
         // ... except, for the band-limited nodes, the bins between the highest in-band bin k and its mirror N-k
         // (quirk Q1 makes bins 511..513 irregular: only skip when the band ends below them)

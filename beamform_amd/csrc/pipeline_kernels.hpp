@@ -40,7 +40,7 @@ constexpr int kQX = kN / 2 + 1;   // the extra problem: bin N/2+1, whose X is th
 // times (stored once, read as the newest and as the oldest frame of the sliding covariance), so the element size sets the
 // chain's traffic; 2^-37 relative on X moves the solved spectrum by < 1e-10 relative L2 at cond(R) = 3e4 (tools/z48_precision.py),
 // and the magnitude gate (mvdr.cpp:85) flips with probability ~1e-11 per bin-frame.  Decoding is two 32-bit operations.
-// Stored HALVED (the stft kernel scales its window by 1/2: exact), so that unpacking a microphone pair is X_a = Z[k] + conj Z[N-k],
+// Stored HALVED like the c128 spectra of these nodes (StftArgs::halve: the stft kernel scales its window by 1/2: exact), so that unpacking a microphone pair is X_a = Z[k] + conj Z[N-k],
 // X_b = -i (Z[k] - conj Z[N-k]) without the two multiplications.
 struct z48 {
     unsigned lo, re_hi, im_hi;  // lo = (re's low dword & 0xFFFF0000) | (im's low dword >> 16)
@@ -57,6 +57,8 @@ struct StftArgs {
     int n_fft_mics;        // channels actually transformed (= n_mics; 1 for the single-channel mcra node)
     int skip_lo, skip_hi;  // packed-spectrum bins in (skip_lo, skip_hi) are never read by the per-bin kernel: not stored
     int z48;               // store z48 elements (mvdr / lcmv)
+    int halve = 0;         // store the packed pair spectra halved (exact; mvdr / lcmv, z48 or c128): the per-bin kernels unpack X_a = Z[k] + conj Z[N-k],
+                           // X_b = -i (Z[k] - conj Z[N-k]) without the two multiplications
     int run_len;           // consecutive frames one half-wavefront walks (N = 1024): the shared hop stays in registers
     const f64x2 *tw_w64 = nullptr;  // twiddle_table_w64_rot (N = 1024): stft_bins_w64_kernel
 };

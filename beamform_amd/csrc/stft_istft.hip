@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void stft_kernel(StftArgs a) {
     {
         const double *twf = reinterpret_cast<const double *>(a.tw);
         for (int i = tid; i < 2048; i += kStftBlock) lds[i] = twf[i];
-        for (int i = tid; i < kN; i += kStftBlock) s_win[(i & 31) * kWinRow + (i >> 5)] = a.win[i] * (Z48 ? 0.5 : 1.0);  // z48 spectra are stored halved (exact)
+        for (int i = tid; i < kN; i += kStftBlock) s_win[(i & 31) * kWinRow + (i >> 5)] = a.win[i] * (a.halve ? 0.5 : 1.0);  // mvdr / lcmv spectra are stored halved (exact): unpacking a pair is then Z[k] +- conj Z[N-k] without the 1/2
         __syncthreads();
     }
     const f64x2 *wrow = reinterpret_cast<const f64x2 *>(s_win + lane * kWinRow);
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(kGenBlock) void stft_generic_kernel(StftArgs a) {
                 va = bs[(long)i * M + ma];
                 vb = bs[(long)i * M + mb];
             }
-            const double h = a.win[n] * (a.z48 ? 0.5 : 1.0);  // z48 spectra are stored halved (exact)
+            const double h = a.win[n] * (a.halve ? 0.5 : 1.0);  // mvdr / lcmv spectra are stored halved (exact)
             s_a[gen_slot(n)] = cd{(double)va * h, b_ok ? (double)vb * h : 0.0};   // buf[j]*hann_win[i]  (util.h:235)
         }
         __syncthreads();
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256) void stft_small_kernel(StftArgs a) {
             const f64x2 w = a.tw[m % (kN / 2)];
             s_tw[i] = m < kN / 2 ? cx<double>{w.x, w.y} : cx<double>{-w.x, -w.y};
         }
-        for (int i = tid; i < kN; i += kBlock) s_win[(i % kNL) * kWinRow + i / kNL] = a.win[i] * (Z48 ? 0.5 : 1.0);  // z48 spectra are stored halved (exact)
+        for (int i = tid; i < kN; i += kBlock) s_win[(i % kNL) * kWinRow + i / kNL] = a.win[i] * (a.halve ? 0.5 : 1.0);  // mvdr / lcmv spectra are stored halved (exact): unpacking a pair is then Z[k] +- conj Z[N-k] without the 1/2
         __syncthreads();
     }
     const int g = lane / kNL, n2 = lane % kNL;
@@ -880,7 +880,7 @@ __global__ __launch_bounds__(256) void stft_wave2048_kernel(StftArgs a) {
             const f64x2 t = a.tw[32 * tid];  // W64^c = W2048^(32 c)
             s_w64[tid] = cx<double>{t.x, t.y};
         }
-        for (int i = tid; i < kN; i += kBlock) s_win[(i & 63) * kWinRow + (i >> 6)] = a.win[i] * (Z48 ? 0.5 : 1.0);  // z48 spectra are stored halved (exact)
+        for (int i = tid; i < kN; i += kBlock) s_win[(i & 63) * kWinRow + (i >> 6)] = a.win[i] * (a.halve ? 0.5 : 1.0);  // mvdr / lcmv spectra are stored halved (exact): unpacking a pair is then Z[k] +- conj Z[N-k] without the 1/2
         __syncthreads();
     }
     const f64x2 *wrow = reinterpret_cast<const f64x2 *>(s_win + lane64 * kWinRow);
