@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
             for (int m = 0; m < MP; ++m) X[m].y = -X[m].y;
         }
     };
-#define BF_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define BF_DMA_WAIT() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); } while (0)  /* vmcnt(0): the builtin, so that hipcc's own counter model sees the drain */
 
     cd R[NT];       // strict lower triangle, row-major: R[i*(i+1)/2 + c], c < i (the diagonal slots are unused)
     double Rd[MP];  // the diagonal is real: kept and updated as such (two FMAs per rank-1 term instead of four)
@@ -162,12 +162,23 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
         pb ^= 1;
     }
     const float thr32 = (float)(a.cfg.freq_mag_threshold * (double)((unsigned)M * (unsigned)kN));
-    cd y_prev{0, 0};  // frame it - 1's output: stored one iteration late, behind the wait below and in front of the next DMA, so that the
-                      // s_waitcnt vmcnt(0) at the top of an iteration never waits for a store issued a few instructions earlier
+    cd y_prev{0, 0};  // frame it - 1's output: stored one iteration late, behind the next frame's DMA requests, so that no s_waitcnt vmcnt(0)
+                      // of an iteration waits for a store issued a few instructions earlier
     for (long it = 0; it < n_it; ++it) {
-        BF_DMA_WAIT();  // frame it (and it - P) have landed in s_pf[pb]
+        BF_DMA_WAIT();  // frame it (and it - P) have landed in s_pf[pb]; frame it - 2's output has been stored
         __builtin_amdgcn_wave_barrier();
-        if (it > 0 && it - 1 < cnt) st_y(a, yidx + (it - 1) * kYhStride, q, y_prev);
+        // The constraint columns: re-read per frame (L2-resident, consecutive lanes = consecutive bins) instead of living in registers
+        // that the factorisation needs.  Requested HERE, in front of the slide that covers their L2 round trip, and drained (vmcnt(0),
+        // the builtin: hipcc's counter model sees it) in front of the next frame's DMA: hipcc prices any vector-memory wait with an
+        // LDS-DMA request in flight at vmcnt(0), so until round 6 -- DMA first, then these loads -- the factorisation's first use of U
+        // waited for the rows requested a few hundred instructions earlier (SQ_WAIT_ANY 17 % of the wave cycles).
+        cd U[KC][MP];
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+            for (int m = 0; m < MP; ++m) U[c][m] = (m < M && c < a.kp1) ? ld(steer + ((long)c * M + m) * kN) : cd{0, 0};
+        cd(&ua)[MP] = U[0];
+        __builtin_amdgcn_sched_barrier(0);
         if (it > 0) {
             // slide the covariance window over the PREVIOUS frame (mvdr.cpp:100-101), whose rows still sit in the other buffer:
             // done here, not behind the solve, so that the updated R is at once the factorisation's working copy -- R itself
@@ -185,14 +196,13 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows have been read: the next DMA may overwrite them
         }
-        if (it + 1 < n_it) dma_frame(it + 1, true, pb ^ 1);
-        cd U[KC][MP];  // the constraint columns: re-read per frame (L2-resident, consecutive lanes = consecutive bins) instead of
-                       // living in registers that the factorisation needs
-#pragma unroll
-        for (int c = 0; c < KC; ++c)
-#pragma unroll
-            for (int m = 0; m < MP; ++m) U[c][m] = (m < M && c < a.kp1) ? ld(steer + ((long)c * M + m) * kN) : cd{0, 0};
-        cd(&ua)[MP] = U[0];
+        // the next frame's rows: requested on every path (the last iteration re-requests its own frame into the idle buffer), with
+        // nothing older in flight; the previous frame's output goes out behind them (the wait at the top of the loop covers it)
+        BF_DMA_WAIT();
+        __builtin_amdgcn_sched_barrier(0);
+        dma_frame(it + 1 < n_it ? it + 1 : it, true, pb ^ 1);
+        if (it > 0 && it - 1 < cnt) st_y(a, yidx + (it - 1) * kYhStride, q, y_prev);
+        __builtin_amdgcn_sched_barrier(0);
         cd X[MP];
         unpack(pb, 0, X);
         // park the unpacked spectra in the slots their packed form came from (a 16-byte slot holds one complex double): the
@@ -313,6 +323,7 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
         y_prev = y;
         pb ^= 1;
     }
+    BF_DMA_WAIT();  // (the last iteration's idle request)
     if (n_it > 0 && n_it - 1 < cnt) st_y(a, yidx + (n_it - 1) * kYhStride, q, y_prev);
 #undef BF_DMA_WAIT
 }
