@@ -814,7 +814,7 @@ __global__ __launch_bounds__(512) void stft_bins_w64_kernel(StftArgs a, BinsArgs
         f64x2 *ltw = reinterpret_cast<f64x2 *>(lds);
         for (int i = tid; i < kTwD / 2; i += 512) ltw[i] = tw2[i];
         for (int i = tid; i < kN; i += 512) lds[oWin + (i & 63) * kWinRow + (i >> 6)] = a.win[i];
-        if (tid <= NT) s_next[tid] = tid == 0 ? NT : 0;  // the first NT frames are handed out statically
+        if (tid <= NT) s_next[tid] = tid == 0 ? 2 * NT : 0;  // the first 2 NT frames are handed out statically (a team holds two: below)
     }
     const int M = a.n_mics, NP = (M + 1) >> 1;
     const bool has_pair = p < NP;
@@ -857,12 +857,16 @@ __global__ __launch_bounds__(512) void stft_bins_w64_kernel(StftArgs a, BinsArgs
             }
         }
     };
-    int lf = team;  // the team's frame (local index); every wavefront of the team follows the same sequence
+    // A team holds TWO frames: lf, whose samples are in na / nb, and lf_next, whose samples are requested as soon as the window stage has
+    // consumed lf's (in flight during lf's transform AND its per-bin pass).  Until round 6 the request went out behind the team barrier,
+    // in front of the per-bin pass -- whose steering loads return in order behind it: every frame's first item waited for the next frame's
+    // samples to arrive from HBM (s_waitcnt vmcnt(0) a few hundred instructions behind 32 HBM loads).
+    int lf = team, lf_next = NT + team;  // local indices; every wavefront of the team follows the same sequence
     if (lf < n_local) request(lf);
     __syncthreads();  // twiddles, window, counters
     int arrivals = 0;
     lds_cnt_t my_arr = s_arr + team;
-    lds_cnt_t my_nxt = s_arr + NT + team;  // the team's next frame, published by its first wavefront
+    lds_cnt_t my_nxt = s_arr + NT + team;  // the frame after lf_next, published by the team's first wavefront
     while (lf < n_local) {
         const long gf = gf0 + lf;
         const int s = (int)(gf / a.n_frames);
@@ -893,6 +897,8 @@ __global__ __launch_bounds__(512) void stft_bins_w64_kernel(StftArgs a, BinsArgs
             }
             cx<double> tw[15];
             BF_STAGE();
+            if (lf_next < n_local) request(lf_next);  // na / nb are consumed: the next frame's samples travel during this transform and the per-bin pass
+            BF_STAGE();
             load_tw1<1, 9>(tw, s_tw1, lane);
             BF_STAGE();
             fft16_core<double, -1, true, 1>(re, im);  // stage 0 is done
@@ -921,15 +927,14 @@ __global__ __launch_bounds__(512) void stft_bins_w64_kernel(StftArgs a, BinsArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) zo[64 * (r >> 2) + 256 * (r & 3)] = f64x2{re[r], im[r]};
         }
-        // the team's next frame: taken by its first wavefront, read by the others behind the barrier
+        // the frame after lf_next: taken by the team's first wavefront, read by the others behind the barrier
         if (p == 0) {
             const int nx = lds_cnt_add(s_next, lane);
             if (lane == 0) *my_nxt = nx;
         }
         arrivals += NPc;
         team_barrier(my_arr, arrivals, lane);
-        const int lf_next = __builtin_amdgcn_readfirstlane(*my_nxt);
-        if (lf_next < n_local) request(lf_next);  // lands while the per-bin pass runs
+        const int lf_next2 = __builtin_amdgcn_readfirstlane(*my_nxt);
         // ---- pass 2: the per-bin stage of the frame, spectra read back from LDS -------------------------------------------------
         const f64x2 *zs = reinterpret_cast<const f64x2 *>(lds + kTwD) + (long)team * NPc * kN;
 #pragma nounroll  // one item's registers at a time (two interleaved items spill 28 registers in the phasempf build)
@@ -970,6 +975,7 @@ __global__ __launch_bounds__(512) void stft_bins_w64_kernel(StftArgs a, BinsArgs
         arrivals += NPc;
         team_barrier(my_arr, arrivals, lane);  // the slots are rewritten by the next frame
         lf = lf_next;
+        lf_next = lf_next2;
     }
 }
 
