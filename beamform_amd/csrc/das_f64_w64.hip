@@ -376,7 +376,7 @@ __device__ __forceinline__ unsigned long long pack_work(unsigned vbase, int chun
     return ((unsigned long long)(vbase & 0xFFFFFFu) << 40) | ((unsigned long long)(unsigned)chunk << 20) | ((unsigned long long)(unsigned)pairs << 10) | (unsigned)next;
 }
 struct PairWork {   // wavefront-uniform
-    int4 d;         // the chunk: {stream, first frame, frames, 0}
+    int4 d;         // the chunk: {stream, first frame, frames, index in the table}
     int pos;        // this pair inside the chunk
     int len;        // pairs of the chunk
     unsigned u;     // virtual index
@@ -384,9 +384,11 @@ struct PairWork {   // wavefront-uniform
 };
 __device__ __forceinline__ int4 load_chunk(const int4 *chunks, int k) {
     const int4 d = chunks[k];
-    return int4{__builtin_amdgcn_readfirstlane(d.x), __builtin_amdgcn_readfirstlane(d.y), __builtin_amdgcn_readfirstlane(d.z), 0};
+    return int4{__builtin_amdgcn_readfirstlane(d.x), __builtin_amdgcn_readfirstlane(d.y), __builtin_amdgcn_readfirstlane(d.z), k};
 }
-__device__ __forceinline__ PairWork draw_pair(lds_u64_t work, const DasSched &sc, int lane) {
+// `held`: the chunk the wavefront is working on.  Nearly every draw stays inside it (104 pairs at the headline size): its row of the table is then
+// not fetched again (a global load + s_waitcnt vmcnt(0) with nothing else in flight: one exposed L2 round trip per pair until round 6)
+__device__ __forceinline__ PairWork draw_pair(lds_u64_t work, const DasSched &sc, int lane, const int4 held) {
     PairWork r;
     r.have = false;
     r.d = int4{0, 0, 0, 0};
@@ -398,7 +400,8 @@ __device__ __forceinline__ PairWork draw_pair(lds_u64_t work, const DasSched &sc
         const unsigned vb = (unsigned)(old >> 40);
         if (k == kChunkEnd) return r;
         if (pos < len) {
-            r.d = load_chunk(sc.chunks, k);
+            if (k == held.w) r.d = held;
+            else r.d = load_chunk(sc.chunks, k);
             r.pos = pos; r.len = len; r.u = vb + (unsigned)pos; r.have = true;
             return r;
         }
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
     BF_STATS_DECL;
     int it = 0;  // pairs this wavefront has done (debug stamps)
     if (!cur.have) {
-        cur = draw_pair(s_work, sc, lane);
+        cur = draw_pair(s_work, sc, lane, cur.d);
         if (cur.have) {
             request_pair_mic(cur.d.x, cur.d.y + 2L * cur.pos, a.slot_mic[0]);
             request_extra(XM >= 0, cur.d.x, cur.d.y + 2L * cur.pos);
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
             if (k + 1 < NT) {
                 request_pair_mic(stream, tA, a.slot_mic[k + 1]);
             } else {
-                nxt = draw_pair(s_work, sc, lane);
+                nxt = draw_pair(s_work, sc, lane, cur.d);
                 if (nxt.have) request_pair_mic(nxt.d.x, nxt.d.y + 2L * nxt.pos, a.slot_mic[0]);
                 else request_pair_mic(stream, tA, a.slot_mic[0]);
             }
