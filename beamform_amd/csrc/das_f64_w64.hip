@@ -337,7 +337,10 @@ constexpr int pTw = 0;
 constexpr int pPlane = kTwP;
 constexpr int pGain = pPlane + kWaves * kPlaneD;
 constexpr int pFlag = pGain + 7 * kGMic * 2;       // microphones 1 .. 7 (microphone 0 has no gains: below)
-constexpr int pWin = pFlag + (kSlots + 4) / 2;           // kSlots ints + the 64-bit work word, padded to 16 bytes
+constexpr int kRingR = 32;                                 // [sample][mic] input: shared hop slots of the block's ring (16 pairs), + one private slot per wavefront
+constexpr int kRingSlots = kRingR + kWaves;
+constexpr int pRing = pFlag + (kSlots + 4) / 2;          // kSlots ints + the 64-bit work word, padded to 16 bytes; then kRingR slot states
+constexpr int pWin = pRing + kRingR / 2;
 constexpr int kLdsP = pWin + 64 * kWinRow;
 static_assert(kLdsP * 8 <= 160 * 1024, "LDS");
 static_assert((pGain & 1) == 0 && (pWin & 1) == 0, "16-byte alignment");
@@ -463,13 +466,25 @@ __device__ unsigned long long g_stamps[256 * 8 * 64];
 #define BF_STAMP(slot) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasSched sc) {
+// LAYOUT 0: planar input.  LAYOUT 1: [sample][mic] input (round 6, second session): the kernel walks ONE microphone at a time, which on that layout
+// makes every 128-byte line cross L2 -> L1 eight times (1.34 ms), and a transposition kernel in front costs 0.35 ms at the copy ceiling while
+// the vector pipes idle.  Here the wavefront that draws a pair transposes the pair's two NEW hops (2 x 512 samples x M microphones, 16-byte
+// loads, through its idle exchange plane) into the block's ring of planar hop slots in global memory and reads its three hops per microphone
+// from there, coalesced, as in the planar case; the hop it shares with the previous pair is that pair's second slot.  Slot states in LDS (as
+// the boundary states): a slot's life is worth 4 -- published 2, readers 1 + 1 (the first hop of a pair has one reader: 2) -- so generation g
+// of a slot starts at 4 g; a writer waits for 4 g (every reader of the previous content is done), a reader for 4 g + 2.  The first pair of
+// a chunk puts the hop in front of it (or the carried hop) into its wavefront's private slot.  The memory side of the transposition
+// overlaps the other wavefronts' transforms: measured with a plain 32 KB + 32 KB copy per pair inside the planar kernel: + 0.19 ms.
+template <int LAYOUT>
+__device__ __forceinline__ void das_f64_pair_body(const DasF64Args &a, const DasSched &sc) {
     __shared__ __attribute__((aligned(16))) double lds[kLdsP];
     const cx<double> *s_tw1 = reinterpret_cast<const cx<double> *>(lds + pTw) - 64;  // row k1 starts at 64 (k1 - 1)
     const cx<double> *s_tw2 = reinterpret_cast<const cx<double> *>(lds + pTw) + 960;
     const cx<double> *s_gain = reinterpret_cast<const cx<double> *>(lds + pGain);
     lds_int_t s_state = (lds_int_t)(lds + pFlag);              // kSlots boundary states
     lds_u64_t s_work = (lds_u64_t)(lds + pFlag + kSlots / 2);  // the block's work word (above)
+    lds_int_t s_ring = (lds_int_t)(lds + pRing);               // LAYOUT 1: states of the ring's shared hop slots
+    (void)s_ring;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -537,6 +552,124 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
         }
     };
 
+    // ---- LAYOUT 1: the block's hop ring ---------------------------------------------------------------------------------------------------
+    struct RingHops { const float *h, *a, *b; };  // slot bases [mic][512] of hops tA - 1, tA, tA + 1 (wavefront-uniform)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int lgM = 31 - __builtin_clz((unsigned)M);  // M is 2, 4 or 8 here (the host checks)
+    float *ringb = LAYOUT == 1 ? a.ring + (size_t)blockIdx.x * kRingSlots * M * kHop : nullptr;
+    auto ring_slot = [&](unsigned j) { return ringb + (size_t)(j & (kRingR - 1)) * M * kHop; };
+    // one hop = 512 M floats in M / 2 tiles of 1024 floats (1024 / M samples), moved in UNITS of two tiles (32 registers): 16-byte loads,
+    // lane l of load i holds floats 4 (64 i + l) ... of its tile
+    auto il_load2 = [&](const float *src, int unit, f4 (&v)[2][4]) {
+        const f4 *s4 = reinterpret_cast<const f4 *>(src);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int t = 2 * unit + tt;
+            if (2 * t < M) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[tt][i] = s4[t * 256 + i * 64 + lane];
+            } else {  // (2 microphones: half a unit; defined on every path)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[tt][i] = f4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    // ... through the wavefront's exchange plane as [sample][M + 1] floats, out as 16-byte stores of 4 consecutive samples of one microphone
+    auto il_store2 = [&](const f4 (&v)[2][4], float *dst, int unit) {
+        float *tile = reinterpret_cast<float *>(plane);
+        const int R1 = M + 1, spt = 1024 >> lgM;  // samples per tile
+        int ln = lane;
+        asm volatile("" : "+v"(ln));  // (the tile addresses depend on the lane only: hipcc would hoist all 32 of them out of the pair loop and spill them there)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int t = 2 * unit + tt;
+            if (2 * t < M) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = 4 * (64 * i + ln);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) tile[((e + c) >> lgM) * R1 + ((e + c) & (M - 1))] = v[tt][i][c];
+                }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();  // (LDS operations of one wavefront execute in issue order)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = 64 * j + ln, mic = f >> (8 - lgM), q4 = f & ((256 >> lgM) - 1);
+                    f4 o;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = tile[(4 * q4 + c) * R1 + mic];
+                    reinterpret_cast<f4 *>(dst + mic * kHop + t * spt)[q4] = o;
+                }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    };
+    // the pair `pw` is about to become this wavefront's: its hops into the ring, then the three slot bases
+    auto prepare_pair = [&](const PairWork &pw) {
+        RingHops r;
+        const unsigned u2 = 2u * pw.u;
+        const int sA = (int)(u2 & (kRingR - 1)), gen4 = 4 * (int)(u2 / kRingR);
+        float *dA = ring_slot(u2), *dB = ring_slot(u2 + 1), *dH = ringb + (size_t)(kRingR + w) * M * kHop;
+        const long tA = pw.d.y + 2L * pw.pos;
+        const float *xs = a.x + (long)pw.d.x * a.stream_stride_x;
+        while (s_ring[sA] < gen4 || s_ring[sA + 1] < gen4) __builtin_amdgcn_s_sleep(1);  // every reader of the slots' previous hops is done
+        f4 v0[2][4], v1[2][4];  // two units in flight: the loads of one travel while the other goes through the plane
+        const bool two = tA + 1 < a.n_frames, first = pw.pos == 0, wide = M > 4;  // wide: a hop is two units
+        const float *srcA = xs + tA * (long)kHop * M, *srcB = srcA + (long)kHop * M;
+        const float *srcH = tA >= 1 ? srcA - (long)kHop * M : a.hist + (long)pw.d.x * M * kHop;
+        il_load2(srcA, 0, v0);
+        if (wide) il_load2(srcA, 1, v1);
+        il_store2(v0, dA, 0);
+        if (two) il_load2(srcB, 0, v0);
+        if (wide) il_store2(v1, dA, 1);
+        if (two && wide) il_load2(srcB, 1, v1);
+        if (two) il_store2(v0, dB, 0);
+        if (first) il_load2(srcH, 0, v0);
+        if (two && wide) il_store2(v1, dB, 1);
+        if (first && wide) il_load2(srcH, 1, v1);
+        if (first) il_store2(v0, dH, 0);
+        if (first && wide) il_store2(v1, dH, 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        (void)lds_fetch_add(s_ring + sA, 2, lane);
+        (void)lds_fetch_add(s_ring + sA + 1, 2, lane);
+        r.a = dA;
+        r.b = two ? dB : dA;  // a lone last frame: any readable hop, unused
+        r.h = dH;
+        if (!first) {  // the previous pair's second hop: published by whoever drew that pair
+            const unsigned jp = u2 - 1;
+            const int sP = (int)(jp & (kRingR - 1)), genp = 4 * (int)(jp / kRingR);
+            while (s_ring[sP] - genp < 2) __builtin_amdgcn_s_sleep(1);
+            r.h = ring_slot(jp);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        return r;
+    };
+    // ... and has read the last of them (has_t: the pair behind it reads its second hop too)
+    auto release_pair = [&](const PairWork &pw, bool has_t) {
+        const unsigned u2 = 2u * pw.u;
+        (void)lds_fetch_add(s_ring + (u2 & (kRingR - 1)), 2, lane);
+        (void)lds_fetch_add(s_ring + ((u2 + 1) & (kRingR - 1)), has_t ? 1 : 2, lane);
+        if (pw.pos > 0) (void)lds_fetch_add(s_ring + ((u2 - 1) & (kRingR - 1)), 1, lane);
+    };
+    auto request_ring_mic = [&](const RingHops &r, int m) { request(r.h + m * kHop, r.a + m * kHop, r.b + m * kHop); };
+    auto request_ring_extra = [&](bool on, const RingHops &r) {
+        if (!on) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e0[j] = e1[j] = e2[j] = 0.f;
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            e0[j] = r.h[XM * kHop + (unsigned)(64 * j + lane)];
+            e1[j] = r.a[XM * kHop + (unsigned)(64 * j + lane)];
+            e2[j] = r.b[XM * kHop + (unsigned)(64 * j + lane)];
+        }
+    };
+    RingHops curR{nullptr, nullptr, nullptr};
+    (void)curR;
+
     BF_STAMP(0);
 #ifdef BF_W64_STAMPS
     if (lane == 0 && blockIdx.x < 256) g_stamps[(blockIdx.x * 8 + w) * 64 + 59] = __builtin_amdgcn_s_memtime();
@@ -549,7 +682,7 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
     cur.pos = w;
     cur.u = (unsigned)w;
     cur.have = w < n_static;
-    if (cur.have) {
+    if (LAYOUT == 0 && cur.have) {
         request_pair_mic(cur.d.x, cur.d.y + 2L * w, a.slot_mic[0]);
         request_extra(XM >= 0, cur.d.x, cur.d.y + 2L * w);
     } else {
@@ -568,17 +701,29 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
 #pragma unroll 2
         for (int i = tid; i < 1024; i += kBlock) lds[pWin + (i & 63) * kWinRow + (i >> 6)] = a.win[i];
         if (tid < kSlots) s_state[tid] = 0;
+        if (tid < kRingR) s_ring[tid] = 0;
         if (tid == 0) *s_work = pack_work(0u, (int)blockIdx.x, cur.len, n_static);
     }
     __syncthreads();
     BF_STAMP(1);
     BF_STATS_DECL;
     int it = 0;  // pairs this wavefront has done (debug stamps)
+    if (LAYOUT == 1 && cur.have) {  // (the ring's states and the exchange plane are needed: behind the barrier)
+        curR = prepare_pair(cur);
+        request_ring_mic(curR, a.slot_mic[0]);
+        request_ring_extra(XM >= 0, curR);
+    }
     if (!cur.have) {
         cur = draw_pair(s_work, sc, lane, cur.d);
         if (cur.have) {
-            request_pair_mic(cur.d.x, cur.d.y + 2L * cur.pos, a.slot_mic[0]);
-            request_extra(XM >= 0, cur.d.x, cur.d.y + 2L * cur.pos);
+            if constexpr (LAYOUT == 1) {
+                curR = prepare_pair(cur);
+                request_ring_mic(curR, a.slot_mic[0]);
+                request_ring_extra(XM >= 0, curR);
+            } else {
+                request_pair_mic(cur.d.x, cur.d.y + 2L * cur.pos, a.slot_mic[0]);
+                request_extra(XM >= 0, cur.d.x, cur.d.y + 2L * cur.pos);
+            }
         }
     }
     while (cur.have) {  // wavefront-uniform; no block barrier below
@@ -646,11 +791,14 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
             }
             // the next microphone, or the first one of this wavefront's next pair (none left: this pair's first again, unused)
             if (k + 1 < NT) {
-                request_pair_mic(stream, tA, a.slot_mic[k + 1]);
+                if constexpr (LAYOUT == 1) request_ring_mic(curR, a.slot_mic[k + 1]);
+                else request_pair_mic(stream, tA, a.slot_mic[k + 1]);
             } else {
                 nxt = draw_pair(s_work, sc, lane, cur.d);
-                if (nxt.have) request_pair_mic(nxt.d.x, nxt.d.y + 2L * nxt.pos, a.slot_mic[0]);
-                else request_pair_mic(stream, tA, a.slot_mic[0]);
+                if constexpr (LAYOUT == 0) {
+                    if (nxt.have) request_pair_mic(nxt.d.x, nxt.d.y + 2L * nxt.pos, a.slot_mic[0]);
+                    else request_pair_mic(stream, tA, a.slot_mic[0]);
+                }  // (LAYOUT 1: the next pair's hops are transposed, and then requested, behind this pair's epilogue)
             }
             cx<double> tw[15];
             BF_STAGE();
@@ -709,14 +857,15 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
         cx<double> tw[15];
         BF_STAGE();
         {  // microphone 0's hops tA - 1, tA, tA + 1: in flight during the backward transform
-            const float *h0 = first_hop ? hist0 : hp0 - kHop, *h2 = last_hop ? hp0 : hp0 + kHop;
+            const float *h0 = LAYOUT == 1 ? curR.h : (first_hop ? hist0 : hp0 - kHop), *h1 = LAYOUT == 1 ? curR.a : hp0;
+            const float *h2 = LAYOUT == 1 ? curR.b : (last_hop ? hp0 : hp0 + kHop);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 q0[j] = h0[(unsigned)(64 * j + lane)];
-                q1[j] = hp0[(unsigned)(64 * j + lane)];
+                q1[j] = h1[(unsigned)(64 * j + lane)];
                 q2[j] = h2[(unsigned)(64 * j + lane)];
             }
-            request_extra(XM >= 0 && nxt.have, nxt.d.x, nxt.d.y + 2L * nxt.pos);  // ... and the next pair's second slot-0 microphone
+            if constexpr (LAYOUT == 0) request_extra(XM >= 0 && nxt.have, nxt.d.x, nxt.d.y + 2L * nxt.pos);  // ... and the next pair's second slot-0 microphone
         }
         BF_STAGE();
         load_tw2<1, 16>(tw, s_tw2, lane);
@@ -860,6 +1009,18 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
                 }
             }
         }
+        if constexpr (LAYOUT == 1) {
+            release_pair(cur, has_t);  // (every load of this pair's hops has been consumed)
+            if (nxt.have) {
+                curR = prepare_pair(nxt);
+                request_ring_mic(curR, a.slot_mic[0]);
+                request_ring_extra(XM >= 0, curR);
+            } else {  // (defined on every path: a conditional definition keeps the 48 registers live through the whole loop)
+                request_ring_extra(false, curR);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) n0[j] = n1[j] = n2[j] = 0.f;
+            }
+        }
         cur = nxt;
         ++it;
     }
@@ -874,6 +1035,10 @@ __global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasS
 #endif
     (void)it;
 }
+
+// (two kernels, one body: the planar kernel keeps its name in every profile and traffic file)
+__global__ __launch_bounds__(kBlock) void das_f64_pair_kernel(DasF64Args a, DasSched sc) { das_f64_pair_body<0>(a, sc); }
+__global__ __launch_bounds__(kBlock) void das_f64_ring_kernel(DasF64Args a, DasSched sc) { das_f64_pair_body<1>(a, sc); }
 
 // The chunk table of one launch + the zeroing of every hop that two chunks complete by atomic adds + the reset of the counter: one
 // small launch in front of the kernel (it replaces the hipMemset2DAsync of the static-run version).  32 threads per chunk.
@@ -931,8 +1096,14 @@ __global__ __launch_bounds__(256) void interleaved_to_planar_kernel(const float 
 // planar input: the frame-pair kernel; [sample][mic] input: the microphone-pair kernel
 // (the frame-pair kernel never transforms microphone 0: it needs the reference's unit weight row there -- das.cpp:33-38, always true for das
 // on a handle that started cold -- and a second microphone; anything else goes through the chain)
+static bool ring_mics(int m) { return m == 2 || m == 4 || m == 8; }  // (the ring's transposition addresses by shifts)
 static bool use_pair_kernel(const DasF64Args &a) {
-    return a.layout == 0 && a.gains_mic != nullptr && a.sched_ws != nullptr && a.mic0_unit != 0 && a.n_mics >= 2 && a.n_tr >= 1;
+    if (!(a.gains_mic != nullptr && a.sched_ws != nullptr && a.mic0_unit != 0 && a.n_mics >= 2 && a.n_tr >= 1)) return false;
+    if (a.layout == 0) return true;
+    return a.ring != nullptr && ring_mics(a.n_mics) && a.hist_out == nullptr;  // [sample][mic]: through the blocks' hop rings
+}
+size_t das_f64_ring_bytes(int n_mics, int n_cus) {
+    return ring_mics(n_mics) ? (size_t)n_cus * kRingSlots * n_mics * kHop * sizeof(float) : 0;
 }
 
 bool das_f64_writes_hist(const DasF64Args &a) { return use_pair_kernel(a) && a.hist_out != nullptr; }
@@ -998,7 +1169,12 @@ hipError_t launch_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s) {
         sc.counter = reinterpret_cast<unsigned *>(a.sched_ws);
         sc.chunks = reinterpret_cast<const int4 *>(reinterpret_cast<char *>(a.sched_ws) + kSchedCounterBytes);
         sc.n_chunks = p.n_chunks;
-        BF_LAUNCH(das_f64_pair_kernel, dim3((unsigned)p.grid), dim3(kBlock), 0, s, a, sc);
+        if (a.layout == 0) {
+            BF_LAUNCH(das_f64_pair_kernel, dim3((unsigned)p.grid), dim3(kBlock), 0, s, a, sc);
+        } else {
+            if (a.ring_bytes < das_f64_ring_bytes(a.n_mics, p.grid)) return hipErrorNotSupported;
+            BF_LAUNCH(das_f64_ring_kernel, dim3((unsigned)p.grid), dim3(kBlock), 0, s, a, sc);
+        }
         return hipGetLastError();
     }
     long fpc, cps;

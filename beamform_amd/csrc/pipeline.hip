@@ -336,7 +336,16 @@ int BinPipelineImpl::run_one(const float *x, long F, float *y, f64x2 *spectrum, 
         da.layout = layout;
         // [sample][mic] input: transposed into a planar scratch (batch + carried hop) in front of the frame-pair kernel, which then runs with its
         // microphone-0 and identical-row savings (das_f64_w64.hip interleaved_to_planar_kernel); the carried hop stays in the handle's layout
-        if (layout == BF_INTERLEAVED && snap.das_mic0_unit && M_ >= 2 && snap.das_slots.n_tr >= 1 && d_das_sched_ != nullptr) {
+        static const int il_ring_env = getenv("BF_DAS_IL_RING") ? atoi(getenv("BF_DAS_IL_RING")) : 1;
+        const size_t ring_bytes = il_ring_env ? das_f64_ring_bytes(M_, n_cus_) : 0;
+        if (layout == BF_INTERLEAVED && snap.das_mic0_unit && M_ >= 2 && snap.das_slots.n_tr >= 1 && d_das_sched_ != nullptr && ring_bytes > 0) {
+            // 2, 4 or 8 microphones: the frame-pair kernel transposes hop by hop into its blocks' rings (das_f64_ring_kernel): 160 MB of
+            // scratch instead of a planar copy of the batch, and the transposition's memory traffic runs under the other wavefronts' transforms
+            const int rc0 = ensure((void **)&d_planar_, &planar_cap_, ring_bytes);
+            if (rc0 != BF_OK) return rc0;
+            da.ring = d_planar_; da.ring_bytes = ring_bytes; da.hist_out = nullptr;
+            da.stream_stride_x = (long)M_ * F * H_;
+        } else if (layout == BF_INTERLEAVED && snap.das_mic0_unit && M_ >= 2 && snap.das_slots.n_tr >= 1 && d_das_sched_ != nullptr) {
             const size_t nb = (size_t)S_ * M_ * F * H_, nh = (size_t)S_ * M_ * H_;
             const int rc0 = ensure((void **)&d_planar_, &planar_cap_, (nb + nh) * sizeof(float));
             if (rc0 != BF_OK) return rc0;

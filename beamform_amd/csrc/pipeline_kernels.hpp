@@ -133,6 +133,8 @@ struct DasF64Args {
     int mic0_unit = 0;                 // the weight row of microphone 0 is identically 1 (das.cpp:33-38): das_f64_pair_kernel adds h x_0 / M in the time domain
     void *sched_ws = nullptr;          // das_f64_pair_kernel: device workspace of its work queue (das_f64_sched_ws_bytes())
     size_t sched_ws_bytes = 0;
+    float *ring = nullptr;             // das_f64_pair_kernel on [sample][mic] input: the blocks' hop rings (das_f64_ring_bytes())
+    size_t ring_bytes = 0;
 };
 
 // the same node on one full wavefront per frame (das_f64_w64.hip; N = 1024 only): `gains` = das_pair_gains_w64_f64, `tw` =
@@ -141,6 +143,7 @@ struct DasF64Args {
 hipError_t prepare_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s);
 hipError_t launch_das_f64_w64(const DasF64Args &a, int n_cus, hipStream_t s);
 size_t das_f64_sched_ws_bytes();
+size_t das_f64_ring_bytes(int n_mics, int n_cus);  // 0: this microphone count has no ring kernel (the transposition in front of the planar kernel serves it)
 // [stream][n][M] -> [stream][M][n] in front of the frame-pair kernel ([sample][mic] handles); n a multiple of 256, M <= 8
 hipError_t launch_interleaved_to_planar(const float *x, float *out, long n, int n_mics, int n_streams, hipStream_t s);
 bool das_f64_writes_hist(const DasF64Args &a);  // the kernel launch_das_f64_w64 picks stores a.hist_out itself (no copy behind it)

@@ -52,6 +52,7 @@ hipError_t launch_das_f64_w64(const DasF64Args &, int, hipStream_t) { return hip
 hipError_t launch_interleaved_to_planar(const float *, float *, long, int, int, hipStream_t) { return hipSuccess; }
 bool das_f64_writes_hist(const DasF64Args &) { return false; }
 size_t das_f64_sched_ws_bytes() { return 256; }
+size_t das_f64_ring_bytes(int, int) { return 0; }
 
 hipError_t prepare_das_fused(const DasFusedArgs &, hipStream_t) { return hipSuccess; }
 hipError_t launch_das_fused(const DasFusedArgs &a, hipStream_t) {

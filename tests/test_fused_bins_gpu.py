@@ -174,14 +174,19 @@ def test_das_f64_one_launch_matches_oracle(M, F, S):
     for s in range(S):
         y_ref, _ = oracle.OracleNode(p).process(xs[s])
         assert rel_l2(y[s], y_ref) < 1e-6       # double arithmetic up to the float stores: far inside the 1e-5 budget
-    # [sample][mic] input (the layout north_star names): transposed on the device into a planar scratch in front of the same kernel
-    # (interleaved_to_planar_kernel; one microphone: das_f64_w64_kernel<1>) -- the same bytes out as for planar input
+    # [sample][mic] input (the layout north_star names): 2, 4 or 8 microphones go through the same kernel body with the hops transposed
+    # wavefront by wavefront into the blocks' rings (das_f64_ring_kernel); other counts are transposed on the device into a planar scratch
+    # in front of das_f64_pair_kernel (interleaved_to_planar_kernel); one microphone: das_f64_w64_kernel<1> -- the same bytes out as for
+    # planar input
     from beamform_amd.capi import BF_INTERLEAVED, launch_trace
     xi = np.ascontiguousarray(xs.transpose(0, 2, 1))
     bil = Beamformer(p, n_streams=S, das_impl=BF_DAS_F64, layout=BF_INTERLEAVED)
     with launch_trace() as tr:
         yi = bil.process(xi if S > 1 else xi[0]).reshape(S, -1)
-    if M >= 2:
+    if M in (2, 4, 8):
+        assert any("das_f64_ring_kernel" in k for k in tr.kernels) and not any("interleaved_to_planar_kernel" in k for k in tr.kernels), tr.kernels
+        assert np.array_equal(yi, y)
+    elif M >= 2:
         assert any("interleaved_to_planar_kernel" in k for k in tr.kernels) and any("das_f64_pair_kernel" in k for k in tr.kernels), tr.kernels
         assert np.array_equal(yi, y)
     else:

@@ -164,10 +164,13 @@ print("RESULT " + json.dumps(res))
 """
 
 
-@pytest.mark.parametrize("env", [{}, {"BF_DAS_F64_SCHED": "0"}, {"BF_DAS_F64_SCHED": "5,3,1"}], ids=["default", "equal-chunks", "tiny-chunks"])
+@pytest.mark.parametrize("env", [{}, {"BF_DAS_F64_SCHED": "0"}, {"BF_DAS_F64_SCHED": "5,3,1"}, {"BF_DAS_IL_RING": "0"}, {"BF_DAS_IL_RING": "1", "BF_DAS_F64_SCHED": "5,3,1"}],
+                         ids=["default", "equal-chunks", "tiny-chunks", "transposer", "ring-tiny-chunks"])
 def test_das_in_double_every_one_launch_kernel(env):
     """das at the reference's precision without a spectrum dump: das_f64_pair_kernel (planar input; its default chunk plan, equal static
-    chunks and a plan of tiny chunks) and das_f64_w64_kernel<1> ([sample][mic] input) against the oracle -- a batch that is cut into
+    chunks and a plan of tiny chunks), [sample][mic] input through das_f64_ring_kernel (8 microphones: the hops transposed into the
+    blocks' rings; tiny chunks: every second pair opens a chunk and fills its wavefront's private slot) and, BF_DAS_IL_RING=0 or another
+    microphone count, through interleaved_to_planar_kernel in front of the planar kernel, against the oracle -- a batch that is cut into
     chunks, an odd microphone count with an odd number of frames, one lone frame."""
     out = subprocess.run([sys.executable, "-c", CHILD_F64 % dict(root=ROOT)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
