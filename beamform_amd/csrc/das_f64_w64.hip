@@ -466,6 +466,36 @@ __device__ unsigned long long g_stamps[256 * 8 * 64];
 #define BF_STAMP(slot) do { } while (0)
 #endif
 
+// One tile of [sample][mic] input -- 1024 floats = 1024 / M samples of M = 2^LG microphones, lane l of load i holding floats 4 (64 i + l) ... + 3 --
+// through a wavefront-private LDS tile [sample][M + 1] and out as [mic][sample]: 16-byte stores of 4 consecutive samples of one microphone
+// into dst + mic * 512 + t * (1024 / M).  With M a template parameter every LDS address is one per-lane base plus an immediate.
+typedef float il_f4 __attribute__((ext_vector_type(4)));
+template <int LG>
+__device__ __forceinline__ void il_tile_through_plane(const il_f4 (&v)[4], float *tile, float *dst, int t, int lane) {
+    constexpr int M = 1 << LG, R1 = M + 1, spt = 1024 >> LG;
+    asm volatile("" : "+v"(lane)::"memory");  // (the bases depend on the lane only: hoisted out of the pair loop they would live, or spill, through every transform)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int e = 256 * i + 4 * lane + c;  // float index in the tile: sample e >> LG, microphone e & (M - 1)
+            tile[(e >> LG) * R1 + (e & (M - 1))] = v[i][c];
+        }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();  // (LDS operations of one wavefront execute in issue order)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = 64 * j + lane, mic = f >> (8 - LG), q4 = f & ((256 >> LG) - 1);
+        il_f4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = tile[(4 * q4 + c) * R1 + mic];
+        reinterpret_cast<il_f4 *>(dst + mic * kHop + t * spt)[q4] = o;
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // LAYOUT 0: planar input.  LAYOUT 1: [sample][mic] input (round 6, second session): the kernel walks ONE microphone at a time, which on that layout
 // makes every 128-byte line cross L2 -> L1 eight times (1.34 ms), and a transposition kernel in front costs 0.35 ms at the copy ceiling while
 // the vector pipes idle.  Here the wavefront that draws a pair transposes the pair's two NEW hops (2 x 512 samples x M microphones, 16-byte
@@ -575,34 +605,16 @@ __device__ __forceinline__ void das_f64_pair_body(const DasF64Args &a, const Das
         }
     };
     // ... through the wavefront's exchange plane as [sample][M + 1] floats, out as 16-byte stores of 4 consecutive samples of one microphone
+    // (il_tile_through_plane below: the microphone count as a template parameter turns every LDS address into lane base + immediate)
     auto il_store2 = [&](const f4 (&v)[2][4], float *dst, int unit) {
         float *tile = reinterpret_cast<float *>(plane);
-        const int R1 = M + 1, spt = 1024 >> lgM;  // samples per tile
-        int ln = lane;
-        asm volatile("" : "+v"(ln));  // (the tile addresses depend on the lane only: hipcc would hoist all 32 of them out of the pair loop and spill them there)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int t = 2 * unit + tt;
             if (2 * t < M) {
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int e = 4 * (64 * i + ln);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) tile[((e + c) >> lgM) * R1 + ((e + c) & (M - 1))] = v[tt][i][c];
-                }
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_wave_barrier();  // (LDS operations of one wavefront execute in issue order)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int f = 64 * j + ln, mic = f >> (8 - lgM), q4 = f & ((256 >> lgM) - 1);
-                    f4 o;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = tile[(4 * q4 + c) * R1 + mic];
-                    reinterpret_cast<f4 *>(dst + mic * kHop + t * spt)[q4] = o;
-                }
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
+                if (lgM == 3) il_tile_through_plane<3>(v[tt], tile, dst, t, lane);
+                else if (lgM == 2) il_tile_through_plane<2>(v[tt], tile, dst, t, lane);
+                else il_tile_through_plane<1>(v[tt], tile, dst, t, lane);
             }
         }
     };
@@ -708,25 +720,19 @@ __device__ __forceinline__ void das_f64_pair_body(const DasF64Args &a, const Das
     BF_STAMP(1);
     BF_STATS_DECL;
     int it = 0;  // pairs this wavefront has done (debug stamps)
-    if (LAYOUT == 1 && cur.have) {  // (the ring's states and the exchange plane are needed: behind the barrier)
-        curR = prepare_pair(cur);
-        request_ring_mic(curR, a.slot_mic[0]);
-        request_ring_extra(XM >= 0, curR);
-    }
     if (!cur.have) {
         cur = draw_pair(s_work, sc, lane, cur.d);
-        if (cur.have) {
-            if constexpr (LAYOUT == 1) {
-                curR = prepare_pair(cur);
-                request_ring_mic(curR, a.slot_mic[0]);
-                request_ring_extra(XM >= 0, curR);
-            } else {
-                request_pair_mic(cur.d.x, cur.d.y + 2L * cur.pos, a.slot_mic[0]);
-                request_extra(XM >= 0, cur.d.x, cur.d.y + 2L * cur.pos);
-            }
+        if (LAYOUT == 0 && cur.have) {
+            request_pair_mic(cur.d.x, cur.d.y + 2L * cur.pos, a.slot_mic[0]);
+            request_extra(XM >= 0, cur.d.x, cur.d.y + 2L * cur.pos);
         }
     }
     while (cur.have) {  // wavefront-uniform; no block barrier below
+        if constexpr (LAYOUT == 1) {  // this pair's hops into the ring (ONE inlined copy of the transposition: here), its first microphone out of it
+            curR = prepare_pair(cur);
+            request_ring_mic(curR, a.slot_mic[0]);
+            request_ring_extra(XM >= 0, curR);
+        }
         const int stream = cur.d.x;
         const long T0 = cur.d.y, T1 = T0 + cur.d.z;  // the chunk
         const long tA = T0 + 2L * cur.pos;
@@ -1010,16 +1016,7 @@ __device__ __forceinline__ void das_f64_pair_body(const DasF64Args &a, const Das
             }
         }
         if constexpr (LAYOUT == 1) {
-            release_pair(cur, has_t);  // (every load of this pair's hops has been consumed)
-            if (nxt.have) {
-                curR = prepare_pair(nxt);
-                request_ring_mic(curR, a.slot_mic[0]);
-                request_ring_extra(XM >= 0, curR);
-            } else {  // (defined on every path: a conditional definition keeps the 48 registers live through the whole loop)
-                request_ring_extra(false, curR);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) n0[j] = n1[j] = n2[j] = 0.f;
-            }
+            release_pair(cur, has_t);  // (every load of this pair's hops has been consumed; the next pair's go in at the top of the loop)
         }
         cur = nxt;
         ++it;
