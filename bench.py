@@ -482,7 +482,7 @@ def main():
                          # PMC traffic exists for the profiled workloads only (profiles/traffic_<tag>.json), and only while the
                          # file's kernels are the ones this run launched
                          "traffic": traffic,
-                         "kernel": ("das_fused_kernel" if das_impl == BF_DAS_FUSED_F32 else ("das_f64_pair_kernel" if args.layout == "planar" else "interleaved_to_planar_kernel + das_f64_pair_kernel")) if args.algo == "das"
+                         "kernel": ("das_fused_kernel" if das_impl == BF_DAS_FUSED_F32 else ("das_f64_pair_kernel" if args.layout == "planar" else "das_f64_ring_kernel")) if args.algo == "das"
                                    else "bin pipeline (stft + per-bin kernel + istft)",
                          "kernels_launched_per_step": sorted({norm_kernel_name(k) for k in launched_headline}),
                          "kernel_ms": k_ms, "call_ms": ms_call, "kernel_launches_timed": n_timed_launches,
@@ -651,9 +651,9 @@ def main():
                                                   note="the headline workload with [sample][mic] input (same bytes read as interleaved samples), fused fp32 kernel")),
             ("das_f64_interleaved", lambda: node_line("das", M, F, 1, das_impl_=BF_DAS_F64, xin=x.reshape(1, F * HOP, M), layout_=BF_INTERLEAVED,
                                                       iters=20, with_traffic=False,
-                                                      note="the headline workload in double on [sample][mic] input: interleaved_to_planar_kernel (a "
-                                                           "transposition through LDS into a planar scratch: the input is read once and written once more) "
-                                                           "in front of the headline kernel; ms_per_step covers both")),
+                                                      note="the headline workload in double on [sample][mic] input: das_f64_ring_kernel (the headline "
+                                                           "kernel's body; the wavefront that draws a frame pair transposes the pair's two new hops through "
+                                                           "its exchange plane into the block's ring of planar hop slots and reads them from there)")),
             ("phasempf", lambda: node_line("phasempf", 8, 256, 256, note="BASELINE config 4: 256 streams x 256 frames, recursion per stream")),
             ("phase", lambda: node_line("phase", M, F, 1, xin=x,
                                         note="uniform noise of this level stays below the node's mag_threshold (0.05): every bin takes the cheap branch "

@@ -54,9 +54,10 @@ enum bf_error {
 /* How bf_process_batch* lays out multichannel input. */
 enum bf_layout {
     BF_PLANAR = 0,      /* [stream][mic][sample]  -- what JACK hands the callback (rosjack.cpp:538-547) */
-    BF_INTERLEAVED = 1  /* [stream][sample][mic]  -- interleaved frame buffer.  das in double (BF_DAS_F64, period 512, <= 8 microphones) transposes
-                           such a batch on the device into a planar scratch of the batch's size (allocated on first use, kept) in front of its
-                           planar kernel; every other node reads the layout directly */
+    BF_INTERLEAVED = 1  /* [stream][sample][mic]  -- interleaved frame buffer.  das in double (BF_DAS_F64, period 512): with 2, 4 or 8 microphones
+                           the kernel transposes hop by hop into per-block rings (160 MB of device scratch on a 256-CU chip, allocated on first
+                           use, kept); with 3, 5, 6 or 7 the batch is transposed on the device into a planar scratch of the batch's size in front
+                           of the planar kernel; every other node reads the layout directly */
 };
 
 /* Arithmetic of the das node.  The reference computes in std::complex<double> end to end (das.cpp:16-24,47-70): BF_DAS_F64 is the
