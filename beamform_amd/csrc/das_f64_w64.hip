@@ -472,7 +472,9 @@ __device__ unsigned long long g_stamps[256 * 8 * 64];
 typedef float il_f4 __attribute__((ext_vector_type(4)));
 template <int LG>
 __device__ __forceinline__ void il_tile_through_plane(const il_f4 (&v)[4], float *tile, float *dst, int t, int lane) {
-    constexpr int M = 1 << LG, R1 = M + 1, spt = 1024 >> LG;
+    // row pitch 10 (8 microphones) / 5 / 3 floats and, on the way out, lane -> (microphone = lane mod M, sample quad = lane / M + (64 / M) j): the 64
+    // lanes of a read then cover all 64 banks once (pitch 9 with the microphone as the slow index: 4 R1 q mod 64 takes 16 values: 4-way conflicts)
+    constexpr int M = 1 << LG, R1 = LG == 3 ? 10 : M + 1, spt = 1024 >> LG;
     asm volatile("" : "+v"(lane)::"memory");  // (the bases depend on the lane only: hoisted out of the pair loop they would live, or spill, through every transform)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -486,7 +488,7 @@ __device__ __forceinline__ void il_tile_through_plane(const il_f4 (&v)[4], float
     __builtin_amdgcn_wave_barrier();  // (LDS operations of one wavefront execute in issue order)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int f = 64 * j + lane, mic = f >> (8 - LG), q4 = f & ((256 >> LG) - 1);
+        const int mic = lane & (M - 1), q4 = (lane >> LG) + (64 >> LG) * j;
         il_f4 o;
 #pragma unroll
         for (int c = 0; c < 4; ++c) o[c] = tile[(4 * q4 + c) * R1 + mic];
@@ -1016,7 +1018,10 @@ __device__ __forceinline__ void das_f64_pair_body(const DasF64Args &a, const Das
             }
         }
         if constexpr (LAYOUT == 1) {
-            release_pair(cur, has_t);  // (every load of this pair's hops has been consumed; the next pair's go in at the top of the loop)
+            // every load of this pair's hops has been consumed -- their values are in the output stores above, which the compiler may not move
+            // across this barrier -- so the slots may be handed on; the next pair's hops go in at the top of the loop
+            asm volatile("" ::: "memory");
+            release_pair(cur, has_t);
         }
         cur = nxt;
         ++it;
