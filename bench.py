@@ -585,13 +585,15 @@ def main():
         with launch_trace() as trn:
             bm.process_device(xin.data_ptr(), F_, yo.data_ptr(), 0, sptr)
         torch.cuda.synchronize(dev)
-        ms, ms_k = bm.time_device(xin.data_ptr(), F_, yo.data_ptr(), iters, sptr)
+        # the median of three batches of `iters` launches (a secondary line; one batch now and then reads 10 % high -- both mvdr lines of one
+        # un-profiled run of round 6 did, + 0.23 ms each, with the profiled run on the same box at the usual figure)
+        ms, ms_k = sorted(bm.time_device(xin.data_ptr(), F_, yo.data_ptr(), iters, sptr) for _ in range(3))[1]
         bm.close()
         fr = S_ * F_
         bpf = algorithmic_bytes_per_frame(M_)
         line = {"workload": f"{algo} {M_}-mic 1024-pt, {S_} stream(s) x {F_} frames" + (f", {len(interf_)} interferers" if interf_ else "")
                             + ("" if not note else "; " + note),
-                "ms_per_step": ms, "frames_per_s": fr / (ms * 1e-3),
+                "ms_per_step": ms, "frames_per_s": fr / (ms * 1e-3), "timing": f"median of 3 batches of {iters} launches",
                 "frac_of_hbm_roofline_algorithmic_bytes": bpf * fr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_frame": bpf,
                 "arithmetic": ("fp32 (BF_DAS_FUSED_F32)" if (algo == "das" and das_impl_ == BF_DAS_FUSED_F32) else
