@@ -135,6 +135,21 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
         }
     };
 #define BF_DMA_WAIT() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); } while (0)  /* vmcnt(0): the builtin, so that hipcc's own counter model sees the drain */
+    // mvdr (KC == 1), round 6: the same 32 KB seen as FOUR half-buffers of MP rows -- a ring of three for the NEWEST frames, requested TWO frames
+    // ahead, and one for the frame that leaves the window, requested one frame ahead (it used to travel two ahead and the newest one: the rows
+    // fresh from the STFT kernel are the ones that come from HBM).  With the steering vector in registers the loop has no load that returns
+    // to a register, so hipcc places no vector-memory wait of its own and the counted s_waitcnt vmcnt(MP) at the loop's top is the only one.
+    constexpr bool DEEP = KC == 1;
+    auto hrow = [&](int h, int row) { return &s_pf[h >> 1][(h & 1) * MP + row][0]; };
+    auto dma_rows = [&](const char *b, int h) {  // the MP rows of the frame at byte base b (+ dt per lane) into half-buffer h
+#pragma unroll
+        for (int p = 0; p < MP / 2; ++p) {
+            const long po = (long)p * kN * kZB;
+            lds_dma<Z128>(b + po + vk, hrow(h, 2 * p));
+            lds_dma<Z128>(b + po + vn, hrow(h, 2 * p + 1));
+        }
+    };
+    auto unpack_h = [&](int h, cd (&X)[MP]) { unpack(h >> 1, (h & 1) * MP, X); };
 
     cd R[NT];       // strict lower triangle, row-major: R[i*(i+1)/2 + c], c < i (the diagonal slots are unused)
     double Rd[MP];  // the diagonal is real: kept and updated as such (two FMAs per rank-1 term instead of four)
@@ -143,10 +158,32 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
 #pragma unroll
     for (int i = 0; i < MP; ++i) Rd[i] = 0.0;
     int pb = 0;  // buffer the next consumer reads
-    dma_frame(-1, false, pb);
+    cd Uk[MP];   // mvdr: the steering vector stays in registers for the whole tile (the factorisation scales its copy in place)
+#pragma unroll
+    for (int m = 0; m < MP; ++m) Uk[m] = (DEEP && m < M) ? ld(steer + (long)m * kN) : cd{0, 0};
+    if constexpr (DEEP) {  // the tile's first two frames into ring slots 0 and 1; the warm-up below walks half-buffers 2 and 3
+        dma_rows(Zu, 0);
+        dma_rows(Zu + (n_it > 1 ? 1 : 0) * frame_bytes, 1);
+        dma_rows(Zu - frame_bytes, 2);
+    } else {
+        dma_frame(-1, false, pb);
+    }
     for (int p = 1; p <= P; ++p) {  // covariance of the P frames in front of the tile
         BF_DMA_WAIT();
         __builtin_amdgcn_wave_barrier();
+        if constexpr (DEEP) {
+            if (p < P) dma_rows(Zu - (long)(p + 1) * frame_bytes, 2 + (p & 1));
+            cd X[MP];
+            unpack_h(2 + ((p - 1) & 1), X);
+#pragma unroll
+            for (int i = 0; i < MP; ++i) {
+#pragma unroll
+                for (int c = 0; c < i; ++c) R[i * (i + 1) / 2 + c] = cfma_conj(R[i * (i + 1) / 2 + c], X[i], X[c]);
+                Rd[i] = fma(X[i].y, X[i].y, fma(X[i].x, X[i].x, Rd[i]));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the half-buffer is rewritten two steps on)
+            continue;
+        }
         if (p < P)
             dma_frame(-p - 1, false, pb ^ 1);
         else
@@ -164,9 +201,21 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
     const float thr32 = (float)(a.cfg.freq_mag_threshold * (double)((unsigned)M * (unsigned)kN));
     cd y_prev{0, 0};  // frame it - 1's output: stored one iteration late, behind the next frame's DMA requests, so that no s_waitcnt vmcnt(0)
                       // of an iteration waits for a store issued a few instructions earlier
+    if constexpr (DEEP) BF_DMA_WAIT();  // (the steering vector and the ring's first two frames are there whatever P is: hipcc's model enters the loop with nothing pending)
+    int sn = 0;  // DEEP: ring slot of frame it (it mod 3)
     for (long it = 0; it < n_it; ++it) {
-        BF_DMA_WAIT();  // frame it (and it - P) have landed in s_pf[pb]; frame it - 2's output has been stored
+        if constexpr (DEEP) {
+            // frame it (requested two iterations ago) and frame it - 1 - P (one ago) have landed, frame it - 2's output has been stored; the MP
+            // requests of frame it + 1 may still travel (vector loads return in order: at most MP outstanding = only those)
+            if constexpr (MP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (MP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (MP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            BF_DMA_WAIT();  // frame it (and it - P) have landed in s_pf[pb]; frame it - 2's output has been stored
+        }
         __builtin_amdgcn_wave_barrier();
+        const int sp = sn == 0 ? 2 : sn - 1;  // DEEP: slot of frame it - 1 = the slot frame it + 2 goes into
         // The constraint columns: re-read per frame (L2-resident, consecutive lanes = consecutive bins) instead of living in registers
         // that the factorisation needs.  Requested HERE, in front of the slide that covers their L2 round trip, and drained (vmcnt(0),
         // the builtin: hipcc's counter model sees it) in front of the next frame's DMA: hipcc prices any vector-memory wait with an
@@ -176,7 +225,10 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
 #pragma unroll
         for (int c = 0; c < KC; ++c)
 #pragma unroll
-            for (int m = 0; m < MP; ++m) U[c][m] = (m < M && c < a.kp1) ? ld(steer + ((long)c * M + m) * kN) : cd{0, 0};
+            for (int m = 0; m < MP; ++m) {
+                if constexpr (DEEP) U[c][m] = Uk[m];
+                else U[c][m] = (m < M && c < a.kp1) ? ld(steer + ((long)c * M + m) * kN) : cd{0, 0};
+            }
         cd(&ua)[MP] = U[0];
         __builtin_amdgcn_sched_barrier(0);
         if (it > 0) {
@@ -185,8 +237,10 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
             // then rests (in the accumulator half of the register file) while the solve has the 256 arithmetic registers
             cd Xn[MP], Xo[MP];
 #pragma unroll
-            for (int m = 0; m < MP; ++m) Xn[m] = ld(reinterpret_cast<const f64x2 *>(&s_pf[pb ^ 1][m][lane]));  // parked by the previous iteration
-            unpack(pb ^ 1, MP, Xo);
+            for (int m = 0; m < MP; ++m)  // parked by the previous iteration
+                Xn[m] = ld(reinterpret_cast<const f64x2 *>(DEEP ? reinterpret_cast<z48slot *>(hrow(sp, m)) + lane : &s_pf[pb ^ 1][m][lane]));
+            if constexpr (DEEP) unpack_h(3, Xo);
+            else unpack(pb ^ 1, MP, Xo);
 #pragma unroll
             for (int i = 0; i < MP; ++i) {
 #pragma unroll
@@ -198,17 +252,29 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
         }
         // the next frame's rows: requested on every path (the last iteration re-requests its own frame into the idle buffer), with
         // nothing older in flight; the previous frame's output goes out behind them (the wait at the top of the loop covers it)
-        BF_DMA_WAIT();
-        __builtin_amdgcn_sched_barrier(0);
-        dma_frame(it + 1 < n_it ? it + 1 : it, true, pb ^ 1);
-        if (it > 0 && it - 1 < cnt) st_y(a, yidx + (it - 1) * kYhStride, q, y_prev);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DEEP) {
+            // the frame that leaves the window at the NEXT slide, the previous frame's output, then frame it + 2 into the slot the slide has just
+            // emptied -- in this order: the next top-of-loop wait lets exactly the youngest MP requests stand
+            __builtin_amdgcn_sched_barrier(0);
+            dma_rows(Zu + (it - P) * frame_bytes, 3);
+            if (it > 0 && it - 1 < cnt) st_y(a, yidx + (it - 1) * kYhStride, q, y_prev);
+            dma_rows(Zu + (it + 2 < n_it ? it + 2 : n_it - 1) * frame_bytes, sp);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            BF_DMA_WAIT();
+            __builtin_amdgcn_sched_barrier(0);
+            dma_frame(it + 1 < n_it ? it + 1 : it, true, pb ^ 1);
+            if (it > 0 && it - 1 < cnt) st_y(a, yidx + (it - 1) * kYhStride, q, y_prev);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         cd X[MP];
-        unpack(pb, 0, X);
+        if constexpr (DEEP) unpack_h(sn, X);
+        else unpack(pb, 0, X);
         // park the unpacked spectra in the slots their packed form came from (a 16-byte slot holds one complex double): the
         // next iteration's slide reads them back with one LDS read each instead of unpacking the frame again
 #pragma unroll
-        for (int m = 0; m < MP; ++m) *reinterpret_cast<f64x2 *>(&s_pf[pb][m][lane]) = f64x2{X[m].x, X[m].y};
+        for (int m = 0; m < MP; ++m)
+            *reinterpret_cast<f64x2 *>(DEEP ? reinterpret_cast<z48slot *>(hrow(sn, m)) + lane : &s_pf[pb][m][lane]) = f64x2{X[m].x, X[m].y};
         // magnitude gate (mvdr.cpp:85,95): sum |X_m| / (M N) > threshold.  Decided in fp32 unless the fp32 sum is within 1e-4
         // of the threshold (its own error is < 1e-6): then, for that wavefront and frame, in the reference's double arithmetic.
         float m32 = 0.f;  // (a zero partner channel of an odd microphone count adds its ~1e-16 |X| rounding residue: irrelevant here)
@@ -322,8 +388,9 @@ __global__ __launch_bounds__(64, 1) void mvdr_fast_kernel(BinsArgs a, FastPlan f
         }
         y_prev = y;
         pb ^= 1;
+        sn = sn == 2 ? 0 : sn + 1;
     }
-    BF_DMA_WAIT();  // (the last iteration's idle request)
+    BF_DMA_WAIT();  // (the last iterations' idle requests)
     if (n_it > 0 && n_it - 1 < cnt) st_y(a, yidx + (n_it - 1) * kYhStride, q, y_prev);
 #undef BF_DMA_WAIT
 }
