@@ -330,3 +330,28 @@ def test_das_f64_pair_kernel_output_does_not_depend_on_the_chunk_plan():
         assert r.returncode == 0, r.stderr[-2000:]
         out[plan] = r.stdout.strip().splitlines()[-1]
     assert len(set(out.values())) == 1, out
+
+
+@pytest.mark.parametrize("M,F,S", [(8, 4099, 2), (4, 64, 3), (2, 1001, 2), (8, 700, 1), (8, 2, 1), (4, 1, 2)])
+def test_das_f64_ring_kernel_is_the_planar_kernel_bit_for_bit(M, F, S):
+    """das_f64_ring_kernel ([sample][mic] input, 2 / 4 / 8 microphones: the frame-pair kernel's body behind a transposition of every pair's
+    two new hops into the block's ring of planar hop slots) against das_f64_pair_kernel on the same samples in the planar layout: the same
+    bytes -- batches of several chunks per block (the ring wraps, generations of slot states), several streams (a chunk's first pair fills its
+    wavefront's private slot), an odd frame count (a lone last frame has no second hop), the carried hop in the [sample][mic] layout
+    across uneven batch cuts, and geometries with and without a merged microphone pair (the extra microphone's loads come from the ring too)."""
+    from beamform_amd.capi import BF_DAS_F64, BF_INTERLEAVED, Beamformer, launch_trace
+    for mics in (None, GEOMETRIES["all distinct"][:M] if M <= 8 else None):
+        p = make_params("das", n_mics=M, theta=-50.0, **({"mics": mics} if mics else {}))
+        xs = np.stack([make_scene(M, F, seed=3300 + 7 * M + s) for s in range(S)])
+        xi = np.ascontiguousarray(xs.transpose(0, 2, 1))
+        y = Beamformer(p, n_streams=S, das_impl=BF_DAS_F64).process(xs if S > 1 else xs[0]).reshape(S, -1)
+        bil = Beamformer(p, n_streams=S, das_impl=BF_DAS_F64, layout=BF_INTERLEAVED)
+        with launch_trace() as tr:
+            yi = bil.process(xi if S > 1 else xi[0]).reshape(S, -1)
+        assert any("das_f64_ring_kernel" in k for k in tr.kernels), tr.kernels
+        assert np.array_equal(yi, y)
+        if S == 1 and F >= 9:   # batch cuts at even frame counts keep every pair where it was: bit for bit, the carried hop included
+            cuts = sorted({0, 2, 2 * (F // 6), 2 * (F // 3), F})
+            b2 = Beamformer(p, das_impl=BF_DAS_F64, layout=BF_INTERLEAVED)
+            parts = [b2.process(np.ascontiguousarray(xi[0][a * 512:b * 512])) for a, b in zip(cuts[:-1], cuts[1:])]
+            assert np.array_equal(np.concatenate(parts), yi[0])
